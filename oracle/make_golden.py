@@ -1,0 +1,293 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+TEST INFRASTRUCTURE.  Run inside the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Each fixture holds the complete inputs of a hot-path call (map arrays, sparse hash
+table, decoder parameters, query points, config scalars) and the reference's
+outputs, so the tests never need the reference tree again.  The reference has no
+golden vectors of its own -- these are the pins.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_loader as R
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (config overrides, decoder (levels, hidden))
+    "c2_wf": (dict(voxel_size_m=0.4, search_alpha=0.5, query_nn_k=8, weighted_first=True,
+                   buffer_size=40009), (2, 32)),
+    "kitti_nwf": (dict(voxel_size_m=0.4, search_alpha=0.2, query_nn_k=6, weighted_first=False,
+                       buffer_size=40009), (1, 64)),
+    "c3_bigtable": (dict(voxel_size_m=0.4, search_alpha=0.5, query_nn_k=8, weighted_first=True,
+                         buffer_size=int(5e7)), (4, 64)),
+}
+
+
+def sheet_points(gen, n, radius, center=(0.0, 0.0), layers=2):
+    r = radius * torch.sqrt(torch.rand(n, generator=gen))
+    th = 2 * np.pi * torch.rand(n, generator=gen)
+    x = center[0] + r * torch.cos(th)
+    y = center[1] + r * torch.sin(th)
+    l = torch.randint(0, layers, (n,), generator=gen).float()
+    z = -2 + 0.8 * l + 0.3 * torch.sin(0.5 * x) * torch.cos(0.5 * y)
+    return torch.stack([x, y, z], 1).float()
+
+
+def flat_decoder(dec):
+    return torch.cat([p.detach().reshape(-1) for p in dec.state_dict().values()]).numpy().copy()
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def build(case):
+    m = R.load()
+    over, (levels, hidden) = CASES[case]
+    cfg = R.make_config(local_map_radius=20.0, local_map_travel_dist_ratio=1.0, bs=512,
+                        feature_std=0.1, gradient_decimation=10, track_on=True, **over)
+    cfg.geo_mlp_level, cfg.geo_mlp_hidden_dim = levels, hidden
+    torch.manual_seed(42)
+    dec = m["Decoder"](cfg, hidden, levels, 1)
+    npts = m["NeuralPoints"](cfg)
+    gen = torch.Generator().manual_seed(0)
+    # three frames, sensor moving 8 m per frame along x: the first frame ends up outside
+    # the travel-distance window (20 m * 1.0) of the last one only partially -> the time
+    # filter and the local-map mask both bite.
+    travel = [0.0, 12.0, 24.0]
+    npts.travel_dist = torch.tensor(travel, dtype=torch.float32)
+    for ts in range(3):
+        pts = sheet_points(gen, 20000, 14.0, center=(8.0 * ts, 0.0))
+        npts.update(pts, torch.tensor([8.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+    # non-trivial certainties / features (update draws features with torch.randn)
+    npts.point_certainties = torch.rand(npts.count(), generator=gen) * 3.0
+    npts.reset_local_map(torch.tensor([16.0, 0.0, 0.0]), torch.eye(3), 2)
+    pretrain(m, cfg, dec, npts, gen)
+    return m, cfg, dec, npts, gen
+
+
+def surface_samples(gen, n, radius, center, sigma=0.12):
+    """Points on the analytic sheets displaced by d along the surface normal; label = d."""
+    base = sheet_points(gen, n, radius, center=center)
+    x, y = base[:, 0], base[:, 1]
+    fx = 0.15 * torch.cos(0.5 * x) * torch.cos(0.5 * y)
+    fy = -0.15 * torch.sin(0.5 * x) * torch.sin(0.5 * y)
+    nrm = torch.stack([-fx, -fy, torch.ones_like(fx)], 1)
+    nrm = nrm / nrm.norm(dim=1, keepdim=True)
+    d = sigma * torch.randn(n, generator=gen)
+    return (base + d[:, None] * nrm).float(), d.float()
+
+
+def pretrain(m, cfg, dec, npts, gen, iters=150):
+    """Train features + decoder with the reference's own Mapper.mapping so that the SDF is a
+    meaningful field (tracking converges, gradients have norm ~1)."""
+    ds = R.FakeDataset(n_frames=3)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": None})
+    mp.determine_used_pose()
+
+    def get_batch(global_coord=False):
+        c, l = surface_samples(gen, cfg.bs, 13.0, (16.0, 0.0))
+        ts = torch.full((cfg.bs,), 2, dtype=torch.int)
+        return c, l, ts, None, None, None, torch.ones(cfg.bs)
+
+    mp.get_batch = get_batch
+    mp.mapping(iters)
+
+
+def map_arrays(npts, cfg, dec):
+    tab = npts.buffer_pt_index
+    slots = torch.nonzero(tab >= 0).flatten()
+    d = dict(
+        buffer_size=np.int64(cfg.buffer_size), table_slots=t2n(slots), table_vals=t2n(tab[slots]),
+        neural_points=t2n(npts.neural_points), point_orientations=t2n(npts.point_orientations),
+        geo_features=t2n(npts.geo_features), point_ts_create=t2n(npts.point_ts_create),
+        point_ts_update=t2n(npts.point_ts_update), point_certainties=t2n(npts.point_certainties),
+        local_mask=t2n(npts.local_mask), global2local=t2n(npts.global2local),
+        local_neural_points=t2n(npts.local_neural_points),
+        local_geo_features=t2n(npts.local_geo_features.data),
+        local_point_certainties=t2n(npts.local_point_certainties),
+        local_point_ts_update=t2n(npts.local_point_ts_update),
+        local_point_orientations=t2n(npts.local_point_orientations),
+        travel_dist=t2n(npts.travel_dist), cur_ts=np.int64(npts.cur_ts),
+        diff_travel_dist_local=np.float64(npts.diff_travel_dist_local),
+        local_map_radius=np.float64(npts.local_map_radius),
+        resolution=np.float64(npts.resolution), neighbor_dx=t2n(npts.neighbor_dx),
+        max_valid_dist2=np.float64(npts.max_valid_dist2), query_nn_k=np.int64(cfg.query_nn_k),
+        weighted_first=np.bool_(cfg.weighted_first), num_nei_cells=np.int64(cfg.num_nei_cells),
+        search_alpha=np.float64(cfg.search_alpha),
+        dec_flat=flat_decoder(dec), dec_levels=np.int64(len(dec.layers)),
+        dec_hidden=np.int64(dec.layers[0].out_features), sdf_scale=np.float64(dec.sdf_scale),
+    )
+    return d
+
+
+def gen_case(case):
+    m, cfg, dec, npts, gen = build(case)
+    out = map_arrays(npts, cfg, dec)
+    tools = m["tools"]
+
+    # ---- queries: points near the sheets, some far (no neighbours), some exactly on voxel faces
+    q = sheet_points(gen, 400, 13.0, center=(16.0, 0.0)) + 0.05 * torch.randn(400, 3, generator=gen)
+    far = torch.tensor([[200.0, 200.0, 50.0], [-300.0, 10.0, 0.0]])
+    face = torch.floor(q[:30] / cfg.voxel_size_m) * cfg.voxel_size_m  # on cell boundaries
+    q = torch.cat([q, far, face], 0).float().contiguous()
+    out["query"] = t2n(q)
+
+    # (1) radius_neighborhood_search with and without the travel-distance filter
+    for tf in (False, True):
+        d2, idx = npts.radius_neighborhood_search(q.clone(), time_filtering=tf)
+        out[f"rs_d2_tf{int(tf)}"] = t2n(d2)
+        out[f"rs_idx_tf{int(tf)}"] = t2n(idx)
+
+    # (2) query_feature, inference mode; local and global; then after_pgo (rotated vectors)
+    for tag, loc in (("loc", True), ("glob", False)):
+        gf, _, w, nn, cert = npts.query_feature(q.clone(), training_mode=False, query_locally=loc)
+        out[f"qf_{tag}_feat"] = t2n(gf); out[f"qf_{tag}_w"] = t2n(w)
+        out[f"qf_{tag}_nn"] = t2n(nn); out[f"qf_{tag}_cert"] = t2n(cert)
+
+    # (3,4) Tracker.query_source_points: sdf, autograd gradient, mask, certainty, std
+    trk = m["Tracker"](cfg, npts, {"sdf": dec, "semantic": None, "color": None})
+    res = trk.query_source_points(q.clone(), cfg.infer_bs, True, True, False, False,
+                                  query_locally=True, mask_min_nn_count=cfg.track_mask_query_nn_k)
+    sdf, grad, _, _, _, mask, cert, std = res
+    out["qsp_sdf"] = t2n(sdf); out["qsp_grad"] = t2n(grad); out["qsp_mask"] = t2n(mask)
+    out["qsp_cert"] = t2n(cert); out["qsp_std"] = t2n(std)
+    out["track_mask_query_nn_k"] = np.int64(cfg.track_mask_query_nn_k)
+
+    # (5) one registration step + full tracking on a bigger, slightly misaligned scan
+    src = sheet_points(gen, 3000, 12.0, center=(16.0, 0.0), layers=2)
+    Tinit = torch.eye(4, dtype=torch.float64)
+    ang = 0.01
+    Tinit[:3, :3] = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    Tinit[:3, 3] = torch.tensor([0.05, -0.03, 0.02], dtype=torch.float64)
+    out["reg_src"] = t2n(src); out["reg_Tinit"] = t2n(Tinit)
+    cur = tools.transform_torch(src, Tinit)
+    out["reg_cur"] = t2n(cur)
+    step = trk.registration_step(cur.clone(), None, torch.zeros(len(src)), None,
+                                 cfg.reg_min_grad_norm, cfg.reg_max_grad_norm,
+                                 cfg.reg_GM_dist_m, cfg.reg_GM_grad, cfg.reg_lm_lambda, False)
+    out["reg_dT"] = t2n(step[0]); out["reg_valid_count"] = np.int64(step[4].shape[0])
+    out["reg_residual_cm"] = np.float64(step[5])
+    cfg.reg_iter_n = 20
+    Tfin, cov, _, vflag = trk.tracking(src.clone(), Tinit.clone())
+    out["trk_T"] = t2n(Tfin); out["trk_valid"] = np.bool_(vflag)
+    out["trk_cov"] = np.asarray(cov) if cov is not None else np.zeros((0,))
+    for kname in ("reg_min_grad_norm", "reg_max_grad_norm", "reg_GM_dist_m", "reg_GM_grad",
+                  "reg_lm_lambda", "surface_sample_range_m", "max_sdf_std_ratio", "reg_iter_n",
+                  "reg_term_thre_deg", "reg_term_thre_m", "final_residual_ratio_thre",
+                  "eigenvalue_ratio_thre"):
+        out["cfg_" + kname] = np.float64(getattr(cfg, kname))
+
+    # (6) Mapper.mapping: two iterations on FIXED batches (get_batch RNG bypassed)
+    ds = R.FakeDataset(n_frames=3)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": None})
+    mp.determine_used_pose()
+    bs = cfg.bs
+    batches = []
+    for it in range(2):
+        coord, label = surface_samples(gen, bs, 12.0, (16.0, 0.0), sigma=0.2)
+        label = (label + 0.02 * torch.randn(bs, generator=gen)).float()
+        ts = torch.randint(0, 3, (bs,), generator=gen).int()
+        w = (0.6 + 0.8 * torch.rand(bs, generator=gen)).float() * torch.where(
+            torch.rand(bs, generator=gen) < 0.5, 1.0, -1.0)
+        batches.append((coord, label, ts, w))
+        out[f"map_coord{it}"] = t2n(coord); out[f"map_label{it}"] = t2n(label)
+        out[f"map_ts{it}"] = t2n(ts); out[f"map_w{it}"] = t2n(w)
+    it_box = {"i": 0}
+
+    def fake_get_batch(global_coord=False):
+        c, l, t, w = batches[it_box["i"]]
+        it_box["i"] += 1
+        return c.clone(), l.clone(), t.clone(), None, None, None, w.clone()
+
+    mp.get_batch = fake_get_batch
+    grads = []
+    real_setup = m["mapper_mod"].setup_optimizer
+
+    def spy_setup(*a, **k):
+        opt = real_setup(*a, **k)
+        real_step = opt.step
+
+        def step(*aa, **kk):
+            g = {}
+            g["feat"] = t2n(npts.local_geo_features.grad)
+            g["dec"] = np.concatenate([t2n(p.grad).ravel() for p in dec.parameters()])
+            grads.append(g)
+            return real_step(*aa, **kk)
+
+        opt.step = step
+        return opt
+
+    m["mapper_mod"].setup_optimizer = spy_setup
+    out["map_eps"] = np.float64(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    out["map_dec"] = np.int64(cfg.gradient_decimation)
+    out["map_weight_e"] = np.float64(cfg.weight_e)
+    out["map_lr"] = np.float64(cfg.lr); out["map_adam_eps"] = np.float64(cfg.adam_eps)
+    out["map_loss_weight_on"] = np.bool_(cfg.loss_weight_on)
+    try:
+        mp.mapping(2)
+    finally:
+        m["mapper_mod"].setup_optimizer = real_setup
+    for it, g in enumerate(grads):
+        out[f"map_gfeat{it}"] = g["feat"]; out[f"map_gdec{it}"] = g["dec"]
+    out["map_feat_after"] = t2n(npts.local_geo_features.data)
+    out["map_dec_after"] = flat_decoder(dec)
+    out["map_cert_after"] = t2n(npts.local_point_certainties)
+    out["map_ts_after"] = t2n(npts.local_point_ts_update)
+    out["map_global_feat_after"] = t2n(npts.geo_features)
+    return out
+
+
+def gen_update():
+    """(7) NeuralPoints.update / reset_local_map resulting arrays (K8/K9 parity)."""
+    m = R.load()
+    cfg = R.make_config(voxel_size_m=0.4, buffer_size=int(5e7), local_map_radius=20.0,
+                        local_map_travel_dist_ratio=1.0)
+    npts = m["NeuralPoints"](cfg)
+    gen = torch.Generator().manual_seed(3)
+    out = {}
+    travel = [0.0, 9.0, 18.0, 27.0]
+    npts.travel_dist = torch.tensor(travel, dtype=torch.float32)
+    out["travel_dist"] = np.asarray(travel, np.float32)
+    for ts in range(4):
+        pts = sheet_points(gen, 8000, 12.0, center=(9.0 * ts, 0.0))
+        out[f"pts{ts}"] = t2n(pts)
+        out[f"sel{ts}"] = t2n(m["tools"].voxel_down_sample_torch(pts, cfg.voxel_size_m))
+        npts.update(pts, torch.tensor([9.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+        out[f"count{ts}"] = np.int64(npts.count())
+        out[f"local_mask{ts}"] = t2n(npts.local_mask)
+        out[f"global2local{ts}"] = t2n(npts.global2local)
+    tab = npts.buffer_pt_index
+    slots = torch.nonzero(tab >= 0).flatten()
+    out.update(table_slots=t2n(slots), table_vals=t2n(tab[slots]), neural_points=t2n(npts.neural_points),
+               point_ts_create=t2n(npts.point_ts_create), buffer_size=np.int64(cfg.buffer_size),
+               resolution=np.float64(cfg.voxel_size_m), local_map_radius=np.float64(npts.local_map_radius),
+               diff_travel_dist_local=np.float64(npts.diff_travel_dist_local))
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for case in CASES:
+        d = gen_case(case)
+        path = os.path.join(OUT, f"{case}.npz")
+        np.savez_compressed(path, **d)
+        print(case, "->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "P =", d["neural_points"].shape[0],
+              "M =", d["local_neural_points"].shape[0])
+    d = gen_update()
+    path = os.path.join(OUT, "update.npz")
+    np.savez_compressed(path, **d)
+    print("update ->", path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

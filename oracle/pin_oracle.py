@@ -1,0 +1,540 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+A plain-numpy restatement of PIN-SLAM's per-frame neural-point SDF hot path, used
+only as the checker by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.  The product path (``pin_slam_amd``) never
+imports this package.
+
+Every function cites the reference file:line it restates (paths relative to the
+PRBonn/PIN_SLAM tree).  The reference ships no tests or golden vectors (SURVEY.md
+section 4), so the oracle is *pinned by executing the reference itself*:
+``oracle/make_golden.py`` imports the unmodified reference modules on CPU in the
+build container and writes ``tests/golden/*.npz``; ``tests/test_oracle_vs_golden.py``
+checks every function below against those fixtures (and, when the reference tree
+is present, against live reference calls).
+
+Conventions
+* float32 everywhere the reference computes in float32, int64 hashing, and the
+  same evaluation order for ``d2`` so neighbour indices are bit-exact.
+* Unstable-sort ties in the reference (``torch.sort`` over candidate distances,
+  neural_points.py:584) are canonicalised as (d2, candidate order); invalid
+  candidates all carry index -1 so their order is immaterial.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+PRIMES = np.array([73856093, 19349669, 83492791], dtype=np.int64)  # neural_points.py:82-84
+IDW_EPS = F32(1e-15)  # neural_points.py:665
+INVALID_D2 = F32(9e3)  # neural_points.py:583
+
+
+# --------------------------------------------------------------------------- K1
+def search_neighborhood(num_nei_cells: int, search_alpha: float, resolution: float):
+    """neural_points.py:910-948 -> (neighbor_dx [Kc,3] int64, max_valid_dist2 float)."""
+    n = int(num_nei_cells)
+    r = np.arange(-n, n + 1, dtype=np.int64)
+    gx, gy, gz = np.meshgrid(r, r, r, indexing="ij")
+    dx = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3)
+    keep = (dx ** 2).sum(-1) < (n + search_alpha) ** 2
+    return np.ascontiguousarray(dx[keep]), 3 * ((n + 1) * resolution) ** 2
+
+
+def grid_coords(points: np.ndarray, resolution: float) -> np.ndarray:
+    """floor(p / res) in float32 true division, then int64 (neural_points.py:963)."""
+    return np.floor(points.astype(F32) / F32(resolution)).astype(np.int64)
+
+
+def hash_slots(cells: np.ndarray, buffer_size: int) -> np.ndarray:
+    """fmod(sum(cell*primes), B) with the negative-index wrap of ``table[hash]``
+    (neural_points.py:972-978): slot = h < 0 ? h + B : h."""
+    h = (cells.astype(np.int64) * PRIMES).sum(-1)
+    h = np.fmod(h, np.int64(buffer_size))
+    return np.where(h < 0, h + np.int64(buffer_size), h)
+
+
+def _d2(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """sum((P - q)**2, -1) in float32, evaluated (dx*dx + dy*dy) + dz*dz like
+    torch's 3-element reduction (neural_points.py:992-995)."""
+    d = (p.astype(F32) - q.astype(F32)).astype(F32)
+    s = d * d
+    return ((s[..., 0] + s[..., 1]).astype(F32) + s[..., 2]).astype(F32)
+
+
+def radius_search(points, table, positions, resolution, neighbor_dx, max_valid_dist2,
+                  ts_create=None, travel_dist=None, cur_ts=0, diff_travel_dist_local=None):
+    """NeuralPoints.radius_neighborhood_search (neural_points.py:950-1009).
+
+    Returns (dist2 [N,Kc] f32, idx [N,Kc] int64 global indices, -1 = invalid).
+    ``travel_dist is not None`` switches the travel-distance window filter on
+    (neural_points.py:982-988)."""
+    points = np.asarray(points, dtype=F32)
+    B = table.shape[0]
+    N, Kc = points.shape[0], neighbor_dx.shape[0]
+    mv = F32(max_valid_dist2)
+    if positions.shape[0] == 0:
+        return np.full((N, Kc), mv, F32), np.full((N, Kc), -1, np.int64)
+    g = grid_coords(points, resolution)
+    cells = g[:, None, :] + neighbor_dx[None, :, :]
+    slot = hash_slots(cells, B)
+    idx = table[slot].astype(np.int64)
+    if travel_dist is not None:
+        td = np.asarray(travel_dist, dtype=F32)
+        diff = np.abs(td[cur_ts] - td[ts_create[idx]])  # idx == -1 reads the last point, as in torch
+        idx = np.where(diff < F32(diff_travel_dist_local), idx, -1)
+    d2 = _d2(positions[idx], points[:, None, :])
+    d2 = np.where(idx == -1, mv, d2).astype(F32)
+    idx = np.where(d2 > mv, -1, idx)
+    return d2, idx
+
+
+# --------------------------------------------------------------------------- K2
+def select_knn(d2, idx, k):
+    """Top-k of query_feature (neural_points.py:583-589) with the canonical
+    (d2, candidate order) tie-break.  ``idx`` is already in the index space that is
+    gathered from (local or global); invalid = -1."""
+    d2 = np.where(idx == -1, INVALID_D2, d2).astype(F32)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(d2, order, 1), np.take_along_axis(idx, order, 1)
+
+
+def quat_rotate(quat, vec):
+    """utils/tools.py:428-437 apply_quaternion_rotation (w,x,y,z; passive per point)."""
+    q0, q1, q2, q3 = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+    R = np.stack([
+        1 - 2 * (q2 ** 2 + q3 ** 2), 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2),
+        2 * (q1 * q2 + q0 * q3), 1 - 2 * (q1 ** 2 + q3 ** 2), 2 * (q2 * q3 - q0 * q1),
+        2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 1 - 2 * (q1 ** 2 + q2 ** 2),
+    ], axis=-1).reshape(quat.shape[:-1] + (3, 3)).astype(vec.dtype)
+    return np.einsum("...ij,...j->...i", R, vec), R
+
+
+def idw_weights(d2k, valid, nn_count, dtype=F32):
+    """neural_points.py:665-683."""
+    u = (dtype(1.0) / (d2k.astype(dtype) + dtype(1e-15))).astype(dtype)
+    u = np.where(valid, u, dtype(0))
+    u = np.where((nn_count == 0)[:, None], dtype(1e-15), u)
+    S = u.sum(1, keepdims=True, dtype=dtype)
+    w = np.where(valid, u / S, dtype(0)).astype(dtype)
+    return u, S, w
+
+
+def query_feature(points, search, feats, positions, certainties=None, k=6,
+                  global2local=None, orientations=None, weighted_first=True,
+                  training_mode=False, query_ts=None, ts_update=None):
+    """NeuralPoints.query_feature (neural_points.py:530-746) for the geometric feature.
+
+    ``search`` = (d2, idx) from :func:`radius_search` (global indices).  When
+    ``global2local`` is given, ``feats/positions/certainties/orientations`` are the
+    *local* arrays.  Returns a dict with geo_feat ([N,F+3] or [N,k,F+3]), weight
+    [N,k,1], nn_count [N], certainty [N], knn_idx [N,k], knn_d2 [N,k], and -- in
+    training mode -- the updated certainties / ts_update copies (the side effects of
+    neural_points.py:685-710)."""
+    points = np.asarray(points, F32)
+    d2, idx = search
+    if global2local is not None:
+        idx = global2local[idx]  # -1 -> last entry, which is -1 (neural_points.py:573, :505)
+    nn_count = (idx >= 0).sum(-1)
+    d2k, idxk = select_knn(d2, idx, k)
+    valid = idxk >= 0
+    F = feats.shape[1]
+    gather = np.where(valid, idxk, 0)
+    f = np.where(valid[..., None], feats[gather], F32(0)).astype(F32)
+    v = (points[:, None, :] - positions[gather]).astype(F32)
+    if orientations is not None:  # after_pgo (neural_points.py:645-648)
+        v, _ = quat_rotate(orientations[gather].astype(F32), v)
+        v = v.astype(F32)
+    v = np.where(valid[..., None], v, F32(0))
+    fv = np.concatenate([f, v], -1)
+    u, S, w = idw_weights(d2k, valid, nn_count)
+    out = dict(nn_count=nn_count.astype(np.int64), weight=w[..., None], knn_idx=idxk, knn_d2=d2k)
+    if certainties is not None:
+        c = np.where(valid, certainties[gather], F32(0))
+        out["certainty"] = (c * w).sum(1, dtype=F32)
+    if training_mode:
+        newc = certainties.copy()
+        np.add.at(newc, gather.ravel(), w.ravel())  # invalid -> row 0, weight 0 (neural_points.py:689)
+        out["certainties_after"] = newc
+        if query_ts is not None and ts_update is not None:
+            newts = ts_update.copy()
+            ts = np.where(valid, np.asarray(query_ts)[:, None], 0).astype(newts.dtype)
+            np.maximum.at(newts, gather.ravel(), ts.ravel())
+            out["ts_update_after"] = newts
+    out["geo_feat"] = (fv * w[..., None]).sum(1, dtype=F32) if weighted_first else fv
+    return out
+
+
+# --------------------------------------------------------------------------- K3
+def unpack_decoder(flat, in_dim, hidden, levels, out_dim=1):
+    """Split the flat parameter buffer (layers.0.weight, layers.0.bias, ...,
+    lout.weight, lout.bias -- the state_dict order of model/decoder.py:46-53)."""
+    flat = np.asarray(flat)
+    Ws, bs, o = [], [], 0
+    d = in_dim
+    for _ in range(levels):
+        Ws.append(flat[o:o + hidden * d].reshape(hidden, d)); o += hidden * d
+        bs.append(flat[o:o + hidden]); o += hidden
+        d = hidden
+    Wo = flat[o:o + out_dim * d].reshape(out_dim, d); o += out_dim * d
+    bo = flat[o:o + out_dim]; o += out_dim
+    assert o == flat.size, (o, flat.size)
+    return Ws, bs, Wo, bo
+
+
+def decoder_param_count(in_dim, hidden, levels, out_dim=1):
+    n, d = 0, in_dim
+    for _ in range(levels):
+        n += hidden * d + hidden
+        d = hidden
+    return n + out_dim * d + out_dim
+
+
+def mlp_forward(z, params, keep=False):
+    """Decoder.mlp (model/decoder.py:61-80): (Linear+ReLU) x L, Linear out."""
+    Ws, bs, Wo, bo = params
+    h = z
+    acts = [z]
+    for W, b in zip(Ws, bs):
+        h = np.maximum(h @ W.T + b, 0).astype(z.dtype)
+        acts.append(h)
+    out = (h @ Wo.T + bo).astype(z.dtype)
+    return (out, acts) if keep else out
+
+
+def mlp_input_jacobian(acts, params):
+    """d out[...,0] / d z, back through the ReLU masks (what autograd's get_gradient,
+    utils/tools.py:247-260, computes through Decoder.mlp)."""
+    Ws, bs, Wo, bo = params
+    a = np.broadcast_to(Wo[0], acts[-1].shape).astype(acts[0].dtype)
+    for li in range(len(Ws) - 1, -1, -1):
+        a = (a * (acts[li + 1] > 0)) @ Ws[li]
+    return a
+
+
+def sdf_and_grad(points, qf, params, sdf_scale, positions, orientations=None, dtype=np.float64):
+    """SDF value, analytic d sdf/d q and (not weighted_first) the std over neighbours.
+
+    Restates Tracker.query_source_points (utils/tracker.py:297-335): Decoder.sdf on the
+    interpolated feature, autograd gradient through the MLP, the neighbour vectors
+    AND the IDW weights.  ``qf`` is the dict returned by
+    :func:`query_feature` called with weighted_first=False (per-neighbour vectors);
+    the mode evaluated here is chosen by ``weighted_first`` stored in qf['mode'].
+    Computed in ``dtype`` (float64 by default: the reference's own float32 autograd
+    carries ~5e-5 relative noise, tests compare with 1e-4)."""
+    T = dtype
+    idxk, d2k = qf["knn_idx"], qf["knn_d2"].astype(T)
+    valid = idxk >= 0
+    nn = qf["nn_count"]
+    fv = qf["fv"].astype(T)  # [N,k,F+3]
+    params = tuple([w.astype(T) for w in p] if isinstance(p, list) else p.astype(T) for p in params)
+    gather = np.where(valid, idxk, 0)
+    diff = (np.asarray(points, T)[:, None, :] - positions[gather].astype(T))  # q - P_t
+    u = np.where(valid, 1.0 / (d2k + T(1e-15)), 0.0)
+    u = np.where((nn == 0)[:, None], T(1e-15), u)
+    S = u.sum(1, keepdims=True)
+    w = np.where(valid, u / S, 0.0)
+    g_u = np.where(valid[..., None], -2.0 * (u ** 2)[..., None] * diff, 0.0)  # d u_t / d q
+    G = g_u.sum(1, keepdims=True)
+    dw = np.where(valid[..., None], g_u / S[..., None] - (u / S ** 2)[..., None] * G, 0.0)  # [N,k,3]
+    s = T(sdf_scale)
+    Fdim = fv.shape[-1] - 3
+    if orientations is not None:
+        _, R = quat_rotate(orientations[gather].astype(T), diff)
+    if qf["mode"] == "weighted_first":
+        z = (fv * w[..., None]).sum(1)
+        out, acts = mlp_forward(z, params, keep=True)
+        a = mlp_input_jacobian(acts, params)  # [N,F+3]
+        c = np.einsum("nf,nkf->nk", a, fv)
+        if orientations is None:
+            direct = a[:, Fdim:] * w.sum(1, keepdims=True)
+        else:
+            direct = np.einsum("nk,nkij,ni->nj", w, R, a[:, Fdim:])
+        grad = s * (direct + np.einsum("nk,nkj->nj", c, dw))
+        return (s * out[:, 0]), grad, np.zeros(len(z), T)
+    out, acts = mlp_forward(fv, params, keep=True)  # [N,k,1]
+    a = mlp_input_jacobian(acts, params)  # [N,k,F+3]
+    sk = s * out[..., 0]
+    mean = (sk * w).sum(1)
+    if orientations is None:
+        direct = (w[..., None] * a[..., Fdim:]).sum(1)
+    else:
+        direct = np.einsum("nk,nkij,nki->nj", w, R, a[..., Fdim:])
+    grad = np.einsum("nk,nkj->nj", sk, dw) + s * direct
+    std = np.sqrt((w * (sk - mean[:, None]) ** 2).sum(1))
+    return mean, grad, std
+
+
+def query_sdf(points, search, feats, positions, params, sdf_scale, k, weighted_first=True,
+              global2local=None, certainties=None, orientations=None, with_grad=True,
+              dtype=np.float64):
+    """Convenience: radius-search result -> (sdf, grad, std, nn_count, certainty)."""
+    qf = query_feature(points, search, feats, positions, certainties, k, global2local,
+                       orientations, weighted_first=False)
+    qf["fv"] = qf["geo_feat"]
+    qf["mode"] = "weighted_first" if weighted_first else "per_neighbor"
+    sdf, grad, std = sdf_and_grad(points, qf, params, sdf_scale, positions, orientations, dtype)
+    return sdf, grad, std, qf["nn_count"], qf.get("certainty")
+
+
+# --------------------------------------------------------------------------- K5
+def expmap(t):
+    """utils/tracker.py:784-795."""
+    angle = np.linalg.norm(t)
+    axis = t / angle
+    S = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + S * np.sin(angle) + (S @ S) * (1.0 - np.cos(angle))
+
+
+def registration_step(points, sdf, grad, std, nn_count, *, valid_nn_k, min_grad_norm=0.5,
+                      max_grad_norm=2.0, max_sdf_std=0.25, GM_dist=0.3, GM_grad=0.1,
+                      lm_lambda=1e-4, sdf_labels=None):
+    """Tracker.registration_step + implicit_reg (utils/tracker.py:409-524, 615-695),
+    geometric term only.  Returns dict(T [4,4] f64, valid_count, residual_cm, N, g)."""
+    points = np.asarray(points, np.float64)
+    sdf = np.asarray(sdf, np.float64)
+    grad = np.asarray(grad, np.float64)
+    gn = np.linalg.norm(grad, axis=-1)
+    valid = (nn_count >= valid_nn_k) & (gn < max_grad_norm) & (gn > min_grad_norm) & (np.asarray(std) < max_sdf_std)
+    n = int(valid.sum())
+    if n < 10:  # tracker.py:430-432
+        return dict(T=np.eye(4), valid_count=n, residual_cm=0.0, valid=valid)
+    p, g, r, gnv = points[valid], grad[valid], sdf[valid], gn[valid]
+    if sdf_labels is not None:
+        r = r - np.asarray(sdf_labels, np.float64)[valid]
+    w = np.ones(n)
+    if GM_grad is not None:
+        w = w * (GM_grad / (GM_grad + (gnv - 1.0) ** 2)) ** 2
+    if GM_dist is not None:
+        w = w * (GM_dist / (GM_dist + r ** 2)) ** 2
+    w = w / (2.0 * w.mean())  # tracker.py:524
+    J = np.concatenate([np.cross(p, g), g], -1)
+    N = J.T @ (w[:, None] * J)
+    N_raw = N.copy()
+    N = N + lm_lambda * np.diag(np.diag(N))
+    b = -(J * w[:, None]).T @ r
+    t = np.linalg.solve(N, b)
+    T = np.eye(4)
+    T[:3, :3] = expmap(t[:3])
+    T[:3, 3] = t[3:]
+    return dict(T=T, valid_count=n, residual_cm=float(np.abs(r).mean() * 100.0), N=N_raw,
+                g=b, valid=valid, weight=w)
+
+
+def transform_points(points, T):
+    """utils/tools.py:534-553 transform_torch: float32 points x float32(T)."""
+    T32 = np.asarray(T).astype(F32)
+    ph = np.concatenate([np.asarray(points, F32), np.ones((len(points), 1), F32)], 1)
+    return (ph @ T32.T)[:, :3].astype(F32)
+
+
+# --------------------------------------------------------------------------- K6 / K7
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def bce_with_logits(x, y, weight=None):
+    """torch.nn.BCEWithLogitsLoss(reduction='mean') as used by utils/loss.py:45-63."""
+    l = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
+    if weight is not None:
+        l = l * weight
+    return l.mean()
+
+
+def mlp_backward(acts, params, dout):
+    """Backprop d loss/d out [...,1] through Decoder.mlp -> (dz, flat param grad)."""
+    Ws, bs, Wo, bo = params
+    h = acts[-1].reshape(-1, acts[-1].shape[-1])
+    d = dout.reshape(-1, dout.shape[-1])
+    gWo, gbo = d.T @ h, d.sum(0)
+    dh = d @ Wo
+    gW, gb = [None] * len(Ws), [None] * len(Ws)
+    for li in range(len(Ws) - 1, -1, -1):
+        dh = dh * (acts[li + 1].reshape(-1, acts[li + 1].shape[-1]) > 0)
+        x = acts[li].reshape(-1, acts[li].shape[-1])
+        gW[li], gb[li] = dh.T @ x, dh.sum(0)
+        dh = dh @ Ws[li]
+    flat = []
+    for a, b in zip(gW, gb):
+        flat += [a.ravel(), b.ravel()]
+    flat += [gWo.ravel(), gbo.ravel()]
+    return dh.reshape(acts[0].shape), np.concatenate(flat)
+
+
+def eikonal_queries(coord, dec, eps):
+    """mapper.py:682-686 + 986-1008: the 6*n_e central-difference query points in the
+    reference's concatenation order (x+, x-, y+, y-, z+, z-), each block [n_e,3]."""
+    x = np.asarray(coord, F32)[::dec]
+    e = F32(eps)
+    offs = [(e, 0, 0), (-e, 0, 0), (0, e, 0), (0, -e, 0), (0, 0, e), (0, 0, -e)]
+    return np.concatenate([(x + np.array(o, F32)).astype(F32) for o in offs], 0)
+
+
+def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat_params,
+               dec_shape, sdf_scale, k, *, weighted_first=True, dec=10, eps=0.08, weight_e=0.5,
+               loss_weight_on=False, ekional=True, dtype=np.float64):
+    """One iteration of Mapper.mapping (utils/mapper.py:645-817) on a FIXED batch:
+    forward (K1-K3), BCE + Eikonal(numerical gradient) loss, backward.
+
+    ``searcher(points) -> dict`` must return :func:`query_feature` output with
+    weighted_first=False vectors (geo_feat [N,k,F+3]) for the given points.
+    Returns dict(loss, sdf_loss, eik_loss, feat_grad [M+1,F], dec_grad [n_param], sdf_pred)."""
+    T = dtype
+    in_dim, hidden, levels = dec_shape
+    params = unpack_decoder(np.asarray(flat_params, T), in_dim, hidden, levels)
+    F = feats.shape[1]
+    feat_grad = np.zeros((feats.shape[0], F), T)
+    s = T(sdf_scale)
+
+    def forward(points):
+        qf = searcher(points)
+        fv = qf["geo_feat"].astype(T)
+        valid = qf["knn_idx"] >= 0
+        _, _, w = idw_weights(qf["knn_d2"], valid, qf["nn_count"], dtype=T)
+        if weighted_first:
+            z = (fv * w[..., None]).sum(1)
+        else:
+            z = fv
+        out, acts = mlp_forward(z, params, keep=True)
+        x = out[..., 0]
+        pred = s * x if weighted_first else (s * x * w).sum(1)
+        return dict(qf=qf, w=w, valid=valid, acts=acts, x=x, pred=pred)
+
+    def backward(fw, dpred):
+        """dpred = d loss / d pred [N]."""
+        if weighted_first:
+            dz, gflat = mlp_backward(fw["acts"], params, (dpred * s)[:, None])
+            dfeat = fw["w"][..., None] * dz[:, None, :F]
+        else:
+            dout = (dpred[:, None] * s * fw["w"])[..., None]
+            dz, gflat = mlp_backward(fw["acts"], params, dout)
+            dfeat = dz[..., :F]
+        dfeat = np.where(fw["valid"][..., None], dfeat, 0.0)
+        gather = np.where(fw["valid"], fw["qf"]["knn_idx"], 0)
+        np.add.at(feat_grad, gather.reshape(-1), dfeat.reshape(-1, F))
+        return gflat
+
+    bs = len(coord)
+    fw = forward(coord)
+    sigma = s
+    xl = fw["pred"] / sigma
+    y = _sigmoid(np.asarray(sdf_label, T) / sigma)
+    wt = np.abs(np.asarray(sample_weight, T)) if loss_weight_on else None
+    sdf_loss = bce_with_logits(xl, y, wt)
+    dxl = (_sigmoid(xl) - y) / bs
+    if wt is not None:
+        dxl = dxl * wt
+    dec_grad = backward(fw, dxl / sigma)
+    eik_loss = 0.0
+    if ekional and weight_e > 0:
+        qe = eikonal_queries(coord, dec, eps)
+        fe = forward(qe)
+        ne = len(qe) // 6
+        P = fe["pred"].reshape(6, ne)
+        g = np.stack([(P[0] - P[1]), (P[2] - P[3]), (P[4] - P[5])], -1) / (2 * T(F32(eps)))
+        nrm = np.linalg.norm(g, axis=-1)
+        eik_loss = ((nrm - 1.0) ** 2).mean()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            dg = np.where(nrm[:, None] > 0, g / nrm[:, None], 0.0)
+        dg = dg * (2.0 * (nrm - 1.0) * weight_e / ne)[:, None] / (2 * T(F32(eps)))
+        dP = np.stack([dg[:, 0], -dg[:, 0], dg[:, 1], -dg[:, 1], dg[:, 2], -dg[:, 2]], 0).reshape(-1)
+        dec_grad = dec_grad + backward(fe, dP)
+    return dict(loss=sdf_loss + weight_e * eik_loss, sdf_loss=sdf_loss, eik_loss=eik_loss,
+                feat_grad=feat_grad, dec_grad=dec_grad, sdf_pred=fw["pred"], fw=fw)
+
+
+def adam_step(p, g, m, v, step, lr=0.01, b1=0.9, b2=0.99, eps=1e-15):
+    """torch.optim.Adam (no amsgrad, no weight decay) as configured by
+    utils/tools.py:198-199 (betas (0.9, 0.99), eps = adam_eps)."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = np.sqrt(v) / np.sqrt(bc2) + eps
+    return p - (lr / bc1) * m / denom, m, v
+
+
+# --------------------------------------------------------------------------- K8 / K9
+def voxel_down_sample(points, voxel_size):
+    """utils/tools.py:583-626 voxel_down_sample_torch: index of the point closest to the
+    voxel centre per voxel (distance quantised to 1000 levels, smallest index wins ties);
+    result ordered by ascending linearised voxel id like torch.unique."""
+    points = np.asarray(points, F32)
+    vs = F32(voxel_size)
+    offset = np.floor(points.min(0) / vs).astype(np.int64)
+    grid = np.floor(points / vs)
+    center = ((grid + F32(0.5)) * vs).astype(F32)
+    dd = (points - center) ** 2
+    dist = ((dd[:, 0] + dd[:, 1]).astype(F32) + dd[:, 2]).astype(F32) ** F32(0.5)
+    dist = (dist / dist.max() * F32(999)).astype(np.int64)
+    gi = grid.astype(np.int64) - offset
+    vsz = gi.max()
+    gid = gi[:, 0] + gi[:, 1] * vsz + gi[:, 2] * vsz * vsz
+    _, inverse = np.unique(gid, return_inverse=True)
+    n = len(points)
+    off = 10 ** len(str(n - 1))
+    key = np.arange(n, dtype=np.int64) + dist * off
+    out = np.full(inverse.max() + 1, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(out, inverse, key)
+    return out % off
+
+
+def map_update(state, points, cur_ts, resolution, travel_dist=None, diff_travel_dist_local=None,
+               reboot_ts=0, temporal=True):
+    """NeuralPoints.update (neural_points.py:311-416) on a dict state with keys
+    table [B] int64, positions [P,3], ts_create [P], ts_update [P].  Appends new points
+    (features/certainties are initialised by the caller) and returns the added points.
+    Duplicate hash slots inside one call resolve 'last writer wins' in index order
+    (the reference's index_put_ is order-unspecified there; tests avoid relying on it)."""
+    points = np.asarray(points, F32)
+    sel = voxel_down_sample(points, resolution)
+    sp = points[sel]
+    B = state["table"].shape[0]
+    slot = hash_slots(grid_coords(sp, resolution), B)
+    hidx = state["table"][slot]
+    P = state["positions"].shape[0]
+    if P > 0 and cur_ts != reboot_ts:
+        d2 = _d2(state["positions"][hidx], sp)
+        mask = (hidx == -1) | (d2 > F32(3 * resolution ** 2))
+        if temporal:
+            td = np.asarray(travel_dist, F32)
+            mask |= (td[cur_ts] - td[state["ts_update"][hidx]]) > F32(diff_travel_dist_local)
+    else:
+        mask = np.ones(len(sp), bool)
+    added = sp[mask]
+    cur = hidx.copy()
+    cur[mask] = np.arange(len(added), dtype=np.int64) + P
+    state["table"][slot] = cur
+    state["positions"] = np.concatenate([state["positions"], added], 0)
+    ts = np.full(len(added), cur_ts, np.int32)
+    state["ts_create"] = np.concatenate([state["ts_create"], ts])
+    state["ts_update"] = np.concatenate([state["ts_update"], ts])
+    return added
+
+
+def local_map_mask(positions, ts_used, sensor_position, radius, travel_dist=None, cur_ts=0,
+                   diff_travel_dist_local=None, reboot_ts=None):
+    """NeuralPoints.reset_local_map (neural_points.py:448-507): (local_mask [P] bool,
+    global2local [P+1] int64).
+
+    Reference quirk, reproduced on purpose: ``torch.full_like(local_mask, -1).long()``
+    (neural_points.py:498) is taken of a *bool* tensor, so the fill value is True -> 1,
+    i.e. NON-LOCAL points map to local index 1, not -1; only the padding entry is -1
+    (neural_points.py:505)."""
+    P = positions.shape[0]
+    if travel_dist is not None:
+        td = np.asarray(travel_dist, F32)
+        tm = np.abs(td[cur_ts] - td[ts_used]) < F32(diff_travel_dist_local)
+        if reboot_ts is not None:
+            tm &= ts_used >= reboot_ts
+        if tm.sum() < 100:
+            tm = np.ones(P, bool)
+    else:
+        tm = np.ones(P, bool)
+    d = (positions - np.asarray(sensor_position, F32)).astype(F32) ** 2
+    dist2 = ((d[:, 0] + d[:, 1]).astype(F32) + d[:, 2]).astype(F32)
+    mask = tm & (dist2 < F32(radius ** 2))
+    g2l = np.full(P + 1, 1, np.int64)
+    g2l[:P][mask] = np.arange(int(mask.sum()))
+    g2l[P] = -1
+    return mask, g2l

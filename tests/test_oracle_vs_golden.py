@@ -1,0 +1,188 @@
+"""Pin the numpy oracle (oracle/pin_oracle.py) against fixtures produced by the real,
+unmodified reference (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import pin_oracle as O
+from tests import golden_util as G
+
+
+@pytest.fixture(scope="module", params=G.CASES)
+def gold(request):
+    d = G.load(request.param)
+    d["table"] = G.dense_table(d)
+    d["params"] = O.unpack_decoder(d["dec_flat"], 11, int(d["dec_hidden"]), int(d["dec_levels"]))
+    return d
+
+
+def _search(d, q, tf):
+    kw = {}
+    if tf:
+        kw = dict(ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                  diff_travel_dist_local=d["diff_travel_dist_local"])
+    return O.radius_search(q, d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"],
+                           d["max_valid_dist2"], **kw)
+
+
+def test_search_neighborhood(gold):
+    dx, mv = O.search_neighborhood(int(gold["num_nei_cells"]), gold["search_alpha"], gold["resolution"])
+    assert np.array_equal(dx, gold["neighbor_dx"])
+    assert mv == gold["max_valid_dist2"]
+
+
+@pytest.mark.parametrize("tf", [0, 1])
+def test_radius_search_bit_exact(gold, tf):
+    d2, idx = _search(gold, gold["query"], tf)
+    assert np.array_equal(idx, gold[f"rs_idx_tf{tf}"])
+    assert np.array_equal(d2.view(np.uint32), gold[f"rs_d2_tf{tf}"].view(np.uint32))
+    assert (idx >= 0).sum() > 1000  # the fixture is not vacuous
+
+
+@pytest.mark.parametrize("tag", ["loc", "glob"])
+def test_query_feature(gold, tag):
+    d, q = gold, gold["query"]
+    loc = tag == "loc"
+    s = _search(d, q, tf=loc)
+    if loc:
+        qf = O.query_feature(q, s, d["local_geo_features"], d["local_neural_points"],
+                             d["local_point_certainties"], int(d["query_nn_k"]),
+                             global2local=d["global2local"], weighted_first=bool(d["weighted_first"]))
+    else:
+        qf = O.query_feature(q, s, d["geo_features"], d["neural_points"], d["point_certainties"],
+                             int(d["query_nn_k"]), weighted_first=bool(d["weighted_first"]))
+    assert np.array_equal(qf["nn_count"], d[f"qf_{tag}_nn"])
+    np.testing.assert_allclose(qf["weight"], d[f"qf_{tag}_w"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(qf["geo_feat"], d[f"qf_{tag}_feat"], rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(qf["certainty"], d[f"qf_{tag}_cert"], rtol=1e-5, atol=1e-6)
+
+
+def _qsdf(d, q):
+    s = _search(d, q, tf=True)
+    return O.query_sdf(q, s, d["local_geo_features"], d["local_neural_points"], d["params"],
+                       d["sdf_scale"], int(d["query_nn_k"]), weighted_first=bool(d["weighted_first"]),
+                       global2local=d["global2local"], certainties=d["local_point_certainties"])
+
+
+def test_query_source_points(gold):
+    d = gold
+    sdf, grad, std, nn, cert = _qsdf(d, d["query"])
+    assert np.array_equal(nn >= d["track_mask_query_nn_k"], d["qsp_mask"])
+    np.testing.assert_allclose(sdf, d["qsp_sdf"], rtol=1e-5, atol=1e-7)
+    # the reference's own float32 autograd gradient carries ~5e-5 relative noise
+    scale = np.abs(d["qsp_grad"]).max(1, keepdims=True) + 1e-6
+    assert np.max(np.abs(grad - d["qsp_grad"]) / scale) < 1e-4
+    np.testing.assert_allclose(std, d["qsp_std"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(cert, d["qsp_cert"], rtol=1e-5, atol=1e-6)
+
+
+def _reg_kwargs(d):
+    return dict(valid_nn_k=int(d["track_mask_query_nn_k"]), min_grad_norm=d["cfg_reg_min_grad_norm"],
+                max_grad_norm=d["cfg_reg_max_grad_norm"],
+                max_sdf_std=d["cfg_surface_sample_range_m"] * d["cfg_max_sdf_std_ratio"],
+                GM_dist=d["cfg_reg_GM_dist_m"], GM_grad=d["cfg_reg_GM_grad"], lm_lambda=d["cfg_reg_lm_lambda"])
+
+
+def test_transform_and_registration_step(gold):
+    d = gold
+    cur = O.transform_points(d["reg_src"], d["reg_Tinit"])
+    np.testing.assert_allclose(cur, d["reg_cur"], rtol=0, atol=2e-6)
+    sdf, grad, std, nn, _ = _qsdf(d, d["reg_cur"])
+    r = O.registration_step(d["reg_cur"], sdf, grad, std, nn, **_reg_kwargs(d))
+    assert r["valid_count"] == d["reg_valid_count"]
+    assert abs(r["residual_cm"] - d["reg_residual_cm"]) < 1e-3 * max(1.0, d["reg_residual_cm"])
+    np.testing.assert_allclose(r["T"], d["reg_dT"], rtol=0, atol=2e-6)
+
+
+def test_tracking_loop(gold):
+    """Tracker.tracking (utils/tracker.py:114-184): GN loop, same termination rule."""
+    d = gold
+    T = d["reg_Tinit"].copy()
+    iter_n = int(d["cfg_reg_iter_n"])
+    converged = False
+    for i in range(iter_n):
+        cur = O.transform_points(d["reg_src"], T)
+        sdf, grad, std, nn, _ = _qsdf(d, cur)
+        r = O.registration_step(cur, sdf, grad, std, nn, **_reg_kwargs(d))
+        T = r["T"] @ T
+        if converged:
+            break
+        dT = r["T"]
+        ang = np.degrees(np.arccos(np.clip((np.trace(dT[:3, :3]) - 1) / 2, -1, 1)))
+        if (abs(ang) < d["cfg_reg_term_thre_deg"] and np.linalg.norm(dT[:3, 3]) < d["cfg_reg_term_thre_m"]) \
+                or i == iter_n - 2:
+            converged = True
+    assert d["trk_valid"]
+    np.testing.assert_allclose(T[:3, 3], d["trk_T"][:3, 3], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(T[:3, :3], d["trk_T"][:3, :3], rtol=0, atol=1e-5)
+
+
+def test_mapping_two_iterations(gold):
+    """Mapper.mapping on fixed batches: gradients of iteration 0/1, post-Adam parameters,
+    certainty / ts side effects (mapper.py:645-818, neural_points.py:685-710)."""
+    d = gold
+    k = int(d["query_nn_k"])
+    wf = bool(d["weighted_first"])
+    feats = d["local_geo_features"].astype(np.float64).copy()
+    flat = d["dec_flat"].astype(np.float64).copy()
+    cert = d["local_point_certainties"].copy()
+    tsu = d["local_point_ts_update"].copy()
+    mf, vf = np.zeros_like(feats), np.zeros_like(feats)
+    md, vd = np.zeros_like(flat), np.zeros_like(flat)
+    shape = (11, int(d["dec_hidden"]), int(d["dec_levels"]))
+    for it in range(2):
+        coord = d[f"map_coord{it}"]
+
+        def searcher(points, main=[True]):
+            s = _search(d, points, tf=True)
+            train = main[0]
+            main[0] = False
+            qf = O.query_feature(points, s, feats.astype(np.float32), d["local_neural_points"], cert, k,
+                                 global2local=d["global2local"], weighted_first=False,
+                                 training_mode=train, query_ts=d[f"map_ts{it}"] if train else None,
+                                 ts_update=tsu)
+            if train:
+                searcher.side = (qf["certainties_after"], qf["ts_update_after"])
+            return qf
+
+        r = O.train_step(coord, d[f"map_label{it}"], d[f"map_w{it}"], searcher, feats, d["local_neural_points"],
+                         flat, shape, d["sdf_scale"], k, weighted_first=wf, dec=int(d["map_dec"]),
+                         eps=d["map_eps"], weight_e=d["map_weight_e"], loss_weight_on=bool(d["map_loss_weight_on"]))
+        cert, tsu = searcher.side
+        gf, gd = d[f"map_gfeat{it}"], d[f"map_gdec{it}"]
+        assert np.max(np.abs(r["feat_grad"] - gf)) < 2e-4 * np.abs(gf).max()
+        assert np.max(np.abs(r["dec_grad"] - gd)) < 2e-4 * np.abs(gd).max()
+        feats, mf, vf = O.adam_step(feats, r["feat_grad"], mf, vf, it + 1, d["map_lr"], eps=d["map_adam_eps"])
+        flat, md, vd = O.adam_step(flat, r["dec_grad"], md, vd, it + 1, d["map_lr"], eps=d["map_adam_eps"])
+    # Adam normalises every touched entry to a +-lr sized step; entries whose gradient is at
+    # float32-noise level can flip sign between implementations -> compare the bulk tightly.
+    df = np.abs(feats - d["map_feat_after"])
+    assert np.mean(df < 1e-4) > 0.995 and df.max() <= 2.1 * d["map_lr"] * 2
+    dd = np.abs(flat - d["map_dec_after"])
+    assert np.mean(dd < 1e-4) > 0.99
+    np.testing.assert_allclose(cert, d["map_cert_after"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(tsu, d["map_ts_after"])
+
+
+def test_update_and_local_map():
+    """NeuralPoints.update / reset_local_map (neural_points.py:311-513) including the
+    voxel down-sampler (utils/tools.py:583-626)."""
+    d = G.load("update")
+    B = int(d["buffer_size"])
+    st = dict(table=np.full(B, -1, np.int64), positions=np.zeros((0, 3), np.float32),
+              ts_create=np.zeros(0, np.int32), ts_update=np.zeros(0, np.int32))
+    for ts in range(4):
+        pts = d[f"pts{ts}"]
+        assert np.array_equal(O.voxel_down_sample(pts, d["resolution"]), d[f"sel{ts}"])
+        O.map_update(st, pts, ts, d["resolution"], travel_dist=d["travel_dist"],
+                     diff_travel_dist_local=d["diff_travel_dist_local"])
+        assert st["positions"].shape[0] == d[f"count{ts}"]
+        mask, g2l = O.local_map_mask(st["positions"], st["ts_create"], [9.0 * ts, 0, 0], d["local_map_radius"],
+                                     travel_dist=d["travel_dist"], cur_ts=ts,
+                                     diff_travel_dist_local=d["diff_travel_dist_local"], reboot_ts=0)
+        assert np.array_equal(mask, d[f"local_mask{ts}"][:-1])
+        assert np.array_equal(g2l, d[f"global2local{ts}"])
+    assert np.array_equal(st["positions"], d["neural_points"])
+    assert np.array_equal(st["ts_create"], d["point_ts_create"])
+    slots = np.nonzero(st["table"] >= 0)[0]
+    assert np.array_equal(slots, d["table_slots"])
+    assert np.array_equal(st["table"][slots], d["table_vals"])
