@@ -1,0 +1,161 @@
+/* pin_abi.h -- C ABI of libpinhip.so: the MI355X (gfx950) implementation of PIN-SLAM's
+ * per-frame neural-point SDF hot path.
+ *
+ * The reference (PRBonn/PIN_SLAM) has no FFI: its boundary for this path is the Python
+ * class surface model/neural_points.py::NeuralPoints, model/decoder.py::Decoder,
+ * utils/mapper.py::Mapper.mapping and utils/tracker.py::Tracker.tracking.  Every entry
+ * point below cites the reference function (file:line, relative to the reference tree)
+ * whose tensor-op chain it replaces.  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch types.  All array pointers are DEVICE pointers
+ *    unless the name ends in _host.  Memory is owned by the caller; the library never
+ *    allocates device memory; scratch comes from caller-provided workspaces.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream) and returns 0 on success, <0 on error; pin_last_error() gives text.
+ *  - indices are int32 on the device (the reference uses int64 tensors); -1 = invalid.
+ *  - float arithmetic is IEEE fp32 with the reference's evaluation order wherever an
+ *    integer result depends on it (voxel coordinates, neighbour distances).
+ */
+#ifndef PIN_ABI_H
+#define PIN_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIN_ABI_VERSION 1
+#define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
+#define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
+#define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
+#define PIN_NONLOCAL (-2)          /* global2local value of a non-local point, see below */
+#define PIN_NBR_QUIRK_BIT 0x40000000
+
+/* ---- voxel-hash search state: NeuralPoints fields used by
+ * radius_neighborhood_search (model/neural_points.py:950-1009) ------------------- */
+typedef struct pin_search_params {
+    const int32_t* table;        /* [buffer_size] slot -> global point index, -1 = empty
+                                    (buffer_pt_index, neural_points.py:88; int64 there) */
+    const float*   pos4;         /* [n_points][4] x, y, z, bit pattern of point_ts_create:
+                                    one 16-byte gather per occupied candidate cell
+                                    (neural_points, point_ts_create: neural_points.py:92,112) */
+    const int32_t* cand_off;     /* [Kc] (dx*p0 + dy*p1 + dz*p2) mod buffer_size for the
+                                    candidate offsets neighbor_dx (neural_points.py:919-932),
+                                    from pin_candidate_offsets() */
+    const float*   travel_dist;  /* [n_ts] accumulated travel distance per frame, or NULL =
+                                    no travel-distance window filter (neural_points.py:982-988) */
+    const int32_t* global2local; /* [n_points+1] or NULL = query the global map.  Values:
+                                    local index, -1 (padding entry), PIN_NONLOCAL for points
+                                    outside the local map.  The reference maps those to local
+                                    index 1 (torch.full_like(bool, -1).long(), neural_points.py:498);
+                                    the kernels reproduce that and flag the neighbour. */
+    int64_t buffer_size;         /* config.buffer_size, < 2^31 */
+    int32_t n_points;
+    int32_t n_cand;              /* Kc = neighbor_K */
+    int32_t cur_ts;              /* NeuralPoints.cur_ts */
+    float   diff_travel_dist_local; /* local_map_radius * local_map_travel_dist_ratio */
+    float   resolution;          /* voxel_size_m */
+    float   max_valid_dist2;     /* 3*((num_nei_cells+1)*resolution)^2 (neural_points.py:947) */
+} pin_search_params;
+
+/* ---- the implicit field: feature tables + decoder (NeuralPoints.query_feature
+ * neural_points.py:530-746, Decoder.mlp/sdf model/decoder.py:61-85) -------------- */
+typedef struct pin_field {
+    const float* feats;      /* [M+1][8] geo features of the index space that was searched
+                                (local_geo_features or geo_features; last row = padding) */
+    const float* certainty;  /* [M] point certainties or NULL */
+    const float* orient;     /* [M][4] quaternions, non-NULL only after PGO (after_pgo,
+                                neural_points.py:645-648) */
+    const float* pos;        /* [M][3] positions of that index space (used only for flagged
+                                neighbours and after PGO) */
+    const float* dec;        /* flat decoder parameters in state_dict order: layers.i.weight
+                                [H][in] row-major, layers.i.bias [H], lout.weight [1][H], lout.bias */
+    int32_t k;               /* query_nn_k, <= PIN_MAX_K */
+    int32_t hidden;          /* 32 or 64 */
+    int32_t levels;          /* hidden layers, 1..4 */
+    int32_t weighted_first;  /* config.weighted_first (utils/config.py:93) */
+    float   sdf_scale;       /* logistic_gaussian_ratio * sigma_sigmoid_m (decoder.py:54-56) */
+} pin_field;
+
+/* ---- Gauss-Newton registration (Tracker.registration_step + implicit_reg,
+ * utils/tracker.py:409-524, 615-695) --------------------------------------------- */
+typedef struct pin_gn_params {
+    int32_t valid_nn_k;      /* track_mask_query_nn_k */
+    float min_grad_norm, max_grad_norm;   /* reg_min/max_grad_norm */
+    float max_sdf_std;       /* surface_sample_range_m * max_sdf_std_ratio */
+    float gm_dist;           /* reg_GM_dist_m, <=0 disables */
+    float gm_grad;           /* reg_GM_grad, <=0 disables */
+} pin_gn_params;
+#define PIN_GN_NSUMS 32
+/* sums layout (double[PIN_GN_NSUMS]): [0..20] upper triangle of sum w J J^T (row-major,
+ * J = [p x g, g]); [21..26] sum w J r; [27] sum w; [28] sum |r|; [29] valid count;
+ * [30] sum w r^2; [31] reserved.  w is the un-normalised robust weight; the host applies
+ * the reference's w /= 2*mean(w) (tracker.py:524) as one scalar. */
+
+/* ---- library ------------------------------------------------------------------- */
+int         pin_version(void);
+const char* pin_last_error(void);
+
+/* host helper: cand_off_host[c] = (dx.primes) mod buffer_size, primes = (73856093,
+ * 19349669, 83492791) (neural_points.py:82-84).  neighbor_dx_host is [n_cand][3]. */
+int pin_candidate_offsets(const int32_t* neighbor_dx_host, int32_t n_cand, int64_t buffer_size,
+                          int32_t* cand_off_host);
+
+/* pos4[i] = (pos[i].xyz, bits(ts_create[i])) for i in [first, first+n) */
+int pin_pack_positions(const float* pos, const int32_t* ts_create, int32_t first, int32_t n,
+                       float* pos4, void* stream);
+
+/* K1: full candidate search, reference API parity.  d2_out [n][Kc] f32, idx_out [n][Kc]
+ * int64 global indices (-1 invalid) -- exactly the two tensors returned by
+ * NeuralPoints.radius_neighborhood_search (neural_points.py:950-1009); global2local is
+ * ignored here.  Used by query_certainty (neural_points.py:1011-1032). */
+int pin_radius_search(const pin_search_params* sp, const float* query, int32_t n,
+                      float* d2_out, int64_t* idx_out, void* stream);
+
+/* K1+K2a: k nearest valid candidates per query, ascending (d2, candidate order).
+ * `pose` (host, 12 floats row-major 3x4, may be NULL) is applied to the query points first
+ * (transform_torch, utils/tools.py:534-553) and the transformed points are written to
+ * query_out (may be NULL or alias nothing).  nbr_out [n][k][4] = (q - P).xyz and the bit
+ * pattern of the neighbour index in the searched index space (-1 invalid, bit 30 set for
+ * PIN_NONLOCAL neighbours); nn_count_out [n] counts valid candidates among ALL Kc
+ * (neural_points.py:577). */
+int pin_knn_query(const pin_search_params* sp, const float* query, int32_t n, int32_t k,
+                  const float* pose_host, float* query_out, float* nbr_out,
+                  int32_t* nn_count_out, void* stream);
+
+/* K2: NeuralPoints.query_feature tensor API (neural_points.py:590-746) from a kNN result.
+ * feat_out: [n][11] (weighted_first) or [n][k][11]; weight_out [n][k]; certainty_out [n]
+ * (NULL ok).  training != 0 applies the side effects of neural_points.py:685-710:
+ * certainty_rw[idx] += w (float atomics), ts_update_rw[idx] = max(., query_ts). */
+int pin_query_feature(const pin_field* f, const float* query, const float* nbr,
+                      const int32_t* nn_count, int32_t n,
+                      float* feat_out, float* weight_out, float* certainty_out,
+                      int32_t training, float* certainty_rw, int32_t* ts_update_rw,
+                      const int32_t* query_ts, void* stream);
+
+/* K3: Decoder.sdf on caller-provided features (model/decoder.py:83-85): in [n][11] ->
+ * out [n] (already multiplied by sdf_scale). */
+int pin_decoder_sdf(const pin_field* f, const float* feat_in, int32_t n, float* sdf_out, void* stream);
+
+/* K2+K3+K4 fused: interpolate, decode, analytic d sdf/d q through MLP, neighbour vectors
+ * and IDW weights (Tracker.query_source_points, utils/tracker.py:297-354, get_gradient
+ * utils/tools.py:247-260).  Any output pointer may be NULL. */
+int pin_sdf_query(const pin_field* f, const float* query, const float* nbr,
+                  const int32_t* nn_count, int32_t n, float* sdf_out, float* grad_out,
+                  float* std_out, float* certainty_out, void* stream);
+
+/* K2..K5 fused: the same plus validity mask, Geman-McClure weights and the Gauss-Newton
+ * normal-equation sums (tracker.py:409-524, 652-671).  sums_out: double[PIN_GN_NSUMS],
+ * zeroed by this call.  sdf_labels may be NULL (all zero).  Per-point outputs optional. */
+int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* query,
+                      const float* nbr, const int32_t* nn_count, const float* sdf_labels,
+                      int32_t n, double* sums_out, float* sdf_out, float* grad_out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIN_ABI_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libpinhip.so (the C ABI declared in include/pin_abi.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  Build it with ``python -m pin_slam_amd.build`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpinhip.so")
+
+PIN_MAX_K = 8
+PIN_MLP_IN = 11
+PIN_FEATURE_DIM = 8
+PIN_NONLOCAL = -2
+PIN_NBR_QUIRK_BIT = 0x40000000
+PIN_GN_NSUMS = 32
+PIN_GN_REPLICAS = 64
+PIN_ABI_VERSION = 1
+
+vp = C.c_void_p
+
+
+class SearchParams(C.Structure):
+    _fields_ = [
+        ("table", vp), ("pos4", vp), ("cand_off", vp), ("travel_dist", vp), ("global2local", vp),
+        ("buffer_size", C.c_int64), ("n_points", C.c_int32), ("n_cand", C.c_int32),
+        ("cur_ts", C.c_int32), ("diff_travel_dist_local", C.c_float), ("resolution", C.c_float),
+        ("max_valid_dist2", C.c_float),
+    ]
+
+
+class Field(C.Structure):
+    _fields_ = [
+        ("feats", vp), ("certainty", vp), ("orient", vp), ("pos", vp), ("dec", vp),
+        ("k", C.c_int32), ("hidden", C.c_int32), ("levels", C.c_int32), ("weighted_first", C.c_int32),
+        ("sdf_scale", C.c_float),
+    ]
+
+
+class GnParams(C.Structure):
+    _fields_ = [
+        ("valid_nn_k", C.c_int32), ("min_grad_norm", C.c_float), ("max_grad_norm", C.c_float),
+        ("max_sdf_std", C.c_float), ("gm_dist", C.c_float), ("gm_grad", C.c_float),
+    ]
+
+
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+P = C.POINTER
+
+# name -> (restype, argtypes).  Every symbol declared in include/pin_abi.h is listed here;
+# tests/test_abi_symbols.py checks the header, this table and the built library agree.
+SIGNATURES = {
+    "pin_version": (i32, []),
+    "pin_last_error": (C.c_char_p, []),
+    "pin_candidate_offsets": (i32, [vp, i32, i64, vp]),
+    "pin_pack_positions": (i32, [vp, vp, i32, i32, vp, vp]),
+    "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),
+    "pin_knn_query": (i32, [P(SearchParams), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_query_feature": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
+    "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "pin_gn_accumulate": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m pin_slam_amd.build`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().pin_last_error()
+        raise RuntimeError(f"libpinhip {what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,71 @@
+// Shared device/host helpers for libpinhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pin_abi.h"
+
+namespace pin {
+
+// ---- error reporting ---------------------------------------------------------------
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+
+#define PIN_CHECK_ARG(cond, msg)                                     \
+    do {                                                             \
+        if (!(cond)) return ::pin::fail(-1, "%s: %s", __func__, msg); \
+    } while (0)
+
+#define PIN_CHECK_LAUNCH()                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return ::pin::fail(-2, "%s: %s", __func__, hipGetErrorString(e_)); \
+    } while (0)
+
+#define PIN_CHECK_HIP(expr)                                                             \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return ::pin::fail(-2, "%s: %s", __func__, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ----------------------------------------------------------------
+constexpr long long PRIME0 = 73856093LL, PRIME1 = 19349669LL, PRIME2 = 83492791LL;
+constexpr float IDW_EPS = 1e-15f;
+
+// Voxel coordinate of one axis: floor(p / res) in IEEE fp32 (true division, like the CPU
+// reference neural_points.py:963), as a 64-bit integer.
+__device__ __forceinline__ long long voxel_coord(float p, float res) {
+#pragma clang fp contract(off)
+    return (long long)floorf(__fdiv_rn(p, res));
+}
+
+// Mathematical (non-negative) modulus of the spatial hash = fmod + negative-index wrap of
+// the reference (neural_points.py:972-978).
+__device__ __forceinline__ uint32_t hash_base(float x, float y, float z, float res, long long B) {
+    long long h = voxel_coord(x, res) * PRIME0 + voxel_coord(y, res) * PRIME1 + voxel_coord(z, res) * PRIME2;
+    long long m = h % B;
+    if (m < 0) m += B;
+    return (uint32_t)m;
+}
+
+// (dx*dx + dy*dy) + dz*dz with one rounding per operation -- never contracted to FMA, so
+// the bits equal torch's CPU float32 result (neural_points.py:992-995).
+__device__ __forceinline__ float dist2_exact(float dx, float dy, float dz) {
+#pragma clang fp contract(off)  // hipcc defaults to -ffp-contract=fast; __fmul_rn alone does not stop fusion
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float xy = xx + yy;
+    return xy + zz;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace pin

@@ -1,0 +1,440 @@
+// Fused feature interpolation -> shallow-MLP SDF -> analytic Jacobian -> Gauss-Newton sums.
+//
+// Replaces (reference paths relative to PRBonn/PIN_SLAM):
+//   NeuralPoints.query_feature        model/neural_points.py:590-746   (gather, IDW, certainty)
+//   Decoder.sdf                       model/decoder.py:83-85
+//   get_gradient (autograd)           utils/tools.py:247-260 via utils/tracker.py:331
+//   Tracker.registration_step/implicit_reg  utils/tracker.py:409-524, 652-671
+//
+// One thread per query.  Input is the kNN record written by knn.hip (k x 16 B, coalesced
+// per thread), so the only random traffic here is the k feature rows (32 B each).
+#include "mlp.h"
+
+namespace pin {
+
+constexpr int SDF_BLOCK = 128;
+constexpr int GN_REPLICAS = 64;  // sums are scattered over 64 replicas to spread atomics
+
+struct Nbrs {
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];  // q - P (global position)
+    float u[PIN_MAX_K], w[PIN_MAX_K];
+    int idx[PIN_MAX_K];  // index into the field arrays, -1 invalid
+    bool quirk[PIN_MAX_K];
+    float S;
+    int nn;
+};
+
+__device__ __forceinline__ void load_neighbors(const float4* __restrict__ nbr, const int* __restrict__ nn_count,
+                                               int qi, int k, Nbrs& nb) {
+    nb.nn = nn_count[qi];
+    float S = 0.f;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t) {
+        nb.idx[t] = -1; nb.u[t] = 0.f; nb.w[t] = 0.f; nb.quirk[t] = false;
+        nb.vx[t] = nb.vy[t] = nb.vz[t] = 0.f;
+        if (t < k) {
+            const float4 e = nbr[(size_t)qi * k + t];
+            const int raw = __float_as_int(e.w);
+            if (raw >= 0) {
+                nb.idx[t] = raw & ~PIN_NBR_QUIRK_BIT;
+                nb.quirk[t] = (raw & PIN_NBR_QUIRK_BIT) != 0;
+                nb.vx[t] = e.x; nb.vy[t] = e.y; nb.vz[t] = e.z;
+                const float d2 = dist2_exact(e.x, e.y, e.z);
+                nb.u[t] = 1.0f / (d2 + IDW_EPS);  // neural_points.py:667
+            }
+            if (nb.nn == 0) nb.u[t] = IDW_EPS;  // neural_points.py:672-674
+            S += nb.u[t];
+        }
+    }
+    nb.S = S;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (t < k && nb.idx[t] >= 0) nb.w[t] = nb.u[t] / S;  // invalid keep 0 (neural_points.py:683)
+}
+
+// neighbour vector fed to the decoder: q - P[idx] (rotated into the point frame after PGO)
+__device__ __forceinline__ void neighbor_vector(const pin_field& f, int idx, bool quirk, float vgx, float vgy,
+                                                float vgz, float qx, float qy, float qz, float (&v)[3],
+                                                float (&Rm)[9]) {
+    v[0] = vgx; v[1] = vgy; v[2] = vgz;
+    if (quirk) {  // reference gathers local point #1 for non-local neighbours
+        const float* p = f.pos + 3 * (size_t)idx;
+        v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+    }
+    if (f.orient != nullptr) {  // apply_quaternion_rotation, utils/tools.py:428-437
+        const float4 q = reinterpret_cast<const float4*>(f.orient)[idx];
+        const float q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w;
+        Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[1] = 2 * (q1 * q2 - q0 * q3); Rm[2] = 2 * (q1 * q3 + q0 * q2);
+        Rm[3] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[5] = 2 * (q2 * q3 - q0 * q1);
+        Rm[6] = 2 * (q1 * q3 - q0 * q2); Rm[7] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+        const float x = v[0], y = v[1], z = v[2];
+        v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+        v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+        v[2] = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+    }
+}
+
+__device__ __forceinline__ void load_feature(const pin_field& f, int idx, float (&ft)[PIN_FEATURE_DIM]) {
+    const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)idx * PIN_FEATURE_DIM);
+    const float4 a = row[0], b = row[1];
+    ft[0] = a.x; ft[1] = a.y; ft[2] = a.z; ft[3] = a.w;
+    ft[4] = b.x; ft[5] = b.y; ft[6] = b.z; ft[7] = b.w;
+}
+
+struct SdfResult {
+    float sdf, gx, gy, gz, std, cert;
+};
+
+// The fused per-query evaluation shared by pin_sdf_query and pin_gn_accumulate.
+template <int H, bool WF, bool GRAD>
+__device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4* __restrict__ nbr,
+                                                const int* __restrict__ nn_count, int qi, float qx, float qy,
+                                                float qz, float* col) {
+    Nbrs nb;
+    load_neighbors(nbr, nn_count, qi, f.k, nb);
+    SdfResult r;
+    r.std = 0.f; r.gx = r.gy = r.gz = 0.f;
+    float cert = 0.f;
+    if (f.certainty != nullptr) {
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) cert = fmaf(f.certainty[nb.idx[t]], nb.w[t], cert);
+    }
+    r.cert = cert;
+    const float s = f.sdf_scale;
+    float Rm[9];
+    // G = sum_t d u_t / d q,  d u_t/d q = -2 u_t^2 (q - P_t)
+    float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
+    if (GRAD) {
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                const float c = -2.f * nb.u[t] * nb.u[t];
+                Gx = fmaf(c, nb.vx[t], Gx); Gy = fmaf(c, nb.vy[t], Gy); Gz = fmaf(c, nb.vz[t], Gz);
+                wsum += nb.w[t];
+            }
+    }
+    MlpMasks mk;
+    if (WF) {
+        float z[MLP_IN];
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                float ft[PIN_FEATURE_DIM], v[3];
+                load_feature(f, nb.idx[t], ft);
+                neighbor_vector(f, nb.idx[t], nb.quirk[t], nb.vx[t], nb.vy[t], nb.vz[t], qx, qy, qz, v, Rm);
+#pragma unroll
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = fmaf(nb.w[t], ft[j], z[j]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) z[PIN_FEATURE_DIM + j] = fmaf(nb.w[t], v[j], z[PIN_FEATURE_DIM + j]);
+            }
+        const float x = mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
+        r.sdf = s * x;
+        if (GRAD) {
+            float a[MLP_IN];
+            mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
+            float cbar = 0.f;
+#pragma unroll
+            for (int j = 0; j < MLP_IN; ++j) cbar = fmaf(a[j], z[j], cbar);  // = sum_t w_t c_t
+            float ax = 0.f, ay = 0.f, az = 0.f;  // sum_t c_t g_t   and the direct a_v term
+            float dxs = 0.f, dys = 0.f, dzs = 0.f;
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t)
+                if (nb.idx[t] >= 0) {
+                    float ft[PIN_FEATURE_DIM], v[3];
+                    load_feature(f, nb.idx[t], ft);
+                    neighbor_vector(f, nb.idx[t], nb.quirk[t], nb.vx[t], nb.vy[t], nb.vz[t], qx, qy, qz, v, Rm);
+                    float c = 0.f;
+#pragma unroll
+                    for (int j = 0; j < PIN_FEATURE_DIM; ++j) c = fmaf(a[j], ft[j], c);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) c = fmaf(a[PIN_FEATURE_DIM + j], v[j], c);
+                    const float cg = -2.f * nb.u[t] * nb.u[t] * c;
+                    ax = fmaf(cg, nb.vx[t], ax); ay = fmaf(cg, nb.vy[t], ay); az = fmaf(cg, nb.vz[t], az);
+                    if (f.orient != nullptr) {  // d v_t / d q = R_t  ->  R_t^T a_v
+                        dxs += nb.w[t] * (Rm[0] * a[8] + Rm[3] * a[9] + Rm[6] * a[10]);
+                        dys += nb.w[t] * (Rm[1] * a[8] + Rm[4] * a[9] + Rm[7] * a[10]);
+                        dzs += nb.w[t] * (Rm[2] * a[8] + Rm[5] * a[9] + Rm[8] * a[10]);
+                    }
+                }
+            if (f.orient == nullptr) { dxs = a[8] * wsum; dys = a[9] * wsum; dzs = a[10] * wsum; }
+            const float invS = 1.0f / nb.S;
+            r.gx = s * (dxs + (ax - cbar * Gx) * invS);
+            r.gy = s * (dys + (ay - cbar * Gy) * invS);
+            r.gz = s * (dzs + (az - cbar * Gz) * invS);
+        }
+    } else {
+        // decode every neighbour, then weight (weighted_first = False, run_kitti.yaml:25)
+        float sk[PIN_MAX_K];
+        float mean = 0.f, dxs = 0.f, dys = 0.f, dzs = 0.f;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < f.k; ++t) {
+            // static-index copies of neighbour t
+            int idx = -1; float wt = 0.f, ut = 0.f, vgx = 0.f, vgy = 0.f, vgz = 0.f;
+#pragma unroll
+            for (int u = 0; u < PIN_MAX_K; ++u)
+                if (u == t) { idx = nb.idx[u]; wt = nb.w[u]; ut = nb.u[u]; vgx = nb.vx[u]; vgy = nb.vy[u]; vgz = nb.vz[u]; }
+            float st = 0.f;
+            if (idx >= 0) {  // invalid neighbours carry zero weight: their decode is never used
+                float z[MLP_IN], ft[PIN_FEATURE_DIM], v[3];
+                load_feature(f, idx, ft);
+                bool qk = false;
+#pragma unroll
+                for (int u = 0; u < PIN_MAX_K; ++u) if (u == t) qk = nb.quirk[u];
+                neighbor_vector(f, idx, qk, vgx, vgy, vgz, qx, qy, qz, v, Rm);
+#pragma unroll
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = ft[j];
+                z[8] = v[0]; z[9] = v[1]; z[10] = v[2];
+                st = s * mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
+                mean = fmaf(wt, st, mean);
+                if (GRAD) {
+                    float a[MLP_IN];
+                    mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
+                    if (f.orient != nullptr) {
+                        dxs += wt * (Rm[0] * a[8] + Rm[3] * a[9] + Rm[6] * a[10]);
+                        dys += wt * (Rm[1] * a[8] + Rm[4] * a[9] + Rm[7] * a[10]);
+                        dzs += wt * (Rm[2] * a[8] + Rm[5] * a[9] + Rm[8] * a[10]);
+                    } else {
+                        dxs = fmaf(wt, a[8], dxs); dys = fmaf(wt, a[9], dys); dzs = fmaf(wt, a[10], dzs);
+                    }
+                    const float cg = -2.f * ut * ut * st;
+                    ax = fmaf(cg, vgx, ax); ay = fmaf(cg, vgy, ay); az = fmaf(cg, vgz, az);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PIN_MAX_K; ++u) if (u == t) sk[u] = st;
+        }
+        r.sdf = mean;
+        float var = 0.f;
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (t < f.k && nb.idx[t] >= 0) { const float d = sk[t] - mean; var = fmaf(nb.w[t], d * d, var); }
+        r.std = sqrtf(var);  // tracker.py:317-322
+        if (GRAD) {
+            const float invS = 1.0f / nb.S;
+            r.gx = s * dxs + (ax - mean * Gx) * invS;
+            r.gy = s * dys + (ay - mean * Gy) * invS;
+            r.gz = s * dzs + (az - mean * Gz) * invS;
+        }
+    }
+    return r;
+}
+
+template <int H, bool WF>
+__global__ __launch_bounds__(SDF_BLOCK) void sdf_query_kernel(pin_field f, const float* __restrict__ query,
+                                                              const float4* __restrict__ nbr,
+                                                              const int* __restrict__ nn_count, int n,
+                                                              float* __restrict__ sdf_out, float* __restrict__ grad_out,
+                                                              float* __restrict__ std_out, float* __restrict__ cert_out) {
+    __shared__ float lds[H * SDF_BLOCK];
+    const int qi = blockIdx.x * SDF_BLOCK + threadIdx.x;
+    if (qi >= n) return;
+    const float qx = query[3 * qi], qy = query[3 * qi + 1], qz = query[3 * qi + 2];
+    SdfResult r;
+    if (grad_out != nullptr) r = eval_query<H, WF, true>(f, nbr, nn_count, qi, qx, qy, qz, lds + threadIdx.x);
+    else r = eval_query<H, WF, false>(f, nbr, nn_count, qi, qx, qy, qz, lds + threadIdx.x);
+    if (sdf_out) sdf_out[qi] = r.sdf;
+    if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
+    if (std_out) std_out[qi] = r.std;
+    if (cert_out) cert_out[qi] = r.cert;
+}
+
+template <int H, bool WF>
+__global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, pin_gn_params gp,
+                                                                  const float* __restrict__ query,
+                                                                  const float4* __restrict__ nbr,
+                                                                  const int* __restrict__ nn_count,
+                                                                  const float* __restrict__ labels, int n,
+                                                                  double* __restrict__ sums, float* __restrict__ sdf_out,
+                                                                  float* __restrict__ grad_out) {
+    __shared__ float lds[H * SDF_BLOCK];
+    const int qi = blockIdx.x * SDF_BLOCK + threadIdx.x;
+    float v[PIN_GN_NSUMS];
+#pragma unroll
+    for (int i = 0; i < PIN_GN_NSUMS; ++i) v[i] = 0.f;
+    if (qi < n) {
+        const float px = query[3 * qi], py = query[3 * qi + 1], pz = query[3 * qi + 2];
+        const SdfResult r = eval_query<H, WF, true>(f, nbr, nn_count, qi, px, py, pz, lds + threadIdx.x);
+        if (sdf_out) sdf_out[qi] = r.sdf;
+        if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
+        const float gn = sqrtf(r.gx * r.gx + r.gy * r.gy + r.gz * r.gz);
+        const bool valid = nn_count[qi] >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm &&
+                           r.std < gp.max_sdf_std;  // tracker.py:419-425
+        if (valid) {
+            const float res = r.sdf - (labels ? labels[qi] : 0.f);
+            float w = 1.f;
+            if (gp.gm_grad > 0.f) { const float a = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + a * a); w *= t * t; }
+            if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); w *= t * t; }
+            float J[6];  // [p x g, g]  (tracker.py:652-655)
+            J[0] = py * r.gz - pz * r.gy; J[1] = pz * r.gx - px * r.gz; J[2] = px * r.gy - py * r.gx;
+            J[3] = r.gx; J[4] = r.gy; J[5] = r.gz;
+            int o = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) v[o++] = w * J[a] * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[21 + a] = w * J[a] * res;
+            v[27] = w; v[28] = fabsf(res); v[29] = 1.f; v[30] = w * res * res;
+        }
+    }
+    double* dst = sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const double t = wave_sum((double)v[i]);
+        if (lane == 0 && t != 0.0) atomicAdd(dst + i, t);
+    }
+}
+
+// ---- tensor-API kernels (Mesher / drop-in query_feature, Decoder.sdf) --------------------
+__global__ __launch_bounds__(256) void query_feature_kernel(pin_field f, const float* __restrict__ query,
+                                                            const float4* __restrict__ nbr,
+                                                            const int* __restrict__ nn_count, int n,
+                                                            float* __restrict__ feat_out, float* __restrict__ weight_out,
+                                                            float* __restrict__ cert_out, int training,
+                                                            float* __restrict__ cert_rw, int* __restrict__ ts_rw,
+                                                            const int* __restrict__ query_ts) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= n) return;
+    Nbrs nb;
+    load_neighbors(nbr, nn_count, qi, f.k, nb);
+    float z[MLP_IN], Rm[9];
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+    float cert = 0.f;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t) {
+        if (t >= f.k) continue;
+        float ft[PIN_FEATURE_DIM] = {0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+        if (nb.idx[t] >= 0) {
+            load_feature(f, nb.idx[t], ft);
+            neighbor_vector(f, nb.idx[t], nb.quirk[t], nb.vx[t], nb.vy[t], nb.vz[t], query[3 * qi], query[3 * qi + 1],
+                            query[3 * qi + 2], v, Rm);
+            if (f.certainty) cert = fmaf(f.certainty[nb.idx[t]], nb.w[t], cert);  // pre-scatter values
+        }
+        if (f.weighted_first) {
+#pragma unroll
+            for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = fmaf(nb.w[t], ft[j], z[j]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) z[8 + j] = fmaf(nb.w[t], v[j], z[8 + j]);
+        } else {
+            float* o = feat_out + ((size_t)qi * f.k + t) * MLP_IN;
+#pragma unroll
+            for (int j = 0; j < PIN_FEATURE_DIM; ++j) o[j] = ft[j];
+            o[8] = v[0]; o[9] = v[1]; o[10] = v[2];
+        }
+        weight_out[(size_t)qi * f.k + t] = nb.w[t];
+    }
+    if (f.weighted_first) {
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) feat_out[(size_t)qi * MLP_IN + j] = z[j];
+    }
+    if (cert_out) cert_out[qi] = cert;
+    if (training) {  // neural_points.py:685-710
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                if (ts_rw && query_ts) atomicMax(ts_rw + nb.idx[t], query_ts[qi]);
+            }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(SDF_BLOCK) void decoder_sdf_kernel(pin_field f, const float* __restrict__ feat, int n,
+                                                                float* __restrict__ out) {
+    __shared__ float lds[H * SDF_BLOCK];
+    const int i = blockIdx.x * SDF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float z[MLP_IN];
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) z[j] = feat[(size_t)i * MLP_IN + j];
+    MlpMasks mk;
+    out[i] = f.sdf_scale * mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, lds + threadIdx.x, mk);
+}
+
+static int check_field(const pin_field* f) {
+    PIN_CHECK_ARG(f != nullptr, "field NULL");
+    PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
+    PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
+    PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
+    PIN_CHECK_ARG(f->dec != nullptr, "decoder parameters NULL");
+    return 0;
+}
+
+}  // namespace pin
+
+using namespace pin;
+
+#define PIN_DISPATCH_HW(f, KERNEL, ...)                                                      \
+    do {                                                                                     \
+        if ((f)->hidden == 64) {                                                             \
+            if ((f)->weighted_first) hipLaunchKernelGGL((KERNEL<64, true>), __VA_ARGS__);    \
+            else hipLaunchKernelGGL((KERNEL<64, false>), __VA_ARGS__);                       \
+        } else {                                                                             \
+            if ((f)->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), __VA_ARGS__);    \
+            else hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);                       \
+        }                                                                                    \
+    } while (0)
+
+extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count,
+                             int32_t n, float* sdf_out, float* grad_out, float* std_out, float* certainty_out,
+                             void* stream) {
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
+    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
+    PIN_DISPATCH_HW(f, sdf_query_kernel, grid, block, 0, as_stream(stream), *f, query,
+                    reinterpret_cast<const float4*>(nbr), nn_count, n, sdf_out, grad_out, std_out, certainty_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* query, const float* nbr,
+                                 const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums_out,
+                                 float* sdf_out, float* grad_out, void* stream) {
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(gp && sums_out, "NULL pointer");
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    hipStream_t s = as_stream(stream);
+    PIN_CHECK_HIP(hipMemsetAsync(sums_out, 0, sizeof(double) * PIN_GN_NSUMS * GN_REPLICAS, s));
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
+    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
+    PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, query, reinterpret_cast<const float4*>(nbr),
+                    nn_count, sdf_labels, n, sums_out, sdf_out, grad_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_query_feature(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count, int32_t n,
+                                 float* feat_out, float* weight_out, float* certainty_out, int32_t training,
+                                 float* certainty_rw, int32_t* ts_update_rw, const int32_t* query_ts, void* stream) {
+    PIN_CHECK_ARG(f != nullptr && f->k >= 1 && f->k <= PIN_MAX_K, "bad field");
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr && nn_count && feat_out && weight_out && f->feats, "NULL pointer");
+    PIN_CHECK_ARG(!training || certainty_rw, "training mode needs certainty_rw");
+    hipLaunchKernelGGL(query_feature_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), *f, query,
+                       reinterpret_cast<const float4*>(nbr), nn_count, n, feat_out, weight_out, certainty_out, training,
+                       certainty_rw, ts_update_rw, query_ts);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_decoder_sdf(const pin_field* f, const float* feat_in, int32_t n, float* sdf_out, void* stream) {
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(feat_in && sdf_out, "NULL pointer");
+    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
+    if (f->hidden == 64) hipLaunchKernelGGL(decoder_sdf_kernel<64>, grid, block, 0, as_stream(stream), *f, feat_in, n, sdf_out);
+    else hipLaunchKernelGGL(decoder_sdf_kernel<32>, grid, block, 0, as_stream(stream), *f, feat_in, n, sdf_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C ABI.  torch tensors are device-memory owners only: every
+function passes raw pointers + sizes to libpinhip on the current HIP stream; no torch op runs
+on the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (PIN_GN_NSUMS, PIN_GN_REPLICAS, PIN_MAX_K, PIN_MLP_IN, PIN_NONLOCAL, Field,
+                   GnParams, SearchParams, check)
+
+PRIMES = (73856093, 19349669, 83492791)
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libpinhip needs device (HIP) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def search_neighborhood(num_nei_cells: int, search_alpha: float, resolution: float):
+    """neighbor_dx [Kc,3] (meshgrid 'ij', x slowest) and max_valid_dist2
+    (NeuralPoints.set_search_neighborhood, model/neural_points.py:910-948)."""
+    n = int(num_nei_cells)
+    r = np.arange(-n, n + 1, dtype=np.int64)
+    g = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1).reshape(-1, 3)
+    dx = np.ascontiguousarray(g[(g ** 2).sum(-1) < (n + search_alpha) ** 2]).astype(np.int32)
+    return dx, 3 * ((n + 1) * resolution) ** 2
+
+
+def candidate_offsets(neighbor_dx: np.ndarray, buffer_size: int) -> np.ndarray:
+    dx = np.ascontiguousarray(neighbor_dx, dtype=np.int32)
+    out = np.empty(dx.shape[0], np.int32)
+    check(_lib.lib().pin_candidate_offsets(dx.ctypes.data, dx.shape[0], int(buffer_size), out.ctypes.data),
+          "pin_candidate_offsets")
+    return out
+
+
+def pack_positions(pos: torch.Tensor, ts_create: torch.Tensor, pos4: torch.Tensor, first: int = 0, n: int = None):
+    n = pos.shape[0] - first if n is None else n
+    check(_lib.lib().pin_pack_positions(_ptr(pos, torch.float32), _ptr(ts_create, torch.int32), first, n,
+                                        _ptr(pos4, torch.float32), _stream()), "pin_pack_positions")
+    return pos4
+
+
+@dataclass
+class SearchState:
+    """Device-side search state of a NeuralPoints map (see pin_search_params in pin_abi.h)."""
+    table: torch.Tensor            # [B] int32
+    pos4: torch.Tensor             # [P,4] f32 (xyz + ts_create bits)
+    cand_off: torch.Tensor         # [Kc] int32
+    n_points: int
+    resolution: float
+    max_valid_dist2: float
+    travel_dist: Optional[torch.Tensor] = None   # [n_ts] f32, None = no time filter
+    cur_ts: int = 0
+    diff_travel_dist_local: float = 0.0
+    global2local: Optional[torch.Tensor] = None  # [P+1] int32 with PIN_NONLOCAL, None = global query
+
+    def params(self, time_filtering=True, local=True) -> SearchParams:
+        sp = SearchParams()
+        sp.table = _ptr(self.table, torch.int32)
+        sp.pos4 = _ptr(self.pos4, torch.float32)
+        sp.cand_off = _ptr(self.cand_off, torch.int32)
+        sp.travel_dist = _ptr(self.travel_dist, torch.float32) if time_filtering else None
+        sp.global2local = _ptr(self.global2local, torch.int32) if local else None
+        sp.buffer_size = self.table.shape[0]
+        sp.n_points = int(self.n_points)
+        sp.n_cand = self.cand_off.shape[0]
+        sp.cur_ts = int(self.cur_ts)
+        sp.diff_travel_dist_local = float(self.diff_travel_dist_local)
+        sp.resolution = float(np.float32(self.resolution))
+        sp.max_valid_dist2 = float(np.float32(self.max_valid_dist2))
+        return sp
+
+
+def radius_search(st: SearchState, query: torch.Tensor, time_filtering: bool = False):
+    """NeuralPoints.radius_neighborhood_search -> (dist2 [N,Kc] f32, idx [N,Kc] int64)."""
+    n, kc = query.shape[0], st.cand_off.shape[0]
+    d2 = torch.empty((n, kc), dtype=torch.float32, device=query.device)
+    idx = torch.empty((n, kc), dtype=torch.int64, device=query.device)
+    sp = st.params(time_filtering=time_filtering, local=False)
+    check(_lib.lib().pin_radius_search(C.byref(sp), _ptr(query, torch.float32), n, _ptr(d2), _ptr(idx), _stream()),
+          "pin_radius_search")
+    return d2, idx
+
+
+def knn_query(st: SearchState, query: torch.Tensor, k: int, time_filtering=True, local=True,
+              pose: Optional[np.ndarray] = None, out=None):
+    """k nearest valid candidates -> (nbr [N,k,4] f32, nn_count [N] int32, query_used [N,3]).
+    ``pose`` (4x4 or 3x4, host) is applied to the query points inside the kernel."""
+    n = query.shape[0]
+    dev = query.device
+    if out is None:
+        nbr = torch.empty((n, k, 4), dtype=torch.float32, device=dev)
+        nn = torch.empty((n,), dtype=torch.int32, device=dev)
+        qout = torch.empty((n, 3), dtype=torch.float32, device=dev) if pose is not None else None
+    else:
+        nbr, nn, qout = out
+    sp = st.params(time_filtering=time_filtering, local=local)
+    pose_p = None
+    if pose is not None:
+        pose32 = np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4].astype(np.float32))
+        pose_p = pose32.ctypes.data
+    check(_lib.lib().pin_knn_query(C.byref(sp), _ptr(query, torch.float32), n, k, pose_p, _ptr(qout), _ptr(nbr),
+                                   _ptr(nn), _stream()), "pin_knn_query")
+    return nbr, nn, (qout if pose is not None else query)
+
+
+@dataclass
+class FieldState:
+    """Feature tables + decoder of the searched index space (pin_field in pin_abi.h)."""
+    feats: torch.Tensor                 # [M+1, 8]
+    dec: torch.Tensor                   # flat decoder parameters
+    k: int
+    hidden: int
+    levels: int
+    weighted_first: bool
+    sdf_scale: float
+    certainty: Optional[torch.Tensor] = None
+    orient: Optional[torch.Tensor] = None   # only after PGO
+    pos: Optional[torch.Tensor] = None      # [M,3]
+
+    def params(self) -> Field:
+        f = Field()
+        f.feats = _ptr(self.feats, torch.float32)
+        f.certainty = _ptr(self.certainty, torch.float32)
+        f.orient = _ptr(self.orient, torch.float32)
+        f.pos = _ptr(self.pos, torch.float32)
+        f.dec = _ptr(self.dec, torch.float32)
+        f.k, f.hidden, f.levels = int(self.k), int(self.hidden), int(self.levels)
+        f.weighted_first = int(bool(self.weighted_first))
+        f.sdf_scale = float(self.sdf_scale)
+        return f
+
+
+def query_feature(fs: FieldState, query, nbr, nn, training=False, certainty_rw=None, ts_update_rw=None,
+                  query_ts=None):
+    """NeuralPoints.query_feature outputs from a kNN record: (feat, weight [N,k], certainty [N])."""
+    n = query.shape[0]
+    dev = query.device
+    shape = (n, PIN_MLP_IN) if fs.weighted_first else (n, fs.k, PIN_MLP_IN)
+    feat = torch.empty(shape, dtype=torch.float32, device=dev)
+    w = torch.empty((n, fs.k), dtype=torch.float32, device=dev)
+    cert = torch.empty((n,), dtype=torch.float32, device=dev)
+    f = fs.params()
+    check(_lib.lib().pin_query_feature(C.byref(f), _ptr(query, torch.float32), _ptr(nbr), _ptr(nn, torch.int32), n,
+                                       _ptr(feat), _ptr(w), _ptr(cert), int(training), _ptr(certainty_rw),
+                                       _ptr(ts_update_rw), _ptr(query_ts), _stream()), "pin_query_feature")
+    return feat, w, cert
+
+
+def decoder_sdf(fs: FieldState, feat: torch.Tensor):
+    """Decoder.sdf on [n, 11] features."""
+    n = feat.shape[0]
+    out = torch.empty((n,), dtype=torch.float32, device=feat.device)
+    f = fs.params()
+    check(_lib.lib().pin_decoder_sdf(C.byref(f), _ptr(feat, torch.float32), n, _ptr(out), _stream()), "pin_decoder_sdf")
+    return out
+
+
+def sdf_query(fs: FieldState, query, nbr, nn, grad=True, std=True, certainty=True):
+    """Fused interpolate + decode + analytic gradient: (sdf, grad, std, certainty)."""
+    n = query.shape[0]
+    dev = query.device
+    sdf = torch.empty((n,), dtype=torch.float32, device=dev)
+    g = torch.empty((n, 3), dtype=torch.float32, device=dev) if grad else None
+    sd = torch.empty((n,), dtype=torch.float32, device=dev) if std else None
+    ce = torch.empty((n,), dtype=torch.float32, device=dev) if (certainty and fs.certainty is not None) else None
+    f = fs.params()
+    check(_lib.lib().pin_sdf_query(C.byref(f), _ptr(query, torch.float32), _ptr(nbr), _ptr(nn, torch.int32), n,
+                                   _ptr(sdf), _ptr(g), _ptr(sd), _ptr(ce), _stream()), "pin_sdf_query")
+    return sdf, g, sd, ce
+
+
+def gn_accumulate(fs: FieldState, gp: GnParams, query, nbr, nn, sdf_labels=None, sums=None, want_points=False):
+    """Fused SDF + Jacobian + Gauss-Newton sums.  Returns the [64, 32] double replica buffer
+    (sum over dim 0 on the host) and optionally per-point (sdf, grad)."""
+    n = query.shape[0]
+    dev = query.device
+    if sums is None:
+        sums = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64, device=dev)
+    sdf = torch.empty((n,), dtype=torch.float32, device=dev) if want_points else None
+    g = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_points else None
+    f = fs.params()
+    check(_lib.lib().pin_gn_accumulate(C.byref(f), C.byref(gp), _ptr(query, torch.float32), _ptr(nbr),
+                                       _ptr(nn, torch.int32), _ptr(sdf_labels), n, _ptr(sums), _ptr(sdf), _ptr(g),
+                                       _stream()), "pin_gn_accumulate")
+    return sums, sdf, g
+
+
+def solve_gn(sums: np.ndarray, lm_lambda: float):
+    """Host side of implicit_reg (utils/tracker.py:656-679): normalise the weights
+    (w /= 2*mean(w), tracker.py:524), LM damping, 6x6 solve in float64, expmap."""
+    s = np.asarray(sums, np.float64).reshape(-1, PIN_GN_NSUMS).sum(0)
+    cnt = int(round(s[29]))
+    if cnt < 10:  # tracker.py:430-432
+        return np.eye(4), cnt, 0.0, None
+    scale = cnt / (2.0 * s[27])
+    N = np.zeros((6, 6))
+    iu = np.triu_indices(6)
+    N[iu] = s[:21]
+    N = N + N.T - np.diag(np.diag(N))
+    N *= scale
+    g = -scale * s[21:27]
+    N_raw = N.copy()
+    N = N + lm_lambda * np.diag(np.diag(N))
+    t = np.linalg.solve(N, g)
+    T = np.eye(4)
+    ang = np.linalg.norm(t[:3])
+    ax = t[:3] / ang
+    S = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    T[:3, :3] = np.eye(3) + S * np.sin(ang) + (S @ S) * (1.0 - np.cos(ang))
+    T[:3, 3] = t[3:]
+    return T, cnt, float(s[28] / cnt * 100.0), dict(N_raw=N_raw, mse=scale * s[30] / cnt)
