@@ -95,6 +95,18 @@ typedef struct pin_gn_params {
  * [30] sum w r^2; [31] reserved.  w is the un-normalised robust weight; the host applies
  * the reference's w /= 2*mean(w) (tracker.py:524) as one scalar. */
 
+/* ---- map training (Mapper.mapping loop body, utils/mapper.py:645-818) ------------ */
+typedef struct pin_train_params {
+    int32_t n_main;          /* batch size bs (config.bs) */
+    int32_t n_eik;           /* ceil(bs / gradient_decimation) Eikonal samples, 0 = Eikonal off */
+    int32_t loss_weight_on;  /* config.loss_weight_on */
+    float sigma;             /* BCE sigmoid scale = Mapper.sdf_scale (mapper.py:66) */
+    float weight_e;          /* config.weight_e */
+    float eik_eps;           /* voxel_size_m * num_grad_step_ratio (mapper.py:685) */
+    float inv_n_main;        /* 1 / GLOBAL batch size  (the loss means; sharded batches pass */
+    float inv_n_eik;         /* 1 / GLOBAL Eikonal count  the global counts)      */
+} pin_train_params;
+
 /* ---- library ------------------------------------------------------------------- */
 int         pin_version(void);
 const char* pin_last_error(void);
@@ -154,6 +166,37 @@ int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* 
                       const float* nbr, const int32_t* nn_count, const float* sdf_labels,
                       int32_t n, double* sums_out, float* sdf_out, float* grad_out,
                       void* stream);
+
+/* K6a: query points of one training iteration: the batch itself followed by the six
+ * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
+ * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with
+ * a = x+, x-, y+, y-, z+, z- (the reference concatenates per axis; results are per-point
+ * so the order is immaterial).  query_out: [n_main + 6*n_eik][3]. */
+int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
+                           float eps, float* query_out, void* stream);
+
+int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels);
+
+/* K6: fused forward -> BCE-with-logits (utils/loss.py:45-63) + Eikonal (mapper.py:777-780)
+ * -> backward over the queries produced by pin_train_make_queries and searched with
+ * pin_knn_query.  Accumulates (+=, float atomics): feat_grad [M+1][8] (gradient of
+ * local_geo_features), dec_grad [n_param] (flat, state_dict order; NULL = decoder frozen,
+ * utils/tools.py:263-292).  Applies the training-mode side effects of query_feature for the
+ * batch samples (certainty_rw += w, ts_update_rw = max(., sample_ts); neural_points.py:685-710).
+ * loss_out: double[2] = (sum of BCE terms, sum of (|g|-1)^2) -- divide by the global counts.
+ * pred_out (optional): sdf prediction of the batch samples [n_main]. */
+int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query,
+                   const float* nbr, const int32_t* nn_count, const float* sdf_label,
+                   const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,
+                   int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
+                   float* pred_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* K7: torch.optim.Adam step (no amsgrad, no weight decay) as configured by setup_optimizer
+ * (utils/tools.py:198-199): betas (0.9, 0.99), eps = adam_eps.  `step` counts from 1.
+ * zero_grad != 0 clears grad in the same pass. */
+int pin_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  int32_t step, float lr, float beta1, float beta2, float eps,
+                  int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,14 @@ class GnParams(C.Structure):
     ]
 
 
+class TrainParams(C.Structure):
+    _fields_ = [
+        ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
+        ("sigma", C.c_float), ("weight_e", C.c_float), ("eik_eps", C.c_float),
+        ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float),
+    ]
+
+
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
 P = C.POINTER
 
@@ -63,6 +71,10 @@ SIGNATURES = {
     "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_gn_accumulate": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pin_train_make_queries": (i32, [vp, i32, i32, i32, f32, vp, vp]),
+    "pin_train_workspace_bytes": (i64, [i32, i32, i32]),
+    "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
 }
 
 _lib = None

@@ -1,0 +1,442 @@
+// Map-training step of Mapper.mapping (utils/mapper.py:645-818) on gfx950:
+//   forward (interpolate + decode) over the batch and its 6*n_e central-difference queries
+//   (get_numerical_gradient, mapper.py:986-1036), BCE-with-logits + Eikonal loss
+//   (utils/loss.py:45-63, mapper.py:732-780), backward to neural-point features (atomic
+//   scatter) and decoder parameters, and Adam (utils/tools.py:198-199).
+//
+// Structure (one C-ABI call = one stream-ordered sequence of launches):
+//   make_queries -> [pin_knn_query by the caller] -> train_fwd -> train_loss -> train_bwd
+//   -> train_dw (one launch per decoder layer, fp32 MFMA 16x16x4 over the batch dimension).
+// Activations and layer deltas go through a caller-provided workspace laid out unit-major
+// ([row][Q], query contiguous) so that thread-per-query kernels write coalesced and the
+// weight-gradient GEMM reads K-contiguous operands.  At the batch sizes of the reference
+// (16k samples + 10k Eikonal queries) the workspace stays in L2 / Infinity Cache.
+#include "mlp.h"
+
+namespace pin {
+
+constexpr int TR_BLOCK = 128;
+
+struct TrainWs {
+    float* z;      // [12][Qs]  interpolated decoder input (row 11 unused)
+    float* h;      // [L*H][Qs] post-ReLU activations
+    float* d;      // [L*H + 1][Qs] deltas; last row = d loss / d mlp_out
+    float* pred;   // [Qs]
+    float* dpred;  // [Qs]
+    int Qs;        // padded query count (multiple of 64)
+};
+
+__host__ __device__ inline size_t train_ws_floats(int Q, int H, int L) {
+    const size_t Qs = (size_t)((Q + 63) / 64) * 64;
+    return Qs * (12 + (size_t)L * H + (size_t)L * H + 1 + 2);
+}
+
+__global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, float eps,
+                                    float* __restrict__ q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = n_main + 6 * n_eik;
+    if (i >= total) return;
+    if (i < n_main) {
+        q[3 * i] = coord[3 * i]; q[3 * i + 1] = coord[3 * i + 1]; q[3 * i + 2] = coord[3 * i + 2];
+        return;
+    }
+    const int e = i - n_main, s = e / 6, a = e - 6 * s;
+    const int src = s * dec;  // coord[::dec]
+    float x = coord[3 * src], y = coord[3 * src + 1], z = coord[3 * src + 2];
+    const float d = (a & 1) ? -eps : eps;  // order x+, x-, y+, y-, z+, z-
+    if ((a >> 1) == 0) x += d; else if ((a >> 1) == 1) y += d; else z += d;
+    q[3 * i] = x; q[3 * i + 1] = y; q[3 * i + 2] = z;
+}
+
+// ---- forward -----------------------------------------------------------------------------
+struct NbrW {
+    float w[PIN_MAX_K];
+    int idx[PIN_MAX_K];
+};
+
+// weights only (no gradient terms), same arithmetic as sdf.hip load_neighbors
+__device__ __forceinline__ void neighbor_weights(const float4* __restrict__ nbr, int nn, int qi, int k, NbrW& nb,
+                                                 float (&vx)[PIN_MAX_K], float (&vy)[PIN_MAX_K],
+                                                 float (&vz)[PIN_MAX_K], bool (&quirk)[PIN_MAX_K]) {
+    float u[PIN_MAX_K];
+    float S = 0.f;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t) {
+        nb.idx[t] = -1; nb.w[t] = 0.f; u[t] = 0.f; quirk[t] = false; vx[t] = vy[t] = vz[t] = 0.f;
+        if (t < k) {
+            const float4 e = nbr[(size_t)qi * k + t];
+            const int raw = __float_as_int(e.w);
+            if (raw >= 0) {
+                nb.idx[t] = raw & ~PIN_NBR_QUIRK_BIT;
+                quirk[t] = (raw & PIN_NBR_QUIRK_BIT) != 0;
+                vx[t] = e.x; vy[t] = e.y; vz[t] = e.z;
+                u[t] = 1.0f / (dist2_exact(e.x, e.y, e.z) + IDW_EPS);
+            }
+            if (nn == 0) u[t] = IDW_EPS;
+            S += u[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (t < k && nb.idx[t] >= 0) nb.w[t] = u[t] / S;
+}
+
+template <int H>
+__global__ __launch_bounds__(TR_BLOCK) void train_fwd_kernel(pin_field f, const float* __restrict__ query,
+                                                             const float4* __restrict__ nbr,
+                                                             const int* __restrict__ nn_count, int Q, int n_main,
+                                                             TrainWs ws, float* __restrict__ cert_rw,
+                                                             int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
+    __shared__ float lds[H * TR_BLOCK];
+    const int qi = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (qi >= Q) return;
+    float* col = lds + threadIdx.x;
+    NbrW nb;
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+    bool quirk[PIN_MAX_K];
+    neighbor_weights(nbr, nn_count[qi], qi, f.k, nb, vx, vy, vz, quirk);
+    const float qx = query[3 * qi], qy = query[3 * qi + 1], qz = query[3 * qi + 2];
+    float z[MLP_IN], Rm[9];
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (nb.idx[t] >= 0) {
+            const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM);
+            const float4 a = row[0], b = row[1];
+            float v[3] = {vx[t], vy[t], vz[t]};
+            if (quirk[t]) {
+                const float* p = f.pos + 3 * (size_t)nb.idx[t];
+                v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+            }
+            if (f.orient != nullptr) {
+                const float4 q4 = reinterpret_cast<const float4*>(f.orient)[nb.idx[t]];
+                const float q0 = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
+                Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[1] = 2 * (q1 * q2 - q0 * q3); Rm[2] = 2 * (q1 * q3 + q0 * q2);
+                Rm[3] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[5] = 2 * (q2 * q3 - q0 * q1);
+                Rm[6] = 2 * (q1 * q3 - q0 * q2); Rm[7] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+                const float x = v[0], y = v[1], zz = v[2];
+                v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * zz;
+                v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * zz;
+                v[2] = Rm[6] * x + Rm[7] * y + Rm[8] * zz;
+            }
+            const float w = nb.w[t];
+            z[0] = fmaf(w, a.x, z[0]); z[1] = fmaf(w, a.y, z[1]); z[2] = fmaf(w, a.z, z[2]); z[3] = fmaf(w, a.w, z[3]);
+            z[4] = fmaf(w, b.x, z[4]); z[5] = fmaf(w, b.y, z[5]); z[6] = fmaf(w, b.z, z[6]); z[7] = fmaf(w, b.w, z[7]);
+            z[8] = fmaf(w, v[0], z[8]); z[9] = fmaf(w, v[1], z[9]); z[10] = fmaf(w, v[2], z[10]);
+        }
+    const int Qs = ws.Qs;
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * Qs + qi] = z[j];
+    ws.z[(size_t)11 * Qs + qi] = 0.f;
+
+    // decoder forward, activations streamed to the workspace (unit-major)
+    cfloatp P = as_const(f.dec);
+    const int L = f.levels;
+    {
+        cfloatp W = P;
+        cfloatp b = P + H * MLP_IN;
+        for (int i = 0; i < H; ++i) {
+            float acc = b[i];
+#pragma unroll
+            for (int j = 0; j < MLP_IN; ++j) acc = fmaf(W[i * MLP_IN + j], z[j], acc);
+            acc = fmaxf(acc, 0.f);
+            col[i * TR_BLOCK] = acc;
+            ws.h[(size_t)i * Qs + qi] = acc;
+        }
+        P += H * MLP_IN + H;
+    }
+    float h[H];
+    for (int l = 1; l < L; ++l) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) h[j] = col[j * TR_BLOCK];
+        cfloatp W = P;
+        cfloatp b = P + H * H;
+        for (int i = 0; i < H; ++i) {
+            float acc = b[i];
+#pragma unroll
+            for (int j = 0; j < H; ++j) acc = fmaf(W[i * H + j], h[j], acc);
+            acc = fmaxf(acc, 0.f);
+            col[i * TR_BLOCK] = acc;
+            ws.h[((size_t)l * H + i) * Qs + qi] = acc;
+        }
+        P += H * H + H;
+    }
+    float out = P[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) out = fmaf(P[j], col[j * TR_BLOCK], out);
+    ws.pred[qi] = f.sdf_scale * out;
+
+    // training-mode side effects of query_feature for the batch samples (neural_points.py:685-710);
+    // the central-difference queries run with training_mode=False (mapper.py:941)
+    if (qi < n_main && cert_rw != nullptr) {
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
+            }
+    }
+}
+
+// ---- loss --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void train_loss_kernel(pin_train_params tp, const float* __restrict__ label,
+                                                         const float* __restrict__ weight, TrainWs ws,
+                                                         double* __restrict__ loss_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double l_bce = 0.0, l_eik = 0.0;
+    if (i < tp.n_main) {
+        const float xl = ws.pred[i] / tp.sigma;
+        const float y = 1.f / (1.f + expf(-label[i] / tp.sigma));
+        float l = fmaxf(xl, 0.f) - xl * y + log1pf(expf(-fabsf(xl)));
+        float g = 1.f / (1.f + expf(-xl)) - y;
+        if (tp.loss_weight_on) { const float w = fabsf(weight[i]); l *= w; g *= w; }
+        ws.dpred[i] = g * tp.inv_n_main / tp.sigma;
+        l_bce = (double)l;
+    } else if (i < tp.n_main + tp.n_eik) {
+        const int s = i - tp.n_main;
+        const float* P = ws.pred + tp.n_main + 6 * s;
+        float* D = ws.dpred + tp.n_main + 6 * s;
+        const float two_eps = 2.f * tp.eik_eps;
+        const float gx = (P[0] - P[1]) / two_eps, gy = (P[2] - P[3]) / two_eps, gz = (P[4] - P[5]) / two_eps;
+        const float n = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float r = n - 1.f;
+        l_eik = (double)(r * r);
+        // d/dg of weight_e * mean((|g|-1)^2); torch's norm backward is 0 at |g| = 0
+        const float c = n > 0.f ? tp.weight_e * 2.f * r * tp.inv_n_eik / (n * two_eps) : 0.f;
+        D[0] = c * gx; D[1] = -c * gx; D[2] = c * gy; D[3] = -c * gy; D[4] = c * gz; D[5] = -c * gz;
+    }
+    l_bce = wave_sum(l_bce);
+    l_eik = wave_sum(l_eik);
+    if ((threadIdx.x & 63) == 0) {
+        if (l_bce != 0.0) atomicAdd(loss_out + 0, l_bce);
+        if (l_eik != 0.0) atomicAdd(loss_out + 1, l_eik);
+    }
+}
+
+// ---- backward: layer deltas + feature-gradient scatter ------------------------------------
+template <int H>
+__global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const float4* __restrict__ nbr,
+                                                             const int* __restrict__ nn_count, int Q, TrainWs ws,
+                                                             float* __restrict__ feat_grad, int want_dec) {
+    __shared__ float lds[H * TR_BLOCK];
+    const int qi = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (qi >= Q) return;
+    float* col = lds + threadIdx.x;
+    const int Qs = ws.Qs;
+    const int L = f.levels;
+    cfloatp P = as_const(f.dec);
+    cfloatp Wo = P + H * MLP_IN + H + (L - 1) * (H * H + H);
+    const float dx = ws.dpred[qi] * f.sdf_scale;  // d loss / d mlp_out
+    if (want_dec) ws.d[(size_t)(L * H) * Qs + qi] = dx;
+    // delta of the last hidden layer
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const float on = ws.h[((size_t)(L - 1) * H + j) * Qs + qi] > 0.f ? 1.f : 0.f;
+        const float dl = dx * Wo[j] * on;
+        col[j * TR_BLOCK] = dl;
+        if (want_dec) ws.d[((size_t)(L - 1) * H + j) * Qs + qi] = dl;
+    }
+    for (int l = L - 1; l >= 1; --l) {
+        cfloatp W = P + H * MLP_IN + H + (l - 1) * (H * H + H);
+        float ap[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) ap[j] = 0.f;
+        for (int i = 0; i < H; ++i) {
+            const float am = col[i * TR_BLOCK];
+#pragma unroll
+            for (int j = 0; j < H; ++j) ap[j] = fmaf(W[i * H + j], am, ap[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const float on = ws.h[((size_t)(l - 1) * H + j) * Qs + qi] > 0.f ? 1.f : 0.f;
+            const float dl = ap[j] * on;
+            col[j * TR_BLOCK] = dl;
+            if (want_dec) ws.d[((size_t)(l - 1) * H + j) * Qs + qi] = dl;
+        }
+    }
+    float dz[PIN_FEATURE_DIM];
+#pragma unroll
+    for (int j = 0; j < PIN_FEATURE_DIM; ++j) dz[j] = 0.f;
+    for (int i = 0; i < H; ++i) {
+        const float am = col[i * TR_BLOCK];
+#pragma unroll
+        for (int j = 0; j < PIN_FEATURE_DIM; ++j) dz[j] = fmaf(P[i * MLP_IN + j], am, dz[j]);
+    }
+    if (dx == 0.f) return;
+    NbrW nb;
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+    bool quirk[PIN_MAX_K];
+    neighbor_weights(nbr, nn_count[qi], qi, f.k, nb, vx, vy, vz, quirk);
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (nb.idx[t] >= 0) {
+            float* g = feat_grad + (size_t)nb.idx[t] * PIN_FEATURE_DIM;
+#pragma unroll
+            for (int j = 0; j < PIN_FEATURE_DIM; ++j) atomicAdd(g + j, nb.w[t] * dz[j]);
+        }
+}
+
+// ---- decoder weight gradients: G[i][j] = sum_q D[i][q] * X[j][q]  (fp32 MFMA 16x16x4) ------
+// One wave per (K-slice, 16-row tile); it sweeps all column tiles.  Bias gradient = row sums.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void train_dw_kernel(const float* __restrict__ D, const float* __restrict__ X,
+                                                      int rows, int cols, int Qs, int Q, int slice,
+                                                      float* __restrict__ gW, float* __restrict__ gb) {
+    const int lane = threadIdx.x;
+    const int it = blockIdx.y;                 // 16-row tile of D
+    const int q0 = blockIdx.x * slice;
+    const int q1 = min(q0 + slice, Q);
+    const int li = lane & 15, g = lane >> 4;
+    const int row = it * 16 + li;
+    const bool row_ok = row < rows;
+    const float* Drow = D + (size_t)(row_ok ? row : 0) * Qs;
+    const int ntile = (cols + 15) / 16;        // <= 4
+    v4f acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int q = q0; q < q1; q += 4) {
+        const int qq = q + g;
+        const float a = (row_ok && qq < q1) ? Drow[qq] : 0.f;
+        bsum += a;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ntile) {
+                const int c = t * 16 + li;
+                const float b = (c < cols && qq < q1) ? X[(size_t)c * Qs + qq] : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane holds C[i = 4*(lane>>4) + r][j = lane&15]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + 4 * g + r, j = t * 16 + li;
+                if (i < rows && j < cols) atomicAdd(gW + (size_t)i * cols + j, acc[t][r]);
+            }
+        }
+    }
+    // bias: sum over the 4 k-groups of this row
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (g == 0 && row_ok) atomicAdd(gb + row, bsum);
+}
+
+// ---- Adam --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
+                                                   float b1, float b2, float eps, int zero_grad) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - b1);               // exp_avg.lerp_(grad, 1-beta1)
+        vi = vi * b2 + (1.f - b2) * gi * gi;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - lr_over_bc1 * (mi / denom);
+        m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+}  // namespace pin
+
+using namespace pin;
+
+extern "C" int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels) {
+    return (int64_t)train_ws_floats(n_queries, hidden, levels) * 4;
+}
+
+extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
+                                      float eps, float* query_out, void* stream) {
+    PIN_CHECK_ARG(n_main >= 0 && n_eik >= 0 && decimation >= 1, "bad sizes");
+    const int total = n_main + 6 * n_eik;
+    if (total == 0) return 0;
+    PIN_CHECK_ARG(coord && query_out, "NULL pointer");
+    PIN_CHECK_ARG(n_eik == 0 || (long)(n_eik - 1) * decimation < n_main, "n_eik too large for decimation");
+    hipLaunchKernelGGL(make_queries_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coord, n_main,
+                       n_eik, decimation, eps, query_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
+                              const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
+                              const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
+                              float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_CHECK_ARG(f && tp, "NULL params");
+    PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
+    PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
+    PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
+    PIN_CHECK_ARG(f->weighted_first, "pin_train_step implements weighted_first=True only");
+    PIN_CHECK_ARG(tp->n_main > 0 && tp->n_eik >= 0, "bad batch sizes");
+    const int Q = tp->n_main + 6 * tp->n_eik;
+    const int H = f->hidden, L = f->levels;
+    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(Q, H, L) * 4, "workspace too small");
+    PIN_CHECK_ARG(query && nbr && nn_count && sdf_label && feat_grad && loss_out && f->feats && f->dec, "NULL pointer");
+    PIN_CHECK_ARG(!tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
+    hipStream_t s = as_stream(stream);
+    TrainWs ws;
+    ws.Qs = ((Q + 63) / 64) * 64;
+    float* w = reinterpret_cast<float*>(workspace);
+    ws.z = w; w += (size_t)12 * ws.Qs;
+    ws.h = w; w += (size_t)L * H * ws.Qs;
+    ws.d = w; w += ((size_t)L * H + 1) * ws.Qs;
+    ws.pred = w; w += ws.Qs;
+    ws.dpred = w;
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
+    PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));
+    if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    PIN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
+                       sample_weight, ws, loss_out);
+    PIN_CHECK_LAUNCH();
+    const int want_dec = dec_grad != nullptr;
+    if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    PIN_CHECK_LAUNCH();
+    if (want_dec) {
+        // slices sized so that at most ~512 waves per layer contend on the gradient atomics
+        int slice = 1024;
+        while ((long)cdiv(Q, slice) > 512) slice *= 2;
+        const int nslice = cdiv(Q, slice);
+        size_t off = 0;
+        for (int l = 0; l <= L; ++l) {
+            const int rows = l < L ? H : 1;
+            const int cols = l == 0 ? MLP_IN : H;
+            const float* Dl = ws.d + (size_t)l * H * ws.Qs;
+            const float* Xl = l == 0 ? ws.z : ws.h + (size_t)(l - 1) * H * ws.Qs;
+            float* gW = dec_grad + off;
+            float* gb = gW + (size_t)rows * cols;
+            hipLaunchKernelGGL(train_dw_kernel, dim3(nslice, cdiv(rows, 16)), dim3(64), 0, s, Dl, Xl, rows, cols,
+                               ws.Qs, Q, slice, gW, gb);
+            PIN_CHECK_LAUNCH();
+            off += (size_t)rows * cols + rows;
+        }
+    }
+    if (pred_out) PIN_CHECK_HIP(hipMemcpyAsync(pred_out, ws.pred, sizeof(float) * tp->n_main, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int pin_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                             float lr, float beta1, float beta2, float eps, int32_t zero_grad, void* stream) {
+    PIN_CHECK_ARG(n >= 0 && step >= 1, "bad n / step");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "NULL pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
+                       (long)n, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, zero_grad);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}

@@ -228,3 +228,52 @@ def solve_gn(sums: np.ndarray, lm_lambda: float):
     T[:3, :3] = np.eye(3) + S * np.sin(ang) + (S @ S) * (1.0 - np.cos(ang))
     T[:3, 3] = t[3:]
     return T, cnt, float(s[28] / cnt * 100.0), dict(N_raw=N_raw, mse=scale * s[30] / cnt)
+
+
+# ------------------------------------------------------------------------------- training
+from ._lib import TrainParams  # noqa: E402
+
+
+class TrainBuffers:
+    """Caller-owned scratch for one training iteration of `n_main` samples (+ Eikonal)."""
+
+    def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda"):
+        self.n_main = int(n_main)
+        self.dec = int(decimation)
+        self.n_eik = (self.n_main + self.dec - 1) // self.dec if eikonal else 0
+        self.Q = self.n_main + 6 * self.n_eik
+        self.query = torch.empty((self.Q, 3), dtype=torch.float32, device=device)
+        self.nbr = torch.empty((self.Q, k, 4), dtype=torch.float32, device=device)
+        self.nn = torch.empty((self.Q,), dtype=torch.int32, device=device)
+        nbytes = _lib.lib().pin_train_workspace_bytes(self.Q, hidden, levels)
+        self.ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
+        self.loss = torch.zeros((2,), dtype=torch.float64, device=device)
+
+
+def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
+               certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
+               global_n_main=None, global_n_eik=None, pred_out=None):
+    """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
+    -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad."""
+    L = _lib.lib()
+    s = _stream()
+    check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, float(np.float32(eik_eps)),
+                                   _ptr(buf.query), s), "pin_train_make_queries")
+    knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None))
+    tp = TrainParams()
+    tp.n_main, tp.n_eik, tp.loss_weight_on = buf.n_main, buf.n_eik, int(bool(loss_weight_on))
+    tp.sigma, tp.weight_e, tp.eik_eps = float(sigma), float(weight_e), float(np.float32(eik_eps))
+    tp.inv_n_main = 1.0 / float(global_n_main or buf.n_main)
+    tp.inv_n_eik = 1.0 / float(global_n_eik or max(buf.n_eik, 1))
+    f = fs.params()
+    check(L.pin_train_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
+                           _ptr(sdf_label, torch.float32), _ptr(sample_weight), _ptr(sample_ts), _ptr(certainty_rw),
+                           _ptr(ts_update_rw), _ptr(feat_grad, torch.float32), _ptr(dec_grad), _ptr(buf.loss),
+                           _ptr(pred_out), _ptr(buf.ws), buf.ws.numel() * 4, s), "pin_train_step")
+    return buf.loss
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15, zero_grad=True):
+    check(_lib.lib().pin_adam_step(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(exp_avg, torch.float32),
+                                   _ptr(exp_avg_sq, torch.float32), param.numel(), int(step), float(lr), float(beta1),
+                                   float(beta2), float(eps), int(bool(zero_grad)), _stream()), "pin_adam_step")
