@@ -167,6 +167,13 @@ int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* 
                       int32_t n, double* sums_out, float* sdf_out, float* grad_out,
                       void* stream);
 
+/* Mapper.get_batch gathers (utils/mapper.py:482-488): rows `index[i]` of the sample pool
+ * (coord_pool / sdf_label_pool / weight_pool / time_pool).  pool_weight / pool_ts / the
+ * matching outputs may be NULL. */
+int pin_gather_batch(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                     const int32_t* pool_ts, const int32_t* index, int32_t n, float* coord_out,
+                     float* label_out, float* weight_out, int32_t* ts_out, void* stream);
+
 /* K6a: query points of one training iteration: the batch itself followed by the six
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
  * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with

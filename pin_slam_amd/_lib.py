@@ -71,6 +71,7 @@ SIGNATURES = {
     "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_gn_accumulate": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pin_gather_batch": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_train_make_queries": (i32, [vp, i32, i32, i32, f32, vp, vp]),
     "pin_train_workspace_bytes": (i64, [i32, i32, i32]),
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
@@ -87,6 +88,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m pin_slam_amd.build`.")
+        # torch bundles its own libamdhip64; it must be the HIP runtime of the process (device
+        # pointers and streams come from torch), so make sure it is loaded before our library
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

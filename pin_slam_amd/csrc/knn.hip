@@ -198,6 +198,7 @@ extern "C" int pin_candidate_offsets(const int32_t* dx, int32_t n_cand, int64_t 
 
 extern "C" int pin_pack_positions(const float* pos, const int32_t* ts_create, int32_t first, int32_t n,
                                   float* pos4, void* stream) {
+    PIN_ENTER();
     PIN_CHECK_ARG(n >= 0 && first >= 0, "negative size");
     if (n == 0) return 0;
     PIN_CHECK_ARG(pos && ts_create && pos4, "NULL pointer");
@@ -209,6 +210,7 @@ extern "C" int pin_pack_positions(const float* pos, const int32_t* ts_create, in
 
 extern "C" int pin_radius_search(const pin_search_params* sp, const float* query, int32_t n, float* d2_out,
                                  int64_t* idx_out, void* stream) {
+    PIN_ENTER();
     if (int e = check_search(sp)) return e;
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;
@@ -223,6 +225,7 @@ extern "C" int pin_radius_search(const pin_search_params* sp, const float* query
 extern "C" int pin_knn_query(const pin_search_params* sp, const float* query, int32_t n, int32_t k,
                              const float* pose_host, float* query_out, float* nbr_out,
                              int32_t* nn_count_out, void* stream) {
+    PIN_ENTER();
     if (int e = check_search(sp)) return e;
     PIN_CHECK_ARG(n >= 0, "n < 0");
     PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K, "k must be in [1, 8]");

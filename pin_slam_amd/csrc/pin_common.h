@@ -18,6 +18,10 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::pin::fail(-1, "%s: %s", __func__, msg); \
     } while (0)
 
+// hipGetLastError() is sticky per thread: another library's failed probe (e.g. a device
+// query before the runtime is initialised) must not be reported as ours.
+#define PIN_ENTER() ((void)hipGetLastError())
+
 #define PIN_CHECK_LAUNCH()                                                              \
     do {                                                                                \
         hipError_t e_ = hipGetLastError();                                              \

@@ -384,6 +384,7 @@ using namespace pin;
 extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count,
                              int32_t n, float* sdf_out, float* grad_out, float* std_out, float* certainty_out,
                              void* stream) {
+    PIN_ENTER();
     if (int e = check_field(f)) return e;
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;
@@ -398,6 +399,7 @@ extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float
 extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* query, const float* nbr,
                                  const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums_out,
                                  float* sdf_out, float* grad_out, void* stream) {
+    PIN_ENTER();
     if (int e = check_field(f)) return e;
     PIN_CHECK_ARG(gp && sums_out, "NULL pointer");
     PIN_CHECK_ARG(n >= 0, "n < 0");
@@ -415,6 +417,7 @@ extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, co
 extern "C" int pin_query_feature(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count, int32_t n,
                                  float* feat_out, float* weight_out, float* certainty_out, int32_t training,
                                  float* certainty_rw, int32_t* ts_update_rw, const int32_t* query_ts, void* stream) {
+    PIN_ENTER();
     PIN_CHECK_ARG(f != nullptr && f->k >= 1 && f->k <= PIN_MAX_K, "bad field");
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;
@@ -428,6 +431,7 @@ extern "C" int pin_query_feature(const pin_field* f, const float* query, const f
 }
 
 extern "C" int pin_decoder_sdf(const pin_field* f, const float* feat_in, int32_t n, float* sdf_out, void* stream) {
+    PIN_ENTER();
     if (int e = check_field(f)) return e;
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;

@@ -48,6 +48,20 @@ __global__ void make_queries_kernel(const float* __restrict__ coord, int n_main,
     q[3 * i] = x; q[3 * i + 1] = y; q[3 * i + 2] = z;
 }
 
+// Mapper.get_batch gathers (utils/mapper.py:482-488): pool rows selected by `index`
+__global__ void gather_batch_kernel(const float* __restrict__ pc, const float* __restrict__ pl,
+                                    const float* __restrict__ pw, const int* __restrict__ pt,
+                                    const int* __restrict__ index, int n, float* __restrict__ coord,
+                                    float* __restrict__ label, float* __restrict__ weight, int* __restrict__ ts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = index[i];
+    coord[3 * i] = pc[3 * (size_t)s]; coord[3 * i + 1] = pc[3 * (size_t)s + 1]; coord[3 * i + 2] = pc[3 * (size_t)s + 2];
+    label[i] = pl[s];
+    if (weight) weight[i] = pw ? pw[s] : 1.f;
+    if (ts) ts[i] = pt ? pt[s] : 0;
+}
+
 // ---- forward -----------------------------------------------------------------------------
 struct NbrW {
     float w[PIN_MAX_K];
@@ -353,8 +367,22 @@ extern "C" int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, 
     return (int64_t)train_ws_floats(n_queries, hidden, levels) * 4;
 }
 
+extern "C" int pin_gather_batch(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                                const int32_t* pool_ts, const int32_t* index, int32_t n, float* coord_out,
+                                float* label_out, float* weight_out, int32_t* ts_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(pool_coord && pool_label && index && coord_out && label_out, "NULL pointer");
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
+                       pool_weight, pool_ts, index, n, coord_out, label_out, weight_out, ts_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
                                       float eps, float* query_out, void* stream) {
+    PIN_ENTER();
     PIN_CHECK_ARG(n_main >= 0 && n_eik >= 0 && decimation >= 1, "bad sizes");
     const int total = n_main + 6 * n_eik;
     if (total == 0) return 0;
@@ -371,6 +399,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
                               const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
                               float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
                               void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
     PIN_CHECK_ARG(f && tp, "NULL params");
     PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
     PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
@@ -429,6 +458,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
 
 extern "C" int pin_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                              float lr, float beta1, float beta2, float eps, int32_t zero_grad, void* stream) {
+    PIN_ENTER();
     PIN_CHECK_ARG(n >= 0 && step >= 1, "bad n / step");
     if (n == 0) return 0;
     PIN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "NULL pointer");

@@ -277,3 +277,12 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=0.01, beta1=0.9, beta2=
     check(_lib.lib().pin_adam_step(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(exp_avg, torch.float32),
                                    _ptr(exp_avg_sq, torch.float32), param.numel(), int(step), float(lr), float(beta1),
                                    float(beta2), float(eps), int(bool(zero_grad)), _stream()), "pin_adam_step")
+
+
+def gather_batch(pool_coord, pool_label, pool_weight, pool_ts, index, out):
+    """Mapper.get_batch gathers; `out` = (coord [n,3], label [n], weight [n] | None, ts [n] | None)."""
+    coord, label, weight, ts = out
+    check(_lib.lib().pin_gather_batch(_ptr(pool_coord, torch.float32), _ptr(pool_label, torch.float32),
+                                      _ptr(pool_weight), _ptr(pool_ts), _ptr(index, torch.int32), index.numel(),
+                                      _ptr(coord), _ptr(label), _ptr(weight), _ptr(ts), _stream()), "pin_gather_batch")
+    return out
