@@ -107,6 +107,53 @@ typedef struct pin_train_params {
     float inv_n_eik;         /* 1 / GLOBAL Eikonal count  the global counts)      */
 } pin_train_params;
 
+/* ---- map maintenance (NeuralPoints.update / reset_local_map / assign_local_to_global,
+ * model/neural_points.py:311-526) ------------------------------------------------- */
+typedef struct pin_map_arrays {      /* the global map, capacity-managed SoA (neural_points.py:88-118) */
+    int32_t* table;        /* [buffer_size] */
+    float*   pos;          /* [cap][3]  neural_points */
+    float*   pos4;         /* [cap][4]  packed search mirror (xyz, ts_create bits) */
+    float*   orient;       /* [cap][4]  point_orientations (w,x,y,z) */
+    float*   geo;          /* [cap+1][8] geo_features, row n_points = padding */
+    float*   color;        /* [cap+1][8] color_features or NULL */
+    int32_t* ts_create;    /* [cap] */
+    int32_t* ts_update;    /* [cap] */
+    float*   certainty;    /* [cap] */
+} pin_map_arrays;
+
+typedef struct pin_local_arrays {    /* the local map (neural_points.py:120-136) */
+    float*   pos;          /* [M][3] */
+    float*   orient;       /* [M][4] */
+    float*   geo;          /* [M+1][8] local_geo_features (+ padding row) */
+    float*   color;        /* [M+1][8] or NULL */
+    float*   certainty;    /* [M] */
+    int32_t* ts_update;    /* [M] */
+    int32_t* global2local; /* [n_points+1], PIN_NONLOCAL for non-local points, -1 padding */
+} pin_local_arrays;
+
+typedef struct pin_update_params {
+    const float* travel_dist;  /* [n_ts] or NULL (temporal_local_map_on == False) */
+    int64_t buffer_size;
+    int32_t n_points;          /* points in the map before the call */
+    int32_t capacity;          /* rows allocated in pin_map_arrays */
+    int32_t n_max;             /* upper bound of *n_sel (size of sel) */
+    int32_t cur_ts;
+    int32_t all_new;           /* empty map or cur_ts == reboot_ts: every sample becomes a point (:341,357) */
+    float resolution;
+    float dist2_thre;          /* 3 * resolution^2 (:345) */
+    float diff_travel_dist_local;
+} pin_update_params;
+
+typedef struct pin_local_params {
+    const float* travel_dist;  /* NULL = temporal_local_map_on False: no time mask */
+    int32_t n_points;
+    int32_t cur_ts;
+    int32_t reboot_ts;         /* >= 0 only when reboot_map (:465-466), else -1 */
+    float diff_travel_dist_local;
+    float sensor[3];
+    float radius2;             /* local_map_radius^2 */
+} pin_local_params;
+
 /* ---- library ------------------------------------------------------------------- */
 int         pin_version(void);
 const char* pin_last_error(void);
@@ -204,6 +251,37 @@ int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* 
 int pin_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   int32_t step, float lr, float beta1, float beta2, float eps,
                   int32_t zero_grad, void* stream);
+
+/* ---- K8..K10 map maintenance --------------------------------------------------------
+ * All counts are produced on the device (int32) so calls can be chained without a host sync;
+ * the host reads them back once per frame. */
+int64_t pin_maint_workspace_bytes(int32_t n);
+
+/* voxel_down_sample_torch (utils/tools.py:583-626): index of the point closest to its voxel
+ * centre (distance quantised to 1000 levels, lowest index wins ties), one per voxel, ordered
+ * by ascending linearised voxel id like torch.unique.  sel_out [<= n], count_out [1]. */
+int pin_voxel_downsample(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
+                         int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* NeuralPoints.update (neural_points.py:334-416) for the down-sampled points points[sel[i]],
+ * i < *n_sel: probe the hash table, decide which samples become new neural points, append
+ * them (positions, packed mirror, identity orientation, timestamps, zero certainty) in sample
+ * order and publish their indices in the table.  Feature rows of the new points are
+ * initialised by the caller.  n_new_out [1] (device). */
+int pin_map_update(const pin_map_arrays* ma, const pin_update_params* up, const float* points,
+                   const int32_t* sel, const int32_t* n_sel, int32_t* n_new_out, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* NeuralPoints.reset_local_map (neural_points.py:445-511): travel-distance window + radius
+ * masks, ordered compaction of the local arrays, global2local.  local_mask_out [n_points+1]
+ * (bytes 0/1, last = 1), n_local_out [1] = M + 1 (the padding entry is counted). */
+int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arrays* la, const pin_local_params* lp,
+                        uint8_t* local_mask_out, int32_t* n_local_out, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+/* NeuralPoints.assign_local_to_global (neural_points.py:515-526). */
+int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
+                               int32_t n_local, void* stream);
 
 #ifdef __cplusplus
 }

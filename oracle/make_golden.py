@@ -163,6 +163,19 @@ def gen_case(case):
     out["qsp_cert"] = t2n(cert); out["qsp_std"] = t2n(std)
     out["track_mask_query_nn_k"] = np.int64(cfg.track_mask_query_nn_k)
 
+    # (4b) after_pgo: neighbour vectors rotated by per-point quaternions (neural_points.py:645-648)
+    quat = torch.randn(npts.local_point_orientations.shape, generator=gen)
+    quat = (quat / quat.norm(dim=1, keepdim=True)).float()
+    saved_q = npts.local_point_orientations
+    npts.local_point_orientations, npts.after_pgo = quat, True
+    res = trk.query_source_points(q.clone(), cfg.infer_bs, True, True, False, False,
+                                  query_locally=True, mask_min_nn_count=cfg.track_mask_query_nn_k)
+    out["pgo_quat"] = t2n(quat); out["pgo_sdf"] = t2n(res[0]); out["pgo_grad"] = t2n(res[1])
+    out["pgo_std"] = t2n(res[7])
+    gf, _, w, nn, cert = npts.query_feature(q.clone(), training_mode=False, query_locally=True)
+    out["pgo_feat"] = t2n(gf)
+    npts.local_point_orientations, npts.after_pgo = saved_q, False
+
     # (5) one registration step + full tracking on a bigger, slightly misaligned scan
     src = sheet_points(gen, 3000, 12.0, center=(16.0, 0.0), layers=2)
     Tinit = torch.eye(4, dtype=torch.float64)

@@ -100,13 +100,16 @@ def select_knn(d2, idx, k):
 
 
 def quat_rotate(quat, vec):
-    """utils/tools.py:428-437 apply_quaternion_rotation (w,x,y,z; passive per point)."""
+    """utils/tools.py:428-437 apply_quaternion_rotation: p' = p + w t + (-q_xyz) x t with
+    t = 2 (-q_xyz) x p, i.e. rotation by the CONJUGATE quaternion (w,x,y,z): p' = R(q)^T p.
+    Returns (p', M) with M = R(q)^T so that p' = M p."""
     q0, q1, q2, q3 = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
     R = np.stack([
         1 - 2 * (q2 ** 2 + q3 ** 2), 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2),
         2 * (q1 * q2 + q0 * q3), 1 - 2 * (q1 ** 2 + q3 ** 2), 2 * (q2 * q3 - q0 * q1),
         2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 1 - 2 * (q1 ** 2 + q2 ** 2),
     ], axis=-1).reshape(quat.shape[:-1] + (3, 3)).astype(vec.dtype)
+    R = np.swapaxes(R, -1, -2)
     return np.einsum("...ij,...j->...i", R, vec), R
 
 

@@ -47,6 +47,30 @@ class GnParams(C.Structure):
     ]
 
 
+class MapArrays(C.Structure):
+    _fields_ = [(n, vp) for n in ("table", "pos", "pos4", "orient", "geo", "color", "ts_create", "ts_update",
+                                  "certainty")]
+
+
+class LocalArrays(C.Structure):
+    _fields_ = [(n, vp) for n in ("pos", "orient", "geo", "color", "certainty", "ts_update", "global2local")]
+
+
+class UpdateParams(C.Structure):
+    _fields_ = [
+        ("travel_dist", vp), ("buffer_size", C.c_int64), ("n_points", C.c_int32), ("capacity", C.c_int32),
+        ("n_max", C.c_int32), ("cur_ts", C.c_int32), ("all_new", C.c_int32), ("resolution", C.c_float),
+        ("dist2_thre", C.c_float), ("diff_travel_dist_local", C.c_float),
+    ]
+
+
+class LocalParams(C.Structure):
+    _fields_ = [
+        ("travel_dist", vp), ("n_points", C.c_int32), ("cur_ts", C.c_int32), ("reboot_ts", C.c_int32),
+        ("diff_travel_dist_local", C.c_float), ("sensor", C.c_float * 3), ("radius2", C.c_float),
+    ]
+
+
 class TrainParams(C.Structure):
     _fields_ = [
         ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
@@ -71,6 +95,11 @@ SIGNATURES = {
     "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_gn_accumulate": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pin_maint_workspace_bytes": (i64, [i32]),
+    "pin_voxel_downsample": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
+    "pin_map_update": (i32, [P(MapArrays), P(UpdateParams), vp, vp, vp, vp, vp, i64, vp]),
+    "pin_reset_local_map": (i32, [P(MapArrays), P(LocalArrays), P(LocalParams), vp, vp, vp, i64, vp]),
+    "pin_assign_local_to_global": (i32, [P(MapArrays), P(LocalArrays), i32, i32, vp]),
     "pin_gather_batch": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_train_make_queries": (i32, [vp, i32, i32, i32, f32, vp, vp]),
     "pin_train_workspace_bytes": (i64, [i32, i32, i32]),

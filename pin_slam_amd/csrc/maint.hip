@@ -1,0 +1,431 @@
+// Per-frame map maintenance on gfx950 (once per frame, HBM-streaming):
+//   voxel_down_sample_torch          utils/tools.py:583-626            (K8a)
+//   NeuralPoints.update              model/neural_points.py:311-416    (K8: probe, mask, append, table write)
+//   NeuralPoints.reset_local_map     model/neural_points.py:424-513    (K9: masks + ordered stream compaction)
+//   NeuralPoints.assign_local_to_global  neural_points.py:515-526      (K10)
+// Ordered compaction = per-wave ballot/popcount prefix, per-block offsets from a small scan
+// kernel; the relative order of kept elements is the global order, as boolean-mask indexing
+// gives in the reference.  The only library primitive is rocPRIM's radix sort (voxel keys).
+#include "pin_common.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace pin {
+
+constexpr int MB = 256;  // block size of the streaming kernels
+
+// ---- ordered compaction helpers ---------------------------------------------------------
+// exclusive prefix of a per-thread flag inside a 256-thread block; returns block total
+__device__ __forceinline__ int block_flag_scan(bool flag, int& total) {
+    __shared__ int wave_cnt[MB / 64];
+    const unsigned long long bal = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MB / 64; ++w) {
+        if (w < wave) off += wave_cnt[w];
+        tot += wave_cnt[w];
+    }
+    __syncthreads();
+    total = tot;
+    return off + before;
+}
+
+__global__ __launch_bounds__(MB) void block_counts_kernel(const unsigned char* __restrict__ flags, int n,
+                                                          int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    block_flag_scan(i < n && flags[i] != 0, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
+// single-block exclusive scan of the per-block counts; total -> *count_out
+__global__ __launch_bounds__(1024) void scan_block_counts_kernel(int* __restrict__ block_cnt, int nblocks,
+                                                                 int* __restrict__ count_out) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, nblocks);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += block_cnt[b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) {
+        const int c = block_cnt[b];
+        block_cnt[b] = run;
+        run += c;
+    }
+    if (t == 1023) *count_out = part[1023];
+}
+
+// ---- K8a: voxel down-sampling ---------------------------------------------------------------
+struct VdsStats {
+    unsigned int minx, miny, minz;  // order-preserving encodings of float minima
+    int gmax;                       // max voxel coordinate (all axes) after the offset
+    unsigned int dmax;              // bits of the max centre distance (>= 0)
+    int nseg;
+};
+
+__device__ __forceinline__ unsigned int enc_f(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned int e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+__global__ void vds_init_kernel(VdsStats* st) {
+    st->minx = st->miny = st->minz = 0xffffffffu;
+    st->gmax = 0; st->dmax = 0u; st->nseg = 0;
+}
+
+__global__ __launch_bounds__(MB) void vds_min_kernel(const float* __restrict__ p, int n, VdsStats* st) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    atomicMin(&st->minx, enc_f(p[3 * i])); atomicMin(&st->miny, enc_f(p[3 * i + 1])); atomicMin(&st->minz, enc_f(p[3 * i + 2]));
+}
+
+__device__ __forceinline__ void vds_point(const float* __restrict__ p, int i, float vs, const VdsStats* st, long long (&g)[3],
+                                          float& dist) {
+#pragma clang fp contract(off)
+    float d[3];
+    const unsigned int mn[3] = {st->minx, st->miny, st->minz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = p[3 * i + a];
+        const float gf = floorf(__fdiv_rn(x, vs));
+        const long long off = (long long)floorf(__fdiv_rn(dec_f(mn[a]), vs));
+        g[a] = (long long)gf - off;
+        const float center = (gf + 0.5f) * vs;
+        d[a] = x - center;
+    }
+    dist = sqrtf(dist2_exact(d[0], d[1], d[2]));
+}
+
+__global__ __launch_bounds__(MB) void vds_max_kernel(const float* __restrict__ p, int n, float vs, VdsStats* st) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    long long g[3]; float dist;
+    vds_point(p, i, vs, st, g, dist);
+    const long long m = max(g[0], max(g[1], g[2]));
+    atomicMax(&st->gmax, (int)m);
+    atomicMax(&st->dmax, __float_as_uint(dist));
+}
+
+__global__ __launch_bounds__(MB) void vds_keys_kernel(const float* __restrict__ p, int n, float vs, const VdsStats* st,
+                                                      long long off10, unsigned long long* __restrict__ keys,
+                                                      unsigned long long* __restrict__ vals) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    long long g[3]; float dist;
+    vds_point(p, i, vs, st, g, dist);
+    const long long v = st->gmax;
+    keys[i] = (unsigned long long)(g[0] + g[1] * v + g[2] * v * v);
+    const float dm = __uint_as_float(st->dmax);
+    const long long dq = (long long)(__fdiv_rn(dist, dm) * 999.0f);
+    vals[i] = (unsigned long long)((long long)i + dq * off10);
+}
+
+__global__ __launch_bounds__(MB) void vds_heads_kernel(const unsigned long long* __restrict__ keys, int n,
+                                                       unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// segment id of every sorted element = (#heads up to and including it) - 1; min of vals per segment
+__global__ __launch_bounds__(MB) void vds_segmin_kernel(const unsigned char* __restrict__ flags,
+                                                        const int* __restrict__ block_off,
+                                                        const unsigned long long* __restrict__ vals, int n,
+                                                        unsigned long long* __restrict__ segmin) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    const bool f = i < n && flags[i] != 0;
+    const int ex = block_flag_scan(f, total);
+    if (i >= n) return;
+    const int seg = block_off[blockIdx.x] + ex + (f ? 1 : 0) - 1;
+    atomicMin(segmin + seg, vals[i]);
+}
+
+__global__ __launch_bounds__(MB) void vds_final_kernel(const unsigned long long* __restrict__ segmin, const int* nseg,
+                                                       long long off10, int* __restrict__ sel) {
+    const int s = blockIdx.x * MB + threadIdx.x;
+    if (s >= *nseg) return;
+    sel[s] = (int)((long long)segmin[s] % off10);
+}
+
+// ---- K8: update -----------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void update_probe_kernel(pin_map_arrays ma, pin_update_params up,
+                                                          const float* __restrict__ pts, const int* __restrict__ sel,
+                                                          const int* __restrict__ n_sel, unsigned char* __restrict__ flags,
+                                                          unsigned int* __restrict__ slots) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const int n = *n_sel;
+    if (i >= n) { if (i < up.n_max) flags[i] = 0; return; }
+    const int s = sel[i];
+    const float x = pts[3 * s], y = pts[3 * s + 1], z = pts[3 * s + 2];
+    const unsigned int slot = hash_base(x, y, z, up.resolution, up.buffer_size);
+    slots[i] = slot;
+    bool add = true;
+    if (up.n_points > 0 && !up.all_new) {
+        const int h = ma.table[slot];
+        if (h >= 0) {  // neural_points.py:341-356
+            const float* P = ma.pos + 3 * (size_t)h;
+            const float d2 = dist2_exact(P[0] - x, P[1] - y, P[2] - z);
+            add = d2 > up.dist2_thre;
+            if (up.travel_dist != nullptr)
+                add = add || (up.travel_dist[up.cur_ts] - up.travel_dist[ma.ts_update[h]] > up.diff_travel_dist_local);
+        }
+    }
+    flags[i] = add ? 1 : 0;
+}
+
+__global__ __launch_bounds__(MB) void update_append_kernel(pin_map_arrays ma, pin_update_params up,
+                                                           const float* __restrict__ pts, const int* __restrict__ sel,
+                                                           const int* __restrict__ n_sel,
+                                                           const unsigned char* __restrict__ flags,
+                                                           const int* __restrict__ block_off,
+                                                           const unsigned int* __restrict__ slots) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const int n = *n_sel;
+    int total;
+    const bool f = i < n && flags[i] != 0;
+    const int ex = block_flag_scan(f, total);
+    if (!f) return;
+    const int idx = up.n_points + block_off[blockIdx.x] + ex;
+    if (idx >= up.capacity) return;  // host checks the count against capacity
+    const int s = sel[i];
+    const float x = pts[3 * s], y = pts[3 * s + 1], z = pts[3 * s + 2];
+    ma.pos[3 * (size_t)idx] = x; ma.pos[3 * (size_t)idx + 1] = y; ma.pos[3 * (size_t)idx + 2] = z;
+    reinterpret_cast<float4*>(ma.pos4)[idx] = make_float4(x, y, z, __int_as_float(up.cur_ts));
+    reinterpret_cast<float4*>(ma.orient)[idx] = make_float4(1.f, 0.f, 0.f, 0.f);
+    ma.ts_create[idx] = up.cur_ts;
+    ma.ts_update[idx] = up.cur_ts;
+    ma.certainty[idx] = 0.f;
+    // duplicate slots inside one call: the highest index wins (= the reference's sequential
+    // CPU index_put_ for two added points; neural_points.py:377)
+    atomicMax(ma.table + slots[i], idx);
+}
+
+// ---- K9: reset_local_map ------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void local_time_count_kernel(pin_map_arrays ma, pin_local_params lp, int* __restrict__ cnt) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    bool t = false;
+    if (i < lp.n_points) {
+        const int ts = ma.ts_create[i];
+        t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
+        if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
+    }
+    const int c = __popcll(__ballot(t));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, c);
+}
+
+__global__ __launch_bounds__(MB) void local_flags_kernel(pin_map_arrays ma, pin_local_params lp,
+                                                         const int* __restrict__ time_cnt,
+                                                         unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i > lp.n_points) return;
+    if (i == lp.n_points) { flags[i] = 1; return; }  // padding entry (neural_points.py:492-494)
+    bool t = true;
+    if (lp.travel_dist != nullptr && *time_cnt >= 100) {  // < 100 points in the window -> all true (:468)
+        const int ts = ma.ts_create[i];
+        t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
+        if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
+    }
+    const float* P = ma.pos + 3 * (size_t)i;
+    const float d2 = dist2_exact(P[0] - lp.sensor[0], P[1] - lp.sensor[1], P[2] - lp.sensor[2]);
+    flags[i] = (t && d2 < lp.radius2) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(MB) void local_scatter_kernel(pin_map_arrays ma, pin_local_arrays la, pin_local_params lp,
+                                                           const unsigned char* __restrict__ flags,
+                                                           const int* __restrict__ block_off) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    const bool f = i <= lp.n_points && flags[i] != 0;
+    const int ex = block_flag_scan(f, total);
+    if (i > lp.n_points) return;
+    const int l = block_off[blockIdx.x] + ex;
+    if (i == lp.n_points) {  // padding row of the feature tables; global2local[-1] = -1 (:505)
+        la.global2local[i] = -1;
+        const float4* s = reinterpret_cast<const float4*>(ma.geo + (size_t)i * PIN_FEATURE_DIM);
+        float4* d = reinterpret_cast<float4*>(la.geo + (size_t)l * PIN_FEATURE_DIM);
+        d[0] = s[0]; d[1] = s[1];
+        if (ma.color && la.color) {
+            const float4* sc = reinterpret_cast<const float4*>(ma.color + (size_t)i * PIN_FEATURE_DIM);
+            float4* dc = reinterpret_cast<float4*>(la.color + (size_t)l * PIN_FEATURE_DIM);
+            dc[0] = sc[0]; dc[1] = sc[1];
+        }
+        return;
+    }
+    la.global2local[i] = f ? l : PIN_NONLOCAL;
+    if (!f) return;
+    la.pos[3 * (size_t)l] = ma.pos[3 * (size_t)i]; la.pos[3 * (size_t)l + 1] = ma.pos[3 * (size_t)i + 1];
+    la.pos[3 * (size_t)l + 2] = ma.pos[3 * (size_t)i + 2];
+    reinterpret_cast<float4*>(la.orient)[l] = reinterpret_cast<const float4*>(ma.orient)[i];
+    la.certainty[l] = ma.certainty[i];
+    la.ts_update[l] = ma.ts_update[i];
+    const float4* s = reinterpret_cast<const float4*>(ma.geo + (size_t)i * PIN_FEATURE_DIM);
+    float4* d = reinterpret_cast<float4*>(la.geo + (size_t)l * PIN_FEATURE_DIM);
+    d[0] = s[0]; d[1] = s[1];
+    if (ma.color && la.color) {
+        const float4* sc = reinterpret_cast<const float4*>(ma.color + (size_t)i * PIN_FEATURE_DIM);
+        float4* dc = reinterpret_cast<float4*>(la.color + (size_t)l * PIN_FEATURE_DIM);
+        dc[0] = sc[0]; dc[1] = sc[1];
+    }
+}
+
+// ---- K10: assign_local_to_global ---------------------------------------------------------------
+__global__ __launch_bounds__(MB) void assign_local_kernel(pin_map_arrays ma, pin_local_arrays la, int n_points, int n_local) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i > n_points) return;
+    int l = i == n_points ? n_local : la.global2local[i];
+    if (l < 0) return;
+    const float4* s = reinterpret_cast<const float4*>(la.geo + (size_t)l * PIN_FEATURE_DIM);
+    float4* d = reinterpret_cast<float4*>(ma.geo + (size_t)i * PIN_FEATURE_DIM);
+    d[0] = s[0]; d[1] = s[1];
+    if (ma.color && la.color) {
+        const float4* sc = reinterpret_cast<const float4*>(la.color + (size_t)l * PIN_FEATURE_DIM);
+        float4* dc = reinterpret_cast<float4*>(ma.color + (size_t)i * PIN_FEATURE_DIM);
+        dc[0] = sc[0]; dc[1] = sc[1];
+    }
+    if (i < n_points) {
+        ma.certainty[i] = la.certainty[l];
+        ma.ts_update[i] = la.ts_update[l];
+    }
+}
+
+// ---- workspace carving --------------------------------------------------------------------------
+struct Carver {
+    char* p;
+    char* end;
+    template <typename T>
+    T* take(size_t n) {
+        size_t a = (reinterpret_cast<size_t>(p) + 255) & ~size_t(255);
+        char* q = reinterpret_cast<char*>(a);
+        p = q + n * sizeof(T);
+        return p <= end ? reinterpret_cast<T*>(q) : nullptr;
+    }
+};
+
+static size_t sort_temp_bytes(int n) {
+    size_t bytes = 0;
+    unsigned long long* k = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0, 64, hipStream_t(0));
+    return bytes;
+}
+
+}  // namespace pin
+
+using namespace pin;
+
+extern "C" int64_t pin_maint_workspace_bytes(int32_t n) {
+    const size_t nb = (size_t)cdiv(n + 1, MB) + 8;
+    return (int64_t)(sizeof(VdsStats) + 4096 + (size_t)n * 8 * 5 + (size_t)(n + 1) * 5 + nb * 4 + sort_temp_bytes(n) +
+                     256 * 16);
+}
+
+extern "C" int pin_voxel_downsample(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
+                                    int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n > 0 && points && sel_out && count_out && workspace, "bad arguments");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    VdsStats* st = c.take<VdsStats>(1);
+    unsigned long long* keys = c.take<unsigned long long>(n);
+    unsigned long long* vals = c.take<unsigned long long>(n);
+    unsigned long long* keys2 = c.take<unsigned long long>(n);
+    unsigned long long* vals2 = c.take<unsigned long long>(n);
+    unsigned long long* segmin = c.take<unsigned long long>(n);
+    unsigned char* flags = c.take<unsigned char>(n + 1);
+    const int nb = cdiv(n, MB);
+    int* block_off = c.take<int>(nb + 1);
+    size_t tb = sort_temp_bytes(n);
+    void* temp = c.take<char>(tb);
+    PIN_CHECK_ARG(temp != nullptr, "workspace carve failed");
+    long long off10 = 1;  // 10 ** len(str(n - 1))  (utils/tools.py:610)
+    for (long long v = n - 1; ; v /= 10) { off10 *= 10; if (v < 10) break; }
+    hipLaunchKernelGGL(vds_init_kernel, dim3(1), dim3(1), 0, s, st);
+    hipLaunchKernelGGL(vds_min_kernel, dim3(nb), dim3(MB), 0, s, points, n, st);
+    hipLaunchKernelGGL(vds_max_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, st);
+    hipLaunchKernelGGL(vds_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, st, off10, keys, vals);
+    PIN_CHECK_LAUNCH();
+    PIN_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (size_t)n, 0, 64, s));
+    hipLaunchKernelGGL(vds_heads_kernel, dim3(nb), dim3(MB), 0, s, keys2, n, flags);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, n, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, count_out);
+    PIN_CHECK_HIP(hipMemsetAsync(segmin, 0xff, (size_t)n * 8, s));
+    hipLaunchKernelGGL(vds_segmin_kernel, dim3(nb), dim3(MB), 0, s, flags, block_off, vals2, n, segmin);
+    hipLaunchKernelGGL(vds_final_kernel, dim3(nb), dim3(MB), 0, s, segmin, count_out, off10, sel_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_map_update(const pin_map_arrays* ma, const pin_update_params* up, const float* points,
+                              const int32_t* sel, const int32_t* n_sel, int32_t* n_new_out, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(ma && up && points && sel && n_sel && n_new_out && workspace, "NULL pointer");
+    PIN_CHECK_ARG(up->n_max > 0 && workspace_bytes >= pin_maint_workspace_bytes(up->n_max), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    const int nb = cdiv(up->n_max, MB);
+    unsigned char* flags = c.take<unsigned char>(up->n_max + 1);
+    unsigned int* slots = c.take<unsigned int>(up->n_max);
+    int* block_off = c.take<int>(nb + 1);
+    PIN_CHECK_ARG(block_off != nullptr, "workspace carve failed");
+    hipLaunchKernelGGL(update_probe_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, slots);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, up->n_max, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_new_out);
+    hipLaunchKernelGGL(update_append_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, block_off, slots);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arrays* la, const pin_local_params* lp,
+                                   uint8_t* local_mask_out, int32_t* n_local_out, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(ma && la && lp && local_mask_out && n_local_out && workspace, "NULL pointer");
+    PIN_CHECK_ARG(lp->n_points > 0, "empty map");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(lp->n_points), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    const int n1 = lp->n_points + 1;
+    const int nb = cdiv(n1, MB);
+    int* block_off = c.take<int>(nb + 1);
+    int* time_cnt = c.take<int>(1);
+    PIN_CHECK_ARG(time_cnt != nullptr, "workspace carve failed");
+    PIN_CHECK_HIP(hipMemsetAsync(time_cnt, 0, sizeof(int), s));
+    if (lp->travel_dist != nullptr)
+        hipLaunchKernelGGL(local_time_count_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt);
+    hipLaunchKernelGGL(local_flags_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt, local_mask_out);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, local_mask_out, n1, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_local_out);
+    hipLaunchKernelGGL(local_scatter_kernel, dim3(nb), dim3(MB), 0, s, *ma, *la, *lp, local_mask_out, block_off);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
+                                          int32_t n_local, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(ma && la && n_points >= 0 && n_local >= 0, "bad arguments");
+    hipLaunchKernelGGL(assign_local_kernel, dim3(cdiv(n_points + 1, MB)), dim3(MB), 0, as_stream(stream), *ma, *la,
+                       n_points, n_local);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}

@@ -61,12 +61,12 @@ __device__ __forceinline__ void neighbor_vector(const pin_field& f, int idx, boo
         const float* p = f.pos + 3 * (size_t)idx;
         v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
     }
-    if (f.orient != nullptr) {  // apply_quaternion_rotation, utils/tools.py:428-437
+    if (f.orient != nullptr) {  // apply_quaternion_rotation (utils/tools.py:428-437) rotates by the conjugate: Rm = R(q)^T
         const float4 q = reinterpret_cast<const float4*>(f.orient)[idx];
         const float q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w;
-        Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[1] = 2 * (q1 * q2 - q0 * q3); Rm[2] = 2 * (q1 * q3 + q0 * q2);
-        Rm[3] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[5] = 2 * (q2 * q3 - q0 * q1);
-        Rm[6] = 2 * (q1 * q3 - q0 * q2); Rm[7] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+        Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[3] = 2 * (q1 * q2 - q0 * q3); Rm[6] = 2 * (q1 * q3 + q0 * q2);
+        Rm[1] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[7] = 2 * (q2 * q3 - q0 * q1);
+        Rm[2] = 2 * (q1 * q3 - q0 * q2); Rm[5] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
         const float x = v[0], y = v[1], z = v[2];
         v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * z;
         v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * z;

@@ -126,9 +126,9 @@ __global__ __launch_bounds__(TR_BLOCK) void train_fwd_kernel(pin_field f, const 
             if (f.orient != nullptr) {
                 const float4 q4 = reinterpret_cast<const float4*>(f.orient)[nb.idx[t]];
                 const float q0 = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
-                Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[1] = 2 * (q1 * q2 - q0 * q3); Rm[2] = 2 * (q1 * q3 + q0 * q2);
-                Rm[3] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[5] = 2 * (q2 * q3 - q0 * q1);
-                Rm[6] = 2 * (q1 * q3 - q0 * q2); Rm[7] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+                Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[3] = 2 * (q1 * q2 - q0 * q3); Rm[6] = 2 * (q1 * q3 + q0 * q2);
+                Rm[1] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[7] = 2 * (q2 * q3 - q0 * q1);
+                Rm[2] = 2 * (q1 * q3 - q0 * q2); Rm[5] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
                 const float x = v[0], y = v[1], zz = v[2];
                 v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * zz;
                 v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * zz;
@@ -292,53 +292,120 @@ __global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const 
 }
 
 // ---- decoder weight gradients: G[i][j] = sum_q D[i][q] * X[j][q]  (fp32 MFMA 16x16x4) ------
-// One wave per (K-slice, 16-row tile); it sweeps all column tiles.  Bias gradient = row sums.
+// A skinny GEMM whose reduction dimension is the batch.  grid = (K-slices, layers); a block is
+// 4 waves, each wave owns a contiguous run of queries and ALL (<= 4x4) 16x16 output tiles.
+// Operands are read K-contiguous as float4 (lane (i, g) takes queries q+4g..q+4g+3 of row i):
+// the MFMA k index is a free permutation as long as A and B agree, so component c of the
+// float4 is k-step c and no cross-lane shuffle is needed.  The 4 waves are summed through
+// LDS and one wave issues the float atomics.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64) void train_dw_kernel(const float* __restrict__ D, const float* __restrict__ X,
-                                                      int rows, int cols, int Qs, int Q, int slice,
-                                                      float* __restrict__ gW, float* __restrict__ gb) {
-    const int lane = threadIdx.x;
-    const int it = blockIdx.y;                 // 16-row tile of D
-    const int q0 = blockIdx.x * slice;
-    const int q1 = min(q0 + slice, Q);
+struct DwLayers {
+    int H, L, Q, Qs, per_wave;
+};
+
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int row, int nrows, int Qs, int q, int Q) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows && q < Q) {
+        v = *reinterpret_cast<const float4*>(base + (size_t)row * Qs + q);
+        if (q + 1 >= Q) v.y = 0.f;
+        if (q + 2 >= Q) v.z = 0.f;
+        if (q + 3 >= Q) v.w = 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, float* __restrict__ dec_grad) {
+    __shared__ float red[3][16 * 256 + 64];
+    const int H = dl.H, L = dl.L, Qs = dl.Qs, Q = dl.Q;
+    const int l = blockIdx.y;
+    const int rows = l < L ? H : 1;
+    const int cols = l == 0 ? 12 : H;       // z carries 12 rows (row 11 is zero)
+    const int cols_out = l == 0 ? MLP_IN : H;
+    const float* __restrict__ D = ws.d + (size_t)l * H * Qs;
+    const float* __restrict__ X = l == 0 ? ws.z : ws.h + (size_t)(l - 1) * H * Qs;
+    size_t off = 0;
+    for (int u = 0; u < l; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
+    float* __restrict__ gW = dec_grad + off;
+    float* __restrict__ gb = gW + (size_t)rows * cols_out;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, g = lane >> 4;
-    const int row = it * 16 + li;
-    const bool row_ok = row < rows;
-    const float* Drow = D + (size_t)(row_ok ? row : 0) * Qs;
-    const int ntile = (cols + 15) / 16;        // <= 4
-    v4f acc[4];
+    const int q0 = (blockIdx.x * 4 + wave) * dl.per_wave;
+    const int q1 = min(q0 + dl.per_wave, Q);
+    const int ntr = (rows + 15) >> 4, ntc = (cols + 15) >> 4;
+    v4f acc[4][4];
+    float bsum[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    for (int q = q0; q < q1; q += 4) {
-        const int qq = q + g;
-        const float a = (row_ok && qq < q1) ? Drow[qq] : 0.f;
-        bsum += a;
+    for (int a = 0; a < 4; ++a) {
+        bsum[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int q = q0; q < q1; q += 16) {
+        float4 av[4], bv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (t < ntile) {
-                const int c = t * 16 + li;
-                const float b = (c < cols && qq < q1) ? X[(size_t)c * Qs + qq] : 0.f;
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            av[t] = t < ntr ? load_row4(D, t * 16 + li, rows, Qs, q + 4 * g, q1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[t] = t < ntc ? load_row4(X, t * 16 + li, cols, Qs, q + 4 * g, q1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bsum[t] += (av[t].x + av[t].y) + (av[t].z + av[t].w);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a >= ntr) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b >= ntc) continue;
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].z, bv[b].z, acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].w, bv[b].w, acc[a][b], 0, 0, 0);
             }
         }
     }
-    // D layout: lane holds C[i = 4*(lane>>4) + r][j = lane&15]
+    // row sums over the 4 k-groups -> bias gradient (kept in lanes g == 0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        if (t < ntile) {
+        bsum[t] += __shfl_xor(bsum[t], 16, 64);
+        bsum[t] += __shfl_xor(bsum[t], 32, 64);
+    }
+    // block reduction: waves 1..3 park their tiles in LDS, wave 0 adds and publishes
+    if (wave > 0) {
+        float* r = red[wave - 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = it * 16 + 4 * g + r, j = t * 16 + li;
-                if (i < rows && j < cols) atomicAdd(gW + (size_t)i * cols + j, acc[t][r]);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[((a * 4 + b) * 4 + c) * 64 + lane] = acc[a][b][c];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (g == 0) r[16 * 256 + t * 16 + li] = bsum[t];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a >= ntr) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b >= ntc) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = ((a * 4 + b) * 4 + c) * 64 + lane;
+                    const float v = acc[a][b][c] + red[0][e] + red[1][e] + red[2][e];
+                    // D layout: C[i = 4*(lane>>4) + c][j = lane&15] of tile (a, b)
+                    const int i = a * 16 + 4 * g + c, j = b * 16 + li;
+                    if (i < rows && j < cols_out && v != 0.f) atomicAdd(gW + (size_t)i * cols_out + j, v);
+                }
+            }
+            if (g == 0) {
+                const int i = a * 16 + li, e = 16 * 256 + a * 16 + li;
+                const float v = bsum[a] + red[0][e] + red[1][e] + red[2][e];
+                if (i < rows && v != 0.f) atomicAdd(gb + i, v);
             }
         }
     }
-    // bias: sum over the 4 k-groups of this row
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (g == 0 && row_ok) atomicAdd(gb + row, bsum);
 }
 
 // ---- Adam --------------------------------------------------------------------------------
@@ -434,23 +501,13 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        // slices sized so that at most ~512 waves per layer contend on the gradient atomics
-        int slice = 1024;
-        while ((long)cdiv(Q, slice) > 512) slice *= 2;
-        const int nslice = cdiv(Q, slice);
-        size_t off = 0;
-        for (int l = 0; l <= L; ++l) {
-            const int rows = l < L ? H : 1;
-            const int cols = l == 0 ? MLP_IN : H;
-            const float* Dl = ws.d + (size_t)l * H * ws.Qs;
-            const float* Xl = l == 0 ? ws.z : ws.h + (size_t)(l - 1) * H * ws.Qs;
-            float* gW = dec_grad + off;
-            float* gb = gW + (size_t)rows * cols;
-            hipLaunchKernelGGL(train_dw_kernel, dim3(nslice, cdiv(rows, 16)), dim3(64), 0, s, Dl, Xl, rows, cols,
-                               ws.Qs, Q, slice, gW, gb);
-            PIN_CHECK_LAUNCH();
-            off += (size_t)rows * cols + rows;
-        }
+        DwLayers dl;
+        dl.H = H; dl.L = L; dl.Q = Q; dl.Qs = ws.Qs;
+        int per_wave = 64;  // multiple of 16; cap the grid at ~256 blocks per layer
+        while ((long)cdiv(Q, per_wave * 4) > 256) per_wave *= 2;
+        dl.per_wave = per_wave;
+        hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(Q, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
+        PIN_CHECK_LAUNCH();
     }
     if (pred_out) PIN_CHECK_HIP(hipMemcpyAsync(pred_out, ws.pred, sizeof(float) * tp->n_main, hipMemcpyDeviceToDevice, s));
     return 0;

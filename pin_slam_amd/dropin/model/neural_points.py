@@ -1,0 +1,432 @@
+"""Drop-in for the reference's ``model.neural_points.NeuralPoints`` (model/neural_points.py:29)
+backed by libpinhip (HIP, gfx950).
+
+Same constructor, attribute names and method signatures as the reference class, so that
+pin_slam.py / utils.mapper / utils.tracker / utils.mesher keep working unchanged; the storage
+is MI355X-first: capacity-managed structure-of-arrays buffers in HBM (no per-frame torch.cat),
+an int32 hash table, a packed (xyz, ts) search mirror, and every per-frame method is a short
+sequence of HIP kernel launches through the C ABI (include/pin_abi.h).  torch tensors are
+memory owners and the currency of the public API only.
+
+Differences, by design:
+* tensors returned by query_feature are forward-only (no autograd graph); the fused kernels
+  in Mapper / Tracker produce gradients directly.
+* ``global2local`` is kept in device format (int32, PIN_NONLOCAL for non-local points); the
+  property of that name converts to the reference's int64 convention (non-local -> 1,
+  neural_points.py:498) for outside readers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+from ..._lib import PIN_NONLOCAL, LocalArrays, LocalParams, MapArrays, UpdateParams, check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class NeuralPoints(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        self.silence = config.silence
+        self.geo_feature_dim = config.feature_dim
+        self.geo_feature_std = config.feature_std
+        self.color_feature_dim = config.feature_dim
+        self.color_feature_std = config.feature_std
+        if config.feature_dim != 8:
+            raise NotImplementedError("libpinhip is built for feature_dim = 8 (config.py:103)")
+        self.mean_grid_sampling = False
+        self.device = config.device
+        self.dtype = config.dtype
+        self.idx_dtype = torch.int64
+        self.resolution = config.voxel_size_m
+        self.buffer_size = int(config.buffer_size)
+        self.temporal_local_map_on = True
+        self.local_map_radius = config.local_map_radius
+        self.diff_travel_dist_local = config.local_map_radius * config.local_map_travel_dist_ratio
+        self.diff_ts_local = config.diff_ts_local
+        self.reboot_ts = 0
+        self.local_orientation = torch.eye(3, device=self.device)
+        self.cur_ts = 0
+        self.max_ts = 0
+        self.travel_dist = None
+        self.est_poses = None
+        self.after_pgo = False
+        self.color_on = bool(config.color_on)
+        self.geo_feature_pca = self.color_feature_pca = None
+        self.cur_memory_mb = 0.0
+        self.memory_footprint = []
+
+        # ---- global map: capacity-managed SoA ----
+        self._n = 0
+        self._cap = 0
+        self._table = torch.full((self.buffer_size,), -1, dtype=torch.int32, device=self.device)
+        self._alloc(1 << 16)
+        # ---- local map ----
+        self._m = 0
+        self._lcap = 0
+        self._lalloc(1 << 16)
+        self.local_geo_features = nn.Parameter()
+        self.local_color_features = nn.Parameter()
+        self._local_mask = None
+        self._g2l = None
+        self._ws = None
+        self._cnt = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.set_search_neighborhood(num_nei_cells=config.num_nei_cells, search_alpha=config.search_alpha)
+
+    # ------------------------------------------------------------------ storage
+    def _alloc(self, cap):
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        new = dict(pos=torch.empty((cap, 3), dtype=f32, device=dev), pos4=torch.empty((cap, 4), dtype=f32, device=dev),
+                   orient=torch.empty((cap, 4), dtype=f32, device=dev),
+                   geo=torch.zeros((cap + 1, 8), dtype=f32, device=dev),
+                   color=torch.zeros((cap + 1, 8), dtype=f32, device=dev) if self.color_on else None,
+                   ts_create=torch.empty((cap,), dtype=i32, device=dev), ts_update=torch.empty((cap,), dtype=i32, device=dev),
+                   cert=torch.empty((cap,), dtype=f32, device=dev))
+        if self._cap:
+            n = self._n
+            for k, t in new.items():
+                if t is not None:
+                    rows = n + 1 if k in ("geo", "color") else n
+                    t[:rows] = self._g[k][:rows]
+        self._g = new
+        self._cap = cap
+
+    def _lalloc(self, cap):
+        dev, f32 = self.device, torch.float32
+        self._l = dict(pos=torch.empty((cap, 3), dtype=f32, device=dev), orient=torch.empty((cap, 4), dtype=f32, device=dev),
+                       geo=torch.zeros((cap + 1, 8), dtype=f32, device=dev),
+                       color=torch.zeros((cap + 1, 8), dtype=f32, device=dev) if self.color_on else None,
+                       cert=torch.empty((cap,), dtype=f32, device=dev),
+                       ts_update=torch.empty((cap,), dtype=torch.int32, device=dev))
+        self._lcap = cap
+
+    def _workspace(self, n):
+        need = _lib.lib().pin_maint_workspace_bytes(int(n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((int(need * 1.25),), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _map_arrays(self) -> MapArrays:
+        g, ma = self._g, MapArrays()
+        ma.table, ma.pos, ma.pos4, ma.orient = _p(self._table), _p(g["pos"]), _p(g["pos4"]), _p(g["orient"])
+        ma.geo, ma.color = _p(g["geo"]), _p(g["color"])
+        ma.ts_create, ma.ts_update, ma.certainty = _p(g["ts_create"]), _p(g["ts_update"]), _p(g["cert"])
+        return ma
+
+    def _local_arrays(self) -> LocalArrays:
+        l, la = self._l, LocalArrays()
+        la.pos, la.orient, la.geo, la.color = _p(l["pos"]), _p(l["orient"]), _p(l["geo"]), _p(l["color"])
+        la.certainty, la.ts_update, la.global2local = _p(l["cert"]), _p(l["ts_update"]), _p(self._g2l)
+        return la
+
+    # ---- the reference's tensor attributes, as views of the capacity buffers ----
+    neural_points = property(lambda s: s._g["pos"][:s._n])
+    point_orientations = property(lambda s: s._g["orient"][:s._n])
+    geo_features = property(lambda s: s._g["geo"][:s._n + 1])
+    color_features = property(lambda s: s._g["color"][:s._n + 1] if s.color_on else None)
+    point_ts_create = property(lambda s: s._g["ts_create"][:s._n])
+    point_ts_update = property(lambda s: s._g["ts_update"][:s._n])
+    point_certainties = property(lambda s: s._g["cert"][:s._n])
+    local_neural_points = property(lambda s: s._l["pos"][:s._m])
+    local_point_orientations = property(lambda s: s._l["orient"][:s._m])
+    local_point_certainties = property(lambda s: s._l["cert"][:s._m])
+    local_point_ts_update = property(lambda s: s._l["ts_update"][:s._m])
+    buffer_pt_index = property(lambda s: s._table)
+
+    @property
+    def local_mask(self):
+        return None if self._local_mask is None else self._local_mask[:self._n + 1].bool()
+
+    @property
+    def global2local(self):
+        """Reference convention (int64; non-local -> 1, padding -> -1; neural_points.py:498-505)."""
+        if self._g2l is None:
+            return None
+        g = self._g2l[:self._n + 1].long()
+        g[g == PIN_NONLOCAL] = 1
+        return g
+
+    def is_empty(self):
+        return self._n == 0
+
+    def count(self):
+        return self._n
+
+    def local_count(self):
+        return self._m
+
+    def record_memory(self, verbose: bool = True, record_footprint: bool = True):
+        point_dim = self.geo_feature_dim + 3 + 4 + (self.color_feature_dim if self.color_on else 0)
+        self.cur_memory_mb = self.count() * point_dim * 4 / 1024 / 1024
+        if verbose:
+            print("# Global neural point: %d" % self.count())
+            print("# Local  neural point: %d" % self.local_count())
+            print("Current map memory consumption: {:.3f} MB".format(self.cur_memory_mb))
+        if record_footprint:
+            self.memory_footprint.append(self.cur_memory_mb)
+
+    # ------------------------------------------------------------------ search state
+    def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 1.0):
+        dx, mv = ops.search_neighborhood(num_nei_cells, search_alpha, self.resolution)
+        self.neighbor_dx = torch.from_numpy(dx.astype(np.int64)).to(self.device)
+        self.neighbor_K = dx.shape[0]
+        self.max_valid_dist2 = mv
+        self._cand_off = torch.from_numpy(ops.candidate_offsets(dx, self.buffer_size)).to(self.device)
+
+    def _travel(self):
+        td = self.travel_dist
+        if td is None:
+            return None
+        if td.dtype != torch.float32 or not td.is_cuda:
+            td = td.to(device=self.device, dtype=torch.float32)
+        return td.contiguous()
+
+    def search_state(self) -> ops.SearchState:
+        return ops.SearchState(table=self._table, pos4=self._g["pos4"], cand_off=self._cand_off, n_points=self._n,
+                               resolution=self.resolution, max_valid_dist2=self.max_valid_dist2,
+                               travel_dist=self._travel(), cur_ts=self.cur_ts,
+                               diff_travel_dist_local=self.diff_travel_dist_local, global2local=self._g2l)
+
+    def field_state(self, decoder, query_locally=True, color=False) -> ops.FieldState:
+        """FieldState over the local (or global) tables for `decoder` (a dropin Decoder)."""
+        l = self._l if query_locally else self._g
+        if query_locally:
+            feats = (self.local_color_features if color else self.local_geo_features).data
+        else:
+            feats = self.color_features if color else self.geo_features
+        return ops.FieldState(
+            feats=feats, dec=decoder.flat_params(), k=self.config.query_nn_k, hidden=decoder.hidden_dim,
+            levels=decoder.hidden_level, weighted_first=self.config.weighted_first, sdf_scale=decoder.sdf_scale,
+            certainty=l["cert"][:self._m if query_locally else self._n],
+            orient=(l["orient"][:self._m if query_locally else self._n] if self.after_pgo else None),
+            pos=l["pos"][:self._m if query_locally else self._n])
+
+    # ------------------------------------------------------------------ K8: update
+    def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
+        L = _lib.lib()
+        points = points.to(device=self.device, dtype=torch.float32).contiguous()
+        n = points.shape[0]
+        ws = self._workspace(max(n, self._n + 1))
+        stream = torch.cuda.current_stream().cuda_stream
+        sel = torch.empty((n,), dtype=torch.int32, device=self.device)
+        check(L.pin_voxel_downsample(_p(points), n, float(np.float32(self.resolution)), _p(sel), _p(self._cnt[0:1]),
+                                     _p(ws), ws.numel(), stream), "pin_voxel_downsample")
+        if self._n + n + 1 > self._cap:  # worst case: every sample is new
+            self._alloc(int(max(self._cap * 1.5, self._n + n + 1)))
+        up = UpdateParams()
+        temporal = self.temporal_local_map_on and self.travel_dist is not None
+        up.travel_dist = _p(self._travel()) if temporal else None
+        up.buffer_size, up.n_points, up.capacity, up.n_max, up.cur_ts = self.buffer_size, self._n, self._cap, n, int(cur_ts)
+        up.all_new = int(self.is_empty() or cur_ts == self.reboot_ts)
+        up.resolution = float(np.float32(self.resolution))
+        up.dist2_thre = float(np.float32(3 * self.resolution ** 2))
+        up.diff_travel_dist_local = float(self.diff_travel_dist_local)
+        ma = self._map_arrays()
+        check(L.pin_map_update(C.byref(ma), C.byref(up), _p(points), _p(sel), _p(self._cnt[0:1]), _p(self._cnt[1:2]),
+                               _p(ws), ws.numel(), stream), "pin_map_update")
+        n_sel, n_new = (int(v) for v in self._cnt[:2].tolist())  # the one host sync of update()
+        old = self._n
+        self._n = old + n_new
+        # feature rows of the new points + the padding row (neural_points.py:395-411)
+        g = self._g
+        g["geo"][old:self._n + 1] = self.geo_feature_std * torch.randn(n_new + 1, 8, device=self.device)
+        if self.color_on:
+            g["color"][old:self._n + 1] = self.color_feature_std * torch.randn(n_new + 1, 8, device=self.device)
+        self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
+        return n_new / max(n_sel, 1)
+
+    # ------------------------------------------------------------------ K9: reset_local_map
+    def reset_local_map(self, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int,
+                        use_travel_dist: bool = True, diff_ts_local: int = 50, reboot_map: bool = False):
+        if not use_travel_dist:
+            raise NotImplementedError("reset_local_map(use_travel_dist=False) is unused by the reference")
+        if self.config.use_mid_ts:
+            raise NotImplementedError("use_mid_ts=True (config.py:97 default False)")
+        self.cur_ts = cur_ts
+        self.max_ts = max(self.max_ts, cur_ts)
+        n = self._n
+        if n + 1 > self._lcap:
+            self._lalloc(int(max(self._lcap * 1.5, n + 1)))
+        if self._g2l is None or self._g2l.numel() < n + 1:
+            self._g2l = torch.empty((int((n + 1) * 1.5),), dtype=torch.int32, device=self.device)
+            self._local_mask = torch.empty((int((n + 1) * 1.5),), dtype=torch.uint8, device=self.device)
+        lp = LocalParams()
+        temporal = self.temporal_local_map_on and self.travel_dist is not None
+        lp.travel_dist = _p(self._travel()) if temporal else None
+        lp.n_points, lp.cur_ts = n, int(cur_ts)
+        lp.reboot_ts = int(self.reboot_ts) if reboot_map else -1
+        lp.diff_travel_dist_local = float(self.diff_travel_dist_local)
+        sp = sensor_position.detach().to("cpu", torch.float32).numpy()
+        lp.sensor[0], lp.sensor[1], lp.sensor[2] = float(sp[0]), float(sp[1]), float(sp[2])
+        lp.radius2 = float(np.float32(self.local_map_radius ** 2))
+        ws = self._workspace(n + 1)
+        ma, la = self._map_arrays(), self._local_arrays()
+        check(_lib.lib().pin_reset_local_map(C.byref(ma), C.byref(la), C.byref(lp), _p(self._local_mask),
+                                             _p(self._cnt[2:3]), _p(ws), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream), "pin_reset_local_map")
+        self._m = int(self._cnt[2].item()) - 1  # the padding entry is counted
+        self.local_geo_features = nn.Parameter(self._l["geo"][:self._m + 1])
+        if self.color_on:
+            self.local_color_features = nn.Parameter(self._l["color"][:self._m + 1])
+        self.local_orientation = sensor_orientation
+
+    # ------------------------------------------------------------------ K10
+    def assign_local_to_global(self):
+        ma, la = self._map_arrays(), self._local_arrays()
+        la.geo = _p(self.local_geo_features.data)
+        if self.color_on:
+            la.color = _p(self.local_color_features.data)
+        check(_lib.lib().pin_assign_local_to_global(C.byref(ma), C.byref(la), self._n, self._m,
+                                                    torch.cuda.current_stream().cuda_stream),
+              "pin_assign_local_to_global")
+
+    # ------------------------------------------------------------------ K1 / K2 tensor API
+    def radius_neighborhood_search(self, points: torch.Tensor, time_filtering: bool = False):
+        points = points.detach().to(torch.float32).contiguous()
+        return ops.radius_search(self.search_state(), points, time_filtering=time_filtering)
+
+    def knn(self, points: torch.Tensor, query_locally: bool = True, pose=None, out=None):
+        """kNN record of the hot path (pin_knn_query)."""
+        tf = self.temporal_local_map_on and query_locally and self.travel_dist is not None
+        return ops.knn_query(self.search_state(), points, self.config.query_nn_k, time_filtering=tf,
+                             local=query_locally, pose=pose, out=out)
+
+    def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,
+                      query_locally: bool = True, query_geo_feature: bool = True, query_color_feature: bool = False):
+        if not query_geo_feature and not query_color_feature:
+            raise SystemExit("you need to at least query one kind of feature")
+        if self.config.layer_norm_on or self.config.pos_encoding_band > 0:
+            raise NotImplementedError("layer_norm_on / positional encoding are off in every shipped config")
+        q = query_points.detach().to(torch.float32).contiguous()
+        nbr, nn_i32, _ = self.knn(q, query_locally)
+        cert = self._l["cert"][:self._m] if query_locally else self._g["cert"][:self._n]
+        tsu = self._l["ts_update"][:self._m] if query_locally else None
+        k = self.config.query_nn_k
+
+        def table(color):
+            if query_locally:
+                return (self.local_color_features if color else self.local_geo_features).data
+            return self.color_features if color else self.geo_features
+
+        def run(color, side_effects):
+            fs = ops.FieldState(feats=table(color), dec=None, k=k, hidden=64, levels=1,
+                                weighted_first=self.config.weighted_first, sdf_scale=1.0, certainty=cert,
+                                orient=((self._l if query_locally else self._g)["orient"] if self.after_pgo else None),
+                                pos=(self._l if query_locally else self._g)["pos"])
+            ts32 = None
+            if side_effects and query_ts is not None:
+                ts32 = query_ts.to(torch.int32).contiguous()
+            return ops.query_feature(fs, q, nbr, nn_i32, training=side_effects, certainty_rw=cert if side_effects else None,
+                                     ts_update_rw=tsu if side_effects else None, query_ts=ts32)
+
+        geo = color = None
+        w = certainty = None
+        if query_geo_feature:
+            geo, w, certainty = run(False, training_mode)
+        if query_color_feature and self.color_on:
+            color, w2, c2 = run(True, training_mode and not query_geo_feature)
+            if w is None:
+                w, certainty = w2, c2
+        return geo, color, w.unsqueeze(-1), nn_i32.long(), certainty
+
+    def query_certainty(self, query_points: torch.Tensor):
+        _, idx = self.radius_neighborhood_search(query_points)
+        cert = self.point_certainties[idx]  # tiny gather (Kc = 1 in the caller, mapper.py:388-396)
+        cert[idx < 0] = 0.0
+        return torch.max(cert, dim=-1)[0]
+
+    # ------------------------------------------------------------------ post-loop maintenance (next-tier rows)
+    def _rebuild_mirror(self):
+        ops.pack_positions(self._g["pos"], self._g["ts_create"], self._g["pos4"], 0, self._n)
+
+    def prune_map(self, prune_certainty_thre, min_prune_count=500, global_prune=False):
+        """neural_points.py:748-789 (host-side torch, not a hot-path kernel)."""
+        certainty_mask = self.point_certainties < prune_certainty_thre
+        if global_prune:
+            prune_mask = certainty_mask
+        else:
+            td = self._travel()
+            diff = torch.abs(td[self.cur_ts] - td[self.point_ts_update.long()])
+            prune_mask = (diff > self.diff_travel_dist_local) & certainty_mask
+        if int(prune_mask.sum().item()) <= min_prune_count:
+            return False
+        keep = ~prune_mask
+        n_new = int(keep.sum().item())
+        g = self._g
+        for k in ("pos", "orient", "ts_create", "ts_update", "cert"):
+            g[k][:n_new] = g[k][:self._n][keep]
+        keep1 = torch.cat((keep, torch.ones(1, dtype=torch.bool, device=self.device)))
+        g["geo"][:n_new + 1] = g["geo"][:self._n + 1][keep1]
+        if self.color_on:
+            g["color"][:n_new + 1] = g["color"][:self._n + 1][keep1]
+        self._n = n_new
+        self._rebuild_mirror()
+        return True
+
+    def adjust_map(self, pose_diff_torch):
+        """neural_points.py:791-817 (per-point SE(3) after PGO; host-side torch, next-tier)."""
+        if self.config.use_mid_ts:
+            raise NotImplementedError("use_mid_ts")
+        self.after_pgo = True
+        used = self.point_ts_create.long()
+        T = pose_diff_torch[used].to(torch.float32)
+        p = self.neural_points
+        self._g["pos"][:self._n] = (torch.bmm(T[:, :3, :3], p.unsqueeze(-1)) + T[:, :3, 3:]).squeeze(-1)
+        from ..quat import quat_multiply, rotmat_to_quat
+        dq = rotmat_to_quat(pose_diff_torch[:, :3, :3].to(torch.float32))
+        self._g["orient"][:self._n] = quat_multiply(dq[used], self.point_orientations)
+        self._rebuild_mirror()
+
+    def recreate_hash(self, sensor_position, sensor_orientation, kept_points: bool = True, with_ts: bool = True, cur_ts=0):
+        """neural_points.py:819-908, kept_points=True path: rebuild the table from all points
+        (voxel winner = smallest |ts - cur_ts| or largest certainty).  Host-side torch, next-tier."""
+        if not kept_points:
+            raise NotImplementedError("recreate_hash(kept_points=False) (merge) is not on the SLAM path")
+        self._table.fill_(-1)
+        value = (torch.abs(self.point_ts_create - cur_ts).float() if with_ts
+                 else self.point_certainties.max() - self.point_certainties)
+        from ..voxel import voxel_down_sample_min_value
+        sample_idx = voxel_down_sample_min_value(self.neural_points, self.resolution, value)
+        sp = self.neural_points[sample_idx]
+        grid = torch.floor(sp / np.float32(self.resolution)).long()
+        primes = torch.tensor(ops.PRIMES, dtype=torch.int64, device=self.device)
+        h = torch.remainder((grid * primes).sum(-1), self.buffer_size)
+        self._table[h] = sample_idx.to(torch.int32)
+        self._rebuild_mirror()
+        if sensor_position is not None:
+            self.reset_local_map(sensor_position, sensor_orientation, cur_ts)
+
+    def clear_temp(self, clean_more: bool = False):
+        """Drop everything that is rebuilt on load (neural_points.py:1035-1055) before pickling."""
+        self._m = 0
+        self.local_geo_features = nn.Parameter()
+        self.local_color_features = nn.Parameter()
+        self._local_mask = None
+        self._g2l = None
+        self._ws = None
+        # shrink to size so the pickled map holds only live rows
+        n = self._n
+        self._g = {k: (None if t is None else t[:(n + 1 if k in ("geo", "color") else n)].clone())
+                   for k, t in self._g.items()}
+        self._cap = n
+        self._lalloc(1)
+        self._table = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if self.__dict__.get("_table") is None:
+            self._table = torch.full((self.buffer_size,), -1, dtype=torch.int32, device=self.device)
+
+    def compute_feature_principle_components(self, down_rate: int = 1):
+        raise NotImplementedError("visualisation helper (gui only), out of scope")
+
+    def get_neural_points_o3d(self, *a, **k):
+        raise NotImplementedError("visualisation helper (open3d), out of scope")

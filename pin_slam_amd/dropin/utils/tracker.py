@@ -1,0 +1,137 @@
+"""Drop-in for the reference's ``utils.tracker.Tracker`` (utils/tracker.py:21): same constructor
+and ``tracking`` / ``registration_step`` / ``query_source_points`` signatures, executed by the
+fused HIP kernels (kNN with the pose applied in-kernel, SDF + analytic Jacobian + Gauss-Newton
+sums) with one 16 KiB read-back and a float64 6x6 solve per iteration."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from ... import engine, ops
+from ..._lib import GnParams
+
+
+class Tracker:
+    def __init__(self, config, neural_points, decoders: dict):
+        self.config = config
+        self.silence = config.silence
+        self.neural_points = neural_points
+        self.sdf_mlp = decoders["sdf"]
+        self.sem_mlp = decoders.get("semantic")
+        self.color_mlp = decoders.get("color")
+        self.device = config.device
+        self.dtype = config.dtype
+        self.reg_local_map = True  # False in localisation mode (pin_slam.py:168)
+        self.sdf_scale = config.logistic_gaussian_ratio * config.sigma_sigmoid_m
+        self._gn = None
+
+    # ------------------------------------------------------------------ helpers
+    def _gn_params(self, min_grad_norm, max_grad_norm, GM_dist, GM_grad) -> GnParams:
+        c = self.config
+        gp = GnParams()
+        gp.valid_nn_k = int(c.track_mask_query_nn_k)
+        gp.min_grad_norm, gp.max_grad_norm = float(min_grad_norm), float(max_grad_norm)
+        gp.max_sdf_std = float(c.surface_sample_range_m * c.max_sdf_std_ratio)
+        gp.gm_dist = float(GM_dist) if GM_dist else 0.0
+        gp.gm_grad = float(GM_grad) if GM_grad else 0.0
+        return gp
+
+    def _engine(self, n, gp, lm_lambda) -> engine.GNTracker:
+        npts = self.neural_points
+        st = npts.search_state()
+        fs = npts.field_state(self.sdf_mlp, query_locally=self.reg_local_map)
+        if self._gn is None or self._gn.nbr.shape[0] < n or self._gn.nbr.shape[1] != fs.k:
+            self._gn = engine.GNTracker(st, fs, gp, lm_lambda, n)
+        g = self._gn
+        g.st, g.fs, g.gp, g.lm_lambda = st, fs, gp, lm_lambda
+        g.local = self.reg_local_map
+        return g
+
+    def _unsupported(self, colors, normals):
+        if normals is not None:
+            raise NotImplementedError("normal-consistency weight (tracker.py:482-488) is not built")
+        if colors is not None and self.config.color_on:
+            raise NotImplementedError("colour / photometric registration (tracker.py:493-542) is C5 scope")
+
+    # ------------------------------------------------------------------ API
+    def tracking(self, source_points, init_pose=None, source_colors=None, source_normals=None,
+                 source_semantics=None, source_sdf=None, cur_ts=None, loop_reg: bool = False,
+                 vis_result: bool = False):
+        c = self.config
+        self._unsupported(source_colors, source_normals)
+        T0 = torch.eye(4, dtype=torch.float64, device=self.device) if init_pose is None else init_pose
+        T = T0.detach().cpu().numpy().astype(np.float64)
+        gp = self._gn_params(c.reg_min_grad_norm, c.reg_max_grad_norm,
+                             c.reg_GM_dist_m if c.reg_GM_dist_m > 0 else None,
+                             c.reg_GM_grad if c.reg_GM_grad > 0 else None)
+        src = source_points.detach().to(torch.float32).contiguous()
+        n = src.shape[0]
+        gn = self._engine(n, gp, c.reg_lm_lambda)
+        labels = None if source_sdf is None else source_sdf.detach().to(torch.float32).contiguous()
+        iter_n = c.reg_iter_n
+        max_valid_final = c.surface_sample_range_m * c.final_residual_ratio_thre * 100.0
+        min_valid_ratio = 0.15 if loop_reg else 0.2
+        converged, valid_flag = False, True
+        last_res, res_cm, cnt, extra, i = 1e5, 0.0, 0, None, 0
+        tf = self.neural_points.temporal_local_map_on and self.reg_local_map
+        for i in range(iter_n):  # tracker.py:114-184
+            dT, cnt, res_cm, extra = gn.step(src, T, time_filtering=tf, local=self.reg_local_map, labels=labels)
+            T = dT @ T
+            if (res_cm - last_res) / last_res > 1.1:
+                valid_flag = False
+            else:
+                last_res = res_cm
+            if cnt < 30 or cnt / n < min_valid_ratio:
+                valid_flag = False
+            if not valid_flag or converged:
+                break
+            ang = math.degrees(math.acos(min(1.0, max(-1.0, (np.trace(dT[:3, :3]) - 1) / 2))))
+            if (abs(ang) < c.reg_term_thre_deg and np.linalg.norm(dT[:3, 3]) < c.reg_term_thre_m) or i == iter_n - 2:
+                converged = True
+        if res_cm > max_valid_final:
+            valid_flag = False
+        cov_mat = None
+        if vis_result and converged and extra is not None:  # only the last iteration computes these
+            N_raw = extra["N_raw"]
+            eig = np.linalg.eigvals(N_raw[3:, 3:]).real
+            if c.eigenvalue_check and eig.min() < cnt * c.eigenvalue_ratio_thre:
+                valid_flag = False
+            cov_mat = np.linalg.inv(N_raw) * extra["mse"]
+        T_out = torch.tensor(T, dtype=torch.float64, device=self.device)
+        if not valid_flag and i < 10:
+            T_out, cov_mat = init_pose, None
+        return T_out, cov_mat, None, valid_flag
+
+    def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, query_color=False,
+                            query_color_grad=False, query_sem=False, query_mask=True, query_certainty=True,
+                            query_locally=True, mask_min_nn_count: int = 4):
+        if query_color or query_color_grad or query_sem:
+            raise NotImplementedError("colour / semantic queries are C5 scope")
+        npts = self.neural_points
+        q = coord.detach().to(torch.float32).contiguous()
+        nbr, nn, _ = npts.knn(q, query_locally)
+        fs = npts.field_state(self.sdf_mlp, query_locally=query_locally)
+        sdf, grad, std, cert = ops.sdf_query(fs, q, nbr, nn, grad=query_sdf_grad)
+        mask = (nn >= mask_min_nn_count) if query_mask else None
+        return sdf, grad, None, None, None, mask, (cert if query_certainty else None), std
+
+    def registration_step(self, points, normals, sdf_labels, colors, min_grad_norm, max_grad_norm, GM_dist=None,
+                          GM_grad=None, lm_lambda=0.0, vis_weight_pc=False):
+        self._unsupported(colors, normals)
+        gp = self._gn_params(min_grad_norm, max_grad_norm, GM_dist, GM_grad)
+        pts = points.detach().to(torch.float32).contiguous()
+        gn = self._engine(pts.shape[0], gp, lm_lambda)
+        tf = self.neural_points.temporal_local_map_on and self.reg_local_map
+        labels = None if sdf_labels is None else sdf_labels.detach().to(torch.float32).contiguous()
+        dT, cnt, res_cm, extra = gn.step(pts, None, time_filtering=tf, local=self.reg_local_map, labels=labels)
+        T = torch.tensor(dT, dtype=torch.float64, device=self.device)
+        if cnt < 10:
+            return T, None, None, None, pts[:0], 0.0, 0.0
+        cov = eig = None
+        if vis_weight_pc and extra is not None:
+            eig = torch.tensor(np.linalg.eigvals(extra["N_raw"][3:, 3:]).real)
+            cov = torch.tensor(np.linalg.inv(extra["N_raw"]) * extra["mse"])
+        valid_points = pts[:cnt]  # callers only use the COUNT of valid points (tracker.py:161)
+        return T, cov, eig, None, valid_points, res_cm, None

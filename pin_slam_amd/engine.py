@@ -30,7 +30,7 @@ class GNTracker:
         self.sums_host = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64).pin_memory()
         self.on_knn = None  # optional hook(start: bool) used by bench.py to bracket the kNN launch
 
-    def step(self, src: torch.Tensor, T: np.ndarray, time_filtering=True, local=True):
+    def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None):
         n = src.shape[0]
         out = (self.nbr[:n], self.nn[:n], self.cur[:n])
         if self.on_knn:
@@ -38,7 +38,8 @@ class GNTracker:
         ops.knn_query(self.st, src, self.fs.k, time_filtering=time_filtering, local=local, pose=T, out=out)
         if self.on_knn:
             self.on_knn(False)
-        ops.gn_accumulate(self.fs, self.gp, out[2], out[0], out[1], sums=self.sums)
+        cur = out[2] if T is not None else src
+        ops.gn_accumulate(self.fs, self.gp, cur, out[0], out[1], sdf_labels=labels, sums=self.sums)
         self.sums_host.copy_(self.sums, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return ops.solve_gn(self.sums_host.numpy(), self.lm_lambda)
@@ -66,7 +67,7 @@ class MapTrainer:
     def __init__(self, st: ops.SearchState, fs: ops.FieldState, pool_coord, pool_label, pool_weight, pool_ts,
                  ts_update, *, bs: int, decimation: int, sigma: float, weight_e: float, eik_eps: float,
                  lr: float = 0.01, adam_eps: float = 1e-15, loss_weight_on: bool = False, train_decoder: bool = True,
-                 rank: int = 0, world: int = 1):
+                 eikonal: bool = True, rank: int = 0, world: int = 1):
         self.st, self.fs = st, fs
         self.pool = (pool_coord, pool_label, pool_weight, pool_ts)
         self.ts_update = ts_update
@@ -84,7 +85,7 @@ class MapTrainer:
         self.gdec, self.gfeat = self.grad[:nd], self.grad[nd:]
         self.m = torch.zeros_like(self.grad)
         self.v = torch.zeros_like(self.grad)
-        self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels)
+        self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal)
         self.coord = torch.empty((self.bs_local, 3), dtype=torch.float32, device=dev)
         self.label = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
@@ -95,7 +96,11 @@ class MapTrainer:
 
     def iteration(self, index_local: torch.Tensor, step: int):
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
-        ops.train_step(self.st, self.fs, self.buf, self.coord, self.label, self.weight, self.ts,
+        self.step_batch(self.coord, self.label, self.weight, self.ts, step)
+
+    def step_batch(self, coord, label, weight, ts, step: int):
+        """One iteration on an explicit (already gathered) batch shard."""
+        ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global)
@@ -107,6 +112,12 @@ class MapTrainer:
         if self.train_decoder:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
+
+    def reset_optimizer(self):
+        """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615)."""
+        self.m.zero_()
+        self.v.zero_()
+        self.grad.zero_()
 
     def mapping(self, index_batches):
         """One Mapper.mapping call: a fresh Adam state (mapper.py:615) and len(index_batches)

@@ -126,7 +126,7 @@ def knn_query(st: SearchState, query: torch.Tensor, k: int, time_filtering=True,
 class FieldState:
     """Feature tables + decoder of the searched index space (pin_field in pin_abi.h)."""
     feats: torch.Tensor                 # [M+1, 8]
-    dec: torch.Tensor                   # flat decoder parameters
+    dec: Optional[torch.Tensor]         # flat decoder parameters (None for feature-only calls)
     k: int
     hidden: int
     levels: int
@@ -142,7 +142,7 @@ class FieldState:
         f.certainty = _ptr(self.certainty, torch.float32)
         f.orient = _ptr(self.orient, torch.float32)
         f.pos = _ptr(self.pos, torch.float32)
-        f.dec = _ptr(self.dec, torch.float32)
+        f.dec = _ptr(self.dec, torch.float32) if self.dec is not None else None
         f.k, f.hidden, f.levels = int(self.k), int(self.hidden), int(self.levels)
         f.weighted_first = int(bool(self.weighted_first))
         f.sdf_scale = float(self.sdf_scale)

@@ -1,0 +1,84 @@
+"""CPU-only checks of the boundary: the C ABI header, the ctypes table and the built library
+agree symbol by symbol; the drop-in classes keep the reference's call surface."""
+import inspect
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "pin_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(pin_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_ctypes_library_agree():
+    from pin_slam_amd import _lib, build
+    build.build(verbose=False)
+    hdr = _header_symbols()
+    assert hdr == set(_lib.SIGNATURES), (hdr ^ set(_lib.SIGNATURES))
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (pin_[a-z0-9_]+)", out))
+    assert hdr <= exported, hdr - exported
+    L = _lib.lib()  # loads without a GPU; no compute call is made here
+    assert L.pin_version() == _lib.PIN_ABI_VERSION
+    assert L.pin_train_workspace_bytes(1000, 64, 4) > 0 and L.pin_maint_workspace_bytes(1000) > 0
+
+
+def test_candidate_offsets_host_helper():
+    import numpy as np
+    from oracle import pin_oracle as O
+    from pin_slam_amd import ops
+    dx, mv = ops.search_neighborhood(2, 0.5, 0.4)
+    odx, omv = O.search_neighborhood(2, 0.5, 0.4)
+    assert np.array_equal(dx, odx) and mv == omv
+    for B in (40009, int(5e7)):
+        off = ops.candidate_offsets(dx, B)
+        ref = np.mod((dx.astype(np.int64) * O.PRIMES).sum(-1), B)
+        assert np.array_equal(off, ref)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: device pointers are required."""
+    import torch
+    from pin_slam_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        ops.pack_positions(torch.zeros(4, 3), torch.zeros(4, dtype=torch.int32), torch.zeros(4, 4))
+
+
+@pytest.mark.reference
+def test_dropin_call_surface_matches_reference():
+    """Every method the drop-in classes implement takes the reference's parameter names, in
+    order; the Mapper drop-in inherits the reference Mapper in drop-in mode."""
+    from oracle import ref_loader as R
+    ref = R.load()
+    from pin_slam_amd import dropin
+    mods = dropin.install(R.REF_ROOT)
+    import model.neural_points as mnp
+    import utils.mapper as um
+    assert mnp is mods["model.neural_points"]
+    pairs = [(ref["NeuralPoints"], mods["model.neural_points"].NeuralPoints,
+              ["__init__", "update", "reset_local_map", "assign_local_to_global", "query_feature",
+               "radius_neighborhood_search", "query_certainty", "set_search_neighborhood", "prune_map",
+               "adjust_map", "recreate_hash", "clear_temp", "record_memory", "is_empty", "count", "local_count"]),
+             (ref["Decoder"], mods["model.decoder"].Decoder, ["__init__", "mlp", "sdf", "regress_color", "sem_label_prob"]),
+             (ref["Tracker"], mods["utils.tracker"].Tracker, ["__init__", "tracking", "query_source_points", "registration_step"]),
+             (ref["Mapper"], um.Mapper, ["__init__", "mapping", "sdf", "sdf_batch", "get_batch", "process_frame",
+                                         "determine_used_pose", "init_pool", "free_pool"])]
+    for rcls, ocls, names in pairs:
+        for n in names:
+            rp = list(inspect.signature(getattr(rcls, n)).parameters)
+            op = list(inspect.signature(getattr(ocls, n)).parameters)
+            assert rp == op, (rcls.__name__, n, rp, op)
+    assert um.Mapper.__mro__[1].__name__ == "Mapper"  # inherits the reference's pool management
+    # restore the plain reference namespace for the other tests
+    import sys
+    for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
+        del sys.modules[k]
+    R._loaded.clear()

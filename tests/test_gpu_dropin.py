@@ -1,0 +1,157 @@
+"""GPU tests of the drop-in classes (stand-alone PinConfig, no reference tree needed):
+map maintenance kernels (K8-K10) bit-exact against the reference's recorded arrays, and a
+small end-to-end loop update -> mapping -> tracking through the reference's call surface."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pin_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    from pin_slam_amd.config import PinConfig
+    base = dict(voxel_size_m=0.4, buffer_size=int(5e7), local_map_radius=20.0, local_map_travel_dist_ratio=1.0)
+    base.update(kw)
+    return PinConfig(**base)
+
+
+def test_voxel_downsample_matches_reference():
+    from pin_slam_amd import _lib
+    d = G.load("update")
+    L = _lib.lib()
+    for ts in range(4):
+        pts = torch.from_numpy(d[f"pts{ts}"]).cuda()
+        n = pts.shape[0]
+        ws = torch.empty(L.pin_maint_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        sel = torch.empty(n, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(L.pin_voxel_downsample(pts.data_ptr(), n, float(np.float32(d["resolution"])), sel.data_ptr(),
+                                          cnt.data_ptr(), ws.data_ptr(), ws.numel(), None), "vds")
+        c = int(cnt.item())
+        assert c == len(d[f"sel{ts}"])
+        assert np.array_equal(sel[:c].cpu().numpy(), d[f"sel{ts}"].astype(np.int32))
+
+
+def test_update_reset_local_map_bit_exact():
+    """NeuralPoints.update / reset_local_map over 4 frames: point count, positions, timestamps,
+    hash table, local mask and global2local equal the reference's (neural_points.py:311-513)."""
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    d = G.load("update")
+    npts = NeuralPoints(_cfg())
+    npts.travel_dist = torch.from_numpy(d["travel_dist"]).cuda()
+    for ts in range(4):
+        npts.update(torch.from_numpy(d[f"pts{ts}"]).cuda(), torch.tensor([9.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+        assert npts.count() == d[f"count{ts}"]
+        assert np.array_equal(npts.local_mask.cpu().numpy(), d[f"local_mask{ts}"])
+        assert np.array_equal(npts.global2local.cpu().numpy(), d[f"global2local{ts}"])
+        M = int(d[f"local_mask{ts}"][:-1].sum())
+        assert npts.local_count() == M and npts.local_geo_features.shape == (M + 1, 8)
+        lp = npts.neural_points[npts.local_mask[:-1]]
+        assert torch.equal(lp, npts.local_neural_points)
+    assert np.array_equal(npts.neural_points.cpu().numpy(), d["neural_points"])
+    assert np.array_equal(npts.point_ts_create.cpu().numpy(), d["point_ts_create"])
+    tab = npts.buffer_pt_index.cpu().numpy()
+    slots = np.nonzero(tab >= 0)[0]
+    assert np.array_equal(slots, d["table_slots"])
+    assert np.array_equal(tab[slots], d["table_vals"].astype(np.int32))
+
+
+def test_assign_local_to_global_and_query_api():
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    d = G.load("update")
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, feature_std=0.1)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.from_numpy(d["travel_dist"]).cuda()
+    for ts in range(2):
+        npts.update(torch.from_numpy(d[f"pts{ts}"]).cuda(), torch.tensor([9.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+    with torch.no_grad():
+        npts.local_geo_features.data.add_(1.0)
+    npts.local_point_certainties.add_(2.0)
+    mask = npts.local_mask
+    before = npts.geo_features.clone()
+    npts.assign_local_to_global()
+    after = npts.geo_features
+    assert torch.allclose(after[mask], before[mask] + 1.0)
+    assert torch.equal(after[~mask], before[~mask])
+    assert torch.allclose(npts.point_certainties[mask[:-1]], torch.full((int(mask[:-1].sum()),), 2.0, device="cuda"))
+    # tensor API (Mesher-style): query_feature -> Decoder.sdf, against the oracle
+    dec = Decoder(cfg, 32, 2, 1)
+    q = torch.from_numpy(d["pts1"][:500] + 0.03).cuda()
+    feat, _, w, nn, cert = npts.query_feature(q, training_mode=False, query_locally=True)
+    sdf = dec.sdf(feat)
+    table = npts.buffer_pt_index.cpu().numpy().astype(np.int64)
+    dx, mv = O.search_neighborhood(2, 0.5, 0.4)
+    s = O.radius_search(q.cpu().numpy(), table, npts.neural_points.cpu().numpy(), 0.4, dx, mv,
+                        ts_create=npts.point_ts_create.cpu().numpy(), travel_dist=d["travel_dist"], cur_ts=1,
+                        diff_travel_dist_local=npts.diff_travel_dist_local)
+    qf = O.query_feature(q.cpu().numpy(), s, npts.local_geo_features.data.cpu().numpy(),
+                         npts.local_neural_points.cpu().numpy(), npts.local_point_certainties.cpu().numpy(), 8,
+                         global2local=npts.global2local.cpu().numpy())
+    assert np.array_equal(nn.cpu().numpy(), qf["nn_count"])
+    np.testing.assert_allclose(feat.cpu().numpy(), qf["geo_feat"], rtol=1e-5, atol=3e-7)
+    params = O.unpack_decoder(dec.flat_params().cpu().numpy(), 11, 32, 2)
+    ref = dec.sdf_scale * O.mlp_forward(qf["geo_feat"].astype(np.float64),
+                                        tuple([x.astype(np.float64) for x in p] if isinstance(p, list) else p.astype(np.float64) for p in params))[:, 0]
+    np.testing.assert_allclose(sdf.cpu().numpy(), ref, rtol=1e-4, atol=1e-6)
+    assert list(dec.state_dict().keys()) == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
+                                             "lout.weight", "lout.bias"]
+
+
+class _FakeDataset:
+    lose_track = False
+    stop_status = False
+
+
+def test_mini_slam_loop_update_map_track():
+    """update -> Mapper.mapping -> Tracker.tracking through the reference's call surface on a
+    synthetic sheet: training lowers the SDF error, registration recovers a known offset."""
+    from pin_slam_amd import synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    from pin_slam_amd.dropin.utils.tracker import Tracker
+    torch.manual_seed(0)
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=4096, local_map_radius=40.0, local_map_travel_dist_ratio=5.0,
+               reg_iter_n=30)
+    rng = np.random.default_rng(0)
+    pts, _ = synth.disc_points(rng, 120_000, 25.0, 2)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.zeros(1, device="cuda")
+    npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+    assert npts.count() > 10_000 and npts.local_count() == npts.count()
+    dec = Decoder(cfg, 64, 1, 1)
+    decoders = {"sdf": dec, "semantic": None, "color": None}
+    mp = Mapper(cfg, _FakeDataset(), npts, decoders)
+    base, _ = synth.disc_points(rng, 400_000, 24.0, 2)
+    nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
+    dd = 0.15 * rng.standard_normal(len(base))
+    mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
+    mp.coord_pool = mp.global_coord_pool
+    mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+    mp.weight_pool = torch.ones(len(base), device="cuda")
+    mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+    mp.pool_sample_count = len(base)
+    probe = mp.global_coord_pool[:20000]
+    lab = mp.sdf_label_pool[:20000]
+    err0 = (mp.sdf(probe)[0] - lab).abs().mean().item()
+    mp.mapping(300)
+    err1 = (mp.sdf(probe)[0] - lab).abs().mean().item()
+    assert err1 < 0.35 * err0 and err1 < 0.05, (err0, err1)
+    assert torch.allclose(npts.geo_features[:-1], npts.local_geo_features.data[:-1])  # assign_local_to_global ran
+    trk = Tracker(cfg, npts, decoders)
+    scan, _ = synth.disc_points(rng, 20_000, 20.0, 2)
+    T_true = np.eye(4)
+    a = 0.004
+    T_true[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    T_true[:3, 3] = [0.06, -0.05, 0.04]
+    src = (np.linalg.inv(T_true)[:3, :3] @ scan.T).T + np.linalg.inv(T_true)[:3, 3]
+    T, cov, _, valid = trk.tracking(torch.from_numpy(src.astype(np.float32)).cuda(),
+                                    torch.eye(4, dtype=torch.float64, device="cuda"))
+    assert valid
+    T = T.cpu().numpy()
+    assert abs(T[2, 3] - T_true[2, 3]) < 0.01, T  # z is observable on the (near horizontal) sheets
+    assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 0.01

@@ -193,28 +193,22 @@ def test_nonlocal_neighbor_quirk(gold):
 
 
 def test_after_pgo_rotation(gold):
-    """after_pgo: neighbour vectors rotated by per-point quaternions (neural_points.py:645-648)."""
+    """after_pgo: neighbour vectors rotated by per-point quaternions (neural_points.py:645-648),
+    against the reference's own outputs."""
     from pin_slam_amd import ops
     from tests import gpu_util as U
     import dataclasses
     d = gold
-    rng = np.random.default_rng(11)
-    M = d["local_neural_points"].shape[0]
-    quat = rng.normal(size=(M, 4)).astype(np.float32)
-    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
-    fs = dataclasses.replace(d["fs_loc"], orient=U.dev(quat))
-    q = d["query"]
-    nbr, nn, _ = ops.knn_query(d["st"], U.dev(q), int(d["query_nn_k"]))
-    sdf, grad, std, _ = [None if t is None else t.cpu().numpy() for t in ops.sdf_query(fs, U.dev(q), nbr, nn)]
-    s = O.radius_search(q, d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
-                        ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
-                        diff_travel_dist_local=d["diff_travel_dist_local"])
-    rs, rg, rstd, _, _ = O.query_sdf(q, s, d["local_geo_features"], d["local_neural_points"], d["params"],
-                                     d["sdf_scale"], int(d["query_nn_k"]), weighted_first=bool(d["weighted_first"]),
-                                     global2local=d["global2local"], orientations=quat)
-    np.testing.assert_allclose(sdf, rs, rtol=1e-4, atol=2e-6)
-    scale = np.abs(rg).max(1, keepdims=True) + 1e-6
-    assert np.max(np.abs(grad - rg) / scale) < 1e-4
+    fs = dataclasses.replace(d["fs_loc"], orient=U.dev(d["pgo_quat"]))
+    q = U.dev(d["query"])
+    nbr, nn, _ = ops.knn_query(d["st"], q, int(d["query_nn_k"]))
+    sdf, grad, std, _ = [None if t is None else t.cpu().numpy() for t in ops.sdf_query(fs, q, nbr, nn)]
+    np.testing.assert_allclose(sdf, d["pgo_sdf"], rtol=1e-4, atol=2e-6)
+    scale = np.abs(d["pgo_grad"]).max(1, keepdims=True) + 1e-6
+    assert np.max(np.abs(grad - d["pgo_grad"]) / scale) < 1e-4
+    np.testing.assert_allclose(std, d["pgo_std"], rtol=3e-4, atol=3e-6)
+    feat, _, _ = ops.query_feature(fs, q, nbr, nn)
+    np.testing.assert_allclose(feat.cpu().numpy(), d["pgo_feat"], rtol=1e-5, atol=3e-7)
 
 
 def test_mapping_two_iterations(gold):

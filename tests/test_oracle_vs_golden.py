@@ -75,6 +75,22 @@ def test_query_source_points(gold):
     np.testing.assert_allclose(cert, d["qsp_cert"], rtol=1e-5, atol=1e-6)
 
 
+def test_after_pgo(gold):
+    """after_pgo: apply_quaternion_rotation (utils/tools.py:428-437) on the neighbour vectors."""
+    d = gold
+    s = _search(d, d["query"], tf=True)
+    sdf, grad, std, nn, _ = O.query_sdf(d["query"], s, d["local_geo_features"], d["local_neural_points"], d["params"],
+                                        d["sdf_scale"], int(d["query_nn_k"]), weighted_first=bool(d["weighted_first"]),
+                                        global2local=d["global2local"], orientations=d["pgo_quat"])
+    np.testing.assert_allclose(sdf, d["pgo_sdf"], rtol=1e-5, atol=1e-7)
+    scale = np.abs(d["pgo_grad"]).max(1, keepdims=True) + 1e-6
+    assert np.max(np.abs(grad - d["pgo_grad"]) / scale) < 1e-4
+    qf = O.query_feature(d["query"], s, d["local_geo_features"], d["local_neural_points"], None, int(d["query_nn_k"]),
+                         global2local=d["global2local"], orientations=d["pgo_quat"],
+                         weighted_first=bool(d["weighted_first"]))
+    np.testing.assert_allclose(qf["geo_feat"], d["pgo_feat"], rtol=1e-5, atol=3e-7)
+
+
 def _reg_kwargs(d):
     return dict(valid_nn_k=int(d["track_mask_query_nn_k"]), min_grad_norm=d["cfg_reg_min_grad_norm"],
                 max_grad_norm=d["cfg_reg_max_grad_norm"],
