@@ -225,9 +225,11 @@ int pin_gather_batch(const float* pool_coord, const float* pool_label, const flo
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
  * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with
  * a = x+, x-, y+, y-, z+, z- (the reference concatenates per axis; results are per-point
- * so the order is immaterial).  query_out: [n_main + 6*n_eik][3]. */
+ * so the order is immaterial).  Sample s is coord[first + s*decimation]; `first` is 0 for a
+ * whole batch and the phase of the shard when the batch is split over GPUs, so that the union
+ * over shards is exactly the global coord[::decimation].  query_out: [n_main + 6*n_eik][3]. */
 int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
-                           float eps, float* query_out, void* stream);
+                           int32_t first, float eps, float* query_out, void* stream);
 
 int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels);
 

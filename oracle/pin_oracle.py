@@ -364,10 +364,11 @@ def mlp_backward(acts, params, dout):
     return dh.reshape(acts[0].shape), np.concatenate(flat)
 
 
-def eikonal_queries(coord, dec, eps):
+def eikonal_queries(coord, dec, eps, first=0):
     """mapper.py:682-686 + 986-1008: the 6*n_e central-difference query points in the
-    reference's concatenation order (x+, x-, y+, y-, z+, z-), each block [n_e,3]."""
-    x = np.asarray(coord, F32)[::dec]
+    reference's concatenation order (x+, x-, y+, y-, z+, z-), each block [n_e,3].
+    ``first`` = phase of a shard of a larger batch (0 for the reference's whole batch)."""
+    x = np.asarray(coord, F32)[first::dec]
     e = F32(eps)
     offs = [(e, 0, 0), (-e, 0, 0), (0, e, 0), (0, -e, 0), (0, 0, e), (0, 0, -e)]
     return np.concatenate([(x + np.array(o, F32)).astype(F32) for o in offs], 0)
@@ -375,13 +376,18 @@ def eikonal_queries(coord, dec, eps):
 
 def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat_params,
                dec_shape, sdf_scale, k, *, weighted_first=True, dec=10, eps=0.08, weight_e=0.5,
-               loss_weight_on=False, ekional=True, dtype=np.float64):
+               loss_weight_on=False, ekional=True, dtype=np.float64, eik_first=0, n_main_global=None,
+               n_eik_global=None):
     """One iteration of Mapper.mapping (utils/mapper.py:645-817) on a FIXED batch:
     forward (K1-K3), BCE + Eikonal(numerical gradient) loss, backward.
 
     ``searcher(points) -> dict`` must return :func:`query_feature` output with
     weighted_first=False vectors (geo_feat [N,k,F+3]) for the given points.
-    Returns dict(loss, sdf_loss, eik_loss, feat_grad [M+1,F], dec_grad [n_param], sdf_pred)."""
+    ``eik_first / n_main_global / n_eik_global`` evaluate one SHARD of a larger batch with the
+    losses normalised by the global counts: gradients of the shards then add up to
+    the whole-batch gradient.  Returns dict(loss, sdf_loss, eik_loss, feat_grad [M+1,F],
+    dec_grad [n_param], sdf_pred); with shard arguments the loss terms are the shard's SUMS
+    divided by the global counts."""
     T = dtype
     in_dim, hidden, levels = dec_shape
     params = unpack_decoder(np.asarray(flat_params, T), in_dim, hidden, levels)
@@ -417,26 +423,27 @@ def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat
         np.add.at(feat_grad, gather.reshape(-1), dfeat.reshape(-1, F))
         return gflat
 
-    bs = len(coord)
+    bs = n_main_global or len(coord)
     fw = forward(coord)
     sigma = s
     xl = fw["pred"] / sigma
     y = _sigmoid(np.asarray(sdf_label, T) / sigma)
     wt = np.abs(np.asarray(sample_weight, T)) if loss_weight_on else None
-    sdf_loss = bce_with_logits(xl, y, wt)
+    sdf_loss = bce_with_logits(xl, y, wt) * len(coord) / bs
     dxl = (_sigmoid(xl) - y) / bs
     if wt is not None:
         dxl = dxl * wt
     dec_grad = backward(fw, dxl / sigma)
     eik_loss = 0.0
     if ekional and weight_e > 0:
-        qe = eikonal_queries(coord, dec, eps)
+        qe = eikonal_queries(coord, dec, eps, eik_first)
         fe = forward(qe)
-        ne = len(qe) // 6
-        P = fe["pred"].reshape(6, ne)
+        ne_local = len(qe) // 6
+        ne = n_eik_global or ne_local
+        P = fe["pred"].reshape(6, ne_local)
         g = np.stack([(P[0] - P[1]), (P[2] - P[3]), (P[4] - P[5])], -1) / (2 * T(F32(eps)))
         nrm = np.linalg.norm(g, axis=-1)
-        eik_loss = ((nrm - 1.0) ** 2).mean()
+        eik_loss = ((nrm - 1.0) ** 2).sum() / ne
         with np.errstate(invalid="ignore", divide="ignore"):
             dg = np.where(nrm[:, None] > 0, g / nrm[:, None], 0.0)
         dg = dg * (2.0 * (nrm - 1.0) * weight_e / ne)[:, None] / (2 * T(F32(eps)))

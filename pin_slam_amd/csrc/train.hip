@@ -31,8 +31,8 @@ __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L) {
     return Qs * (12 + (size_t)L * H + (size_t)L * H + 1 + 2);
 }
 
-__global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, float eps,
-                                    float* __restrict__ q) {
+__global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, int first,
+                                    float eps, float* __restrict__ q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = n_main + 6 * n_eik;
     if (i >= total) return;
@@ -41,7 +41,7 @@ __global__ void make_queries_kernel(const float* __restrict__ coord, int n_main,
         return;
     }
     const int e = i - n_main, s = e / 6, a = e - 6 * s;
-    const int src = s * dec;  // coord[::dec]
+    const int src = first + s * dec;  // coord[::dec] of the GLOBAL batch (first = shard phase)
     float x = coord[3 * src], y = coord[3 * src + 1], z = coord[3 * src + 2];
     const float d = (a & 1) ? -eps : eps;  // order x+, x-, y+, y-, z+, z-
     if ((a >> 1) == 0) x += d; else if ((a >> 1) == 1) y += d; else z += d;
@@ -448,15 +448,16 @@ extern "C" int pin_gather_batch(const float* pool_coord, const float* pool_label
 }
 
 extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
-                                      float eps, float* query_out, void* stream) {
+                                      int32_t first, float eps, float* query_out, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n_main >= 0 && n_eik >= 0 && decimation >= 1, "bad sizes");
     const int total = n_main + 6 * n_eik;
     if (total == 0) return 0;
     PIN_CHECK_ARG(coord && query_out, "NULL pointer");
-    PIN_CHECK_ARG(n_eik == 0 || (long)(n_eik - 1) * decimation < n_main, "n_eik too large for decimation");
+    PIN_CHECK_ARG(first >= 0 && (n_eik == 0 || first + (long)(n_eik - 1) * decimation < n_main),
+                  "n_eik / first too large for decimation");
     hipLaunchKernelGGL(make_queries_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coord, n_main,
-                       n_eik, decimation, eps, query_out);
+                       n_eik, decimation, first, eps, query_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -85,13 +85,16 @@ class MapTrainer:
         self.gdec, self.gfeat = self.grad[:nd], self.grad[nd:]
         self.m = torch.zeros_like(self.grad)
         self.v = torch.zeros_like(self.grad)
-        self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal)
+        from .sharding import n_eik_global, shard_range
+        start, _ = shard_range(self.bs, rank, world)
+        self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
+                                    shard_start=start)
         self.coord = torch.empty((self.bs_local, 3), dtype=torch.float32, device=dev)
         self.label = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.ts = torch.empty((self.bs_local,), dtype=torch.int32, device=dev)
-        # global Eikonal count: every rank decimates its own contiguous shard
-        self.n_eik_global = self.buf.n_eik * world
+        # Eikonal samples are the global batch's coord[::dec]; each rank owns those in its shard
+        self.n_eik_global = n_eik_global(self.bs, self.dec) if eikonal else 0
         self.total_iter = 0
 
     def iteration(self, index_local: torch.Tensor, step: int):

@@ -237,10 +237,12 @@ from ._lib import TrainParams  # noqa: E402
 class TrainBuffers:
     """Caller-owned scratch for one training iteration of `n_main` samples (+ Eikonal)."""
 
-    def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda"):
+    def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda",
+                 shard_start: int = 0):
+        from .sharding import eikonal_shard
         self.n_main = int(n_main)
         self.dec = int(decimation)
-        self.n_eik = (self.n_main + self.dec - 1) // self.dec if eikonal else 0
+        self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if eikonal else (0, 0)
         self.Q = self.n_main + 6 * self.n_eik
         self.query = torch.empty((self.Q, 3), dtype=torch.float32, device=device)
         self.nbr = torch.empty((self.Q, k, 4), dtype=torch.float32, device=device)
@@ -257,7 +259,8 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad."""
     L = _lib.lib()
     s = _stream()
-    check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, float(np.float32(eik_eps)),
+    check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
+                                   float(np.float32(eik_eps)),
                                    _ptr(buf.query), s), "pin_train_make_queries")
     knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None))
     tp = TrainParams()

@@ -248,3 +248,31 @@ def test_mapping_two_iterations(gold):
     assert np.mean(dd < 1e-4) > 0.99
     np.testing.assert_allclose(cert.cpu().numpy(), d["map_cert_after"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(tsu.cpu().numpy(), d["map_ts_after"])
+
+
+def test_sharded_train_step_sums_to_full_batch(gold):
+    """Two contiguous shards of the batch (as two ranks would run them), normalised by the
+    global counts, accumulate to the reference's whole-batch gradient."""
+    from pin_slam_amd import ops, sharding
+    from tests import gpu_util as U
+    import dataclasses
+    d = gold
+    if not d["weighted_first"]:
+        pytest.skip("training kernel covers weighted_first=True")
+    k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
+    dec = int(d["map_dec"])
+    bs = d["map_coord0"].shape[0]
+    fs = dataclasses.replace(d["fs_loc"], certainty=U.dev(d["local_point_certainties"]))
+    gfeat = torch.zeros_like(fs.feats); gdec = torch.zeros_like(fs.dec)
+    tsu = U.dev(d["local_point_ts_update"], torch.int32)
+    world = 2
+    for r in range(world):
+        a, b = sharding.shard_range(bs, r, world)
+        buf = ops.TrainBuffers(b - a, dec, k, H, L, shard_start=a)
+        ops.train_step(d["st"], fs, buf, U.dev(d["map_coord0"][a:b]), U.dev(d["map_label0"][a:b]),
+                       U.dev(d["map_w0"][a:b]), U.dev(d["map_ts0"][a:b], torch.int32), fs.certainty, tsu, gfeat, gdec,
+                       sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"],
+                       global_n_main=bs, global_n_eik=sharding.n_eik_global(bs, dec))
+    gf, gd = d["map_gfeat0"], d["map_gdec0"]
+    assert np.max(np.abs(gfeat.cpu().numpy() - gf)) < 3e-4 * np.abs(gf).max()
+    assert np.max(np.abs(gdec.cpu().numpy() - gd)) < 3e-4 * np.abs(gd).max()

@@ -1,0 +1,82 @@
+"""The N > 1 mapper path on CPU: two gloo ranks shard one global batch exactly as
+engine.MapTrainer does (pin_slam_amd.sharding), evaluate their shards (the oracle stands in
+for the HIP kernels here -- this is a test of the sharding math and of the all-reduce
+plumbing, not of the kernels), all-reduce the flat [decoder | feature] gradient buffer and
+must reproduce the single-rank gradient of the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pin_oracle as O
+from pin_slam_amd import sharding
+from tests import golden_util as G
+
+
+def test_eikonal_shard_partition():
+    for bs, world, dec in [(16384, 8, 10), (512, 2, 10), (1 << 20, 8, 10), (1000, 4, 7)]:
+        picked = []
+        for r in range(world):
+            a, b = sharding.shard_range(bs, r, world)
+            first, cnt = sharding.eikonal_shard(a, b - a, dec)
+            picked += [a + first + s * dec for s in range(cnt)]
+        assert picked == list(range(0, bs, dec))
+        assert len(picked) == sharding.n_eik_global(bs, dec)
+
+
+def _shard_grad(d, rank, world):
+    k = int(d["query_nn_k"])
+    table = G.dense_table(d)
+    bs = d["map_coord0"].shape[0]
+    a, b = sharding.shard_range(bs, rank, world)
+    first, _ = sharding.eikonal_shard(a, b - a, int(d["map_dec"]))
+
+    def searcher(points):
+        s = O.radius_search(points, table, d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
+                            ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                            diff_travel_dist_local=d["diff_travel_dist_local"])
+        return O.query_feature(points, s, d["local_geo_features"], d["local_neural_points"], None, k,
+                               global2local=d["global2local"], weighted_first=False)
+
+    r = O.train_step(d["map_coord0"][a:b], d["map_label0"][a:b], d["map_w0"][a:b], searcher, d["local_geo_features"],
+                     d["local_neural_points"], d["dec_flat"], (11, int(d["dec_hidden"]), int(d["dec_levels"])),
+                     d["sdf_scale"], k, dec=int(d["map_dec"]), eps=d["map_eps"], weight_e=d["map_weight_e"],
+                     eik_first=first, n_main_global=bs, n_eik_global=sharding.n_eik_global(bs, int(d["map_dec"])))
+    return np.concatenate([r["dec_grad"], r["feat_grad"].ravel()]), r["loss"]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = G.load("c2_wf")
+    flat, loss = _shard_grad(d, rank, world)
+    t = torch.from_numpy(flat)
+    dist.all_reduce(t)  # the single collective of an iteration
+    l = torch.tensor([loss])
+    dist.all_reduce(l)
+    if rank == 0:
+        q.put((t.numpy(), float(l.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allreduce_equals_single_rank_gradient():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    flat, loss = q.get(timeout=240)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    d = G.load("c2_wf")
+    ref = np.concatenate([d["map_gdec0"], d["map_gfeat0"].ravel()])  # the REFERENCE's whole-batch gradient
+    assert np.max(np.abs(flat - ref)) < 2e-4 * np.abs(ref).max()
+    one, loss1 = _shard_grad(d, 0, 1)
+    assert np.max(np.abs(flat - one)) < 1e-9 * max(1.0, np.abs(one).max())
+    assert abs(loss - loss1) < 1e-9
