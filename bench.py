@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sort-scan", type=int, default=1, help="voxel-order the scan once per frame")
+    ap.add_argument("--bricks", type=int, default=1, help="per-frame brick cache for the kNN (identical results)")
     return ap.parse_args()
 
 
@@ -147,12 +148,16 @@ def main():
             b.record()
             ev_pairs.append((cur_ev["a"], b))
 
+    bricks = ops.BrickCache(dx, 2) if args.bricks else None
     frame_batches = [batches(args.map_iters) for _ in range(args.warmup + args.steps)]
     stats = {}
 
     def frame(i, timed):
         t0 = time.perf_counter()
-        T, cnt, res_cm, its = tracker.track(scan, T_init, args.reg_iters, early_exit=False)
+        if bricks is not None:  # rebuilt every frame, as reset_local_map does after each map update
+            bricks.build(st)
+            tracker.bricks = trainer.bricks = bricks
+        T, cnt, res_cm, its, _, _ = tracker.track(scan, T_init, args.reg_iters, early_exit=False)
         t1 = time.perf_counter()
         trainer.mapping(frame_batches[i])
         torch.cuda.synchronize()
@@ -210,13 +215,13 @@ def main():
         "config": {"workload": f"{args.workload}: {wl['desc']}; frame = {args.reg_iters} GN iterations (no early exit) "
                                f"+ {args.map_iters} mapping iterations of batch {args.bs} (+{trainer.buf.n_eik}x6 Eikonal)",
                    "neural_points": P, "scan_points": args.scan, "knn_k": k, "candidate_cells": Kc,
-                   "decoder": f"{L}x{H}", "occupancy_rho": round(rho, 4), "scan_voxel_sorted": bool(args.sort_scan),
+                   "decoder": f"{L}x{H}", "occupancy_rho": round(rho, 4), "scan_voxel_sorted": bool(args.sort_scan), "brick_cache": bool(args.bricks),
                    "parallelism": "1 GPU" if world == 1 else f"tracker replicas x{world}, mapper dp{world} (RCCL all-reduce)"},
         "mapper_samples_per_sec": round(world * args.bs * args.map_iters / float(np.mean(stats["map"])), 1),
         "tracker_ms_per_frame": round(1e3 * float(np.mean(stats["track"])), 3),
         "mapper_ms_per_frame": round(1e3 * float(np.mean(stats["map"])), 3),
         "gn_valid_points": int(stats["last"][1]), "gn_residual_cm": round(float(stats["last"][2]), 4),
-        "roofline": {"kernel": "knn_query_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+        "roofline": {"kernel": "knn_brick_kernel" if args.bricks else "knn_query_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
                      "algorithmic_bytes_per_query": round(bytes_q, 1)},

@@ -61,6 +61,24 @@ typedef struct pin_search_params {
     float   max_valid_dist2;     /* 3*((num_nei_cells+1)*resolution)^2 (neural_points.py:947) */
 } pin_search_params;
 
+/* ---- brick cache: a cell-coherent, per-frame view of the SAME lookups (csrc/brick.hip) ----
+ * Built by pin_brick_build from a pin_search_params (its travel_dist / global2local settings
+ * are baked in); pin_knn_query_bricks must be called with the same search params and returns
+ * results identical to pin_knn_query.  All buffers are caller-owned. */
+typedef struct pin_brick_cache {
+    uint64_t* dir_keys;      /* [dir_mask+1] open-addressing directory: packed brick coordinate */
+    int32_t*  dir_vals;      /* [dir_mask+1] brick id */
+    uint64_t* brick_keys;    /* [max_bricks] */
+    uint64_t* brick_mask;    /* [max_bricks] occupancy of the 4x4x4 cells, bit = (x&3)<<4|(y&3)<<2|(z&3) */
+    int32_t*  brick_base;    /* [max_bricks] first entry of the brick */
+    float*    entries;       /* [max_entries][4] x, y, z, neighbour-index bits (as in the kNN record) */
+    const int32_t* cand_dx;  /* [n_cand][3] candidate cell offsets (neighbor_dx, neural_points.py:919-932) */
+    uint32_t dir_mask;       /* directory size - 1 (size is a power of two) */
+    int32_t max_bricks;
+    int32_t max_entries;
+    int32_t n_dilate;        /* = num_nei_cells (<= 2): bricks cover every cell within n of a local point */
+} pin_brick_cache;
+
 /* ---- the implicit field: feature tables + decoder (NeuralPoints.query_feature
  * neural_points.py:530-746, Decoder.mlp/sdf model/decoder.py:61-85) -------------- */
 typedef struct pin_field {
@@ -90,6 +108,34 @@ typedef struct pin_gn_params {
     float gm_grad;           /* reg_GM_grad, <=0 disables */
 } pin_gn_params;
 #define PIN_GN_NSUMS 32
+#define PIN_GN_REPLICAS 64
+/* Device-resident state of one Tracker.tracking call (utils/tracker.py:114-184), doubles:
+ * [0..15] current pose T (row-major 4x4)   [16] last_sdf_residual_cm   [17] sdf_residual_cm
+ * [18] valid point count   [19] valid_flag   [20] converged   [21] done (loop has ended)
+ * [22] iterations run      [23] weighted mse (cov scale)     [24..59] un-damped J^T W J (6x6)
+ * [60] source point count */
+#define PIN_GN_STATE_DOUBLES 64
+#define PIN_GN_STATE_LAST_RES 16
+#define PIN_GN_STATE_RES 17
+#define PIN_GN_STATE_CNT 18
+#define PIN_GN_STATE_VALID 19
+#define PIN_GN_STATE_CONVERGED 20
+#define PIN_GN_STATE_DONE 21
+#define PIN_GN_STATE_ITERS 22
+#define PIN_GN_STATE_MSE 23
+#define PIN_GN_STATE_NRAW 24
+#define PIN_GN_STATE_NSRC 60
+
+typedef struct pin_gn_loop_params {      /* Tracker.tracking constants (tracker.py:77-101) */
+    double lm_lambda;                    /* reg_lm_lambda */
+    double term_thre_deg, term_thre_m;   /* reg_term_thre_deg / _m */
+    double min_valid_ratio;              /* 0.2, 0.15 for loop registration */
+    double max_increment_ratio;          /* 1.1 */
+    int32_t min_valid_points;            /* 30 */
+    int32_t iter_n;                      /* reg_iter_n */
+    int32_t early_exit;                  /* 0: ignore the convergence test (benchmark worst case) */
+} pin_gn_loop_params;
+
 /* sums layout (double[PIN_GN_NSUMS]): [0..20] upper triangle of sum w J J^T (row-major,
  * J = [p x g, g]); [21..26] sum w J r; [27] sum w; [28] sum |r|; [29] valid count;
  * [30] sum w r^2; [31] reserved.  w is the un-normalised robust weight; the host applies
@@ -184,6 +230,35 @@ int pin_radius_search(const pin_search_params* sp, const float* query, int32_t n
 int pin_knn_query(const pin_search_params* sp, const float* query, int32_t n, int32_t k,
                   const float* pose_host, float* query_out, float* nbr_out,
                   int32_t* nn_count_out, void* stream);
+
+/* ---- device-resident Gauss-Newton loop: no host round trip per iteration ---------------
+ * pin_gn_state_init: state <- (T_init, last_res = 1e5, valid = 1, everything else 0).
+ * pin_gn_knn: pin_knn_query / pin_knn_query_bricks (bc may be NULL) with the pose taken from
+ *   the state; returns immediately on the device once the loop is done.
+ * pin_gn_accumulate_solve: pin_gn_accumulate on the transformed points, then ONE wave sums the
+ *   replicas, applies w /= 2 mean(w) (tracker.py:524), LM damping, the 6x6 float64 solve and
+ *   expmap (tracker.py:656-679), T <- dT T and the reference's validity / convergence rules
+ *   (tracker.py:147-184), and clears the sums for the next iteration (sums must be zeroed by
+ *   the caller before the first one).  The host reads the 64 doubles back once per frame. */
+int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, void* stream);
+int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n,
+               int32_t k, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
+               void* stream);
+int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
+                            const float* cur, const float* nbr, const int32_t* nn_count,
+                            const float* sdf_labels, int32_t n, double* sums, double* state,
+                            void* stream);
+
+/* Per-frame build of the brick cache (after reset_local_map / update).  counters_out:
+ * int32[4] on the device = (bricks, entries, overflow flags, 0); flags != 0 or counts beyond
+ * the capacities mean the caller must enlarge the buffers and rebuild. */
+int pin_brick_build(const pin_search_params* sp, const pin_brick_cache* bc, int32_t* counters_out,
+                    void* stream);
+
+/* pin_knn_query through the brick cache: same arguments, same outputs, same results. */
+int pin_knn_query_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query,
+                         int32_t n, int32_t k, const float* pose_host, float* query_out,
+                         float* nbr_out, int32_t* nn_count_out, void* stream);
 
 /* K2: NeuralPoints.query_feature tensor API (neural_points.py:590-746) from a kNN result.
  * feat_out: [n][11] (weighted_first) or [n][k][11]; weight_out [n][k]; certainty_out [n]

@@ -32,6 +32,14 @@ class SearchParams(C.Structure):
     ]
 
 
+class BrickCacheC(C.Structure):
+    _fields_ = [
+        ("dir_keys", vp), ("dir_vals", vp), ("brick_keys", vp), ("brick_mask", vp), ("brick_base", vp),
+        ("entries", vp), ("cand_dx", vp), ("dir_mask", C.c_uint32), ("max_bricks", C.c_int32),
+        ("max_entries", C.c_int32), ("n_dilate", C.c_int32),
+    ]
+
+
 class Field(C.Structure):
     _fields_ = [
         ("feats", vp), ("certainty", vp), ("orient", vp), ("pos", vp), ("dec", vp),
@@ -45,6 +53,17 @@ class GnParams(C.Structure):
         ("valid_nn_k", C.c_int32), ("min_grad_norm", C.c_float), ("max_grad_norm", C.c_float),
         ("max_sdf_std", C.c_float), ("gm_dist", C.c_float), ("gm_grad", C.c_float),
     ]
+
+
+class GnLoopParams(C.Structure):
+    _fields_ = [
+        ("lm_lambda", C.c_double), ("term_thre_deg", C.c_double), ("term_thre_m", C.c_double),
+        ("min_valid_ratio", C.c_double), ("max_increment_ratio", C.c_double), ("min_valid_points", C.c_int32),
+        ("iter_n", C.c_int32), ("early_exit", C.c_int32),
+    ]
+
+
+PIN_GN_STATE_DOUBLES = 64
 
 
 class MapArrays(C.Structure):
@@ -91,6 +110,11 @@ SIGNATURES = {
     "pin_pack_positions": (i32, [vp, vp, i32, i32, vp, vp]),
     "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),
     "pin_knn_query": (i32, [P(SearchParams), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_gn_state_init": (i32, [vp, vp, i32, vp]),
+    "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_gn_accumulate_solve": (i32, [P(Field), P(GnParams), P(GnLoopParams), vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pin_brick_build": (i32, [P(SearchParams), P(BrickCacheC), vp, vp]),
+    "pin_knn_query_bricks": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_query_feature": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),

@@ -1,0 +1,335 @@
+// Brick cache: a cell-coherent view of the voxel hash for the per-frame hot queries (gfx950).
+//
+// The reference probes  table[hash(cell)]  for Kc candidate cells per query
+// (model/neural_points.py:965-978); its hash scatters neighbouring cells over a 200 MB
+// table, so every probe is its own memory sector and is followed by two more dependent random
+// gathers (position/timestamp, global2local).  Measured on MI355X (profiles/r01_knn_pmc.json):
+// 2.7x the algorithmic bytes, 60 % L2 hit rate.
+//
+// Once per frame (after reset_local_map) we evaluate the SAME lookups for every cell of every
+// 4x4x4-cell "brick" near a local neural point and store the answers contiguously:
+//   directory : open-addressing hash  brick coordinate -> brick id   (ours; small, L2 resident)
+//   header    : 64-bit occupancy mask + base offset per brick
+//   entries   : (x, y, z, local index bits) per occupied cell, contiguous per brick
+// An entry is exactly what the reference chain  table -> travel-distance filter -> global2local
+// would yield for that cell (hash collisions included: a colliding far point is stored and is
+// rejected by the distance test at query time, as in the reference).  Entries that can never
+// pass the distance test for any query that probes the cell are pruned.  Cells of bricks that
+// are not in the directory fall back to the exact slow path, so results are identical to
+// pin_knn_query in all cases (tests/test_gpu_bricks.py checks bit equality).
+#include "pin_common.h"
+
+namespace pin {
+
+constexpr unsigned long long BRICK_EMPTY = ~0ull;
+constexpr int BRICK_GROUP = 16;
+constexpr int BRICK_BLOCK = 256;
+
+__device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz) {
+    return ((unsigned long long)(unsigned)(bx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(by + (1 << 20)) << 21) |
+           (unsigned long long)(unsigned)(bz + (1 << 20));
+}
+__device__ __forceinline__ unsigned int mix64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+__device__ __forceinline__ int dir_find(const pin_brick_cache& bc, unsigned long long key) {
+    unsigned int h = mix64(key) & bc.dir_mask;
+    for (int probe = 0; probe < 64; ++probe) {
+        const unsigned long long k = bc.dir_keys[h];
+        if (k == key) return bc.dir_vals[h];
+        if (k == BRICK_EMPTY) return -1;
+        h = (h + 1) & bc.dir_mask;
+    }
+    return -1;
+}
+
+// ---- build ----------------------------------------------------------------------------------
+// A: every local point registers the (up to 8) bricks that cover its +-n cell neighbourhood.
+__global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin_search_params sp, int n_dilate,
+                                                         int* __restrict__ counters) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= sp.n_points) return;
+    if (sp.global2local != nullptr && sp.global2local[j] < 0) return;  // not in the local map
+    const float4 P = reinterpret_cast<const float4*>(sp.pos4)[j];
+    const int g[3] = {(int)voxel_coord(P.x, sp.resolution), (int)voxel_coord(P.y, sp.resolution),
+                      (int)voxel_coord(P.z, sp.resolution)};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = (g[a] - n_dilate) >> 2; hi[a] = (g[a] + n_dilate) >> 2; }
+    for (int bx = lo[0]; bx <= hi[0]; ++bx)
+        for (int by = lo[1]; by <= hi[1]; ++by)
+            for (int bz = lo[2]; bz <= hi[2]; ++bz) {
+                const unsigned long long key = brick_key(bx, by, bz);
+                unsigned int h = mix64(key) & bc.dir_mask;
+                for (int probe = 0; probe < 64; ++probe) {
+                    // most points find their bricks already registered: plain load before the CAS
+                    unsigned long long prev = __hip_atomic_load(reinterpret_cast<unsigned long long*>(bc.dir_keys) + h,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == BRICK_EMPTY)
+                        prev = atomicCAS(reinterpret_cast<unsigned long long*>(bc.dir_keys) + h, BRICK_EMPTY, key);
+                    if (prev == BRICK_EMPTY) {  // we own the slot: allocate a brick id
+                        const int id = atomicAdd(counters + 0, 1);
+                        if (id < bc.max_bricks) { bc.brick_keys[id] = key; bc.dir_vals[h] = id; }
+                        else { bc.dir_vals[h] = -1; atomicOr(counters + 2, 1); }
+                        break;
+                    }
+                    if (prev == key) break;
+                    h = (h + 1) & bc.dir_mask;
+                    if (probe == 63) atomicOr(counters + 2, 2);
+                }
+            }
+}
+
+// the reference's lookup chain for one cell: table -> time filter -> index space
+__device__ __forceinline__ bool lookup_cell(const pin_search_params& sp, long long cx, long long cy, long long cz,
+                                            float d_cur, float4& P, int& l) {
+    const long long h = cx * PRIME0 + cy * PRIME1 + cz * PRIME2;
+    long long m = h % sp.buffer_size;
+    if (m < 0) m += sp.buffer_size;
+    const int j = sp.table[m];
+    if (j < 0) return false;
+    P = reinterpret_cast<const float4*>(sp.pos4)[j];
+    if (sp.travel_dist != nullptr) {
+        const float dts = sp.travel_dist[__float_as_int(P.w)];
+        if (!(fabsf(d_cur - dts) < sp.diff_travel_dist_local)) return false;
+    }
+    l = j;
+    if (sp.global2local != nullptr) {
+        l = sp.global2local[j];
+        if (l == PIN_NONLOCAL) l = 1 | PIN_NBR_QUIRK_BIT;
+    }
+    return l >= 0;
+}
+
+// B: one wave per brick, one lane per cell; ballot -> mask, one atomic -> base, entries.
+__global__ __launch_bounds__(64) void brick_fill_kernel(pin_brick_cache bc, pin_search_params sp, float prune_dist2,
+                                                        int* __restrict__ counters) {
+    const int b = blockIdx.x;
+    if (b >= min(counters[0], bc.max_bricks)) return;
+    const int lane = threadIdx.x;
+    const unsigned long long key = bc.brick_keys[b];
+    const int bx = (int)((key >> 42) & 0x1fffff) - (1 << 20), by = (int)((key >> 21) & 0x1fffff) - (1 << 20),
+              bz = (int)(key & 0x1fffff) - (1 << 20);
+    const int cx = bx * 4 + (lane >> 4), cy = by * 4 + ((lane >> 2) & 3), cz = bz * 4 + (lane & 3);
+    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+    float4 P; int l = -1;
+    bool ok = lookup_cell(sp, cx, cy, cz, d_cur, P, l);
+    if (ok) {  // prune what no probing query can accept (exactness preserved: see header)
+        const float r = sp.resolution;
+        const float ex = P.x - (cx + 0.5f) * r, ey = P.y - (cy + 0.5f) * r, ez = P.z - (cz + 0.5f) * r;
+        ok = (ex * ex + ey * ey + ez * ez) <= prune_dist2;
+    }
+    const unsigned long long mask = __ballot(ok);
+    int base = 0;
+    if (lane == 0) {
+        base = atomicAdd(counters + 1, __popcll(mask));
+        bc.brick_mask[b] = mask;
+        bc.brick_base[b] = base;
+    }
+    base = __shfl(base, 0, 64);
+    if (ok) {
+        const int e = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (e < bc.max_entries) reinterpret_cast<float4*>(bc.entries)[e] = make_float4(P.x, P.y, P.z, __int_as_float(l));
+        else atomicOr(counters + 2, 4);
+    }
+}
+
+__global__ void brick_clear_kernel(unsigned long long* keys, int n, int* counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = BRICK_EMPTY;
+    if (i < 4) counters[i] = 0;
+}
+
+// ---- query ----------------------------------------------------------------------------------
+struct PoseB {
+    float m[12];
+    int on;
+};
+
+template <int R>
+__global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
+                                                                const float* __restrict__ query, int n, int k, PoseB pose,
+                                                                float* __restrict__ query_out, float4* __restrict__ nbr,
+                                                                int* __restrict__ nn_count, const double* __restrict__ state) {
+    if (state != nullptr) {
+        if (state[PIN_GN_STATE_DONE] != 0.0) return;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pose.m[i] = (float)state[i];
+        pose.on = 1;
+    }
+    const int sub = threadIdx.x & (BRICK_GROUP - 1);
+    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / BRICK_GROUP;
+    const bool active = qi < n;
+    const int qq = active ? qi : n - 1;
+    float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+    if (pose.on) {
+        const float* m = pose.m;
+        const float tx = fmaf(qz, m[2], fmaf(qy, m[1], qx * m[0])) + m[3];
+        const float ty = fmaf(qz, m[6], fmaf(qy, m[5], qx * m[4])) + m[7];
+        const float tz = fmaf(qz, m[10], fmaf(qy, m[9], qx * m[8])) + m[11];
+        qx = tx; qy = ty; qz = tz;
+        if (query_out != nullptr && active && sub == 0) {
+            query_out[3 * qi + 0] = qx; query_out[3 * qi + 1] = qy; query_out[3 * qi + 2] = qz;
+        }
+    }
+    const long long gx = voxel_coord(qx, sp.resolution), gy = voxel_coord(qy, sp.resolution),
+                    gz = voxel_coord(qz, sp.resolution);
+    const int nd = bc.n_dilate;
+    const int b0x = (int)((gx - nd) >> 2), b0y = (int)((gy - nd) >> 2), b0z = (int)((gz - nd) >> 2);
+    // lanes 0..7 resolve the 2x2x2 bricks that cover the candidate window
+    int my_id = -1, my_base = 0;
+    unsigned long long my_mask = 0;
+    if (sub < 8) {
+        const int bx = b0x + (sub >> 2), by = b0y + ((sub >> 1) & 1), bz = b0z + (sub & 1);
+        my_id = dir_find(bc, brick_key(bx, by, bz));
+        if (my_id >= 0) { my_mask = bc.brick_mask[my_id]; my_base = bc.brick_base[my_id]; }
+    }
+    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+    const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+
+    unsigned long long key[R];
+    float4 P[R];
+    int li[R];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c = r * BRICK_GROUP + sub;
+        key[r] = ~0ull; li[r] = -1; P[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool has = c < sp.n_cand;
+        const int cc = has ? c : 0;
+        const long long cx = gx + bc.cand_dx[3 * cc], cy = gy + bc.cand_dx[3 * cc + 1], cz = gz + bc.cand_dx[3 * cc + 2];
+        const int sel = ((int)((cx >> 2) - b0x) << 2) | ((int)((cy >> 2) - b0y) << 1) | (int)((cz >> 2) - b0z);
+        // all 16 lanes take part in the shuffles
+        const int id = __shfl(my_id, sel & 7, BRICK_GROUP);
+        const int base = __shfl(my_base, sel & 7, BRICK_GROUP);
+        const unsigned long long mask = __shfl(my_mask, sel & 7, BRICK_GROUP);
+        if (!has) continue;
+        bool ok = false;
+        int l = -1;
+        float4 E;
+        if (id >= 0) {
+            const int bit = (int)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
+            if ((mask >> bit) & 1ull) {
+                E = entries[base + __popcll(mask & ((1ull << bit) - 1ull))];
+                l = __float_as_int(E.w);
+                ok = true;
+            }
+        } else {
+            ok = lookup_cell(sp, cx, cy, cz, d_cur, E, l);  // exact slow path for uncached bricks
+        }
+        if (ok) {
+            const float dx = E.x - qx, dy = E.y - qy, dz = E.z - qz;
+            const float d2 = dist2_exact(dx, dy, dz);
+            if (!(d2 > sp.max_valid_dist2)) {
+                key[r] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+                li[r] = l;
+                P[r].x = -dx; P[r].y = -dy; P[r].z = -dz;
+                ++cnt;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = BRICK_GROUP / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, BRICK_GROUP);
+    if (active && sub == 0) nn_count[qi] = cnt;
+
+    float4* __restrict__ out = nbr + (size_t)qq * k;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) best = key[r] < best ? key[r] : best;
+        unsigned long long win = best;
+#pragma unroll
+        for (int o = BRICK_GROUP / 2; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(win, o, BRICK_GROUP);
+            win = other < win ? other : win;
+        }
+        if (win == ~0ull) {
+            if (active && sub == 0)
+                for (int u = t; u < k; ++u) out[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            break;
+        }
+        if (best == win) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (key[r] == win) {
+                    if (active) out[t] = make_float4(P[r].x, P[r].y, P[r].z, __int_as_float(li[r]));
+                    key[r] = ~0ull;
+                }
+        }
+    }
+}
+
+}  // namespace pin
+
+using namespace pin;
+
+extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cache* bc, int32_t* counters_out,
+                               void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(sp && bc && counters_out, "NULL pointer");
+    PIN_CHECK_ARG(sp->n_points > 0 && sp->table && sp->pos4, "empty map");
+    PIN_CHECK_ARG(bc->dir_keys && bc->dir_vals && bc->brick_keys && bc->brick_mask && bc->brick_base && bc->entries,
+                  "brick cache buffers NULL");
+    PIN_CHECK_ARG((bc->dir_mask & (bc->dir_mask + 1)) == 0 && bc->dir_mask > 0, "directory size must be a power of two");
+    PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 3, "n_dilate must be in [0, 3]");
+    hipStream_t s = as_stream(stream);
+    const int D = (int)bc->dir_mask + 1;
+    hipLaunchKernelGGL(brick_clear_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s,
+                       reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out);
+    hipLaunchKernelGGL(brick_mark_kernel, dim3(cdiv(sp->n_points, 256)), dim3(256), 0, s, *bc, *sp, bc->n_dilate,
+                       counters_out);
+    // a probing query sits within (n+1) cells (per axis) of the cell centre and accepts points
+    // within sqrt(max_valid_dist2): anything farther from the cell centre can never be accepted
+    const float reach = (bc->n_dilate + 1.0f) * sp->resolution * 1.7320508f + sqrtf(sp->max_valid_dist2);
+    const float prune = reach * reach * 1.02f;
+    hipLaunchKernelGGL(brick_fill_kernel, dim3(bc->max_bricks), dim3(64), 0, s, *bc, *sp, prune, counters_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
+                      const float* pose_host, const double* state, float* query_out, float* nbr_out,
+                      int32_t* nn_count_out, void* stream);
+
+extern "C" int pin_knn_query_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query,
+                                    int32_t n, int32_t k, const float* pose_host, float* query_out, float* nbr_out,
+                                    int32_t* nn_count_out, void* stream) {
+    PIN_ENTER();
+    return knn_bricks(sp, bc, query, n, k, pose_host, nullptr, query_out, nbr_out, nn_count_out, stream);
+}
+
+namespace pin {
+int knn_bricks_dev(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
+                   const double* state, float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream) {
+    return knn_bricks(sp, bc, query, n, k, nullptr, state, query_out, nbr_out, nn_count_out, stream);
+}
+}  // namespace pin
+
+static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
+                      const float* pose_host, const double* state, float* query_out, float* nbr_out,
+                      int32_t* nn_count_out, void* stream) {
+    PIN_CHECK_ARG(sp && bc, "NULL params");
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K, "k must be in [1, 8]");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr_out && nn_count_out && bc->cand_dx, "NULL pointer");
+    PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && sp->n_cand <= 256, "bad search state");
+    PoseB pose;
+    pose.on = pose_host != nullptr;
+    if (pose.on) memcpy(pose.m, pose_host, sizeof(pose.m));
+    const dim3 grid(cdiv((long)n * BRICK_GROUP, BRICK_BLOCK)), block(BRICK_BLOCK);
+    float4* nbr = reinterpret_cast<float4*>(nbr_out);
+    hipStream_t s = as_stream(stream);
+    const int rounds = cdiv(sp->n_cand, BRICK_GROUP);
+#define PIN_LAUNCH_KB(R) \
+    hipLaunchKernelGGL(knn_brick_kernel<R>, grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
+    if (rounds <= 3) PIN_LAUNCH_KB(3);
+    else if (rounds <= 6) PIN_LAUNCH_KB(6);
+    else if (rounds <= 10) PIN_LAUNCH_KB(10);
+    else PIN_LAUNCH_KB(16);
+#undef PIN_LAUNCH_KB
+    PIN_CHECK_LAUNCH();
+    return 0;
+}

@@ -25,7 +25,14 @@ struct Pose34 {
 template <int R>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_query_kernel(
     pin_search_params sp, const float* __restrict__ query, int n, int k, Pose34 pose,
-    float* __restrict__ query_out, float4* __restrict__ nbr, int* __restrict__ nn_count) {
+    float* __restrict__ query_out, float4* __restrict__ nbr, int* __restrict__ nn_count,
+    const double* __restrict__ state) {
+    if (state != nullptr) {  // device-resident GN loop: pose from the state, stop when done
+        if (state[PIN_GN_STATE_DONE] != 0.0) return;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pose.m[i] = (float)state[i];
+        pose.on = 1;
+    }
     const int sub = threadIdx.x & (GROUP - 1);
     const int qi = (blockIdx.x * KNN_BLOCK + threadIdx.x) / GROUP;
     const bool active = qi < n;
@@ -222,10 +229,25 @@ extern "C" int pin_radius_search(const pin_search_params* sp, const float* query
     return 0;
 }
 
+static int knn_direct(const pin_search_params* sp, const float* query, int32_t n, int32_t k, const float* pose_host,
+                      const double* state, float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream);
+
 extern "C" int pin_knn_query(const pin_search_params* sp, const float* query, int32_t n, int32_t k,
                              const float* pose_host, float* query_out, float* nbr_out,
                              int32_t* nn_count_out, void* stream) {
     PIN_ENTER();
+    return knn_direct(sp, query, n, k, pose_host, nullptr, query_out, nbr_out, nn_count_out, stream);
+}
+
+namespace pin {
+int knn_direct_dev(const pin_search_params* sp, const float* query, int32_t n, int32_t k, const double* state,
+                   float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream) {
+    return knn_direct(sp, query, n, k, nullptr, state, query_out, nbr_out, nn_count_out, stream);
+}
+}  // namespace pin
+
+static int knn_direct(const pin_search_params* sp, const float* query, int32_t n, int32_t k, const float* pose_host,
+                      const double* state, float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream) {
     if (int e = check_search(sp)) return e;
     PIN_CHECK_ARG(n >= 0, "n < 0");
     PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K, "k must be in [1, 8]");
@@ -240,7 +262,7 @@ extern "C" int pin_knn_query(const pin_search_params* sp, const float* query, in
     hipStream_t s = as_stream(stream);
     const int rounds = cdiv(sp->n_cand, GROUP);
 #define PIN_LAUNCH_KNN(R) \
-    hipLaunchKernelGGL(knn_query_kernel<R>, grid, block, 0, s, *sp, query, n, k, pose, query_out, nbr, nn_count_out)
+    hipLaunchKernelGGL(knn_query_kernel<R>, grid, block, 0, s, *sp, query, n, k, pose, query_out, nbr, nn_count_out, state)
     if (rounds <= 3) PIN_LAUNCH_KNN(3);
     else if (rounds <= 6) PIN_LAUNCH_KNN(6);
     else if (rounds <= 10) PIN_LAUNCH_KNN(10);

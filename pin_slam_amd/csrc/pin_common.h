@@ -37,6 +37,12 @@ int fail(int code, const char* fmt, ...);
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// internal: kNN launches whose pose / stop flag live in the device-resident GN state
+int knn_direct_dev(const pin_search_params* sp, const float* query, int32_t n, int32_t k, const double* state,
+                   float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream);
+int knn_bricks_dev(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
+                   const double* state, float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream);
+
 // ---- device helpers ----------------------------------------------------------------
 constexpr long long PRIME0 = 73856093LL, PRIME1 = 19349669LL, PRIME2 = 83492791LL;
 constexpr float IDW_EPS = 1e-15f;

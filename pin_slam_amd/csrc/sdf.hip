@@ -13,7 +13,7 @@
 namespace pin {
 
 constexpr int SDF_BLOCK = 128;
-constexpr int GN_REPLICAS = 64;  // sums are scattered over 64 replicas to spread atomics
+constexpr int GN_REPLICAS = PIN_GN_REPLICAS;  // sums are scattered over 64 replicas to spread atomics
 
 struct Nbrs {
     float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];  // q - P (global position)
@@ -249,8 +249,10 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
                                                                   const int* __restrict__ nn_count,
                                                                   const float* __restrict__ labels, int n,
                                                                   double* __restrict__ sums, float* __restrict__ sdf_out,
-                                                                  float* __restrict__ grad_out) {
+                                                                  float* __restrict__ grad_out,
+                                                                  const double* __restrict__ state) {
     __shared__ float lds[H * SDF_BLOCK];
+    if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
     const int qi = blockIdx.x * SDF_BLOCK + threadIdx.x;
     float v[PIN_GN_NSUMS];
 #pragma unroll
@@ -288,6 +290,102 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
         const double t = wave_sum((double)v[i]);
         if (lane == 0 && t != 0.0) atomicAdd(dst + i, t);
     }
+}
+
+// ---- device-side normal-equation solve + loop control (one wave) ---------------------------
+// implicit_reg (utils/tracker.py:656-679) and the bookkeeping of Tracker.tracking (:147-184).
+__global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums, double* __restrict__ st,
+                                                      pin_gn_loop_params lp) {
+    __shared__ double s[PIN_GN_NSUMS];
+    const int lane = threadIdx.x;
+    if (st[PIN_GN_STATE_DONE] != 0.0) return;
+    if (lane < PIN_GN_NSUMS) {
+        double a = 0.0;
+        for (int r = 0; r < GN_REPLICAS; ++r) a += sums[r * PIN_GN_NSUMS + lane];
+        s[lane] = a;
+    }
+    __syncthreads();
+    for (int i = lane; i < GN_REPLICAS * PIN_GN_NSUMS; i += 64) sums[i] = 0.0;  // ready for the next iteration
+    if (lane != 0) return;
+    const double cnt = rint(s[29]);
+    double dT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double res_cm = 0.0;
+    if (cnt >= 10.0) {  // tracker.py:430-432
+        const double scale = cnt / (2.0 * s[27]);  // w /= 2*mean(w)
+        double N[6][7];
+        int o = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { N[a][b] = N[b][a] = scale * s[o++]; }
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) st[PIN_GN_STATE_NRAW + a * 6 + b] = N[a][b];
+            N[a][6] = -scale * s[21 + a];
+        }
+        st[PIN_GN_STATE_MSE] = scale * s[30] / cnt;
+        for (int a = 0; a < 6; ++a) N[a][a] += lp.lm_lambda * N[a][a];
+        // Gaussian elimination with partial pivoting (float64)
+        for (int c = 0; c < 6; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < 6; ++r) if (fabs(N[r][c]) > fabs(N[piv][c])) piv = r;
+            if (piv != c) for (int b = 0; b < 7; ++b) { const double t = N[c][b]; N[c][b] = N[piv][b]; N[piv][b] = t; }
+            const double inv = 1.0 / N[c][c];
+            for (int r = c + 1; r < 6; ++r) {
+                const double f = N[r][c] * inv;
+                for (int b = c; b < 7; ++b) N[r][b] -= f * N[c][b];
+            }
+        }
+        double t[6];
+        for (int r = 5; r >= 0; --r) {
+            double acc = N[r][6];
+            for (int b = r + 1; b < 6; ++b) acc -= N[r][b] * t[b];
+            t[r] = acc / N[r][r];
+        }
+        // expmap (tracker.py:784-795)
+        const double ang = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const double ax = t[0] / ang, ay = t[1] / ang, az = t[2] / ang;
+        const double sn = sin(ang), cs = 1.0 - cos(ang);
+        const double S[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double ss = 0.0;
+                for (int c = 0; c < 3; ++c) ss += S[a * 3 + c] * S[c * 3 + b];
+                dT[a * 4 + b] = (a == b ? 1.0 : 0.0) + S[a * 3 + b] * sn + ss * cs;
+            }
+        dT[3] = t[3]; dT[7] = t[4]; dT[11] = t[5];
+        res_cm = s[28] / cnt * 100.0;
+    }
+    // T = dT @ T
+    double Tn[16];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            double acc = 0.0;
+            for (int c = 0; c < 4; ++c) acc += dT[a * 4 + c] * st[c * 4 + b];
+            Tn[a * 4 + b] = acc;
+        }
+    for (int i = 0; i < 16; ++i) st[i] = Tn[i];
+    st[PIN_GN_STATE_RES] = res_cm;
+    st[PIN_GN_STATE_CNT] = cnt;
+    const double last = st[PIN_GN_STATE_LAST_RES];
+    bool valid = st[PIN_GN_STATE_VALID] != 0.0;
+    if ((res_cm - last) / last > lp.max_increment_ratio) valid = false;  // tracker.py:150-159
+    else st[PIN_GN_STATE_LAST_RES] = res_cm;
+    const double nsrc = st[PIN_GN_STATE_NSRC];
+    if (cnt < lp.min_valid_points || cnt / nsrc < lp.min_valid_ratio) valid = false;  // :161-169
+    st[PIN_GN_STATE_VALID] = valid ? 1.0 : 0.0;
+    const int i = (int)st[PIN_GN_STATE_ITERS];
+    st[PIN_GN_STATE_ITERS] = i + 1;
+    const bool converged = st[PIN_GN_STATE_CONVERGED] != 0.0;
+    if (!valid || converged || i + 1 >= lp.iter_n) { st[PIN_GN_STATE_DONE] = 1.0; return; }  // :171-172
+    const double rot_deg = acos((dT[0] + dT[5] + dT[10] - 1.0) / 2.0) * 180.0 / 3.14159265358979323846;
+    const double tran = sqrt(dT[3] * dT[3] + dT[7] * dT[7] + dT[11] * dT[11]);
+    if ((lp.early_exit && fabs(rot_deg) < lp.term_thre_deg && tran < lp.term_thre_m) || i == lp.iter_n - 2)
+        st[PIN_GN_STATE_CONVERGED] = 1.0;  // :179-184
+}
+
+__global__ void gn_state_init_kernel(double* st, int n_src) {
+    const int i = threadIdx.x;
+    if (i >= 16 && i < PIN_GN_STATE_DOUBLES) st[i] = 0.0;
+    __syncthreads();
+    if (i == 0) { st[PIN_GN_STATE_LAST_RES] = 1e5; st[PIN_GN_STATE_VALID] = 1.0; st[PIN_GN_STATE_NSRC] = (double)n_src; }
 }
 
 // ---- tensor-API kernels (Mesher / drop-in query_feature, Decoder.sdf) --------------------
@@ -409,7 +507,41 @@ extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, co
     PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
     const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
     PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, query, reinterpret_cast<const float4*>(nbr),
-                    nn_count, sdf_labels, n, sums_out, sdf_out, grad_out);
+                    nn_count, sdf_labels, n, sums_out, sdf_out, grad_out, (const double*)nullptr);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(state && T_init_host && n_src > 0, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    PIN_CHECK_HIP(hipMemcpyAsync(state, T_init_host, 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gn_state_init_kernel, dim3(1), dim3(64), 0, s, state, n_src);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
+                          const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(state && cur_out, "state / cur_out NULL");
+    if (bc != nullptr) return knn_bricks_dev(sp, bc, src, n, k, state, cur_out, nbr_out, nn_count_out, stream);
+    return knn_direct_dev(sp, src, n, k, state, cur_out, nbr_out, nn_count_out, stream);
+}
+
+extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
+                                       const float* cur, const float* nbr, const int32_t* nn_count,
+                                       const float* sdf_labels, int32_t n, double* sums, double* state, void* stream) {
+    PIN_ENTER();
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(gp && lp && sums && state && n > 0, "bad arguments");
+    PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
+    PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, cur, reinterpret_cast<const float4*>(nbr),
+                    nn_count, sdf_labels, n, sums, (float*)nullptr, (float*)nullptr, (const double*)state);
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, s, sums, state, *lp);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -79,6 +79,7 @@ class NeuralPoints(nn.Module):
         self._g2l = None
         self._ws = None
         self._cnt = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._bricks = self._brick_cache = None
         self.set_search_neighborhood(num_nei_cells=config.num_nei_cells, search_alpha=config.search_alpha)
 
     # ------------------------------------------------------------------ storage
@@ -273,10 +274,21 @@ class NeuralPoints(nn.Module):
                                              _p(self._cnt[2:3]), _p(ws), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream), "pin_reset_local_map")
         self._m = int(self._cnt[2].item()) - 1  # the padding entry is counted
+        self._rebuild_bricks()
         self.local_geo_features = nn.Parameter(self._l["geo"][:self._m + 1])
         if self.color_on:
             self.local_color_features = nn.Parameter(self._l["color"][:self._m + 1])
         self.local_orientation = sensor_orientation
+
+    def _rebuild_bricks(self):
+        """Per-frame cell-coherent cache of the hash lookups for local, time-filtered queries."""
+        self._bricks = None
+        if self.config.num_nei_cells > 2 or self._n == 0:
+            return
+        if self._brick_cache is None or self._brick_cache.cand_dx.shape[0] != self.neighbor_K:
+            self._brick_cache = ops.BrickCache(self.neighbor_dx.cpu().numpy(), int(self.config.num_nei_cells), self.device)
+        tf = self.temporal_local_map_on and self.travel_dist is not None
+        self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
 
     # ------------------------------------------------------------------ K10
     def assign_local_to_global(self):
@@ -296,8 +308,11 @@ class NeuralPoints(nn.Module):
     def knn(self, points: torch.Tensor, query_locally: bool = True, pose=None, out=None):
         """kNN record of the hot path (pin_knn_query)."""
         tf = self.temporal_local_map_on and query_locally and self.travel_dist is not None
+        b = self._bricks
+        if b is not None and (not query_locally or b.mode[:2] != (bool(tf), True) or self.neighbor_K != b.cand_dx.shape[0]):
+            b = None  # global queries / a temporarily changed neighbourhood use the direct probe
         return ops.knn_query(self.search_state(), points, self.config.query_nn_k, time_filtering=tf,
-                             local=query_locally, pose=pose, out=out)
+                             local=query_locally, pose=pose, out=out, bricks=b)
 
     def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,
                       query_locally: bool = True, query_geo_feature: bool = True, query_color_feature: bool = False):
@@ -412,6 +427,7 @@ class NeuralPoints(nn.Module):
         self._local_mask = None
         self._g2l = None
         self._ws = None
+        self._bricks = self._brick_cache = None
         # shrink to size so the pickled map holds only live rows
         n = self._n
         self._g = {k: (None if t is None else t[:(n + 1 if k in ("geo", "color") else n)].clone())

@@ -112,6 +112,9 @@ class Mapper(_Base):
                                   loss_weight_on=c.loss_weight_on, eikonal=eik)
             self._trainer = t
         t.st, t.fs, t.ts_update, t.train_decoder = st, fs, npts.local_point_ts_update, train_dec
+        b = npts._bricks
+        tf = bool(npts.temporal_local_map_on and npts.travel_dist is not None)
+        t.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
         return t
 
     def mapping(self, iter_count):

@@ -46,6 +46,9 @@ class Tracker:
             self._gn = engine.GNTracker(st, fs, gp, lm_lambda, n)
         g = self._gn
         g.st, g.fs, g.gp, g.lm_lambda = st, fs, gp, lm_lambda
+        tf = bool(npts.temporal_local_map_on and self.reg_local_map and npts.travel_dist is not None)
+        b = npts._bricks if self.reg_local_map else None
+        g.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
         g.local = self.reg_local_map
         return g
 
@@ -72,28 +75,18 @@ class Tracker:
         labels = None if source_sdf is None else source_sdf.detach().to(torch.float32).contiguous()
         iter_n = c.reg_iter_n
         max_valid_final = c.surface_sample_range_m * c.final_residual_ratio_thre * 100.0
-        min_valid_ratio = 0.15 if loop_reg else 0.2
-        converged, valid_flag = False, True
-        last_res, res_cm, cnt, extra, i = 1e5, 0.0, 0, None, 0
-        tf = self.neural_points.temporal_local_map_on and self.reg_local_map
-        for i in range(iter_n):  # tracker.py:114-184
-            dT, cnt, res_cm, extra = gn.step(src, T, time_filtering=tf, local=self.reg_local_map, labels=labels)
-            T = dT @ T
-            if (res_cm - last_res) / last_res > 1.1:
-                valid_flag = False
-            else:
-                last_res = res_cm
-            if cnt < 30 or cnt / n < min_valid_ratio:
-                valid_flag = False
-            if not valid_flag or converged:
-                break
-            ang = math.degrees(math.acos(min(1.0, max(-1.0, (np.trace(dT[:3, :3]) - 1) / 2))))
-            if (abs(ang) < c.reg_term_thre_deg and np.linalg.norm(dT[:3, 3]) < c.reg_term_thre_m) or i == iter_n - 2:
-                converged = True
+        tf = bool(self.neural_points.temporal_local_map_on and self.reg_local_map
+                  and self.neural_points.travel_dist is not None)
+        # the whole GN loop runs on the device (tracker.py:114-184); one read-back
+        T, cnt, res_cm, iters, valid_flag, extra = gn.track(
+            src, T, iter_n, term_deg=c.reg_term_thre_deg, term_m=c.reg_term_thre_m, early_exit=True,
+            min_valid_ratio=0.15 if loop_reg else 0.2, time_filtering=tf, local=self.reg_local_map, labels=labels)
+        i = iters - 1
+        converged = extra["converged"]
         if res_cm > max_valid_final:
             valid_flag = False
         cov_mat = None
-        if vis_result and converged and extra is not None:  # only the last iteration computes these
+        if vis_result and converged and cnt >= 10:  # only the last iteration computes these
             N_raw = extra["N_raw"]
             eig = np.linalg.eigvals(N_raw[3:, 3:]).real
             if c.eigenvalue_check and eig.min() < cnt * c.eigenvalue_ratio_thre:
@@ -123,7 +116,8 @@ class Tracker:
         gp = self._gn_params(min_grad_norm, max_grad_norm, GM_dist, GM_grad)
         pts = points.detach().to(torch.float32).contiguous()
         gn = self._engine(pts.shape[0], gp, lm_lambda)
-        tf = self.neural_points.temporal_local_map_on and self.reg_local_map
+        tf = bool(self.neural_points.temporal_local_map_on and self.reg_local_map
+                  and self.neural_points.travel_dist is not None)
         labels = None if sdf_labels is None else sdf_labels.detach().to(torch.float32).contiguous()
         dT, cnt, res_cm, extra = gn.step(pts, None, time_filtering=tf, local=self.reg_local_map, labels=labels)
         T = torch.tensor(dT, dtype=torch.float64, device=self.device)

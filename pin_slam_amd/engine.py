@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import PIN_GN_NSUMS, PIN_GN_REPLICAS, GnParams
+from . import _lib
+from ._lib import PIN_GN_NSUMS, PIN_GN_REPLICAS, GnParams, check
 
 
 class GNTracker:
@@ -29,13 +30,16 @@ class GNTracker:
         self.sums = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64, device=dev)
         self.sums_host = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64).pin_memory()
         self.on_knn = None  # optional hook(start: bool) used by bench.py to bracket the kNN launch
+        self.bricks = None  # ops.BrickCache built for (time_filtering, local) of the calls below
+        self.state = self.state_host = None
 
     def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None):
         n = src.shape[0]
         out = (self.nbr[:n], self.nn[:n], self.cur[:n])
         if self.on_knn:
             self.on_knn(True)
-        ops.knn_query(self.st, src, self.fs.k, time_filtering=time_filtering, local=local, pose=T, out=out)
+        ops.knn_query(self.st, src, self.fs.k, time_filtering=time_filtering, local=local, pose=T, out=out,
+                      bricks=self.bricks)
         if self.on_knn:
             self.on_knn(False)
         cur = out[2] if T is not None else src
@@ -45,22 +49,55 @@ class GNTracker:
         return ops.solve_gn(self.sums_host.numpy(), self.lm_lambda)
 
     def track(self, src: torch.Tensor, T_init: np.ndarray, iters: int, term_deg: float = 0.01,
-              term_m: float = 0.001, early_exit: bool = True):
-        """GN loop with the reference's termination rule (tracker.py:174-184).  Returns
-        (T, valid_count, residual_cm, iterations)."""
-        T = np.array(T_init, dtype=np.float64)
-        converged = False
-        cnt, res, it = 0, 0.0, 0
-        for it in range(iters):
-            dT, cnt, res, _ = self.step(src, T)
-            T = dT @ T
-            if converged:
-                break
-            if early_exit:
-                ang = np.degrees(np.arccos(np.clip((np.trace(dT[:3, :3]) - 1) / 2, -1, 1)))
-                if (abs(ang) < term_deg and np.linalg.norm(dT[:3, 3]) < term_m) or it == iters - 2:
-                    converged = True
-        return T, cnt, res, it + 1
+              term_m: float = 0.001, early_exit: bool = True, min_valid_ratio: float = 0.2,
+              time_filtering=True, local=True, labels=None):
+        """Device-resident GN loop (Tracker.tracking, tracker.py:114-184): `iters` x (kNN with the
+        pose read from device state, fused SDF+Jacobian+sums, one-wave 6x6 solve + loop control)
+        enqueued back to back; kernels turn into no-ops once the loop has ended on the device.
+        ONE read-back per call.  Returns (T, valid_count, residual_cm, iterations, valid_flag,
+        extra) with extra = dict(N_raw, mse, converged)."""
+        L = _lib.lib()
+        n = src.shape[0]
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.state is None:
+            self.state = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device=src.device)
+            self.state_host = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64).pin_memory()
+        T0 = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64))
+        check(L.pin_gn_state_init(self.state.data_ptr(), T0.ctypes.data, n, stream), "pin_gn_state_init")
+        self.sums.zero_()
+        sp = self.st.params(time_filtering=time_filtering, local=local)
+        f = self.fs.params()
+        bc = None
+        if self.bricks is not None:
+            if self.bricks.mode[:2] != (bool(time_filtering), bool(local)):
+                raise RuntimeError("brick cache was built for another query mode")
+            bc = self.bricks.params()
+        lp = _lib.GnLoopParams()
+        lp.lm_lambda, lp.term_thre_deg, lp.term_thre_m = float(self.lm_lambda), float(term_deg), float(term_m)
+        lp.min_valid_ratio, lp.max_increment_ratio, lp.min_valid_points = float(min_valid_ratio), 1.1, 30
+        lp.iter_n, lp.early_exit = int(iters), int(bool(early_exit))
+        import ctypes as C
+        sp_r, f_r, gp_r, lp_r = C.byref(sp), C.byref(f), C.byref(self.gp), C.byref(lp)
+        bc_r = C.byref(bc) if bc is not None else None
+        src_p, cur_p, nbr_p, nn_p = src.data_ptr(), self.cur.data_ptr(), self.nbr.data_ptr(), self.nn.data_ptr()
+        sums_p, st_p = self.sums.data_ptr(), self.state.data_ptr()
+        lab_p = None if labels is None else labels.data_ptr()
+        k = self.fs.k
+        for _ in range(iters):
+            if self.on_knn:
+                self.on_knn(True)
+            rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)
+            if self.on_knn:
+                self.on_knn(False)
+            rc |= L.pin_gn_accumulate_solve(f_r, gp_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+            if rc:
+                check(rc, "pin_gn_knn / pin_gn_accumulate_solve")
+        self.state_host.copy_(self.state, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        s = self.state_host.numpy()
+        T = s[:16].reshape(4, 4).copy()
+        extra = dict(N_raw=s[24:60].reshape(6, 6).copy(), mse=float(s[23]), converged=bool(s[20]))
+        return T, int(s[18]), float(s[17]), int(s[22]), bool(s[19]), extra
 
 
 class MapTrainer:
@@ -96,6 +133,7 @@ class MapTrainer:
         # Eikonal samples are the global batch's coord[::dec]; each rank owns those in its shard
         self.n_eik_global = n_eik_global(self.bs, self.dec) if eikonal else 0
         self.total_iter = 0
+        self.bricks = None
 
     def iteration(self, index_local: torch.Tensor, step: int):
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
@@ -106,7 +144,8 @@ class MapTrainer:
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
-                       loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global)
+                       loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
+                       bricks=self.bricks)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad if self.train_decoder else self.gfeat)

@@ -100,8 +100,61 @@ def radius_search(st: SearchState, query: torch.Tensor, time_filtering: bool = F
     return d2, idx
 
 
+class BrickCache:
+    """Per-frame cell-coherent cache of the hash lookups (csrc/brick.hip).  Valid for the
+    (time_filtering, local) mode it was built with and until the map / local map changes."""
+
+    def __init__(self, neighbor_dx: np.ndarray, n_dilate: int, device="cuda"):
+        if n_dilate > 2 or np.abs(neighbor_dx).max() > n_dilate:
+            raise NotImplementedError("brick cache covers num_nei_cells <= 2")
+        self.n_dilate = int(n_dilate)
+        self.cand_dx = torch.from_numpy(np.ascontiguousarray(neighbor_dx, dtype=np.int32)).to(device)
+        self.device = device
+        self.counters = torch.zeros(4, dtype=torch.int32, device=device)
+        self.mode = None
+        self.n_bricks = self.n_entries = 0
+        self._alloc(1 << 16, 1 << 18)
+
+    def _alloc(self, max_bricks, max_entries):
+        d = self.device
+        dsize = 1
+        while dsize < 4 * max_bricks:
+            dsize *= 2
+        self.dir_keys = torch.empty(dsize, dtype=torch.int64, device=d)
+        self.dir_vals = torch.empty(dsize, dtype=torch.int32, device=d)
+        self.brick_keys = torch.empty(max_bricks, dtype=torch.int64, device=d)
+        self.brick_mask = torch.empty(max_bricks, dtype=torch.int64, device=d)
+        self.brick_base = torch.empty(max_bricks, dtype=torch.int32, device=d)
+        self.entries = torch.empty((max_entries, 4), dtype=torch.float32, device=d)
+        self.max_bricks, self.max_entries, self.dsize = max_bricks, max_entries, dsize
+
+    def params(self) -> "_lib.BrickCacheC":
+        bc = _lib.BrickCacheC()
+        bc.dir_keys, bc.dir_vals, bc.brick_keys = self.dir_keys.data_ptr(), self.dir_vals.data_ptr(), self.brick_keys.data_ptr()
+        bc.brick_mask, bc.brick_base, bc.entries = self.brick_mask.data_ptr(), self.brick_base.data_ptr(), self.entries.data_ptr()
+        bc.cand_dx = self.cand_dx.data_ptr()
+        bc.dir_mask, bc.max_bricks, bc.max_entries, bc.n_dilate = self.dsize - 1, self.max_bricks, self.max_entries, self.n_dilate
+        return bc
+
+    def build(self, st: "SearchState", time_filtering=True, local=True):
+        """(Re)build for the current map; grows the buffers and retries on overflow (one host
+        sync per build, once per frame)."""
+        sp = st.params(time_filtering=time_filtering, local=local)
+        while True:
+            bc = self.params()
+            check(_lib.lib().pin_brick_build(C.byref(sp), C.byref(bc), self.counters.data_ptr(), _stream()), "pin_brick_build")
+            nb, ne, flags, _ = self.counters.tolist()
+            if flags == 0 and nb <= self.max_bricks and ne <= self.max_entries:
+                break
+            self._alloc(max(self.max_bricks, int(nb * 1.5) + 1024) if (flags & 3 or nb > self.max_bricks) else self.max_bricks,
+                        max(self.max_entries, int(ne * 1.5) + 1024))
+        self.n_bricks, self.n_entries = nb, ne
+        self.mode = (bool(time_filtering), bool(local), st.n_points, st.cur_ts)
+        return self
+
+
 def knn_query(st: SearchState, query: torch.Tensor, k: int, time_filtering=True, local=True,
-              pose: Optional[np.ndarray] = None, out=None):
+              pose: Optional[np.ndarray] = None, out=None, bricks: Optional[BrickCache] = None):
     """k nearest valid candidates -> (nbr [N,k,4] f32, nn_count [N] int32, query_used [N,3]).
     ``pose`` (4x4 or 3x4, host) is applied to the query points inside the kernel."""
     n = query.shape[0]
@@ -117,8 +170,15 @@ def knn_query(st: SearchState, query: torch.Tensor, k: int, time_filtering=True,
     if pose is not None:
         pose32 = np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4].astype(np.float32))
         pose_p = pose32.ctypes.data
-    check(_lib.lib().pin_knn_query(C.byref(sp), _ptr(query, torch.float32), n, k, pose_p, _ptr(qout), _ptr(nbr),
-                                   _ptr(nn), _stream()), "pin_knn_query")
+    if bricks is not None:
+        if bricks.mode is None or bricks.mode[:2] != (bool(time_filtering), bool(local)):
+            raise RuntimeError("brick cache was built for another query mode")
+        bc = bricks.params()
+        check(_lib.lib().pin_knn_query_bricks(C.byref(sp), C.byref(bc), _ptr(query, torch.float32), n, k, pose_p,
+                                              _ptr(qout), _ptr(nbr), _ptr(nn), _stream()), "pin_knn_query_bricks")
+    else:
+        check(_lib.lib().pin_knn_query(C.byref(sp), _ptr(query, torch.float32), n, k, pose_p, _ptr(qout), _ptr(nbr),
+                                       _ptr(nn), _stream()), "pin_knn_query")
     return nbr, nn, (qout if pose is not None else query)
 
 
@@ -254,7 +314,7 @@ class TrainBuffers:
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
-               global_n_main=None, global_n_eik=None, pred_out=None):
+               global_n_main=None, global_n_eik=None, pred_out=None, bricks=None):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad."""
     L = _lib.lib()
@@ -262,7 +322,7 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
                                    float(np.float32(eik_eps)),
                                    _ptr(buf.query), s), "pin_train_make_queries")
-    knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None))
+    knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None), bricks=bricks)
     tp = TrainParams()
     tp.n_main, tp.n_eik, tp.loss_weight_on = buf.n_main, buf.n_eik, int(bool(loss_weight_on))
     tp.sigma, tp.weight_e, tp.eik_eps = float(sigma), float(weight_e), float(np.float32(eik_eps))

@@ -34,5 +34,11 @@ t_sdf = ev(lambda: ops.sdf_query(fs, cur, nbr, nn))
 key = torch.floor(scan / 0.4).long(); k2 = (key[:,0]+4096) + ((key[:,1]+4096) << 14) + ((key[:,2]+4096) << 28)
 scan_s = scan[torch.argsort(k2)].contiguous()
 t_knn_s = ev(lambda: ops.knn_query(st, scan_s, 8, pose=np.eye(4), out=out))
+bricks = ops.BrickCache(dx, 2)
+t_build = ev(lambda: bricks.build(st), n=5)
+print("bricks", bricks.n_bricks, "entries", bricks.n_entries, "build ms", t_build)
+t_knn_b = ev(lambda: ops.knn_query(st, scan, 8, pose=np.eye(4), out=out, bricks=bricks))
+t_knn_bs = ev(lambda: ops.knn_query(st, scan_s, 8, pose=np.eye(4), out=out, bricks=bricks))
+print(f"knn bricks {t_knn_b*1e3:.1f} us  bricks(sorted) {t_knn_bs*1e3:.1f} us")
 print(f"layers={layers} P={P} knn {t_knn*1e3:.1f} us  knn(sorted) {t_knn_s*1e3:.1f} us  gn {t_gn*1e3:.1f} us  sdf_query {t_sdf*1e3:.1f} us")
 s = sums.cpu().numpy().sum(0); print("valid", s[29])

@@ -1,0 +1,90 @@
+"""The brick cache must return bit-identical kNN records to the direct hash-probe kernel
+(which is itself bit-exact against the reference): collision-heavy small tables, the
+non-local quirk, queries far from the map (fallback path), and a large synthetic map."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pin_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(st, q, k, bricks, **kw):
+    from pin_slam_amd import ops
+    a = ops.knn_query(st, q, k, **kw)
+    b = ops.knn_query(st, q, k, bricks=bricks, **kw)
+    assert torch.equal(a[1], b[1]), "nn_count differs"
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), "kNN record differs"
+    if kw.get("pose") is not None:
+        assert torch.equal(a[2], b[2])
+    return a
+
+
+@pytest.mark.parametrize("case", G.CASES)
+def test_bricks_equal_direct_probe_on_fixtures(case):
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = G.load(case)
+    st = U.search_state(d)
+    k = int(d["query_nn_k"])
+    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st)
+    assert bricks.n_bricks > 100 and bricks.n_entries > 1000
+    rng = np.random.default_rng(0)
+    far = rng.uniform(-200, 200, (500, 3)).astype(np.float32)          # mostly outside the cached bricks
+    near = (d["local_neural_points"][::3] + rng.normal(0, 0.3, d["local_neural_points"][::3].shape)).astype(np.float32)
+    for pts in (d["query"], d["reg_src"], d["map_coord0"], far, near):
+        nbr, nn, _ = _same(st, U.dev(pts), k, bricks)
+    assert int((nn > 0).sum()) > 100
+    _same(st, U.dev(d["reg_src"]), k, bricks, pose=d["reg_Tinit"])
+
+
+def test_bricks_reproduce_nonlocal_quirk():
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = G.load("c2_wf")
+    mask, g2l = O.local_map_mask(d["neural_points"], d["point_ts_create"], [16.0, 0, 0], 6.0,
+                                 travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                                 diff_travel_dist_local=d["diff_travel_dist_local"], reboot_ts=0)
+    st = dataclasses.replace(U.search_state(d), global2local=U.dev(U.g2l_to_device_format(g2l, np.append(mask, True))))
+    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st)
+    nbr, nn, _ = _same(st, U.dev(d["query"]), 8, bricks)
+    _, idx, flag = U.nbr_split(nbr)
+    assert flag.sum() > 50
+
+
+def test_bricks_mode_is_checked_and_global_queries_use_direct_path():
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = G.load("c2_wf")
+    st = U.search_state(d)
+    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st)
+    with pytest.raises(RuntimeError):
+        ops.knn_query(st, U.dev(d["query"]), 8, time_filtering=False, local=False, bricks=bricks)
+    b2 = ops.BrickCache(d["neighbor_dx"], 2).build(st, time_filtering=False, local=False)
+    _same(st, U.dev(d["query"]), 8, b2, time_filtering=False, local=False)
+
+
+def test_bricks_large_synthetic_map():
+    from pin_slam_amd import ops, synth
+    from tests import gpu_util as U
+    m = synth.build_map(layers=3, radius=40.0, raw_per_layer=400_000)
+    P = len(m.positions)
+    pos = U.dev(m.positions)
+    pos4 = torch.empty((P, 4), dtype=torch.float32, device="cuda")
+    ops.pack_positions(pos, torch.zeros(P, dtype=torch.int32, device="cuda"), pos4)
+    dx, mv = ops.search_neighborhood(2, 0.5, 0.4)
+    g2l = torch.arange(P + 1, dtype=torch.int32, device="cuda"); g2l[-1] = -1
+    st = ops.SearchState(table=U.dev(m.table), pos4=pos4, cand_off=U.dev(ops.candidate_offsets(dx, m.buffer_size)),
+                         n_points=P, resolution=0.4, max_valid_dist2=mv,
+                         travel_dist=torch.zeros(1, device="cuda"), cur_ts=0, diff_travel_dist_local=400.0,
+                         global2local=g2l)
+    bricks = ops.BrickCache(dx, 2).build(st)
+    scan = synth.make_scan(m, n=50_000)
+    pool, _ = synth.make_pool(m, n=50_000, sigma=0.6)
+    for pts in (scan, pool):
+        nbr, nn, _ = _same(st, U.dev(pts), 8, bricks)
+    assert float(nn.float().mean()) > 20

@@ -276,3 +276,26 @@ def test_sharded_train_step_sums_to_full_batch(gold):
     gf, gd = d["map_gfeat0"], d["map_gdec0"]
     assert np.max(np.abs(gfeat.cpu().numpy() - gf)) < 3e-4 * np.abs(gf).max()
     assert np.max(np.abs(gdec.cpu().numpy() - gd)) < 3e-4 * np.abs(gd).max()
+
+
+@pytest.mark.parametrize("use_bricks", [False, True])
+def test_tracking_device_loop(gold, use_bricks):
+    """Tracker.tracking with the GN loop resident on the device (6x6 solve, pose update,
+    validity and convergence rules in a one-wave kernel): final pose, valid flag and
+    iteration count against the reference's run."""
+    from pin_slam_amd import engine, ops
+    from tests import gpu_util as U
+    d = gold
+    src = U.dev(d["reg_src"])
+    gn = engine.GNTracker(d["st"], d["fs_loc"], _gn_params(d), d["cfg_reg_lm_lambda"], src.shape[0])
+    if use_bricks:
+        gn.bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(d["st"])
+    T, cnt, res_cm, iters, valid, extra = gn.track(src, d["reg_Tinit"], int(d["cfg_reg_iter_n"]),
+                                                   term_deg=d["cfg_reg_term_thre_deg"], term_m=d["cfg_reg_term_thre_m"])
+    assert valid == bool(d["trk_valid"]) and extra["converged"]
+    assert iters < int(d["cfg_reg_iter_n"])
+    np.testing.assert_allclose(T[:3, 3], d["trk_T"][:3, 3], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(T[:3, :3], d["trk_T"][:3, :3], rtol=0, atol=1e-5)
+    # host-loop and device-loop agree on the first step as well
+    dT, cnt1, res1, _ = gn.step(src, d["reg_Tinit"])
+    np.testing.assert_allclose(dT, d["reg_dT"], rtol=0, atol=1e-5)
