@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin
     int lo[3], hi[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { lo[a] = (g[a] - n_dilate) >> 2; hi[a] = (g[a] + n_dilate) >> 2; }
+    // points are appended in voxel order per frame, so neighbours in memory mostly cover the
+    // same bricks: skip the directory traffic when the previous local point already did it
+    if (j > 0 && (sp.global2local == nullptr || sp.global2local[j - 1] >= 0)) {
+        const float4 Q = reinterpret_cast<const float4*>(sp.pos4)[j - 1];
+        const int q[3] = {(int)voxel_coord(Q.x, sp.resolution), (int)voxel_coord(Q.y, sp.resolution),
+                          (int)voxel_coord(Q.z, sp.resolution)};
+        bool same = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) same = same && ((q[a] - n_dilate) >> 2) == lo[a] && ((q[a] + n_dilate) >> 2) == hi[a];
+        if (same) return;
+    }
     for (int bx = lo[0]; bx <= hi[0]; ++bx)
         for (int by = lo[1]; by <= hi[1]; ++by)
             for (int bz = lo[2]; bz <= hi[2]; ++bz) {

@@ -1,0 +1,238 @@
+// Shallow-MLP decoder on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Decoder.mlp (model/decoder.py:61-80) and its input Jacobian for 64 queries per wave.
+// Matrix roles:  D[unit][query] += W[unit][k] * H[k][query]   (M = 16 output units per tile,
+// N = 16 queries per tile, K = 4 inputs per instruction).  Why the matrix cores although the
+// fp32 MFMA rate equals the vector rate: operand delivery.  On the vector path every FMA needs
+// its own wave-uniform weight (scalar-load bound for 53 KB of 4x64 weights) or a broadcast LDS
+// read (LDS bound); an MFMA consumes ONE weight register per lane for 16x16x4 = 1024 FMAs,
+// so all weights stream from LDS at a few % of its bandwidth.
+//
+// Layout trick (no data movement between layers): the 16x16x4 result tile puts
+//   D[unit = 16*mt + 4*g + r][query = n]  in lane (n = lane & 15, g = lane >> 4), register r,
+// and the B operand of the next layer wants  H[k][query = n]  in lane (n, g) for k-slot g.
+// The k index of an MFMA is a free permutation as long as A and B agree, so K-step (mt, r) of
+// the next layer is declared to cover units {16*mt + 4*g + r, g = 0..3}: the activation
+// registers ARE the B operands, and the weights are stored in LDS pre-permuted to match
+// (A operand of step (kt, r), lane (i, g):  W[16*mt_out + i][16*kt + 4*g + r]).
+// The same array read with a different index serves the transposed product of the Jacobian.
+#pragma once
+#include "mlp.h"
+
+namespace pin {
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, so only the
+// compiler has to be kept from moving them across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int H>
+struct MfmaDecoder {
+    static constexpr int MT = H / 16;          // unit tiles
+    static constexpr int XSTRIDE = 13;         // per-query stride of the z / a exchange buffer
+    // LDS image (floats)
+    static constexpr int OFF_A0 = 0;                       // [MT][3][64]      layer-0 forward operand
+    static constexpr int OFF_A0T = OFF_A0 + MT * 3 * 64;   // [MT][4][64]      layer-0 transposed operand
+    static constexpr int OFF_B0 = OFF_A0T + MT * 4 * 64;   // [H]
+    static constexpr int OFF_HID = OFF_B0 + H;             // per hidden layer: F [MT][MT][64][4], bias [H]
+    static constexpr int HID_SZ = H * H + H;
+    __host__ __device__ static constexpr int off_out(int L) { return OFF_HID + (L - 1) * HID_SZ; }  // Wo [H], bo, pad
+    __host__ __device__ static constexpr int weight_floats(int L) { return off_out(L) + H + 4; }
+    __host__ __device__ static constexpr int scratch_floats() { return 64 * XSTRIDE; }  // per wave
+
+    // Block-cooperative: permute the flat state_dict-ordered parameters into the LDS image.
+    __device__ static void stage(const float* __restrict__ dec, int L, float* __restrict__ w, int tid, int nthreads) {
+        const float* W0 = dec;
+        const float* b0 = dec + H * MLP_IN;
+        for (int e = tid; e < MT * 3 * 64; e += nthreads) {
+            const int lane = e & 63, s = (e >> 6) % 3, mt = e / (3 * 64);
+            const int i = lane & 15, g = lane >> 4, c = 4 * s + g;
+            w[OFF_A0 + e] = c < MLP_IN ? W0[(16 * mt + i) * MLP_IN + c] : 0.f;
+        }
+        for (int e = tid; e < MT * 4 * 64; e += nthreads) {
+            const int lane = e & 63, r = (e >> 6) & 3, kt = e >> 8;
+            const int c = lane & 15, g = lane >> 4;
+            w[OFF_A0T + e] = c < MLP_IN ? W0[(16 * kt + 4 * g + r) * MLP_IN + c] : 0.f;
+        }
+        for (int e = tid; e < H; e += nthreads) w[OFF_B0 + e] = b0[e];
+        const float* P = dec + H * MLP_IN + H;
+        for (int l = 1; l < L; ++l) {
+            float* F = w + OFF_HID + (l - 1) * HID_SZ;
+            for (int e = tid; e < H * H; e += nthreads) {
+                const int r = e & 3, lane = (e >> 2) & 63, kt = (e >> 8) % MT, mt = e / (256 * MT);
+                const int i = lane & 15, g = lane >> 4;
+                F[e] = P[(16 * mt + i) * H + 16 * kt + 4 * g + r];
+            }
+            for (int e = tid; e < H; e += nthreads) F[H * H + e] = P[H * H + e];
+            P += H * H + H;
+        }
+        float* O = w + off_out(L);
+        for (int e = tid; e < H + 1; e += nthreads) O[e] = P[e];
+    }
+
+    // Forward (+ input Jacobian) for the 64 queries of this wave.  z: this lane's query input.
+    // Returns the raw MLP output of this lane's query; a_in = d out / d z if GRAD.
+    template <bool GRAD>
+    __device__ __forceinline__ static float run(const float* __restrict__ w, int L, float* __restrict__ xb,
+                                                const float (&z)[MLP_IN], float (&a_in)[MLP_IN]) {
+        const int lane = threadIdx.x & 63;
+        const int n = lane & 15, g = lane >> 4;
+        // ---- exchange: thread-per-query z  ->  B operand layout
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) xb[lane * XSTRIDE + j] = z[j];
+        xb[lane * XSTRIDE + 11] = 0.f;
+        wave_lds_sync();
+        v4f_t h[MT][4];   // activations: [unit tile][query tile], register r = unit 4g + r
+        v4f_t acc[MT][4];
+        unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;  // ReLU masks per layer, bit (mt*4+nt)*4+r
+        {
+            float zb[4][3];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) zb[nt][s] = xb[(16 * nt + n) * XSTRIDE + 4 * s + g];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const v4f_t b4 = *reinterpret_cast<const v4f_t*>(w + OFF_B0 + 16 * mt + 4 * g);
+                float a0[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) a0[s] = w[OFF_A0 + (mt * 3 + s) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    v4f_t c = b4;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], zb[nt][s], c, 0, 0, 0);
+                    acc[mt][nt] = c;
+                }
+            }
+        }
+        auto relu_mask = [&](unsigned long long& m) {
+            unsigned long long mm = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = acc[mt][nt][r] > 0.f;
+                        mm |= (unsigned long long)on << ((mt * 4 + nt) * 4 + r);
+                        h[mt][nt][r] = on ? acc[mt][nt][r] : 0.f;
+                    }
+            m = mm;
+        };
+        relu_mask(m0);
+        for (int l = 1; l < L; ++l) {
+            const float* __restrict__ F = w + OFF_HID + (l - 1) * HID_SZ;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const v4f_t b4 = *reinterpret_cast<const v4f_t*>(F + H * H + 16 * mt + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b4;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    const v4f_t a4 = *reinterpret_cast<const v4f_t*>(F + ((mt * MT + kt) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], h[kt][nt][r], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            unsigned long long mm;
+            relu_mask(mm);
+            m1 = l == 1 ? mm : m1; m2 = l == 2 ? mm : m2; m3 = l == 3 ? mm : m3;
+        }
+        // ---- output layer: partial dot over this lane's units, reduced over the 4 k-groups
+        const float* __restrict__ O = w + off_out(L);
+        float xo[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[nt] = fmaf(wo[r], h[kt][nt][r], xo[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            xo[nt] += __shfl_xor(xo[nt], 16, 64);
+            xo[nt] += __shfl_xor(xo[nt], 32, 64);
+        }
+        // this lane's own query is 16*g + n, i.e. query tile nt = g
+        const float out = O[H] + (g == 0 ? xo[0] : g == 1 ? xo[1] : g == 2 ? xo[2] : xo[3]);
+        if (!GRAD) return out;
+
+        // ---- input Jacobian: a = W_out masked, then a <- mask .* (W_l^T a) down the layers
+        auto layer_mask = [&](int l) { return l == 0 ? m0 : l == 1 ? m1 : l == 2 ? m2 : m3; };
+        {
+            const unsigned long long mm = layer_mask(L - 1);
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[kt][nt][r] = ((mm >> ((kt * 4 + nt) * 4 + r)) & 1ull) ? wo[r] : 0.f;
+            }
+        }
+        for (int l = L - 1; l >= 1; --l) {
+            const float* __restrict__ F = w + OFF_HID + (l - 1) * HID_SZ;
+            const unsigned long long mm = layer_mask(l - 1);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mj][nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ki = 0; ki < MT; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // W_l[16*ki + 4*g + r][16*mj + n] out of the forward image (see header)
+                        const float at = F[((ki * MT + mj) * 64 + 16 * (n >> 2) + 4 * g + r) * 4 + (n & 3)];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[ki][nt][r], acc[mj][nt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[mj][nt][r] = ((mm >> ((mj * 4 + nt) * 4 + r)) & 1ull) ? acc[mj][nt][r] : 0.f;
+        }
+        // layer 0 transposed: a_in[c][q] = sum_i W0[i][c] a0[i][q]
+        v4f_t ai[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ai[nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float at = w[OFF_A0T + (kt * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    ai[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[kt][nt][r], ai[nt], 0, 0, 0);
+            }
+        // ---- exchange back: lane (n, g) holds components 4g + r of query 16*nt + n
+        wave_lds_sync();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < 12) xb[(16 * nt + n) * XSTRIDE + 4 * g + r] = ai[nt][r];
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) a_in[j] = xb[lane * XSTRIDE + j];
+        wave_lds_sync();
+        return out;
+    }
+};
+
+}  // namespace pin

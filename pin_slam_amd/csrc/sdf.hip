@@ -8,7 +8,7 @@
 //
 // One thread per query.  Input is the kNN record written by knn.hip (k x 16 B, coalesced
 // per thread), so the only random traffic here is the k feature rows (32 B each).
-#include "mlp.h"
+#include "mlp_mfma.h"
 
 namespace pin {
 
@@ -86,10 +86,24 @@ struct SdfResult {
 };
 
 // The fused per-query evaluation shared by pin_sdf_query and pin_gn_accumulate.
-template <int H, bool WF, bool GRAD>
+// decoder back-ends: VALU (thread-private LDS column `col`) or MFMA (block weights `col`, wave scratch `xb`)
+template <int H, bool GRAD, bool MFMA>
+__device__ __forceinline__ float decode(const pin_field& f, const float (&z)[MLP_IN], float (&a)[MLP_IN], float* col,
+                                        float* xb) {
+    if constexpr (MFMA) {
+        return MfmaDecoder<H>::template run<GRAD>(col, f.levels, xb, z, a);
+    } else {
+        MlpMasks mk;
+        const float x = mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
+        if (GRAD) mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
+        return x;
+    }
+}
+
+template <int H, bool WF, bool GRAD, bool MFMA = false>
 __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4* __restrict__ nbr,
                                                 const int* __restrict__ nn_count, int qi, float qx, float qy,
-                                                float qz, float* col) {
+                                                float qz, float* col, float* xb = nullptr) {
     Nbrs nb;
     load_neighbors(nbr, nn_count, qi, f.k, nb);
     SdfResult r;
@@ -114,7 +128,6 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
                 wsum += nb.w[t];
             }
     }
-    MlpMasks mk;
     if (WF) {
         float z[MLP_IN];
 #pragma unroll
@@ -130,11 +143,10 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
 #pragma unroll
                 for (int j = 0; j < 3; ++j) z[PIN_FEATURE_DIM + j] = fmaf(nb.w[t], v[j], z[PIN_FEATURE_DIM + j]);
             }
-        const float x = mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
+        float a[MLP_IN];
+        const float x = decode<H, GRAD, MFMA>(f, z, a, col, xb);
         r.sdf = s * x;
         if (GRAD) {
-            float a[MLP_IN];
-            mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
             float cbar = 0.f;
 #pragma unroll
             for (int j = 0; j < MLP_IN; ++j) cbar = fmaf(a[j], z[j], cbar);  // = sum_t w_t c_t
@@ -178,30 +190,35 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
             for (int u = 0; u < PIN_MAX_K; ++u)
                 if (u == t) { idx = nb.idx[u]; wt = nb.w[u]; ut = nb.u[u]; vgx = nb.vx[u]; vgy = nb.vy[u]; vgz = nb.vz[u]; }
             float st = 0.f;
-            if (idx >= 0) {  // invalid neighbours carry zero weight: their decode is never used
-                float z[MLP_IN], ft[PIN_FEATURE_DIM], v[3];
-                load_feature(f, idx, ft);
-                bool qk = false;
+            {   // every lane decodes (the MFMA back-end is wave-wide); invalid neighbours decode
+                // zeros and are discarded: their weight is zero in the reference too
+                float z[MLP_IN], ft[PIN_FEATURE_DIM] = {0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+                if (idx >= 0) {
+                    load_feature(f, idx, ft);
+                    bool qk = false;
 #pragma unroll
-                for (int u = 0; u < PIN_MAX_K; ++u) if (u == t) qk = nb.quirk[u];
-                neighbor_vector(f, idx, qk, vgx, vgy, vgz, qx, qy, qz, v, Rm);
+                    for (int u = 0; u < PIN_MAX_K; ++u) if (u == t) qk = nb.quirk[u];
+                    neighbor_vector(f, idx, qk, vgx, vgy, vgz, qx, qy, qz, v, Rm);
+                }
 #pragma unroll
                 for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = ft[j];
                 z[8] = v[0]; z[9] = v[1]; z[10] = v[2];
-                st = s * mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
-                mean = fmaf(wt, st, mean);
-                if (GRAD) {
-                    float a[MLP_IN];
-                    mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
-                    if (f.orient != nullptr) {
-                        dxs += wt * (Rm[0] * a[8] + Rm[3] * a[9] + Rm[6] * a[10]);
-                        dys += wt * (Rm[1] * a[8] + Rm[4] * a[9] + Rm[7] * a[10]);
-                        dzs += wt * (Rm[2] * a[8] + Rm[5] * a[9] + Rm[8] * a[10]);
-                    } else {
-                        dxs = fmaf(wt, a[8], dxs); dys = fmaf(wt, a[9], dys); dzs = fmaf(wt, a[10], dzs);
+                float a[MLP_IN];
+                const float xt = decode<H, GRAD, MFMA>(f, z, a, col, xb);
+                if (idx >= 0) {
+                    st = s * xt;
+                    mean = fmaf(wt, st, mean);
+                    if (GRAD) {
+                        if (f.orient != nullptr) {
+                            dxs += wt * (Rm[0] * a[8] + Rm[3] * a[9] + Rm[6] * a[10]);
+                            dys += wt * (Rm[1] * a[8] + Rm[4] * a[9] + Rm[7] * a[10]);
+                            dzs += wt * (Rm[2] * a[8] + Rm[5] * a[9] + Rm[8] * a[10]);
+                        } else {
+                            dxs = fmaf(wt, a[8], dxs); dys = fmaf(wt, a[9], dys); dzs = fmaf(wt, a[10], dzs);
+                        }
+                        const float cg = -2.f * ut * ut * st;
+                        ax = fmaf(cg, vgx, ax); ay = fmaf(cg, vgy, ay); az = fmaf(cg, vgz, az);
                     }
-                    const float cg = -2.f * ut * ut * st;
-                    ax = fmaf(cg, vgx, ax); ay = fmaf(cg, vgy, ay); az = fmaf(cg, vgz, az);
                 }
             }
 #pragma unroll
@@ -290,6 +307,110 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
         const double t = wave_sum((double)v[i]);
         if (lane == 0 && t != 0.0) atomicAdd(dst + i, t);
     }
+}
+
+// ---- the same two kernels with the decoder on the fp32 matrix cores (mlp_mfma.h) -----------
+constexpr int MF_BLOCK = 256;
+
+template <int H>
+struct MfmaLds {
+    static constexpr int W = MfmaDecoder<H>::weight_floats(MLP_MAX_LEVELS);
+    static constexpr int TOTAL = W + (MF_BLOCK / 64) * MfmaDecoder<H>::scratch_floats();
+};
+
+template <int H, bool WF>
+__global__ __launch_bounds__(MF_BLOCK) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
+                                                                  const float4* __restrict__ nbr,
+                                                                  const int* __restrict__ nn_count, int n,
+                                                                  float* __restrict__ sdf_out, float* __restrict__ grad_out,
+                                                                  float* __restrict__ std_out, float* __restrict__ cert_out) {
+    __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
+    float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    __syncthreads();
+    const int qi = blockIdx.x * MF_BLOCK + threadIdx.x;
+    const bool active = qi < n;
+    const int qq = active ? qi : n - 1;  // every lane takes part in the wave-wide MFMAs
+    const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+    SdfResult r;
+    if (grad_out != nullptr) r = eval_query<H, WF, true, true>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb);
+    else r = eval_query<H, WF, false, true>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb);
+    if (!active) return;
+    if (sdf_out) sdf_out[qi] = r.sdf;
+    if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
+    if (std_out) std_out[qi] = r.std;
+    if (cert_out) cert_out[qi] = r.cert;
+}
+
+template <int H, bool WF>
+__global__ __launch_bounds__(MF_BLOCK) void gn_accumulate_mfma_kernel(pin_field f, pin_gn_params gp,
+                                                                      const float* __restrict__ query,
+                                                                      const float4* __restrict__ nbr,
+                                                                      const int* __restrict__ nn_count,
+                                                                      const float* __restrict__ labels, int n,
+                                                                      double* __restrict__ sums, float* __restrict__ sdf_out,
+                                                                      float* __restrict__ grad_out,
+                                                                      const double* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
+    if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
+    float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    __syncthreads();
+    const int qi = blockIdx.x * MF_BLOCK + threadIdx.x;
+    const bool active = qi < n;
+    const int qq = active ? qi : n - 1;
+    float v[PIN_GN_NSUMS];
+#pragma unroll
+    for (int i = 0; i < PIN_GN_NSUMS; ++i) v[i] = 0.f;
+    const float px = query[3 * qq], py = query[3 * qq + 1], pz = query[3 * qq + 2];
+    const SdfResult r = eval_query<H, WF, true, true>(f, nbr, nn_count, qq, px, py, pz, lds, xb);
+    if (active) {
+        if (sdf_out) sdf_out[qi] = r.sdf;
+        if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
+        const float gn = sqrtf(r.gx * r.gx + r.gy * r.gy + r.gz * r.gz);
+        const bool valid = nn_count[qi] >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm &&
+                           r.std < gp.max_sdf_std;
+        if (valid) {
+            const float res = r.sdf - (labels ? labels[qi] : 0.f);
+            float w = 1.f;
+            if (gp.gm_grad > 0.f) { const float a = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + a * a); w *= t * t; }
+            if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); w *= t * t; }
+            float J[6];
+            J[0] = py * r.gz - pz * r.gy; J[1] = pz * r.gx - px * r.gz; J[2] = px * r.gy - py * r.gx;
+            J[3] = r.gx; J[4] = r.gy; J[5] = r.gz;
+            int o = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) v[o++] = w * J[a] * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[21 + a] = w * J[a] * res;
+            v[27] = w; v[28] = fabsf(res); v[29] = 1.f; v[30] = w * res * res;
+        }
+    }
+    // block reduction first (4 waves -> one set of atomics): same-address f64 atomics serialise in L2
+    __shared__ double red[MF_BLOCK / 64][PIN_GN_NSUMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const double t = wave_sum((double)v[i]);
+        if (lane == 0) red[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 31) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < MF_BLOCK / 64; ++w) t += red[w][threadIdx.x];
+        if (t != 0.0) atomicAdd(sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS + threadIdx.x, t);
+    }
+}
+
+static bool use_mfma_decoder() {
+    static const int on = [] {
+        const char* e = getenv("PIN_DECODER");
+        return (e != nullptr && strcmp(e, "valu") == 0) ? 0 : 1;
+    }();
+    return on != 0;
 }
 
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
@@ -479,6 +600,17 @@ using namespace pin;
         }                                                                                    \
     } while (0)
 
+#define PIN_DISPATCH_FIELD(f, KERNEL, n, stream, ...)                                               \
+    do {                                                                                            \
+        if (use_mfma_decoder()) {                                                                   \
+            const dim3 grid_(cdiv(n, MF_BLOCK)), block_(MF_BLOCK);                                  \
+            PIN_DISPATCH_HW(f, KERNEL##_mfma_kernel, grid_, block_, 0, stream, __VA_ARGS__);        \
+        } else {                                                                                    \
+            const dim3 grid_(cdiv(n, SDF_BLOCK)), block_(SDF_BLOCK);                                \
+            PIN_DISPATCH_HW(f, KERNEL##_kernel, grid_, block_, 0, stream, __VA_ARGS__);             \
+        }                                                                                           \
+    } while (0)
+
 extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count,
                              int32_t n, float* sdf_out, float* grad_out, float* std_out, float* certainty_out,
                              void* stream) {
@@ -487,9 +619,8 @@ extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;
     PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
-    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
-    PIN_DISPATCH_HW(f, sdf_query_kernel, grid, block, 0, as_stream(stream), *f, query,
-                    reinterpret_cast<const float4*>(nbr), nn_count, n, sdf_out, grad_out, std_out, certainty_out);
+    PIN_DISPATCH_FIELD(f, sdf_query, n, as_stream(stream), *f, query, reinterpret_cast<const float4*>(nbr), nn_count, n,
+                       sdf_out, grad_out, std_out, certainty_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -505,9 +636,8 @@ extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, co
     PIN_CHECK_HIP(hipMemsetAsync(sums_out, 0, sizeof(double) * PIN_GN_NSUMS * GN_REPLICAS, s));
     if (n == 0) return 0;
     PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
-    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
-    PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, query, reinterpret_cast<const float4*>(nbr),
-                    nn_count, sdf_labels, n, sums_out, sdf_out, grad_out, (const double*)nullptr);
+    PIN_DISPATCH_FIELD(f, gn_accumulate, n, s, *f, *gp, query, reinterpret_cast<const float4*>(nbr), nn_count,
+                       sdf_labels, n, sums_out, sdf_out, grad_out, (const double*)nullptr);
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -538,9 +668,8 @@ extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* 
     PIN_CHECK_ARG(gp && lp && sums && state && n > 0, "bad arguments");
     PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
     hipStream_t s = as_stream(stream);
-    const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
-    PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, cur, reinterpret_cast<const float4*>(nbr),
-                    nn_count, sdf_labels, n, sums, (float*)nullptr, (float*)nullptr, (const double*)state);
+    PIN_DISPATCH_FIELD(f, gn_accumulate, n, s, *f, *gp, cur, reinterpret_cast<const float4*>(nbr), nn_count, sdf_labels,
+                       n, sums, (float*)nullptr, (float*)nullptr, (const double*)state);
     hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, s, sums, state, *lp);
     PIN_CHECK_LAUNCH();
     return 0;

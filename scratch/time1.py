@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pin_slam_amd import ops, synth
 from pin_slam_amd._lib import GnParams
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
