@@ -31,6 +31,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+constexpr int MF_BLOCK = 256;  // 4 waves share one LDS image of the weights
+
+// PIN_DECODER=valu selects the thread-per-query vector decoder (A/B runs); default: matrix cores
+static inline bool use_mfma_decoder() {
+    static const int on = [] {
+        const char* e = getenv("PIN_DECODER");
+        return (e != nullptr && strcmp(e, "valu") == 0) ? 0 : 1;
+    }();
+    return on != 0;
+}
+
 template <int H>
 struct MfmaDecoder {
     static constexpr int MT = H / 16;          // unit tiles
@@ -233,6 +244,191 @@ struct MfmaDecoder {
         wave_lds_sync();
         return out;
     }
+
+    // ---- training: forward that leaves activations (unit-major rows, for the weight-gradient
+    // GEMM) and ReLU masks (one 64-bit word per lane and layer) in the workspace ----------------
+    __device__ __forceinline__ static float forward_store(const float* __restrict__ w, int L, float* __restrict__ xb,
+                                                          const float (&z)[MLP_IN], float* __restrict__ hws, size_t Qs,
+                                                          size_t q0, unsigned long long* __restrict__ mws,
+                                                          size_t mask_stride) {
+        const int lane = threadIdx.x & 63;
+        const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) xb[lane * XSTRIDE + j] = z[j];
+        xb[lane * XSTRIDE + 11] = 0.f;
+        wave_lds_sync();
+        v4f_t h[MT][4];
+        v4f_t acc[MT][4];
+        {
+            float zb[4][3];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) zb[nt][s] = xb[(16 * nt + n) * XSTRIDE + 4 * s + g];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const v4f_t b4 = *reinterpret_cast<const v4f_t*>(w + OFF_B0 + 16 * mt + 4 * g);
+                float a0[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) a0[s] = w[OFF_A0 + (mt * 3 + s) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    v4f_t c = b4;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], zb[nt][s], c, 0, 0, 0);
+                    acc[mt][nt] = c;
+                }
+            }
+        }
+        auto relu_store = [&](int l) {
+            unsigned long long mm = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = acc[mt][nt][r] > 0.f;
+                        mm |= (unsigned long long)on << ((mt * 4 + nt) * 4 + r);
+                        const float v = on ? acc[mt][nt][r] : 0.f;
+                        h[mt][nt][r] = v;
+                        hws[((size_t)l * H + 16 * mt + 4 * g + r) * Qs + q0 + 16 * nt + n] = v;
+                    }
+            mws[(size_t)l * mask_stride + lane] = mm;
+        };
+        relu_store(0);
+        for (int l = 1; l < L; ++l) {
+            const float* __restrict__ F = w + OFF_HID + (l - 1) * HID_SZ;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const v4f_t b4 = *reinterpret_cast<const v4f_t*>(F + H * H + 16 * mt + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b4;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    const v4f_t a4 = *reinterpret_cast<const v4f_t*>(F + ((mt * MT + kt) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], h[kt][nt][r], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            relu_store(l);
+        }
+        const float* __restrict__ O = w + off_out(L);
+        float xo[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[nt] = fmaf(wo[r], h[kt][nt][r], xo[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            xo[nt] += __shfl_xor(xo[nt], 16, 64);
+            xo[nt] += __shfl_xor(xo[nt], 32, 64);
+        }
+        wave_lds_sync();
+        return O[H] + (g == 0 ? xo[0] : g == 1 ? xo[1] : g == 2 ? xo[2] : xo[3]);
+    }
+
+    // ---- training: layer deltas from d loss / d out (per lane's own query), written unit-major
+    // for the weight-gradient GEMM; returns d loss / d z of this lane's query --------------------
+    __device__ __forceinline__ static void backward_store(const float* __restrict__ w, int L, float* __restrict__ xb,
+                                                          float dx, const unsigned long long* __restrict__ mws,
+                                                          size_t mask_stride, float* __restrict__ dws, size_t Qs,
+                                                          size_t q0, bool store, float (&dz)[MLP_IN]) {
+        const int lane = threadIdx.x & 63;
+        const int n = lane & 15, g = lane >> 4;
+        xb[lane] = dx;
+        wave_lds_sync();
+        float dxq[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dxq[nt] = xb[16 * nt + n];
+        wave_lds_sync();
+        const float* __restrict__ O = w + off_out(L);
+        v4f_t h[MT][4];
+        v4f_t acc[MT][4];
+        auto put = [&](int l) {
+            if (!store) return;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dws[((size_t)l * H + 16 * mt + 4 * g + r) * Qs + q0 + 16 * nt + n] = h[mt][nt][r];
+        };
+        {
+            const unsigned long long mm = mws[(size_t)(L - 1) * mask_stride + lane];
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[kt][nt][r] = ((mm >> ((kt * 4 + nt) * 4 + r)) & 1ull) ? wo[r] * dxq[nt] : 0.f;
+            }
+            put(L - 1);
+        }
+        for (int l = L - 1; l >= 1; --l) {
+            const float* __restrict__ F = w + OFF_HID + (l - 1) * HID_SZ;
+            const unsigned long long mm = mws[(size_t)(l - 1) * mask_stride + lane];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mj][nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ki = 0; ki < MT; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float at = F[((ki * MT + mj) * 64 + 16 * (n >> 2) + 4 * g + r) * 4 + (n & 3)];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[ki][nt][r], acc[mj][nt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[mj][nt][r] = ((mm >> ((mj * 4 + nt) * 4 + r)) & 1ull) ? acc[mj][nt][r] : 0.f;
+            put(l - 1);
+        }
+        v4f_t ai[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ai[nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float at = w[OFF_A0T + (kt * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    ai[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[kt][nt][r], ai[nt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < 12) xb[(16 * nt + n) * XSTRIDE + 4 * g + r] = ai[nt][r];
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) dz[j] = xb[lane * XSTRIDE + j];
+        wave_lds_sync();
+    }
+};
+
+template <int H>
+struct MfmaLds {
+    static constexpr int W = MfmaDecoder<H>::weight_floats(MLP_MAX_LEVELS);
+    static constexpr int TOTAL = W + (MF_BLOCK / 64) * MfmaDecoder<H>::scratch_floats();
 };
 
 }  // namespace pin

@@ -310,13 +310,6 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
 }
 
 // ---- the same two kernels with the decoder on the fp32 matrix cores (mlp_mfma.h) -----------
-constexpr int MF_BLOCK = 256;
-
-template <int H>
-struct MfmaLds {
-    static constexpr int W = MfmaDecoder<H>::weight_floats(MLP_MAX_LEVELS);
-    static constexpr int TOTAL = W + (MF_BLOCK / 64) * MfmaDecoder<H>::scratch_floats();
-};
 
 template <int H, bool WF>
 __global__ __launch_bounds__(MF_BLOCK) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
@@ -405,13 +398,6 @@ __global__ __launch_bounds__(MF_BLOCK) void gn_accumulate_mfma_kernel(pin_field 
     }
 }
 
-static bool use_mfma_decoder() {
-    static const int on = [] {
-        const char* e = getenv("PIN_DECODER");
-        return (e != nullptr && strcmp(e, "valu") == 0) ? 0 : 1;
-    }();
-    return on != 0;
-}
 
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
 // implicit_reg (utils/tracker.py:656-679) and the bookkeeping of Tracker.tracking (:147-184).

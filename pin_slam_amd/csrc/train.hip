@@ -11,7 +11,7 @@
 // ([row][Q], query contiguous) so that thread-per-query kernels write coalesced and the
 // weight-gradient GEMM reads K-contiguous operands.  At the batch sizes of the reference
 // (16k samples + 10k Eikonal queries) the workspace stays in L2 / Infinity Cache.
-#include "mlp.h"
+#include "mlp_mfma.h"
 
 namespace pin {
 
@@ -23,12 +23,13 @@ struct TrainWs {
     float* d;      // [L*H + 1][Qs] deltas; last row = d loss / d mlp_out
     float* pred;   // [Qs]
     float* dpred;  // [Qs]
+    unsigned long long* mask;  // [L][Qs] ReLU masks of the MFMA decoder (one word per lane and layer)
     int Qs;        // padded query count (multiple of 64)
 };
 
 __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L) {
     const size_t Qs = (size_t)((Q + 63) / 64) * 64;
-    return Qs * (12 + (size_t)L * H + (size_t)L * H + 1 + 2);
+    return Qs * (12 + (size_t)L * H + (size_t)L * H + 1 + 2 + 2 * (size_t)L);
 }
 
 __global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, int first,
@@ -191,6 +192,101 @@ __global__ __launch_bounds__(TR_BLOCK) void train_fwd_kernel(pin_field f, const 
                 if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
             }
     }
+}
+
+// ---- forward / backward with the decoder on the matrix cores (mlp_mfma.h) -------------------
+template <int H>
+__global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, const float* __restrict__ query,
+                                                                  const float4* __restrict__ nbr,
+                                                                  const int* __restrict__ nn_count, int Q, int n_main,
+                                                                  TrainWs ws, float* __restrict__ cert_rw,
+                                                                  int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
+    __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
+    float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    __syncthreads();
+    const int q0 = (blockIdx.x * (MF_BLOCK / 64) + (threadIdx.x >> 6)) * 64;
+    if (q0 >= ws.Qs) return;  // whole wave
+    const int qi = q0 + (threadIdx.x & 63);
+    const bool active = qi < Q;
+    const int qq = active ? qi : Q - 1;
+    NbrW nb;
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+    bool quirk[PIN_MAX_K];
+    neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
+    const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+    float z[MLP_IN];
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (nb.idx[t] >= 0) {
+            const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM);
+            const float4 a = row[0], b = row[1];
+            float v[3] = {vx[t], vy[t], vz[t]};
+            if (quirk[t]) {
+                const float* p = f.pos + 3 * (size_t)nb.idx[t];
+                v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+            }
+            if (f.orient != nullptr) {
+                const float4 q4 = reinterpret_cast<const float4*>(f.orient)[nb.idx[t]];
+                const float q0_ = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
+                const float r0 = 1 - 2 * (q2 * q2 + q3 * q3), r3 = 2 * (q1 * q2 - q0_ * q3), r6 = 2 * (q1 * q3 + q0_ * q2);
+                const float r1 = 2 * (q1 * q2 + q0_ * q3), r4 = 1 - 2 * (q1 * q1 + q3 * q3), r7 = 2 * (q2 * q3 - q0_ * q1);
+                const float r2 = 2 * (q1 * q3 - q0_ * q2), r5 = 2 * (q2 * q3 + q0_ * q1), r8 = 1 - 2 * (q1 * q1 + q2 * q2);
+                const float x = v[0], y = v[1], zz = v[2];
+                v[0] = r0 * x + r1 * y + r2 * zz; v[1] = r3 * x + r4 * y + r5 * zz; v[2] = r6 * x + r7 * y + r8 * zz;
+            }
+            const float w = nb.w[t];
+            z[0] = fmaf(w, a.x, z[0]); z[1] = fmaf(w, a.y, z[1]); z[2] = fmaf(w, a.z, z[2]); z[3] = fmaf(w, a.w, z[3]);
+            z[4] = fmaf(w, b.x, z[4]); z[5] = fmaf(w, b.y, z[5]); z[6] = fmaf(w, b.z, z[6]); z[7] = fmaf(w, b.w, z[7]);
+            z[8] = fmaf(w, v[0], z[8]); z[9] = fmaf(w, v[1], z[9]); z[10] = fmaf(w, v[2], z[10]);
+        }
+    const size_t Qs = ws.Qs;
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * Qs + qi] = z[j];
+    ws.z[(size_t)11 * Qs + qi] = 0.f;
+    const float out = MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, Qs, (size_t)q0, ws.mask + q0, Qs);
+    ws.pred[qi] = f.sdf_scale * out;
+    if (active && qi < n_main && cert_rw != nullptr) {
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
+            }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, const float4* __restrict__ nbr,
+                                                                  const int* __restrict__ nn_count, int Q, TrainWs ws,
+                                                                  float* __restrict__ feat_grad, int want_dec) {
+    __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
+    float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    __syncthreads();
+    const int q0 = (blockIdx.x * (MF_BLOCK / 64) + (threadIdx.x >> 6)) * 64;
+    if (q0 >= ws.Qs) return;
+    const int qi = q0 + (threadIdx.x & 63);
+    const bool active = qi < Q;
+    const size_t Qs = ws.Qs;
+    const float dx = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // d loss / d mlp_out
+    if (want_dec) ws.d[(size_t)(f.levels * H) * Qs + qi] = dx;
+    float dz[MLP_IN];
+    MfmaDecoder<H>::backward_store(lds, f.levels, xb, dx, ws.mask + q0, Qs, ws.d, Qs, (size_t)q0, want_dec != 0, dz);
+    if (!active || dx == 0.f) return;
+    NbrW nb;
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+    bool quirk[PIN_MAX_K];
+    neighbor_weights(nbr, nn_count[qi], qi, f.k, nb, vx, vy, vz, quirk);
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (nb.idx[t] >= 0) {
+            float* gp = feat_grad + (size_t)nb.idx[t] * PIN_FEATURE_DIM;
+#pragma unroll
+            for (int j = 0; j < PIN_FEATURE_DIM; ++j) atomicAdd(gp + j, nb.w[t] * dz[j]);
+        }
 }
 
 // ---- loss --------------------------------------------------------------------------------
@@ -487,19 +583,32 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     ws.h = w; w += (size_t)L * H * ws.Qs;
     ws.d = w; w += ((size_t)L * H + 1) * ws.Qs;
     ws.pred = w; w += ws.Qs;
-    ws.dpred = w;
+    ws.dpred = w; w += ws.Qs;
+    ws.mask = reinterpret_cast<unsigned long long*>(w);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
     PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));
-    if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
-    else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    const bool mfma = use_mfma_decoder();
+    const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
+    if (mfma) {
+        if (H == 64) hipLaunchKernelGGL(train_fwd_mfma_kernel<64>, mgrid, mblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        else hipLaunchKernelGGL(train_fwd_mfma_kernel<32>, mgrid, mblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    } else {
+        if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    }
     PIN_CHECK_LAUNCH();
     hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
                        sample_weight, ws, loss_out);
     PIN_CHECK_LAUNCH();
     const int want_dec = dec_grad != nullptr;
-    if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
-    else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    if (mfma) {
+        if (H == 64) hipLaunchKernelGGL(train_bwd_mfma_kernel<64>, mgrid, mblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        else hipLaunchKernelGGL(train_bwd_mfma_kernel<32>, mgrid, mblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    } else {
+        if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    }
     PIN_CHECK_LAUNCH();
     if (want_dec) {
         DwLayers dl;
