@@ -47,50 +47,63 @@ __device__ __forceinline__ int dir_find(const pin_brick_cache& bc, unsigned long
 
 // ---- build ----------------------------------------------------------------------------------
 // A: every local point registers the (up to 8) bricks that cover its +-n cell neighbourhood.
+// Brick ids are allocated wave-aggregated (one atomic per wave and slot, not per brick).
 __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin_search_params sp, int n_dilate,
                                                          int* __restrict__ counters) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= sp.n_points) return;
-    if (sp.global2local != nullptr && sp.global2local[j] < 0) return;  // not in the local map
-    const float4 P = reinterpret_cast<const float4*>(sp.pos4)[j];
-    const int g[3] = {(int)voxel_coord(P.x, sp.resolution), (int)voxel_coord(P.y, sp.resolution),
-                      (int)voxel_coord(P.z, sp.resolution)};
-    int lo[3], hi[3];
+    bool work = j < sp.n_points && !(sp.global2local != nullptr && sp.global2local[j] < 0);
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (work) {
+        const float4 P = reinterpret_cast<const float4*>(sp.pos4)[j];
+        const int g[3] = {(int)voxel_coord(P.x, sp.resolution), (int)voxel_coord(P.y, sp.resolution),
+                          (int)voxel_coord(P.z, sp.resolution)};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { lo[a] = (g[a] - n_dilate) >> 2; hi[a] = (g[a] + n_dilate) >> 2; }
-    // points are appended in voxel order per frame, so neighbours in memory mostly cover the
-    // same bricks: skip the directory traffic when the previous local point already did it
-    if (j > 0 && (sp.global2local == nullptr || sp.global2local[j - 1] >= 0)) {
-        const float4 Q = reinterpret_cast<const float4*>(sp.pos4)[j - 1];
-        const int q[3] = {(int)voxel_coord(Q.x, sp.resolution), (int)voxel_coord(Q.y, sp.resolution),
-                          (int)voxel_coord(Q.z, sp.resolution)};
-        bool same = true;
+        for (int a = 0; a < 3; ++a) { lo[a] = (g[a] - n_dilate) >> 2; hi[a] = (g[a] + n_dilate) >> 2; }
+        // points are appended in voxel order per frame, so neighbours in memory mostly cover the
+        // same bricks: skip the directory traffic when the previous local point already did it
+        if (j > 0 && (sp.global2local == nullptr || sp.global2local[j - 1] >= 0)) {
+            const float4 Q = reinterpret_cast<const float4*>(sp.pos4)[j - 1];
+            const int q[3] = {(int)voxel_coord(Q.x, sp.resolution), (int)voxel_coord(Q.y, sp.resolution),
+                              (int)voxel_coord(Q.z, sp.resolution)};
+            bool same = true;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) same = same && ((q[a] - n_dilate) >> 2) == lo[a] && ((q[a] + n_dilate) >> 2) == hi[a];
-        if (same) return;
+            for (int a = 0; a < 3; ++a) same = same && ((q[a] - n_dilate) >> 2) == lo[a] && ((q[a] + n_dilate) >> 2) == hi[a];
+            if (same) work = false;
+        }
     }
-    for (int bx = lo[0]; bx <= hi[0]; ++bx)
-        for (int by = lo[1]; by <= hi[1]; ++by)
-            for (int bz = lo[2]; bz <= hi[2]; ++bz) {
-                const unsigned long long key = brick_key(bx, by, bz);
-                unsigned int h = mix64(key) & bc.dir_mask;
-                for (int probe = 0; probe < 64; ++probe) {
-                    // most points find their bricks already registered: plain load before the CAS
-                    unsigned long long prev = __hip_atomic_load(reinterpret_cast<unsigned long long*>(bc.dir_keys) + h,
-                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (prev == BRICK_EMPTY)
-                        prev = atomicCAS(reinterpret_cast<unsigned long long*>(bc.dir_keys) + h, BRICK_EMPTY, key);
-                    if (prev == BRICK_EMPTY) {  // we own the slot: allocate a brick id
-                        const int id = atomicAdd(counters + 0, 1);
-                        if (id < bc.max_bricks) { bc.brick_keys[id] = key; bc.dir_vals[h] = id; }
-                        else { bc.dir_vals[h] = -1; atomicOr(counters + 2, 1); }
-                        break;
-                    }
-                    if (prev == key) break;
-                    h = (h + 1) & bc.dir_mask;
-                    if (probe == 63) atomicOr(counters + 2, 2);
-                }
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(bc.dir_keys);
+    const int lane = threadIdx.x & 63;
+    for (int s = 0; s < 8; ++s) {  // wave-uniform loop over the 2x2x2 brick slots
+        const int bx = lo[0] + (s >> 2), by = lo[1] + ((s >> 1) & 1), bz = lo[2] + (s & 1);
+        const bool has = work && bx <= hi[0] && by <= hi[1] && bz <= hi[2];
+        bool won = false;
+        unsigned int h = 0;
+        unsigned long long key = 0;
+        if (has) {
+            key = brick_key(bx, by, bz);
+            h = mix64(key) & bc.dir_mask;
+            for (int probe = 0; probe < 64; ++probe) {
+                unsigned long long prev = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev == BRICK_EMPTY) prev = atomicCAS(keys + h, BRICK_EMPTY, key);
+                if (prev == BRICK_EMPTY) { won = true; break; }
+                if (prev == key) break;
+                h = (h + 1) & bc.dir_mask;
+                if (probe == 63) atomicOr(counters + 2, 2);
             }
+        }
+        const unsigned long long bal = __ballot(won);
+        if (bal != 0ull) {
+            int base = 0;
+            const int leader = __ffsll((long long)bal) - 1;
+            if (lane == leader) base = atomicAdd(counters + 0, __popcll(bal));
+            base = __shfl(base, leader, 64);
+            if (won) {
+                const int id = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (id < bc.max_bricks) { bc.brick_keys[id] = key; bc.dir_vals[h] = id; }
+                else { bc.dir_vals[h] = -1; atomicOr(counters + 2, 1); }
+            }
+        }
+    }
 }
 
 // the reference's lookup chain for one cell: table -> time filter -> index space
@@ -114,36 +127,62 @@ __device__ __forceinline__ bool lookup_cell(const pin_search_params& sp, long lo
     return l >= 0;
 }
 
-// B: one wave per brick, one lane per cell; ballot -> mask, one atomic -> base, entries.
-__global__ __launch_bounds__(64) void brick_fill_kernel(pin_brick_cache bc, pin_search_params sp, float prune_dist2,
+// B: one lane per cell, one wave per brick at a time; a block (4 waves) takes 32 bricks and
+// reserves their entries with ONE atomic (a same-address atomic per brick serialises in L2:
+// that alone was 0.7 ms at 74k bricks).
+constexpr int FILL_PER_WAVE = 8;
+__global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin_search_params sp, float prune_dist2,
                                                         int* __restrict__ counters) {
-    const int b = blockIdx.x;
-    if (b >= min(counters[0], bc.max_bricks)) return;
-    const int lane = threadIdx.x;
-    const unsigned long long key = bc.brick_keys[b];
-    const int bx = (int)((key >> 42) & 0x1fffff) - (1 << 20), by = (int)((key >> 21) & 0x1fffff) - (1 << 20),
-              bz = (int)(key & 0x1fffff) - (1 << 20);
-    const int cx = bx * 4 + (lane >> 4), cy = by * 4 + ((lane >> 2) & 3), cz = bz * 4 + (lane & 3);
+    __shared__ int wave_tot[4];
+    __shared__ int block_base;
+    const int nb = min(counters[0], bc.max_bricks);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = (blockIdx.x * 4 + wave) * FILL_PER_WAVE;
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
-    float4 P; int l = -1;
-    bool ok = lookup_cell(sp, cx, cy, cz, d_cur, P, l);
-    if (ok) {  // prune what no probing query can accept (exactness preserved: see header)
-        const float r = sp.resolution;
-        const float ex = P.x - (cx + 0.5f) * r, ey = P.y - (cy + 0.5f) * r, ez = P.z - (cz + 0.5f) * r;
-        ok = (ex * ex + ey * ey + ez * ez) <= prune_dist2;
+    float4 P[FILL_PER_WAVE];
+    int l[FILL_PER_WAVE];
+    unsigned long long mask[FILL_PER_WAVE];
+    int tot = 0;
+#pragma unroll
+    for (int u = 0; u < FILL_PER_WAVE; ++u) {
+        const int b = b0 + u;
+        bool ok = false;
+        l[u] = -1;
+        if (b < nb) {
+            const unsigned long long key = bc.brick_keys[b];
+            const int bx = (int)((key >> 42) & 0x1fffff) - (1 << 20), by = (int)((key >> 21) & 0x1fffff) - (1 << 20),
+                      bz = (int)(key & 0x1fffff) - (1 << 20);
+            const int cx = bx * 4 + (lane >> 4), cy = by * 4 + ((lane >> 2) & 3), cz = bz * 4 + (lane & 3);
+            ok = lookup_cell(sp, cx, cy, cz, d_cur, P[u], l[u]);
+            if (ok) {  // prune what no probing query can accept (exactness preserved: see header)
+                const float r = sp.resolution;
+                const float ex = P[u].x - (cx + 0.5f) * r, ey = P[u].y - (cy + 0.5f) * r, ez = P[u].z - (cz + 0.5f) * r;
+                ok = (ex * ex + ey * ey + ez * ez) <= prune_dist2;
+            }
+        }
+        if (!ok) l[u] = -1;
+        mask[u] = __ballot(ok);
+        tot += __popcll(mask[u]);
     }
-    const unsigned long long mask = __ballot(ok);
-    int base = 0;
-    if (lane == 0) {
-        base = atomicAdd(counters + 1, __popcll(mask));
-        bc.brick_mask[b] = mask;
-        bc.brick_base[b] = base;
-    }
-    base = __shfl(base, 0, 64);
-    if (ok) {
-        const int e = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (e < bc.max_entries) reinterpret_cast<float4*>(bc.entries)[e] = make_float4(P.x, P.y, P.z, __int_as_float(l));
-        else atomicOr(counters + 2, 4);
+    if (lane == 0) wave_tot[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) block_base = atomicAdd(counters + 1, wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+    int base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+#pragma unroll
+    for (int u = 0; u < FILL_PER_WAVE; ++u) {
+        const int b = b0 + u;
+        if (b < nb) {
+            if (lane == 0) { bc.brick_mask[b] = mask[u]; bc.brick_base[b] = base; }
+            if (l[u] >= 0) {
+                const int e = base + __popcll(mask[u] & ((1ull << lane) - 1ull));
+                if (e < bc.max_entries)
+                    reinterpret_cast<float4*>(bc.entries)[e] = make_float4(P[u].x, P[u].y, P[u].z, __int_as_float(l[u]));
+                else atomicOr(counters + 2, 4);
+            }
+        }
+        base += __popcll(mask[u]);
     }
 }
 
@@ -295,7 +334,8 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     // within sqrt(max_valid_dist2): anything farther from the cell centre can never be accepted
     const float reach = (bc->n_dilate + 1.0f) * sp->resolution * 1.7320508f + sqrtf(sp->max_valid_dist2);
     const float prune = reach * reach * 1.02f;
-    hipLaunchKernelGGL(brick_fill_kernel, dim3(bc->max_bricks), dim3(64), 0, s, *bc, *sp, prune, counters_out);
+    hipLaunchKernelGGL(brick_fill_kernel, dim3(cdiv(bc->max_bricks, 4 * FILL_PER_WAVE)), dim3(256), 0, s, *bc, *sp, prune,
+                       counters_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
