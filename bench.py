@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sort-scan", type=int, default=1, help="voxel-order the scan once per frame")
+    ap.add_argument("--events", default="all", choices=["none", "knn", "all"],
+                    help="HIP events around the tracker's kNN / GN launches inside the timed region")
     ap.add_argument("--bricks", type=int, default=1, help="per-frame brick cache for the kNN (identical results)")
     return ap.parse_args()
 
@@ -135,18 +137,33 @@ def main():
     T_init[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
     T_init[:3, 3] = [0.05, -0.04, 0.02]
 
-    # HIP events around every kNN launch of the tracker (the dominant kernel), on the launch stream
-    ev_pairs = []
+    # HIP events around every GN-accumulate launch (the dominant kernel of the frame) and every kNN
+    # launch of the tracker, recorded on the launch stream inside the timed region
+    ev_pairs, gn_pairs = [], []
     cur_ev = {}
 
-    def on_knn(start):
-        if start:
-            cur_ev["a"] = torch.cuda.Event(enable_timing=True)
-            cur_ev["a"].record()
-        else:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
-            ev_pairs.append((cur_ev["a"], b))
+    ev_frames = min(2, args.steps)  # instrument the first timed frames only (events cost ~3 % each)
+    n_ev = ev_frames * args.reg_iters
+    pool = {t: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+            for t in ("k", "g")}  # created (and warmed) outside the timed region
+    for t in pool:
+        for a_, b_ in pool[t]:
+            a_.record(); b_.record()
+    torch.cuda.synchronize()
+
+    def bracket(store, tag):
+        def hook(start):
+            i = len(store) if start else len(store)
+            if start:
+                cur_ev[tag] = pool[tag][len(store)]
+                cur_ev[tag][0].record()
+            else:
+                cur_ev[tag][1].record()
+                store.append(cur_ev[tag])
+        return hook
+
+    on_knn = bracket(ev_pairs, "k") if args.events in ("knn", "all") else None
+    on_gn = bracket(gn_pairs, "g") if args.events == "all" else None
 
     bricks = ops.BrickCache(dx, 2) if args.bricks else None
     frame_batches = [batches(args.map_iters) for _ in range(args.warmup + args.steps)]
@@ -175,14 +192,14 @@ def main():
 
     for i in range(args.warmup):
         frame(i, False)
-    tracker.on_knn = on_knn
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        tracker.on_knn, tracker.on_gn = (on_knn, on_gn) if i < ev_frames else (None, None)
         frame(args.warmup + i, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    tracker.on_knn = None
+    tracker.on_knn = tracker.on_gn = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -190,6 +207,11 @@ def main():
         elapsed = float(t.item())
 
     knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+    gn_ms = float(np.mean([a.elapsed_time(b) for a, b in gn_pairs])) if gn_pairs else float("nan")
+    # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian
+    flops_q = 2 * 2 * (11 * H + (L - 1) * H * H + H)
+    gn_tflops = flops_q * args.scan / (gn_ms * 1e-3) / 1e12
+    FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA rate
     nn_mean = float(tracker.nn[:args.scan].float().mean().item())
     Kc = int(st.cand_off.numel())
     rho = nn_mean / Kc
@@ -197,13 +219,18 @@ def main():
     # one 4-byte slot per candidate cell, one 16-byte position per occupied cell, kNN record out
     bytes_q = 12 + 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4
     achieved = bytes_q * args.scan / (knn_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc.json")
+    pmc_data = {}
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pmc_data = json.load(open(pmc))
         except Exception:
-            traffic = None
+            pmc_data = {}
+
+    def pmc_get(key):
+        return pmc_data.get(key)
+
+    traffic = pmc_get("knn_brick_hbm_bytes_per_launch" if args.bricks else "knn_hbm_bytes_per_launch")
 
     frames_per_s = world * args.steps / elapsed
     q_total = trainer.buf.Q
@@ -221,10 +248,17 @@ def main():
         "tracker_ms_per_frame": round(1e3 * float(np.mean(stats["track"])), 3),
         "mapper_ms_per_frame": round(1e3 * float(np.mean(stats["map"])), 3),
         "gn_valid_points": int(stats["last"][1]), "gn_residual_cm": round(float(stats["last"][2]), 4),
-        "roofline": {"kernel": "knn_brick_kernel" if args.bricks else "knn_query_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
-                     "algorithmic_bytes_per_query": round(bytes_q, 1)},
+        "roofline": {"kernel": "gn_accumulate_mfma_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
+                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
+                     "traffic": pmc_get("gn_hbm_bytes_per_launch"), "avg_launch_ms": round(gn_ms, 4),
+                     "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,
+                     "share_of_frame": round(gn_ms * args.reg_iters / (1e3 * elapsed / args.steps), 3)},
+        "roofline_knn": {"kernel": "knn_brick_kernel" if args.bricks else "knn_query_kernel", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
+                         "algorithmic_bytes_per_query": round(bytes_q, 1),
+                         "share_of_frame": round(knn_ms * args.reg_iters / (1e3 * elapsed / args.steps), 3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(m, scan_np, pool_c, pool_l, feats.cpu().numpy(), dec.cpu().numpy(),

@@ -244,6 +244,12 @@ int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, v
 int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n,
                int32_t k, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
                void* stream);
+/* the two halves of pin_gn_accumulate_solve, separately launchable (bench.py brackets the
+ * accumulate kernel with HIP events) */
+int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const float* cur, const float* nbr,
+                          const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
+                          const double* state, void* stream);
+int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream);
 int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
                             const float* cur, const float* nbr, const int32_t* nn_count,
                             const float* sdf_labels, int32_t n, double* sums, double* state,

@@ -57,56 +57,95 @@ struct MfmaDecoder {
     __host__ __device__ static constexpr int scratch_floats() { return 64 * XSTRIDE; }  // per wave
 
     // Block-cooperative: permute the flat state_dict-ordered parameters into the LDS image.
+    // Loads are issued in batches of 8 independent requests per thread: a plain load->store loop
+    // is one L2 round trip per element (measured: ~35k of a wave's ~50k wait cycles).
+    template <typename SrcIndex>
+    __device__ __forceinline__ static void copy_permuted(const float* __restrict__ src, float* __restrict__ dst, int count,
+                                                         int tid, int nthreads, SrcIndex idx) {
+        for (int e0 = tid; e0 < count; e0 += 8 * nthreads) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * nthreads;
+                const int si = e < count ? idx(e) : -1;
+                v[u] = si >= 0 ? src[si] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * nthreads;
+                if (e < count) dst[e] = v[u];
+            }
+        }
+    }
+
     __device__ static void stage(const float* __restrict__ dec, int L, float* __restrict__ w, int tid, int nthreads) {
         const float* W0 = dec;
-        const float* b0 = dec + H * MLP_IN;
-        for (int e = tid; e < MT * 3 * 64; e += nthreads) {
+        copy_permuted(W0, w + OFF_A0, MT * 3 * 64, tid, nthreads, [](int e) {
             const int lane = e & 63, s = (e >> 6) % 3, mt = e / (3 * 64);
-            const int i = lane & 15, g = lane >> 4, c = 4 * s + g;
-            w[OFF_A0 + e] = c < MLP_IN ? W0[(16 * mt + i) * MLP_IN + c] : 0.f;
-        }
-        for (int e = tid; e < MT * 4 * 64; e += nthreads) {
+            const int c = 4 * s + (lane >> 4);
+            return c < MLP_IN ? (16 * mt + (lane & 15)) * MLP_IN + c : -1;
+        });
+        copy_permuted(W0, w + OFF_A0T, MT * 4 * 64, tid, nthreads, [](int e) {
             const int lane = e & 63, r = (e >> 6) & 3, kt = e >> 8;
-            const int c = lane & 15, g = lane >> 4;
-            w[OFF_A0T + e] = c < MLP_IN ? W0[(16 * kt + 4 * g + r) * MLP_IN + c] : 0.f;
-        }
-        for (int e = tid; e < H; e += nthreads) w[OFF_B0 + e] = b0[e];
+            const int c = lane & 15;
+            return c < MLP_IN ? (16 * kt + 4 * (lane >> 4) + r) * MLP_IN + c : -1;
+        });
+        copy_permuted(dec + H * MLP_IN, w + OFF_B0, H, tid, nthreads, [](int e) { return e; });
         const float* P = dec + H * MLP_IN + H;
         for (int l = 1; l < L; ++l) {
             float* F = w + OFF_HID + (l - 1) * HID_SZ;
-            for (int e = tid; e < H * H; e += nthreads) {
+            copy_permuted(P, F, H * H, tid, nthreads, [](int e) {
                 const int r = e & 3, lane = (e >> 2) & 63, kt = (e >> 8) % MT, mt = e / (256 * MT);
-                const int i = lane & 15, g = lane >> 4;
-                F[e] = P[(16 * mt + i) * H + 16 * kt + 4 * g + r];
-            }
-            for (int e = tid; e < H; e += nthreads) F[H * H + e] = P[H * H + e];
+                return (16 * mt + (lane & 15)) * H + 16 * kt + 4 * (lane >> 4) + r;
+            });
+            copy_permuted(P + H * H, F + H * H, H, tid, nthreads, [](int e) { return e; });
             P += H * H + H;
         }
-        float* O = w + off_out(L);
-        for (int e = tid; e < H + 1; e += nthreads) O[e] = P[e];
+        copy_permuted(P, w + off_out(L), H + 1, tid, nthreads, [](int e) { return e; });
     }
 
-    // Forward (+ input Jacobian) for the 64 queries of this wave.  z: this lane's query input.
-    // Returns the raw MLP output of this lane's query; a_in = d out / d z if GRAD.
-    template <bool GRAD>
+    // Forward (+ input Jacobian) for the 64 queries of this wave, NT query tiles (16 queries
+    // each) per pass: fewer live accumulators -> 2 waves per SIMD, whose memory phases then
+    // overlap the other wave's MFMAs.  z: this lane's query input.  Returns the raw MLP output
+    // of this lane's query; a_in = d out / d z if GRAD.
+    template <bool GRAD, int NT = 2>
     __device__ __forceinline__ static float run(const float* __restrict__ w, int L, float* __restrict__ xb,
                                                 const float (&z)[MLP_IN], float (&a_in)[MLP_IN]) {
         const int lane = threadIdx.x & 63;
-        const int n = lane & 15, g = lane >> 4;
-        // ---- exchange: thread-per-query z  ->  B operand layout
 #pragma unroll
         for (int j = 0; j < MLP_IN; ++j) xb[lane * XSTRIDE + j] = z[j];
         xb[lane * XSTRIDE + 11] = 0.f;
         wave_lds_sync();
-        v4f_t h[MT][4];   // activations: [unit tile][query tile], register r = unit 4g + r
-        v4f_t acc[MT][4];
-        unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;  // ReLU masks per layer, bit (mt*4+nt)*4+r
+        float out = 0.f;
+#pragma unroll 1
+        for (int p = 0; p < 4 / NT; ++p) {
+            const float o = pass<GRAD, NT>(w, L, xb, 16 * NT * p);
+            if ((lane >> 4) / NT == p) out = o;
+        }
+        if (GRAD) {
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < MLP_IN; ++j) a_in[j] = xb[lane * XSTRIDE + j];
+            wave_lds_sync();
+        }
+        return out;
+    }
+
+    // one pass: queries qb .. qb + 16*NT - 1 of the wave (rows of xb); z rows are consumed before
+    // the Jacobian rows of the same queries are written back
+    template <bool GRAD, int NT>
+    __device__ __forceinline__ static float pass(const float* __restrict__ w, int L, float* __restrict__ xb, int qb) {
+        const int lane = threadIdx.x & 63;
+        const int n = lane & 15, g = lane >> 4;
+        v4f_t h[MT][NT];   // activations: [unit tile][query tile], register r = unit 4g + r
+        v4f_t acc[MT][NT];
+        unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;  // ReLU masks per layer, bit (mt*NT+nt)*4+r
         {
-            float zb[4][3];
+            float zb[NT][3];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) zb[nt][s] = xb[(16 * nt + n) * XSTRIDE + 4 * s + g];
+                for (int s = 0; s < 3; ++s) zb[nt][s] = xb[(qb + 16 * nt + n) * XSTRIDE + 4 * s + g];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const v4f_t b4 = *reinterpret_cast<const v4f_t*>(w + OFF_B0 + 16 * mt + 4 * g);
@@ -114,7 +153,7 @@ struct MfmaDecoder {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) a0[s] = w[OFF_A0 + (mt * 3 + s) * 64 + lane];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     v4f_t c = b4;
 #pragma unroll
                     for (int s = 0; s < 3; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], zb[nt][s], c, 0, 0, 0);
@@ -127,11 +166,11 @@ struct MfmaDecoder {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool on = acc[mt][nt][r] > 0.f;
-                        mm |= (unsigned long long)on << ((mt * 4 + nt) * 4 + r);
+                        mm |= (unsigned long long)on << ((mt * NT + nt) * 4 + r);
                         h[mt][nt][r] = on ? acc[mt][nt][r] : 0.f;
                     }
             m = mm;
@@ -143,14 +182,14 @@ struct MfmaDecoder {
             for (int mt = 0; mt < MT; ++mt) {
                 const v4f_t b4 = *reinterpret_cast<const v4f_t*>(F + H * H + 16 * mt + 4 * g);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = b4;
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b4;
 #pragma unroll
                 for (int kt = 0; kt < MT; ++kt) {
                     const v4f_t a4 = *reinterpret_cast<const v4f_t*>(F + ((mt * MT + kt) * 64 + lane) * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
+                        for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], h[kt][nt][r], acc[mt][nt], 0, 0, 0);
                 }
             }
@@ -160,22 +199,26 @@ struct MfmaDecoder {
         }
         // ---- output layer: partial dot over this lane's units, reduced over the 4 k-groups
         const float* __restrict__ O = w + off_out(L);
-        float xo[4] = {0.f, 0.f, 0.f, 0.f};
+        float xo[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xo[nt] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xo[nt] = fmaf(wo[r], h[kt][nt][r], xo[nt]);
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             xo[nt] += __shfl_xor(xo[nt], 16, 64);
             xo[nt] += __shfl_xor(xo[nt], 32, 64);
         }
-        // this lane's own query is 16*g + n, i.e. query tile nt = g
-        const float out = O[H] + (g == 0 ? xo[0] : g == 1 ? xo[1] : g == 2 ? xo[2] : xo[3]);
+        // this lane's own query is row `lane`: inside this pass it is query tile (lane - qb) / 16
+        float out = O[H];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) out += (lane - qb == 16 * nt + n) ? xo[nt] : 0.f;
         if (!GRAD) return out;
 
         // ---- input Jacobian: a = W_out masked, then a <- mask .* (W_l^T a) down the layers
@@ -186,10 +229,10 @@ struct MfmaDecoder {
             for (int kt = 0; kt < MT; ++kt) {
                 const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h[kt][nt][r] = ((mm >> ((kt * 4 + nt) * 4 + r)) & 1ull) ? wo[r] : 0.f;
+                        h[kt][nt][r] = ((mm >> ((kt * NT + nt) * 4 + r)) & 1ull) ? wo[r] : 0.f;
             }
         }
         for (int l = L - 1; l >= 1; --l) {
@@ -198,7 +241,7 @@ struct MfmaDecoder {
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mj][nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NT; ++nt) acc[mj][nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ki = 0; ki < MT; ++ki)
 #pragma unroll
@@ -206,42 +249,37 @@ struct MfmaDecoder {
                         // W_l[16*ki + 4*g + r][16*mj + n] out of the forward image (see header)
                         const float at = F[((ki * MT + mj) * 64 + 16 * (n >> 2) + 4 * g + r) * 4 + (n & 3)];
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
+                        for (int nt = 0; nt < NT; ++nt)
                             acc[mj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[ki][nt][r], acc[mj][nt], 0, 0, 0);
                     }
             }
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h[mj][nt][r] = ((mm >> ((mj * 4 + nt) * 4 + r)) & 1ull) ? acc[mj][nt][r] : 0.f;
+                        h[mj][nt][r] = ((mm >> ((mj * NT + nt) * 4 + r)) & 1ull) ? acc[mj][nt][r] : 0.f;
         }
         // layer 0 transposed: a_in[c][q] = sum_i W0[i][c] a0[i][q]
-        v4f_t ai[4];
+        v4f_t ai[NT];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) ai[nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) ai[nt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float at = w[OFF_A0T + (kt * 4 + r) * 64 + lane];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     ai[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, h[kt][nt][r], ai[nt], 0, 0, 0);
             }
-        // ---- exchange back: lane (n, g) holds components 4g + r of query 16*nt + n
-        wave_lds_sync();
+        // ---- exchange back: lane (n, g) holds components 4g + r of query qb + 16*nt + n
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * g + r < 12) xb[(16 * nt + n) * XSTRIDE + 4 * g + r] = ai[nt][r];
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < MLP_IN; ++j) a_in[j] = xb[lane * XSTRIDE + j];
-        wave_lds_sync();
+                if (4 * g + r < 12) xb[(qb + 16 * nt + n) * XSTRIDE + 4 * g + r] = ai[nt][r];
         return out;
     }
 

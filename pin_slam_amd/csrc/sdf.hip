@@ -312,7 +312,7 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
 // ---- the same two kernels with the decoder on the fp32 matrix cores (mlp_mfma.h) -----------
 
 template <int H, bool WF>
-__global__ __launch_bounds__(MF_BLOCK) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
+__global__ __launch_bounds__(MF_BLOCK, 2) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int n,
                                                                   float* __restrict__ sdf_out, float* __restrict__ grad_out,
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(MF_BLOCK) void sdf_query_mfma_kernel(pin_field f, c
 }
 
 template <int H, bool WF>
-__global__ __launch_bounds__(MF_BLOCK) void gn_accumulate_mfma_kernel(pin_field f, pin_gn_params gp,
+__global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_field f, pin_gn_params gp,
                                                                       const float* __restrict__ query,
                                                                       const float4* __restrict__ nbr,
                                                                       const int* __restrict__ nn_count,
@@ -646,19 +646,33 @@ extern "C" int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc
     return knn_direct_dev(sp, src, n, k, state, cur_out, nbr_out, nn_count_out, stream);
 }
 
-extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
-                                       const float* cur, const float* nbr, const int32_t* nn_count,
-                                       const float* sdf_labels, int32_t n, double* sums, double* state, void* stream) {
+extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const float* cur, const float* nbr,
+                                    const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
+                                    const double* state, void* stream) {
     PIN_ENTER();
     if (int e = check_field(f)) return e;
-    PIN_CHECK_ARG(gp && lp && sums && state && n > 0, "bad arguments");
+    PIN_CHECK_ARG(gp && sums && state && n > 0, "bad arguments");
     PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
     hipStream_t s = as_stream(stream);
     PIN_DISPATCH_FIELD(f, gn_accumulate, n, s, *f, *gp, cur, reinterpret_cast<const float4*>(nbr), nn_count, sdf_labels,
-                       n, sums, (float*)nullptr, (float*)nullptr, (const double*)state);
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, s, sums, state, *lp);
+                       n, sums, (float*)nullptr, (float*)nullptr, state);
     PIN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(sums && state && lp, "NULL pointer");
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
+                                       const float* cur, const float* nbr, const int32_t* nn_count,
+                                       const float* sdf_labels, int32_t n, double* sums, double* state, void* stream) {
+    if (int e = pin_gn_accumulate_dev(f, gp, cur, nbr, nn_count, sdf_labels, n, sums, state, stream)) return e;
+    return pin_gn_solve(sums, state, lp, stream);
 }
 
 extern "C" int pin_query_feature(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count, int32_t n,

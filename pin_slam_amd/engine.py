@@ -29,7 +29,8 @@ class GNTracker:
         self.cur = torch.empty((n_max, 3), dtype=torch.float32, device=dev)
         self.sums = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64, device=dev)
         self.sums_host = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64).pin_memory()
-        self.on_knn = None  # optional hook(start: bool) used by bench.py to bracket the kNN launch
+        self.on_knn = None  # optional hooks(start: bool) used by bench.py to bracket the kNN / GN launches
+        self.on_gn = None
         self.bricks = None  # ops.BrickCache built for (time_filtering, local) of the calls below
         self.state = self.state_host = None
 
@@ -89,7 +90,13 @@ class GNTracker:
             rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)
             if self.on_knn:
                 self.on_knn(False)
-            rc |= L.pin_gn_accumulate_solve(f_r, gp_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+            if self.on_gn:
+                self.on_gn(True)
+                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+                self.on_gn(False)
+                rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
+            else:
+                rc |= L.pin_gn_accumulate_solve(f_r, gp_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
             if rc:
                 check(rc, "pin_gn_knn / pin_gn_accumulate_solve")
         self.state_host.copy_(self.state, non_blocking=True)

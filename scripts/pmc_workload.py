@@ -33,8 +33,10 @@ for _ in range(3):
     b.copy_(a)
 torch.cuda.synchronize()
 out = None
+bricks = ops.BrickCache(dx, 2).build(st)
 for i in range(10):
-    nbr, nn, cur = ops.knn_query(st, scan, 8, pose=np.eye(4), out=out)
+    nbr, nn, cur = ops.knn_query(st, scan, 8, pose=np.eye(4), out=out)       # direct hash probe (r01 a-c)
+    nbr, nn, cur = ops.knn_query(st, scan, 8, pose=np.eye(4), out=out, bricks=bricks)  # brick cache
     out = (nbr, nn, cur)
     sums, _, _ = ops.gn_accumulate(fs, gp, cur, nbr, nn)
 torch.cuda.synchronize()
