@@ -312,7 +312,8 @@ int pin_gather_batch(const float* pool_coord, const float* pool_label, const flo
 int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
                            int32_t first, float eps, float* query_out, void* stream);
 
-int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels);
+/* expand = 1 for weighted_first, query_nn_k otherwise (one decode per neighbour) */
+int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels, int32_t expand);
 
 /* K6: fused forward -> BCE-with-logits (utils/loss.py:45-63) + Eikonal (mapper.py:777-780)
  * -> backward over the queries produced by pin_train_make_queries and searched with

@@ -23,13 +23,15 @@ struct TrainWs {
     float* d;      // [L*H + 1][Qs] deltas; last row = d loss / d mlp_out
     float* pred;   // [Qs]
     float* dpred;  // [Qs]
-    unsigned long long* mask;  // [L][Qs] ReLU masks of the MFMA decoder (one word per lane and layer)
+    unsigned long long* mask;  // [L][QsT] ReLU masks of the MFMA decoder (one word per lane and layer)
     int Qs;        // padded query count (multiple of 64)
+    int QsT;       // sample columns of z / h / d / mask: Qs (weighted_first) or k * Qs (one decode per neighbour)
 };
 
-__host__ __device__ inline size_t train_ws_floats(int Q, int H, int L) {
+__host__ __device__ inline size_t train_ws_floats(int Q, int H, int L, int expand) {
     const size_t Qs = (size_t)((Q + 63) / 64) * 64;
-    return Qs * (12 + (size_t)L * H + (size_t)L * H + 1 + 2 + 2 * (size_t)L);
+    const size_t QsT = Qs * (size_t)expand;
+    return QsT * (12 + (size_t)L * H + (size_t)L * H + 1 + 2 * (size_t)L) + 2 * Qs;
 }
 
 __global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, int first,
@@ -195,7 +197,29 @@ __global__ __launch_bounds__(TR_BLOCK) void train_fwd_kernel(pin_field f, const 
 }
 
 // ---- forward / backward with the decoder on the matrix cores (mlp_mfma.h) -------------------
-template <int H>
+// one neighbour's decoder input [f_t; v_t]
+__device__ __forceinline__ void neighbor_input(const pin_field& f, int idx, bool quirk, float vgx, float vgy, float vgz,
+                                               float qx, float qy, float qz, float (&ft)[PIN_FEATURE_DIM], float (&v)[3]) {
+    const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)idx * PIN_FEATURE_DIM);
+    const float4 a = row[0], b = row[1];
+    ft[0] = a.x; ft[1] = a.y; ft[2] = a.z; ft[3] = a.w; ft[4] = b.x; ft[5] = b.y; ft[6] = b.z; ft[7] = b.w;
+    v[0] = vgx; v[1] = vgy; v[2] = vgz;
+    if (quirk) {
+        const float* p = f.pos + 3 * (size_t)idx;
+        v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+    }
+    if (f.orient != nullptr) {  // apply_quaternion_rotation (utils/tools.py:428-437): conjugate rotation
+        const float4 q4 = reinterpret_cast<const float4*>(f.orient)[idx];
+        const float q0_ = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
+        const float r0 = 1 - 2 * (q2 * q2 + q3 * q3), r3 = 2 * (q1 * q2 - q0_ * q3), r6 = 2 * (q1 * q3 + q0_ * q2);
+        const float r1 = 2 * (q1 * q2 + q0_ * q3), r4 = 1 - 2 * (q1 * q1 + q3 * q3), r7 = 2 * (q2 * q3 - q0_ * q1);
+        const float r2 = 2 * (q1 * q3 - q0_ * q2), r5 = 2 * (q2 * q3 + q0_ * q1), r8 = 1 - 2 * (q1 * q1 + q2 * q2);
+        const float x = v[0], y = v[1], zz = v[2];
+        v[0] = r0 * x + r1 * y + r2 * zz; v[1] = r3 * x + r4 * y + r5 * zz; v[2] = r6 * x + r7 * y + r8 * zz;
+    }
+}
+
+template <int H, bool WF>
 __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int Q, int n_main,
@@ -215,39 +239,55 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
     bool quirk[PIN_MAX_K];
     neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
     const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
-    float z[MLP_IN];
+    const size_t QsT = ws.QsT;
+    float pred;
+    if (WF) {
+        float z[MLP_IN];
 #pragma unroll
-    for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+        for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
 #pragma unroll
-    for (int t = 0; t < PIN_MAX_K; ++t)
-        if (nb.idx[t] >= 0) {
-            const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM);
-            const float4 a = row[0], b = row[1];
-            float v[3] = {vx[t], vy[t], vz[t]};
-            if (quirk[t]) {
-                const float* p = f.pos + 3 * (size_t)nb.idx[t];
-                v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+        for (int t = 0; t < PIN_MAX_K; ++t)
+            if (nb.idx[t] >= 0) {
+                float ft[PIN_FEATURE_DIM], v[3];
+                neighbor_input(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, ft, v);
+                const float w = nb.w[t];
+#pragma unroll
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = fmaf(w, ft[j], z[j]);
+                z[8] = fmaf(w, v[0], z[8]); z[9] = fmaf(w, v[1], z[9]); z[10] = fmaf(w, v[2], z[10]);
             }
-            if (f.orient != nullptr) {
-                const float4 q4 = reinterpret_cast<const float4*>(f.orient)[nb.idx[t]];
-                const float q0_ = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
-                const float r0 = 1 - 2 * (q2 * q2 + q3 * q3), r3 = 2 * (q1 * q2 - q0_ * q3), r6 = 2 * (q1 * q3 + q0_ * q2);
-                const float r1 = 2 * (q1 * q2 + q0_ * q3), r4 = 1 - 2 * (q1 * q1 + q3 * q3), r7 = 2 * (q2 * q3 - q0_ * q1);
-                const float r2 = 2 * (q1 * q3 - q0_ * q2), r5 = 2 * (q2 * q3 + q0_ * q1), r8 = 1 - 2 * (q1 * q1 + q2 * q2);
-                const float x = v[0], y = v[1], zz = v[2];
-                v[0] = r0 * x + r1 * y + r2 * zz; v[1] = r3 * x + r4 * y + r5 * zz; v[2] = r6 * x + r7 * y + r8 * zz;
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + qi] = z[j];
+        ws.z[(size_t)11 * QsT + qi] = 0.f;
+        pred = f.sdf_scale * MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, QsT, (size_t)q0, ws.mask + q0, QsT);
+    } else {
+        // weighted_first = False (run_kitti.yaml:25): decode every neighbour, then weight the
+        // predictions (mapper.py:658-662); neighbour t of all queries forms sample block t
+        pred = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < f.k; ++t) {
+            int idx = -1; float wt = 0.f, gx = 0.f, gy = 0.f, gz = 0.f; bool qk = false;
+#pragma unroll
+            for (int u = 0; u < PIN_MAX_K; ++u)
+                if (u == t) { idx = nb.idx[u]; wt = nb.w[u]; gx = vx[u]; gy = vy[u]; gz = vz[u]; qk = quirk[u]; }
+            float z[MLP_IN];
+#pragma unroll
+            for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+            if (idx >= 0) {
+                float ft[PIN_FEATURE_DIM], v[3];
+                neighbor_input(f, idx, qk, gx, gy, gz, qx, qy, qz, ft, v);
+#pragma unroll
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = ft[j];
+                z[8] = v[0]; z[9] = v[1]; z[10] = v[2];
             }
-            const float w = nb.w[t];
-            z[0] = fmaf(w, a.x, z[0]); z[1] = fmaf(w, a.y, z[1]); z[2] = fmaf(w, a.z, z[2]); z[3] = fmaf(w, a.w, z[3]);
-            z[4] = fmaf(w, b.x, z[4]); z[5] = fmaf(w, b.y, z[5]); z[6] = fmaf(w, b.z, z[6]); z[7] = fmaf(w, b.w, z[7]);
-            z[8] = fmaf(w, v[0], z[8]); z[9] = fmaf(w, v[1], z[9]); z[10] = fmaf(w, v[2], z[10]);
+            const size_t col0 = (size_t)t * ws.Qs + q0;
+#pragma unroll
+            for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + col0 + (threadIdx.x & 63)] = z[j];
+            ws.z[(size_t)11 * QsT + col0 + (threadIdx.x & 63)] = 0.f;
+            const float xt = MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, QsT, col0, ws.mask + col0, QsT);
+            if (idx >= 0) pred = fmaf(wt, f.sdf_scale * xt, pred);
         }
-    const size_t Qs = ws.Qs;
-#pragma unroll
-    for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * Qs + qi] = z[j];
-    ws.z[(size_t)11 * Qs + qi] = 0.f;
-    const float out = MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, Qs, (size_t)q0, ws.mask + q0, Qs);
-    ws.pred[qi] = f.sdf_scale * out;
+    }
+    ws.pred[qi] = pred;
     if (active && qi < n_main && cert_rw != nullptr) {
 #pragma unroll
         for (int t = 0; t < PIN_MAX_K; ++t)
@@ -258,7 +298,7 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
     }
 }
 
-template <int H>
+template <int H, bool WF>
 __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int Q, TrainWs ws,
                                                                   float* __restrict__ feat_grad, int want_dec) {
@@ -268,16 +308,11 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
     __syncthreads();
     const int q0 = (blockIdx.x * (MF_BLOCK / 64) + (threadIdx.x >> 6)) * 64;
     if (q0 >= ws.Qs) return;
-    const int qi = q0 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    const int qi = q0 + lane;
     const bool active = qi < Q;
-    const size_t Qs = ws.Qs;
-    const float dx = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // d loss / d mlp_out
-    if (want_dec) ws.d[(size_t)(f.levels * H) * Qs + qi] = dx;
-    float dz[MLP_IN];
-    MfmaDecoder<H>::backward_store(lds, f.levels, xb, dx, ws.mask + q0, Qs, ws.d, Qs, (size_t)q0, want_dec != 0, dz);
-    // Feature-gradient scatter.  One atomic instruction per QUERY: its 64 lanes are the 8
-    // neighbours x 8 feature dims, so every instruction touches 8 whole 32-byte rows instead of
-    // 64 different rows (the L2 atomic units work per cache line; measured 4x on this kernel).
+    const size_t QsT = ws.QsT;
+    const float dxq = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // d loss / d (sum_t w_t x_t)
     NbrW nb;
     {
         float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
@@ -285,29 +320,61 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
         const int qq = active ? qi : Q - 1;
         neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
     }
-    const bool live = active && dx != 0.f;
-    const int lane = threadIdx.x & 63;
-    float* sdz = xb;                 // [32][8]
+    const bool live = active && dxq != 0.f;
+    float* sdz = xb;                 // [32][8] (WF) / [64][8] (per-neighbour mode)
     float* sw = xb + 256;            // [32][8]
-    int* sidx = reinterpret_cast<int*>(xb + 512);  // [32][8]
-    for (int half = 0; half < 2; ++half) {
-        if ((lane >> 5) == half) {
-            const int ql = lane & 31;
+    int* sidx = reinterpret_cast<int*>(xb + 512);  // [32][8] / [64]
+    if (WF) {
+        if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + qi] = dxq;
+        float dz[MLP_IN];
+        MfmaDecoder<H>::backward_store(lds, f.levels, xb, dxq, ws.mask + q0, QsT, ws.d, QsT, (size_t)q0, want_dec != 0, dz);
+        // Feature-gradient scatter.  One atomic instruction per QUERY: its 64 lanes are the 8
+        // neighbours x 8 feature dims, so every instruction touches 8 whole 32-byte rows instead
+        // of 64 different rows (the L2 atomic units work per cache line; measured 3x on this kernel).
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+                const int ql = lane & 31;
 #pragma unroll
-            for (int j = 0; j < PIN_FEATURE_DIM; ++j) sdz[ql * 8 + j] = dz[j];
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) sdz[ql * 8 + j] = dz[j];
 #pragma unroll
-            for (int t = 0; t < PIN_MAX_K; ++t) {
-                sw[ql * 8 + t] = nb.w[t];
-                sidx[ql * 8 + t] = live ? nb.idx[t] : -1;
+                for (int t = 0; t < PIN_MAX_K; ++t) {
+                    sw[ql * 8 + t] = nb.w[t];
+                    sidx[ql * 8 + t] = live ? nb.idx[t] : -1;
+                }
             }
+            wave_lds_sync();
+            const int t = lane >> 3, j = lane & 7;
+            for (int i = 0; i < 32; ++i) {
+                const int idx = sidx[i * 8 + t];
+                if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
+            }
+            wave_lds_sync();
         }
-        wave_lds_sync();
-        const int t = lane >> 3, j = lane & 7;
-        for (int i = 0; i < 32; ++i) {
-            const int idx = sidx[i * 8 + t];
-            if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < f.k; ++t) {
+            int idx = -1; float wt = 0.f;
+#pragma unroll
+            for (int u = 0; u < PIN_MAX_K; ++u)
+                if (u == t) { idx = nb.idx[u]; wt = nb.w[u]; }
+            const float dx = (live && idx >= 0) ? dxq * wt : 0.f;  // d loss / d x_t
+            const size_t col0 = (size_t)t * ws.Qs + q0;
+            if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + col0 + lane] = dx;
+            float dz[MLP_IN];
+            MfmaDecoder<H>::backward_store(lds, f.levels, xb, dx, ws.mask + col0, QsT, ws.d, QsT, col0, want_dec != 0, dz);
+            // one neighbour per query here: 8 queries x 8 feature dims per atomic instruction
+#pragma unroll
+            for (int j = 0; j < PIN_FEATURE_DIM; ++j) sdz[lane * 8 + j] = dz[j];
+            sidx[lane] = dx != 0.f ? idx : -1;
+            wave_lds_sync();
+            const int qo = lane >> 3, j = lane & 7;
+            for (int i = 0; i < 8; ++i) {
+                const int ql = i * 8 + qo;
+                const int id = sidx[ql];
+                if (id >= 0) atomicAdd(feat_grad + (size_t)id * PIN_FEATURE_DIM + j, sdz[ql * 8 + j]);
+            }
+            wave_lds_sync();
         }
-        wave_lds_sync();
     }
 }
 
@@ -419,7 +486,7 @@ __global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DwLayers {
-    int H, L, Q, Qs, per_wave;
+    int H, L, Q, Qs, per_wave;  // Q / Qs: sample columns (valid / row stride)
 };
 
 __device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int row, int nrows, int Qs, int q, int Q) {
@@ -548,8 +615,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 
 using namespace pin;
 
-extern "C" int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels) {
-    return (int64_t)train_ws_floats(n_queries, hidden, levels) * 4;
+extern "C" int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels, int32_t expand) {
+    return (int64_t)train_ws_floats(n_queries, hidden, levels, expand < 1 ? 1 : expand) * 4;
 }
 
 extern "C" int pin_gather_batch(const float* pool_coord, const float* pool_label, const float* pool_weight,
@@ -590,31 +657,39 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
     PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
     PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
-    PIN_CHECK_ARG(f->weighted_first, "pin_train_step implements weighted_first=True only");
+    const bool mfma = use_mfma_decoder();
+    PIN_CHECK_ARG(f->weighted_first || mfma, "weighted_first=False training needs the MFMA decoder (unset PIN_DECODER)");
+    const int expand = f->weighted_first ? 1 : f->k;
     PIN_CHECK_ARG(tp->n_main > 0 && tp->n_eik >= 0, "bad batch sizes");
     const int Q = tp->n_main + 6 * tp->n_eik;
     const int H = f->hidden, L = f->levels;
-    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(Q, H, L) * 4, "workspace too small");
+    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(Q, H, L, expand) * 4, "workspace too small");
     PIN_CHECK_ARG(query && nbr && nn_count && sdf_label && feat_grad && loss_out && f->feats && f->dec, "NULL pointer");
     PIN_CHECK_ARG(!tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
     hipStream_t s = as_stream(stream);
     TrainWs ws;
     ws.Qs = ((Q + 63) / 64) * 64;
+    ws.QsT = ws.Qs * expand;
     float* w = reinterpret_cast<float*>(workspace);
-    ws.z = w; w += (size_t)12 * ws.Qs;
-    ws.h = w; w += (size_t)L * H * ws.Qs;
-    ws.d = w; w += ((size_t)L * H + 1) * ws.Qs;
     ws.pred = w; w += ws.Qs;
     ws.dpred = w; w += ws.Qs;
+    ws.z = w; w += (size_t)12 * ws.QsT;
+    ws.h = w; w += (size_t)L * H * ws.QsT;
+    ws.d = w; w += ((size_t)L * H + 1) * ws.QsT;
     ws.mask = reinterpret_cast<unsigned long long*>(w);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
     PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));
-    const bool mfma = use_mfma_decoder();
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
+#define PIN_TRAIN_MFMA(KERNEL, ...)                                                                      \
+    do {                                                                                                 \
+        if (H == 64) { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<64, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
+                       else hipLaunchKernelGGL((KERNEL<64, false>), mgrid, mblock, 0, s, __VA_ARGS__); }  \
+        else { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
+               else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__); }          \
+    } while (0)
     if (mfma) {
-        if (H == 64) hipLaunchKernelGGL(train_fwd_mfma_kernel<64>, mgrid, mblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
-        else hipLaunchKernelGGL(train_fwd_mfma_kernel<32>, mgrid, mblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     } else {
         if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
         else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
@@ -625,8 +700,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     PIN_CHECK_LAUNCH();
     const int want_dec = dec_grad != nullptr;
     if (mfma) {
-        if (H == 64) hipLaunchKernelGGL(train_bwd_mfma_kernel<64>, mgrid, mblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
-        else hipLaunchKernelGGL(train_bwd_mfma_kernel<32>, mgrid, mblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     } else {
         if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
         else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
@@ -634,11 +708,13 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     PIN_CHECK_LAUNCH();
     if (want_dec) {
         DwLayers dl;
-        dl.H = H; dl.L = L; dl.Q = Q; dl.Qs = ws.Qs;
+        // sample columns: Q for weighted_first; k blocks of Qs otherwise (padding columns carry zero deltas)
+        const int QT = expand == 1 ? Q : ws.QsT;
+        dl.H = H; dl.L = L; dl.Q = QT; dl.Qs = ws.QsT;
         int per_wave = 64;  // multiple of 16; cap the grid at ~256 blocks per layer
-        while ((long)cdiv(Q, per_wave * 4) > 256) per_wave *= 2;
+        while ((long)cdiv(QT, per_wave * 4) > 256) per_wave *= 2;
         dl.per_wave = per_wave;
-        hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(Q, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
+        hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(QT, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
         PIN_CHECK_LAUNCH();
     }
     if (pred_out) PIN_CHECK_HIP(hipMemcpyAsync(pred_out, ws.pred, sizeof(float) * tp->n_main, hipMemcpyDeviceToDevice, s));

@@ -91,7 +91,6 @@ class Mapper(_Base):
         if c.ekional_loss_on and c.ekional_add_to != "all": bad.append("ekional_add_to != all")
         if not c.opt_adam: bad.append("SGD")
         if c.weight_decay != 0.0: bad.append("weight_decay")
-        if not c.weighted_first: bad.append("weighted_first=False training")
         if self.ba_done_flag: bad.append("mapping after bundle adjustment")
         if bad:
             raise NotImplementedError("Mapper.mapping on libpinhip does not cover: " + ", ".join(bad))
@@ -104,7 +103,7 @@ class Mapper(_Base):
         eik = bool(c.ekional_loss_on and c.weight_e > 0)
         t = self._trainer
         if (t is None or t.fs.feats.numel() != fs.feats.numel() or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel()
-                or (t.buf.n_eik > 0) != eik):
+                or (t.buf.n_eik > 0) != eik or t.fs.weighted_first != fs.weighted_first):
             t = engine.MapTrainer(st, fs, None, None, None, None, npts.local_point_ts_update, bs=c.bs,
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,
                                   weight_e=c.weight_e if eik else 0.0,

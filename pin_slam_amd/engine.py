@@ -132,7 +132,7 @@ class MapTrainer:
         from .sharding import n_eik_global, shard_range
         start, _ = shard_range(self.bs, rank, world)
         self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
-                                    shard_start=start)
+                                    shard_start=start, weighted_first=fs.weighted_first)
         self.coord = torch.empty((self.bs_local, 3), dtype=torch.float32, device=dev)
         self.label = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)

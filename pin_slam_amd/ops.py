@@ -298,7 +298,7 @@ class TrainBuffers:
     """Caller-owned scratch for one training iteration of `n_main` samples (+ Eikonal)."""
 
     def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda",
-                 shard_start: int = 0):
+                 shard_start: int = 0, weighted_first: bool = True):
         from .sharding import eikonal_shard
         self.n_main = int(n_main)
         self.dec = int(decimation)
@@ -307,7 +307,7 @@ class TrainBuffers:
         self.query = torch.empty((self.Q, 3), dtype=torch.float32, device=device)
         self.nbr = torch.empty((self.Q, k, 4), dtype=torch.float32, device=device)
         self.nn = torch.empty((self.Q,), dtype=torch.int32, device=device)
-        nbytes = _lib.lib().pin_train_workspace_bytes(self.Q, hidden, levels)
+        nbytes = _lib.lib().pin_train_workspace_bytes(self.Q, hidden, levels, 1 if weighted_first else k)
         self.ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
         self.loss = torch.zeros((2,), dtype=torch.float64, device=device)
 

@@ -26,7 +26,7 @@ def test_header_ctypes_library_agree():
     assert hdr <= exported, hdr - exported
     L = _lib.lib()  # loads without a GPU; no compute call is made here
     assert L.pin_version() == _lib.PIN_ABI_VERSION
-    assert L.pin_train_workspace_bytes(1000, 64, 4) > 0 and L.pin_maint_workspace_bytes(1000) > 0
+    assert L.pin_train_workspace_bytes(1000, 64, 4, 1) > 0 and L.pin_maint_workspace_bytes(1000) > 0
 
 
 def test_candidate_offsets_host_helper():

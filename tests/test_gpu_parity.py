@@ -218,8 +218,6 @@ def test_mapping_two_iterations(gold):
     from tests import gpu_util as U
     import dataclasses
     d = gold
-    if not d["weighted_first"]:
-        pytest.skip("training kernel covers weighted_first=True (run.yaml default); see DESIGN.md")
     k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
     feats = U.dev(d["local_geo_features"])
     dec = U.dev(d["dec_flat"])
@@ -230,7 +228,7 @@ def test_mapping_two_iterations(gold):
     mf, vf = torch.zeros_like(feats), torch.zeros_like(feats)
     md, vd = torch.zeros_like(dec), torch.zeros_like(dec)
     bs = d["map_coord0"].shape[0]
-    buf = ops.TrainBuffers(bs, int(d["map_dec"]), k, H, L)
+    buf = ops.TrainBuffers(bs, int(d["map_dec"]), k, H, L, weighted_first=bool(d["weighted_first"]))
     for it in range(2):
         loss = ops.train_step(d["st"], fs, buf, U.dev(d[f"map_coord{it}"]), U.dev(d[f"map_label{it}"]),
                               U.dev(d[f"map_w{it}"]), U.dev(d[f"map_ts{it}"], torch.int32), cert, tsu, gfeat, gdec,
@@ -257,8 +255,6 @@ def test_sharded_train_step_sums_to_full_batch(gold):
     from tests import gpu_util as U
     import dataclasses
     d = gold
-    if not d["weighted_first"]:
-        pytest.skip("training kernel covers weighted_first=True")
     k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
     dec = int(d["map_dec"])
     bs = d["map_coord0"].shape[0]
@@ -268,7 +264,7 @@ def test_sharded_train_step_sums_to_full_batch(gold):
     world = 2
     for r in range(world):
         a, b = sharding.shard_range(bs, r, world)
-        buf = ops.TrainBuffers(b - a, dec, k, H, L, shard_start=a)
+        buf = ops.TrainBuffers(b - a, dec, k, H, L, shard_start=a, weighted_first=bool(d["weighted_first"]))
         ops.train_step(d["st"], fs, buf, U.dev(d["map_coord0"][a:b]), U.dev(d["map_label0"][a:b]),
                        U.dev(d["map_w0"][a:b]), U.dev(d["map_ts0"][a:b], torch.int32), fs.certainty, tsu, gfeat, gdec,
                        sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"],
