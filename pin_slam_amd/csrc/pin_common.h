@@ -79,4 +79,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// float wave sum on the DPP path (no LDS crossbar): quad xor 1, 2, row_half_mirror, row_mirror
+// give every lane its 16-lane row sum; the 4 row sums are then added through readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+
 }  // namespace pin

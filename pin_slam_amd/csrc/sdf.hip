@@ -132,16 +132,44 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
         float z[MLP_IN];
 #pragma unroll
         for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
+        // One pass over the neighbours also accumulates what the gradient needs afterwards, so the
+        // feature rows are gathered once:  sum_t c_t g_t = Y a  with  Y = sum_t g_t (x) [f_t; v_t]
+        // (c_t = a . [f_t; v_t], g_t = d u_t / d q), and after PGO  sum_t w_t R_t^T a_v = M a_v.
+        float Y[3][MLP_IN];
+        float M[9];
+        if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < MLP_IN; ++j) Y[c][j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) M[c] = 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < PIN_MAX_K; ++t)
             if (nb.idx[t] >= 0) {
-                float ft[PIN_FEATURE_DIM], v[3];
+                float y[MLP_IN], ft[PIN_FEATURE_DIM], v[3];
                 load_feature(f, nb.idx[t], ft);
                 neighbor_vector(f, nb.idx[t], nb.quirk[t], nb.vx[t], nb.vy[t], nb.vz[t], qx, qy, qz, v, Rm);
 #pragma unroll
-                for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = fmaf(nb.w[t], ft[j], z[j]);
+                for (int j = 0; j < PIN_FEATURE_DIM; ++j) y[j] = ft[j];
+                y[8] = v[0]; y[9] = v[1]; y[10] = v[2];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) z[PIN_FEATURE_DIM + j] = fmaf(nb.w[t], v[j], z[PIN_FEATURE_DIM + j]);
+                for (int j = 0; j < MLP_IN; ++j) z[j] = fmaf(nb.w[t], y[j], z[j]);
+                if (GRAD) {
+                    const float cg = -2.f * nb.u[t] * nb.u[t];
+                    const float g0 = cg * nb.vx[t], g1 = cg * nb.vy[t], g2 = cg * nb.vz[t];
+#pragma unroll
+                    for (int j = 0; j < MLP_IN; ++j) {
+                        Y[0][j] = fmaf(g0, y[j], Y[0][j]); Y[1][j] = fmaf(g1, y[j], Y[1][j]); Y[2][j] = fmaf(g2, y[j], Y[2][j]);
+                    }
+                    if (f.orient != nullptr) {  // d v_t / d q = R_t: accumulate w_t R_t^T
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                            for (int cc = 0; cc < 3; ++cc) M[rr * 3 + cc] = fmaf(nb.w[t], Rm[cc * 3 + rr], M[rr * 3 + cc]);
+                    }
+                }
             }
         float a[MLP_IN];
         const float x = decode<H, GRAD, MFMA>(f, z, a, col, xb);
@@ -150,28 +178,15 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
             float cbar = 0.f;
 #pragma unroll
             for (int j = 0; j < MLP_IN; ++j) cbar = fmaf(a[j], z[j], cbar);  // = sum_t w_t c_t
-            float ax = 0.f, ay = 0.f, az = 0.f;  // sum_t c_t g_t   and the direct a_v term
-            float dxs = 0.f, dys = 0.f, dzs = 0.f;
+            float ax = 0.f, ay = 0.f, az = 0.f;  // sum_t c_t g_t
 #pragma unroll
-            for (int t = 0; t < PIN_MAX_K; ++t)
-                if (nb.idx[t] >= 0) {
-                    float ft[PIN_FEATURE_DIM], v[3];
-                    load_feature(f, nb.idx[t], ft);
-                    neighbor_vector(f, nb.idx[t], nb.quirk[t], nb.vx[t], nb.vy[t], nb.vz[t], qx, qy, qz, v, Rm);
-                    float c = 0.f;
-#pragma unroll
-                    for (int j = 0; j < PIN_FEATURE_DIM; ++j) c = fmaf(a[j], ft[j], c);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) c = fmaf(a[PIN_FEATURE_DIM + j], v[j], c);
-                    const float cg = -2.f * nb.u[t] * nb.u[t] * c;
-                    ax = fmaf(cg, nb.vx[t], ax); ay = fmaf(cg, nb.vy[t], ay); az = fmaf(cg, nb.vz[t], az);
-                    if (f.orient != nullptr) {  // d v_t / d q = R_t  ->  R_t^T a_v
-                        dxs += nb.w[t] * (Rm[0] * a[8] + Rm[3] * a[9] + Rm[6] * a[10]);
-                        dys += nb.w[t] * (Rm[1] * a[8] + Rm[4] * a[9] + Rm[7] * a[10]);
-                        dzs += nb.w[t] * (Rm[2] * a[8] + Rm[5] * a[9] + Rm[8] * a[10]);
-                    }
-                }
-            if (f.orient == nullptr) { dxs = a[8] * wsum; dys = a[9] * wsum; dzs = a[10] * wsum; }
+            for (int j = 0; j < MLP_IN; ++j) { ax = fmaf(Y[0][j], a[j], ax); ay = fmaf(Y[1][j], a[j], ay); az = fmaf(Y[2][j], a[j], az); }
+            float dxs, dys, dzs;  // the direct a_v term
+            if (f.orient != nullptr) {
+                dxs = M[0] * a[8] + M[1] * a[9] + M[2] * a[10];
+                dys = M[3] * a[8] + M[4] * a[9] + M[5] * a[10];
+                dzs = M[6] * a[8] + M[7] * a[9] + M[8] * a[10];
+            } else { dxs = a[8] * wsum; dys = a[9] * wsum; dzs = a[10] * wsum; }
             const float invS = 1.0f / nb.S;
             r.gx = s * (dxs + (ax - cbar * Gx) * invS);
             r.gy = s * (dys + (ay - cbar * Gy) * invS);
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 31; ++i) {
-        const double t = wave_sum((double)v[i]);
+        const double t = (double)wave_sum_f32(v[i]);
         if (lane == 0 && t != 0.0) atomicAdd(dst + i, t);
     }
 }
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 31; ++i) {
-        const double t = wave_sum((double)v[i]);
+        const double t = (double)wave_sum_f32(v[i]);  // the reference sums these in float32 (torch mm)
         if (lane == 0) red[wave][i] = t;
     }
     __syncthreads();
