@@ -260,6 +260,137 @@ def gen_case(case):
     return out
 
 
+def color_of(p):
+    """Smooth synthetic colour field in [0.1, 0.9]^3."""
+    x, y = p[:, 0], p[:, 1]
+    return (0.5 + 0.4 * torch.stack([torch.sin(0.7 * x), torch.cos(0.5 * y), torch.sin(0.3 * x + 0.4 * y)], 1)).float()
+
+
+def gen_color_case():
+    """C5-style colour path (run_replica.yaml: colour features + colour decoder + photometric
+    registration): reference outputs for query_feature(colour), regress_color + per-channel
+    autograd gradients, registration with the photometric term / the consistency weight, and
+    two mapping iterations with the colour loss."""
+    m = R.load()
+    cfg = R.make_config(local_map_radius=20.0, local_map_travel_dist_ratio=1.0, bs=512, feature_std=0.1,
+                        gradient_decimation=10, track_on=True, voxel_size_m=0.4, search_alpha=0.2, query_nn_k=6,
+                        weighted_first=True, buffer_size=int(5e7), color_on=True, color_channel=3,
+                        photometric_loss_on=True, photometric_loss_weight=0.01, consist_wieght_on=True, weight_i=1.0)
+    torch.manual_seed(7)
+    dec = m["Decoder"](cfg, 64, 1, 1)
+    cdec = m["Decoder"](cfg, 64, 1, 3)
+    decoders = {"sdf": dec, "semantic": None, "color": cdec}
+    npts = m["NeuralPoints"](cfg)
+    gen = torch.Generator().manual_seed(5)
+    npts.travel_dist = torch.tensor([0.0, 12.0, 24.0], dtype=torch.float32)
+    for ts in range(3):
+        pts = sheet_points(gen, 20000, 14.0, center=(8.0 * ts, 0.0))
+        npts.update(pts, torch.tensor([8.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+    npts.point_certainties = torch.rand(npts.count(), generator=gen) * 3.0
+    npts.reset_local_map(torch.tensor([16.0, 0.0, 0.0]), torch.eye(3), 2)
+    ds = R.FakeDataset(n_frames=3)
+    mp = m["Mapper"](cfg, ds, npts, decoders)
+    mp.determine_used_pose()
+
+    def train_batch(global_coord=False):
+        c, l = surface_samples(gen, cfg.bs, 13.0, (16.0, 0.0))
+        ts = torch.full((cfg.bs,), 2, dtype=torch.int)
+        return c, l, ts, None, None, color_of(c), torch.ones(cfg.bs)
+
+    mp.get_batch = train_batch
+    mp.mapping(200)
+    out = map_arrays(npts, cfg, dec)
+    out.update(color_features=t2n(npts.color_features), local_color_features=t2n(npts.local_color_features.data),
+               cdec_flat=flat_decoder(cdec), cdec_levels=np.int64(1), cdec_hidden=np.int64(64),
+               surface_sample_range_m=np.float64(cfg.surface_sample_range_m), weight_i=np.float64(cfg.weight_i),
+               photometric_loss_weight=np.float64(cfg.photometric_loss_weight))
+    q = sheet_points(gen, 300, 13.0, center=(16.0, 0.0)) + 0.05 * torch.randn(300, 3, generator=gen)
+    q = q.float().contiguous()
+    out["query"] = t2n(q)
+    gf, cf, w, nn, cert = npts.query_feature(q.clone(), training_mode=False, query_locally=True, query_color_feature=True)
+    out["qf_color_feat"] = t2n(cf); out["qf_geo_feat"] = t2n(gf)
+    trk = m["Tracker"](cfg, npts, decoders)
+    res = trk.query_source_points(q.clone(), cfg.infer_bs, True, True, True, True, query_locally=True,
+                                  mask_min_nn_count=cfg.track_mask_query_nn_k)
+    out["qsp_sdf"] = t2n(res[0]); out["qsp_grad"] = t2n(res[1]); out["qsp_color"] = t2n(res[2])
+    out["qsp_color_grad"] = t2n(res[3]); out["qsp_mask"] = t2n(res[5])
+    out["track_mask_query_nn_k"] = np.int64(cfg.track_mask_query_nn_k)
+    # registration with colours: photometric term on, then off (consistency weight instead)
+    src = sheet_points(gen, 3000, 12.0, center=(16.0, 0.0), layers=2)
+    Tinit = torch.eye(4, dtype=torch.float64)
+    ang = 0.008
+    Tinit[:3, :3] = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    Tinit[:3, 3] = torch.tensor([0.04, -0.03, 0.02], dtype=torch.float64)
+    tools = m["tools"]
+    cur = tools.transform_torch(src, Tinit)
+    src_col = (color_of(src) + 0.02 * torch.randn(len(src), 3, generator=gen)).clamp(0, 1).float()
+    out["reg_src"] = t2n(src); out["reg_Tinit"] = t2n(Tinit); out["reg_cur"] = t2n(cur); out["reg_colors"] = t2n(src_col)
+    for tag, photo in (("photo", True), ("consist", False)):
+        cfg.photometric_loss_on = photo
+        step = trk.registration_step(cur.clone(), None, torch.zeros(len(src)), src_col.clone(),
+                                     cfg.reg_min_grad_norm, cfg.reg_max_grad_norm, cfg.reg_GM_dist_m, cfg.reg_GM_grad,
+                                     cfg.reg_lm_lambda, False)
+        out[f"reg_dT_{tag}"] = t2n(step[0]); out[f"reg_valid_{tag}"] = np.int64(step[4].shape[0])
+        out[f"reg_res_{tag}"] = np.float64(step[5])
+        out[f"reg_photo_res_{tag}"] = np.float64(step[6] if step[6] is not None else -1.0)
+    cfg.photometric_loss_on = True
+    cfg.reg_iter_n = 20
+    Tfin, cov, _, vflag = trk.tracking(src.clone(), Tinit.clone(), source_colors=src_col.clone())
+    out["trk_T"] = t2n(Tfin); out["trk_valid"] = np.bool_(vflag)
+    for kname in ("reg_min_grad_norm", "reg_max_grad_norm", "reg_GM_dist_m", "reg_GM_grad", "reg_lm_lambda",
+                  "max_sdf_std_ratio", "reg_iter_n", "reg_term_thre_deg", "reg_term_thre_m"):
+        out["cfg_" + kname] = np.float64(getattr(cfg, kname))
+    # two mapping iterations on fixed batches with colour labels
+    bs = cfg.bs
+    batches = []
+    for it in range(2):
+        coord, label = surface_samples(gen, bs, 12.0, (16.0, 0.0), sigma=0.2)
+        ts = torch.randint(0, 3, (bs,), generator=gen).int()
+        w = (0.6 + 0.8 * torch.rand(bs, generator=gen)).float()
+        col = (color_of(coord) + 0.05 * torch.randn(bs, 3, generator=gen)).clamp(0, 1).float()
+        batches.append((coord, label.float(), ts, w, col))
+        for nme, v in zip(("coord", "label", "ts", "w", "color"), batches[-1]):
+            out[f"map_{nme}{it}"] = t2n(v)
+    box = {"i": 0}
+
+    def fixed_batch(global_coord=False):
+        c, l, t, w, col = batches[box["i"]]
+        box["i"] += 1
+        return c.clone(), l.clone(), t.clone(), None, None, col.clone(), w.clone()
+
+    mp.get_batch = fixed_batch
+    grads = []
+    real_setup = m["mapper_mod"].setup_optimizer
+
+    def spy_setup(*a, **k):
+        opt = real_setup(*a, **k)
+        real_step = opt.step
+
+        def step(*aa, **kk):
+            grads.append(dict(gfeat=t2n(npts.local_geo_features.grad), cfeat=t2n(npts.local_color_features.grad),
+                              gdec=np.concatenate([t2n(p.grad).ravel() for p in dec.parameters()]),
+                              cdec=np.concatenate([t2n(p.grad).ravel() for p in cdec.parameters()])))
+            return real_step(*aa, **kk)
+
+        opt.step = step
+        return opt
+
+    m["mapper_mod"].setup_optimizer = spy_setup
+    out["map_eps"] = np.float64(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    out["map_dec"] = np.int64(cfg.gradient_decimation); out["map_weight_e"] = np.float64(cfg.weight_e)
+    out["map_lr"] = np.float64(cfg.lr); out["map_adam_eps"] = np.float64(cfg.adam_eps)
+    try:
+        mp.mapping(2)
+    finally:
+        m["mapper_mod"].setup_optimizer = real_setup
+    for it, g in enumerate(grads):
+        for kk, v in g.items():
+            out[f"map_{kk}{it}"] = v
+    out["map_geo_after"] = t2n(npts.local_geo_features.data); out["map_color_after"] = t2n(npts.local_color_features.data)
+    out["map_gdec_after"] = flat_decoder(dec); out["map_cdec_after"] = flat_decoder(cdec)
+    return out
+
+
 def gen_update():
     """(7) NeuralPoints.update / reset_local_map resulting arrays (K8/K9 parity)."""
     m = R.load()
@@ -290,12 +421,22 @@ def gen_update():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     for case in CASES:
+        if only not in (None, case):
+            continue
         d = gen_case(case)
         path = os.path.join(OUT, f"{case}.npz")
         np.savez_compressed(path, **d)
         print(case, "->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "P =", d["neural_points"].shape[0],
               "M =", d["local_neural_points"].shape[0])
+    if only in (None, "replica_color"):
+        d = gen_color_case()
+        path = os.path.join(OUT, "replica_color.npz")
+        np.savez_compressed(path, **d)
+        print("replica_color ->", path, f"{os.path.getsize(path)/1e6:.2f} MB")
+    if only not in (None, "update"):
+        return
     d = gen_update()
     path = os.path.join(OUT, "update.npz")
     np.savez_compressed(path, **d)

@@ -280,6 +280,68 @@ def query_sdf(points, search, feats, positions, params, sdf_scale, k, weighted_f
     return sdf, grad, std, qf["nn_count"], qf.get("certainty")
 
 
+# --------------------------------------------------------------------------- colour head (C5)
+INTENSITY = np.array([0.299, 0.587, 0.114])  # utils/tools.py:408-410 color_to_intensity
+
+
+def mlp_input_jacobian_multi(acts, params):
+    """d out[..., c] / d z for every output channel c -> [..., C, in]."""
+    Ws, bs, Wo, bo = params
+    outs = []
+    for c in range(Wo.shape[0]):
+        a = np.broadcast_to(Wo[c], acts[-1].shape).astype(acts[0].dtype)
+        for li in range(len(Ws) - 1, -1, -1):
+            a = (a * (acts[li + 1] > 0)) @ Ws[li]
+        outs.append(a)
+    return np.stack(outs, -2)
+
+
+def query_color(points, search, cfeats, positions, params, k, weighted_first=True, global2local=None,
+                orientations=None, dtype=np.float64):
+    """Decoder.regress_color (model/decoder.py:112: sigmoid(mlp)) on the interpolated COLOUR
+    features and the per-channel autograd gradients of Tracker.query_source_points
+    (utils/tracker.py:342-350).  Returns (color [N,C], color_grad [N,C,3], nn_count)."""
+    T = dtype
+    qf = query_feature(points, search, cfeats, positions, None, k, global2local, orientations, weighted_first=False)
+    fv = qf["geo_feat"].astype(T)
+    idxk, d2k = qf["knn_idx"], qf["knn_d2"].astype(T)
+    valid = idxk >= 0
+    nn = qf["nn_count"]
+    params = tuple([w.astype(T) for w in p] if isinstance(p, list) else p.astype(T) for p in params)
+    gather = np.where(valid, idxk, 0)
+    diff = np.asarray(points, T)[:, None, :] - positions[gather].astype(T)
+    u = np.where(valid, 1.0 / (d2k + T(1e-15)), 0.0)
+    u = np.where((nn == 0)[:, None], T(1e-15), u)
+    S = u.sum(1, keepdims=True)
+    w = np.where(valid, u / S, 0.0)
+    g_u = np.where(valid[..., None], -2.0 * (u ** 2)[..., None] * diff, 0.0)
+    G = g_u.sum(1, keepdims=True)
+    dw = np.where(valid[..., None], g_u / S[..., None] - (u / S ** 2)[..., None] * G, 0.0)
+    Fdim = fv.shape[-1] - 3
+    if orientations is not None:
+        _, R = quat_rotate(orientations[gather].astype(T), diff)
+    if weighted_first:
+        z = (fv * w[..., None]).sum(1)
+        out, acts = mlp_forward(z, params, keep=True)
+        p = _sigmoid(out)  # [N,C]
+        a = mlp_input_jacobian_multi(acts, params) * (p * (1 - p))[..., None]  # [N,C,in]
+        c = np.einsum("ncf,nkf->nck", a, fv)
+        if orientations is None:
+            direct = a[..., Fdim:] * w.sum(1)[:, None, None]
+        else:
+            direct = np.einsum("nk,nkij,nci->ncj", w, R, a[..., Fdim:])
+        return p, direct + np.einsum("nck,nkj->ncj", c, dw), nn
+    out, acts = mlp_forward(fv, params, keep=True)  # [N,k,C]
+    p = _sigmoid(out)
+    a = mlp_input_jacobian_multi(acts, params) * (p * (1 - p))[..., None]  # [N,k,C,in]
+    col = (p * w[..., None]).sum(1)
+    if orientations is None:
+        direct = (w[..., None, None] * a[..., Fdim:]).sum(1)
+    else:
+        direct = np.einsum("nk,nkij,nkci->ncj", w, R, a[..., Fdim:])
+    return col, np.einsum("nkc,nkj->ncj", p, dw) + direct, nn
+
+
 # --------------------------------------------------------------------------- K5
 def expmap(t):
     """utils/tracker.py:784-795."""
@@ -291,7 +353,8 @@ def expmap(t):
 
 def registration_step(points, sdf, grad, std, nn_count, *, valid_nn_k, min_grad_norm=0.5,
                       max_grad_norm=2.0, max_sdf_std=0.25, GM_dist=0.3, GM_grad=0.1,
-                      lm_lambda=1e-4, sdf_labels=None):
+                      lm_lambda=1e-4, sdf_labels=None, colors=None, color_pred=None, color_grad=None,
+                      photo_loss=False, photo_weight=0.01, consist_weight=True):
     """Tracker.registration_step + implicit_reg (utils/tracker.py:409-524, 615-695),
     geometric term only.  Returns dict(T [4,4] f64, valid_count, residual_cm, N, g)."""
     points = np.asarray(points, np.float64)
@@ -310,18 +373,31 @@ def registration_step(points, sdf, grad, std, nn_count, *, valid_nn_k, min_grad_
         w = w * (GM_grad / (GM_grad + (gnv - 1.0) ** 2)) ** 2
     if GM_dist is not None:
         w = w * (GM_dist / (GM_dist + r ** 2)) ** 2
+    photo_res = None
+    if colors is not None:  # tracker.py:493-514 (3 channels -> intensity)
+        ci = np.asarray(colors, np.float64)[valid] @ INTENSITY
+        pi = np.asarray(color_pred, np.float64)[valid] @ INTENSITY
+        if (not photo_loss) and consist_weight:
+            w = w * np.exp(-np.abs(ci - pi))
     w = w / (2.0 * w.mean())  # tracker.py:524
     J = np.concatenate([np.cross(p, g), g], -1)
     N = J.T @ (w[:, None] * J)
+    b = -(J * w[:, None]).T @ r
+    if colors is not None and photo_loss:  # implicit_color_reg, tracker.py:699-744
+        gi = np.einsum("c,ncj->nj", INTENSITY, np.asarray(color_grad, np.float64)[valid])
+        rc = pi - ci
+        photo_res = float(np.abs(rc).mean())
+        Jc = np.concatenate([np.cross(p, gi), gi], -1)
+        N = N + photo_weight * (Jc.T @ (w[:, None] * Jc))
+        b = b + photo_weight * (-(Jc * w[:, None]).T @ rc)
     N_raw = N.copy()
     N = N + lm_lambda * np.diag(np.diag(N))
-    b = -(J * w[:, None]).T @ r
     t = np.linalg.solve(N, b)
     T = np.eye(4)
     T[:3, :3] = expmap(t[:3])
     T[:3, 3] = t[3:]
     return dict(T=T, valid_count=n, residual_cm=float(np.abs(r).mean() * 100.0), N=N_raw,
-                g=b, valid=valid, weight=w)
+                g=b, valid=valid, weight=w, photo_residual=photo_res)
 
 
 def transform_points(points, T):
@@ -451,6 +527,45 @@ def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat
         dec_grad = dec_grad + backward(fe, dP)
     return dict(loss=sdf_loss + weight_e * eik_loss, sdf_loss=sdf_loss, eik_loss=eik_loss,
                 feat_grad=feat_grad, dec_grad=dec_grad, sdf_pred=fw["pred"], fw=fw)
+
+
+def train_color_step(coord, sdf_label, color_label, sample_weight, searcher, cfeats, flat_params, dec_shape, k, *,
+                     weighted_first=True, surface_range=0.25, weight_i=1.0, loss_weight_on=False, dtype=np.float64):
+    """Colour term of Mapper.mapping (utils/mapper.py:668-675, 804-812; utils/loss.py:31-42):
+    weight_i * mean over surface samples (|sdf_label| < surface_sample_range_m) and channels of
+    |sigmoid(mlp_color(z_color)) - colour label|, backward to colour features and colour decoder.
+    ``searcher(points)`` returns query_feature output over the COLOUR feature table with
+    per-neighbour vectors.  Returns dict(loss, feat_grad, dec_grad, color_pred)."""
+    T = dtype
+    in_dim, hidden, levels, out_dim = dec_shape
+    params = unpack_decoder(np.asarray(flat_params, T), in_dim, hidden, levels, out_dim)
+    F = cfeats.shape[1]
+    feat_grad = np.zeros((cfeats.shape[0], F), T)
+    qf = searcher(coord)
+    fv = qf["geo_feat"].astype(T)
+    valid = qf["knn_idx"] >= 0
+    _, _, w = idw_weights(qf["knn_d2"], valid, qf["nn_count"], dtype=T)
+    z = (fv * w[..., None]).sum(1) if weighted_first else fv
+    out, acts = mlp_forward(z, params, keep=True)
+    p = _sigmoid(out)
+    pred = p if weighted_first else (p * w[..., None]).sum(1)
+    mask = np.abs(np.asarray(sdf_label, T)) < surface_range
+    n_s = int(mask.sum())
+    diff = pred - np.asarray(color_label, T)
+    wt = np.abs(np.asarray(sample_weight, T))[:, None] if loss_weight_on else 1.0
+    loss = weight_i * (wt * np.abs(diff))[mask].mean() if n_s else 0.0
+    dpred = np.where(mask[:, None], weight_i * wt * np.sign(diff) / max(n_s * out_dim, 1), 0.0)
+    if weighted_first:
+        dout = dpred * p * (1 - p)
+        dz, gflat = mlp_backward(acts, params, dout)
+        dfeat = w[..., None] * dz[:, None, :F]
+    else:
+        dout = dpred[:, None, :] * w[..., None] * p * (1 - p)
+        dz, gflat = mlp_backward(acts, params, dout)
+        dfeat = dz[..., :F]
+    dfeat = np.where(valid[..., None], dfeat, 0.0)
+    np.add.at(feat_grad, np.where(valid, qf["knn_idx"], 0).reshape(-1), dfeat.reshape(-1, F))
+    return dict(loss=loss, feat_grad=feat_grad, dec_grad=gflat, color_pred=pred)
 
 
 def adam_step(p, g, m, v, step, lr=0.01, b1=0.9, b2=0.99, eps=1e-15):

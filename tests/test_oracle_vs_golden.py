@@ -202,3 +202,76 @@ def test_update_and_local_map():
     slots = np.nonzero(st["table"] >= 0)[0]
     assert np.array_equal(slots, d["table_slots"])
     assert np.array_equal(st["table"][slots], d["table_vals"])
+
+
+# ---------------------------------------------------------------- colour path (C5, run_replica.yaml)
+@pytest.fixture(scope="module")
+def cgold():
+    d = G.load("replica_color")
+    d["table"] = G.dense_table(d)
+    d["params"] = O.unpack_decoder(d["dec_flat"], 11, 64, 1)
+    d["cparams"] = O.unpack_decoder(d["cdec_flat"], 11, 64, 1, out_dim=3)
+    return d
+
+
+def _csearch(d, q):
+    return O.radius_search(q, d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
+                           ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                           diff_travel_dist_local=d["diff_travel_dist_local"])
+
+
+def test_color_query(cgold):
+    d = cgold
+    s = _csearch(d, d["query"])
+    col, cgrad, nn = O.query_color(d["query"], s, d["local_color_features"], d["local_neural_points"], d["cparams"],
+                                   int(d["query_nn_k"]), global2local=d["global2local"])
+    np.testing.assert_allclose(col, d["qsp_color"], rtol=1e-5, atol=1e-6)
+    scale = np.abs(d["qsp_color_grad"]).max(-1, keepdims=True) + 1e-5
+    assert np.max(np.abs(cgrad - d["qsp_color_grad"]) / scale) < 2e-4
+    qf = O.query_feature(d["query"], s, d["local_color_features"], d["local_neural_points"], None, int(d["query_nn_k"]),
+                         global2local=d["global2local"])
+    np.testing.assert_allclose(qf["geo_feat"], d["qf_color_feat"], rtol=1e-5, atol=3e-7)
+
+
+@pytest.mark.parametrize("tag", ["photo", "consist"])
+def test_color_registration_step(cgold, tag):
+    d = cgold
+    k = int(d["query_nn_k"])
+    s = _csearch(d, d["reg_cur"])
+    sdf, grad, std, nn, _ = O.query_sdf(d["reg_cur"], s, d["local_geo_features"], d["local_neural_points"], d["params"],
+                                        d["sdf_scale"], k, global2local=d["global2local"])
+    col, cgrad, _ = O.query_color(d["reg_cur"], s, d["local_color_features"], d["local_neural_points"], d["cparams"], k,
+                                  global2local=d["global2local"])
+    r = O.registration_step(d["reg_cur"], sdf, grad, std, nn, valid_nn_k=int(d["track_mask_query_nn_k"]),
+                            min_grad_norm=d["cfg_reg_min_grad_norm"], max_grad_norm=d["cfg_reg_max_grad_norm"],
+                            max_sdf_std=d["surface_sample_range_m"] * d["cfg_max_sdf_std_ratio"],
+                            GM_dist=d["cfg_reg_GM_dist_m"], GM_grad=d["cfg_reg_GM_grad"], lm_lambda=d["cfg_reg_lm_lambda"],
+                            colors=d["reg_colors"], color_pred=col, color_grad=cgrad, photo_loss=(tag == "photo"),
+                            photo_weight=d["photometric_loss_weight"])
+    assert r["valid_count"] == d[f"reg_valid_{tag}"]
+    np.testing.assert_allclose(r["T"], d[f"reg_dT_{tag}"], rtol=0, atol=3e-6)
+    if tag == "photo":
+        assert abs(r["photo_residual"] - d["reg_photo_res_photo"]) < 1e-5
+
+
+def test_color_mapping_gradients(cgold):
+    """Iteration 0 of Mapper.mapping with colour: gradients of geo/colour features and of both
+    decoders against the reference's autograd."""
+    d = cgold
+    k = int(d["query_nn_k"])
+
+    def searcher_for(feats):
+        def searcher(points):
+            return O.query_feature(points, _csearch(d, points), feats, d["local_neural_points"], None, k,
+                                   global2local=d["global2local"], weighted_first=False)
+        return searcher
+
+    r = O.train_step(d["map_coord0"], d["map_label0"], d["map_w0"], searcher_for(d["local_geo_features"]),
+                     d["local_geo_features"], d["local_neural_points"], d["dec_flat"], (11, 64, 1), d["sdf_scale"], k,
+                     dec=int(d["map_dec"]), eps=d["map_eps"], weight_e=d["map_weight_e"])
+    rc = O.train_color_step(d["map_coord0"], d["map_label0"], d["map_color0"], d["map_w0"],
+                            searcher_for(d["local_color_features"]), d["local_color_features"], d["cdec_flat"],
+                            (11, 64, 1, 3), k, surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"])
+    for got, ref in ((r["feat_grad"], d["map_gfeat0"]), (r["dec_grad"], d["map_gdec0"]),
+                     (rc["feat_grad"], d["map_cfeat0"]), (rc["dec_grad"], d["map_cdec0"])):
+        assert np.max(np.abs(got - ref)) < 3e-4 * np.abs(ref).max()
