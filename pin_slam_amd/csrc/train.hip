@@ -258,7 +258,9 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
 #pragma unroll
         for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + qi] = z[j];
         ws.z[(size_t)11 * QsT + qi] = 0.f;
-        pred = f.sdf_scale * MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, QsT, (size_t)q0, ws.mask + q0, QsT);
+        float o[1];
+        MfmaDecoder<H>::template forward_store<1>(lds, f.levels, xb, z, ws.h, QsT, (size_t)q0, ws.mask + q0, QsT, o);
+        pred = f.sdf_scale * o[0];
     } else {
         // weighted_first = False (run_kitti.yaml:25): decode every neighbour, then weight the
         // predictions (mapper.py:658-662); neighbour t of all queries forms sample block t
@@ -283,8 +285,9 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
 #pragma unroll
             for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + col0 + (threadIdx.x & 63)] = z[j];
             ws.z[(size_t)11 * QsT + col0 + (threadIdx.x & 63)] = 0.f;
-            const float xt = MfmaDecoder<H>::forward_store(lds, f.levels, xb, z, ws.h, QsT, col0, ws.mask + col0, QsT);
-            if (idx >= 0) pred = fmaf(wt, f.sdf_scale * xt, pred);
+            float o[1];
+            MfmaDecoder<H>::template forward_store<1>(lds, f.levels, xb, z, ws.h, QsT, col0, ws.mask + col0, QsT, o);
+            if (idx >= 0) pred = fmaf(wt, f.sdf_scale * o[0], pred);
         }
     }
     ws.pred[qi] = pred;
@@ -327,7 +330,9 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
     if (WF) {
         if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + qi] = dxq;
         float dz[MLP_IN];
-        MfmaDecoder<H>::backward_store(lds, f.levels, xb, dxq, ws.mask + q0, QsT, ws.d, QsT, (size_t)q0, want_dec != 0, dz);
+        const float dxa[1] = {dxq};
+        MfmaDecoder<H>::template backward_store<1>(lds, f.levels, xb, dxa, ws.mask + q0, QsT, ws.d, QsT, (size_t)q0,
+                                                   want_dec != 0, dz);
         // Feature-gradient scatter.  One atomic instruction per QUERY: its 64 lanes are the 8
         // neighbours x 8 feature dims, so every instruction touches 8 whole 32-byte rows instead
         // of 64 different rows (the L2 atomic units work per cache line; measured 3x on this kernel).
@@ -361,7 +366,9 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
             const size_t col0 = (size_t)t * ws.Qs + q0;
             if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + col0 + lane] = dx;
             float dz[MLP_IN];
-            MfmaDecoder<H>::backward_store(lds, f.levels, xb, dx, ws.mask + col0, QsT, ws.d, QsT, col0, want_dec != 0, dz);
+            const float dxa[1] = {dx};
+            MfmaDecoder<H>::template backward_store<1>(lds, f.levels, xb, dxa, ws.mask + col0, QsT, ws.d, QsT, col0,
+                                                       want_dec != 0, dz);
             // one neighbour per query here: 8 queries x 8 feature dims per atomic instruction
 #pragma unroll
             for (int j = 0; j < PIN_FEATURE_DIM; ++j) sdz[lane * 8 + j] = dz[j];
