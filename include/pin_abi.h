@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 1
+#define PIN_ABI_VERSION 2
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -96,6 +96,7 @@ typedef struct pin_field {
     int32_t levels;          /* hidden layers, 1..4 */
     int32_t weighted_first;  /* config.weighted_first (utils/config.py:93) */
     float   sdf_scale;       /* logistic_gaussian_ratio * sigma_sigmoid_m (decoder.py:54-56) */
+    int32_t out_dim;         /* decoder heads: 1 (sdf; 0 means 1) or 3 (colour, Decoder.regress_color) */
 } pin_field;
 
 /* ---- Gauss-Newton registration (Tracker.registration_step + implicit_reg,
@@ -107,6 +108,15 @@ typedef struct pin_gn_params {
     float gm_dist;           /* reg_GM_dist_m, <=0 disables */
     float gm_grad;           /* reg_GM_grad, <=0 disables */
 } pin_gn_params;
+/* optional colour term of the registration (utils/tracker.py:493-542, 699-744) */
+typedef struct pin_color_term {
+    const pin_field* field;  /* colour feature table + colour decoder (out_dim 3), same k / hidden /
+                                weighting mode as the sdf field */
+    const float* colors;     /* [n][3] measured colours of the source points (device) */
+    int32_t mode;            /* 0 off; 1 consistency weight exp(-|I_meas - I_pred|) (consist_wieght_on);
+                                2 photometric term (photometric_loss_on) */
+    float photo_weight;      /* photometric_loss_weight */
+} pin_color_term;
 #define PIN_GN_NSUMS 32
 #define PIN_GN_REPLICAS 64
 /* Device-resident state of one Tracker.tracking call (utils/tracker.py:114-184), doubles:
@@ -138,7 +148,7 @@ typedef struct pin_gn_loop_params {      /* Tracker.tracking constants (tracker.
 
 /* sums layout (double[PIN_GN_NSUMS]): [0..20] upper triangle of sum w J J^T (row-major,
  * J = [p x g, g]); [21..26] sum w J r; [27] sum w; [28] sum |r|; [29] valid count;
- * [30] sum w r^2; [31] reserved.  w is the un-normalised robust weight; the host applies
+ * [30] sum w r^2; [31] sum |I_pred - I_meas| (photometric mode).  w is the un-normalised robust weight; the host applies
  * the reference's w /= 2*mean(w) (tracker.py:524) as one scalar. */
 
 /* ---- map training (Mapper.mapping loop body, utils/mapper.py:645-818) ------------ */
@@ -246,14 +256,14 @@ int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const flo
                void* stream);
 /* the two halves of pin_gn_accumulate_solve, separately launchable (bench.py brackets the
  * accumulate kernel with HIP events) */
-int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const float* cur, const float* nbr,
-                          const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
-                          const double* state, void* stream);
+int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                          const float* cur, const float* nbr, const int32_t* nn_count, const float* sdf_labels,
+                          int32_t n, double* sums, const double* state, void* stream);
 int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream);
-int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
-                            const float* cur, const float* nbr, const int32_t* nn_count,
-                            const float* sdf_labels, int32_t n, double* sums, double* state,
-                            void* stream);
+int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                            const pin_gn_loop_params* lp, const float* cur, const float* nbr,
+                            const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
+                            double* state, void* stream);
 
 /* Per-frame build of the brick cache (after reset_local_map / update).  counters_out:
  * int32[4] on the device = (bricks, entries, overflow flags, 0); flags != 0 or counts beyond
@@ -280,6 +290,20 @@ int pin_query_feature(const pin_field* f, const float* query, const float* nbr,
  * out [n] (already multiplied by sdf_scale). */
 int pin_decoder_sdf(const pin_field* f, const float* feat_in, int32_t n, float* sdf_out, void* stream);
 
+/* Decoder.regress_color (model/decoder.py:112): sigmoid(mlp) of the 3 colour heads on
+ * caller-provided features [n][11] -> color_out [n][3]. */
+int pin_decoder_color(const pin_field* f, const float* feat_in, int32_t n, float* color_out, void* stream);
+
+/* Colour branch of Tracker.query_source_points (utils/tracker.py:342-350) over the COLOUR
+ * feature table fc->feats with fc->dec (3 heads): color_out [n][3] = regress_color (weighted
+ * over the neighbours when weighted_first is off); value_out [n] = sum_c kappa[c]*color[c] and
+ * grad_out [n][3] = its analytic gradient w.r.t. the query (kappa = (0.299, 0.587, 0.114) gives
+ * the intensity used by registration, tools.py:408; a one-hot kappa gives one channel's
+ * gradient).  Outputs may be NULL. */
+int pin_color_query(const pin_field* fc, const float* query, const float* nbr, const int32_t* nn_count,
+                    int32_t n, const float* kappa_host, float* color_out, float* value_out, float* grad_out,
+                    void* stream);
+
 /* K2+K3+K4 fused: interpolate, decode, analytic d sdf/d q through MLP, neighbour vectors
  * and IDW weights (Tracker.query_source_points, utils/tracker.py:297-354, get_gradient
  * utils/tools.py:247-260).  Any output pointer may be NULL. */
@@ -289,11 +313,13 @@ int pin_sdf_query(const pin_field* f, const float* query, const float* nbr,
 
 /* K2..K5 fused: the same plus validity mask, Geman-McClure weights and the Gauss-Newton
  * normal-equation sums (tracker.py:409-524, 652-671).  sums_out: double[PIN_GN_NSUMS],
- * zeroed by this call.  sdf_labels may be NULL (all zero).  Per-point outputs optional. */
-int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* query,
-                      const float* nbr, const int32_t* nn_count, const float* sdf_labels,
-                      int32_t n, double* sums_out, float* sdf_out, float* grad_out,
-                      void* stream);
+ * zeroed by this call.  sdf_labels may be NULL (all zero).  Per-point outputs optional.
+ * color (NULL = off) adds the consistency weight or the photometric term of registration_step /
+ * implicit_color_reg; sums_out is double[PIN_GN_REPLICAS][PIN_GN_NSUMS] (sum over replicas). */
+int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                      const float* query, const float* nbr, const int32_t* nn_count,
+                      const float* sdf_labels, int32_t n, double* sums_out, float* sdf_out,
+                      float* grad_out, void* stream);
 
 /* Mapper.get_batch gathers (utils/mapper.py:482-488): rows `index[i]` of the sample pool
  * (coord_pool / sdf_label_pool / weight_pool / time_pool).  pool_weight / pool_ts / the

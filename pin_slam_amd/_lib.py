@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 64
-PIN_ABI_VERSION = 1
+PIN_ABI_VERSION = 2
 
 vp = C.c_void_p
 
@@ -44,8 +44,12 @@ class Field(C.Structure):
     _fields_ = [
         ("feats", vp), ("certainty", vp), ("orient", vp), ("pos", vp), ("dec", vp),
         ("k", C.c_int32), ("hidden", C.c_int32), ("levels", C.c_int32), ("weighted_first", C.c_int32),
-        ("sdf_scale", C.c_float),
+        ("sdf_scale", C.c_float), ("out_dim", C.c_int32),
     ]
+
+
+class ColorTerm(C.Structure):
+    _fields_ = [("field", C.POINTER(Field)), ("colors", vp), ("mode", C.c_int32), ("photo_weight", C.c_float)]
 
 
 class GnParams(C.Structure):
@@ -112,15 +116,17 @@ SIGNATURES = {
     "pin_knn_query": (i32, [P(SearchParams), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_gn_state_init": (i32, [vp, vp, i32, vp]),
     "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
-    "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_gn_solve": (i32, [vp, vp, P(GnLoopParams), vp]),
-    "pin_gn_accumulate_solve": (i32, [P(Field), P(GnParams), P(GnLoopParams), vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pin_gn_accumulate_solve": (i32, [P(Field), P(GnParams), P(ColorTerm), P(GnLoopParams), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_brick_build": (i32, [P(SearchParams), P(BrickCacheC), vp, vp]),
     "pin_knn_query_bricks": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_query_feature": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "pin_decoder_sdf": (i32, [P(Field), vp, i32, vp, vp]),
+    "pin_decoder_color": (i32, [P(Field), vp, i32, vp, vp]),
+    "pin_color_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
-    "pin_gn_accumulate": (i32, [P(Field), P(GnParams), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pin_gn_accumulate": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "pin_maint_workspace_bytes": (i64, [i32]),
     "pin_voxel_downsample": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_map_update": (i32, [P(MapArrays), P(UpdateParams), vp, vp, vp, vp, vp, i64, vp]),

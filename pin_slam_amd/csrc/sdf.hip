@@ -83,16 +83,35 @@ __device__ __forceinline__ void load_feature(const pin_field& f, int idx, float 
 
 struct SdfResult {
     float sdf, gx, gy, gz, std, cert;
+    float p[MF_OD_MAX];  // colour heads: sigmoid outputs (interpolated over neighbours if per-neighbour decode)
+};
+
+struct ColorTerm {
+    pin_field fc;          // colour feature table + colour decoder (3 heads)
+    const float* colors;   // [n][3] measured colours of the source points
+    int mode;              // 0 none, 1 consistency weight, 2 photometric term
+    float photo_weight;
+};
+
+struct Kappa {
+    float k[MF_OD_MAX];  // value = sum_c k[c] * sigmoid(out_c) for the colour decoder
 };
 
 // The fused per-query evaluation shared by pin_sdf_query and pin_gn_accumulate.
 // decoder back-ends: VALU (thread-private LDS column `col`) or MFMA (block weights `col`, wave scratch `xb`)
-template <int H, bool GRAD, bool MFMA>
+template <int H, bool GRAD, bool MFMA, int OD = 1>
 __device__ __forceinline__ float decode(const pin_field& f, const float (&z)[MLP_IN], float (&a)[MLP_IN], float* col,
-                                        float* xb) {
+                                        float* xb, const Kappa& kap, float (&p)[MF_OD_MAX]) {
     if constexpr (MFMA) {
-        return MfmaDecoder<H>::template run<GRAD>(col, f.levels, xb, z, a);
+        float kk[OD], pp[OD];
+#pragma unroll
+        for (int c = 0; c < OD; ++c) kk[c] = kap.k[c];
+        const float v = MfmaDecoder<H>::template run_heads<GRAD, 2, OD>(col, f.levels, xb, z, kk, pp, a);
+#pragma unroll
+        for (int c = 0; c < OD; ++c) p[c] = pp[c];
+        return v;
     } else {
+        static_assert(OD == 1, "the vector decoder has one output head");
         MlpMasks mk;
         const float x = mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
         if (GRAD) mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
@@ -100,14 +119,16 @@ __device__ __forceinline__ float decode(const pin_field& f, const float (&z)[MLP
     }
 }
 
-template <int H, bool WF, bool GRAD, bool MFMA = false>
+template <int H, bool WF, bool GRAD, bool MFMA = false, int OD = 1>
 __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4* __restrict__ nbr,
                                                 const int* __restrict__ nn_count, int qi, float qx, float qy,
-                                                float qz, float* col, float* xb = nullptr) {
+                                                float qz, float* col, float* xb = nullptr, Kappa kap = Kappa()) {
     Nbrs nb;
     load_neighbors(nbr, nn_count, qi, f.k, nb);
     SdfResult r;
     r.std = 0.f; r.gx = r.gy = r.gz = 0.f;
+#pragma unroll
+    for (int c = 0; c < MF_OD_MAX; ++c) r.p[c] = 0.f;
     float cert = 0.f;
     if (f.certainty != nullptr) {
 #pragma unroll
@@ -115,7 +136,7 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
             if (nb.idx[t] >= 0) cert = fmaf(f.certainty[nb.idx[t]], nb.w[t], cert);
     }
     r.cert = cert;
-    const float s = f.sdf_scale;
+    const float s = OD == 1 ? f.sdf_scale : 1.f;  // colour heads are not scaled (decoder.py:112)
     float Rm[9];
     // G = sum_t d u_t / d q,  d u_t/d q = -2 u_t^2 (q - P_t)
     float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
@@ -172,7 +193,7 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
                 }
             }
         float a[MLP_IN];
-        const float x = decode<H, GRAD, MFMA>(f, z, a, col, xb);
+        const float x = decode<H, GRAD, MFMA, OD>(f, z, a, col, xb, kap, r.p);
         r.sdf = s * x;
         if (GRAD) {
             float cbar = 0.f;
@@ -219,8 +240,11 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
                 for (int j = 0; j < PIN_FEATURE_DIM; ++j) z[j] = ft[j];
                 z[8] = v[0]; z[9] = v[1]; z[10] = v[2];
                 float a[MLP_IN];
-                const float xt = decode<H, GRAD, MFMA>(f, z, a, col, xb);
+                float pt[MF_OD_MAX];
+                const float xt = decode<H, GRAD, MFMA, OD>(f, z, a, col, xb, kap, pt);
                 if (idx >= 0) {
+#pragma unroll
+                    for (int c = 0; c < OD; ++c) r.p[c] = fmaf(wt, pt[c], r.p[c]);
                     st = s * xt;
                     mean = fmaf(wt, st, mean);
                     if (GRAD) {
@@ -326,24 +350,29 @@ __global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, p
 
 // ---- the same two kernels with the decoder on the fp32 matrix cores (mlp_mfma.h) -----------
 
-template <int H, bool WF>
+template <int H, bool WF, int OD = 1>
 __global__ __launch_bounds__(MF_BLOCK, 2) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int n,
                                                                   float* __restrict__ sdf_out, float* __restrict__ grad_out,
-                                                                  float* __restrict__ std_out, float* __restrict__ cert_out) {
+                                                                  float* __restrict__ std_out, float* __restrict__ cert_out,
+                                                                  Kappa kap = Kappa(), float* __restrict__ color_out = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
     float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
-    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK, OD);
     __syncthreads();
     const int qi = blockIdx.x * MF_BLOCK + threadIdx.x;
     const bool active = qi < n;
     const int qq = active ? qi : n - 1;  // every lane takes part in the wave-wide MFMAs
     const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
     SdfResult r;
-    if (grad_out != nullptr) r = eval_query<H, WF, true, true>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb);
-    else r = eval_query<H, WF, false, true>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb);
+    if (grad_out != nullptr) r = eval_query<H, WF, true, true, OD>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb, kap);
+    else r = eval_query<H, WF, false, true, OD>(f, nbr, nn_count, qq, qx, qy, qz, lds, xb, kap);
     if (!active) return;
+    if (color_out) {
+#pragma unroll
+        for (int c = 0; c < OD; ++c) color_out[(size_t)qi * OD + c] = r.p[c];
+    }
     if (sdf_out) sdf_out[qi] = r.sdf;
     if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
     if (std_out) std_out[qi] = r.std;
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
                                                                       const float* __restrict__ labels, int n,
                                                                       double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                       float* __restrict__ grad_out,
-                                                                      const double* __restrict__ state) {
+                                                                      const double* __restrict__ state, ColorTerm ct) {
     __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
     float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
@@ -372,6 +401,19 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
     for (int i = 0; i < PIN_GN_NSUMS; ++i) v[i] = 0.f;
     const float px = query[3 * qq], py = query[3 * qq + 1], pz = query[3 * qq + 2];
     const SdfResult r = eval_query<H, WF, true, true>(f, nbr, nn_count, qq, px, py, pz, lds, xb);
+    // colour term (tracker.py:493-542): the colour decoder reuses the LDS image after the SDF pass
+    float ipred = 0.f, igx = 0.f, igy = 0.f, igz = 0.f;
+    if (ct.mode != 0) {
+        __syncthreads();
+        MfmaDecoder<H>::stage(ct.fc.dec, ct.fc.levels, lds, threadIdx.x, MF_BLOCK, 3);
+        __syncthreads();
+        Kappa kap;
+        kap.k[0] = 0.299f; kap.k[1] = 0.587f; kap.k[2] = 0.114f;  // color_to_intensity, tools.py:408
+        SdfResult rc;
+        if (ct.mode == 2) rc = eval_query<H, WF, true, true, 3>(ct.fc, nbr, nn_count, qq, px, py, pz, lds, xb, kap);
+        else rc = eval_query<H, WF, false, true, 3>(ct.fc, nbr, nn_count, qq, px, py, pz, lds, xb, kap);
+        ipred = rc.sdf; igx = rc.gx; igy = rc.gy; igz = rc.gz;
+    }
     if (active) {
         if (sdf_out) sdf_out[qi] = r.sdf;
         if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
@@ -383,6 +425,13 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
             float w = 1.f;
             if (gp.gm_grad > 0.f) { const float a = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + a * a); w *= t * t; }
             if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); w *= t * t; }
+            float cres = 0.f;
+            if (ct.mode != 0) {
+                const float* cm = ct.colors + 3 * (size_t)qi;
+                const float imeas = 0.299f * cm[0] + 0.587f * cm[1] + 0.114f * cm[2];
+                cres = ipred - imeas;
+                if (ct.mode == 1) w *= expf(-fabsf(cres));  // consistency weight (tracker.py:509-514)
+            }
             float J[6];
             J[0] = py * r.gz - pz * r.gy; J[1] = pz * r.gx - px * r.gz; J[2] = px * r.gy - py * r.gx;
             J[3] = r.gx; J[4] = r.gy; J[5] = r.gz;
@@ -394,18 +443,32 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
 #pragma unroll
             for (int a = 0; a < 6; ++a) v[21 + a] = w * J[a] * res;
             v[27] = w; v[28] = fabsf(res); v[29] = 1.f; v[30] = w * res * res;
+            if (ct.mode == 2) {  // implicit_color_reg (tracker.py:699-744): + w_photo * Jc^T W Jc, Jc^T W rc
+                float Jc[6];
+                Jc[0] = py * igz - pz * igy; Jc[1] = pz * igx - px * igz; Jc[2] = px * igy - py * igx;
+                Jc[3] = igx; Jc[4] = igy; Jc[5] = igz;
+                const float wp = w * ct.photo_weight;
+                o = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) v[o++] += wp * Jc[a] * Jc[b];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) v[21 + a] += wp * Jc[a] * cres;
+                v[31] = fabsf(cres);
+            }
         }
     }
     // block reduction first (4 waves -> one set of atomics): same-address f64 atomics serialise in L2
     __shared__ double red[MF_BLOCK / 64][PIN_GN_NSUMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 31; ++i) {
+    for (int i = 0; i < PIN_GN_NSUMS; ++i) {
         const double t = (double)wave_sum_f32(v[i]);  // the reference sums these in float32 (torch mm)
         if (lane == 0) red[wave][i] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 31) {
+    if (threadIdx.x < PIN_GN_NSUMS) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < MF_BLOCK / 64; ++w) t += red[w][threadIdx.x];
@@ -583,6 +646,7 @@ static int check_field(const pin_field* f) {
     PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
     PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
     PIN_CHECK_ARG(f->dec != nullptr, "decoder parameters NULL");
+    PIN_CHECK_ARG(f->out_dim == 0 || f->out_dim == 1 || f->out_dim == 3, "out_dim must be 1 (sdf) or 3 (colour)");
     return 0;
 }
 
@@ -612,6 +676,36 @@ using namespace pin;
         }                                                                                           \
     } while (0)
 
+static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color, const float* pts,
+                     const float* nbr, const int32_t* nn_count, const float* labels, int32_t n, double* sums,
+                     float* sdf_out, float* grad_out, const double* state, hipStream_t s) {
+    ColorTerm ct;
+    memset(&ct, 0, sizeof(ct));
+    if (color != nullptr && color->mode != 0) {
+        PIN_CHECK_ARG(use_mfma_decoder(), "the colour term needs the MFMA decoder (unset PIN_DECODER)");
+        PIN_CHECK_ARG(color->field && color->colors, "colour term: field / colors NULL");
+        if (int e = check_field(color->field)) return e;
+        PIN_CHECK_ARG(color->field->out_dim == 3 && color->field->hidden == f->hidden && color->field->k == f->k &&
+                          color->field->weighted_first == f->weighted_first,
+                      "colour decoder must have 3 heads and the sdf decoder's hidden width / k / weighting mode");
+        ct.fc = *color->field;
+        ct.colors = color->colors;
+        ct.mode = color->mode;
+        ct.photo_weight = color->photo_weight;
+    }
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    if (use_mfma_decoder()) {
+        const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
+        PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
+                        sdf_out, grad_out, state, ct);
+    } else {
+        const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
+        PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out,
+                        grad_out, state);
+    }
+    return 0;
+}
+
 extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count,
                              int32_t n, float* sdf_out, float* grad_out, float* std_out, float* certainty_out,
                              void* stream) {
@@ -626,9 +720,65 @@ extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float
     return 0;
 }
 
-extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const float* query, const float* nbr,
-                                 const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums_out,
-                                 float* sdf_out, float* grad_out, void* stream) {
+// Decoder.regress_color on caller-provided features: sigmoid(mlp) for the 3 colour heads
+template <int H>
+__global__ __launch_bounds__(MF_BLOCK, 2) void decoder_color_mfma_kernel(pin_field f, const float* __restrict__ feat, int n,
+                                                                         float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
+    float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK, 3);
+    __syncthreads();
+    const int i = blockIdx.x * MF_BLOCK + threadIdx.x;
+    const int ii = i < n ? i : n - 1;
+    float z[MLP_IN], a[MLP_IN], p[3];
+#pragma unroll
+    for (int j = 0; j < MLP_IN; ++j) z[j] = feat[(size_t)ii * MLP_IN + j];
+    const float kk[3] = {0.f, 0.f, 0.f};
+    MfmaDecoder<H>::template run_heads<false, 2, 3>(lds, f.levels, xb, z, kk, p, a);
+    if (i < n) { out[3 * (size_t)i] = p[0]; out[3 * (size_t)i + 1] = p[1]; out[3 * (size_t)i + 2] = p[2]; }
+}
+
+extern "C" int pin_decoder_color(const pin_field* f, const float* feat_in, int32_t n, float* color_out, void* stream) {
+    PIN_ENTER();
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(f->out_dim == 3, "colour decoder must have 3 output heads");
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(feat_in && color_out, "NULL pointer");
+    const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
+    if (f->hidden == 64) hipLaunchKernelGGL(decoder_color_mfma_kernel<64>, grid, block, 0, as_stream(stream), *f, feat_in, n, color_out);
+    else hipLaunchKernelGGL(decoder_color_mfma_kernel<32>, grid, block, 0, as_stream(stream), *f, feat_in, n, color_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_color_query(const pin_field* fc, const float* query, const float* nbr, const int32_t* nn_count,
+                               int32_t n, const float* kappa_host, float* color_out, float* value_out, float* grad_out,
+                               void* stream) {
+    PIN_ENTER();
+    if (int e = check_field(fc)) return e;
+    PIN_CHECK_ARG(fc->out_dim == 3, "colour field must have 3 output heads");
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr && nn_count && fc->feats && kappa_host, "NULL pointer");
+    Kappa kap;
+    for (int c = 0; c < 3; ++c) kap.k[c] = kappa_host[c];
+    const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    hipStream_t s = as_stream(stream);
+#define PIN_COLOR_Q(HH, WFV) \
+    hipLaunchKernelGGL((sdf_query_mfma_kernel<HH, WFV, 3>), grid, block, 0, s, *fc, query, nb4, nn_count, n, value_out, \
+                       grad_out, (float*)nullptr, (float*)nullptr, kap, color_out)
+    if (fc->hidden == 64) { if (fc->weighted_first) PIN_COLOR_Q(64, true); else PIN_COLOR_Q(64, false); }
+    else { if (fc->weighted_first) PIN_COLOR_Q(32, true); else PIN_COLOR_Q(32, false); }
+#undef PIN_COLOR_Q
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                                 const float* query, const float* nbr, const int32_t* nn_count, const float* sdf_labels,
+                                 int32_t n, double* sums_out, float* sdf_out, float* grad_out, void* stream) {
     PIN_ENTER();
     if (int e = check_field(f)) return e;
     PIN_CHECK_ARG(gp && sums_out, "NULL pointer");
@@ -637,8 +787,7 @@ extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, co
     PIN_CHECK_HIP(hipMemsetAsync(sums_out, 0, sizeof(double) * PIN_GN_NSUMS * GN_REPLICAS, s));
     if (n == 0) return 0;
     PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
-    PIN_DISPATCH_FIELD(f, gn_accumulate, n, s, *f, *gp, query, reinterpret_cast<const float4*>(nbr), nn_count,
-                       sdf_labels, n, sums_out, sdf_out, grad_out, (const double*)nullptr);
+    if (int e = launch_gn(f, gp, color, query, nbr, nn_count, sdf_labels, n, sums_out, sdf_out, grad_out, nullptr, s)) return e;
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -661,16 +810,15 @@ extern "C" int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc
     return knn_direct_dev(sp, src, n, k, state, cur_out, nbr_out, nn_count_out, stream);
 }
 
-extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const float* cur, const float* nbr,
-                                    const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
-                                    const double* state, void* stream) {
+extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                                    const float* cur, const float* nbr, const int32_t* nn_count, const float* sdf_labels,
+                                    int32_t n, double* sums, const double* state, void* stream) {
     PIN_ENTER();
     if (int e = check_field(f)) return e;
     PIN_CHECK_ARG(gp && sums && state && n > 0, "bad arguments");
     PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
     hipStream_t s = as_stream(stream);
-    PIN_DISPATCH_FIELD(f, gn_accumulate, n, s, *f, *gp, cur, reinterpret_cast<const float4*>(nbr), nn_count, sdf_labels,
-                       n, sums, (float*)nullptr, (float*)nullptr, state);
+    if (int e = launch_gn(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, nullptr, nullptr, state, s)) return e;
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -683,10 +831,11 @@ extern "C" int pin_gn_solve(double* sums, double* state, const pin_gn_loop_param
     return 0;
 }
 
-extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_gn_loop_params* lp,
-                                       const float* cur, const float* nbr, const int32_t* nn_count,
-                                       const float* sdf_labels, int32_t n, double* sums, double* state, void* stream) {
-    if (int e = pin_gn_accumulate_dev(f, gp, cur, nbr, nn_count, sdf_labels, n, sums, state, stream)) return e;
+extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
+                                       const pin_gn_loop_params* lp, const float* cur, const float* nbr,
+                                       const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
+                                       double* state, void* stream) {
+    if (int e = pin_gn_accumulate_dev(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, state, stream)) return e;
     return pin_gn_solve(sums, state, lp, stream);
 }
 

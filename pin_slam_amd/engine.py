@@ -34,7 +34,8 @@ class GNTracker:
         self.bricks = None  # ops.BrickCache built for (time_filtering, local) of the calls below
         self.state = self.state_host = None
 
-    def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None):
+    def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None,
+             color=None):
         n = src.shape[0]
         out = (self.nbr[:n], self.nn[:n], self.cur[:n])
         if self.on_knn:
@@ -44,14 +45,14 @@ class GNTracker:
         if self.on_knn:
             self.on_knn(False)
         cur = out[2] if T is not None else src
-        ops.gn_accumulate(self.fs, self.gp, cur, out[0], out[1], sdf_labels=labels, sums=self.sums)
+        ops.gn_accumulate(self.fs, self.gp, cur, out[0], out[1], sdf_labels=labels, sums=self.sums, color=color)
         self.sums_host.copy_(self.sums, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return ops.solve_gn(self.sums_host.numpy(), self.lm_lambda)
 
     def track(self, src: torch.Tensor, T_init: np.ndarray, iters: int, term_deg: float = 0.01,
               term_m: float = 0.001, early_exit: bool = True, min_valid_ratio: float = 0.2,
-              time_filtering=True, local=True, labels=None):
+              time_filtering=True, local=True, labels=None, color=None):
         """Device-resident GN loop (Tracker.tracking, tracker.py:114-184): `iters` x (kNN with the
         pose read from device state, fused SDF+Jacobian+sums, one-wave 6x6 solve + loop control)
         enqueued back to back; kernels turn into no-ops once the loop has ended on the device.
@@ -79,6 +80,7 @@ class GNTracker:
         lp.iter_n, lp.early_exit = int(iters), int(bool(early_exit))
         import ctypes as C
         sp_r, f_r, gp_r, lp_r = C.byref(sp), C.byref(f), C.byref(self.gp), C.byref(lp)
+        ct_r = C.byref(color) if color is not None else None
         bc_r = C.byref(bc) if bc is not None else None
         src_p, cur_p, nbr_p, nn_p = src.data_ptr(), self.cur.data_ptr(), self.nbr.data_ptr(), self.nn.data_ptr()
         sums_p, st_p = self.sums.data_ptr(), self.state.data_ptr()
@@ -92,11 +94,11 @@ class GNTracker:
                 self.on_knn(False)
             if self.on_gn:
                 self.on_gn(True)
-                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, ct_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
                 self.on_gn(False)
                 rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
             else:
-                rc |= L.pin_gn_accumulate_solve(f_r, gp_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+                rc |= L.pin_gn_accumulate_solve(f_r, gp_r, ct_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
             if rc:
                 check(rc, "pin_gn_knn / pin_gn_accumulate_solve")
         self.state_host.copy_(self.state, non_blocking=True)

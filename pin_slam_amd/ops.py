@@ -195,6 +195,7 @@ class FieldState:
     certainty: Optional[torch.Tensor] = None
     orient: Optional[torch.Tensor] = None   # only after PGO
     pos: Optional[torch.Tensor] = None      # [M,3]
+    out_dim: int = 1                        # 1 = sdf head, 3 = colour heads
 
     def params(self) -> Field:
         f = Field()
@@ -206,6 +207,7 @@ class FieldState:
         f.k, f.hidden, f.levels = int(self.k), int(self.hidden), int(self.levels)
         f.weighted_first = int(bool(self.weighted_first))
         f.sdf_scale = float(self.sdf_scale)
+        f.out_dim = int(self.out_dim)
         return f
 
 
@@ -248,7 +250,24 @@ def sdf_query(fs: FieldState, query, nbr, nn, grad=True, std=True, certainty=Tru
     return sdf, g, sd, ce
 
 
-def gn_accumulate(fs: FieldState, gp: GnParams, query, nbr, nn, sdf_labels=None, sums=None, want_points=False):
+def color_term(fc: Optional[FieldState], colors: Optional[torch.Tensor], photometric: bool, photo_weight: float = 0.01,
+               consist_weight: bool = True):
+    """(ColorTerm struct, keep-alive refs) for the registration kernels, or (None, None)."""
+    if fc is None or colors is None:
+        return None, None
+    mode = 2 if photometric else (1 if consist_weight else 0)
+    if mode == 0:
+        return None, None
+    f = fc.params()
+    ct = _lib.ColorTerm()
+    ct.field = C.pointer(f)
+    ct.colors = _ptr(colors, torch.float32)
+    ct.mode, ct.photo_weight = mode, float(photo_weight)
+    return ct, (f, colors)
+
+
+def gn_accumulate(fs: FieldState, gp: GnParams, query, nbr, nn, sdf_labels=None, sums=None, want_points=False,
+                  color=None):
     """Fused SDF + Jacobian + Gauss-Newton sums.  Returns the [64, 32] double replica buffer
     (sum over dim 0 on the host) and optionally per-point (sdf, grad)."""
     n = query.shape[0]
@@ -258,7 +277,8 @@ def gn_accumulate(fs: FieldState, gp: GnParams, query, nbr, nn, sdf_labels=None,
     sdf = torch.empty((n,), dtype=torch.float32, device=dev) if want_points else None
     g = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_points else None
     f = fs.params()
-    check(_lib.lib().pin_gn_accumulate(C.byref(f), C.byref(gp), _ptr(query, torch.float32), _ptr(nbr),
+    check(_lib.lib().pin_gn_accumulate(C.byref(f), C.byref(gp), C.byref(color) if color is not None else None,
+                                       _ptr(query, torch.float32), _ptr(nbr),
                                        _ptr(nn, torch.int32), _ptr(sdf_labels), n, _ptr(sums), _ptr(sdf), _ptr(g),
                                        _stream()), "pin_gn_accumulate")
     return sums, sdf, g
@@ -287,7 +307,7 @@ def solve_gn(sums: np.ndarray, lm_lambda: float):
     S = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
     T[:3, :3] = np.eye(3) + S * np.sin(ang) + (S @ S) * (1.0 - np.cos(ang))
     T[:3, 3] = t[3:]
-    return T, cnt, float(s[28] / cnt * 100.0), dict(N_raw=N_raw, mse=scale * s[30] / cnt)
+    return T, cnt, float(s[28] / cnt * 100.0), dict(N_raw=N_raw, mse=scale * s[30] / cnt, photo_residual=float(s[31] / cnt))
 
 
 # ------------------------------------------------------------------------------- training
@@ -349,3 +369,29 @@ def gather_batch(pool_coord, pool_label, pool_weight, pool_ts, index, out):
                                       _ptr(pool_weight), _ptr(pool_ts), _ptr(index, torch.int32), index.numel(),
                                       _ptr(coord), _ptr(label), _ptr(weight), _ptr(ts), _stream()), "pin_gather_batch")
     return out
+
+
+INTENSITY = (0.299, 0.587, 0.114)  # color_to_intensity, utils/tools.py:408-410
+
+
+def decoder_color(fs: FieldState, feat: torch.Tensor):
+    """Decoder.regress_color on [n, 11] features -> [n, 3]."""
+    n = feat.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=feat.device)
+    f = fs.params()
+    check(_lib.lib().pin_decoder_color(C.byref(f), _ptr(feat, torch.float32), n, _ptr(out), _stream()), "pin_decoder_color")
+    return out
+
+
+def color_query(fc: FieldState, query, nbr, nn, kappa=INTENSITY, want_color=True, want_grad=True):
+    """Colour prediction [n,3], value = kappa . colour [n] and its gradient [n,3]."""
+    n = query.shape[0]
+    dev = query.device
+    col = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_color else None
+    val = torch.empty((n,), dtype=torch.float32, device=dev)
+    g = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_grad else None
+    kap = np.ascontiguousarray(np.asarray(kappa, dtype=np.float32))
+    f = fc.params()
+    check(_lib.lib().pin_color_query(C.byref(f), _ptr(query, torch.float32), _ptr(nbr), _ptr(nn, torch.int32), n,
+                                     kap.ctypes.data, _ptr(col), _ptr(val), _ptr(g), _stream()), "pin_color_query")
+    return col, val, g
