@@ -210,6 +210,13 @@ typedef struct pin_local_params {
     float radius2;             /* local_map_radius^2 */
 } pin_local_params;
 
+typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapper.py:668-675, 804-812) */
+    int32_t n_main;          /* batch size */
+    int32_t loss_weight_on;  /* config.loss_weight_on */
+    float surface_range;     /* surface_sample_range_m: samples with |sdf_label| below it carry colour */
+    float weight_i;          /* config.weight_i */
+} pin_train_color_params;
+
 /* ---- library ------------------------------------------------------------------- */
 int         pin_version(void);
 const char* pin_last_error(void);
@@ -354,6 +361,19 @@ int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* 
                    const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,
                    int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
                    float* pred_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Colour term of one training iteration: regress_color on the colour features of the batch
+ * (first n_main queries / kNN records of pin_train_step's query set), L1 loss on the surface
+ * samples (color_diff_loss, utils/loss.py:31-42), backward into feat_grad (gradient of
+ * local_color_features, +=) and dec_grad (colour decoder, +=; NULL = frozen).  loss_out:
+ * double[1] = sum of (weighted) |pred - label| over surface samples and channels.  The workspace
+ * needs pin_train_workspace_bytes(n_main, hidden, levels, expand) + 256 bytes.  Single GPU
+ * (the surface-sample count of the mean is not all-reduced). */
+int pin_train_color_step(const pin_field* fc, const pin_train_color_params* tp, const float* query,
+                         const float* nbr, const int32_t* nn_count, const float* sdf_label,
+                         const float* color_label, const float* sample_weight, float* feat_grad,
+                         float* dec_grad, double* loss_out, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 
 /* K7: torch.optim.Adam step (no amsgrad, no weight decay) as configured by setup_optimizer
  * (utils/tools.py:198-199): betas (0.9, 0.99), eps = adam_eps.  `step` counts from 1.

@@ -102,6 +102,11 @@ class TrainParams(C.Structure):
     ]
 
 
+class TrainColorParams(C.Structure):
+    _fields_ = [("n_main", C.c_int32), ("loss_weight_on", C.c_int32), ("surface_range", C.c_float),
+                ("weight_i", C.c_float)]
+
+
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
 P = C.POINTER
 
@@ -136,6 +141,7 @@ SIGNATURES = {
     "pin_train_make_queries": (i32, [vp, i32, i32, i32, i32, f32, vp, vp]),
     "pin_train_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "pin_train_color_step": (i32, [P(Field), P(TrainColorParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
 }
 

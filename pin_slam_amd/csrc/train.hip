@@ -20,9 +20,10 @@ constexpr int TR_BLOCK = 128;
 struct TrainWs {
     float* z;      // [12][Qs]  interpolated decoder input (row 11 unused)
     float* h;      // [L*H][Qs] post-ReLU activations
-    float* d;      // [L*H + 1][Qs] deltas; last row = d loss / d mlp_out
-    float* pred;   // [Qs]
-    float* dpred;  // [Qs]
+    float* d;      // [L*H + OD][QsT] deltas; last rows = d loss / d head outputs
+    float* pred;   // [OD][Qs]
+    float* dpred;  // [OD][Qs]
+    float* xraw;   // [OD][QsT] raw head outputs per neighbour sample (colour, per-neighbour decode)
     unsigned long long* mask;  // [L][QsT] ReLU masks of the MFMA decoder (one word per lane and layer)
     int Qs;        // padded query count (multiple of 64)
     int QsT;       // sample columns of z / h / d / mask: Qs (weighted_first) or k * Qs (one decode per neighbour)
@@ -31,7 +32,17 @@ struct TrainWs {
 __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L, int expand) {
     const size_t Qs = (size_t)((Q + 63) / 64) * 64;
     const size_t QsT = Qs * (size_t)expand;
-    return QsT * (12 + (size_t)L * H + (size_t)L * H + 1 + 2 * (size_t)L) + 2 * Qs;
+    return QsT * (12 + (size_t)L * H + (size_t)L * H + MF_OD_MAX + 2 * (size_t)L + MF_OD_MAX) + 2 * MF_OD_MAX * Qs;
+}
+
+static void carve_ws(TrainWs& ws, float* w, int H, int L) {
+    ws.pred = w; w += (size_t)MF_OD_MAX * ws.Qs;
+    ws.dpred = w; w += (size_t)MF_OD_MAX * ws.Qs;
+    ws.z = w; w += (size_t)12 * ws.QsT;
+    ws.h = w; w += (size_t)L * H * ws.QsT;
+    ws.d = w; w += ((size_t)L * H + MF_OD_MAX) * ws.QsT;
+    ws.xraw = w; w += (size_t)MF_OD_MAX * ws.QsT;
+    ws.mask = reinterpret_cast<unsigned long long*>(w);
 }
 
 __global__ void make_queries_kernel(const float* __restrict__ coord, int n_main, int n_eik, int dec, int first,
@@ -219,7 +230,7 @@ __device__ __forceinline__ void neighbor_input(const pin_field& f, int idx, bool
     }
 }
 
-template <int H, bool WF>
+template <int H, bool WF, int OD = 1>
 __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int Q, int n_main,
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
                                                                   int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
     __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
     float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
-    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK, OD);
     __syncthreads();
     const int q0 = (blockIdx.x * (MF_BLOCK / 64) + (threadIdx.x >> 6)) * 64;
     if (q0 >= ws.Qs) return;  // whole wave
@@ -240,7 +251,9 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
     neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
     const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
     const size_t QsT = ws.QsT;
-    float pred;
+    float pred[OD];  // OD = 1: sdf (scaled); OD = 3: colour = sigmoid(head) (decoder.py:112)
+#pragma unroll
+    for (int c = 0; c < OD; ++c) pred[c] = 0.f;
     if (WF) {
         float z[MLP_IN];
 #pragma unroll
@@ -258,13 +271,13 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
 #pragma unroll
         for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + qi] = z[j];
         ws.z[(size_t)11 * QsT + qi] = 0.f;
-        float o[1];
-        MfmaDecoder<H>::template forward_store<1>(lds, f.levels, xb, z, ws.h, QsT, (size_t)q0, ws.mask + q0, QsT, o);
-        pred = f.sdf_scale * o[0];
+        float o[OD];
+        MfmaDecoder<H>::template forward_store<OD>(lds, f.levels, xb, z, ws.h, QsT, (size_t)q0, ws.mask + q0, QsT, o);
+#pragma unroll
+        for (int c = 0; c < OD; ++c) pred[c] = OD == 1 ? f.sdf_scale * o[c] : sigmoidf_(o[c]);
     } else {
         // weighted_first = False (run_kitti.yaml:25): decode every neighbour, then weight the
         // predictions (mapper.py:658-662); neighbour t of all queries forms sample block t
-        pred = 0.f;
 #pragma unroll 1
         for (int t = 0; t < f.k; ++t) {
             int idx = -1; float wt = 0.f, gx = 0.f, gy = 0.f, gz = 0.f; bool qk = false;
@@ -285,12 +298,17 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
 #pragma unroll
             for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * QsT + col0 + (threadIdx.x & 63)] = z[j];
             ws.z[(size_t)11 * QsT + col0 + (threadIdx.x & 63)] = 0.f;
-            float o[1];
-            MfmaDecoder<H>::template forward_store<1>(lds, f.levels, xb, z, ws.h, QsT, col0, ws.mask + col0, QsT, o);
-            if (idx >= 0) pred = fmaf(wt, f.sdf_scale * o[0], pred);
+            float o[OD];
+            MfmaDecoder<H>::template forward_store<OD>(lds, f.levels, xb, z, ws.h, QsT, col0, ws.mask + col0, QsT, o);
+#pragma unroll
+            for (int c = 0; c < OD; ++c) {
+                if (OD > 1) ws.xraw[(size_t)c * QsT + col0 + (threadIdx.x & 63)] = o[c];
+                if (idx >= 0) pred[c] = fmaf(wt, OD == 1 ? f.sdf_scale * o[c] : sigmoidf_(o[c]), pred[c]);
+            }
         }
     }
-    ws.pred[qi] = pred;
+#pragma unroll
+    for (int c = 0; c < OD; ++c) ws.pred[(size_t)c * ws.Qs + qi] = pred[c];
     if (active && qi < n_main && cert_rw != nullptr) {
 #pragma unroll
         for (int t = 0; t < PIN_MAX_K; ++t)
@@ -301,13 +319,13 @@ __global__ __launch_bounds__(MF_BLOCK) void train_fwd_mfma_kernel(pin_field f, c
     }
 }
 
-template <int H, bool WF>
+template <int H, bool WF, int OD = 1>
 __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int Q, TrainWs ws,
                                                                   float* __restrict__ feat_grad, int want_dec) {
     __shared__ __attribute__((aligned(16))) float lds[MfmaLds<H>::TOTAL];
     float* xb = lds + MfmaLds<H>::W + (threadIdx.x >> 6) * MfmaDecoder<H>::scratch_floats();
-    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK);
+    MfmaDecoder<H>::stage(f.dec, f.levels, lds, threadIdx.x, MF_BLOCK, OD);
     __syncthreads();
     const int q0 = (blockIdx.x * (MF_BLOCK / 64) + (threadIdx.x >> 6)) * 64;
     if (q0 >= ws.Qs) return;
@@ -315,7 +333,14 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
     const int qi = q0 + lane;
     const bool active = qi < Q;
     const size_t QsT = ws.QsT;
-    const float dxq = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // d loss / d (sum_t w_t x_t)
+    // d loss / d prediction per head; sdf: the prediction is sdf_scale * head
+    float dpq[OD];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < OD; ++c) {
+        dpq[c] = active ? ws.dpred[(size_t)c * ws.Qs + qi] * (OD == 1 ? f.sdf_scale : 1.f) : 0.f;
+        any = any || dpq[c] != 0.f;
+    }
     NbrW nb;
     {
         float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
@@ -323,16 +348,22 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
         const int qq = active ? qi : Q - 1;
         neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
     }
-    const bool live = active && dxq != 0.f;
+    const bool live = active && any;
     float* sdz = xb;                 // [32][8] (WF) / [64][8] (per-neighbour mode)
     float* sw = xb + 256;            // [32][8]
     int* sidx = reinterpret_cast<int*>(xb + 512);  // [32][8] / [64]
     if (WF) {
-        if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + qi] = dxq;
+        float dxa[OD];
+#pragma unroll
+        for (int c = 0; c < OD; ++c) {
+            float dh = dpq[c];  // through the sigmoid of the colour heads: p (1 - p)
+            if (OD > 1) { const float pc = ws.pred[(size_t)c * ws.Qs + (active ? qi : 0)]; dh *= pc * (1.f - pc); }
+            dxa[c] = dh;
+            if (want_dec) ws.d[(size_t)(f.levels * H + c) * QsT + qi] = dh;
+        }
         float dz[MLP_IN];
-        const float dxa[1] = {dxq};
-        MfmaDecoder<H>::template backward_store<1>(lds, f.levels, xb, dxa, ws.mask + q0, QsT, ws.d, QsT, (size_t)q0,
-                                                   want_dec != 0, dz);
+        MfmaDecoder<H>::template backward_store<OD>(lds, f.levels, xb, dxa, ws.mask + q0, QsT, ws.d, QsT, (size_t)q0,
+                                                    want_dec != 0, dz);
         // Feature-gradient scatter.  One atomic instruction per QUERY: its 64 lanes are the 8
         // neighbours x 8 feature dims, so every instruction touches 8 whole 32-byte rows instead
         // of 64 different rows (the L2 atomic units work per cache line; measured 3x on this kernel).
@@ -362,17 +393,24 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
 #pragma unroll
             for (int u = 0; u < PIN_MAX_K; ++u)
                 if (u == t) { idx = nb.idx[u]; wt = nb.w[u]; }
-            const float dx = (live && idx >= 0) ? dxq * wt : 0.f;  // d loss / d x_t
             const size_t col0 = (size_t)t * ws.Qs + q0;
-            if (want_dec) ws.d[(size_t)(f.levels * H) * QsT + col0 + lane] = dx;
+            float dxa[OD];
+            bool nz = false;
+#pragma unroll
+            for (int c = 0; c < OD; ++c) {
+                float dh = (live && idx >= 0) ? dpq[c] * wt : 0.f;  // d loss / d head_c of neighbour t
+                if (OD > 1) { const float pc = sigmoidf_(ws.xraw[(size_t)c * QsT + col0 + lane]); dh *= pc * (1.f - pc); }
+                dxa[c] = dh;
+                nz = nz || dh != 0.f;
+                if (want_dec) ws.d[(size_t)(f.levels * H + c) * QsT + col0 + lane] = dh;
+            }
             float dz[MLP_IN];
-            const float dxa[1] = {dx};
-            MfmaDecoder<H>::template backward_store<1>(lds, f.levels, xb, dxa, ws.mask + col0, QsT, ws.d, QsT, col0,
-                                                       want_dec != 0, dz);
+            MfmaDecoder<H>::template backward_store<OD>(lds, f.levels, xb, dxa, ws.mask + col0, QsT, ws.d, QsT, col0,
+                                                        want_dec != 0, dz);
             // one neighbour per query here: 8 queries x 8 feature dims per atomic instruction
 #pragma unroll
             for (int j = 0; j < PIN_FEATURE_DIM; ++j) sdz[lane * 8 + j] = dz[j];
-            sidx[lane] = dx != 0.f ? idx : -1;
+            sidx[lane] = nz ? idx : -1;
             wave_lds_sync();
             const int qo = lane >> 3, j = lane & 7;
             for (int i = 0; i < 8; ++i) {
@@ -483,6 +521,37 @@ __global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const 
         }
 }
 
+// ---- colour loss: weight_i * mean over surface samples and channels of |pred - label| ---------
+// (color_diff_loss, utils/loss.py:31-42; mapper.py:673-675, 804-812)
+__global__ __launch_bounds__(256) void color_count_kernel(const float* __restrict__ label, int n, float range,
+                                                          int* __restrict__ count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < n && fabsf(label[i]) < range;
+    const int c = __popcll(__ballot(on));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__global__ __launch_bounds__(256) void train_color_loss_kernel(pin_train_color_params tp, const float* __restrict__ label,
+                                                               const float* __restrict__ color,
+                                                               const float* __restrict__ weight, TrainWs ws,
+                                                               const int* __restrict__ count, double* __restrict__ loss_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double l = 0.0;
+    if (i < tp.n_main) {
+        const bool on = fabsf(label[i]) < tp.surface_range;
+        const float wt = tp.loss_weight_on ? fabsf(weight[i]) : 1.f;
+        const float scale = tp.weight_i * wt / fmaxf((float)(*count) * 3.f, 1.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float diff = ws.pred[(size_t)c * ws.Qs + i] - color[3 * (size_t)i + c];
+            ws.dpred[(size_t)c * ws.Qs + i] = on ? (diff > 0.f ? scale : (diff < 0.f ? -scale : 0.f)) : 0.f;
+            if (on) l += (double)(wt * fabsf(diff));
+        }
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0 && l != 0.0) atomicAdd(loss_out, l);
+}
+
 // ---- decoder weight gradients: G[i][j] = sum_q D[i][q] * X[j][q]  (fp32 MFMA 16x16x4) ------
 // A skinny GEMM whose reduction dimension is the batch.  grid = (K-slices, layers); a block is
 // 4 waves, each wave owns a contiguous run of queries and ALL (<= 4x4) 16x16 output tiles.
@@ -493,7 +562,7 @@ __global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DwLayers {
-    int H, L, Q, Qs, per_wave;  // Q / Qs: sample columns (valid / row stride)
+    int H, L, Q, Qs, per_wave, OD;  // Q / Qs: sample columns (valid / row stride); OD output heads
 };
 
 __device__ __forceinline__ float4 load_row4(const float* __restrict__ base, int row, int nrows, int Qs, int q, int Q) {
@@ -511,7 +580,7 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
     __shared__ float red[3][16 * 256 + 64];
     const int H = dl.H, L = dl.L, Qs = dl.Qs, Q = dl.Q;
     const int l = blockIdx.y;
-    const int rows = l < L ? H : 1;
+    const int rows = l < L ? H : dl.OD;
     const int cols = l == 0 ? 12 : H;       // z carries 12 rows (row 11 is zero)
     const int cols_out = l == 0 ? MLP_IN : H;
     const float* __restrict__ D = ws.d + (size_t)l * H * Qs;
@@ -677,13 +746,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     TrainWs ws;
     ws.Qs = ((Q + 63) / 64) * 64;
     ws.QsT = ws.Qs * expand;
-    float* w = reinterpret_cast<float*>(workspace);
-    ws.pred = w; w += ws.Qs;
-    ws.dpred = w; w += ws.Qs;
-    ws.z = w; w += (size_t)12 * ws.QsT;
-    ws.h = w; w += (size_t)L * H * ws.QsT;
-    ws.d = w; w += ((size_t)L * H + 1) * ws.QsT;
-    ws.mask = reinterpret_cast<unsigned long long*>(w);
+    carve_ws(ws, reinterpret_cast<float*>(workspace), H, L);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
     PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));
@@ -717,7 +780,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         DwLayers dl;
         // sample columns: Q for weighted_first; k blocks of Qs otherwise (padding columns carry zero deltas)
         const int QT = expand == 1 ? Q : ws.QsT;
-        dl.H = H; dl.L = L; dl.Q = QT; dl.Qs = ws.QsT;
+        dl.H = H; dl.L = L; dl.Q = QT; dl.Qs = ws.QsT; dl.OD = 1;
         int per_wave = 64;  // multiple of 16; cap the grid at ~256 blocks per layer
         while ((long)cdiv(QT, per_wave * 4) > 256) per_wave *= 2;
         dl.per_wave = per_wave;
@@ -725,6 +788,61 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         PIN_CHECK_LAUNCH();
     }
     if (pred_out) PIN_CHECK_HIP(hipMemcpyAsync(pred_out, ws.pred, sizeof(float) * tp->n_main, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_params* tp, const float* query,
+                                    const float* nbr, const int32_t* nn_count, const float* sdf_label,
+                                    const float* color_label, const float* sample_weight, float* feat_grad,
+                                    float* dec_grad, double* loss_out, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(fc && tp, "NULL params");
+    PIN_CHECK_ARG(use_mfma_decoder(), "the colour term needs the MFMA decoder (unset PIN_DECODER)");
+    PIN_CHECK_ARG(fc->out_dim == 3, "colour field must have 3 output heads");
+    PIN_CHECK_ARG(fc->k >= 1 && fc->k <= PIN_MAX_K && (fc->hidden == 32 || fc->hidden == 64) && fc->levels >= 1 &&
+                      fc->levels <= MLP_MAX_LEVELS, "bad colour field");
+    PIN_CHECK_ARG(tp->n_main > 0, "bad batch size");
+    const int Q = tp->n_main, H = fc->hidden, L = fc->levels;
+    const int expand = fc->weighted_first ? 1 : fc->k;
+    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(Q, H, L, expand) * 4 + 256, "workspace too small");
+    PIN_CHECK_ARG(query && nbr && nn_count && sdf_label && color_label && feat_grad && loss_out && fc->feats && fc->dec,
+                  "NULL pointer");
+    PIN_CHECK_ARG(!tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
+    hipStream_t s = as_stream(stream);
+    TrainWs ws;
+    ws.Qs = ((Q + 63) / 64) * 64;
+    ws.QsT = ws.Qs * expand;
+    carve_ws(ws, reinterpret_cast<float*>(workspace), H, L);
+    int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)train_ws_floats(Q, H, L, expand) * 4);
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
+    PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, sizeof(double), s));
+    PIN_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+#define PIN_TRAIN_C(KERNEL, ...)                                                                          \
+    do {                                                                                                  \
+        if (H == 64) { if (fc->weighted_first) hipLaunchKernelGGL((KERNEL<64, true, 3>), mgrid, mblock, 0, s, __VA_ARGS__); \
+                       else hipLaunchKernelGGL((KERNEL<64, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__); } \
+        else { if (fc->weighted_first) hipLaunchKernelGGL((KERNEL<32, true, 3>), mgrid, mblock, 0, s, __VA_ARGS__); \
+               else hipLaunchKernelGGL((KERNEL<32, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__); }        \
+    } while (0)
+    PIN_TRAIN_C(train_fwd_mfma_kernel, *fc, query, nb4, nn_count, Q, Q, ws, (float*)nullptr, (int*)nullptr, (const int*)nullptr);
+    hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
+    hipLaunchKernelGGL(train_color_loss_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, *tp, sdf_label, color_label,
+                       sample_weight, ws, count, loss_out);
+    const int want_dec = dec_grad != nullptr;
+    PIN_TRAIN_C(train_bwd_mfma_kernel, *fc, nb4, nn_count, Q, ws, feat_grad, want_dec);
+#undef PIN_TRAIN_C
+    if (want_dec) {
+        DwLayers dl;
+        const int QT = expand == 1 ? Q : ws.QsT;
+        dl.H = H; dl.L = L; dl.Q = QT; dl.Qs = ws.QsT; dl.OD = 3;
+        int per_wave = 64;
+        while ((long)cdiv(QT, per_wave * 4) > 256) per_wave *= 2;
+        dl.per_wave = per_wave;
+        hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(QT, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
+    }
+    PIN_CHECK_LAUNCH();
     return 0;
 }
 

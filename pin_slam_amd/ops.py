@@ -330,6 +330,7 @@ class TrainBuffers:
         nbytes = _lib.lib().pin_train_workspace_bytes(self.Q, hidden, levels, 1 if weighted_first else k)
         self.ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
         self.loss = torch.zeros((2,), dtype=torch.float64, device=device)
+        self.color_ws = self.color_loss = None
 
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
@@ -354,6 +355,25 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
                            _ptr(ts_update_rw), _ptr(feat_grad, torch.float32), _ptr(dec_grad), _ptr(buf.loss),
                            _ptr(pred_out), _ptr(buf.ws), buf.ws.numel() * 4, s), "pin_train_step")
     return buf.loss
+
+
+def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
+                     surface_range, weight_i=1.0, loss_weight_on=False):
+    """Colour term of a training iteration; call after train_step (reuses its queries / kNN)."""
+    if buf.color_ws is None:
+        nbytes = _lib.lib().pin_train_workspace_bytes(buf.n_main, fc.hidden, fc.levels, 1 if fc.weighted_first else fc.k) + 256
+        buf.color_ws = torch.empty((nbytes // 4 + 1,), dtype=torch.float32, device=buf.query.device)
+        buf.color_loss = torch.zeros((1,), dtype=torch.float64, device=buf.query.device)
+    tp = _lib.TrainColorParams()
+    tp.n_main, tp.loss_weight_on = buf.n_main, int(bool(loss_weight_on))
+    tp.surface_range, tp.weight_i = float(surface_range), float(weight_i)
+    f = fc.params()
+    check(_lib.lib().pin_train_color_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
+                                          _ptr(sdf_label, torch.float32), _ptr(color_label, torch.float32),
+                                          _ptr(sample_weight), _ptr(feat_grad, torch.float32), _ptr(dec_grad),
+                                          _ptr(buf.color_loss), _ptr(buf.color_ws), buf.color_ws.numel() * 4, _stream()),
+          "pin_train_color_step")
+    return buf.color_loss
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15, zero_grad=True):

@@ -87,3 +87,37 @@ def test_color_tracking(cg):
     assert valid == bool(d["trk_valid"])
     np.testing.assert_allclose(T[:3, 3], d["trk_T"][:3, 3], rtol=0, atol=1e-4)
     np.testing.assert_allclose(T[:3, :3], d["trk_T"][:3, :3], rtol=0, atol=1e-5)
+
+
+def test_color_mapping_two_iterations(cg):
+    """Mapper.mapping with colour_on: gradients of geo / colour features and of both decoders for
+    two iterations, post-Adam parameters (mapper.py:645-818, loss.py:31-42)."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = cg
+    k = int(d["query_nn_k"])
+    geo, col = U.dev(d["local_geo_features"]), U.dev(d["local_color_features"])
+    gdec, cdec = U.dev(d["dec_flat"]), U.dev(d["cdec_flat"])
+    cert = U.dev(d["local_point_certainties"]); tsu = U.dev(d["local_point_ts_update"], torch.int32)
+    fs = dataclasses.replace(d["fs"], feats=geo, dec=gdec, certainty=cert)
+    fc = dataclasses.replace(d["fc"], feats=col, dec=cdec, certainty=cert)
+    g = {n: torch.zeros_like(t) for n, t in (("geo", geo), ("col", col), ("gdec", gdec), ("cdec", cdec))}
+    m = {n: torch.zeros_like(t) for n, t in g.items()}
+    v = {n: torch.zeros_like(t) for n, t in g.items()}
+    params = {"geo": geo, "col": col, "gdec": gdec, "cdec": cdec}
+    bs = d["map_coord0"].shape[0]
+    buf = ops.TrainBuffers(bs, int(d["map_dec"]), k, 64, 1)
+    for it in range(2):
+        lab, w = U.dev(d[f"map_label{it}"]), U.dev(d[f"map_w{it}"])
+        ops.train_step(d["st"], fs, buf, U.dev(d[f"map_coord{it}"]), lab, w, U.dev(d[f"map_ts{it}"], torch.int32), cert, tsu,
+                       g["geo"], g["gdec"], sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"])
+        ops.train_color_step(fc, buf, lab, U.dev(d[f"map_color{it}"]), w, g["col"], g["cdec"],
+                             surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"])
+        for name, key in (("geo", "gfeat"), ("col", "cfeat"), ("gdec", "gdec"), ("cdec", "cdec")):
+            ref = d[f"map_{key}{it}"]
+            assert np.max(np.abs(g[name].cpu().numpy() - ref)) < 4e-4 * np.abs(ref).max(), (name, it)
+        for name in params:
+            ops.adam_step(params[name], g[name], m[name], v[name], it + 1, d["map_lr"], eps=d["map_adam_eps"])
+    for name, key in (("geo", "map_geo_after"), ("col", "map_color_after"), ("gdec", "map_gdec_after"), ("cdec", "map_cdec_after")):
+        diff = np.abs(params[name].cpu().numpy() - d[key])
+        assert np.mean(diff < 1e-4) > 0.99, name
