@@ -36,6 +36,8 @@ class PinConfig:
         self.mlp_leaky_relu = False
         self.geo_mlp_level = 1
         self.geo_mlp_hidden_dim = 64
+        self.color_mlp_level = 1
+        self.color_mlp_hidden_dim = 64
         self.use_gaussian_pe = False
         self.pos_encoding_band = 0
         self.pos_input_dim = 3
@@ -51,6 +53,7 @@ class PinConfig:
         self.ekional_loss_on = True
         self.ekional_add_to = "all"
         self.weight_e = 0.5
+        self.weight_i = 1.0
         self.proj_correction_on = False
         self.consistency_loss_on = False
         self.iters = 12
@@ -65,6 +68,8 @@ class PinConfig:
         self.wandb_vis_on = False
         # tracking (config.py:209-236)
         self.photometric_loss_on = False
+        self.photometric_loss_weight = 0.01
+        self.consist_wieght_on = True  # (sic) config.py:215
         self.reg_min_grad_norm = 0.5
         self.reg_max_grad_norm = 2.0
         self.max_sdf_ratio = 5.0

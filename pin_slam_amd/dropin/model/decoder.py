@@ -67,11 +67,12 @@ class Decoder(nn.Module):
 
     def _field(self):
         return ops.FieldState(feats=self.flat_params(), dec=self.flat_params(), k=1, hidden=self.hidden_dim,
-                              levels=self.hidden_level, weighted_first=True, sdf_scale=self.sdf_scale)
+                              levels=self.hidden_level, weighted_first=True, sdf_scale=self.sdf_scale,
+                              out_dim=self.out_dim)
 
     def mlp(self, features):
         if self.out_dim != 1:
-            raise NotImplementedError("colour / semantic heads (out_dim > 1) are not built yet (C5 scope)")
+            raise NotImplementedError("raw multi-head outputs are only reachable through regress_color (3 heads)")
         shape = features.shape[:-1]
         f = features.detach().reshape(-1, 11).to(torch.float32).contiguous()
         fs = self._field()
@@ -85,7 +86,12 @@ class Decoder(nn.Module):
         return torch.sigmoid(self.sdf(features) / -self.sdf_scale)
 
     def regress_color(self, features):
-        raise NotImplementedError("colour decoder head is not built yet (C5 scope)")
+        """sigmoid(mlp(features)) with 3 heads (decoder.py:112-114); [..., 11] -> [..., 3]."""
+        if self.out_dim != 3:
+            raise NotImplementedError("libpinhip colour decoders have 3 heads (color_channel = 3)")
+        shape = features.shape[:-1]
+        f = features.detach().reshape(-1, 11).to(torch.float32).contiguous()
+        return ops.decoder_color(self._field(), f).reshape(*shape, 3)
 
     def sem_label_prob(self, features):
         raise NotImplementedError("semantic decoder head is out of the benchmark scope")

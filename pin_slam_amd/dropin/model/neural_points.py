@@ -208,7 +208,7 @@ class NeuralPoints(nn.Module):
             levels=decoder.hidden_level, weighted_first=self.config.weighted_first, sdf_scale=decoder.sdf_scale,
             certainty=l["cert"][:self._m if query_locally else self._n],
             orient=(l["orient"][:self._m if query_locally else self._n] if self.after_pgo else None),
-            pos=l["pos"][:self._m if query_locally else self._n])
+            pos=l["pos"][:self._m if query_locally else self._n], out_dim=int(getattr(decoder, "out_dim", 1)))
 
     # ------------------------------------------------------------------ K8: update
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):

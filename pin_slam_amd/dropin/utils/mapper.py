@@ -57,6 +57,7 @@ class _StandaloneBase:
         self.coord_pool = torch.empty((0, 3), device=d, dtype=f)
         self.global_coord_pool = torch.empty((0, 3), device=d, dtype=f)
         self.sdf_label_pool = torch.empty((0,), device=d, dtype=f)
+        self.color_pool = torch.empty((0, self.config.color_channel), device=d, dtype=f) if self.config.color_on else None
         self.weight_pool = torch.empty((0,), device=d, dtype=f)
         self.time_pool = torch.empty((0,), device=d, dtype=torch.int)
         self.pool_sample_count = 0
@@ -68,7 +69,8 @@ class _StandaloneBase:
         """Uniform pool sampling (mapper.py:477-503; the 'new sample' half needs process_frame)."""
         index = torch.randint(0, self.pool_sample_count, (self.config.bs,), device=self.device)
         coord = (self.global_coord_pool if global_coord else self.coord_pool)[index, :]
-        return coord, self.sdf_label_pool[index], self.time_pool[index], None, None, None, self.weight_pool[index]
+        color = self.color_pool[index] if self.color_pool is not None else None
+        return coord, self.sdf_label_pool[index], self.time_pool[index], None, None, color, self.weight_pool[index]
 
 
 _Base = _reference_mapper_base() or _StandaloneBase
@@ -84,7 +86,7 @@ class Mapper(_Base):
         c = self.config
         bad = []
         if getattr(c, "semantic_on", False): bad.append("semantic_on")
-        if getattr(c, "color_on", False): bad.append("color_on (C5)")
+        if getattr(c, "color_on", False) and c.color_channel != 3: bad.append("color_channel != 3")
         if c.main_loss_type != "bce": bad.append("main_loss_type != bce")
         if c.proj_correction_on or c.consistency_loss_on: bad.append("proj_correction / consistency loss")
         if c.ekional_loss_on and not c.numerical_grad: bad.append("analytic Eikonal (numerical_grad=False)")
@@ -111,6 +113,12 @@ class Mapper(_Base):
                                   loss_weight_on=c.loss_weight_on, eikonal=eik)
             self._trainer = t
         t.st, t.fs, t.ts_update, t.train_decoder = st, fs, npts.local_point_ts_update, train_dec
+        if c.color_on and c.weight_i > 0:  # colour branch (mapper.py:668-671, 802-812)
+            fc = npts.field_state(self.color_mlp, query_locally=True, color=True)
+            t.set_color(fc, surface_range=c.surface_sample_range_m, weight_i=c.weight_i,
+                        train_decoder=bool(self.color_mlp.lout.weight.requires_grad))
+        else:
+            t.set_color(None)
         b = npts._bricks
         tf = bool(npts.temporal_local_map_on and npts.travel_dist is not None)
         t.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
@@ -123,9 +131,12 @@ class Mapper(_Base):
         t = self._get_trainer()
         t.reset_optimizer()  # a new Adam per call (mapper.py:615)
         for it in range(iter_count):
-            coord, sdf_label, ts, _, _, _, weight = self.get_batch(global_coord=not self.ba_done_flag)
+            coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
+            if t.fc is not None and color_label is None:
+                raise RuntimeError("color_on but the data pool holds no colour labels")
             t.step_batch(coord.to(torch.float32).contiguous(), sdf_label.to(torch.float32).contiguous(),
-                         weight.to(torch.float32).contiguous(), ts.to(torch.int32).contiguous(), it + 1)
+                         weight.to(torch.float32).contiguous(), ts.to(torch.int32).contiguous(), it + 1,
+                         color_label=None if t.fc is None else color_label[:, :3].to(torch.float32).contiguous())
             self.total_iter += 1
         self.neural_points.assign_local_to_global()
 

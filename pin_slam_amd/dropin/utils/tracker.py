@@ -55,8 +55,24 @@ class Tracker:
     def _unsupported(self, colors, normals):
         if normals is not None:
             raise NotImplementedError("normal-consistency weight (tracker.py:482-488) is not built")
-        if colors is not None and self.config.color_on:
-            raise NotImplementedError("colour / photometric registration (tracker.py:493-542) is C5 scope")
+        if colors is not None and self.config.color_on and self.config.color_channel != 3:
+            raise NotImplementedError("libpinhip colour decoders have 3 heads (color_channel = 3)")
+
+    def _color_field(self, query_locally):
+        return self.neural_points.field_state(self.color_mlp, query_locally=query_locally, color=True)
+
+    def _color_term(self, colors):
+        """Colour term of registration_step (tracker.py:385-386, 492-518): photometric residual
+        rows, or exp(-|dI|) consistency weights, on the intensity of the RGB prediction."""
+        c = self.config
+        if colors is None or not c.color_on:
+            return None, None
+        photo = bool(c.photometric_loss_on)
+        if not photo and not c.consist_wieght_on:
+            return None, None
+        col = colors.detach()[:, :3].to(torch.float32).contiguous()
+        return ops.color_term(self._color_field(self.reg_local_map), col, photometric=photo,
+                              photo_weight=c.photometric_loss_weight, consist_weight=bool(c.consist_wieght_on))
 
     # ------------------------------------------------------------------ API
     def tracking(self, source_points, init_pose=None, source_colors=None, source_normals=None,
@@ -78,9 +94,11 @@ class Tracker:
         tf = bool(self.neural_points.temporal_local_map_on and self.reg_local_map
                   and self.neural_points.travel_dist is not None)
         # the whole GN loop runs on the device (tracker.py:114-184); one read-back
+        ct, _keep = self._color_term(source_colors)
         T, cnt, res_cm, iters, valid_flag, extra = gn.track(
             src, T, iter_n, term_deg=c.reg_term_thre_deg, term_m=c.reg_term_thre_m, early_exit=True,
-            min_valid_ratio=0.15 if loop_reg else 0.2, time_filtering=tf, local=self.reg_local_map, labels=labels)
+            min_valid_ratio=0.15 if loop_reg else 0.2, time_filtering=tf, local=self.reg_local_map, labels=labels,
+            color=ct)
         i = iters - 1
         converged = extra["converged"]
         if res_cm > max_valid_final:
@@ -100,15 +118,29 @@ class Tracker:
     def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, query_color=False,
                             query_color_grad=False, query_sem=False, query_mask=True, query_certainty=True,
                             query_locally=True, mask_min_nn_count: int = 4):
-        if query_color or query_color_grad or query_sem:
-            raise NotImplementedError("colour / semantic queries are C5 scope")
+        if query_sem:
+            raise NotImplementedError("semantic queries are out of the hot-path scope")
+        if (query_color or query_color_grad) and self.config.color_channel != 3:
+            raise NotImplementedError("libpinhip colour decoders have 3 heads (color_channel = 3)")
         npts = self.neural_points
         q = coord.detach().to(torch.float32).contiguous()
         nbr, nn, _ = npts.knn(q, query_locally)
-        fs = npts.field_state(self.sdf_mlp, query_locally=query_locally)
-        sdf, grad, std, cert = ops.sdf_query(fs, q, nbr, nn, grad=query_sdf_grad)
+        sdf = grad = std = cert = None
+        if query_sdf or query_sdf_grad or query_certainty:
+            fs = npts.field_state(self.sdf_mlp, query_locally=query_locally)
+            sdf, grad, std, cert = ops.sdf_query(fs, q, nbr, nn, grad=query_sdf_grad)
+        color = color_grad = None
+        if query_color:
+            fc = self._color_field(query_locally)
+            if query_color_grad:  # d colour_c / d x for each channel (tracker.py:346-349)
+                color_grad = torch.empty((q.shape[0], 3, 3), dtype=torch.float32, device=q.device)
+                for ch in range(3):
+                    color, _, g = ops.color_query(fc, q, nbr, nn, kappa=[float(ch == j) for j in range(3)])
+                    color_grad[:, ch, :] = g
+            else:
+                color, _, _ = ops.color_query(fc, q, nbr, nn, want_grad=False)
         mask = (nn >= mask_min_nn_count) if query_mask else None
-        return sdf, grad, None, None, None, mask, (cert if query_certainty else None), std
+        return sdf, grad, color, color_grad, None, mask, (cert if query_certainty else None), std
 
     def registration_step(self, points, normals, sdf_labels, colors, min_grad_norm, max_grad_norm, GM_dist=None,
                           GM_grad=None, lm_lambda=0.0, vis_weight_pc=False):
@@ -119,13 +151,17 @@ class Tracker:
         tf = bool(self.neural_points.temporal_local_map_on and self.reg_local_map
                   and self.neural_points.travel_dist is not None)
         labels = None if sdf_labels is None else sdf_labels.detach().to(torch.float32).contiguous()
-        dT, cnt, res_cm, extra = gn.step(pts, None, time_filtering=tf, local=self.reg_local_map, labels=labels)
+        ct, _keep = self._color_term(colors)
+        dT, cnt, res_cm, extra = gn.step(pts, None, time_filtering=tf, local=self.reg_local_map, labels=labels, color=ct)
         T = torch.tensor(dT, dtype=torch.float64, device=self.device)
         if cnt < 10:
             return T, None, None, None, pts[:0], 0.0, 0.0
+        photo_res = None
+        if ct is not None and ct.mode == 2 and extra is not None:  # mean |I_pred - I_meas| (tracker.py:523-525)
+            photo_res = extra.get("photo_residual")
         cov = eig = None
         if vis_weight_pc and extra is not None:
             eig = torch.tensor(np.linalg.eigvals(extra["N_raw"][3:, 3:]).real)
             cov = torch.tensor(np.linalg.inv(extra["N_raw"]) * extra["mse"])
         valid_points = pts[:cnt]  # callers only use the COUNT of valid points (tracker.py:161)
-        return T, cov, eig, None, valid_points, res_cm, None
+        return T, cov, eig, None, valid_points, res_cm, photo_res

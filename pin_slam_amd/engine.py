@@ -143,18 +143,43 @@ class MapTrainer:
         self.n_eik_global = n_eik_global(self.bs, self.dec) if eikonal else 0
         self.total_iter = 0
         self.bricks = None
+        self.fc = None  # colour field (set_color)
+
+    def set_color(self, fc: Optional[ops.FieldState], surface_range: float = 0.0, weight_i: float = 0.0,
+                  train_decoder: bool = True):
+        """Enable the colour branch of Mapper.mapping (mapper.py:668-671, 802-812): a second
+        decoder with 3 sigmoid heads over the colour feature table, L1 loss on the surface
+        samples, reusing the neighbour records / IDW weights of the geometry pass."""
+        if fc is None:
+            self.fc = None
+            return
+        if self.world > 1:
+            raise NotImplementedError("colour training is single-GPU for now (the geometry all-reduce buffer excludes it)")
+        nf, nd = fc.feats.numel(), fc.dec.numel()
+        if self.fc is None or self.cgrad.numel() != nf + nd:
+            self.cgrad = torch.zeros((nd + nf,), dtype=torch.float32, device=fc.feats.device)
+            self.cm, self.cv = torch.zeros_like(self.cgrad), torch.zeros_like(self.cgrad)
+        self.fc, self.c_range, self.c_weight, self.c_train_dec = fc, float(surface_range), float(weight_i), train_decoder
 
     def iteration(self, index_local: torch.Tensor, step: int):
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
         self.step_batch(self.coord, self.label, self.weight, self.ts, step)
 
-    def step_batch(self, coord, label, weight, ts, step: int):
+    def step_batch(self, coord, label, weight, ts, step: int, color_label=None):
         """One iteration on an explicit (already gathered) batch shard."""
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
                        bricks=self.bricks)
+        if self.fc is not None:
+            cnd = self.fc.dec.numel()
+            ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
+                                 self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
+                                 weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
+            ops.adam_step(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, self.lr, eps=self.adam_eps)
+            if self.c_train_dec:
+                ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad if self.train_decoder else self.gfeat)
@@ -169,6 +194,10 @@ class MapTrainer:
         self.m.zero_()
         self.v.zero_()
         self.grad.zero_()
+        if self.fc is not None:
+            self.cm.zero_()
+            self.cv.zero_()
+            self.cgrad.zero_()
 
     def mapping(self, index_batches):
         """One Mapper.mapping call: a fresh Adam state (mapper.py:615) and len(index_batches)

@@ -155,3 +155,67 @@ def test_mini_slam_loop_update_map_track():
     T = T.cpu().numpy()
     assert abs(T[2, 3] - T_true[2, 3]) < 0.01, T  # z is observable on the (near horizontal) sheets
     assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 0.01
+
+
+def test_mini_slam_loop_with_colour():
+    """colour_on through the drop-in classes: Mapper.mapping trains the colour field next to the
+    SDF (mapper.py:668-671, 802-812), Tracker.query_source_points returns colour + per-channel
+    gradients (tracker.py:342-350) and Tracker.tracking runs with the photometric term
+    (tracker.py:493-542)."""
+    from pin_slam_amd import synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    from pin_slam_amd.dropin.utils.tracker import Tracker
+    torch.manual_seed(0)
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=4096, local_map_radius=40.0, local_map_travel_dist_ratio=5.0,
+               reg_iter_n=30, color_on=True, color_channel=3, photometric_loss_on=True, feature_std=0.01)
+    rng = np.random.default_rng(0)
+    pts, _ = synth.disc_points(rng, 120_000, 25.0, 2)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.zeros(1, device="cuda")
+    npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+    assert npts.local_color_features.shape == (npts.local_count() + 1, 8)
+    decoders = {"sdf": Decoder(cfg, 64, 1, 1), "semantic": None, "color": Decoder(cfg, 64, 1, 3)}
+    mp = Mapper(cfg, _FakeDataset(), npts, decoders)
+
+    def paint(p):  # smooth RGB texture over the sheets
+        x, y = p[:, 0], p[:, 1]
+        return np.stack([0.5 + 0.4 * np.sin(0.7 * x), 0.5 + 0.4 * np.cos(0.5 * y), 0.5 + 0.3 * np.sin(0.4 * (x + y))], 1).astype(np.float32)
+
+    base, _ = synth.disc_points(rng, 400_000, 24.0, 2)
+    nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
+    dd = 0.15 * rng.standard_normal(len(base))
+    mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
+    mp.coord_pool = mp.global_coord_pool
+    mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+    mp.color_pool = torch.from_numpy(paint(base)).cuda()
+    mp.weight_pool = torch.ones(len(base), device="cuda")
+    mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+    mp.pool_sample_count = len(base)
+    trk = Tracker(cfg, npts, decoders)
+    probe = torch.from_numpy(base[:20000]).cuda()
+    target = torch.from_numpy(paint(base[:20000])).cuda()
+    col0 = trk.query_source_points(probe, cfg.infer_bs, query_color=True)[2]
+    mp.mapping(300)
+    sdf, grad, col1, cgrad, _, mask, cert, std = trk.query_source_points(probe, cfg.infer_bs, query_color=True,
+                                                                         query_color_grad=True)
+    e0, e1 = (col0 - target).abs().mean().item(), (col1 - target).abs().mean().item()
+    assert e1 < 0.4 * e0 and e1 < 0.05, (e0, e1)
+    assert cgrad.shape == (20000, 3, 3) and torch.isfinite(cgrad[mask]).all()
+    assert torch.allclose(npts.color_features[:-1], npts.local_color_features.data[:-1])
+    # regress_color on the queried colour features == the fused colour query (tensor API vs kernel)
+    _, cfeat, w, nn, _ = npts.query_feature(probe, training_mode=False, query_geo_feature=False, query_color_feature=True)
+    np.testing.assert_allclose(decoders["color"].regress_color(cfeat).cpu().numpy(), col1.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    scan, _ = synth.disc_points(rng, 20_000, 20.0, 2)
+    T_true = np.eye(4)
+    T_true[:3, 3] = [0.06, -0.05, 0.04]
+    src = scan - T_true[:3, 3]
+    T, cov, _, valid = trk.tracking(torch.from_numpy(src.astype(np.float32)).cuda(),
+                                    torch.eye(4, dtype=torch.float64, device="cuda"),
+                                    source_colors=torch.from_numpy(paint(scan)).cuda())
+    assert valid
+    T = T.cpu().numpy()
+    assert abs(T[2, 3] - T_true[2, 3]) < 0.01, T
+    # the colour texture makes the in-plane translation observable as well
+    assert np.abs(T[:2, 3] - T_true[:2, 3]).max() < 0.03, T
