@@ -23,11 +23,38 @@
 
 #include <stdint.h>
 
+/* The sample pool of Mapper (utils/mapper.py:76-97: coord_pool, global_coord_pool,
+ * sdf_label_pool, weight_pool, time_pool, color_pool), capacity-managed by the caller; the
+ * pointers passed to pin_sample_rays are already advanced to the append position. */
+typedef struct pin_pool_arrays {
+    float* coord;         /* [n][3] sensor-frame sample positions */
+    float* global_coord;  /* [n][3] transform_torch(coord, pose of the frame) */
+    float* sdf_label;     /* [n]    projective signed distance (behind +, in front -) */
+    float* weight;        /* [n]    sample weight, negative = free-space sample */
+    int32_t* ts;          /* [n]    frame id */
+    float* color;         /* [n][color_channels] or NULL */
+    int32_t color_channels;
+    int32_t reserved;
+} pin_pool_arrays;
+
+/* DataSampler.sample configuration (utils/data_sampler.py:26-36, config.py:124-129,169-171).
+ * Values are the reference's python floats (double); the library casts them to float32 exactly
+ * where torch does. */
+typedef struct pin_sample_params {
+    int32_t surface_n, front_n, behind_n;   /* surface_sample_n, free_front_n, free_behind_n */
+    int32_t dist_weight_on, behind_dropoff_on;
+    int32_t frame_id;                       /* written to the time pool */
+    double surface_range;                   /* surface_sample_range_m */
+    double free_begin_ratio, free_end_dist; /* free_sample_begin_ratio, free_sample_end_dist_m */
+    double dist_weight_scale, max_range;
+    double pose[12];                        /* sensor pose rows [R|t] (cur_pose_torch[:3,:]) */
+} pin_sample_params;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 2
+#define PIN_ABI_VERSION 3
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -412,6 +439,57 @@ int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arrays* la, co
 /* NeuralPoints.assign_local_to_global (neural_points.py:515-526). */
 int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
                                int32_t n_local, void* stream);
+
+/* ---- Mapper.process_frame data path (utils/mapper.py:162-449) ------------------------------ */
+
+/* Bytes of workspace for the pool kernels on n elements (pin_new_sample_index needs n more). */
+int64_t pin_pool_workspace_bytes(int64_t n);
+
+/* K12: DataSampler.sample (utils/data_sampler.py:18-260) fused with the pool append and the
+ * sensor->world transform of Mapper.process_frame (utils/mapper.py:275-300).  points: n scan
+ * points in the sensor frame, rows of `row_stride` floats (xyz first); colors: pointer to the
+ * first colour channel of row 0 (same stride) or NULL.  rnd_surface [surface_n*n] ~ N(0,1),
+ * rnd_front [front_n*n], rnd_behind [behind_n*n] ~ U[0,1): the reference's torch.randn / rand
+ * draws in its order of generation (entry s*n + i belongs to ray i).  Writes n*A samples
+ * (A = 1 + surface_n + front_n + behind_n) ray-wise: sample j of ray i at i*A + j. */
+int pin_sample_rays(const pin_sample_params* p, const float* points, const float* colors, int32_t row_stride,
+                    int32_t n, const float* rnd_surface, const float* rnd_front, const float* rnd_behind,
+                    const pin_pool_arrays* out, void* stream);
+
+/* K13a: distance window of the pool filter (utils/mapper.py:303-310): mask[i] =
+ * ||global_coord[i] - origin||^2 < radius^2 evaluated in float64; count_out [1] = kept;
+ * true_index [n] (optional) = torch.nonzero(mask) for the random discard. */
+int pin_pool_window_mask(const float* global_coord, int32_t n, const double* origin, double radius,
+                         uint8_t* mask, int32_t* true_index, int32_t* count_out, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/* K13b: filter_mask[true_indices[discarded_index]] = False (utils/mapper.py:314-323);
+ * discard_index are the caller's torch.randint draws. */
+int pin_pool_discard(uint8_t* mask, const int32_t* true_index, const int64_t* discard_index,
+                     int32_t n_discard, void* stream);
+
+/* K13c: pool[filter_mask] for all pool arrays at once, order preserved, out of place
+ * (src -> dst).  counts_out [2] = {kept, kept among the last n_cur elements}
+ * (pool_sample_count, cur_sample_count of utils/mapper.py:338-346). */
+int pin_pool_compact(const pin_pool_arrays* src, const pin_pool_arrays* dst, const uint8_t* mask, int32_t n,
+                     int32_t n_cur, int32_t* counts_out, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
+/* K14: NeuralPoints.query_certainty (model/neural_points.py:1011-1033): max over the valid
+ * candidates (sp->cand_off, sp->max_valid_dist2; no time filter) of certainty[global index],
+ * 0 if none.  process_frame calls it with the own-cell neighbourhood (1 candidate). */
+int pin_query_certainty(const pin_search_params* sp, const float* certainty, const float* query, int32_t n,
+                        float* certainty_out, void* stream);
+
+/* K14b: new_idx = where(certainty < certainty_thre & |sdf_label| < label_thre) + offset
+ * (utils/mapper.py:405-416), ascending.  index_out [<= n] int64, count_out [1]. */
+int pin_new_sample_index(const float* certainty, const float* sdf_label, int32_t n, float certainty_thre,
+                         float label_thre, int64_t offset, int64_t* index_out, int32_t* count_out,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Row gather out[i] = src[index[i]] for pools pin_gather_batch does not cover (color_pool,
+ * utils/mapper.py:494-495). */
+int pin_gather_rows(const float* src, int32_t width, const int32_t* index, int32_t n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -419,6 +419,131 @@ def gen_update():
     return out
 
 
+class _RngSpy:
+    """Records every torch.randn / rand / randint result drawn while active (the reference draws
+    its sampling noise inside process_frame; the kernels take the same numbers as inputs)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        self._orig = {n: getattr(torch, n) for n in ("randn", "rand", "randint")}
+        for n, f in self._orig.items():
+            def wrap(*a, _f=f, _n=n, **k):
+                r = _f(*a, **k)
+                self.calls.append((_n, r.detach().clone()))
+                return r
+            setattr(torch, n, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(torch, n, f)
+
+
+def gen_process(color=False):
+    """(8) Mapper.process_frame data path (utils/mapper.py:162-449): DataSampler.sample, pool
+    append, distance window + random discard, query_certainty and the new-sample index, for four
+    frames of a moving sensor with a short Mapper.mapping in between (so certainties are real).
+    Config chosen so that every branch bites: window radius smaller than the travelled distance,
+    pool capacity exceeded from frame 2 on."""
+    m = R.load()
+    cfg = R.make_config(voxel_size_m=0.4, buffer_size=40009, local_map_radius=22.0, local_map_travel_dist_ratio=5.0,
+                        bs=1024, bs_new_sample=256, feature_std=0.05, track_on=True, pool_capacity=(14000 if color else 33000),
+                        pool_filter_freq=1, new_certainty_thre=1.0, surface_sample_range_m=0.25,
+                        free_sample_end_dist_m=1.0, max_range=20.0, behind_dropoff_on=bool(color),
+                        adaptive_iters=True, search_alpha=0.5, query_nn_k=6)
+    cfg.window_radius = 13.0
+    if color:
+        cfg.color_on, cfg.color_channel = True, 3
+    torch.manual_seed(7)
+    dec = m["Decoder"](cfg, 32, 1, 1)
+    cdec = m["Decoder"](cfg, 32, 1, 3) if color else None
+    npts = m["NeuralPoints"](cfg)
+    nfr = 3 if color else 4
+    ds = R.FakeDataset(n_frames=nfr)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": cdec})
+    gen = torch.Generator().manual_seed(11)
+    out = dict(n_frames=np.int64(nfr), buffer_size=np.int64(cfg.buffer_size), resolution=np.float64(cfg.voxel_size_m))
+    for k in ("surface_sample_range_m", "surface_sample_n", "free_front_n", "free_behind_n", "free_sample_begin_ratio",
+              "free_sample_end_dist_m", "dist_weight_on", "dist_weight_scale", "max_range", "behind_dropoff_on",
+              "window_radius", "pool_capacity", "new_certainty_thre", "map_surface_ratio", "bs_new_sample",
+              "new_sample_ratio_less", "new_sample_ratio_more", "new_sample_ratio_restart", "freeze_after_frame"):
+        out[k] = np.asarray(getattr(cfg, k))
+    travel = [0.0]
+    for ts in range(nfr):
+        a = 0.15 * ts
+        pose = np.eye(4)
+        pose[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        pose[:3, 3] = [6.0 * ts, 0.5 * ts, 0.1 * ts]
+        if ts:
+            travel.append(travel[-1] + float(np.linalg.norm(pose[:3, 3] - prev[:3, 3])))
+        prev = pose
+        ds.odom_poses[ts] = pose
+        ds.processed_frame = ts
+        npts.travel_dist = torch.tensor(travel + [0.0] * (nfr - len(travel)), dtype=torch.float32)
+        scan = sheet_points(gen, 1500 if color else 2500, 12.0)
+        if color:
+            scan = torch.cat([scan, color_of(scan)], 1)
+        pool_before = {k: t2n(getattr(mp, k)) for k in ("coord_pool", "global_coord_pool", "sdf_label_pool",
+                                                        "weight_pool", "time_pool")}
+        if color:
+            pool_before["color_pool"] = t2n(mp.color_pool)
+        spy_cert = {}
+        orig_qc = npts.query_certainty
+
+        def qc(points, _o=orig_qc, _s=spy_cert):
+            tab = npts.buffer_pt_index
+            slots = torch.nonzero(tab >= 0).flatten()
+            r = _o(points)
+            _s.update(qc_out=t2n(r), qc_table_slots=t2n(slots), qc_table_vals=t2n(tab[slots]),
+                      qc_positions=t2n(npts.neural_points), qc_certainties=t2n(npts.point_certainties))
+            return r
+
+        npts.query_certainty = qc
+        spy_s = {}
+        orig_sample = mp.sampler.sample
+
+        def sample(*a, _o=orig_sample, _s=spy_s):
+            r = _o(*a)
+            _s["out"] = r
+            return r
+
+        mp.sampler.sample = sample
+        pose_t = torch.tensor(pose, dtype=torch.float64)
+        with _RngSpy() as spy:
+            mp.process_frame(scan, None, pose_t, ts)
+        mp.sampler.sample, npts.query_certainty = orig_sample, orig_qc
+        names = [c[0] for c in spy.calls]
+        # draws: randn (surface), rand (front), rand (behind), randn (new point features: geo [, colour]), [randint discard]
+        assert names[:3] == ["randn", "rand", "rand"], names
+        f = f"f{ts}_"
+        out[f + "scan"] = t2n(scan)
+        out[f + "pose"] = pose
+        out[f + "rnd_surface"], out[f + "rnd_front"], out[f + "rnd_behind"] = (t2n(c[1]).reshape(-1) for c in spy.calls[:3])
+        disc = [c[1] for c in spy.calls if c[0] == "randint"]
+        out[f + "discard_index"] = t2n(disc[0]) if disc else np.zeros((0,), np.int64)
+        co, lab, _, _, col, w = spy_s["out"]
+        out[f + "s_coord"], out[f + "s_label"], out[f + "s_weight"] = t2n(co), t2n(lab), t2n(w)
+        if color:
+            out[f + "s_color"] = t2n(col)
+        if ts == 0:
+            assert all(v.shape[0] == 0 for v in pool_before.values())  # frame t starts from frame t-1's "after" pools
+        for k in pool_before:
+            out[f + "after_" + k] = t2n(getattr(mp, k))
+        out[f + "cur_sample_count"] = np.int64(mp.cur_sample_count)
+        out[f + "pool_sample_count"] = np.int64(mp.pool_sample_count)
+        out[f + "new_idx"] = t2n(mp.new_idx)
+        out[f + "adaptive_iter_offset"] = np.int64(mp.adaptive_iter_offset)
+        out[f + "count"] = np.int64(npts.count())
+        for k, v in spy_cert.items():
+            out[f + k] = v
+        mp.mapping(6)  # accumulates certainties in the cells the batch touches
+    out["travel_dist"] = np.asarray(travel, np.float32)
+    return out
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -435,6 +560,15 @@ def main():
         path = os.path.join(OUT, "replica_color.npz")
         np.savez_compressed(path, **d)
         print("replica_color ->", path, f"{os.path.getsize(path)/1e6:.2f} MB")
+    for name, col in (("process", False), ("process_color", True)):
+        if only in (None, name):
+            d = gen_process(color=col)
+            path = os.path.join(OUT, f"{name}.npz")
+            np.savez_compressed(path, **d)
+            print(name, "->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "pool", [int(d[f"f{t}_pool_sample_count"]) for t in range(int(d["n_frames"]))],
+                  "new", [len(d[f"f{t}_new_idx"]) for t in range(int(d["n_frames"]))],
+                  "discard", [len(d[f"f{t}_discard_index"]) for t in range(int(d["n_frames"]))],
+                  "adaptive", [int(d[f"f{t}_adaptive_iter_offset"]) for t in range(int(d["n_frames"]))])
     if only not in (None, "update"):
         return
     d = gen_update()

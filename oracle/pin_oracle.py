@@ -663,3 +663,109 @@ def local_map_mask(positions, ts_used, sensor_position, radius, travel_dist=None
     g2l[:P][mask] = np.arange(int(mask.sum()))
     g2l[P] = -1
     return mask, g2l
+
+
+# --------------------------------------------------------------------------- K12-K14: process_frame data path
+def sample_rays(points, colors, rnd_surface, rnd_front, rnd_behind, *, surface_range, surface_n, front_n, behind_n,
+                free_begin_ratio, free_end_dist, dist_weight_on=True, dist_weight_scale=0.8, max_range=60.0,
+                behind_dropoff_on=False):
+    """DataSampler.sample (utils/data_sampler.py:18-260) with the three random draws as inputs
+    (randn [N*surface_n], rand [N*front_n], rand [N*behind_n], in the reference's order of
+    generation).  float32 throughout, operation order of the reference.
+    Returns (coord [N*A,3], sdf_label [N*A], color [N*A,C] or None, weight [N*A]) in the
+    reference's ray-wise order (sample j of ray i at i*A + j; j = measured, surface.., front.., behind..)."""
+    p = np.asarray(points, F32)
+    N = p.shape[0]
+    A = surface_n + front_n + behind_n + 1
+    # torch.linalg.norm on CPU accumulates with fused multiply-adds: fma(z,z, fma(y,y, x*x))
+    x, y, z = (p[:, i].astype(np.float64) for i in range(3))
+    acc = (x * x).astype(F32).astype(np.float64)
+    acc = (y * y + acc).astype(F32).astype(np.float64)
+    acc = (z * z + acc).astype(F32)
+    dist = np.sqrt(acc).astype(F32)[:, None]
+    sr = F32(surface_range)
+    half = F32(2.0 * surface_range)  # sigma_ratio * surface_sample_range (python float, then cast)
+    disp_s = (np.asarray(rnd_surface, F32).reshape(-1, 1) * sr).astype(F32)
+    rep = np.tile(dist, (surface_n, 1))
+    ratio_s = (disp_s / rep + F32(1.0)).astype(F32)
+    rep = np.tile(dist, (front_n, 1))
+    fmax = (F32(1.0) - half / rep).astype(F32)
+    fdiff = (fmax - F32(free_begin_ratio)).astype(F32)
+    ratio_f = (np.asarray(rnd_front, F32).reshape(-1, 1) * fdiff + F32(free_begin_ratio)).astype(F32)
+    disp_f = ((ratio_f - F32(1.0)) * rep).astype(F32)
+    rep = np.tile(dist, (behind_n, 1))
+    bmax = (F32(free_end_dist) / rep + F32(1.0)).astype(F32)
+    bmin = (F32(1.0) + half / rep).astype(F32)
+    bdiff = (bmax - bmin).astype(F32)
+    ratio_b = (np.asarray(rnd_behind, F32).reshape(-1, 1) * bdiff + bmin).astype(F32)
+    disp_b = ((ratio_b - F32(1.0)) * rep).astype(F32)
+    disp = np.concatenate([np.zeros_like(dist), disp_s, disp_f, disp_b], 0)
+    ratio = np.concatenate([np.ones_like(dist), ratio_s, ratio_f, ratio_b], 0)
+    rep_d = np.tile(dist, (A, 1))
+    pts = (np.tile(p, (A, 1)) * ratio).astype(F32)
+    w = np.ones_like(rep_d)
+    ns = N * (surface_n + 1)
+    if dist_weight_on:
+        w[:ns] = (F32(1 + dist_weight_scale * 0.5) - (rep_d[:ns] / F32(max_range)) * F32(dist_weight_scale)).astype(F32)
+    if behind_dropoff_on:
+        dmin, dmax = 0.2 * free_end_dist, free_end_dist
+        dw = ((F32(dmax) - disp) / F32(dmax - dmin)).astype(F32)
+        dw = np.clip(dw, F32(0.0), F32(1.0))
+        dw = (dw * F32(0.8) + F32(0.2)).astype(F32)
+        w = (w * dw).astype(F32)
+    w[ns:] *= F32(-1.0)
+    coord = pts.reshape(A, N, 3).transpose(1, 0, 2).reshape(-1, 3)
+    label = (-disp[:, 0]).reshape(A, N).T.reshape(-1)
+    weight = w[:, 0].reshape(A, N).T.reshape(-1)
+    color = None
+    if colors is not None:
+        c = np.asarray(colors, F32)
+        C = c.shape[1]
+        call = np.concatenate([np.tile(c, (surface_n + 1, 1)), np.zeros((N * (front_n + behind_n), C), F32)], 0)
+        color = call.reshape(A, N, C).transpose(1, 0, 2).reshape(-1, C)
+    return np.ascontiguousarray(coord), np.ascontiguousarray(label), color, np.ascontiguousarray(weight)
+
+
+def pool_filter_mask(global_coord, origin, window_radius, pool_capacity=None, discard_index=None):
+    """Distance window + random discard of Mapper.process_frame (utils/mapper.py:303-323).  The
+    subtraction promotes to float64 (float32 pool - float64 pose column).  `discard_index` are
+    the reference's torch.randint draws (indices into the kept list); they are only applied
+    when more than pool_capacity samples survive the window."""
+    rel = np.asarray(global_coord, F32).astype(np.float64) - np.asarray(origin, np.float64)[None, :]
+    d2 = (rel[:, 0] ** 2 + rel[:, 1] ** 2) + rel[:, 2] ** 2
+    mask = d2 < float(window_radius) ** 2
+    kept = np.nonzero(mask)[0]
+    if pool_capacity is not None and len(kept) > pool_capacity:
+        assert discard_index is not None and len(discard_index) == len(kept) - pool_capacity
+        mask[kept[np.asarray(discard_index, np.int64)]] = False
+    return mask
+
+
+def query_certainty(points, table, positions, certainties, resolution):
+    """NeuralPoints.query_certainty (neural_points.py:1011-1033) under the search neighbourhood
+    process_frame sets for it (num_nei_cells=1, search_alpha=0: the query's own cell only,
+    mapper.py:385-387): max over candidates of the (global) certainty, 0 where invalid."""
+    dx, mv = search_neighborhood(1, 0.0, resolution)
+    _, idx = radius_search(points, table, positions, resolution, dx, mv)
+    cert = np.asarray(certainties, F32)[idx]
+    cert = np.where(idx < 0, F32(0.0), cert)
+    return cert.max(axis=-1).astype(F32)
+
+
+def new_sample_index(certainty, sdf_label, new_certainty_thre, surface_range, offset=0):
+    """mapper.py:405-416: close-to-surface samples of the current frame in not-yet-certain cells."""
+    sel = (np.asarray(certainty, F32) < F32(new_certainty_thre)) & (np.abs(np.asarray(sdf_label, F32)) < F32(surface_range * 3.0))
+    return np.nonzero(sel)[0].astype(np.int64) + int(offset)
+
+
+def adaptive_iter_offset(new_sample_count, cur_sample_count, frame_id, *, adaptive_iters, ratio_less=0.02,
+                         ratio_more=0.15, ratio_restart=0.3, freeze_after_frame=40):
+    """mapper.py:424-439."""
+    if not adaptive_iters:
+        return 0
+    r = new_sample_count / cur_sample_count
+    if r < ratio_less:
+        return -5
+    if r > ratio_more:
+        return 10 if (frame_id > freeze_after_frame and r > ratio_restart) else 5
+    return 0

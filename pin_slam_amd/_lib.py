@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 64
-PIN_ABI_VERSION = 2
+PIN_ABI_VERSION = 3
 
 vp = C.c_void_p
 
@@ -107,7 +107,21 @@ class TrainColorParams(C.Structure):
                 ("weight_i", C.c_float)]
 
 
-i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+class PoolArrays(C.Structure):
+    _fields_ = [("coord", vp), ("global_coord", vp), ("sdf_label", vp), ("weight", vp), ("ts", vp), ("color", vp),
+                ("color_channels", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [
+        ("surface_n", C.c_int32), ("front_n", C.c_int32), ("behind_n", C.c_int32), ("dist_weight_on", C.c_int32),
+        ("behind_dropoff_on", C.c_int32), ("frame_id", C.c_int32), ("surface_range", C.c_double),
+        ("free_begin_ratio", C.c_double), ("free_end_dist", C.c_double), ("dist_weight_scale", C.c_double),
+        ("max_range", C.c_double), ("pose", C.c_double * 12),
+    ]
+
+
+i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 P = C.POINTER
 
 # name -> (restype, argtypes).  Every symbol declared in include/pin_abi.h is listed here;
@@ -143,6 +157,14 @@ SIGNATURES = {
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_train_color_step": (i32, [P(Field), P(TrainColorParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
+    "pin_pool_workspace_bytes": (i64, [i64]),
+    "pin_sample_rays": (i32, [P(SampleParams), vp, vp, i32, i32, vp, vp, vp, P(PoolArrays), vp]),
+    "pin_pool_window_mask": (i32, [vp, i32, vp, f64, vp, vp, vp, vp, i64, vp]),
+    "pin_pool_discard": (i32, [vp, vp, vp, i32, vp]),
+    "pin_pool_compact": (i32, [P(PoolArrays), P(PoolArrays), vp, i32, i32, vp, vp, i64, vp]),
+    "pin_query_certainty": (i32, [P(SearchParams), vp, vp, i32, vp, vp]),
+    "pin_new_sample_index": (i32, [vp, vp, i32, f32, f32, i64, vp, vp, vp, i64, vp]),
+    "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
 }
 
 _lib = None

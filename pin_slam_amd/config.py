@@ -45,6 +45,30 @@ class PinConfig:
         self.sigma_sigmoid_m = 0.1
         self.logistic_gaussian_ratio = 0.55
         self.surface_sample_range_m = 0.25
+        # sampler / pool (config.py:124-136, 169-171)
+        self.surface_sample_n = 3
+        self.free_sample_begin_ratio = 0.3
+        self.free_sample_end_dist_m = 1.0
+        self.free_front_n = 2
+        self.free_behind_n = 1
+        self.dist_weight_on = True
+        self.dist_weight_scale = 0.8
+        self.behind_dropoff_on = False
+        self.window_radius = 50.0
+        self.pool_capacity = int(1e7)
+        self.new_certainty_thre = 1.0
+        self.pool_filter_freq = 10
+        self.from_sample_points = True
+        self.from_all_samples = False
+        self.map_surface_ratio = 0.5
+        self.prune_map_on = False
+        self.max_prune_certainty = 3.0
+        self.prune_freq_frame = 100
+        self.adaptive_iters = False
+        self.new_sample_ratio_less = 0.02
+        self.new_sample_ratio_more = 0.15
+        self.new_sample_ratio_restart = 0.3
+        self.freeze_after_frame = 40
         # mapping (config.py:160-199)
         self.loss_weight_on = False
         self.numerical_grad = True

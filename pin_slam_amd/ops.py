@@ -415,3 +415,43 @@ def color_query(fc: FieldState, query, nbr, nn, kappa=INTENSITY, want_color=True
     check(_lib.lib().pin_color_query(C.byref(f), _ptr(query, torch.float32), _ptr(nbr), _ptr(nn, torch.int32), n,
                                      kap.ctypes.data, _ptr(col), _ptr(val), _ptr(g), _stream()), "pin_color_query")
     return col, val, g
+
+
+# ------------------------------------------------------------------------------- process_frame data path
+def query_certainty(st: SearchState, certainty: torch.Tensor, points: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """NeuralPoints.query_certainty over the global map with the neighbourhood held by `st`."""
+    n = points.shape[0]
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=points.device)
+    sp = st.params(time_filtering=False, local=False)
+    check(_lib.lib().pin_query_certainty(C.byref(sp), _ptr(certainty, torch.float32), _ptr(points, torch.float32), n,
+                                         _ptr(out, torch.float32), _stream()), "pin_query_certainty")
+    return out
+
+
+def pool_workspace(n: int, device, extra: int = 0) -> torch.Tensor:
+    return torch.empty((_lib.lib().pin_pool_workspace_bytes(n) + extra,), dtype=torch.uint8, device=device)
+
+
+def new_sample_index(certainty, sdf_label, certainty_thre, label_thre, offset=0, ws=None):
+    """where(certainty < thre & |label| < label_thre) + offset -> (int64 index buffer [n], count tensor [1])."""
+    n = certainty.shape[0]
+    dev = certainty.device
+    idx = torch.empty((n,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    if ws is None or ws.numel() < _lib.lib().pin_pool_workspace_bytes(n) + n:
+        ws = pool_workspace(n, dev, extra=n)
+    check(_lib.lib().pin_new_sample_index(_ptr(certainty, torch.float32), _ptr(sdf_label, torch.float32), n,
+                                          float(certainty_thre), float(label_thre), int(offset), _ptr(idx), _ptr(cnt),
+                                          _ptr(ws), ws.numel(), _stream()), "pin_new_sample_index")
+    return idx, cnt
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """out[i] = src[index[i]] for a [n, width] float32 pool (color_pool gather of Mapper.get_batch)."""
+    width = src.shape[1]
+    if out is None:
+        out = torch.empty((index.numel(), width), dtype=torch.float32, device=src.device)
+    check(_lib.lib().pin_gather_rows(_ptr(src, torch.float32), width, _ptr(index, torch.int32), index.numel(), _ptr(out),
+                                     _stream()), "pin_gather_rows")
+    return out
