@@ -487,6 +487,19 @@ int pin_new_sample_index(const float* certainty, const float* sdf_label, int32_t
                          float label_thre, int64_t offset, int64_t* index_out, int32_t* count_out,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* update_points of process_frame (utils/mapper.py:236-246): rows[i] ([n][3]) of the samples with
+ * |sdf_label[i]| < label_thre (= surface_sample_range_m * map_surface_ratio), order preserved.
+ * out [<= n][3], count_out [1]. */
+int pin_select_surface_points(const float* rows, const float* sdf_label, int32_t n, float label_thre,
+                              float* out, int32_t* count_out, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+
+/* transform_torch (utils/tools.py:534-553): out[i] = R * points[i] + t in float32 with the pose
+ * rows [R|t] given as 12 doubles (cast to float32 like `transformation.to(points)`).  points
+ * rows have `row_stride` floats (xyz first); out [n][3]. */
+int pin_transform_points(const float* points, int32_t row_stride, int32_t n, const double* pose, float* out,
+                         void* stream);
+
 /* Row gather out[i] = src[index[i]] for pools pin_gather_batch does not cover (color_pool,
  * utils/mapper.py:494-495). */
 int pin_gather_rows(const float* src, int32_t width, const int32_t* index, int32_t n, float* out, void* stream);

@@ -609,8 +609,8 @@ def map_update(state, points, cur_ts, resolution, travel_dist=None, diff_travel_
     """NeuralPoints.update (neural_points.py:311-416) on a dict state with keys
     table [B] int64, positions [P,3], ts_create [P], ts_update [P].  Appends new points
     (features/certainties are initialised by the caller) and returns the added points.
-    Duplicate hash slots inside one call resolve 'last writer wins' in index order
-    (the reference's index_put_ is order-unspecified there; tests avoid relying on it)."""
+    Duplicate hash slots inside one call resolve 'last writer wins' in sample order, as the
+    CPU reference's sequential index_put_ does (neural_points.py:377)."""
     points = np.asarray(points, F32)
     sel = voxel_down_sample(points, resolution)
     sp = points[sel]

@@ -164,6 +164,8 @@ SIGNATURES = {
     "pin_pool_compact": (i32, [P(PoolArrays), P(PoolArrays), vp, i32, i32, vp, vp, i64, vp]),
     "pin_query_certainty": (i32, [P(SearchParams), vp, vp, i32, vp, vp]),
     "pin_new_sample_index": (i32, [vp, vp, i32, f32, f32, i64, vp, vp, vp, i64, vp]),
+    "pin_select_surface_points": (i32, [vp, vp, i32, f32, vp, vp, vp, i64, vp]),
+    "pin_transform_points": (i32, [vp, i32, i32, vp, vp, vp]),
     "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
 }
 

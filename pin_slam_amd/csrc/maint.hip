@@ -115,7 +115,7 @@ __global__ __launch_bounds__(MB) void vds_final_kernel(const unsigned long long*
 __global__ __launch_bounds__(MB) void update_probe_kernel(pin_map_arrays ma, pin_update_params up,
                                                           const float* __restrict__ pts, const int* __restrict__ sel,
                                                           const int* __restrict__ n_sel, unsigned char* __restrict__ flags,
-                                                          unsigned int* __restrict__ slots) {
+                                                          unsigned int* __restrict__ slots, int* __restrict__ held) {
     const int i = blockIdx.x * MB + threadIdx.x;
     const int n = *n_sel;
     if (i >= n) { if (i < up.n_max) flags[i] = 0; return; }
@@ -123,9 +123,10 @@ __global__ __launch_bounds__(MB) void update_probe_kernel(pin_map_arrays ma, pin
     const float x = pts[3 * s], y = pts[3 * s + 1], z = pts[3 * s + 2];
     const unsigned int slot = hash_base(x, y, z, up.resolution, up.buffer_size);
     slots[i] = slot;
+    const int h = ma.table[slot];
+    held[i] = h;  // cur_pt_idx = buffer_pt_index[hash] (neural_points.py:368)
     bool add = true;
     if (up.n_points > 0 && !up.all_new) {
-        const int h = ma.table[slot];
         if (h >= 0) {  // neural_points.py:341-356
             const float* P = ma.pos + 3 * (size_t)h;
             const float d2 = dist2_exact(P[0] - x, P[1] - y, P[2] - z);
@@ -137,20 +138,40 @@ __global__ __launch_bounds__(MB) void update_probe_kernel(pin_map_arrays ma, pin
     flags[i] = add ? 1 : 0;
 }
 
+// `buffer_pt_index[hash] = cur_pt_idx` (neural_points.py:377) assigns sample by sample on the CPU
+// reference: when several samples of one call share a slot, the LAST sample's value stays --
+// its new index if it was added, the entry it found otherwise.  Reproduced in two steps: every
+// sample claims its slot with atomicMin(-(i+2)) (the largest i wins), then the winner alone
+// publishes its value.
+__global__ __launch_bounds__(MB) void update_claim_kernel(pin_map_arrays ma, const int* __restrict__ n_sel,
+                                                          const unsigned int* __restrict__ slots) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i < *n_sel) atomicMin(ma.table + slots[i], -(i + 2));
+}
+
 __global__ __launch_bounds__(MB) void update_append_kernel(pin_map_arrays ma, pin_update_params up,
                                                            const float* __restrict__ pts, const int* __restrict__ sel,
                                                            const int* __restrict__ n_sel,
                                                            const unsigned char* __restrict__ flags,
                                                            const int* __restrict__ block_off,
-                                                           const unsigned int* __restrict__ slots) {
+                                                           const unsigned int* __restrict__ slots,
+                                                           const int* __restrict__ held) {
     const int i = blockIdx.x * MB + threadIdx.x;
     const int n = *n_sel;
     int total;
     const bool f = i < n && flags[i] != 0;
     const int ex = block_flag_scan(f, total);
-    if (!f) return;
+    if (i >= n) return;
+    const bool winner = ma.table[slots[i]] == -(i + 2);
+    if (!f) {
+        if (winner) ma.table[slots[i]] = held[i];
+        return;
+    }
     const int idx = up.n_points + block_off[blockIdx.x] + ex;
-    if (idx >= up.capacity) return;  // host checks the count against capacity
+    if (idx >= up.capacity) {  // host checks the count against capacity
+        if (winner) ma.table[slots[i]] = held[i];
+        return;
+    }
     const int s = sel[i];
     const float x = pts[3 * s], y = pts[3 * s + 1], z = pts[3 * s + 2];
     ma.pos[3 * (size_t)idx] = x; ma.pos[3 * (size_t)idx + 1] = y; ma.pos[3 * (size_t)idx + 2] = z;
@@ -159,9 +180,7 @@ __global__ __launch_bounds__(MB) void update_append_kernel(pin_map_arrays ma, pi
     ma.ts_create[idx] = up.cur_ts;
     ma.ts_update[idx] = up.cur_ts;
     ma.certainty[idx] = 0.f;
-    // duplicate slots inside one call: the highest index wins (= the reference's sequential
-    // CPU index_put_ for two added points; neural_points.py:377)
-    atomicMax(ma.table + slots[i], idx);
+    if (winner) ma.table[slots[i]] = idx;
 }
 
 // ---- K9: reset_local_map ------------------------------------------------------------------------
@@ -318,11 +337,14 @@ extern "C" int pin_map_update(const pin_map_arrays* ma, const pin_update_params*
     unsigned char* flags = c.take<unsigned char>(up->n_max + 1);
     unsigned int* slots = c.take<unsigned int>(up->n_max);
     int* block_off = c.take<int>(nb + 1);
-    PIN_CHECK_ARG(block_off != nullptr, "workspace carve failed");
-    hipLaunchKernelGGL(update_probe_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, slots);
+    int* held = c.take<int>(up->n_max);
+    PIN_CHECK_ARG(held != nullptr, "workspace carve failed");
+    hipLaunchKernelGGL(update_probe_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, slots, held);
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, up->n_max, block_off);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_new_out);
-    hipLaunchKernelGGL(update_append_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, block_off, slots);
+    hipLaunchKernelGGL(update_claim_kernel, dim3(nb), dim3(MB), 0, s, *ma, n_sel, slots);
+    hipLaunchKernelGGL(update_append_kernel, dim3(nb), dim3(MB), 0, s, *ma, *up, points, sel, n_sel, flags, block_off, slots,
+                       held);
     PIN_CHECK_LAUNCH();
     return 0;
 }

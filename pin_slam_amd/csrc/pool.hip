@@ -195,12 +195,47 @@ __global__ __launch_bounds__(MB) void new_sample_index_kernel(const unsigned cha
     if (f) idx_out[block_off[blockIdx.x] + ex] = offset + i;
 }
 
+// rows[|label| < thr] (update_points of process_frame, utils/mapper.py:236-246), order preserved
+__global__ __launch_bounds__(MB) void surface_flags_kernel(const float* __restrict__ label, int n, float thr,
+                                                           unsigned char* __restrict__ flags, int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && fabsf(label[i]) < thr;
+    if (i < n) flags[i] = f ? 1 : 0;
+    int total;
+    block_flag_scan(f, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(MB) void select_rows3_kernel(const float* __restrict__ rows, const unsigned char* __restrict__ flags,
+                                                          int n, const int* __restrict__ block_off, float* __restrict__ out) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    int total;
+    const int ex = block_flag_scan(f, total);
+    if (!f) return;
+    const size_t d = (size_t)(block_off[blockIdx.x] + ex), s = (size_t)i;
+    out[3 * d] = rows[3 * s]; out[3 * d + 1] = rows[3 * s + 1]; out[3 * d + 2] = rows[3 * s + 2];
+}
+
 __global__ __launch_bounds__(MB) void gather_rows_kernel(const float* __restrict__ src, int width, const int* __restrict__ index,
                                                          int n, float* __restrict__ out) {
     const long t = (long)blockIdx.x * MB + threadIdx.x;
     if (t >= (long)n * width) return;
     const int i = (int)(t / width), c = (int)(t - (long)i * width);
     out[t] = src[(size_t)index[i] * width + c];
+}
+
+// transform_torch (utils/tools.py:534-553): homogeneous point x float32(T)^T
+struct Pose12 { float m[12]; };
+__global__ __launch_bounds__(MB) void transform_points_kernel(const float* __restrict__ pts, int stride, int n, Pose12 T,
+                                                              float* __restrict__ out) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1], z = pts[(size_t)i * stride + 2];
+    const float* m = T.m;
+    out[3 * (size_t)i] = fmaf(z, m[2], fmaf(y, m[1], x * m[0])) + m[3];
+    out[3 * (size_t)i + 1] = fmaf(z, m[6], fmaf(y, m[5], x * m[4])) + m[7];
+    out[3 * (size_t)i + 2] = fmaf(z, m[10], fmaf(y, m[9], x * m[8])) + m[11];
 }
 
 static int check_pool(const pin_pool_arrays* p, const char* what) {
@@ -343,6 +378,40 @@ extern "C" int pin_new_sample_index(const float* certainty, const float* sdf_lab
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, count_out);
     hipLaunchKernelGGL(new_sample_index_kernel, dim3(nb), dim3(MB), 0, s, flags, n, block_cnt, (long long)offset,
                        reinterpret_cast<long long*>(index_out));
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_select_surface_points(const float* rows, const float* sdf_label, int32_t n, float label_thre,
+                                         float* out, int32_t* count_out, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && count_out, "n < 0 or NULL count");
+    hipStream_t s = as_stream(stream);
+    if (n == 0) { PIN_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int), s)); return 0; }
+    PIN_CHECK_ARG(rows && sdf_label && out && workspace, "NULL pointer");
+    PIN_CHECK_ARG(workspace_bytes >= pin_pool_workspace_bytes(n) + n, "workspace too small (pin_pool_workspace_bytes(n) + n)");
+    Carver cv{static_cast<char*>(workspace), static_cast<char*>(workspace) + workspace_bytes};
+    const int nb = cdiv(n, MB);
+    int* block_cnt = cv.take<int>(nb);
+    unsigned char* flags = cv.take<unsigned char>(n);
+    PIN_CHECK_ARG(flags != nullptr, "workspace too small");
+    hipLaunchKernelGGL(surface_flags_kernel, dim3(nb), dim3(MB), 0, s, sdf_label, n, label_thre, flags, block_cnt);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, count_out);
+    hipLaunchKernelGGL(select_rows3_kernel, dim3(nb), dim3(MB), 0, s, rows, flags, n, block_cnt, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_transform_points(const float* points, int32_t row_stride, int32_t n, const double* pose, float* out,
+                                    void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && row_stride >= 3, "n < 0 or row stride < 3");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(points && pose && out, "NULL pointer");
+    Pose12 T;
+    for (int i = 0; i < 12; ++i) T.m[i] = (float)pose[i];
+    hipLaunchKernelGGL(transform_points_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, as_stream(stream), points, row_stride, n, T, out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -190,9 +190,18 @@ class NeuralPoints(nn.Module):
             td = td.to(device=self.device, dtype=torch.float32)
         return td.contiguous()
 
-    def search_state(self) -> ops.SearchState:
-        return ops.SearchState(table=self._table, pos4=self._g["pos4"], cand_off=self._cand_off, n_points=self._n,
-                               resolution=self.resolution, max_valid_dist2=self.max_valid_dist2,
+    def search_state(self, own_cell: bool = False) -> ops.SearchState:
+        """Device search state; own_cell=True is the neighbourhood process_frame sets for
+        query_certainty (num_nei_cells=1, search_alpha=0: the query's own cell, mapper.py:385-387)
+        without touching the neighbourhood of the hot path."""
+        cand, mv = self._cand_off, self.max_valid_dist2
+        if own_cell:
+            if getattr(self, "_cand_own", None) is None:
+                dx, _ = ops.search_neighborhood(1, 0.0, self.resolution)
+                self._cand_own = torch.from_numpy(ops.candidate_offsets(dx, self.buffer_size)).to(self.device)
+            cand, mv = self._cand_own, 3 * (2 * self.resolution) ** 2
+        return ops.SearchState(table=self._table, pos4=self._g["pos4"], cand_off=cand, n_points=self._n,
+                               resolution=self.resolution, max_valid_dist2=mv,
                                travel_dist=self._travel(), cur_ts=self.cur_ts,
                                diff_travel_dist_local=self.diff_travel_dist_local, global2local=self._g2l)
 
@@ -353,10 +362,11 @@ class NeuralPoints(nn.Module):
         return geo, color, w.unsqueeze(-1), nn_i32.long(), certainty
 
     def query_certainty(self, query_points: torch.Tensor):
-        _, idx = self.radius_neighborhood_search(query_points)
-        cert = self.point_certainties[idx]  # tiny gather (Kc = 1 in the caller, mapper.py:388-396)
-        cert[idx < 0] = 0.0
-        return torch.max(cert, dim=-1)[0]
+        return self._query_certainty(query_points, own_cell=False)
+
+    def _query_certainty(self, query_points: torch.Tensor, own_cell: bool):
+        q = query_points.detach().to(torch.float32).contiguous()
+        return ops.query_certainty(self.search_state(own_cell=own_cell), self._g["cert"][:max(self._n, 1)], q)
 
     # ------------------------------------------------------------------ post-loop maintenance (next-tier rows)
     def _rebuild_mirror(self):

@@ -15,7 +15,10 @@ import sys
 
 import torch
 
+import numpy as np
+
 from ... import engine, ops
+from ... import pool as pool_mod
 
 
 def _reference_mapper_base():
@@ -65,6 +68,13 @@ class _StandaloneBase:
     def free_pool(self):
         self.coord_pool = self.weight_pool = self.sdf_label_pool = self.time_pool = None
 
+    def determine_used_pose(self):
+        """mapper.py:139-160."""
+        ds, c = self.dataset, self.config
+        cur = ds.processed_frame
+        src = ds.pgo_poses if c.pgo_on else (ds.odom_poses if c.track_on else ds.gt_poses)
+        self.used_poses = torch.tensor(np.asarray(src[:cur + 1]), device=self.device, dtype=torch.float64)
+
     def get_batch(self, global_coord=False):
         """Uniform pool sampling (mapper.py:477-503; the 'new sample' half needs process_frame)."""
         index = torch.randint(0, self.pool_sample_count, (self.config.bs,), device=self.device)
@@ -80,13 +90,171 @@ class Mapper(_Base):
     def __init__(self, config, dataset, neural_points, decoders: dict):
         super().__init__(config, dataset, neural_points, decoders)
         self._trainer = None
+        self._spool = None  # device-resident sample pool (pin_slam_amd.pool.SamplePool)
+        self.static_mask = None
+        self.cur_sample_count = 0
+        self.cur_new_point_ratio = 0.0
+
+    # ------------------------------------------------------------------ data pool
+    _POOL_ATTRS = (("coord_pool", "coord"), ("global_coord_pool", "global_coord"), ("sdf_label_pool", "sdf_label"),
+                   ("weight_pool", "weight"), ("time_pool", "ts"), ("color_pool", "color"))
+
+    def _pool(self) -> pool_mod.SamplePool:
+        c = self.config
+        C = int(c.color_channel) if c.color_on else 0
+        if self._spool is None or self._spool.C != C:
+            self._spool = pool_mod.SamplePool(self.device, color_channels=C)
+            self._spool.clear()
+        p = self._spool
+        # somebody replaced a pool tensor (init_pool, transform_data_pool, bundle adjustment, a test): adopt it
+        lab = getattr(self, "sdf_label_pool", None)
+        n_ext = 0 if lab is None else lab.shape[0]
+        stale = n_ext != p.n
+        if not stale and p.n:
+            for attr, name in self._POOL_ATTRS:
+                t, v = getattr(self, attr, None), p.view(name)
+                if v is not None and (t is None or t.data_ptr() != v.data_ptr()):
+                    stale = True
+        if stale:
+            if n_ext == 0:
+                p.clear()
+            else:
+                p.adopt(**{name: getattr(self, attr, None) for attr, name in self._POOL_ATTRS})
+        return p
+
+    def _publish_pool(self):
+        """The reference's pool attributes as views of the device pool (no copies)."""
+        p = self._spool
+        for attr, name in self._POOL_ATTRS:
+            setattr(self, attr, p.view(name))
+        self.sem_label_pool = self.normal_label_pool = None
+        self.pool_sample_count = p.n
+
+    def dynamic_filter(self, points_torch, type_2_on: bool = True):
+        """mapper.py:98-137 on the fused SDF query (SDF, analytic gradient, certainty in one launch)."""
+        c, npts = self.config, self.neural_points
+        q = points_torch.detach().to(torch.float32).contiguous()
+        nbr, nn, _ = npts.knn(q, True)
+        fs = npts.field_state(self.sdf_mlp, query_locally=True)
+        sdf, grad, _, cert = ops.sdf_query(fs, q, nbr, nn, grad=type_2_on, std=False)
+        static_mask = (cert < c.dynamic_certainty_thre) | (sdf < c.dynamic_sdf_ratio_thre * c.voxel_size_m)
+        if type_2_on:
+            static_mask &= (grad.norm(dim=-1) > c.dynamic_min_grad_norm_thre) | (cert < c.dynamic_certainty_thre)
+        return static_mask
+
+    def process_frame(self, point_cloud_torch, frame_label_torch, cur_pose_torch, frame_id: int,
+                      filter_dynamic: bool = False):
+        """Mapper.process_frame (mapper.py:162-449): sample the scan, grow the map, maintain the
+        sample pool, find the newly observed samples.  Device-resident: the sampler writes at the
+        pool tail, the filter compacts between the pool's two generations; host syncs = the
+        counts the reference reads back as well."""
+        c, npts = self.config, self.neural_points
+        if frame_label_torch is not None or getattr(c, "semantic_on", False):
+            raise NotImplementedError("semantic labels are outside the hot-path scope")
+        if self.ba_done_flag:
+            raise NotImplementedError("process_frame after bundle adjustment (pool re-projection with per-frame poses)")
+        if c.color_on and c.color_channel not in (1, 3):
+            raise NotImplementedError("colour pool with color_channel not in (1, 3)")
+        pose = cur_pose_torch.detach().to("cpu", torch.float64)
+        pose_np = pose.numpy()
+        origin, orientation = cur_pose_torch[:3, 3], cur_pose_torch[:3, :3]
+        scan = point_cloud_torch.detach()
+        if scan.dtype != torch.float32 or not scan.is_cuda or scan.stride(1) != 1:
+            scan = scan.to(device=self.device, dtype=torch.float32).contiguous()
+        n_scan = scan.shape[0]
+        self.static_mask = torch.ones(n_scan, dtype=torch.bool, device=self.device)
+        if filter_dynamic:
+            npts.reset_local_map(origin, orientation, frame_id)
+            glob = torch.empty((n_scan, 3), dtype=torch.float32, device=self.device)
+            ops.transform_points(scan, pose_np, glob)
+            self.static_mask = self.dynamic_filter(glob)
+            scan = scan[self.static_mask].contiguous()
+        self.dataset.static_mask = self.static_mask
+
+        # K12: DataSampler.sample + pool append + sensor->world transform
+        p = self._pool()
+        n_hist = p.n
+        n_new = p.append_samples(scan, pool_mod.sample_params(c, pose_np, frame_id))
+        self.cur_sample_count = n_new
+        self.pool_sample_count = n_hist
+
+        # map growth (mapper.py:236-262)
+        tail = slice(n_hist, n_hist + n_new)
+        lab_new = p.bufs[0]["sdf_label"][tail]
+        if c.from_sample_points:
+            if c.from_all_samples:  # the reference passes sensor-frame samples here (mapper.py:238)
+                update_points = p.bufs[0]["coord"][tail]
+            else:
+                sel, cnt = ops.select_surface_points(p.bufs[0]["global_coord"][tail], lab_new,
+                                                     np.float32(c.surface_sample_range_m * c.map_surface_ratio))
+                update_points = sel[:int(cnt.item())]
+        else:
+            update_points = torch.empty((scan.shape[0], 3), dtype=torch.float32, device=self.device)
+            ops.transform_points(scan, pose_np, update_points)
+        if c.prune_map_on and ((frame_id + 1) % c.prune_freq_frame == 0):
+            if npts.prune_map(c.max_prune_certainty):
+                npts.recreate_hash(None, None, True, True, frame_id)
+        self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
+        npts.record_memory(verbose=(not self.silence))
+        self.determine_used_pose()
+
+        # K13: pool window + capacity (mapper.py:303-360)
+        if (frame_id + 1) % c.pool_filter_freq == 0:
+            self.pool_sample_count, self.cur_sample_count = p.filter(pose_np[:3, 3], c.window_radius, int(c.pool_capacity))
+        else:
+            self.cur_sample_count, self.pool_sample_count = n_new, p.n
+        self._publish_pool()
+
+        # K14: newly observed close-to-surface samples (mapper.py:368-439)
+        if c.bs_new_sample > 0:
+            cur = self.cur_sample_count
+            first = self.pool_sample_count - cur
+            cert = npts._query_certainty(p.bufs[0]["global_coord"][first:first + cur], own_cell=True)
+            idx, cnt = ops.new_sample_index(cert, p.bufs[0]["sdf_label"][first:first + cur], c.new_certainty_thre,
+                                            np.float32(c.surface_sample_range_m * 3.0), offset=first)
+            new_count = int(cnt.item())
+            self.new_idx = idx[:new_count]
+            self.adaptive_iter_offset = 0
+            if c.adaptive_iters and cur > 0:
+                r = new_count / cur
+                if r < c.new_sample_ratio_less:
+                    self.adaptive_iter_offset = -5
+                elif r > c.new_sample_ratio_more:
+                    self.adaptive_iter_offset = 5
+                    if frame_id > c.freeze_after_frame and r > c.new_sample_ratio_restart:
+                        self.adaptive_iter_offset = 10
+
+    def get_batch(self, global_coord=False):
+        """Mapper.get_batch (mapper.py:452-503): the same torch.randint draws in the same order,
+        gathers by the pool kernels."""
+        c = self.config
+        p = self._pool()
+        n = self.pool_sample_count
+        new_idx = self.new_idx
+        ds = self.dataset
+        if (c.bs_new_sample > 0 and new_idx is not None and not getattr(ds, "lose_track", False)
+                and not getattr(ds, "stop_status", False) and new_idx.shape[0] > 0):
+            bs_new = min(new_idx.shape[0], c.bs_new_sample)
+            index_history = torch.randint(0, n, (c.bs - bs_new,), device=self.device)
+            index_new_batch = torch.randint(0, new_idx.shape[0], (bs_new,), device=self.device)
+            index = torch.cat((index_history, new_idx[index_new_batch]), dim=0)
+        else:
+            index = torch.randint(0, n, (c.bs,), device=self.device)
+        idx32 = index.to(torch.int32)
+        b = p.bufs[0]
+        dev = self.device
+        out = (torch.empty((c.bs, 3), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.float32, device=dev),
+               torch.empty((c.bs,), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.int32, device=dev))
+        ops.gather_batch(b["global_coord"] if global_coord else b["coord"], b["sdf_label"], b["weight"], b["ts"], idx32, out)
+        color = ops.gather_rows(b["color"], idx32) if p.C else None
+        return out[0], out[1], out[3], None, None, color, out[2]
 
     # ------------------------------------------------------------------ hot loop
     def _check_supported(self):
         c = self.config
         bad = []
         if getattr(c, "semantic_on", False): bad.append("semantic_on")
-        if getattr(c, "color_on", False) and c.color_channel != 3: bad.append("color_channel != 3")
+        if getattr(c, "color_on", False) and c.weight_i > 0 and c.color_channel != 3: bad.append("color_channel != 3")
         if c.main_loss_type != "bce": bad.append("main_loss_type != bce")
         if c.proj_correction_on or c.consistency_loss_on: bad.append("proj_correction / consistency loss")
         if c.ekional_loss_on and not c.numerical_grad: bad.append("analytic Eikonal (numerical_grad=False)")

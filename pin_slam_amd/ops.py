@@ -447,6 +447,33 @@ def new_sample_index(certainty, sdf_label, certainty_thre, label_thre, offset=0,
     return idx, cnt
 
 
+def select_surface_points(rows, sdf_label, label_thre, ws=None):
+    """rows[|sdf_label| < label_thre] -> (buffer [n,3], count tensor [1]); order preserved."""
+    n = sdf_label.shape[0]
+    dev = rows.device
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    if ws is None or ws.numel() < _lib.lib().pin_pool_workspace_bytes(n) + n:
+        ws = pool_workspace(n, dev, extra=n)
+    check(_lib.lib().pin_select_surface_points(_ptr(rows, torch.float32), _ptr(sdf_label, torch.float32), n, float(label_thre),
+                                               _ptr(out), _ptr(cnt), _ptr(ws), ws.numel(), _stream()),
+          "pin_select_surface_points")
+    return out, cnt
+
+
+def transform_points(points: torch.Tensor, pose, out: Optional[torch.Tensor] = None):
+    """transform_torch: points [N, >=3] (unit column stride) -> out [N,3] = R p + t (float32)."""
+    if not (points.is_cuda and points.dtype == torch.float32 and points.stride(1) == 1):
+        raise RuntimeError("points must be a float32 device tensor with unit column stride")
+    n = points.shape[0]
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=points.device)
+    T = np.ascontiguousarray(np.asarray(pose, np.float64)[:3, :4])
+    check(_lib.lib().pin_transform_points(points.data_ptr(), points.stride(0), n, T.ctypes.data, _ptr(out, torch.float32),
+                                          _stream()), "pin_transform_points")
+    return out
+
+
 def gather_rows(src: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None):
     """out[i] = src[index[i]] for a [n, width] float32 pool (color_pool gather of Mapper.get_batch)."""
     width = src.shape[1]

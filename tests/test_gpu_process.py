@@ -120,3 +120,129 @@ def test_sampler_large_random_matches_oracle():
     assert np.array_equal(pool.view("coord").cpu().numpy().view(np.uint32), coord.view(np.uint32))
     assert np.array_equal(pool.view("sdf_label").cpu().numpy().view(np.uint32), label.view(np.uint32))
     assert np.array_equal(pool.view("weight").cpu().numpy().view(np.uint32), weight.view(np.uint32))
+
+
+class _Spy:
+    """Records torch.randn / rand / randint results (the drop-in draws them in the reference's order)."""
+
+    def __enter__(self):
+        self.calls = []
+        self._orig = {n: getattr(torch, n) for n in ("randn", "rand", "randint")}
+        for n, f in self._orig.items():
+            def wrap(*a, _f=f, _n=n, **k):
+                r = _f(*a, **k)
+                self.calls.append((_n, r.detach().cpu().numpy().copy()))
+                return r
+            setattr(torch, n, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(torch, n, f)
+
+
+class _Dataset:
+    lose_track = False
+    stop_status = False
+    static_mask = None
+
+    def __init__(self, n):
+        self.processed_frame = 0
+        self.odom_poses = np.tile(np.eye(4), (n, 1, 1))
+        self.pgo_poses = self.gt_poses = self.odom_poses
+        self.gt_pose_provided = True
+
+
+def test_dropin_process_frame_matches_oracle(monkeypatch):
+    """Mapper.process_frame through the drop-in classes for four frames (with Mapper.mapping in
+    between so certainties are real), replayed step by step with the oracle on the same random
+    draws: sample pools, counts, new-sample index, adaptive offset and the grown map agree."""
+    from pin_slam_amd import pool as P
+    from pin_slam_amd.config import PinConfig
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    d = G.load("process")
+    B = 40009
+    cfg = PinConfig(voxel_size_m=0.4, buffer_size=B, local_map_radius=22.0, local_map_travel_dist_ratio=5.0, bs=1024,
+                    bs_new_sample=256, feature_std=0.05, pool_capacity=33000, pool_filter_freq=1, window_radius=13.0,
+                    max_range=20.0, adaptive_iters=True, search_alpha=0.5, query_nn_k=6)
+    torch.manual_seed(0)
+    npts = NeuralPoints(cfg)
+    nfr = int(d["n_frames"])
+    ds = _Dataset(nfr)
+    mp = Mapper(cfg, ds, npts, {"sdf": Decoder(cfg, 32, 1, 1), "semantic": None, "color": None})
+    snap = {}
+    orig_filter = P.SamplePool.filter
+
+    def spy_filter(self, *a, **k):
+        snap["global"] = self.view("global_coord").cpu().numpy().copy()
+        return orig_filter(self, *a, **k)
+
+    monkeypatch.setattr(P.SamplePool, "filter", spy_filter)
+    state = dict(table=np.full(B, -1, np.int64), positions=np.zeros((0, 3), np.float32),
+                 ts_create=np.zeros(0, np.int32), ts_update=np.zeros(0, np.int32))
+    pools = {k: np.zeros((0, 3) if "coord" in k else (0,), np.int32 if k == "time_pool" else np.float32) for k in POOLS}
+    kw = dict(surface_range=cfg.surface_sample_range_m, surface_n=3, front_n=2, behind_n=1,
+              free_begin_ratio=cfg.free_sample_begin_ratio, free_end_dist=cfg.free_sample_end_dist_m,
+              dist_weight_on=True, dist_weight_scale=cfg.dist_weight_scale, max_range=cfg.max_range)
+    travel = [0.0]
+    discards = 0
+    for t in range(nfr):
+        pose = d[f"f{t}_pose"]
+        if t:
+            travel.append(travel[-1] + float(np.linalg.norm(pose[:3, 3] - d[f"f{t-1}_pose"][:3, 3])))
+        ds.odom_poses[t] = pose
+        ds.processed_frame = t
+        npts.travel_dist = torch.tensor(travel + [0.0] * (nfr - len(travel)), dtype=torch.float32, device="cuda")
+        scan = torch.from_numpy(d[f"f{t}_scan"]).cuda()
+        with _Spy() as spy:
+            mp.process_frame(scan, None, torch.tensor(pose, dtype=torch.float64, device="cuda"), t)
+        names = [c[0] for c in spy.calls]
+        assert names[:4] == ["randn", "rand", "rand", "randn"], names  # surface, front, behind, new-point features
+        # ---- oracle replay on the same draws
+        coord, label, _, weight = O.sample_rays(d[f"f{t}_scan"], None, *(c[1].reshape(-1) for c in spy.calls[:3]), **kw)
+        g_or = O.transform_points(coord, pose)
+        n_new = len(label)
+        g_gpu = snap["global"]
+        np.testing.assert_allclose(g_gpu[-n_new:], g_or, rtol=0, atol=4e-6)
+        upd = g_gpu[-n_new:][np.abs(label) < np.float32(cfg.surface_sample_range_m * cfg.map_surface_ratio)]
+        O.map_update(state, upd, t, cfg.voxel_size_m, travel_dist=np.asarray(travel + [0.0] * (nfr - len(travel)), np.float32),
+                     diff_travel_dist_local=npts.diff_travel_dist_local)
+        assert npts.count() == len(state["positions"])
+        assert np.array_equal(npts.neural_points.cpu().numpy(), state["positions"])
+        # 40 009 slots: many samples of one call collide; the table keeps the LAST sample's value like the reference
+        assert np.array_equal(npts.buffer_pt_index.cpu().numpy().astype(np.int64), state["table"])
+        before = dict(coord_pool=np.concatenate([pools["coord_pool"], coord]), global_coord_pool=g_gpu,
+                      sdf_label_pool=np.concatenate([pools["sdf_label_pool"], label]),
+                      weight_pool=np.concatenate([pools["weight_pool"], weight]),
+                      time_pool=np.concatenate([pools["time_pool"], np.full(n_new, t, np.int32)]))
+        disc = [c[1] for c in spy.calls if c[0] == "randint"]
+        discards += len(disc)
+        mask = O.pool_filter_mask(g_gpu, pose[:3, 3], cfg.window_radius, cfg.pool_capacity, disc[0] if disc else None)
+        pools = {k: v[mask] for k, v in before.items()}
+        assert mp.pool_sample_count == int(mask.sum()) and mp.cur_sample_count == int(mask[-n_new:].sum())
+        for k in POOLS:
+            assert np.array_equal(getattr(mp, k).cpu().numpy(), pools[k]), (k, t)
+        cur = mp.cur_sample_count
+        cert = O.query_certainty(pools["global_coord_pool"][-cur:], state["table"], state["positions"],
+                                 npts.point_certainties.cpu().numpy(), cfg.voxel_size_m)
+        idx = O.new_sample_index(cert, pools["sdf_label_pool"][-cur:], cfg.new_certainty_thre, cfg.surface_sample_range_m,
+                                 offset=mp.pool_sample_count - cur)
+        got = mp.new_idx.cpu().numpy()
+        assert np.array_equal(got, idx), (t, len(got), len(idx), np.setdiff1d(got, idx)[:5], np.setdiff1d(idx, got)[:5])
+        assert mp.adaptive_iter_offset == O.adaptive_iter_offset(len(idx), cur, t, adaptive_iters=True)
+        # ---- get_batch: the reference's draw order (history, then new samples), rows gathered from the pool
+        with _Spy() as spy:
+            co, lab, ts, _, _, col, w = mp.get_batch(global_coord=True)
+        hist, newb = spy.calls[0][1], spy.calls[1][1]
+        index = np.concatenate([hist, idx[newb]])
+        assert len(index) == cfg.bs and len(newb) == min(len(idx), cfg.bs_new_sample)
+        assert np.array_equal(co.cpu().numpy(), pools["global_coord_pool"][index])
+        assert np.array_equal(lab.cpu().numpy(), pools["sdf_label_pool"][index])
+        assert np.array_equal(ts.cpu().numpy(), pools["time_pool"][index])
+        assert np.array_equal(w.cpu().numpy(), pools["weight_pool"][index])
+        mp.mapping(6)
+        state["ts_update"] = npts.point_ts_update.cpu().numpy().copy()  # training refreshes ts_update of touched points
+    assert discards > 0
+    assert float(npts.point_certainties.max()) > 0
