@@ -504,6 +504,26 @@ int pin_transform_points(const float* points, int32_t row_stride, int32_t n, con
  * utils/mapper.py:494-495). */
 int pin_gather_rows(const float* src, int32_t width, const int32_t* index, int32_t n, float* out, void* stream);
 
+/* ---- SLAMDataset.preprocess_frame data path (dataset/slam_dataset.py:359-505) ----------------
+ * The two voxel_down_sample_torch passes are pin_voxel_downsample + pin_gather_rows. */
+
+/* crop_frame (dataset/slam_dataset.py:1229-1247): rows ([n][width], xyz first) with
+ * min_range < ||xyz|| < max_range and min_z < z < max_z, order preserved, with their
+ * per-point timestamps (ts / ts_out may be NULL).  count_out [1]; workspace
+ * pin_pool_workspace_bytes(n) + n bytes. */
+int pin_crop_frame(const float* points, int32_t width, int32_t n, const float* ts, float min_z, float max_z,
+                   float min_range, float max_range, float* points_out, float* ts_out, int32_t* count_out,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* intrinsic_correct (dataset/slam_dataset.py:1251-1269), in place on rows of `width` floats. */
+int pin_intrinsic_correct(float* points, int32_t width, int32_t n, double correct_deg, void* stream);
+
+/* deskewing (utils/tools.py:747-779), in place: p_i <- exp(t_i log R) p_i + t_i trans with
+ * t_i = (ts_i - min ts)/(max ts - min ts) - ts_mid_pose and pose = T_last<-cur as 16 doubles
+ * (row-major 4x4).  workspace >= 64 bytes. */
+int pin_deskew(float* points, int32_t width, int32_t n, const float* ts, const double* pose, double ts_mid_pose,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -544,6 +544,59 @@ def gen_process(color=False):
 
 
 
+def gen_preprocess():
+    """(9) SLAMDataset.preprocess_frame data path (dataset/slam_dataset.py:359-505): the two
+    voxel_down_sample_torch passes, crop_frame, intrinsic_correct and deskewing, each called as
+    the reference function on one synthetic scan.  roma is not installed here: deskewing runs
+    with roma.rotmat_slerp replaced by exp(t*log(R)) through scipy (what roma computes), so the
+    fixture pins the reference's surrounding arithmetic (timestamp normalisation, mid-pose
+    shift, translation lerp), not roma's own rounding."""
+    import importlib
+    from scipy.spatial.transform import Rotation
+    m = R.load()
+    sys.path.insert(0, R.REF_ROOT)
+    try:
+        sd = importlib.import_module("dataset.slam_dataset")
+    finally:
+        sys.path.remove(R.REF_ROOT)
+    tools = m["tools"]
+    gen = torch.Generator().manual_seed(21)
+    n = 30000
+    pts = sheet_points(gen, n, 45.0, layers=4)
+    pts[:, 2] += 1.5 * torch.randn(n, generator=gen)
+    inten = torch.rand(n, 1, generator=gen)
+    scan = torch.cat([pts, inten], 1).float()
+    ts = torch.rand(n, generator=gen).float()
+    out = dict(scan=t2n(scan), ts=t2n(ts), vox_down_m=np.float64(0.12), source_vox_down_m=np.float64(0.8),
+               min_z=np.float64(-3.0), max_z=np.float64(2.5), min_range=np.float64(2.5), max_range=np.float64(40.0),
+               correct_deg=np.float64(0.195))
+    idx = tools.voxel_down_sample_torch(scan[:, :3], out["vox_down_m"].item())
+    out["idx_train"] = t2n(idx)
+    pc, pts_ts = scan[idx], ts[idx]
+    pc, pts_ts = sd.crop_frame(pc, pts_ts, -3.0, 2.5, 2.5, 40.0)
+    out["cropped"], out["cropped_ts"] = t2n(pc), t2n(pts_ts)
+    pc = sd.intrinsic_correct(pc.clone(), 0.195)
+    out["corrected"] = t2n(pc)
+    idx2 = tools.voxel_down_sample_torch(pc[:, :3], out["source_vox_down_m"].item())
+    out["idx_source"] = t2n(idx2)
+    src, src_ts = pc[idx2][:, :3].clone(), pts_ts[idx2].clone()
+    out["source"], out["source_ts"] = t2n(src), t2n(src_ts)
+    pose = np.eye(4)
+    pose[:3, :3] = Rotation.from_rotvec([0.01, -0.02, 0.06]).as_matrix()
+    pose[:3, 3] = [1.1, 0.05, -0.02]
+    out["last_odom_tran"] = pose
+
+    def slerp(R0, R1, steps):
+        rv = Rotation.from_matrix((R0.T @ R1).double().numpy()).as_rotvec()
+        Rs = Rotation.from_rotvec(steps.double().numpy()[:, None] * rv[None, :]).as_matrix()
+        return (R0.double() @ torch.from_numpy(Rs)).to(R1)
+
+    tools.roma.rotmat_slerp = slerp
+    out["deskewed"] = t2n(tools.deskewing(src.clone(), src_ts.clone(), torch.tensor(pose, dtype=torch.float32)))
+    return out
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -569,6 +622,12 @@ def main():
                   "new", [len(d[f"f{t}_new_idx"]) for t in range(int(d["n_frames"]))],
                   "discard", [len(d[f"f{t}_discard_index"]) for t in range(int(d["n_frames"]))],
                   "adaptive", [int(d[f"f{t}_adaptive_iter_offset"]) for t in range(int(d["n_frames"]))])
+    if only in (None, "preprocess"):
+        d = gen_preprocess()
+        path = os.path.join(OUT, "preprocess.npz")
+        np.savez_compressed(path, **d)
+        print("preprocess ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "train", len(d["idx_train"]), "cropped",
+              len(d["cropped"]), "source", len(d["idx_source"]))
     if only not in (None, "update"):
         return
     d = gen_update()

@@ -769,3 +769,66 @@ def adaptive_iter_offset(new_sample_count, cur_sample_count, frame_id, *, adapti
     if r > ratio_more:
         return 10 if (frame_id > freeze_after_frame and r > ratio_restart) else 5
     return 0
+
+
+# --------------------------------------------------------------------------- preprocess_frame data path
+def _norm3(p):
+    """torch.norm / torch.linalg.norm over 3 columns on CPU: fma(z,z, fma(y,y, x*x)), then sqrt."""
+    x, y, z = (np.asarray(p[:, i], F32).astype(np.float64) for i in range(3))
+    acc = (x * x).astype(F32).astype(np.float64)
+    acc = (y * y + acc).astype(F32).astype(np.float64)
+    acc = (z * z + acc).astype(F32)
+    return np.sqrt(acc).astype(F32)
+
+
+def crop_frame_mask(points, min_z, max_z, min_range, max_range):
+    """crop_frame (dataset/slam_dataset.py:1229-1247): rows kept (order preserved)."""
+    p = np.asarray(points, F32)
+    dist = _norm3(p)
+    return (dist > F32(min_range)) & (dist < F32(max_range)) & (p[:, 2] > F32(min_z)) & (p[:, 2] < F32(max_z))
+
+
+def intrinsic_correct(points, correct_deg):
+    """intrinsic_correct (dataset/slam_dataset.py:1251-1269), float32 like the reference."""
+    p = np.array(points, F32, copy=True)
+    if correct_deg == 0.0:
+        return p
+    dist = _norm3(p)
+    ang = F32(correct_deg / 180.0 * np.pi)
+    v = np.arcsin((p[:, 2] / dist).astype(F32)).astype(F32)
+    vc = (v + ang).astype(F32)
+    hs = (np.cos(vc).astype(F32) / np.cos(v).astype(F32)).astype(F32)
+    p[:, 0] *= hs
+    p[:, 1] *= hs
+    p[:, 2] = dist * np.sin(vc).astype(F32)
+    return p
+
+
+def rotvec_of(R):
+    """log map of a rotation matrix (float64), shortest arc."""
+    R = np.asarray(R, np.float64)
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    th = np.arccos(c)
+    if th < 1e-12:
+        return np.zeros(3)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * np.sin(th))
+    return w * th
+
+
+def deskewing(points, ts, pose, ts_mid_pose=0.5):
+    """deskewing (utils/tools.py:747-779): per-point motion undistortion with the relative pose
+    T_last<-cur.  roma.rotmat_slerp(I, R, t) = exp(t * log(R)) (roma's unit-quaternion slerp with
+    shortest_arc; t may be negative), evaluated here in float64 and applied in float32."""
+    p = np.asarray(points, F32)
+    t = np.asarray(ts, F32).reshape(-1)
+    t = ((t - t.min()) / (t.max() - t.min())).astype(F32)
+    t = (t - F32(ts_mid_pose)).astype(F32)
+    T = np.asarray(pose, F32)
+    rv = rotvec_of(T[:3, :3].astype(np.float64))
+    th = np.linalg.norm(rv)
+    ax = rv / th if th > 0 else np.array([1.0, 0.0, 0.0])
+    a = t.astype(np.float64) * th
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rm = np.eye(3)[None] + np.sin(a)[:, None, None] * K[None] + (1 - np.cos(a))[:, None, None] * (K @ K)[None]
+    out = np.einsum("nij,nj->ni", Rm.astype(F32), p[:, :3]).astype(F32) + (t[:, None] * T[:3, 3][None, :]).astype(F32)
+    return out.astype(F32)

@@ -166,6 +166,9 @@ SIGNATURES = {
     "pin_new_sample_index": (i32, [vp, vp, i32, f32, f32, i64, vp, vp, vp, i64, vp]),
     "pin_select_surface_points": (i32, [vp, vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_transform_points": (i32, [vp, i32, i32, vp, vp, vp]),
+    "pin_crop_frame": (i32, [vp, i32, i32, vp, f32, f32, f32, f32, vp, vp, vp, vp, i64, vp]),
+    "pin_intrinsic_correct": (i32, [vp, i32, i32, f64, vp]),
+    "pin_deskew": (i32, [vp, i32, i32, vp, vp, f64, vp, i64, vp]),
     "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
 }
 

@@ -12,6 +12,18 @@ class PinConfig:
         self.device = "cuda"
         self.dtype = torch.float32
         self.silence = True
+        # preprocessing (config.py:53-68, 216)
+        self.deskew = False
+        self.min_range = 2.5
+        self.min_z = -5.0
+        self.max_z = 80.0
+        self.rand_downsample = False
+        self.rand_down_r = 1.0
+        self.vox_down_m = 0.05
+        self.source_vox_down_m = 0.8
+        self.adaptive_range_on = False
+        self.kitti_correction_on = False
+        self.correction_deg = 0.0
         # neural points (config.py:91-103)
         self.voxel_size_m = 0.3
         self.weighted_first = True

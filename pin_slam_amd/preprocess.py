@@ -1,0 +1,146 @@
+"""SLAMDataset.preprocess_frame data path (dataset/slam_dataset.py:359-505) on libpinhip:
+function-level mirrors of the reference helpers it calls -- ``voxel_down_sample_torch``
+(utils/tools.py:583), ``crop_frame`` (slam_dataset.py:1229), ``intrinsic_correct`` (:1251),
+``deskewing`` (utils/tools.py:747) -- with the reference's signatures, and :class:`ScanPreprocessor`
+that chains them for one frame.  ``patch_reference()`` rebinds the reference's module-level
+names to these functions (drop-in mode)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+_ws_cache = {}
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    key = str(device)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty((int(nbytes * 1.25) + 256,), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def _dev_f32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("libpinhip needs device (HIP) tensors; there is no CPU path")
+    return t.detach().to(torch.float32)
+
+
+def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """Index (int64, ordered by voxel id) of the point closest to its voxel centre, per voxel."""
+    L = _lib.lib()
+    pts = _dev_f32(points).contiguous()
+    n = pts.shape[0]
+    ws = _ws(L.pin_maint_workspace_bytes(n), pts.device)
+    sel = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)
+    check(L.pin_voxel_downsample(pts.data_ptr(), n, float(np.float32(voxel_size)), sel.data_ptr(), cnt.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), ops._stream()), "pin_voxel_downsample")
+    return sel[:int(cnt.item())].long()
+
+
+def crop_frame(points: torch.Tensor, ts: Optional[torch.Tensor], min_z_th=-3.0, max_z_th=100.0, min_range=2.75,
+               max_range=100.0):
+    L = _lib.lib()
+    pts = _dev_f32(points).contiguous()
+    n, w = pts.shape
+    t32 = None if ts is None else _dev_f32(ts).reshape(-1).contiguous()
+    out = torch.empty_like(pts)
+    ts_out = None if ts is None else torch.empty_like(t32)
+    cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)
+    ws = _ws(L.pin_pool_workspace_bytes(n) + n, pts.device)
+    check(L.pin_crop_frame(pts.data_ptr(), w, n, None if t32 is None else t32.data_ptr(), float(min_z_th), float(max_z_th),
+                           float(min_range), float(max_range), out.data_ptr(), None if ts_out is None else ts_out.data_ptr(),
+                           cnt.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "pin_crop_frame")
+    c = int(cnt.item())
+    if ts is not None:
+        ts_out = ts_out[:c].to(ts.dtype).reshape((c,) + tuple(ts.shape[1:]))
+    return out[:c], ts_out
+
+
+def intrinsic_correct(points: torch.Tensor, correct_deg=0.0):
+    if correct_deg == 0.0:
+        return points
+    if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()):
+        raise RuntimeError("intrinsic_correct works in place on a contiguous float32 device tensor")
+    check(_lib.lib().pin_intrinsic_correct(points.data_ptr(), points.shape[1], points.shape[0], float(correct_deg),
+                                           ops._stream()), "pin_intrinsic_correct")
+    return points
+
+
+def deskewing(points: torch.Tensor, ts: Optional[torch.Tensor], pose: torch.Tensor, ts_mid_pose=0.5):
+    if ts is None:
+        return points
+    if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()):
+        raise RuntimeError("deskewing works in place on a contiguous float32 device tensor")
+    t32 = _dev_f32(ts).reshape(-1).contiguous()
+    T = np.ascontiguousarray(pose.detach().to("cpu", torch.float64).numpy() if isinstance(pose, torch.Tensor)
+                             else np.asarray(pose, np.float64))
+    ws = _ws(64, points.device)
+    check(_lib.lib().pin_deskew(points.data_ptr(), points.shape[1], points.shape[0], t32.data_ptr(), T.ctypes.data,
+                                float(ts_mid_pose), ws.data_ptr(), ws.numel(), ops._stream()), "pin_deskew")
+    return points
+
+
+def gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """points[idx] for [n, w] float32 rows through pin_gather_rows."""
+    return ops.gather_rows(points, idx.to(torch.int32))
+
+
+class ScanPreprocessor:
+    """The data half of SLAMDataset.preprocess_frame for one frame: train-resolution voxel
+    down-sampling, crop, optional KITTI correction, source-resolution down-sampling and
+    deskewing of the registration source.  Pose bookkeeping stays with the caller."""
+
+    def __init__(self, config):
+        self.config = config
+
+    def __call__(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None,
+                 frame_id: int = 1, lose_track: bool = False):
+        c = self.config
+        if getattr(c, "adaptive_range_on", False):
+            raise NotImplementedError("adaptive_range_on")
+        crop_max = c.max_range
+        train_vox = (crop_max / c.max_range) * c.vox_down_m
+        source_vox = (crop_max / c.max_range) * c.source_vox_down_m
+        scan = _dev_f32(scan).contiguous()
+        if getattr(c, "rand_downsample", False):
+            idx = torch.randint(0, scan.shape[0], (int(scan.shape[0] * c.rand_down_r),), device=scan.device)
+        else:
+            idx = voxel_down_sample_torch(scan[:, :3], train_vox)
+        pc = gather(scan, idx)
+        ts = None if point_ts is None else point_ts[idx]
+        pc, ts = crop_frame(pc, ts, c.min_z, c.max_z, c.min_range, crop_max)
+        if getattr(c, "kitti_correction_on", False):
+            pc = intrinsic_correct(pc, c.correction_deg)
+        source = source_colors = None
+        if frame_id > 0:
+            idx2 = voxel_down_sample_torch(pc[:, :3], source_vox)
+            src = gather(pc, idx2)
+            source = src[:, :3].contiguous()
+            if c.color_on:
+                source_colors = src[:, 3:]
+            if getattr(c, "deskew", False) and not lose_track and ts is not None and last_odom_tran is not None:
+                source = deskewing(source, ts[idx2], torch.as_tensor(last_odom_tran))
+        return pc, ts, source, source_colors
+
+
+def patch_reference():
+    """Drop-in mode: rebind the reference's module-level helpers (``dataset.slam_dataset`` and
+    ``utils.tools`` must already be importable, i.e. after ``dropin.install``)."""
+    import importlib
+    sd = importlib.import_module("dataset.slam_dataset")
+    tools = importlib.import_module("utils.tools")
+    for mod in (sd, tools):
+        for name, fn in (("voxel_down_sample_torch", voxel_down_sample_torch), ("crop_frame", crop_frame),
+                         ("intrinsic_correct", intrinsic_correct), ("deskewing", deskewing)):
+            if hasattr(mod, name):
+                setattr(mod, name, fn)
+    return sd

@@ -1,0 +1,60 @@
+"""GPU parity of the preprocess_frame data path (crop_frame, intrinsic_correct, deskewing and the
+two voxel down-sampling passes) through the C ABI against the reference fixture and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pin_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pp():
+    return G.load("preprocess")
+
+
+def test_preprocess_steps_follow_reference(pp):
+    from pin_slam_amd import preprocess as PP
+    d = pp
+    scan, ts = torch.from_numpy(d["scan"]).cuda(), torch.from_numpy(d["ts"]).cuda()
+    idx = PP.voxel_down_sample_torch(scan[:, :3], d["vox_down_m"])
+    assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), d["idx_train"])
+    pc, pts_ts = PP.crop_frame(PP.gather(scan, idx), ts[idx], d["min_z"], d["max_z"], d["min_range"], d["max_range"])
+    assert np.array_equal(pc.cpu().numpy(), d["cropped"]) and np.array_equal(pts_ts.cpu().numpy(), d["cropped_ts"])
+    pc = PP.intrinsic_correct(pc.clone(), d["correct_deg"])
+    np.testing.assert_allclose(pc.cpu().numpy(), d["corrected"], rtol=1e-6, atol=1e-6)
+    ref = torch.from_numpy(d["corrected"]).cuda()  # continue from the reference's bits: voxel ids are discontinuous
+    idx2 = PP.voxel_down_sample_torch(ref[:, :3], d["source_vox_down_m"])
+    assert np.array_equal(idx2.cpu().numpy(), d["idx_source"])
+    src = PP.gather(ref, idx2)[:, :3].contiguous()
+    assert np.array_equal(src.cpu().numpy(), d["source"])
+    out = PP.deskewing(src.clone(), torch.from_numpy(d["source_ts"]).cuda(), torch.from_numpy(d["last_odom_tran"]))
+    np.testing.assert_allclose(out.cpu().numpy(), d["deskewed"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), O.deskewing(d["source"], d["source_ts"], d["last_odom_tran"]), rtol=0, atol=2e-5)
+
+
+def test_scan_preprocessor_matches_oracle_chain():
+    """100k-point scan through ScanPreprocessor vs the oracle functions chained the same way."""
+    from pin_slam_amd import preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    cfg = PinConfig(vox_down_m=0.08, source_vox_down_m=0.8, min_range=2.5, max_range=60.0, min_z=-5.0, max_z=60.0, deskew=True)
+    g = torch.Generator().manual_seed(2)
+    n = 100_000
+    r = 70.0 * torch.sqrt(torch.rand(n, generator=g)); th = 6.2831853 * torch.rand(n, generator=g)
+    scan = torch.stack([r * torch.cos(th), r * torch.sin(th), -2 + 0.3 * torch.sin(0.5 * r) + 0.5 * torch.randn(n, generator=g),
+                        torch.rand(n, generator=g)], 1).float()
+    ts = torch.rand(n, generator=g).float()
+    T = np.eye(4); T[:3, 3] = [0.9, 0.02, 0.0]
+    c, s = np.cos(0.03), np.sin(0.03); T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    pc, pts_ts, src, _ = PP.ScanPreprocessor(cfg)(scan.cuda(), ts.cuda(), last_odom_tran=T, frame_id=3)
+    sn, tn = scan.numpy(), ts.numpy()
+    i1 = O.voxel_down_sample(sn[:, :3], cfg.vox_down_m)
+    m = O.crop_frame_mask(sn[i1], cfg.min_z, cfg.max_z, cfg.min_range, cfg.max_range)
+    ref_pc, ref_ts = sn[i1][m], tn[i1][m]
+    assert np.array_equal(pc.cpu().numpy(), ref_pc) and np.array_equal(pts_ts.cpu().numpy(), ref_ts)
+    i2 = O.voxel_down_sample(ref_pc[:, :3], cfg.source_vox_down_m)
+    ref_src = O.deskewing(ref_pc[i2][:, :3], ref_ts[i2], T)
+    np.testing.assert_allclose(src.cpu().numpy(), ref_src, rtol=0, atol=3e-5)
+    assert 1000 < len(i2) < len(i1)
