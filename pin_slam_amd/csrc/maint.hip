@@ -35,10 +35,27 @@ __global__ void vds_init_kernel(VdsStats* st) {
     st->gmax = 0; st->dmax = 0u; st->nseg = 0;
 }
 
+// wave-level reductions: one atomic per wave, grids capped (REDUCE_BLOCKS) so that a few
+// thousand atomics hit each address instead of one per point
+constexpr int REDUCE_BLOCKS = 512;
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
 __global__ __launch_bounds__(MB) void vds_min_kernel(const float* __restrict__ p, int n, VdsStats* st) {
-    const int i = blockIdx.x * MB + threadIdx.x;
-    if (i >= n) return;
-    atomicMin(&st->minx, enc_f(p[3 * i])); atomicMin(&st->miny, enc_f(p[3 * i + 1])); atomicMin(&st->minz, enc_f(p[3 * i + 2]));
+    unsigned int mx = 0xffffffffu, my = 0xffffffffu, mz = 0xffffffffu;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) {
+        mx = min(mx, enc_f(p[3 * i])); my = min(my, enc_f(p[3 * i + 1])); mz = min(mz, enc_f(p[3 * i + 2]));
+    }
+    mx = wave_min_u32(mx); my = wave_min_u32(my); mz = wave_min_u32(mz);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&st->minx, mx); atomicMin(&st->miny, my); atomicMin(&st->minz, mz); }
 }
 
 __device__ __forceinline__ void vds_point(const float* __restrict__ p, int i, float vs, const VdsStats* st, long long (&g)[3],
@@ -55,17 +72,20 @@ __device__ __forceinline__ void vds_point(const float* __restrict__ p, int i, fl
         const float center = (gf + 0.5f) * vs;
         d[a] = x - center;
     }
-    dist = sqrtf(dist2_exact(d[0], d[1], d[2]));
+    dist = (float)sqrt((double)dist2_exact(d[0], d[1], d[2]));  // correctly rounded (v_sqrt_f32 alone is 1 ulp)
 }
 
 __global__ __launch_bounds__(MB) void vds_max_kernel(const float* __restrict__ p, int n, float vs, VdsStats* st) {
-    const int i = blockIdx.x * MB + threadIdx.x;
-    if (i >= n) return;
-    long long g[3]; float dist;
-    vds_point(p, i, vs, st, g, dist);
-    const long long m = max(g[0], max(g[1], g[2]));
-    atomicMax(&st->gmax, (int)m);
-    atomicMax(&st->dmax, __float_as_uint(dist));
+    int gm = 0;
+    unsigned int dm = 0u;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) {
+        long long g[3]; float dist;
+        vds_point(p, i, vs, st, g, dist);
+        gm = max(gm, (int)max(g[0], max(g[1], g[2])));  // offsets make every g >= 0
+        dm = max(dm, __float_as_uint(dist));
+    }
+    gm = (int)wave_max_u32((unsigned int)gm); dm = wave_max_u32(dm);
+    if ((threadIdx.x & 63) == 0) { atomicMax(&st->gmax, gm); atomicMax(&st->dmax, dm); }
 }
 
 __global__ __launch_bounds__(MB) void vds_keys_kernel(const float* __restrict__ p, int n, float vs, const VdsStats* st,
@@ -185,14 +205,15 @@ __global__ __launch_bounds__(MB) void update_append_kernel(pin_map_arrays ma, pi
 
 // ---- K9: reset_local_map ------------------------------------------------------------------------
 __global__ __launch_bounds__(MB) void local_time_count_kernel(pin_map_arrays ma, pin_local_params lp, int* __restrict__ cnt) {
-    const int i = blockIdx.x * MB + threadIdx.x;
-    bool t = false;
-    if (i < lp.n_points) {
+    int c = 0;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < lp.n_points; i += gridDim.x * MB) {
         const int ts = ma.ts_create[i];
-        t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
+        bool t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
         if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
+        c += t ? 1 : 0;
     }
-    const int c = __popcll(__ballot(t));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, c);
 }
 
@@ -310,8 +331,8 @@ extern "C" int pin_voxel_downsample(const float* points, int32_t n, float voxel_
     long long off10 = 1;  // 10 ** len(str(n - 1))  (utils/tools.py:610)
     for (long long v = n - 1; ; v /= 10) { off10 *= 10; if (v < 10) break; }
     hipLaunchKernelGGL(vds_init_kernel, dim3(1), dim3(1), 0, s, st);
-    hipLaunchKernelGGL(vds_min_kernel, dim3(nb), dim3(MB), 0, s, points, n, st);
-    hipLaunchKernelGGL(vds_max_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, st);
+    hipLaunchKernelGGL(vds_min_kernel, dim3(min(nb, REDUCE_BLOCKS)), dim3(MB), 0, s, points, n, st);
+    hipLaunchKernelGGL(vds_max_kernel, dim3(min(nb, REDUCE_BLOCKS)), dim3(MB), 0, s, points, n, voxel_size, st);
     hipLaunchKernelGGL(vds_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, st, off10, keys, vals);
     PIN_CHECK_LAUNCH();
     PIN_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (size_t)n, 0, 64, s));
@@ -365,7 +386,7 @@ extern "C" int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arr
     PIN_CHECK_ARG(time_cnt != nullptr, "workspace carve failed");
     PIN_CHECK_HIP(hipMemsetAsync(time_cnt, 0, sizeof(int), s));
     if (lp->travel_dist != nullptr)
-        hipLaunchKernelGGL(local_time_count_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt);
+        hipLaunchKernelGGL(local_time_count_kernel, dim3(min(nb, REDUCE_BLOCKS)), dim3(MB), 0, s, *ma, *lp, time_cnt);
     hipLaunchKernelGGL(local_flags_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt, local_mask_out);
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, local_mask_out, n1, block_off);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_local_out);

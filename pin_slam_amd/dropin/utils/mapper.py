@@ -91,6 +91,9 @@ class Mapper(_Base):
         super().__init__(config, dataset, neural_points, decoders)
         self._trainer = None
         self._spool = None  # device-resident sample pool (pin_slam_amd.pool.SamplePool)
+        # data-parallel mapping: config.bs is the GLOBAL batch, every rank draws the same
+        # batch (same seed) and trains on its contiguous shard; set by the launcher, 1 rank by default
+        self.dp_rank, self.dp_world = 0, 1
         self.static_mask = None
         self.cur_sample_count = 0
         self.cur_new_point_ratio = 0.0
@@ -273,12 +276,13 @@ class Mapper(_Base):
         eik = bool(c.ekional_loss_on and c.weight_e > 0)
         t = self._trainer
         if (t is None or t.fs.feats.numel() != fs.feats.numel() or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel()
-                or (t.buf.n_eik > 0) != eik or t.fs.weighted_first != fs.weighted_first):
+                or (t.buf.n_eik > 0) != eik or t.fs.weighted_first != fs.weighted_first
+                or (t.rank, t.world) != (self.dp_rank, self.dp_world)):
             t = engine.MapTrainer(st, fs, None, None, None, None, npts.local_point_ts_update, bs=c.bs,
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,
                                   weight_e=c.weight_e if eik else 0.0,
                                   eik_eps=c.voxel_size_m * c.num_grad_step_ratio, lr=c.lr, adam_eps=c.adam_eps,
-                                  loss_weight_on=c.loss_weight_on, eikonal=eik)
+                                  loss_weight_on=c.loss_weight_on, eikonal=eik, rank=self.dp_rank, world=self.dp_world)
             self._trainer = t
         t.st, t.fs, t.ts_update, t.train_decoder = st, fs, npts.local_point_ts_update, train_dec
         if c.color_on and c.weight_i > 0:  # colour branch (mapper.py:668-671, 802-812)
@@ -298,14 +302,25 @@ class Mapper(_Base):
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         t = self._get_trainer()
         t.reset_optimizer()  # a new Adam per call (mapper.py:615)
+        from ...sharding import shard_range
+        lo, hi = shard_range(self.config.bs, self.dp_rank, self.dp_world)
+        sh = slice(lo, hi)
+        if self.dp_world > 1:
+            cert0 = t.fs.certainty.clone()
         for it in range(iter_count):
             coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
             if t.fc is not None and color_label is None:
                 raise RuntimeError("color_on but the data pool holds no colour labels")
-            t.step_batch(coord.to(torch.float32).contiguous(), sdf_label.to(torch.float32).contiguous(),
-                         weight.to(torch.float32).contiguous(), ts.to(torch.int32).contiguous(), it + 1,
-                         color_label=None if t.fc is None else color_label[:, :3].to(torch.float32).contiguous())
+            t.step_batch(coord[sh].to(torch.float32).contiguous(), sdf_label[sh].to(torch.float32).contiguous(),
+                         weight[sh].to(torch.float32).contiguous(), ts[sh].to(torch.int32).contiguous(), it + 1,
+                         color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous())
             self.total_iter += 1
+        if self.dp_world > 1:  # certainty / ts side effects of the other ranks' shards (engine.MapTrainer.mapping)
+            import torch.distributed as dist
+            delta = t.fs.certainty - cert0
+            dist.all_reduce(delta)
+            t.fs.certainty.copy_(cert0 + delta)
+            dist.all_reduce(t.ts_update, op=dist.ReduceOp.MAX)
         self.neural_points.assign_local_to_global()
 
     def sdf(self, x, get_std=False, min_nn_count=1, accumulate_stability=False):

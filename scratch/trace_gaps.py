@@ -1,0 +1,21 @@
+"""Analyse a rocprofv3 kernel trace of bench.py: per-frame GPU busy time and idle gaps."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
+# frames: split at brick_mark (start of reset_local_map in process_frame) -- use vds_init as frame marker (first kernel of preprocess)
+marks = [i for i, e in enumerate(ev) if "vds_init" in e[2]]
+# 3 voxel downsamples per frame (2 preprocess + 1 update); take every 3rd as frame start, from the end
+frames = marks[::3]
+print("events", len(ev), "vds_init", len(marks))
+for a, b in list(zip(frames[:-1], frames[1:]))[-8:]:
+    seg = ev[a:b]
+    wall = seg[-1][1] - seg[0][0]
+    busy = sum(e[1] - e[0] for e in seg)
+    gaps = collections.Counter()
+    for x, y in zip(seg[:-1], seg[1:]):
+        g = y[0] - x[1]
+        if g > 20000:
+            gaps[(x[2][:40], y[2][:40])] += g
+    print(f"frame kernels={len(seg)} wall={wall/1e6:.3f} ms busy={busy/1e6:.3f} ms idle={(wall-busy)/1e6:.3f} ms")
+    for k, v in gaps.most_common(8):
+        print(f"    gap {v/1e3:8.1f} us  {k[0]} -> {k[1]}")
