@@ -25,6 +25,26 @@ constexpr unsigned long long BRICK_EMPTY = ~0ull;
 constexpr int BRICK_GROUP = 16;
 constexpr int BRICK_BLOCK = 256;
 
+// 16-lane (one DPP row) all-reductions: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned int row_min_u32(unsigned int v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned int row_sum_u32(unsigned int v) {
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    v += dpp_u32<0x140>(v);
+    return v;
+}
+
 __device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz) {
     return ((unsigned long long)(unsigned)(bx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(by + (1 << 20)) << 21) |
            (unsigned long long)(unsigned)(bz + (1 << 20));
@@ -227,90 +247,99 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     const long long gx = voxel_coord(qx, sp.resolution), gy = voxel_coord(qy, sp.resolution),
                     gz = voxel_coord(qz, sp.resolution);
     const int nd = bc.n_dilate;
-    const int b0x = (int)((gx - nd) >> 2), b0y = (int)((gy - nd) >> 2), b0z = (int)((gz - nd) >> 2);
+    // the cached path works on 32-bit cell coordinates; anything farther than 2^29 cells from the
+    // origin (never the case for a metric map) takes the exact 64-bit probe for every candidate
+    const long long lim = 1LL << 29;
+    const bool far = gx >= lim || gx < -lim || gy >= lim || gy < -lim || gz >= lim || gz < -lim;
+    const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
+    const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
     // lanes 0..7 resolve the 2x2x2 bricks that cover the candidate window
-    int my_id = -1, my_base = 0;
-    unsigned long long my_mask = 0;
-    if (sub < 8) {
+    int my_base = -1;  // -1: brick not cached
+    unsigned int my_lo = 0, my_hi = 0;
+    if (sub < 8 && !far) {
         const int bx = b0x + (sub >> 2), by = b0y + ((sub >> 1) & 1), bz = b0z + (sub & 1);
-        my_id = dir_find(bc, brick_key(bx, by, bz));
-        if (my_id >= 0) { my_mask = bc.brick_mask[my_id]; my_base = bc.brick_base[my_id]; }
+        const int id = dir_find(bc, brick_key(bx, by, bz));
+        if (id >= 0) {
+            const unsigned long long mk = bc.brick_mask[id];
+            my_lo = (unsigned int)mk; my_hi = (unsigned int)(mk >> 32);
+            my_base = bc.brick_base[id];
+        }
     }
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
     const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
 
-    unsigned long long key[R];
-    float4 P[R];
-    int li[R];
+    // accepted candidates: distance bits in registers, (q - P, index) records staged in LDS so that
+    // the winner of a round fetches its record with a dynamic index instead of a select chain
+    __shared__ float4 stage[R][BRICK_BLOCK];
+    unsigned int d2b[R];
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int c = r * BRICK_GROUP + sub;
-        key[r] = ~0ull; li[r] = -1; P[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        d2b[r] = 0xffffffffu;
         const bool has = c < sp.n_cand;
         const int cc = has ? c : 0;
-        const long long cx = gx + bc.cand_dx[3 * cc], cy = gy + bc.cand_dx[3 * cc + 1], cz = gz + bc.cand_dx[3 * cc + 2];
-        const int sel = ((int)((cx >> 2) - b0x) << 2) | ((int)((cy >> 2) - b0y) << 1) | (int)((cz >> 2) - b0z);
+        const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
+        const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
+        const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
         // all 16 lanes take part in the shuffles
-        const int id = __shfl(my_id, sel & 7, BRICK_GROUP);
         const int base = __shfl(my_base, sel & 7, BRICK_GROUP);
-        const unsigned long long mask = __shfl(my_mask, sel & 7, BRICK_GROUP);
+        const unsigned int lo = __shfl(my_lo, sel & 7, BRICK_GROUP);
+        const unsigned int hi = __shfl(my_hi, sel & 7, BRICK_GROUP);
         if (!has) continue;
         bool ok = false;
         int l = -1;
         float4 E;
-        if (id >= 0) {
-            const int bit = (int)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
-            if ((mask >> bit) & 1ull) {
-                E = entries[base + __popcll(mask & ((1ull << bit) - 1ull))];
+        if (base >= 0) {
+            const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+            const unsigned int word = bit < 32 ? lo : hi;
+            if ((word >> (bit & 31)) & 1u) {
+                const unsigned int below = word & ((1u << (bit & 31)) - 1u);
+                E = entries[base + __popc(below) + (bit < 32 ? 0 : __popc(lo))];
                 l = __float_as_int(E.w);
                 ok = true;
             }
         } else {
-            ok = lookup_cell(sp, cx, cy, cz, d_cur, E, l);  // exact slow path for uncached bricks
+            ok = lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, E, l);  // exact slow path for uncached bricks
         }
         if (ok) {
             const float dx = E.x - qx, dy = E.y - qy, dz = E.z - qz;
             const float d2 = dist2_exact(dx, dy, dz);
             if (!(d2 > sp.max_valid_dist2)) {
-                key[r] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
-                li[r] = l;
-                P[r].x = -dx; P[r].y = -dy; P[r].z = -dz;
+                d2b[r] = __float_as_uint(d2);  // d2 >= 0: the bit pattern orders like the value
+                stage[r][threadIdx.x] = make_float4(-dx, -dy, -dz, __int_as_float(l));
                 ++cnt;
             }
         }
     }
-#pragma unroll
-    for (int o = BRICK_GROUP / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, BRICK_GROUP);
+    cnt = (int)row_sum_u32((unsigned int)cnt);
     if (active && sub == 0) nn_count[qi] = cnt;
 
+    // k rounds of a 16-lane tournament on (d2 bits, candidate order): two 32-bit row reductions
+    // on the DPP path per round (no LDS crossbar, no 64-bit keys)
     float4* __restrict__ out = nbr + (size_t)qq * k;
     for (int t = 0; t < k; ++t) {
-        unsigned long long best = ~0ull;
+        unsigned int bd = d2b[0];
+        int br = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) best = key[r] < best ? key[r] : best;
-        unsigned long long win = best;
-#pragma unroll
-        for (int o = BRICK_GROUP / 2; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(win, o, BRICK_GROUP);
-            win = other < win ? other : win;
-        }
-        if (win == ~0ull) {
+        for (int r = 1; r < R; ++r)
+            if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
+        const unsigned int wd = row_min_u32(bd);
+        if (wd == 0xffffffffu) {
             if (active && sub == 0)
                 for (int u = t; u < k; ++u) out[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             break;
         }
-        if (best == win) {
+        const unsigned int myc = bd == wd ? (unsigned int)(br * BRICK_GROUP + sub) : 0xffffffffu;
+        const unsigned int wc = row_min_u32(myc);
+        if (myc == wc) {  // exactly one lane of the row
+            if (active) out[t] = stage[br][threadIdx.x];
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (key[r] == win) {
-                    if (active) out[t] = make_float4(P[r].x, P[r].y, P[r].z, __int_as_float(li[r]));
-                    key[r] = ~0ull;
-                }
+                if (r == br) d2b[r] = 0xffffffffu;
         }
     }
 }
-
 }  // namespace pin
 
 using namespace pin;
