@@ -285,7 +285,7 @@ def main():
         "frames_per_sec_source_downsampled": round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,
         "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
-        "roofline": {"kernel": "gn_accumulate_mfma_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
+        "roofline": {"kernel": "gn_accumulate_quad_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
                      "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "avg_launch_ms": round(gn_ms, 4),
                      "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,

@@ -477,6 +477,10 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
 }
 
 
+}  // namespace pin
+#include "gn_quad.h"
+namespace pin {
+
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
 // implicit_reg (utils/tracker.py:656-679) and the bookkeeping of Tracker.tracking (:147-184).
 __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums, double* __restrict__ st,
@@ -694,7 +698,23 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
         ct.photo_weight = color->photo_weight;
     }
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
-    if (use_mfma_decoder()) {
+    if (use_mfma_decoder() && use_quad_gn() && f->weighted_first && ct.mode == 0) {
+        // persistent blocks, one per CU, 16-query tiles dealt round-robin to the SIMDs (gn_quad.h)
+        static const int n_cu = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            return v;
+        }();
+        const int tiles = cdiv(n, 16);
+        const dim3 grid(min(n_cu, cdiv(tiles, GQ_BLOCK / 64))), block(GQ_BLOCK);
+#define PIN_LAUNCH_GQ(HH, OO) \
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<HH, OO>), grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, \
+                       sdf_out, grad_out, state)
+        if (f->hidden == 64) { if (f->orient) PIN_LAUNCH_GQ(64, true); else PIN_LAUNCH_GQ(64, false); }
+        else { if (f->orient) PIN_LAUNCH_GQ(32, true); else PIN_LAUNCH_GQ(32, false); }
+#undef PIN_LAUNCH_GQ
+    } else if (use_mfma_decoder()) {
         const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
         PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
                         sdf_out, grad_out, state, ct);
