@@ -1,0 +1,74 @@
+// Device helpers of the brick cache shared by the search kernels (brick.hip) and the fused
+// Gauss-Newton tile kernel (gn_fused.h): directory lookup, brick keys, the exact per-cell probe.
+#pragma once
+#include "pin_common.h"
+
+namespace pin {
+
+constexpr unsigned long long BRICK_EMPTY = ~0ull;
+constexpr int BRICK_GROUP = 16;
+constexpr int BRICK_BLOCK = 256;
+
+// 16-lane (one DPP row) all-reductions: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned int row_min_u32(unsigned int v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned int row_sum_u32(unsigned int v) {
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    v += dpp_u32<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz) {
+    return ((unsigned long long)(unsigned)(bx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(by + (1 << 20)) << 21) |
+           (unsigned long long)(unsigned)(bz + (1 << 20));
+}
+__device__ __forceinline__ unsigned int mix64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+__device__ __forceinline__ int dir_find(const pin_brick_cache& bc, unsigned long long key) {
+    unsigned int h = mix64(key) & bc.dir_mask;
+    for (int probe = 0; probe < 64; ++probe) {
+        const unsigned long long k = bc.dir_keys[h];
+        if (k == key) return bc.dir_vals[h];
+        if (k == BRICK_EMPTY) return -1;
+        h = (h + 1) & bc.dir_mask;
+    }
+    return -1;
+}
+
+// the reference's lookup chain for one cell: table -> time filter -> index space
+__device__ __forceinline__ bool lookup_cell(const pin_search_params& sp, long long cx, long long cy, long long cz,
+                                            float d_cur, float4& P, int& l) {
+    const long long h = cx * PRIME0 + cy * PRIME1 + cz * PRIME2;
+    long long m = h % sp.buffer_size;
+    if (m < 0) m += sp.buffer_size;
+    const int j = sp.table[m];
+    if (j < 0) return false;
+    P = reinterpret_cast<const float4*>(sp.pos4)[j];
+    if (sp.travel_dist != nullptr) {
+        const float dts = sp.travel_dist[__float_as_int(P.w)];
+        if (!(fabsf(d_cur - dts) < sp.diff_travel_dist_local)) return false;
+    }
+    l = j;
+    if (sp.global2local != nullptr) {
+        l = sp.global2local[j];
+        if (l == PIN_NONLOCAL) l = 1 | PIN_NBR_QUIRK_BIT;
+    }
+    return l >= 0;
+}
+
+
+}  // namespace pin

@@ -680,6 +680,49 @@ using namespace pin;
         }                                                                                           \
     } while (0)
 
+// persistent blocks, one per CU (gn_quad.h)
+static int gq_cu_count() {
+    static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n_cu;
+}
+
+static int launch_quad(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                       const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                       float* grad_out, const double* state, hipStream_t s) {
+    const int tiles = cdiv(n, 16);
+    const dim3 grid(min(gq_cu_count(), cdiv(tiles, GQ_BLOCK / 64))), block(GQ_BLOCK);
+#define PIN_LQ(HH, OO) \
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<HH, OO>), grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, \
+                       sdf_out, grad_out, state)
+    if (f->hidden == 64) { if (f->orient) PIN_LQ(64, true); else PIN_LQ(64, false); }
+    else { if (f->orient) PIN_LQ(32, true); else PIN_LQ(32, false); }
+#undef PIN_LQ
+    return 0;
+}
+
+template <int H, int R>
+static int launch_iteration_inst(const pin_field* f, const pin_gn_params* gp, const pin_search_params* sp,
+                                 const pin_brick_cache* bc, const float* src, const float* labels, int32_t n, int k,
+                                 double* sums, const double* state, float* cur_out, float4* nbr_out, int32_t* nn_out,
+                                 hipStream_t s) {
+    constexpr int lds_bytes = gi_lds_floats<H>() * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_iteration_kernel<H, R>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "gn iteration kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    QuadPose pose;
+    memset(&pose, 0, sizeof(pose));
+    const int tiles = cdiv(n, 16);
+    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);
+    hipLaunchKernelGGL((gn_iteration_kernel<H, R>), grid, block, lds_bytes, s, *f, *gp, *sp, *bc, src, labels, n, k, sums, state,
+                       pose, cur_out, nbr_out, nn_out);
+    return 0;
+}
+
 static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color, const float* pts,
                      const float* nbr, const int32_t* nn_count, const float* labels, int32_t n, double* sums,
                      float* sdf_out, float* grad_out, const double* state, hipStream_t s) {
@@ -699,21 +742,7 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
     }
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     if (use_mfma_decoder() && use_quad_gn() && f->weighted_first && ct.mode == 0) {
-        // persistent blocks, one per CU, 16-query tiles dealt round-robin to the SIMDs (gn_quad.h)
-        static const int n_cu = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            return v;
-        }();
-        const int tiles = cdiv(n, 16);
-        const dim3 grid(min(n_cu, cdiv(tiles, GQ_BLOCK / 64))), block(GQ_BLOCK);
-#define PIN_LAUNCH_GQ(HH, OO) \
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<HH, OO>), grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, \
-                       sdf_out, grad_out, state)
-        if (f->hidden == 64) { if (f->orient) PIN_LAUNCH_GQ(64, true); else PIN_LAUNCH_GQ(64, false); }
-        else { if (f->orient) PIN_LAUNCH_GQ(32, true); else PIN_LAUNCH_GQ(32, false); }
-#undef PIN_LAUNCH_GQ
+        if (int e = launch_quad(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
     } else if (use_mfma_decoder()) {
         const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
         PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
@@ -839,6 +868,34 @@ extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp
     PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
     hipStream_t s = as_stream(stream);
     if (int e = launch_gn(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, nullptr, nullptr, state, s)) return e;
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gn_iteration(const pin_search_params* sp, const pin_brick_cache* bc, const pin_field* f,
+                                const pin_gn_params* gp, const float* src, int32_t n, int32_t k, const float* sdf_labels,
+                                double* sums, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
+                                void* stream) {
+    PIN_ENTER();
+    if (int e = check_field(f)) return e;
+    PIN_CHECK_ARG(sp && bc && gp && sums && state && src && n > 0, "bad arguments");
+    PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K && k == f->k, "k must equal the field's neighbour count (<= 8)");
+    PIN_CHECK_ARG(f->weighted_first && (f->out_dim == 0 || f->out_dim == 1), "fused iteration: weighted_first SDF field only");
+    PIN_CHECK_ARG(use_mfma_decoder(), "fused iteration needs the MFMA decoder (unset PIN_DECODER)");
+    PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && bc->cand_dx && bc->entries && f->feats, "empty map / NULL pointer");
+    const int per_lane = cdiv(sp->n_cand, 4);
+    if (f->orient != nullptr || per_lane > 21)
+        return fail(-3, "fused GN iteration: after-PGO fields / more than 84 candidate cells use the separate kernels");
+    hipStream_t s = as_stream(stream);
+    float4* nb4 = reinterpret_cast<float4*>(nbr_out);
+    int e;
+    if (f->hidden == 64)
+        e = per_lane <= 9 ? launch_iteration_inst<64, 9>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s)
+                          : launch_iteration_inst<64, 21>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s);
+    else
+        e = per_lane <= 9 ? launch_iteration_inst<32, 9>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s)
+                          : launch_iteration_inst<32, 21>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s);
+    if (e) return e;
     PIN_CHECK_LAUNCH();
     return 0;
 }
