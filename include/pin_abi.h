@@ -453,6 +453,17 @@ int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arrays* la, co
 int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
                                int32_t n_local, void* stream);
 
+/* Exact sparse Adam for the feature tables.  The optimiser state is created anew by every
+ * Mapper.mapping call (utils/mapper.py:615), so a row that no query of this call has touched yet
+ * has g = m = v = 0 and its dense update is exactly zero; pin_adam_step_rows skips those rows and
+ * is bit-identical to pin_adam_step over the whole table.  pin_mark_rows sets row_flags[idx] = 1
+ * for every valid neighbour of the kNN records of an iteration ([n_records][4] floats); the caller
+ * clears row_flags together with the optimiser state. */
+int pin_mark_rows(const float* nbr, int64_t n_records, uint8_t* row_flags, void* stream);
+int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_rows,
+                       int32_t row_width, const uint8_t* row_flags, int32_t step, float lr, float beta1,
+                       float beta2, float eps, int32_t zero_grad, void* stream);
+
 /* ---- Mapper.process_frame data path (utils/mapper.py:162-449) ------------------------------ */
 
 /* Bytes of workspace for the pool kernels on n elements (pin_new_sample_index needs n more). */

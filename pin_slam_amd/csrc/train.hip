@@ -687,6 +687,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// Exact sparse form of the same step for the neural-point feature tables.  Adam state is reset at every
+// Mapper.mapping call (mapper.py:615), so a row no query has touched since then has g = m = v = 0 and its
+// dense update is exactly p -= lr * 0 / (0 + eps) = 0: skipping it changes no bit.  `row_flags` marks the
+// rows touched so far in this call (mark_rows_kernel, from the kNN records of every training iteration).
+__global__ __launch_bounds__(256) void mark_rows_kernel(const float4* __restrict__ nbr, long total,
+                                                        unsigned char* __restrict__ row_flags) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int raw = __float_as_int(nbr[i].w);
+    if (raw >= 0) row_flags[raw & ~PIN_NBR_QUIRK_BIT] = 1;
+}
+
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, int row_width,
+                                                        const unsigned char* __restrict__ row_flags, float lr_over_bc1,
+                                                        float inv_sqrt_bc2, float b1, float b2, float eps, int zero_grad) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        if (!row_flags[i / row_width]) continue;
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - b1);
+        vi = vi * b2 + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - lr_over_bc1 * (mi / denom);
+        m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
 }  // namespace pin
 
 using namespace pin;
@@ -857,6 +888,34 @@ extern "C" int pin_adam_step(float* param, float* grad, float* exp_avg, float* e
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
                        (long)n, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, zero_grad);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_mark_rows(const float* nbr, int64_t n_records, uint8_t* row_flags, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_records >= 0, "n_records < 0");
+    if (n_records == 0) return 0;
+    PIN_CHECK_ARG(nbr && row_flags, "NULL pointer");
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n_records, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(nbr), (long)n_records, row_flags);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_rows,
+                                  int32_t row_width, const uint8_t* row_flags, int32_t step, float lr, float beta1,
+                                  float beta2, float eps, int32_t zero_grad, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_rows >= 0 && row_width >= 1 && step >= 1, "bad sizes");
+    if (n_rows == 0) return 0;
+    PIN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && row_flags, "NULL pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const long n = (long)n_rows * row_width;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       row_width, row_flags, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, zero_grad);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -146,6 +146,8 @@ class MapTrainer:
         self.gdec, self.gfeat = self.grad[:nd], self.grad[nd:]
         self.m = torch.zeros_like(self.grad)
         self.v = torch.zeros_like(self.grad)
+        # rows touched since the optimiser state was reset: Adam skips the others, bit-identically (ops.adam_step_rows)
+        self.dirty = torch.zeros((fs.feats.shape[0],), dtype=torch.uint8, device=dev)
         from .sharding import n_eik_global, shard_range
         start, _ = shard_range(self.bs, rank, world)
         self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
@@ -192,14 +194,20 @@ class MapTrainer:
             ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                  self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
                                  weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
-            ops.adam_step(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, self.lr, eps=self.adam_eps)
+            ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
+            ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
+                               eps=self.adam_eps)
             if self.c_train_dec:
                 ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad if self.train_decoder else self.gfeat)
         nd = self.gdec.numel()
-        ops.adam_step(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, self.lr, eps=self.adam_eps)
+        if self.world == 1:
+            ops.mark_rows(self.buf.nbr, self.dirty)
+            ops.adam_step_rows(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], self.dirty, step, self.lr, eps=self.adam_eps)
+        else:  # rows touched by the other ranks' shards arrive through the all-reduce: dense update
+            ops.adam_step(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, self.lr, eps=self.adam_eps)
         if self.train_decoder:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
@@ -209,6 +217,7 @@ class MapTrainer:
         self.m.zero_()
         self.v.zero_()
         self.grad.zero_()
+        self.dirty.zero_()
         if self.fc is not None:
             self.cm.zero_()
             self.cv.zero_()
@@ -219,6 +228,7 @@ class MapTrainer:
         iterations.  index_batches[i] is this rank's int32 shard of the i-th global batch."""
         self.m.zero_()
         self.v.zero_()
+        self.dirty.zero_()
         if self.world > 1:
             cert0 = self.fs.certainty.clone()
         for i, idx in enumerate(index_batches):

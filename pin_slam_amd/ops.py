@@ -382,6 +382,22 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=0.01, beta1=0.9, beta2=
                                    float(beta2), float(eps), int(bool(zero_grad)), _stream()), "pin_adam_step")
 
 
+def mark_rows(nbr: torch.Tensor, row_flags: torch.Tensor):
+    """row_flags[idx] = 1 for every valid neighbour of the kNN records `nbr` [Q, k, 4]."""
+    check(_lib.lib().pin_mark_rows(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(row_flags, torch.uint8), _stream()),
+          "pin_mark_rows")
+
+
+def adam_step_rows(param, grad, exp_avg, exp_avg_sq, row_flags, step, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15,
+                   zero_grad=True):
+    """Adam over the rows flagged in `row_flags` only (exact when the unflagged rows have g = m = v = 0)."""
+    rows, width = param.shape[0], param.numel() // param.shape[0]
+    check(_lib.lib().pin_adam_step_rows(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(exp_avg, torch.float32),
+                                        _ptr(exp_avg_sq, torch.float32), rows, width, _ptr(row_flags, torch.uint8), int(step),
+                                        float(lr), float(beta1), float(beta2), float(eps), int(bool(zero_grad)), _stream()),
+          "pin_adam_step_rows")
+
+
 def gather_batch(pool_coord, pool_label, pool_weight, pool_ts, index, out):
     """Mapper.get_batch gathers; `out` = (coord [n,3], label [n], weight [n] | None, ts [n] | None)."""
     coord, label, weight, ts = out

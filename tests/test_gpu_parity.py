@@ -295,3 +295,34 @@ def test_tracking_device_loop(gold, use_bricks):
     # host-loop and device-loop agree on the first step as well
     dT, cnt1, res1, _ = gn.step(src, d["reg_Tinit"])
     np.testing.assert_allclose(dT, d["reg_dT"], rtol=0, atol=1e-5)
+
+
+def test_sparse_adam_is_bit_identical_to_dense():
+    """pin_adam_step_rows + pin_mark_rows against the dense pin_adam_step over three iterations that touch
+    different row subsets (state reset before, as Mapper.mapping does): every bit of p, m, v equal."""
+    from pin_slam_amd import ops
+    torch.manual_seed(0)
+    rows, k, Q = 50_000, 8, 4000
+    p0 = torch.randn(rows + 1, 8, device="cuda")
+    pd, ps = p0.clone(), p0.clone()
+    md, vd, gd = (torch.zeros_like(p0) for _ in range(3))
+    ms, vs, gs = (torch.zeros_like(p0) for _ in range(3))
+    flags = torch.zeros(rows + 1, dtype=torch.uint8, device="cuda")
+    for step in range(1, 4):
+        idx = torch.randint(0, rows, (Q, k), device="cuda")
+        idx[torch.rand(Q, k, device="cuda") < 0.2] = -1  # invalid neighbours
+        nbr = torch.zeros((Q, k, 4), dtype=torch.float32, device="cuda")
+        nbr[..., 3] = idx.to(torch.int32).view(torch.float32) if False else torch.zeros(Q, k, device="cuda")
+        nbr.view(torch.int32)[..., 3] = idx.to(torch.int32)
+        g = torch.zeros_like(p0)
+        valid = idx[idx >= 0]
+        g[valid] = torch.randn(valid.numel(), 8, device="cuda")
+        gd.copy_(g); gs.copy_(g)
+        ops.adam_step(pd, gd, md, vd, step, 0.01, eps=1e-15)
+        ops.mark_rows(nbr, flags)
+        ops.adam_step_rows(ps, gs, ms, vs, flags, step, 0.01, eps=1e-15)
+        assert int(flags.sum()) == len(torch.unique(torch.cat([valid, torch.nonzero(flags).flatten()])))
+    for a, b in ((pd, ps), (md, ms), (vd, vs), (gd, gs)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert 0.05 < float(flags.float().mean()) < 0.9
+    assert not torch.equal(pd, p0)
