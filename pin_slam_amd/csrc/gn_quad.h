@@ -336,8 +336,12 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[21 + i] = wgt * J[i] * res;
             v[27] = wgt; v[28] = fabsf(res); v[29] = 1.f; v[30] = wgt * res * res; v[31] = 0.f;
+            // lane g keeps sums 4j + g.  Written as masked FMAs: a select chain over v[] is turned into a
+            // dynamically indexed private array (scratch memory) by the compiler
+            const float m0 = g == 0 ? 1.f : 0.f, m1 = g == 1 ? 1.f : 0.f, m2 = g == 2 ? 1.f : 0.f, m3 = g == 3 ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tot[j] += g == 0 ? v[4 * j] : g == 1 ? v[4 * j + 1] : g == 2 ? v[4 * j + 2] : v[4 * j + 3];
+            for (int j = 0; j < 8; ++j)
+                tot[j] += fmaf(m0, v[4 * j], fmaf(m1, v[4 * j + 1], fmaf(m2, v[4 * j + 2], m3 * v[4 * j + 3])));
         }
     }
 }
