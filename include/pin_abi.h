@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 3
+#define PIN_ABI_VERSION 4
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -104,6 +104,8 @@ typedef struct pin_brick_cache {
     int32_t max_bricks;
     int32_t max_entries;
     int32_t n_dilate;        /* = num_nei_cells (<= 2): bricks cover every cell within n of a local point */
+    uint64_t* dir_pack;      /* [dir_mask+1][4] what a query reads: key, mask, base (low 32 bits; -1 = not cached), pad --
+                                one 32-byte slot per probe instead of the key -> id -> mask/base chain */
 } pin_brick_cache;
 
 /* ---- the implicit field: feature tables + decoder (NeuralPoints.query_feature

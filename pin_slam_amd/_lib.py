@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 64
-PIN_ABI_VERSION = 3
+PIN_ABI_VERSION = 4
 
 vp = C.c_void_p
 
@@ -36,7 +36,7 @@ class BrickCacheC(C.Structure):
     _fields_ = [
         ("dir_keys", vp), ("dir_vals", vp), ("brick_keys", vp), ("brick_mask", vp), ("brick_base", vp),
         ("entries", vp), ("cand_dx", vp), ("dir_mask", C.c_uint32), ("max_bricks", C.c_int32),
-        ("max_entries", C.c_int32), ("n_dilate", C.c_int32),
+        ("max_entries", C.c_int32), ("n_dilate", C.c_int32), ("dir_pack", vp),
     ]
 
 

@@ -49,6 +49,31 @@ __device__ __forceinline__ int dir_find(const pin_brick_cache& bc, unsigned long
     return -1;
 }
 
+// What a query needs of a brick, from ONE 32-byte directory slot per probe (dir_pack, written by
+// brick_publish_kernel): base < 0 means "not cached" (absent, or dropped for lack of room) and sends
+// the cell to the exact probe.
+struct BrickInfo {
+    int base;
+    unsigned int lo, hi;
+};
+__device__ __forceinline__ BrickInfo dir_lookup(const pin_brick_cache& bc, unsigned long long key) {
+    BrickInfo r;
+    r.base = -1; r.lo = 0; r.hi = 0;
+    unsigned int h = mix64(key) & bc.dir_mask;
+    const ulonglong2* __restrict__ pack = reinterpret_cast<const ulonglong2*>(bc.dir_pack);
+    for (int probe = 0; probe < 64; ++probe) {
+        const ulonglong2 a = pack[2 * (size_t)h], b = pack[2 * (size_t)h + 1];  // key, mask | base, pad
+        if (a.x == key) {
+            r.base = (int)(unsigned int)b.x;
+            r.lo = (unsigned int)a.y; r.hi = (unsigned int)(a.y >> 32);
+            return r;
+        }
+        if (a.x == BRICK_EMPTY) return r;
+        h = (h + 1) & bc.dir_mask;
+    }
+    return r;
+}
+
 // the reference's lookup chain for one cell: table -> time filter -> index space
 __device__ __forceinline__ bool lookup_cell(const pin_search_params& sp, long long cx, long long cy, long long cz,
                                             float d_cur, float4& P, int& l) {

@@ -153,6 +153,21 @@ struct PoseB {
     int on;
 };
 
+// C: one 32-byte slot per directory entry with everything a query reads (see dir_lookup)
+__global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) {
+    const unsigned int h = blockIdx.x * 256 + threadIdx.x;
+    if (h > bc.dir_mask) return;
+    const unsigned long long key = bc.dir_keys[h];
+    unsigned long long mask = 0, base = 0xffffffffull;
+    if (key != BRICK_EMPTY) {
+        const int id = bc.dir_vals[h];
+        if (id >= 0 && id < bc.max_bricks) { mask = bc.brick_mask[id]; base = (unsigned long long)(unsigned int)bc.brick_base[id]; }
+    }
+    ulonglong2* pack = reinterpret_cast<ulonglong2*>(bc.dir_pack);
+    pack[2 * (size_t)h] = make_ulonglong2(key, mask);
+    pack[2 * (size_t)h + 1] = make_ulonglong2(base, 0ull);
+}
+
 template <int R>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,
@@ -193,12 +208,8 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     unsigned int my_lo = 0, my_hi = 0;
     if (sub < 8 && !far) {
         const int bx = b0x + (sub >> 2), by = b0y + ((sub >> 1) & 1), bz = b0z + (sub & 1);
-        const int id = dir_find(bc, brick_key(bx, by, bz));
-        if (id >= 0) {
-            const unsigned long long mk = bc.brick_mask[id];
-            my_lo = (unsigned int)mk; my_hi = (unsigned int)(mk >> 32);
-            my_base = bc.brick_base[id];
-        }
+        const BrickInfo bi = dir_lookup(bc, brick_key(bx, by, bz));
+        my_base = bi.base; my_lo = bi.lo; my_hi = bi.hi;
     }
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
     const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
@@ -284,7 +295,7 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     PIN_ENTER();
     PIN_CHECK_ARG(sp && bc && counters_out, "NULL pointer");
     PIN_CHECK_ARG(sp->n_points > 0 && sp->table && sp->pos4, "empty map");
-    PIN_CHECK_ARG(bc->dir_keys && bc->dir_vals && bc->brick_keys && bc->brick_mask && bc->brick_base && bc->entries,
+    PIN_CHECK_ARG(bc->dir_keys && bc->dir_vals && bc->brick_keys && bc->brick_mask && bc->brick_base && bc->entries && bc->dir_pack,
                   "brick cache buffers NULL");
     PIN_CHECK_ARG((bc->dir_mask & (bc->dir_mask + 1)) == 0 && bc->dir_mask > 0, "directory size must be a power of two");
     PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 3, "n_dilate must be in [0, 3]");
@@ -300,6 +311,7 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     const float prune = reach * reach * 1.02f;
     hipLaunchKernelGGL(brick_fill_kernel, dim3(cdiv(bc->max_bricks, 4 * FILL_PER_WAVE)), dim3(256), 0, s, *bc, *sp, prune,
                        counters_out);
+    hipLaunchKernelGGL(brick_publish_kernel, dim3(cdiv((long)bc->dir_mask + 1, 256)), dim3(256), 0, s, *bc);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -482,12 +482,8 @@ __device__ __forceinline__ void knn_quad(const pin_search_params& sp, const pin_
         int base = -1;
         unsigned int lo = 0, hi = 0;
         if (!far) {
-            const int id = dir_find(bc, brick_key(b0x + (b >> 2), b0y + ((b >> 1) & 1), b0z + (b & 1)));
-            if (id >= 0) {
-                const unsigned long long mk = bc.brick_mask[id];
-                lo = (unsigned int)mk; hi = (unsigned int)(mk >> 32);
-                base = bc.brick_base[id];
-            }
+            const BrickInfo bi = dir_lookup(bc, brick_key(b0x + (b >> 2), b0y + ((b >> 1) & 1), b0z + (b & 1)));
+            base = bi.base; lo = bi.lo; hi = bi.hi;
         }
         bricks[nq * 8 + b] = make_float4(__int_as_float(base), __uint_as_float(lo), __uint_as_float(hi), 0.f);
     }

@@ -122,6 +122,7 @@ class BrickCache:
             dsize *= 2
         self.dir_keys = torch.empty(dsize, dtype=torch.int64, device=d)
         self.dir_vals = torch.empty(dsize, dtype=torch.int32, device=d)
+        self.dir_pack = torch.empty((dsize, 4), dtype=torch.int64, device=d)
         self.brick_keys = torch.empty(max_bricks, dtype=torch.int64, device=d)
         self.brick_mask = torch.empty(max_bricks, dtype=torch.int64, device=d)
         self.brick_base = torch.empty(max_bricks, dtype=torch.int32, device=d)
@@ -133,6 +134,7 @@ class BrickCache:
         bc.dir_keys, bc.dir_vals, bc.brick_keys = self.dir_keys.data_ptr(), self.dir_vals.data_ptr(), self.brick_keys.data_ptr()
         bc.brick_mask, bc.brick_base, bc.entries = self.brick_mask.data_ptr(), self.brick_base.data_ptr(), self.entries.data_ptr()
         bc.cand_dx = self.cand_dx.data_ptr()
+        bc.dir_pack = self.dir_pack.data_ptr()
         bc.dir_mask, bc.max_bricks, bc.max_entries, bc.n_dilate = self.dsize - 1, self.max_bricks, self.max_entries, self.n_dilate
         return bc
 
