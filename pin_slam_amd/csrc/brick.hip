@@ -214,9 +214,9 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
     const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
 
-    // accepted candidates: distance bits in registers, (q - P, index) records staged in LDS so that
-    // the winner of a round fetches its record with a dynamic index instead of a select chain
-    __shared__ float4 stage[R][BRICK_BLOCK];
+    // accepted candidates: only the distance bits stay (registers); the k winners' entries are fetched
+    // again at the end (cache hits), one winner per lane -- no LDS staging, so the occupancy is set by
+    // the ~40 VGPRs alone and more waves hide the dependent-load latency this kernel is bound by
     unsigned int d2b[R];
     int cnt = 0;
 #pragma unroll
@@ -253,7 +253,6 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
             const float d2 = dist2_exact(dx, dy, dz);
             if (!(d2 > sp.max_valid_dist2)) {
                 d2b[r] = __float_as_uint(d2);  // d2 >= 0: the bit pattern orders like the value
-                stage[r][threadIdx.x] = make_float4(-dx, -dy, -dz, __int_as_float(l));
                 ++cnt;
             }
         }
@@ -262,8 +261,8 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     if (active && sub == 0) nn_count[qi] = cnt;
 
     // k rounds of a 16-lane tournament on (d2 bits, candidate order): two 32-bit row reductions
-    // on the DPP path per round (no LDS crossbar, no 64-bit keys)
-    float4* __restrict__ out = nbr + (size_t)qq * k;
+    // on the DPP path per round (no LDS crossbar, no 64-bit keys); lane t remembers winner t
+    int mine = -1;
     for (int t = 0; t < k; ++t) {
         unsigned int bd = d2b[0];
         int br = 0;
@@ -271,19 +270,42 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         for (int r = 1; r < R; ++r)
             if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
         const unsigned int wd = row_min_u32(bd);
-        if (wd == 0xffffffffu) {
-            if (active && sub == 0)
-                for (int u = t; u < k; ++u) out[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            break;
-        }
+        if (wd == 0xffffffffu) break;
         const unsigned int myc = bd == wd ? (unsigned int)(br * BRICK_GROUP + sub) : 0xffffffffu;
         const unsigned int wc = row_min_u32(myc);
         if (myc == wc) {  // exactly one lane of the row
-            if (active) out[t] = stage[br][threadIdx.x];
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (r == br) d2b[r] = 0xffffffffu;
         }
+        if (sub == t) mine = (int)wc;
+    }
+    // lane t < k publishes record t: the winner's entry again (same bits as in the candidate pass)
+    {
+        const int cc = mine >= 0 ? mine : 0;
+        const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
+        const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
+        const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
+        const int base = __shfl(my_base, sel & 7, BRICK_GROUP);
+        const unsigned int lo = __shfl(my_lo, sel & 7, BRICK_GROUP);
+        const unsigned int hi = __shfl(my_hi, sel & 7, BRICK_GROUP);
+        float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (mine >= 0) {
+            float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
+            int l = -1;
+            if (base >= 0) {
+                const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+                const unsigned int word = bit < 32 ? lo : hi;
+                const unsigned int below = word & ((1u << (bit & 31)) - 1u);
+                E = entries[base + __popc(below) + (bit < 32 ? 0 : __popc(lo))];
+                l = __float_as_int(E.w);
+            } else {
+                lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, E, l);
+            }
+            const float dx = E.x - qx, dy = E.y - qy, dz = E.z - qz;
+            rec = make_float4(-dx, -dy, -dz, __int_as_float(l));
+        }
+        if (active && sub < k) nbr[(size_t)qq * k + sub] = rec;
     }
 }
 }  // namespace pin
