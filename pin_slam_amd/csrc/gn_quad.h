@@ -22,7 +22,7 @@
 
 namespace pin {
 
-constexpr int GQ_BLOCK = 1024;
+constexpr int GQ_BLOCK = 768;
 
 template <int H>
 struct QuadDecoder {
@@ -578,7 +578,7 @@ struct QuadPose { float m[12]; int on; };
 // happens when every wave searches, gathers and decodes its own tile.  Slots form a ring; per-slot
 // sequence numbers in LDS (ready / done) are the only synchronisation, all 16 waves are resident.
 constexpr int GI_SLOTS = 24;            // tile slots per CU (one tile = 16 queries)
-constexpr int GI_PRODUCERS = 8;
+constexpr int GI_PRODUCERS = 6;
 template <int H>
 __host__ __device__ constexpr int gi_lds_floats() {
     return QuadDecoder<H>::TOTAL + (GQ_BLOCK / 64) * PIN_GN_NSUMS + GI_SLOTS * 16 * GQ_ROW * 4 + GI_PRODUCERS * 16 * 8 * 4 +
