@@ -180,34 +180,33 @@ def main():
     stats = {}
     state = {"fid": 1, "cloud": None, "src": None}
 
+    stage_events = []  # per timed frame: 5 events at the stage boundaries (no host sync between the stages)
+
     def frame(timed, hooks=(None, None), source_downsampled=False):
         fid = state["fid"]
         state["fid"] += 1
         ds.processed_frame = fid
-        t0 = time.perf_counter()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        if ev: ev[0].record()
         if args.stages == "all" or state["cloud"] is None:
             pc, _, src, _ = prep(raw, raw_ts, last_odom_tran=last_odom, frame_id=fid)
             state["cloud"], state["src"] = pc, src
             state["xyz"] = pc[:, :3].contiguous()
         pc = state["cloud"]
         reg = state["src"] if source_downsampled else state["xyz"]
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        if ev: ev[1].record()
         gn = trk._engine(reg.shape[0], gp, cfg.reg_lm_lambda)
         gn.on_knn, gn.on_gn = hooks
         T, cnt, res_cm, its, _, _ = gn.track(reg, T_init, args.reg_iters, early_exit=False)
         gn.on_knn = gn.on_gn = None
-        t2 = time.perf_counter()
+        if ev: ev[2].record()
         if args.stages == "all":
             mp.process_frame(pc, None, pose_t, fid)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
+        if ev: ev[3].record()
         mp.mapping(args.map_iters)
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        if timed:
-            for name, dt in (("preprocess", t1 - t0), ("odometry", t2 - t1), ("map_prep", t3 - t2), ("mapping", t4 - t3)):
-                stats.setdefault(name, []).append(dt)
+        if ev:
+            ev[4].record()
+            stage_events.append(ev)
         stats["last"] = (T, cnt, res_cm, its, reg.shape[0], gn)
 
     def barrier():
@@ -231,7 +230,8 @@ def main():
         elapsed = float(t.item())
     T, cnt, res_cm, its, n_reg, gn = stats["last"]
     nn_mean = float(gn.nn[:n_reg].float().mean().item())
-    stage_ms = {n: round(1e3 * float(np.mean(stats[n])), 3) for n in ("preprocess", "odometry", "map_prep", "mapping")}
+    names = ("preprocess", "odometry", "map_prep", "mapping")
+    stage_ms = {n: round(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in stage_events])), 3) for i, n in enumerate(names)}
     pool_now, new_now, n_src = mp.pool_sample_count, (0 if mp.new_idx is None else int(mp.new_idx.shape[0])), int(state["src"].shape[0])
 
     # the reference's own odometry workload: register the source-down-sampled subset (reported, not `value`)
@@ -281,7 +281,7 @@ def main():
                    "stages": args.stages,
                    "parallelism": "1 GPU" if world == 1 else f"preprocess/odometry/map-prep replicas x{world}, mapper dp{world} (RCCL all-reduce)"},
         "stage_ms_per_frame": stage_ms,
-        "mapper_samples_per_sec": round(world * args.bs * args.map_iters / float(np.mean(stats["mapping"])), 1),
+        "mapper_samples_per_sec": round(world * args.bs * args.map_iters / (1e-3 * stage_ms["mapping"]), 1),
         "frames_per_sec_source_downsampled": round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,
         "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin
     for (int u = 0; u < FILL_PER_WAVE; ++u) {
         const int b = b0 + u;
         if (b < nb) {
-            if (lane == 0) { bc.brick_mask[b] = mask[u]; bc.brick_base[b] = base; }
+            // a brick whose entries do not fit is published as "not cached": its cells take the exact probe,
+            // so an overflow costs time, never correctness, and the host may learn about it a frame later
+            const bool fits = base + __popcll(mask[u]) <= bc.max_entries;
+            if (lane == 0) { bc.brick_mask[b] = mask[u]; bc.brick_base[b] = fits ? base : -1; }
             if (l[u] >= 0) {
                 const int e = base + __popcll(mask[u] & ((1ull << lane) - 1ull));
                 if (e < bc.max_entries)
@@ -161,7 +164,10 @@ __global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) 
     unsigned long long mask = 0, base = 0xffffffffull;
     if (key != BRICK_EMPTY) {
         const int id = bc.dir_vals[h];
-        if (id >= 0 && id < bc.max_bricks) { mask = bc.brick_mask[id]; base = (unsigned long long)(unsigned int)bc.brick_base[id]; }
+        if (id >= 0 && id < bc.max_bricks && bc.brick_base[id] >= 0) {
+            mask = bc.brick_mask[id];
+            base = (unsigned long long)(unsigned int)bc.brick_base[id];
+        }
     }
     ulonglong2* pack = reinterpret_cast<ulonglong2*>(bc.dir_pack);
     pack[2 * (size_t)h] = make_ulonglong2(key, mask);

@@ -181,16 +181,23 @@ class Mapper(_Base):
         self.cur_sample_count = n_new
         self.pool_sample_count = n_hist
 
-        # map growth (mapper.py:236-262)
+        # map growth (mapper.py:236-262).  The window mask of the pool filter does not depend on the map, so it
+        # is queued first and its kept-count comes back in the same read-back as the surface-point count.
         tail = slice(n_hist, n_hist + n_new)
         lab_new = p.bufs[0]["sdf_label"][tail]
-        if c.from_sample_points:
-            if c.from_all_samples:  # the reference passes sensor-frame samples here (mapper.py:238)
-                update_points = p.bufs[0]["coord"][tail]
-            else:
-                sel, cnt = ops.select_surface_points(p.bufs[0]["global_coord"][tail], lab_new,
-                                                     np.float32(c.surface_sample_range_m * c.map_surface_ratio))
-                update_points = sel[:int(cnt.item())]
+        filtering = (frame_id + 1) % c.pool_filter_freq == 0
+        sel = cnt = None
+        if c.from_sample_points and not c.from_all_samples:
+            sel, cnt = ops.select_surface_points(p.bufs[0]["global_coord"][tail], lab_new,
+                                                 np.float32(c.surface_sample_range_m * c.map_surface_ratio))
+        if filtering:
+            p.filter_begin(pose_np[:3, 3], c.window_radius, int(c.pool_capacity))
+        kept = None
+        if sel is not None:
+            both = torch.stack((cnt[0], p.counts[0])).tolist() if filtering else [int(cnt.item()), None]
+            update_points, kept = sel[:both[0]], both[1]
+        elif c.from_sample_points:  # from_all_samples: the reference passes sensor-frame samples here (mapper.py:238)
+            update_points = p.bufs[0]["coord"][tail]
         else:
             update_points = torch.empty((scan.shape[0], 3), dtype=torch.float32, device=self.device)
             ops.transform_points(scan, pose_np, update_points)
@@ -201,9 +208,9 @@ class Mapper(_Base):
         npts.record_memory(verbose=(not self.silence))
         self.determine_used_pose()
 
-        # K13: pool window + capacity (mapper.py:303-360)
-        if (frame_id + 1) % c.pool_filter_freq == 0:
-            self.pool_sample_count, self.cur_sample_count = p.filter(pose_np[:3, 3], c.window_radius, int(c.pool_capacity))
+        # K13: pool window + capacity (mapper.py:303-360); the discard draw comes after update's, as in the reference
+        if filtering:
+            self.pool_sample_count, self.cur_sample_count = p.filter_finish(int(c.pool_capacity), kept=kept)
         else:
             self.cur_sample_count, self.pool_sample_count = n_new, p.n
         self._publish_pool()

@@ -113,6 +113,8 @@ class BrickCache:
         self.counters = torch.zeros(4, dtype=torch.int32, device=device)
         self.mode = None
         self.n_bricks = self.n_entries = 0
+        self._host = self._event = None
+        self._pending = False
         self._alloc(1 << 16, 1 << 18)
 
     def _alloc(self, max_bricks, max_entries):
@@ -138,21 +140,39 @@ class BrickCache:
         bc.dir_mask, bc.max_bricks, bc.max_entries, bc.n_dilate = self.dsize - 1, self.max_bricks, self.max_entries, self.n_dilate
         return bc
 
-    def build(self, st: "SearchState", time_filtering=True, local=True):
-        """(Re)build for the current map; grows the buffers and retries on overflow (one host
-        sync per build, once per frame)."""
+    def build(self, st: "SearchState", time_filtering=True, local=True, wait: bool = False):
+        """(Re)build for the current map, without a host sync: the counters are read back asynchronously and
+        looked at by the NEXT build, which grows the buffers if this one overflowed.  Until then nothing is
+        wrong -- bricks that did not fit are published as "not cached" and their cells take the exact probe
+        (identical results, slower).  wait=True checks (and rebuilds) right away."""
+        self._settle()
         sp = st.params(time_filtering=time_filtering, local=local)
-        while True:
-            bc = self.params()
-            check(_lib.lib().pin_brick_build(C.byref(sp), C.byref(bc), self.counters.data_ptr(), _stream()), "pin_brick_build")
-            nb, ne, flags, _ = self.counters.tolist()
-            if flags == 0 and nb <= self.max_bricks and ne <= self.max_entries:
-                break
-            self._alloc(max(self.max_bricks, int(nb * 1.5) + 1024) if (flags & 3 or nb > self.max_bricks) else self.max_bricks,
-                        max(self.max_entries, int(ne * 1.5) + 1024))
-        self.n_bricks, self.n_entries = nb, ne
+        bc = self.params()
+        check(_lib.lib().pin_brick_build(C.byref(sp), C.byref(bc), self.counters.data_ptr(), _stream()), "pin_brick_build")
+        if self._host is None:
+            self._host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._event = torch.cuda.Event()
+        self._host.copy_(self.counters, non_blocking=True)
+        self._event.record()
+        self._pending = True
         self.mode = (bool(time_filtering), bool(local), st.n_points, st.cur_ts)
+        if wait and self._settle():
+            return self.build(st, time_filtering, local, wait=True)
         return self
+
+    def _settle(self) -> bool:
+        """Look at the counters of the last build; grow the buffers if it overflowed (returns True then)."""
+        if not getattr(self, "_pending", False):
+            return False
+        self._event.synchronize()
+        self._pending = False
+        nb, ne, flags, _ = self._host.tolist()
+        self.n_bricks, self.n_entries = nb, ne
+        if flags == 0 and nb <= self.max_bricks and ne <= self.max_entries:
+            return False
+        self._alloc(max(self.max_bricks, int(nb * 1.5) + 1024) if (flags & 3 or nb > self.max_bricks) else self.max_bricks,
+                    max(self.max_entries, int(ne * 1.5) + 1024))
+        return True
 
 
 def knn_query(st: SearchState, query: torch.Tensor, k: int, time_filtering=True, local=True,

@@ -126,12 +126,18 @@ class SamplePool:
     # ------------------------------------------------------------------ K13
     def filter(self, origin, radius: float, capacity: int, discard_index: Optional[torch.Tensor] = None):
         """Distance window + random discard + ordered compaction (utils/mapper.py:303-346).
-        Returns (pool_sample_count, cur_sample_count).  One 8-byte read-back (two when the
-        capacity is exceeded, like the reference's .shape[0] / .item() syncs)."""
+        Returns (pool_sample_count, cur_sample_count)."""
+        self.filter_begin(origin, radius, capacity)
+        return self.filter_finish(capacity, discard_index)
+
+    def filter_begin(self, origin, radius: float, capacity: int):
+        """Window mask (+ list of kept indices when the capacity can be exceeded): launch only.  The kept
+        count lands in `self.counts[0]`; callers that have other read-backs pending fetch them together."""
         L = _lib.lib()
         n, dev = self.n, self.device
+        self._over = False
         if n == 0:
-            return 0, 0
+            return
         if self.mask is None or self.mask.numel() < self.cap:
             self.mask = torch.empty((self.cap,), dtype=torch.uint8, device=dev)
             self.true_index = None
@@ -139,16 +145,27 @@ class SamplePool:
         if self.bufs[1] is None or self.bufs[1]["sdf_label"].shape[0] < self.cap:
             self.bufs[1] = self._alloc(self.cap)
         o = np.ascontiguousarray(np.asarray(origin, dtype=np.float64))
-        stream = ops._stream()
         over = n > capacity  # only then can the window keep more than `capacity` samples
         if over and (self.true_index is None or self.true_index.numel() < self.cap):
             self.true_index = torch.empty((self.cap,), dtype=torch.int32, device=dev)
+        self._over = over
+        check(L.pin_pool_window_mask(self.bufs[0]["global_coord"].data_ptr(), n, o.ctypes.data, float(radius),
+                                     self.mask.data_ptr(), self.true_index.data_ptr() if over else None,
+                                     self.counts.data_ptr(), self.ws.data_ptr(), self.ws.numel(), ops._stream()),
+              "pin_pool_window_mask")
+
+    def filter_finish(self, capacity: int, discard_index: Optional[torch.Tensor] = None, kept: Optional[int] = None):
+        """Random discard (the reference's torch.randint draw) + compaction + the two counts (one read-back;
+        one more for `kept` if the caller has not fetched it)."""
+        L = _lib.lib()
+        n, dev = self.n, self.device
+        if n == 0:
+            return 0, 0
+        stream = ops._stream()
         src = self.bufs[0]
-        check(L.pin_pool_window_mask(src["global_coord"].data_ptr(), n, o.ctypes.data, float(radius), self.mask.data_ptr(),
-                                     self.true_index.data_ptr() if over else None, self.counts.data_ptr(),
-                                     self.ws.data_ptr(), self.ws.numel(), stream), "pin_pool_window_mask")
-        if over:
-            kept = int(self.counts[0].item())
+        if self._over:
+            if kept is None:
+                kept = int(self.counts[0].item())
             if kept > capacity:
                 nd = kept - capacity
                 if discard_index is None:

@@ -18,7 +18,7 @@ N = 100_000
 scan = dev(synth.make_scan(m, n=N))
 key = torch.floor(scan / 0.4).long()
 scan = scan[torch.argsort((key[:, 0] + 4096) + ((key[:, 1] + 4096) << 14) + ((key[:, 2] + 4096) << 28))].contiguous()
-bricks = ops.BrickCache(dx, 2).build(st)
+bricks = ops.BrickCache(dx, 2).build(st, wait=True)
 L = _lib.lib()
 state = torch.zeros(64, dtype=torch.float64, device="cuda")
 T0 = np.eye(4)

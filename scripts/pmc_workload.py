@@ -33,7 +33,7 @@ for _ in range(3):
     b.copy_(a)
 torch.cuda.synchronize()
 out = None
-bricks = ops.BrickCache(dx, 2).build(st)
+bricks = ops.BrickCache(dx, 2).build(st, wait=True)
 for i in range(10):
     nbr, nn, cur = ops.knn_query(st, scan, 8, pose=np.eye(4), out=out)       # direct hash probe (r01 a-c)
     nbr, nn, cur = ops.knn_query(st, scan, 8, pose=np.eye(4), out=out, bricks=bricks)  # brick cache

@@ -31,7 +31,7 @@ def test_bricks_equal_direct_probe_on_fixtures(case):
     d = G.load(case)
     st = U.search_state(d)
     k = int(d["query_nn_k"])
-    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st)
+    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st, wait=True)
     assert bricks.n_bricks > 100 and bricks.n_entries > 1000
     rng = np.random.default_rng(0)
     far = rng.uniform(-200, 200, (500, 3)).astype(np.float32)          # mostly outside the cached bricks
@@ -50,7 +50,7 @@ def test_bricks_reproduce_nonlocal_quirk():
                                  travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
                                  diff_travel_dist_local=d["diff_travel_dist_local"], reboot_ts=0)
     st = dataclasses.replace(U.search_state(d), global2local=U.dev(U.g2l_to_device_format(g2l, np.append(mask, True))))
-    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st)
+    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st, wait=True)
     nbr, nn, _ = _same(st, U.dev(d["query"]), 8, bricks)
     _, idx, flag = U.nbr_split(nbr)
     assert flag.sum() > 50
@@ -61,7 +61,7 @@ def test_bricks_mode_is_checked_and_global_queries_use_direct_path():
     from tests import gpu_util as U
     d = G.load("c2_wf")
     st = U.search_state(d)
-    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st)
+    bricks = ops.BrickCache(d["neighbor_dx"], 2).build(st, wait=True)
     with pytest.raises(RuntimeError):
         ops.knn_query(st, U.dev(d["query"]), 8, time_filtering=False, local=False, bricks=bricks)
     b2 = ops.BrickCache(d["neighbor_dx"], 2).build(st, time_filtering=False, local=False)
@@ -82,7 +82,7 @@ def test_bricks_large_synthetic_map():
                          n_points=P, resolution=0.4, max_valid_dist2=mv,
                          travel_dist=torch.zeros(1, device="cuda"), cur_ts=0, diff_travel_dist_local=400.0,
                          global2local=g2l)
-    bricks = ops.BrickCache(dx, 2).build(st)
+    bricks = ops.BrickCache(dx, 2).build(st, wait=True)
     scan = synth.make_scan(m, n=50_000)
     pool, _ = synth.make_pool(m, n=50_000, sigma=0.6)
     for pts in (scan, pool):
@@ -102,7 +102,7 @@ def test_fused_gn_iteration_matches_separate_kernels():
     for case in ("c2_wf", "c3_bigtable"):
         d = G.load(case)
         st, fs = U.search_state(d), U.field_state(d, local=True)
-        bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st)
+        bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st, wait=True)
         k = int(d["query_nn_k"])
         rng = np.random.default_rng(3)
         src = torch.from_numpy(np.concatenate([d["query"], d["query"] + rng.normal(0, 0.3, d["query"].shape).astype(np.float32)])).cuda()

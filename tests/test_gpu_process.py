@@ -173,13 +173,13 @@ def test_dropin_process_frame_matches_oracle(monkeypatch):
     ds = _Dataset(nfr)
     mp = Mapper(cfg, ds, npts, {"sdf": Decoder(cfg, 32, 1, 1), "semantic": None, "color": None})
     snap = {}
-    orig_filter = P.SamplePool.filter
+    orig_filter = P.SamplePool.filter_begin
 
     def spy_filter(self, *a, **k):
         snap["global"] = self.view("global_coord").cpu().numpy().copy()
         return orig_filter(self, *a, **k)
 
-    monkeypatch.setattr(P.SamplePool, "filter", spy_filter)
+    monkeypatch.setattr(P.SamplePool, "filter_begin", spy_filter)
     state = dict(table=np.full(B, -1, np.int64), positions=np.zeros((0, 3), np.float32),
                  ts_create=np.zeros(0, np.int32), ts_update=np.zeros(0, np.int32))
     pools = {k: np.zeros((0, 3) if "coord" in k else (0,), np.int32 if k == "time_pool" else np.float32) for k in POOLS}
