@@ -597,6 +597,40 @@ def gen_preprocess():
 
 
 
+def gen_mesher():
+    """(10) Mesher.query_points (utils/mesher.py:40-164): bulk forward-only SDF queries + marching-cubes
+    mask over a regular grid that reaches into empty space, global and local index space, both
+    weighting modes.  Map geometry = the c2_wf / kitti_nwf fixtures (seeded build; checked)."""
+    import importlib
+    out = {}
+    for case in ("c2_wf", "kitti_nwf"):
+        m, cfg, dec, npts, gen = build(case)
+        ref = dict(np.load(os.path.join(OUT, case + ".npz")))
+        # geometry (positions, table, local map) is reproduced bit for bit; the reference's multi-threaded
+        # pre-training is not, so the trained arrays travel with this fixture
+        assert np.array_equal(ref["neural_points"], t2n(npts.neural_points)) and np.array_equal(ref["local_mask"], t2n(npts.local_mask))
+        out[case + "_geo_features"] = t2n(npts.geo_features)
+        out[case + "_local_geo_features"] = t2n(npts.local_geo_features.data)
+        out[case + "_dec_flat"] = flat_decoder(dec)
+        sys.path.insert(0, R.REF_ROOT)
+        try:
+            mm = importlib.import_module("utils.mesher")
+        finally:
+            sys.path.remove(R.REF_ROOT)
+        mesher = mm.Mesher(cfg, npts, {"sdf": dec, "semantic": None, "color": None})
+        ax = torch.arange(4.0, 26.0, 0.55)
+        az = torch.arange(-3.2, 0.4, 0.45)
+        grid = torch.stack(torch.meshgrid(ax, torch.arange(-9.0, 9.0, 0.55), az, indexing="ij"), -1).reshape(-1, 3).float()
+        out[case + "_grid"] = t2n(grid)
+        for loc in (False, True):
+            sdf, _, _, mask = mesher.query_points(grid, 4096, True, False, False, True, query_locally=loc,
+                                                  mask_min_nn_count=4, out_torch=True)
+            out[f"{case}_sdf_{'local' if loc else 'global'}"] = t2n(sdf)
+            out[f"{case}_mask_{'local' if loc else 'global'}"] = t2n(mask)
+    return out
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -622,6 +656,11 @@ def main():
                   "new", [len(d[f"f{t}_new_idx"]) for t in range(int(d["n_frames"]))],
                   "discard", [len(d[f"f{t}_discard_index"]) for t in range(int(d["n_frames"]))],
                   "adaptive", [int(d[f"f{t}_adaptive_iter_offset"]) for t in range(int(d["n_frames"]))])
+    if only in (None, "mesher"):
+        d = gen_mesher()
+        path = os.path.join(OUT, "mesher.npz")
+        np.savez_compressed(path, **d)
+        print("mesher ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", {k: (v.shape, float(np.mean(v != 0))) for k, v in d.items() if "mask" in k})
     if only in (None, "preprocess"):
         d = gen_preprocess()
         path = os.path.join(OUT, "preprocess.npz")

@@ -832,3 +832,13 @@ def deskewing(points, ts, pose, ts_mid_pose=0.5):
     Rm = np.eye(3)[None] + np.sin(a)[:, None, None] * K[None] + (1 - np.cos(a))[:, None, None] * (K @ K)[None]
     out = np.einsum("nij,nj->ni", Rm.astype(F32), p[:, :3]).astype(F32) + (t[:, None] * T[:3, 3][None, :]).astype(F32)
     return out.astype(F32)
+
+
+# --------------------------------------------------------------------------- Mesher.query_points (utils/mesher.py:40-164)
+def mesher_query(points, search, feats, positions, params, sdf_scale, k, weighted_first=True, global2local=None,
+                 mask_min_nn_count=4):
+    """Forward-only bulk query: (sdf [N] with 0 where no neighbour was found, marching-cubes mask [N])."""
+    sdf, _, _, nn, _ = query_sdf(points, search, feats, positions, params, sdf_scale, k, weighted_first=weighted_first,
+                                 global2local=global2local, with_grad=False, dtype=np.float32)
+    sdf = np.where(nn >= 1, sdf, 0.0).astype(F32)
+    return sdf, nn >= mask_min_nn_count

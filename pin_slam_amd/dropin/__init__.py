@@ -1,7 +1,7 @@
 """Drop-in mirrors of the reference's hot-path classes.
 
-``install(reference_root)`` makes ``model.neural_points``, ``model.decoder``, ``utils.mapper``
-and ``utils.tracker`` resolve to this package while every other ``model.*`` / ``utils.*`` /
+``install(reference_root)`` makes ``model.neural_points``, ``model.decoder``, ``utils.mapper``,
+``utils.tracker`` and ``utils.mesher`` resolve to this package while every other ``model.*`` / ``utils.*`` /
 ``dataset.*`` module keeps resolving to the reference tree, so the reference's ``pin_slam.py``
 runs unchanged.  Nothing is copied from the reference."""
 from __future__ import annotations
@@ -11,7 +11,7 @@ import os
 import sys
 import types
 
-_OURS = ("model.decoder", "model.neural_points", "utils.tracker", "utils.mapper")
+_OURS = ("model.decoder", "model.neural_points", "utils.tracker", "utils.mapper", "utils.mesher")
 
 
 def install(reference_root: str):

@@ -70,13 +70,16 @@ def test_dropin_call_surface_matches_reference():
              (ref["Decoder"], mods["model.decoder"].Decoder, ["__init__", "mlp", "sdf", "regress_color", "sem_label_prob"]),
              (ref["Tracker"], mods["utils.tracker"].Tracker, ["__init__", "tracking", "query_source_points", "registration_step"]),
              (ref["Mapper"], um.Mapper, ["__init__", "mapping", "sdf", "sdf_batch", "get_batch", "process_frame",
-                                         "determine_used_pose", "init_pool", "free_pool"])]
+                                         "determine_used_pose", "init_pool", "free_pool"]),
+             # the drop-in Mesher inherits the reference class: its overrides must keep the inherited signatures
+             (mods["utils.mesher"].Mesher.__mro__[1], mods["utils.mesher"].Mesher, ["__init__", "query_points"])]
     for rcls, ocls, names in pairs:
         for n in names:
             rp = list(inspect.signature(getattr(rcls, n)).parameters)
             op = list(inspect.signature(getattr(ocls, n)).parameters)
             assert rp == op, (rcls.__name__, n, rp, op)
     assert um.Mapper.__mro__[1].__name__ == "Mapper"  # inherits the reference's pool management
+    assert mods["utils.mesher"].Mesher.__mro__[1].__name__ == "Mesher" and hasattr(mods["utils.mesher"].Mesher, "get_query_from_bbx")
     # restore the plain reference namespace for the other tests
     import sys
     for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:

@@ -219,3 +219,38 @@ def test_mini_slam_loop_with_colour():
     assert abs(T[2, 3] - T_true[2, 3]) < 0.01, T
     # the colour texture makes the in-plane translation observable as well
     assert np.abs(T[:2, 3] - T_true[:2, 3]).max() < 0.03, T
+
+
+@pytest.mark.parametrize("case", ["c2_wf", "kitti_nwf"])
+@pytest.mark.parametrize("local", [False, True])
+def test_mesher_query_points_matches_reference(case, local):
+    """Drop-in Mesher.query_points (fused search + decode, chunked) against the reference's output on a grid
+    that reaches into unobserved space: mask identical, SDF within 1e-4, zeros where nothing is near."""
+    import ctypes as C
+    from pin_slam_amd import _lib, ops
+    from pin_slam_amd.dropin.utils.mesher import Mesher
+    from tests import gpu_util as U
+    d, mz = G.load(case), G.load("mesher")
+    st = U.search_state(d)
+    d2 = dict(d)
+    d2["geo_features"], d2["local_geo_features"], d2["dec_flat"] = (mz[case + "_geo_features"], mz[case + "_local_geo_features"],
+                                                                   mz[case + "_dec_flat"])
+
+    class _Pts:  # the two calls Mesher.query_points makes on the map object
+        def knn(self, q, query_locally):
+            return ops.knn_query(st, q, int(d["query_nn_k"]), time_filtering=query_locally, local=query_locally)
+
+        def field_state(self, decoder, query_locally=True, color=False):
+            return U.field_state(d2, local=query_locally)
+
+    class _Cfg:
+        silence, device, dtype, color_channel = True, "cuda", torch.float32, 0
+
+    mesher = Mesher(_Cfg(), _Pts(), {"sdf": None, "semantic": None, "color": None})
+    grid = torch.from_numpy(mz[case + "_grid"]).cuda()
+    sdf, _, _, mask = mesher.query_points(grid, 3000, True, False, False, True, query_locally=local, out_torch=True)
+    key = "local" if local else "global"
+    assert np.array_equal(mask.numpy() != 0, mz[f"{case}_mask_{key}"] != 0)
+    np.testing.assert_allclose(sdf.numpy(), mz[f"{case}_sdf_{key}"], rtol=1e-4, atol=3e-6)
+    sdf_np, _, _, mask_np = mesher.query_points(grid[:500], 200, out_torch=False)
+    assert sdf_np.dtype == np.float64 and sdf_np.shape == (500,) and mask_np.shape == (500,)
