@@ -526,6 +526,13 @@ int pin_select_surface_points(const float* rows, const float* sdf_label, int32_t
 int pin_transform_points(const float* points, int32_t row_stride, int32_t n, const double* pose, float* out,
                          void* stream);
 
+/* transform_batch_torch (utils/tools.py:556-580), in place: points[i] <- R_f p + t_f with f = frame[i] and
+ * T [n_frames][12] float32 rows [R|t] (NeuralPoints.adjust_map neural_points.py:791-817 with f = ts_create,
+ * Mapper.transform_data_pool utils/mapper.py:527-531 with f = time_pool).  quat / dquat (optional): the
+ * orientation update of adjust_map, quat[i] <- quat_multiply(dquat[f], quat[i]) (w, x, y, z). */
+int pin_transform_by_frame(float* points, int32_t n, const int32_t* frame, const float* T, int32_t n_frames,
+                           float* quat, const float* dquat, void* stream);
+
 /* Row gather out[i] = src[index[i]] for pools pin_gather_batch does not cover (color_pool,
  * utils/mapper.py:494-495). */
 int pin_gather_rows(const float* src, int32_t width, const int32_t* index, int32_t n, float* out, void* stream);

@@ -631,6 +631,69 @@ def gen_mesher():
 
 
 
+def gen_postloop():
+    """(11) post-loop map maintenance: NeuralPoints.adjust_map, recreate_hash
+    (kept_points, by timestamp and by certainty), prune_map (local / global) and
+    Mapper.transform_data_pool, on a four-frame map with per-frame pose corrections."""
+    from scipy.spatial.transform import Rotation
+    m = R.load()
+    cfg = R.make_config(voxel_size_m=0.4, buffer_size=40009, local_map_radius=20.0, local_map_travel_dist_ratio=1.0,
+                        feature_std=0.05, track_on=True)
+    npts = m["NeuralPoints"](cfg)
+    gen = torch.Generator().manual_seed(31)
+    travel = [0.0, 9.0, 18.0, 27.0]
+    npts.travel_dist = torch.tensor(travel, dtype=torch.float32)
+    for ts in range(4):
+        pts = sheet_points(gen, 6000, 12.0, center=(9.0 * ts, 0.0))
+        npts.update(pts, torch.tensor([9.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+    P = npts.count()
+    npts.point_certainties = torch.rand(P, generator=gen) * 4.0
+    npts.point_ts_update = torch.randint(0, 4, (P,), generator=gen).int()
+    out = dict(buffer_size=np.int64(cfg.buffer_size), resolution=np.float64(cfg.voxel_size_m), travel_dist=np.asarray(travel, np.float32),
+               diff_travel_dist_local=np.float64(npts.diff_travel_dist_local), cur_ts=np.int64(3),
+               neural_points=t2n(npts.neural_points), point_orientations=t2n(npts.point_orientations),
+               point_ts_create=t2n(npts.point_ts_create), point_ts_update=t2n(npts.point_ts_update),
+               point_certainties=t2n(npts.point_certainties), geo_features=t2n(npts.geo_features))
+    rng = np.random.default_rng(4)
+    pd = np.tile(np.eye(4), (4, 1, 1))
+    for i in range(4):
+        pd[i, :3, :3] = Rotation.from_rotvec(rng.normal(0, 0.03, 3)).as_matrix()
+        pd[i, :3, 3] = rng.normal(0, 0.2, 3)
+    out["pose_diff"] = pd
+    pd_t = torch.tensor(pd, dtype=torch.float64)
+    # Mapper.transform_data_pool (mapper.py:527-531)
+    ds = R.FakeDataset(n_frames=4)
+    dec = m["Decoder"](cfg, 32, 1, 1)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": None})
+    n_pool = 20000
+    mp.global_coord_pool = sheet_points(gen, n_pool, 30.0, center=(13.0, 0.0))
+    mp.time_pool = torch.randint(0, 4, (n_pool,), generator=gen).int()
+    out["pool_global"], out["pool_ts"] = t2n(mp.global_coord_pool), t2n(mp.time_pool)
+    mp.transform_data_pool(pd_t)
+    out["pool_global_after"] = t2n(mp.global_coord_pool)
+    # prune masks (computed like prune_map, without mutating)
+    npts.cur_ts = 3
+    for name, gp in (("local", False), ("global", True)):
+        import copy
+        q = copy.deepcopy(npts)
+        q.silence = True
+        changed = q.prune_map(1.0, min_prune_count=50, global_prune=gp)
+        out[f"prune_{name}_changed"] = np.bool_(changed)
+        out[f"prune_{name}_points"] = t2n(q.neural_points)
+        out[f"prune_{name}_geo"] = t2n(q.geo_features)
+        out[f"prune_{name}_ts_create"] = t2n(q.point_ts_create)
+    # adjust_map, then recreate_hash in both selection modes
+    npts.adjust_map(pd_t)
+    out["adj_points"], out["adj_orient"] = t2n(npts.neural_points), t2n(npts.point_orientations)
+    for name, with_ts in (("ts", True), ("cert", False)):
+        npts.recreate_hash(None, None, True, with_ts, 3)
+        tab = npts.buffer_pt_index
+        slots = torch.nonzero(tab >= 0).flatten()
+        out[f"rehash_{name}_slots"], out[f"rehash_{name}_vals"] = t2n(slots), t2n(tab[slots])
+    return out
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -656,6 +719,12 @@ def main():
                   "new", [len(d[f"f{t}_new_idx"]) for t in range(int(d["n_frames"]))],
                   "discard", [len(d[f"f{t}_discard_index"]) for t in range(int(d["n_frames"]))],
                   "adaptive", [int(d[f"f{t}_adaptive_iter_offset"]) for t in range(int(d["n_frames"]))])
+    if only in (None, "postloop"):
+        d = gen_postloop()
+        path = os.path.join(OUT, "postloop.npz")
+        np.savez_compressed(path, **d)
+        print("postloop ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "P", len(d["neural_points"]), "pruned",
+              len(d["neural_points"]) - len(d["prune_local_points"]), len(d["neural_points"]) - len(d["prune_global_points"]))
     if only in (None, "mesher"):
         d = gen_mesher()
         path = os.path.join(OUT, "mesher.npz")

@@ -842,3 +842,77 @@ def mesher_query(points, search, feats, positions, params, sdf_scale, k, weighte
                                  global2local=global2local, with_grad=False, dtype=np.float32)
     sdf = np.where(nn >= 1, sdf, 0.0).astype(F32)
     return sdf, nn >= mask_min_nn_count
+
+
+# --------------------------------------------------------------------------- post-loop map maintenance
+def transform_batch(points, T):
+    """transform_batch_torch (utils/tools.py:556-580): float32 bmm R_i p_i + t_i."""
+    p = np.asarray(points, F32)
+    T = np.asarray(T).astype(F32)
+    return (np.einsum("nij,nj->ni", T[:, :3, :3], p).astype(F32) + T[:, :3, 3]).astype(F32)
+
+
+def rotmat_to_quat(Rm):
+    """utils/tools.py:441-456 (w, x, y, z), float32, no normalisation."""
+    Rm = np.asarray(Rm, F32)
+    qw = (np.sqrt(F32(1.0) + Rm[:, 0, 0] + Rm[:, 1, 1] + Rm[:, 2, 2]) / F32(2.0)).astype(F32)
+    q4 = (F32(4.0) * qw).astype(F32)
+    return np.stack([qw, (Rm[:, 2, 1] - Rm[:, 1, 2]) / q4, (Rm[:, 0, 2] - Rm[:, 2, 0]) / q4, (Rm[:, 1, 0] - Rm[:, 0, 1]) / q4], 1).astype(F32)
+
+
+def quat_multiply(q1, q2):
+    """utils/tools.py:499-514."""
+    w1, x1, y1, z1 = (np.asarray(q1, F32)[:, i] for i in range(4))
+    w2, x2, y2, z2 = (np.asarray(q2, F32)[:, i] for i in range(4))
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1).astype(F32)
+
+
+def adjust_map(positions, orientations, ts_create, pose_diff):
+    """NeuralPoints.adjust_map (neural_points.py:791-817): per-point SE(3) by creation frame."""
+    used = np.asarray(ts_create, np.int64)
+    pd = np.asarray(pose_diff)
+    pos = transform_batch(positions, pd[used])
+    dq = rotmat_to_quat(pd[:, :3, :3].astype(F32))
+    return pos, quat_multiply(dq[used], orientations)
+
+
+def voxel_down_sample_min_value(points, voxel_size, value):
+    """utils/tools.py:629-668: per voxel the index of the point with the smallest value (1000 levels, lowest index on ties)."""
+    points = np.asarray(points, F32)
+    vs = F32(voxel_size)
+    offset = np.floor(points.min(0) / vs).astype(np.int64)
+    gi = np.floor(points / vs).astype(np.int64) - offset
+    vsz = gi.max()
+    gid = gi[:, 0] + gi[:, 1] * vsz + gi[:, 2] * vsz * vsz
+    _, inverse = np.unique(gid, return_inverse=True)
+    n = len(points)
+    off = 10 ** len(str(n - 1))
+    v = np.asarray(value, F32)
+    q = (v / v.max() * F32(999)).astype(np.int64)
+    key = np.arange(n, dtype=np.int64) + q * off
+    out = np.full(inverse.max() + 1, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(out, inverse, key)
+    return out % off
+
+
+def recreate_hash(positions, ts_create, cur_ts, resolution, buffer_size, certainties=None, with_ts=True):
+    """NeuralPoints.recreate_hash(kept_points=True) (neural_points.py:819-870): the rebuilt table."""
+    if with_ts:
+        value = np.abs(np.asarray(ts_create, np.int64) - cur_ts).astype(F32)
+    else:
+        c = np.asarray(certainties, F32)
+        value = (c.max() - c).astype(F32)
+    sel = voxel_down_sample_min_value(positions, resolution, value)
+    table = np.full(buffer_size, -1, np.int64)
+    table[hash_slots(grid_coords(np.asarray(positions, F32)[sel], resolution), buffer_size)] = sel
+    return table, sel
+
+
+def prune_mask(certainties, ts_update, travel_dist, cur_ts, diff_travel_dist_local, thre, global_prune=False):
+    """NeuralPoints.prune_map (neural_points.py:748-789): True = pruned."""
+    m = np.asarray(certainties, F32) < F32(thre)
+    if not global_prune:
+        td = np.asarray(travel_dist, F32)
+        m &= np.abs(td[cur_ts] - td[np.asarray(ts_update, np.int64)]) > F32(diff_travel_dist_local)
+    return m

@@ -172,6 +172,7 @@ SIGNATURES = {
     "pin_crop_frame": (i32, [vp, i32, i32, vp, f32, f32, f32, f32, vp, vp, vp, vp, i64, vp]),
     "pin_intrinsic_correct": (i32, [vp, i32, i32, f64, vp]),
     "pin_deskew": (i32, [vp, i32, i32, vp, vp, f64, vp, i64, vp]),
+    "pin_transform_by_frame": (i32, [vp, i32, vp, vp, i32, vp, vp, vp]),
     "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
 }
 

@@ -240,6 +240,32 @@ __global__ __launch_bounds__(MB) void transform_points_kernel(const float* __res
     out[3 * (size_t)i + 2] = fmaf(z, m[10], fmaf(y, m[9], x * m[8])) + m[11];
 }
 
+// transform_batch_torch (utils/tools.py:556-580) with the per-point matrix picked by a frame index, plus the
+// quaternion update of NeuralPoints.adjust_map (quat_multiply(dq[frame], q), utils/tools.py:499-514)
+__global__ __launch_bounds__(MB) void transform_by_frame_kernel(float* __restrict__ pts, int n, const int* __restrict__ frame,
+                                                                const float* __restrict__ T, int n_frames,
+                                                                float* __restrict__ quat, const float* __restrict__ dq) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    int fr = frame[i];
+    fr = fr < 0 ? fr + n_frames : fr;  // torch indexing semantics for negative indices
+    const float* m = T + 12 * (size_t)fr;
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    pts[3 * (size_t)i] = fmaf(z, m[2], fmaf(y, m[1], x * m[0])) + m[3];
+    pts[3 * (size_t)i + 1] = fmaf(z, m[6], fmaf(y, m[5], x * m[4])) + m[7];
+    pts[3 * (size_t)i + 2] = fmaf(z, m[10], fmaf(y, m[9], x * m[8])) + m[11];
+    if (quat != nullptr) {
+        const float4 a = reinterpret_cast<const float4*>(dq)[fr];  // w, x, y, z
+        const float4 b = reinterpret_cast<const float4*>(quat)[i];
+        float4 r;
+        r.x = a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w;
+        r.y = a.x * b.y + a.y * b.x + a.z * b.w - a.w * b.z;
+        r.z = a.x * b.z - a.y * b.w + a.z * b.x + a.w * b.y;
+        r.w = a.x * b.w + a.y * b.z - a.z * b.y + a.w * b.x;
+        reinterpret_cast<float4*>(quat)[i] = r;
+    }
+}
+
 static int check_pool(const pin_pool_arrays* p, const char* what) {
     if (!(p && p->coord && p->global_coord && p->sdf_label && p->weight && p->ts)) return fail(-1, "%s: NULL pool array", what);
     if (p->color_channels < 0 || p->color_channels > 4 || (p->color_channels > 0 && !p->color))
@@ -414,6 +440,18 @@ extern "C" int pin_transform_points(const float* points, int32_t row_stride, int
     Pose12 T;
     for (int i = 0; i < 12; ++i) T.m[i] = (float)pose[i];
     hipLaunchKernelGGL(transform_points_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, as_stream(stream), points, row_stride, n, T, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_transform_by_frame(float* points, int32_t n, const int32_t* frame, const float* T, int32_t n_frames,
+                                      float* quat, const float* dquat, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && n_frames > 0, "n < 0 or no frames");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(points && frame && T && (quat == nullptr || dquat != nullptr), "NULL pointer");
+    hipLaunchKernelGGL(transform_by_frame_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, as_stream(stream), points, n, frame, T,
+                       n_frames, quat, dquat);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -397,17 +397,15 @@ class NeuralPoints(nn.Module):
         return True
 
     def adjust_map(self, pose_diff_torch):
-        """neural_points.py:791-817 (per-point SE(3) after PGO; host-side torch, next-tier)."""
+        """neural_points.py:791-817: per-point SE(3) by creation frame + orientation update, one kernel."""
         if self.config.use_mid_ts:
             raise NotImplementedError("use_mid_ts")
         self.after_pgo = True
-        used = self.point_ts_create.long()
-        T = pose_diff_torch[used].to(torch.float32)
-        p = self.neural_points
-        self._g["pos"][:self._n] = (torch.bmm(T[:, :3, :3], p.unsqueeze(-1)) + T[:, :3, 3:]).squeeze(-1)
-        from ..quat import quat_multiply, rotmat_to_quat
-        dq = rotmat_to_quat(pose_diff_torch[:, :3, :3].to(torch.float32))
-        self._g["orient"][:self._n] = quat_multiply(dq[used], self.point_orientations)
+        from ..quat import rotmat_to_quat
+        pd = pose_diff_torch.detach().to(device=self.device)
+        dq = rotmat_to_quat(pd[:, :3, :3].to(torch.float32)).contiguous()
+        ops.transform_by_frame(self._g["pos"][:self._n], self._g["ts_create"][:self._n], pd, quat=self._g["orient"][:self._n],
+                               dquat=dq)
         self._rebuild_mirror()
 
     def recreate_hash(self, sensor_position, sensor_orientation, kept_points: bool = True, with_ts: bool = True, cur_ts=0):

@@ -1,5 +1,4 @@
-"""Quaternion helpers (w,x,y,z) used by NeuralPoints.adjust_map -- restating the math of
-utils/tools.py rotmat_to_quat / quat_multiply (next-tier, host-side torch)."""
+"""Quaternion helpers (w, x, y, z) of NeuralPoints.adjust_map, restating utils/tools.py:441-456 / 499-514."""
 import torch
 
 
@@ -14,14 +13,9 @@ def quat_multiply(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
 
 
 def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
-    """Batched rotation matrix -> unit quaternion (w >= 0 branch-free form)."""
-    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
-    w = torch.sqrt(torch.clamp(1 + m00 + m11 + m22, min=1e-12)) / 2
-    x = torch.sqrt(torch.clamp(1 + m00 - m11 - m22, min=0)) / 2
-    y = torch.sqrt(torch.clamp(1 - m00 + m11 - m22, min=0)) / 2
-    z = torch.sqrt(torch.clamp(1 - m00 - m11 + m22, min=0)) / 2
-    x = torch.copysign(x, R[..., 2, 1] - R[..., 1, 2])
-    y = torch.copysign(y, R[..., 0, 2] - R[..., 2, 0])
-    z = torch.copysign(z, R[..., 1, 0] - R[..., 0, 1])
-    q = torch.stack([w, x, y, z], -1)
-    return q / q.norm(dim=-1, keepdim=True)
+    """Batched rotation matrix -> quaternion, the reference's formula (w from the trace, no normalisation)."""
+    qw = torch.sqrt(1.0 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) / 2.0
+    qx = (R[:, 2, 1] - R[:, 1, 2]) / (4.0 * qw)
+    qy = (R[:, 0, 2] - R[:, 2, 0]) / (4.0 * qw)
+    qz = (R[:, 1, 0] - R[:, 0, 1]) / (4.0 * qw)
+    return torch.stack((qw, qx, qy, qz), dim=1)

@@ -234,6 +234,13 @@ class Mapper(_Base):
                     if frame_id > c.freeze_after_frame and r > c.new_sample_ratio_restart:
                         self.adaptive_iter_offset = 10
 
+    def transform_data_pool(self, pose_diff_torch):
+        """mapper.py:527-531: re-project the global sample coordinates after a pose-graph correction."""
+        p = self._pool()
+        if p.n:
+            ops.transform_by_frame(p.bufs[0]["global_coord"][:p.n], p.bufs[0]["ts"][:p.n], pose_diff_torch)
+        self._publish_pool()
+
     def get_batch(self, global_coord=False):
         """Mapper.get_batch (mapper.py:452-503): the same torch.randint draws in the same order,
         gathers by the pool kernels."""

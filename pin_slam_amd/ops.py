@@ -512,6 +512,15 @@ def transform_points(points: torch.Tensor, pose, out: Optional[torch.Tensor] = N
     return out
 
 
+def transform_by_frame(points: torch.Tensor, frame: torch.Tensor, pose: torch.Tensor, quat: Optional[torch.Tensor] = None,
+                       dquat: Optional[torch.Tensor] = None):
+    """In place: points[i] <- pose[frame[i]] applied (float32), optionally quat[i] <- dquat[frame[i]] * quat[i]."""
+    T = pose.detach().to(device=points.device, dtype=torch.float32)[:, :3, :4].contiguous()
+    check(_lib.lib().pin_transform_by_frame(_ptr(points, torch.float32), points.shape[0], _ptr(frame, torch.int32), _ptr(T),
+                                            T.shape[0], _ptr(quat), _ptr(dquat), _stream()), "pin_transform_by_frame")
+    return points
+
+
 def gather_rows(src: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None):
     """out[i] = src[index[i]] for a [n, width] float32 pool (color_pool gather of Mapper.get_batch)."""
     width = src.shape[1]

@@ -254,3 +254,71 @@ def test_mesher_query_points_matches_reference(case, local):
     np.testing.assert_allclose(sdf.numpy(), mz[f"{case}_sdf_{key}"], rtol=1e-4, atol=3e-6)
     sdf_np, _, _, mask_np = mesher.query_points(grid[:500], 200, out_torch=False)
     assert sdf_np.dtype == np.float64 and sdf_np.shape == (500,) and mask_np.shape == (500,)
+
+
+def _postloop_map(pl, cfg):
+    """A drop-in NeuralPoints holding the map of the postloop fixture."""
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.from_numpy(pl["travel_dist"]).cuda()
+    P = len(pl["neural_points"])
+    npts._alloc(P + 64)  # the arrays are written directly: replaying update() would depend on how the reference's
+    g = npts._g          # multi-threaded index_put_ happened to resolve colliding hash slots
+    g["pos"][:P] = torch.from_numpy(pl["neural_points"]).cuda()
+    g["orient"][:P] = torch.from_numpy(pl["point_orientations"]).cuda()
+    g["ts_create"][:P] = torch.from_numpy(pl["point_ts_create"]).cuda()
+    g["ts_update"][:P] = torch.from_numpy(pl["point_ts_update"]).cuda()
+    g["cert"][:P] = torch.from_numpy(pl["point_certainties"]).cuda()
+    g["geo"][:P + 1] = torch.from_numpy(pl["geo_features"]).cuda()
+    npts._n = P
+    npts._rebuild_mirror()
+    return npts
+
+
+def test_post_loop_maintenance_matches_reference():
+    """adjust_map, recreate_hash (both selection modes), prune_map (local / global) and transform_data_pool of the
+    drop-in classes against the reference fixture."""
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    pl = G.load("postloop")
+    cfg = _cfg(buffer_size=40009, local_map_radius=20.0, local_map_travel_dist_ratio=1.0, feature_std=0.05)
+    B = 40009
+    # prune_map on two copies
+    for mode in ("local", "global"):
+        npts = _postloop_map(pl, cfg)
+        npts.cur_ts = 3
+        assert npts.prune_map(1.0, min_prune_count=50, global_prune=mode == "global") == bool(pl[f"prune_{mode}_changed"])
+        assert np.array_equal(npts.neural_points.cpu().numpy(), pl[f"prune_{mode}_points"])
+        assert np.array_equal(npts.point_ts_create.cpu().numpy(), pl[f"prune_{mode}_ts_create"])
+        assert np.array_equal(npts.geo_features.cpu().numpy(), pl[f"prune_{mode}_geo"])
+    npts = _postloop_map(pl, cfg)
+    pd = torch.from_numpy(pl["pose_diff"]).cuda()
+    npts.adjust_map(pd)
+    assert npts.after_pgo
+    np.testing.assert_allclose(npts.neural_points.cpu().numpy(), pl["adj_points"], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(npts.point_orientations.cpu().numpy(), pl["adj_orient"], rtol=0, atol=1e-6)
+    # continue from the reference's adjusted positions (voxel membership is discontinuous in the last bit)
+    npts._g["pos"][:npts.count()] = torch.from_numpy(pl["adj_points"]).cuda()
+    for mode in ("ts", "cert"):
+        npts.recreate_hash(None, None, True, mode == "ts", 3)
+        tab = npts.buffer_pt_index.cpu().numpy().astype(np.int64)
+        ref_tab, sel = O.recreate_hash(pl["adj_points"], pl["point_ts_create"], 3, pl["resolution"], B,
+                                       certainties=pl["point_certainties"], with_ts=mode == "ts")
+        slots = np.nonzero(tab >= 0)[0]
+        assert np.array_equal(slots, pl[f"rehash_{mode}_slots"])
+        writers = np.bincount(O.hash_slots(O.grid_coords(pl["adj_points"][sel], pl["resolution"]), B), minlength=B)
+        ref = np.full(B, -1, np.int64); ref[pl[f"rehash_{mode}_slots"]] = pl[f"rehash_{mode}_vals"]
+        assert np.array_equal(tab[writers == 1], ref[writers == 1])   # single-writer slots: the reference's table
+        cand = np.isin(tab[writers > 1], sel)                        # colliding slots: one of the voxel winners
+        assert cand.all()
+    # Mapper.transform_data_pool
+    mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": Decoder(cfg, 32, 1, 1), "semantic": None, "color": None})
+    n = len(pl["pool_ts"])
+    mp.coord_pool = torch.from_numpy(pl["pool_global"]).cuda()
+    mp.global_coord_pool = torch.from_numpy(pl["pool_global"]).cuda()
+    mp.sdf_label_pool = torch.zeros(n, device="cuda"); mp.weight_pool = torch.ones(n, device="cuda")
+    mp.time_pool = torch.from_numpy(pl["pool_ts"]).cuda()
+    mp.pool_sample_count = n
+    mp.transform_data_pool(pd)
+    np.testing.assert_allclose(mp.global_coord_pool.cpu().numpy(), pl["pool_global_after"], rtol=0, atol=4e-6)
+    assert np.array_equal(mp.coord_pool.cpu().numpy(), pl["pool_global"])
