@@ -377,6 +377,16 @@ int pin_gather_batch(const float* pool_coord, const float* pool_label, const flo
                      const int32_t* pool_ts, const int32_t* index, int32_t n, float* coord_out,
                      float* label_out, float* weight_out, int32_t* ts_out, void* stream);
 
+/* All of Mapper.get_batch after its two torch.randint draws (utils/mapper.py:462-500) in one launch:
+ * output row i < n_history is pool row index_history[i]; the remaining n - n_history rows are pool rows
+ * new_idx[index_new_batch[i - n_history]] (the newly observed samples).  Indices are torch's int64 draws.
+ * pool_color / color_out [..][color_channels] are optional (color_channels = 0). */
+int pin_gather_batch_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                           const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
+                           const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                           const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
+                           float* weight_out, int32_t* ts_out, float* color_out, void* stream);
+
 /* K6a: query points of one training iteration: the batch itself followed by the six
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
  * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with

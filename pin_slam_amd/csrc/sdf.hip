@@ -488,10 +488,13 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
     __shared__ double s[PIN_GN_NSUMS];
     const int lane = threadIdx.x;
     if (st[PIN_GN_STATE_DONE] != 0.0) return;
-    if (lane < PIN_GN_NSUMS) {
+    {   // replica sum: two lanes per sum, 32 independent loads each
+        const int i = lane & 31, h = lane >> 5;
         double a = 0.0;
-        for (int r = 0; r < GN_REPLICAS; ++r) a += sums[r * PIN_GN_NSUMS + lane];
-        s[lane] = a;
+#pragma unroll 8
+        for (int r = 0; r < GN_REPLICAS / 2; ++r) a += sums[(h * (GN_REPLICAS / 2) + r) * PIN_GN_NSUMS + i];
+        a += __shfl_xor(a, 32, 64);
+        if (h == 0) s[i] = a;
     }
     __syncthreads();
     for (int i = lane; i < GN_REPLICAS * PIN_GN_NSUMS; i += 64) sums[i] = 0.0;  // ready for the next iteration
@@ -501,30 +504,52 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
     double res_cm = 0.0;
     if (cnt >= 10.0) {  // tracker.py:430-432
         const double scale = cnt / (2.0 * s[27]);  // w /= 2*mean(w)
+        // every loop below is fully unrolled with compile-time indices: the 6x7 system lives in registers
+        // (dynamic indexing would put it in scratch memory, which also costs at launch)
         double N[6][7];
-        int o = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b) { N[a][b] = N[b][a] = scale * s[o++]; }
+        {
+            int o = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) { N[a][b] = N[b][a] = scale * s[o++]; }
+        }
+#pragma unroll
         for (int a = 0; a < 6; ++a) {
+#pragma unroll
             for (int b = 0; b < 6; ++b) st[PIN_GN_STATE_NRAW + a * 6 + b] = N[a][b];
             N[a][6] = -scale * s[21 + a];
         }
         st[PIN_GN_STATE_MSE] = scale * s[30] / cnt;
+#pragma unroll
         for (int a = 0; a < 6; ++a) N[a][a] += lp.lm_lambda * N[a][a];
-        // Gaussian elimination with partial pivoting (float64)
+        // Gaussian elimination with partial pivoting (float64); the pivot row is brought up by conditional
+        // row exchanges (select instructions), no data-dependent indexing
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
-            int piv = c;
-            for (int r = c + 1; r < 6; ++r) if (fabs(N[r][c]) > fabs(N[piv][c])) piv = r;
-            if (piv != c) for (int b = 0; b < 7; ++b) { const double t = N[c][b]; N[c][b] = N[piv][b]; N[piv][b] = t; }
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                const bool sw = fabs(N[r][c]) > fabs(N[c][c]);
+#pragma unroll
+                for (int b = c; b < 7; ++b) {
+                    const double x = N[c][b], y = N[r][b];
+                    N[c][b] = sw ? y : x;
+                    N[r][b] = sw ? x : y;
+                }
+            }
             const double inv = 1.0 / N[c][c];
+#pragma unroll
             for (int r = c + 1; r < 6; ++r) {
                 const double f = N[r][c] * inv;
+#pragma unroll
                 for (int b = c; b < 7; ++b) N[r][b] -= f * N[c][b];
             }
         }
         double t[6];
+#pragma unroll
         for (int r = 5; r >= 0; --r) {
             double acc = N[r][6];
+#pragma unroll
             for (int b = r + 1; b < 6; ++b) acc -= N[r][b] * t[b];
             t[r] = acc / N[r][r];
         }
@@ -533,9 +558,12 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
         const double ax = t[0] / ang, ay = t[1] / ang, az = t[2] / ang;
         const double sn = sin(ang), cs = 1.0 - cos(ang);
         const double S[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+#pragma unroll
         for (int a = 0; a < 3; ++a)
+#pragma unroll
             for (int b = 0; b < 3; ++b) {
                 double ss = 0.0;
+#pragma unroll
                 for (int c = 0; c < 3; ++c) ss += S[a * 3 + c] * S[c * 3 + b];
                 dT[a * 4 + b] = (a == b ? 1.0 : 0.0) + S[a * 3 + b] * sn + ss * cs;
             }
@@ -544,12 +572,16 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
     }
     // T = dT @ T
     double Tn[16];
+#pragma unroll
     for (int a = 0; a < 4; ++a)
+#pragma unroll
         for (int b = 0; b < 4; ++b) {
             double acc = 0.0;
+#pragma unroll
             for (int c = 0; c < 4; ++c) acc += dT[a * 4 + c] * st[c * 4 + b];
             Tn[a * 4 + b] = acc;
         }
+#pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = Tn[i];
     st[PIN_GN_STATE_RES] = res_cm;
     st[PIN_GN_STATE_CNT] = cnt;

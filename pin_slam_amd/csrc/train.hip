@@ -76,6 +76,25 @@ __global__ void gather_batch_kernel(const float* __restrict__ pc, const float* _
     if (ts) ts[i] = pt ? pt[s] : 0;
 }
 
+// The whole of Mapper.get_batch after its two torch.randint draws (utils/mapper.py:462-500): rows
+// index_history[i] for i < n_hist, rows new_idx[index_new_batch[i - n_hist]] after that
+__global__ void gather_batch_drawn_kernel(const float* __restrict__ pc, const float* __restrict__ pl,
+                                          const float* __restrict__ pw, const int* __restrict__ pt,
+                                          const float* __restrict__ pcol, int cw, const long long* __restrict__ index_hist,
+                                          int n_hist, const long long* __restrict__ index_new_batch,
+                                          const long long* __restrict__ new_idx, int n, float* __restrict__ coord,
+                                          float* __restrict__ label, float* __restrict__ weight, int* __restrict__ ts,
+                                          float* __restrict__ color) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t s = (size_t)(i < n_hist ? index_hist[i] : new_idx[index_new_batch[i - n_hist]]);
+    coord[3 * i] = pc[3 * s]; coord[3 * i + 1] = pc[3 * s + 1]; coord[3 * i + 2] = pc[3 * s + 2];
+    label[i] = pl[s];
+    weight[i] = pw[s];
+    ts[i] = pt[s];
+    for (int c = 0; c < cw; ++c) color[(size_t)i * cw + c] = pcol[s * cw + c];
+}
+
 // ---- forward -----------------------------------------------------------------------------
 struct NbrW {
     float w[PIN_MAX_K];
@@ -735,6 +754,26 @@ extern "C" int pin_gather_batch(const float* pool_coord, const float* pool_label
     PIN_CHECK_ARG(pool_coord && pool_label && index && coord_out && label_out, "NULL pointer");
     hipLaunchKernelGGL(gather_batch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
                        pool_weight, pool_ts, index, n, coord_out, label_out, weight_out, ts_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gather_batch_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                                      const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
+                                      const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                                      const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
+                                      float* weight_out, int32_t* ts_out, float* color_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && color_channels >= 0, "bad sizes");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(pool_coord && pool_label && pool_weight && pool_ts && coord_out && label_out && weight_out && ts_out, "NULL pointer");
+    PIN_CHECK_ARG(n_history == 0 || index_history, "index_history NULL");
+    PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
+    PIN_CHECK_ARG(color_channels == 0 || (pool_color && color_out), "colour pool / output NULL");
+    hipLaunchKernelGGL(gather_batch_drawn_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
+                       pool_weight, pool_ts, pool_color, color_channels, reinterpret_cast<const long long*>(index_history),
+                       n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
+                       n, coord_out, label_out, weight_out, ts_out, color_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -17,7 +17,7 @@ import torch
 
 import numpy as np
 
-from ... import engine, ops
+from ... import _lib, engine, ops
 from ... import pool as pool_mod
 
 
@@ -249,21 +249,26 @@ class Mapper(_Base):
         n = self.pool_sample_count
         new_idx = self.new_idx
         ds = self.dataset
+        index_new_batch = None
         if (c.bs_new_sample > 0 and new_idx is not None and not getattr(ds, "lose_track", False)
                 and not getattr(ds, "stop_status", False) and new_idx.shape[0] > 0):
             bs_new = min(new_idx.shape[0], c.bs_new_sample)
             index_history = torch.randint(0, n, (c.bs - bs_new,), device=self.device)
             index_new_batch = torch.randint(0, new_idx.shape[0], (bs_new,), device=self.device)
-            index = torch.cat((index_history, new_idx[index_new_batch]), dim=0)
         else:
-            index = torch.randint(0, n, (c.bs,), device=self.device)
-        idx32 = index.to(torch.int32)
+            index_history = torch.randint(0, n, (c.bs,), device=self.device)
         b = p.bufs[0]
         dev = self.device
         out = (torch.empty((c.bs, 3), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.float32, device=dev),
                torch.empty((c.bs,), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.int32, device=dev))
-        ops.gather_batch(b["global_coord"] if global_coord else b["coord"], b["sdf_label"], b["weight"], b["ts"], idx32, out)
-        color = ops.gather_rows(b["color"], idx32) if p.C else None
+        color = torch.empty((c.bs, p.C), dtype=torch.float32, device=dev) if p.C else None
+        L = _lib.lib()
+        _lib.check(L.pin_gather_batch_drawn(
+            (b["global_coord"] if global_coord else b["coord"]).data_ptr(), b["sdf_label"].data_ptr(), b["weight"].data_ptr(),
+            b["ts"].data_ptr(), b["color"].data_ptr() if p.C else None, p.C, index_history.data_ptr(), index_history.shape[0],
+            None if index_new_batch is None else index_new_batch.data_ptr(), None if index_new_batch is None else new_idx.data_ptr(),
+            c.bs, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+            None if color is None else color.data_ptr(), torch.cuda.current_stream().cuda_stream), "pin_gather_batch_drawn")
         return out[0], out[1], out[3], None, None, color, out[2]
 
     # ------------------------------------------------------------------ hot loop

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for d in 0 12; do
+for d in 0; do
 rm -rf $R/gpurun_out/prof4 && mkdir -p $R/gpurun_out/prof4
 PIN_GQ_DBG=$d rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof4 -o t -- python $R/scratch/time4.py > $R/gpurun_out/prof4/log.txt 2>&1
 python - <<PY
