@@ -11,7 +11,7 @@
 // ([row][Q], query contiguous) so that thread-per-query kernels write coalesced and the
 // weight-gradient GEMM reads K-contiguous operands.  At the batch sizes of the reference
 // (16k samples + 10k Eikonal queries) the workspace stays in L2 / Infinity Cache.
-#include "mlp_mfma.h"
+#include "mlp_quad.h"
 
 namespace pin {
 
@@ -233,6 +233,25 @@ __device__ __forceinline__ void neighbor_input(const pin_field& f, int idx, bool
     const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)idx * PIN_FEATURE_DIM);
     const float4 a = row[0], b = row[1];
     ft[0] = a.x; ft[1] = a.y; ft[2] = a.z; ft[3] = a.w; ft[4] = b.x; ft[5] = b.y; ft[6] = b.z; ft[7] = b.w;
+    v[0] = vgx; v[1] = vgy; v[2] = vgz;
+    if (quirk) {
+        const float* p = f.pos + 3 * (size_t)idx;
+        v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+    }
+    if (f.orient != nullptr) {  // apply_quaternion_rotation (utils/tools.py:428-437): conjugate rotation
+        const float4 q4 = reinterpret_cast<const float4*>(f.orient)[idx];
+        const float q0_ = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
+        const float r0 = 1 - 2 * (q2 * q2 + q3 * q3), r3 = 2 * (q1 * q2 - q0_ * q3), r6 = 2 * (q1 * q3 + q0_ * q2);
+        const float r1 = 2 * (q1 * q2 + q0_ * q3), r4 = 1 - 2 * (q1 * q1 + q3 * q3), r7 = 2 * (q2 * q3 - q0_ * q1);
+        const float r2 = 2 * (q1 * q3 - q0_ * q2), r5 = 2 * (q2 * q3 + q0_ * q1), r8 = 1 - 2 * (q1 * q1 + q2 * q2);
+        const float x = v[0], y = v[1], zz = v[2];
+        v[0] = r0 * x + r1 * y + r2 * zz; v[1] = r3 * x + r4 * y + r5 * zz; v[2] = r6 * x + r7 * y + r8 * zz;
+    }
+}
+
+// only the relative-position part of neighbor_input (the feature row is read by other lanes)
+__device__ __forceinline__ void neighbor_vector_only(const pin_field& f, int idx, bool quirk, float vgx, float vgy, float vgz,
+                                                     float qx, float qy, float qz, float (&v)[3]) {
     v[0] = vgx; v[1] = vgy; v[2] = vgz;
     if (quirk) {
         const float* p = f.pos + 3 * (size_t)idx;
@@ -688,6 +707,126 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
     }
 }
 
+// ---- the same forward / backward with FOUR LANES PER QUERY (weighted_first, one SDF head) ---------------------
+// A training iteration has only ~26k queries: with 64 queries per wave that is 410 waves for 1024 SIMDs.
+// As in gn_quad.h a wave carries one 16-query tile and lane (n, g) owns input components 4g..4g+3, so the
+// batch spreads over four times as many waves, the input / its gradient never go through LDS, and the
+// blocks are persistent (weights staged once per CU).
+constexpr int TQ_BLOCK = GQ_BLOCK;
+
+template <int H>
+__global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f, const float* __restrict__ query,
+                                                                     const float4* __restrict__ nbr,
+                                                                     const int* __restrict__ nn_count, int Q, int n_main,
+                                                                     TrainWs ws, float* __restrict__ cert_rw,
+                                                                     int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
+    using QD = QuadDecoder<H>;
+    __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
+    QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int n_tiles = (Q + 15) >> 4;
+    const int n_waves = gridDim.x * (TQ_BLOCK / 64);
+    for (int tile = blockIdx.x + gridDim.x * wave; tile < n_tiles; tile += n_waves) {
+        // the row stride is re-read per tile behind an optimisation barrier: hoisted out of the loop, the ~70
+        // row addresses of the activation stores become live 64-bit values and spill to scratch memory
+        int qst32 = ws.QsT;
+        asm volatile("" : "+s"(qst32));
+        const size_t QsT = (size_t)qst32;
+        const int qi = tile * 16 + nq;  // < ws.Qs: the padded column count is a multiple of 64
+        const bool active = qi < Q;
+        const int qq = active ? qi : Q - 1;
+        const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+        NbrW nb;
+        float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+        bool quirk[PIN_MAX_K];
+        neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
+        // training-mode side effects first (neural_points.py:685-710), so the neighbour arrays die before the decoder
+        if (g == 3 && active && qi < n_main && cert_rw != nullptr) {
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t)
+                if (nb.idx[t] >= 0) {
+                    atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                    if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
+                }
+        }
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            if (nb.idx[t] < 0) continue;
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g < 2) {
+                const float4 ft = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM)[g];
+                y[0] = ft.x; y[1] = ft.y; y[2] = ft.z; y[3] = ft.w;
+            } else if (g == 2) {
+                float v[3];
+                neighbor_vector_only(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, v);
+                y[0] = v[0]; y[1] = v[1]; y[2] = v[2];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = fmaf(nb.w[t], y[r], z[r]);
+        }
+        if (g < 3) {  // rows 0..11 of the input block (row 11 = 0 comes from lane g == 2, r == 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ws.z[(size_t)(4 * g + r) * QsT + qi] = z[r];
+        }
+        const float x = QD::forward_store(lds, f.levels, z, ws.h, QsT, (size_t)qi, ws.mask, QsT);
+        if (g == 0) ws.pred[qi] = f.sdf_scale * x;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f, const float4* __restrict__ nbr,
+                                                                     const int* __restrict__ nn_count, int Q, TrainWs ws,
+                                                                     float* __restrict__ feat_grad, int want_dec) {
+    using QD = QuadDecoder<H>;
+    __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
+    __shared__ float xch[TQ_BLOCK / 64][3 * 16 * 8];  // per wave: dz [16][8], w [16][8], idx [16][8]
+    QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int n_tiles = (Q + 15) >> 4;
+    const int n_waves = gridDim.x * (TQ_BLOCK / 64);
+    float* sdz = xch[wave];
+    float* sw = sdz + 16 * 8;
+    int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
+    for (int tile = blockIdx.x + gridDim.x * wave; tile < n_tiles; tile += n_waves) {
+        int qst32 = ws.QsT;  // see train_fwd_quad_kernel
+        asm volatile("" : "+s"(qst32));
+        const size_t QsT = (size_t)qst32;
+        const int qi = tile * 16 + nq;
+        const bool active = qi < Q;
+        const int qq = active ? qi : Q - 1;
+        const float dx = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // the prediction is sdf_scale * head
+        if (want_dec && g == 0) ws.d[(size_t)(f.levels * H) * QsT + qi] = dx;
+        float dz[4];
+        QD::backward_store(lds, f.levels, dx, ws.mask, QsT, ws.d, QsT, (size_t)qi, want_dec != 0, dz);
+        // Feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature dims,
+        // whole 32-byte rows per instruction; see train_bwd_mfma_kernel): exchange through the wave's LDS patch
+        NbrW nb;
+        {
+            float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+            bool quirk[PIN_MAX_K];
+            neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
+        }
+        const bool live = active && dx != 0.f;
+        if (g < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r];
+        } else if (g == 2) {
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t) { sw[nq * 8 + t] = nb.w[t]; sidx[nq * 8 + t] = live ? nb.idx[t] : -1; }
+        }
+        wave_lds_sync();
+        const int t = lane >> 3, j = lane & 7;
+        for (int i = 0; i < 16; ++i) {
+            const int idx = sidx[i * 8 + t];
+            if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
+        }
+        wave_lds_sync();
+    }
+}
+
 // ---- Adam --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
@@ -828,7 +967,19 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         else { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
                else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__); }          \
     } while (0)
-    if (mfma) {
+    // weighted_first: four lanes per query on persistent blocks (PIN_TRAIN=wave keeps 64 queries per wave)
+    static const bool quad_on = [] { const char* e = getenv("PIN_TRAIN"); return !(e && strcmp(e, "wave") == 0); }();
+    const bool quad = mfma && quad_on && f->weighted_first;
+    static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    const dim3 qgrid(min(n_cu, cdiv(cdiv(Q, 16), TQ_BLOCK / 64))), qblock(TQ_BLOCK);
+    if (quad) {
+        if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    } else if (mfma) {
         PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     } else {
         if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
@@ -839,7 +990,10 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
                        sample_weight, ws, loss_out);
     PIN_CHECK_LAUNCH();
     const int want_dec = dec_grad != nullptr;
-    if (mfma) {
+    if (quad) {
+        if (H == 64) hipLaunchKernelGGL((train_bwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        else hipLaunchKernelGGL((train_bwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+    } else if (mfma) {
         PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     } else {
         if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
