@@ -727,7 +727,7 @@ static int launch_quad(const pin_field* f, const pin_gn_params* gp, const float*
                        const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                        float* grad_out, const double* state, hipStream_t s) {
     const int tiles = cdiv(n, 16);
-    const dim3 grid(min(gq_cu_count(), cdiv(tiles, GQ_BLOCK / 64))), block(GQ_BLOCK);
+    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
 #define PIN_LQ(HH, OO) \
     hipLaunchKernelGGL((gn_accumulate_quad_kernel<HH, OO>), grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, \
                        sdf_out, grad_out, state)

@@ -975,7 +975,7 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         return v;
     }();
-    const dim3 qgrid(min(n_cu, cdiv(cdiv(Q, 16), TQ_BLOCK / 64))), qblock(TQ_BLOCK);
+    const dim3 qgrid(min(n_cu, cdiv(Q, 16))), qblock(TQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
     if (quad) {
         if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
         else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);

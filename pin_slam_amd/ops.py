@@ -146,6 +146,11 @@ class BrickCache:
         wrong -- bricks that did not fit are published as "not cached" and their cells take the exact probe
         (identical results, slower).  wait=True checks (and rebuilds) right away."""
         self._settle()
+        # size for the map at hand before the first launch (about one entry per occupied cell, a brick per ~16
+        # of them); anything beyond is caught by the counters one build later
+        want_b, want_e = st.n_points // 8 + 4096, st.n_points + st.n_points // 4 + 4096
+        if want_b > self.max_bricks or want_e > self.max_entries:
+            self._alloc(max(self.max_bricks, want_b), max(self.max_entries, want_e))
         sp = st.params(time_filtering=time_filtering, local=local)
         bc = self.params()
         check(_lib.lib().pin_brick_build(C.byref(sp), C.byref(bc), self.counters.data_ptr(), _stream()), "pin_brick_build")
