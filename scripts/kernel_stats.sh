@@ -10,5 +10,5 @@ f=glob.glob("$R/gpurun_out/prof/**/*kernel_stats.csv", recursive=True)
 rows=list(csv.DictReader(open(f[0])))
 for r in rows[:32]: print(r["Name"][:70].ljust(70), r["Calls"].rjust(7), r["TotalDurationNs"].rjust(12), r["AverageNs"].rjust(10), r["Percentage"].rjust(7))
 PY
-python $R/scratch/trace_gaps.py $R/gpurun_out/prof/bench_kernel_trace.csv
+python $R/scripts/trace_gaps.py $R/gpurun_out/prof/bench_kernel_trace.csv
 tail -1 $R/gpurun_out/prof/bench.log | cut -c1-300

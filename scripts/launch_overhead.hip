@@ -1,3 +1,8 @@
+// Launch-overhead microbenchmark behind DESIGN.md's "no scratch memory in the hot kernels" rule:
+//   hipcc --offload-arch=gfx950 -O2 -o launch_overhead scripts/launch_overhead.hip && ./launch_overhead
+// MI355X, ROCm 7.2 (200 back-to-back launches, HIP events): every empty kernel costs ~3 us whatever its
+// grid / LDS size, but a kernel with a scratch (private memory) segment costs 15.5 us at 256 x 1024 threads
+// and 78.8 us at 6250 x 256 threads -- ~12 ns per wave.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int LDS>
