@@ -123,11 +123,19 @@ __global__ __launch_bounds__(MB) void pool_discard_kernel(unsigned char* __restr
 
 __global__ __launch_bounds__(MB) void pool_tail_count_kernel(const unsigned char* __restrict__ mask, int first, int n,
                                                              int* __restrict__ cnt) {
+    __shared__ int red[MB / 64];
     int c = 0;
     for (int i = first + blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) c += mask[i] != 0 ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, c);  // grid capped at 256 blocks: <= 1024 atomics
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block, grid capped at 128 blocks: same-address atomics serialise
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < MB / 64; ++w) t += red[w];
+        if (t) atomicAdd(cnt, t);
+    }
 }
 
 __global__ __launch_bounds__(MB) void pool_scatter_kernel(pin_pool_arrays src, pin_pool_arrays dst,
@@ -367,7 +375,7 @@ extern "C" int pin_pool_compact(const pin_pool_arrays* src, const pin_pool_array
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, mask, n, block_cnt);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, counts_out);
     if (n_cur > 0)
-        hipLaunchKernelGGL(pool_tail_count_kernel, dim3(min(cdiv(n_cur, MB), 256)), dim3(MB), 0, s, mask, n - n_cur, n, counts_out + 1);
+        hipLaunchKernelGGL(pool_tail_count_kernel, dim3(min(cdiv(n_cur, MB), 128)), dim3(MB), 0, s, mask, n - n_cur, n, counts_out + 1);
     hipLaunchKernelGGL(pool_scatter_kernel, dim3(nb), dim3(MB), 0, s, *src, *dst, mask, n, block_cnt);
     PIN_CHECK_LAUNCH();
     return 0;

@@ -294,16 +294,16 @@ class Mapper(_Base):
         train_dec = bool(self.sdf_mlp.lout.weight.requires_grad)  # freeze_decoders (tools.py:263-292)
         eik = bool(c.ekional_loss_on and c.weight_e > 0)
         t = self._trainer
-        if (t is None or t.fs.feats.numel() != fs.feats.numel() or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel()
-                or (t.buf.n_eik > 0) != eik or t.fs.weighted_first != fs.weighted_first
-                or (t.rank, t.world) != (self.dp_rank, self.dp_world)):
+        if (t is None or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel() or (t.buf.n_eik > 0) != eik
+                or t.fs.weighted_first != fs.weighted_first or (t.rank, t.world) != (self.dp_rank, self.dp_world)):
             t = engine.MapTrainer(st, fs, None, None, None, None, npts.local_point_ts_update, bs=c.bs,
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,
                                   weight_e=c.weight_e if eik else 0.0,
                                   eik_eps=c.voxel_size_m * c.num_grad_step_ratio, lr=c.lr, adam_eps=c.adam_eps,
                                   loss_weight_on=c.loss_weight_on, eikonal=eik, rank=self.dp_rank, world=self.dp_world)
             self._trainer = t
-        t.st, t.fs, t.ts_update, t.train_decoder = st, fs, npts.local_point_ts_update, train_dec
+        t.resize(fs)  # the local map changes size every frame: same buffers, new views
+        t.st, t.ts_update, t.train_decoder = st, npts.local_point_ts_update, train_dec
         if c.color_on and c.weight_i > 0:  # colour branch (mapper.py:668-671, 802-812)
             fc = npts.field_state(self.color_mlp, query_locally=True, color=True)
             t.set_color(fc, surface_range=c.surface_sample_range_m, weight_i=c.weight_i,

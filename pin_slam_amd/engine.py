@@ -140,14 +140,8 @@ class MapTrainer:
         assert self.bs % world == 0, "global batch must divide over the ranks"
         self.bs_local = self.bs // world
         dev = fs.feats.device
-        nf, nd = fs.feats.numel(), fs.dec.numel()
-        # one flat gradient buffer [decoder | features]: a single all-reduce payload
-        self.grad = torch.zeros((nd + nf,), dtype=torch.float32, device=dev)
-        self.gdec, self.gfeat = self.grad[:nd], self.grad[nd:]
-        self.m = torch.zeros_like(self.grad)
-        self.v = torch.zeros_like(self.grad)
-        # rows touched since the optimiser state was reset: Adam skips the others, bit-identically (ops.adam_step_rows)
-        self.dirty = torch.zeros((fs.feats.shape[0],), dtype=torch.uint8, device=dev)
+        self._store = None
+        self.resize(fs)
         from .sharding import n_eik_global, shard_range
         start, _ = shard_range(self.bs, rank, world)
         self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
@@ -161,6 +155,25 @@ class MapTrainer:
         self.total_iter = 0
         self.bricks = None
         self.fc = None  # colour field (set_color)
+
+    def resize(self, fs: ops.FieldState):
+        """Point the optimiser buffers at `fs` (the local map changes size every frame): views of
+        capacity-managed stores, reallocated only when the map outgrows them.  Contents are
+        undefined until reset_optimizer(), which every Mapper.mapping call starts with."""
+        nf, nd, rows = fs.feats.numel(), fs.dec.numel(), fs.feats.shape[0]
+        if self._store is None or self._store[0].numel() < nd + nf or self._nd != nd:
+            cap = nd + int(nf * 1.25) + 1024
+            dev = fs.feats.device
+            self._store = tuple(torch.zeros((cap,), dtype=torch.float32, device=dev) for _ in range(3)) + (
+                torch.zeros((cap // 8 + 8,), dtype=torch.uint8, device=dev),)
+            self._nd = nd
+        g, m, v, d = self._store
+        # one flat gradient buffer [decoder | features]: a single all-reduce payload (SURVEY 8e)
+        self.grad, self.m, self.v = g[:nd + nf], m[:nd + nf], v[:nd + nf]
+        self.gdec, self.gfeat = self.grad[:nd], self.grad[nd:]
+        # rows touched since the optimiser state was reset: Adam skips the others, bit-identically (ops.adam_step_rows)
+        self.dirty = d[:rows]
+        self.fs = fs
 
     def set_color(self, fc: Optional[ops.FieldState], surface_range: float = 0.0, weight_i: float = 0.0,
                   train_decoder: bool = True):
