@@ -322,3 +322,35 @@ def test_post_loop_maintenance_matches_reference():
     mp.transform_data_pool(pd)
     np.testing.assert_allclose(mp.global_coord_pool.cpu().numpy(), pl["pool_global_after"], rtol=0, atol=4e-6)
     assert np.array_equal(mp.coord_pool.cpu().numpy(), pl["pool_global"])
+
+
+def test_map_pickles_like_the_reference_saves_it():
+    """tools.py:295-317 saves {"neural_points": <module>, "sdf": state_dict}: the drop-in module must pickle
+    (no ctypes handles in its state) and come back usable after recreate_hash, as vis_pin_map.py does."""
+    import io
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    d = G.load("update")
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, feature_std=0.1)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.from_numpy(d["travel_dist"]).cuda()
+    for ts in range(2):
+        npts.update(torch.from_numpy(d[f"pts{ts}"]).cuda(), torch.tensor([9.0 * ts, 0.0, 0.0]), torch.eye(3), ts)
+    dec = Decoder(cfg, 32, 2, 1)
+    q = torch.from_numpy(d["pts1"][:300] + 0.02).cuda()
+    feat0, _, _, nn0, _ = npts.query_feature(q, training_mode=False, query_locally=False)
+    sdf0 = dec.sdf(feat0)
+    n0 = npts.count()
+    npts.clear_temp()
+    buf = io.BytesIO()
+    torch.save({"neural_points": npts, "sdf": dec.state_dict()}, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    npts2 = loaded["neural_points"]
+    dec2 = Decoder(cfg, 32, 2, 1)
+    dec2.load_state_dict(loaded["sdf"])
+    assert npts2.count() == n0
+    npts2.recreate_hash(None, None, True, False, 1)  # vis_pin_map.py: rebuild the table by certainty
+    feat1, _, _, nn1, _ = npts2.query_feature(q, training_mode=False, query_locally=False)
+    assert torch.equal(nn0, nn1)
+    np.testing.assert_allclose(dec2.sdf(feat1).cpu().numpy(), sdf0.cpu().numpy(), rtol=1e-6, atol=1e-7)

@@ -1,0 +1,144 @@
+"""Edge cases of the hot path through the C ABI on MI355X: empty inputs, ragged sizes around the
+tile / wave / block boundaries, queries with no neighbour at all, a one-point scan -- against the oracle
+or by consistency between sizes (every kernel is per-query, so a prefix must give a prefix)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pin_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gd():
+    from tests import gpu_util as U
+    d = G.load("c2_wf")
+    d["st"], d["fs"] = U.search_state(d), U.field_state(d)
+    d["table"] = G.dense_table(d)
+    return d
+
+
+def _gp(d):
+    from pin_slam_amd._lib import GnParams
+    gp = GnParams()
+    gp.valid_nn_k = int(d["track_mask_query_nn_k"]); gp.min_grad_norm = 0.3; gp.max_grad_norm = 3.0
+    gp.max_sdf_std = 0.5; gp.gm_dist = 0.3; gp.gm_grad = 0.1
+    return gp
+
+
+def test_empty_inputs_are_no_ops(gd):
+    from pin_slam_amd import ops, pool as P, preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    d = gd
+    k = int(d["query_nn_k"])
+    q0 = torch.empty((0, 3), dtype=torch.float32, device="cuda")
+    nbr, nn, _ = ops.knn_query(d["st"], q0, k)
+    assert nbr.shape == (0, k, 4) and nn.shape == (0,)
+    sdf, grad, std, cert = ops.sdf_query(d["fs"], q0, nbr, nn)
+    assert sdf.shape == (0,) and grad.shape == (0, 3)
+    pool = P.SamplePool(capacity=1024)
+    assert pool.filter(np.zeros(3), 10.0, 100) == (0, 0)
+    n = pool.append_samples(torch.empty((0, 3), dtype=torch.float32, device="cuda"), P.sample_params(PinConfig(), np.eye(4), 0))
+    assert n == 0 and pool.n == 0
+    pts, ts = PP.crop_frame(torch.empty((0, 4), dtype=torch.float32, device="cuda"), None)
+    assert pts.shape == (0, 4) and ts is None
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 255, 257, 1000])
+def test_ragged_sizes_give_prefixes(gd, n):
+    """kNN, SDF query and the GN sums at sizes around the 16-query tile, the 64-lane wave and the 256-thread
+    block: the first n results never depend on what comes after them."""
+    from pin_slam_amd import ops
+    d = gd
+    k = int(d["query_nn_k"])
+    q_all = torch.from_numpy(d["query"]).cuda()
+    nbr_all, nn_all, _ = ops.knn_query(d["st"], q_all, k)
+    sdf_all, grad_all, _, _ = ops.sdf_query(d["fs"], q_all, nbr_all, nn_all)
+    q = q_all[:n].contiguous()
+    nbr, nn, _ = ops.knn_query(d["st"], q, k)
+    assert torch.equal(nbr.view(torch.int32), nbr_all[:n].view(torch.int32)) and torch.equal(nn, nn_all[:n])
+    sdf, grad, _, _ = ops.sdf_query(d["fs"], q, nbr, nn)
+    assert torch.equal(sdf, sdf_all[:n]) and torch.equal(grad, grad_all[:n])
+    # GN sums of the prefix: the per-point outputs of the fused kernel are the SDF query's, the count is exact
+    sums, s2, g2 = ops.gn_accumulate(d["fs"], _gp(d), q, nbr, nn, want_points=True)
+    np.testing.assert_allclose(s2.cpu().numpy(), sdf.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    tot = sums.cpu().numpy().sum(0)
+    gn = np.linalg.norm(grad.cpu().numpy(), axis=1)
+    valid = (nn.cpu().numpy() >= int(d["track_mask_query_nn_k"])) & (gn < 3.0) & (gn > 0.3)
+    assert int(round(tot[29])) == int(valid.sum())
+
+
+def test_queries_without_any_neighbour(gd):
+    """Points far outside the map (incl. > 2^29 cells away): no candidates, zero features, mask off, no NaN."""
+    from pin_slam_amd import ops
+    d = gd
+    k = int(d["query_nn_k"])
+    far = np.array([[500.0, -300.0, 40.0], [1e6, 1e6, -1e6], [3e8, 0.0, 0.0], [-3e8, 5.0, 2.0]], np.float32)
+    q = torch.from_numpy(np.concatenate([far, d["query"][:12]])).cuda()
+    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(d["st"], wait=True)
+    for b in (None, bricks):
+        nbr, nn, _ = ops.knn_query(d["st"], q, k, bricks=b)
+        assert (nn[:4] == 0).all() and (nbr[:4, :, 3].view(torch.int32) == -1).all()
+        s = O.radius_search(q.cpu().numpy(), d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
+                            ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                            diff_travel_dist_local=d["diff_travel_dist_local"])
+        assert np.array_equal(nn.cpu().numpy(), (s[1] >= 0).sum(1))
+        sdf, grad, std, cert = ops.sdf_query(d["fs"], q, nbr, nn)
+        assert torch.isfinite(sdf).all() and torch.isfinite(grad).all() and (cert[:4] == 0).all()
+        sums, _, _ = ops.gn_accumulate(d["fs"], _gp(d), q, nbr, nn)
+        assert np.isfinite(sums.cpu().numpy()).all()
+
+
+def test_tiny_training_batch_matches_oracle(gd):
+    """A 20-sample batch (2 Eikonal samples, 32 queries: half a wave) through pin_train_step vs the oracle."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = gd
+    k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
+    bs, dec = 20, int(d["map_dec"])
+    coord, label, w, ts = d["map_coord0"][:bs], d["map_label0"][:bs], d["map_w0"][:bs], d["map_ts0"][:bs]
+    feats, decf = U.dev(d["local_geo_features"]), U.dev(d["dec_flat"])
+    cert, tsu = U.dev(d["local_point_certainties"]), U.dev(d["local_point_ts_update"], torch.int32)
+    fs = dataclasses.replace(d["fs"], feats=feats, dec=decf, certainty=cert)
+    buf = ops.TrainBuffers(bs, dec, k, H, L)
+    gfeat, gdec = torch.zeros_like(feats), torch.zeros_like(decf)
+    ops.train_step(d["st"], fs, buf, U.dev(coord), U.dev(label), U.dev(w), U.dev(ts, torch.int32), cert, tsu, gfeat, gdec,
+                   sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"])
+
+    def searcher(p):
+        s = O.radius_search(p, d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
+                            ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                            diff_travel_dist_local=d["diff_travel_dist_local"])
+        return O.query_feature(p, s, d["local_geo_features"], d["local_neural_points"], None, k, global2local=d["global2local"],
+                               weighted_first=False)
+    ref = O.train_step(coord, label, w, searcher, d["local_geo_features"], d["local_neural_points"], d["dec_flat"], (11, H, L),
+                       d["sdf_scale"], k, dec=dec, eps=d["map_eps"], weight_e=d["map_weight_e"])
+    gf, gd_ = ref["feat_grad"], ref["dec_grad"]
+    assert np.max(np.abs(gfeat.cpu().numpy() - gf)) < 3e-4 * np.abs(gf).max()
+    assert np.max(np.abs(gdec.cpu().numpy() - gd_)) < 3e-4 * np.abs(gd_).max()
+
+
+def test_one_point_scan_through_the_sampler_and_voxel_filter():
+    from pin_slam_amd import pool as P, preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    cfg = PinConfig()
+    scan = torch.tensor([[3.0, -4.0, 1.0]], device="cuda")
+    pool = P.SamplePool(capacity=64)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rnd = (torch.randn(3, 1, device="cuda", generator=g), torch.rand(2, 1, device="cuda", generator=g), torch.rand(1, 1, device="cuda", generator=g))
+    assert pool.append_samples(scan, P.sample_params(cfg, np.eye(4), 0), rnd=rnd) == 7
+    coord, label, _, weight = O.sample_rays(scan.cpu().numpy(), None, *(r.cpu().numpy().reshape(-1) for r in rnd),
+                                            surface_range=cfg.surface_sample_range_m, surface_n=3, front_n=2, behind_n=1,
+                                            free_begin_ratio=cfg.free_sample_begin_ratio, free_end_dist=cfg.free_sample_end_dist_m,
+                                            max_range=cfg.max_range)
+    assert np.array_equal(pool.view("coord").cpu().numpy().view(np.uint32), coord.view(np.uint32))
+    assert np.array_equal(pool.view("sdf_label").cpu().numpy().view(np.uint32), label.view(np.uint32))
+    idx = PP.voxel_down_sample_torch(scan, 0.4)
+    assert idx.tolist() == [0]
+    kept, _ = PP.crop_frame(scan, None, min_range=10.0)  # 5.1 m < 10 m: cropped away
+    assert kept.shape[0] == 0
