@@ -476,6 +476,23 @@ int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg
                        int32_t row_width, const uint8_t* row_flags, int32_t step, float lr, float beta1,
                        float beta2, float eps, int32_t zero_grad, void* stream);
 
+/* Lazy exact Adam for the 8-wide feature tables (bit-identical to running pin_adam_step over the whole
+ * table every iteration, as the reference does).  State: last_step [rows] and claim [rows] (int32, both
+ * cleared when the optimiser is reset; exp_avg / exp_avg_sq need no clearing), coef [2][t_max+1] =
+ * lr/(1-beta1^t) and 1/sqrt(1-beta2^t) for t = 0..t_max (entry 0 unused), computed once on the host.
+ * Per iteration t, over the kNN records of that iteration ([n_records][4]):
+ *   phase 0 (before the forward pass): rows whose state stopped at step l < t-1 replay the gradient-free
+ *           steps l+1 .. t-1;  phase 1 (after the backward pass): step t with the row's gradient (cleared).
+ * `stamp` must grow with every call of one optimiser lifetime (it elects one owner per row and call).
+ * pin_adam_lazy_flush replays the skipped steps of every touched row up to t_final (end of Mapper.mapping). */
+int pin_adam_lazy_records(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
+                          float* exp_avg_sq, int32_t* last_step, int32_t* claim, int32_t step, int32_t phase,
+                          int32_t stamp, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                          void* stream);
+int pin_adam_lazy_flush(float* param, float* exp_avg, float* exp_avg_sq, const int32_t* last_step, int64_t n_rows,
+                        int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                        void* stream);
+
 /* ---- Mapper.process_frame data path (utils/mapper.py:162-449) ------------------------------ */
 
 /* Bytes of workspace for the pool kernels on n elements (pin_new_sample_index needs n more). */

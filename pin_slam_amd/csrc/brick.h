@@ -28,6 +28,23 @@ __device__ __forceinline__ unsigned int row_sum_u32(unsigned int v) {
     v += dpp_u32<0x140>(v);
     return v;
 }
+// the same over aligned groups of G = 8 or 16 lanes
+template <int G>
+__device__ __forceinline__ unsigned int group_min_u32(unsigned int v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    if (G == 16) v = min(v, dpp_u32<0x140>(v));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned int group_sum_u32(unsigned int v) {
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    if (G == 16) v += dpp_u32<0x140>(v);
+    return v;
+}
 
 __device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz) {
     return ((unsigned long long)(unsigned)(bx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(by + (1 << 20)) << 21) |

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) 
     pack[2 * (size_t)h + 1] = make_ulonglong2(base, 0ull);
 }
 
-template <int R>
+// G lanes per query (8 or 16), R = ceil(n_cand / G) candidates per lane
+template <int R, int G>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,
                                                                 float* __restrict__ query_out, float4* __restrict__ nbr,
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         for (int i = 0; i < 12; ++i) pose.m[i] = (float)state[i];
         pose.on = 1;
     }
-    const int sub = threadIdx.x & (BRICK_GROUP - 1);
-    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / BRICK_GROUP;
+    const int sub = threadIdx.x & (G - 1);
+    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
     const bool active = qi < n;
     const int qq = active ? qi : n - 1;
     float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     // lanes 0..7 resolve the 2x2x2 bricks that cover the candidate window
     int my_base = -1;  // -1: brick not cached
     unsigned int my_lo = 0, my_hi = 0;
-    if (sub < 8 && !far) {
+    if (sub < 8 && !far) {  // (every lane when G == 8)
         const int bx = b0x + (sub >> 2), by = b0y + ((sub >> 1) & 1), bz = b0z + (sub & 1);
         const BrickInfo bi = dir_lookup(bc, brick_key(bx, by, bz));
         my_base = bi.base; my_lo = bi.lo; my_hi = bi.hi;
@@ -221,49 +222,62 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
 
     // accepted candidates: only the distance bits stay (registers); the k winners' entries are fetched
-    // again at the end (cache hits), one winner per lane -- no LDS staging, so the occupancy is set by
-    // the ~40 VGPRs alone and more waves hide the dependent-load latency this kernel is bound by
+    // again at the end (cache hits), one winner per lane.  The candidate pass is straight-line: every lane
+    // issues its R entry loads back to back (an empty cell reads a dummy slot), so a wave pays one memory
+    // round trip for all rounds instead of one per round; cells of uncached bricks are left to a second,
+    // rarely taken pass with the reference's exact probe.
     unsigned int d2b[R];
-    int cnt = 0;
+    float4 E[R];
+    unsigned int occ = 0, slow = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int c = r * BRICK_GROUP + sub;
-        d2b[r] = 0xffffffffu;
+        const int c = r * G + sub;
         const bool has = c < sp.n_cand;
         const int cc = has ? c : 0;
         const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
         const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
         const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
         // all 16 lanes take part in the shuffles
-        const int base = __shfl(my_base, sel & 7, BRICK_GROUP);
-        const unsigned int lo = __shfl(my_lo, sel & 7, BRICK_GROUP);
-        const unsigned int hi = __shfl(my_hi, sel & 7, BRICK_GROUP);
-        if (!has) continue;
-        bool ok = false;
-        int l = -1;
-        float4 E;
-        if (base >= 0) {
-            const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
-            const unsigned int word = bit < 32 ? lo : hi;
-            if ((word >> (bit & 31)) & 1u) {
-                const unsigned int below = word & ((1u << (bit & 31)) - 1u);
-                E = entries[base + __popc(below) + (bit < 32 ? 0 : __popc(lo))];
-                l = __float_as_int(E.w);
-                ok = true;
-            }
-        } else {
-            ok = lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, E, l);  // exact slow path for uncached bricks
-        }
-        if (ok) {
-            const float dx = E.x - qx, dy = E.y - qy, dz = E.z - qz;
+        const int base = __shfl(my_base, sel & 7, G);
+        const unsigned int lo = __shfl(my_lo, sel & 7, G);
+        const unsigned int hi = __shfl(my_hi, sel & 7, G);
+        const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+        const unsigned int word = bit < 32 ? lo : hi;
+        const bool hit = has && base >= 0 && ((word >> (bit & 31)) & 1u);
+        const unsigned int below = word & ((1u << (bit & 31)) - 1u);
+        const int off = base + __popc(below) + (bit < 32 ? 0 : __popc(lo));
+        const float4* src = hit ? entries + off : reinterpret_cast<const float4*>(bc.dir_pack);
+        E[r] = *src;
+        occ |= (hit ? 1u : 0u) << r;
+        slow |= ((has && base < 0) ? 1u : 0u) << r;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
+        const float d2 = dist2_exact(dx, dy, dz);
+        const bool acc = ((occ >> r) & 1u) && !(d2 > sp.max_valid_dist2);
+        d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;  // d2 >= 0: the bit pattern orders like the value
+        cnt += acc ? 1 : 0;
+    }
+    if (slow != 0) {  // exact slow path for uncached bricks
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            if (!((slow >> r) & 1u)) continue;
+            const int c = r * G + sub;
+            const int dxc = bc.cand_dx[3 * c], dyc = bc.cand_dx[3 * c + 1], dzc = bc.cand_dx[3 * c + 2];
+            float4 P;
+            int l = -1;
+            if (!lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, P, l)) continue;
+            const float dx = P.x - qx, dy = P.y - qy, dz = P.z - qz;
             const float d2 = dist2_exact(dx, dy, dz);
-            if (!(d2 > sp.max_valid_dist2)) {
-                d2b[r] = __float_as_uint(d2);  // d2 >= 0: the bit pattern orders like the value
-                ++cnt;
-            }
+            if (d2 > sp.max_valid_dist2) continue;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) d2b[rr] = rr == r ? __float_as_uint(d2) : d2b[rr];
+            ++cnt;
         }
     }
-    cnt = (int)row_sum_u32((unsigned int)cnt);
+    cnt = (int)group_sum_u32<G>((unsigned int)cnt);
     if (active && sub == 0) nn_count[qi] = cnt;
 
     // k rounds of a 16-lane tournament on (d2 bits, candidate order): two 32-bit row reductions
@@ -275,10 +289,10 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
 #pragma unroll
         for (int r = 1; r < R; ++r)
             if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
-        const unsigned int wd = row_min_u32(bd);
+        const unsigned int wd = group_min_u32<G>(bd);
         if (wd == 0xffffffffu) break;
-        const unsigned int myc = bd == wd ? (unsigned int)(br * BRICK_GROUP + sub) : 0xffffffffu;
-        const unsigned int wc = row_min_u32(myc);
+        const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
+        const unsigned int wc = group_min_u32<G>(myc);
         if (myc == wc) {  // exactly one lane of the row
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -292,9 +306,9 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
         const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
         const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
-        const int base = __shfl(my_base, sel & 7, BRICK_GROUP);
-        const unsigned int lo = __shfl(my_lo, sel & 7, BRICK_GROUP);
-        const unsigned int hi = __shfl(my_hi, sel & 7, BRICK_GROUP);
+        const int base = __shfl(my_base, sel & 7, G);
+        const unsigned int lo = __shfl(my_lo, sel & 7, G);
+        const unsigned int hi = __shfl(my_hi, sel & 7, G);
         float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (mine >= 0) {
             float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -369,21 +383,32 @@ static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, co
     PIN_CHECK_ARG(n >= 0, "n < 0");
     PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K, "k must be in [1, 8]");
     if (n == 0) return 0;
-    PIN_CHECK_ARG(query && nbr_out && nn_count_out && bc->cand_dx, "NULL pointer");
+    PIN_CHECK_ARG(query && nbr_out && nn_count_out && bc->cand_dx && bc->dir_pack, "NULL pointer");
     PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && sp->n_cand <= 256, "bad search state");
     PoseB pose;
     pose.on = pose_host != nullptr;
     if (pose.on) memcpy(pose.m, pose_host, sizeof(pose.m));
-    const dim3 grid(cdiv((long)n * BRICK_GROUP, BRICK_BLOCK)), block(BRICK_BLOCK);
     float4* nbr = reinterpret_cast<float4*>(nbr_out);
     hipStream_t s = as_stream(stream);
-    const int rounds = cdiv(sp->n_cand, BRICK_GROUP);
-#define PIN_LAUNCH_KB(R) \
-    hipLaunchKernelGGL(knn_brick_kernel<R>, grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
-    if (rounds <= 3) PIN_LAUNCH_KB(3);
-    else if (rounds <= 6) PIN_LAUNCH_KB(6);
-    else if (rounds <= 10) PIN_LAUNCH_KB(10);
-    else PIN_LAUNCH_KB(16);
+    // Eight lanes per query while a lane's candidate list stays short: the per-query setup and the k rounds of
+    // the selection tournament are shared by twice as many queries per wave (the kernel is VALU-bound).
+    static const int forced = [] { const char* e = getenv("PIN_KNN_GROUP"); return e ? atoi(e) : 0; }();
+    const int G = sp->n_cand > 128 ? 16 : (forced == 8 || forced == 16 ? forced : 8);
+    const dim3 grid(cdiv((long)n * G, BRICK_BLOCK)), block(BRICK_BLOCK);
+    const int rounds = cdiv(sp->n_cand, G);
+#define PIN_LAUNCH_KB(R, GG) \
+    hipLaunchKernelGGL((knn_brick_kernel<R, GG>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
+    if (G == 8) {
+        if (rounds <= 4) PIN_LAUNCH_KB(4, 8);
+        else if (rounds <= 8) PIN_LAUNCH_KB(8, 8);
+        else if (rounds <= 11) PIN_LAUNCH_KB(11, 8);
+        else PIN_LAUNCH_KB(16, 8);
+    } else {
+        if (rounds <= 3) PIN_LAUNCH_KB(3, 16);
+        else if (rounds <= 6) PIN_LAUNCH_KB(6, 16);
+        else if (rounds <= 10) PIN_LAUNCH_KB(10, 16);
+        else PIN_LAUNCH_KB(16, 16);
+    }
 #undef PIN_LAUNCH_KB
     PIN_CHECK_LAUNCH();
     return 0;

@@ -828,19 +828,26 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f
 }
 
 // ---- Adam --------------------------------------------------------------------------------
+// One element, one step (torch.optim.Adam, tools.py:198-199).  Contraction is off so that every kernel
+// that applies a step -- dense, row-flagged, lazy replay -- performs the same roundings.
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr_over_bc1, float inv_sqrt_bc2,
+                                          float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = m + (g - m) * (1.f - b1);               // exp_avg.lerp_(grad, 1-beta1)
+    v = v * b2 + (1.f - b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p = p - lr_over_bc1 * (m / denom);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
                                                    float b1, float b2, float eps, int zero_grad) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     for (; i < n; i += stride) {
-        const float gi = g[i];
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * (1.f - b1);               // exp_avg.lerp_(grad, 1-beta1)
-        vi = vi * b2 + (1.f - b2) * gi * gi;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] = p[i] - lr_over_bc1 * (mi / denom);
-        m[i] = mi; v[i] = vi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, mi, vi, g[i], lr_over_bc1, inv_sqrt_bc2, b1, b2, eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
         if (zero_grad) g[i] = 0.f;
     }
 }
@@ -865,14 +872,69 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
     const long stride = (long)gridDim.x * 256;
     for (; i < n; i += stride) {
         if (!row_flags[i / row_width]) continue;
-        const float gi = g[i];
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * (1.f - b1);
-        vi = vi * b2 + (1.f - b2) * gi * gi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] = p[i] - lr_over_bc1 * (mi / denom);
-        m[i] = mi; v[i] = vi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, mi, vi, g[i], lr_over_bc1, inv_sqrt_bc2, b1, b2, eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
         if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// Lazy exact Adam for the feature tables.  The dense step moves every row that has been touched since the
+// optimiser reset (momentum), but a row's values only matter when a query reads it.  So per iteration only the
+// rows in the kNN records are visited: (phase 0, before the forward pass) a row last advanced at step l < t-1
+// replays the gradient-free steps l+1 .. t-1 it skipped; (phase 1, after the backward pass) it takes step t with
+// its gradient; rows that were touched and then left alone are replayed to the final step once, at the end
+// (adam_lazy_flush_kernel).  Every element goes through the same sequence of adam_elem calls as in the dense
+// schedule, hence bit-identical tables (tests/test_gpu_parity.py); first-touch rows start from m = v = 0
+// without the state arrays ever being cleared.  One owner per row and phase via an atomicMax stamp.
+__global__ __launch_bounds__(256) void adam_lazy_records_kernel(const float4* __restrict__ nbr, long n_records,
+                                                                float* __restrict__ p, float* __restrict__ g,
+                                                                float* __restrict__ m, float* __restrict__ v,
+                                                                int* __restrict__ last, int* __restrict__ claim, int step,
+                                                                int phase, int stamp, const float* __restrict__ coef, int t_max,
+                                                                float b1, float b2, float eps) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long rec = tid >> 3;
+    const int j = (int)(tid & 7), lane = threadIdx.x & 63;
+    int row = -1, own = 0;
+    if (rec < n_records) {
+        const int raw = __float_as_int(nbr[rec].w);
+        if (raw >= 0) row = raw & ~PIN_NBR_QUIRK_BIT;
+    }
+    if (row >= 0 && j == 0) own = atomicMax(claim + row, stamp) < stamp ? 1 : 0;
+    own = __shfl(own, lane & ~7, 64);  // the 8 lanes of a record follow their leader
+    if (!own) return;
+    const int l = last[row];
+    const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
+    if (phase == 0) {
+        if (l >= 1 && l < step - 1) {
+            float pi = p[i], mi = m[i], vi = v[i];
+            for (int s = l + 1; s <= step - 1; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+            if (j == 0) last[row] = step - 1;
+        }
+    } else {
+        float pi = p[i], mi = 0.f, vi = 0.f;
+        if (l != 0) { mi = m[i]; vi = v[i]; }  // first touch since the reset: the state starts at zero
+        adam_elem(pi, mi, vi, g[i], coef[step], coef[t_max + 1 + step], b1, b2, eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        g[i] = 0.f;
+        if (j == 0) last[row] = step;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                              float* __restrict__ v, const int* __restrict__ last, long n,
+                                                              int t_final, const float* __restrict__ coef, int t_max, float b1,
+                                                              float b2, float eps) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const int l = last[i / PIN_FEATURE_DIM];
+        if (l < 1 || l >= t_final) continue;
+        float pi = p[i], mi = m[i], vi = v[i];
+        for (int s = l + 1; s <= t_final; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -1109,6 +1171,36 @@ extern "C" int pin_adam_step_rows(float* param, float* grad, float* exp_avg, flo
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                        row_width, row_flags, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, zero_grad);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_adam_lazy_records(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
+                                     float* exp_avg_sq, int32_t* last_step, int32_t* claim, int32_t step, int32_t phase,
+                                     int32_t stamp, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                                     void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max && (phase == 0 || phase == 1), "bad step / phase");
+    if (n_records == 0) return 0;
+    PIN_CHECK_ARG(nbr && param && grad && exp_avg && exp_avg_sq && last_step && claim && coef, "NULL pointer");
+    hipLaunchKernelGGL(adam_lazy_records_kernel, dim3(cdiv(n_records * 8, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, last_step, claim,
+                       step, phase, stamp, coef, t_max, beta1, beta2, eps);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_adam_lazy_flush(float* param, float* exp_avg, float* exp_avg_sq, const int32_t* last_step, int64_t n_rows,
+                                   int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                                   void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_rows >= 0 && t_final >= 0 && t_final <= t_max, "bad sizes");
+    if (n_rows == 0 || t_final == 0) return 0;
+    PIN_CHECK_ARG(param && exp_avg && exp_avg_sq && last_step && coef, "NULL pointer");
+    const long n = (long)n_rows * PIN_FEATURE_DIM;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq,
+                       last_step, n, t_final, coef, t_max, beta1, beta2, eps);
     PIN_CHECK_LAUNCH();
     return 0;
 }

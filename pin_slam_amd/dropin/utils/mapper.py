@@ -320,7 +320,7 @@ class Mapper(_Base):
         self._check_supported()
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         t = self._get_trainer()
-        t.reset_optimizer()  # a new Adam per call (mapper.py:615)
+        t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
         from ...sharding import shard_range
         lo, hi = shard_range(self.config.bs, self.dp_rank, self.dp_world)
         sh = slice(lo, hi)
@@ -334,6 +334,7 @@ class Mapper(_Base):
                          weight[sh].to(torch.float32).contiguous(), ts[sh].to(torch.int32).contiguous(), it + 1,
                          color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous())
             self.total_iter += 1
+        t.finish_optimizer()
         if self.dp_world > 1:  # certainty / ts side effects of the other ranks' shards (engine.MapTrainer.mapping)
             import torch.distributed as dist
             delta = t.fs.certainty - cert0

@@ -174,6 +174,10 @@ class MapTrainer:
         # rows touched since the optimiser state was reset: Adam skips the others, bit-identically (ops.adam_step_rows)
         self.dirty = d[:rows]
         self.fs = fs
+        if not hasattr(self, "lazy"):  # single GPU: rows are advanced only when an iteration reads them (ops.LazyAdam)
+            self.lazy = ops.LazyAdam(self.lr, eps=self.adam_eps)
+            self.lazy_c = ops.LazyAdam(self.lr, eps=self.adam_eps)
+            self.lazy_on = False
 
     def set_color(self, fc: Optional[ops.FieldState], surface_range: float = 0.0, weight_i: float = 0.0,
                   train_decoder: bool = True):
@@ -197,26 +201,35 @@ class MapTrainer:
 
     def step_batch(self, coord, label, weight, ts, step: int, color_label=None):
         """One iteration on an explicit (already gathered) batch shard."""
+        nd = self.gdec.numel()
+        lazy = self.lazy_on
+        pre = (lambda: self.lazy.catch_up(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step)) if lazy else None
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
-                       bricks=self.bricks)
+                       bricks=self.bricks, before_forward=pre)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
+            if lazy:
+                self.lazy_c.catch_up(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step)
             ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                  self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
                                  weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
-            ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
-            ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
-                               eps=self.adam_eps)
+            if lazy:
+                self.lazy_c.step(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step)
+            else:
+                ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
+                ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
+                                   eps=self.adam_eps)
             if self.c_train_dec:
                 ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad if self.train_decoder else self.gfeat)
-        nd = self.gdec.numel()
-        if self.world == 1:
+        if lazy:
+            self.lazy.step(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step)
+        elif self.world == 1:
             ops.mark_rows(self.buf.nbr, self.dirty)
             ops.adam_step_rows(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], self.dirty, step, self.lr, eps=self.adam_eps)
         else:  # rows touched by the other ranks' shards arrive through the all-reduce: dense update
@@ -225,27 +238,53 @@ class MapTrainer:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
 
-    def reset_optimizer(self):
-        """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615)."""
-        self.m.zero_()
-        self.v.zero_()
+    def reset_optimizer(self, iters: Optional[int] = None):
+        """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615).  With the iteration count
+        known (and one GPU) the feature tables use the lazy exact Adam: call finish_optimizer() after the last
+        iteration; without it, the row-flagged / dense step."""
+        self.lazy_on = bool(iters) and self.world == 1
+        nd = self.gdec.numel()
+        if self.lazy_on:
+            dev = self.fs.feats.device
+            self.m[:nd].zero_()
+            self.v[:nd].zero_()
+            self.lazy.reset(self.fs.feats.shape[0], iters, dev)
+        else:
+            self.m.zero_()
+            self.v.zero_()
+            self.dirty.zero_()
         self.grad.zero_()
-        self.dirty.zero_()
         if self.fc is not None:
-            self.cm.zero_()
-            self.cv.zero_()
+            cnd = self.fc.dec.numel()
+            if self.lazy_on:
+                self.cm[:cnd].zero_()
+                self.cv[:cnd].zero_()
+                self.lazy_c.reset(self.fc.feats.shape[0], iters, self.fc.feats.device)
+            else:
+                self.cm.zero_()
+                self.cv.zero_()
             self.cgrad.zero_()
+
+    def finish_optimizer(self):
+        """Bring the rows the lazy optimiser left behind to the final step (no-op otherwise)."""
+        if not self.lazy_on:
+            return
+        nd = self.gdec.numel()
+        self.lazy.flush(self.fs.feats, self.m[nd:], self.v[nd:])
+        if self.fc is not None:
+            cnd = self.fc.dec.numel()
+            self.lazy_c.flush(self.fc.feats, self.cm[cnd:], self.cv[cnd:])
+        self.lazy_on = False
 
     def mapping(self, index_batches):
         """One Mapper.mapping call: a fresh Adam state (mapper.py:615) and len(index_batches)
         iterations.  index_batches[i] is this rank's int32 shard of the i-th global batch."""
-        self.m.zero_()
-        self.v.zero_()
-        self.dirty.zero_()
+        self.reset_optimizer(len(index_batches))
         if self.world > 1:
             cert0 = self.fs.certainty.clone()
         for i, idx in enumerate(index_batches):
             self.iteration(idx, i + 1)
+        self.finish_optimizer()
         if self.world > 1:  # certainty / ts side effects of the other ranks' shards
             import torch.distributed as dist
             delta = self.fs.certainty - cert0

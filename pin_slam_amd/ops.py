@@ -7,6 +7,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional
 
+import math
+
 import numpy as np
 import torch
 
@@ -362,15 +364,18 @@ class TrainBuffers:
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
-               global_n_main=None, global_n_eik=None, pred_out=None, bricks=None):
+               global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
-    -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad."""
+    -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
+    `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up)."""
     L = _lib.lib()
     s = _stream()
     check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
                                    float(np.float32(eik_eps)),
                                    _ptr(buf.query), s), "pin_train_make_queries")
     knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None), bricks=bricks)
+    if before_forward is not None:
+        before_forward()
     tp = TrainParams()
     tp.n_main, tp.n_eik, tp.loss_weight_on = buf.n_main, buf.n_eik, int(bool(loss_weight_on))
     tp.sigma, tp.weight_e, tp.eik_eps = float(sigma), float(weight_e), float(np.float32(eik_eps))
@@ -423,6 +428,69 @@ def adam_step_rows(param, grad, exp_avg, exp_avg_sq, row_flags, step, lr=0.01, b
                                         _ptr(exp_avg_sq, torch.float32), rows, width, _ptr(row_flags, torch.uint8), int(step),
                                         float(lr), float(beta1), float(beta2), float(eps), int(bool(zero_grad)), _stream()),
           "pin_adam_step_rows")
+
+
+_ADAM_COEF = {}
+
+
+def adam_coef(lr, t_max, beta1=0.9, beta2=0.99, device="cuda"):
+    """[2][t_max+1] table of lr/(1-beta1^t) and 1/sqrt(1-beta2^t), rounded exactly as pin_adam_step rounds them."""
+    key = (float(lr), float(beta1), float(beta2), str(device))
+    tab = _ADAM_COEF.get(key)
+    if tab is None or tab[1] < t_max:
+        cap = max(64, int(t_max) * 2)
+        lr32, b1, b2 = float(np.float32(lr)), float(np.float32(beta1)), float(np.float32(beta2))
+        a = np.zeros((2, cap + 1), dtype=np.float32)
+        for t in range(1, cap + 1):
+            a[0, t] = np.float32(lr32 / (1.0 - math.pow(b1, float(t))))
+            a[1, t] = np.float32(1.0 / math.sqrt(1.0 - math.pow(b2, float(t))))
+        tab = (torch.from_numpy(a).to(device), cap)
+        _ADAM_COEF[key] = tab
+    return tab
+
+
+class LazyAdam:
+    """Exact Adam over an 8-wide feature table that only visits the rows an iteration reads (pin_adam_lazy_*):
+    bit-identical to adam_step over the whole table every iteration.  reset() per Mapper.mapping call,
+    catch_up(records, t) before the forward pass, step(records, t) after the backward pass, flush() at the end."""
+
+    def __init__(self, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15):
+        self.lr, self.b1, self.b2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
+        self.state = None
+        self.t = 0
+
+    def reset(self, rows, t_max, device):
+        if self.state is None or self.state.shape[1] < rows:
+            self.state = torch.zeros((2, int(rows * 1.25) + 1024), dtype=torch.int32, device=device)
+        else:
+            self.state.zero_()
+        self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
+        self.t, self.stamp = 0, 0
+
+    def _records(self, nbr, param, grad, m, v, step, phase):
+        self.stamp += 1
+        check(_lib.lib().pin_adam_lazy_records(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
+                                               _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                               self.state[0].data_ptr(), self.state[1].data_ptr(), int(step), phase,
+                                               self.stamp, _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
+                                               _stream()), "pin_adam_lazy_records")
+
+    def catch_up(self, nbr, param, grad, m, v, step):
+        if step > self.t_max:
+            raise ValueError("more iterations than reset() was sized for")
+        self._records(nbr, param, grad, m, v, step, 0)
+
+    def step(self, nbr, param, grad, m, v, step):
+        self._records(nbr, param, grad, m, v, step, 1)
+        self.t = int(step)
+
+    def flush(self, param, m, v):
+        if self.t == 0:
+            return
+        check(_lib.lib().pin_adam_lazy_flush(_ptr(param, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                             self.state[0].data_ptr(), param.shape[0], self.t, _ptr(self.coef), self.t_max,
+                                             self.b1, self.b2, self.eps, _stream()), "pin_adam_lazy_flush")
+        self.t = 0
 
 
 def gather_batch(pool_coord, pool_label, pool_weight, pool_ts, index, out):

@@ -19,3 +19,12 @@ for a, b in list(zip(frames[:-1], frames[1:]))[-8:]:
     print(f"frame kernels={len(seg)} wall={wall/1e6:.3f} ms busy={busy/1e6:.3f} ms idle={(wall-busy)/1e6:.3f} ms")
     for k, v in gaps.most_common(8):
         print(f"    gap {v/1e3:8.1f} us  {k[0]} -> {k[1]}")
+
+# one mapping iteration in detail: kernels between two consecutive query builds, late in the run
+q = [i for i, e in enumerate(ev) if "make_queries" in e[2]]
+if len(q) > 4:
+    a, b = q[-3], q[-2]
+    print("one mapping iteration (start offset us, duration us, gap before us):")
+    t0 = ev[a][0]
+    for i in range(a, b + 1):
+        print(f"    {(ev[i][0]-t0)/1e3:8.1f} {(ev[i][1]-ev[i][0])/1e3:7.1f} {(ev[i][0]-ev[i-1][1])/1e3:7.1f}  {ev[i][2][:70]}")

@@ -326,3 +326,44 @@ def test_sparse_adam_is_bit_identical_to_dense():
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     assert 0.05 < float(flags.float().mean()) < 0.9
     assert not torch.equal(pd, p0)
+
+
+@pytest.mark.parametrize("steps", [1, 12, 70])
+def test_lazy_adam_is_bit_identical_to_dense(steps):
+    """ops.LazyAdam (catch-up before the forward pass, step after the backward pass, flush at the end)
+    against the dense pin_adam_step every iteration: the parameter table is equal bit for bit at the end,
+    and at every iteration the rows about to be read hold their dense values.  The m / v arrays start
+    as garbage on the lazy side (it never clears them); 70 steps goes beyond the default table size."""
+    from pin_slam_amd import ops
+    torch.manual_seed(steps)
+    rows, k, Q = 30_000, 8, 1500
+    p0 = torch.randn(rows + 1, 8, device="cuda")
+    pd, pl = p0.clone(), p0.clone()
+    md, vd, gd = (torch.zeros_like(p0) for _ in range(3))
+    ml, vl = torch.randn_like(p0), torch.rand_like(p0)
+    gl = torch.zeros_like(p0)
+    lazy = ops.LazyAdam(0.01, eps=1e-15)
+    lazy.reset(rows + 1, steps, "cuda")
+    touched = torch.zeros(rows + 1, dtype=torch.bool, device="cuda")
+    for step in range(1, steps + 1):
+        idx = torch.randint(0, rows, (Q, k), device="cuda")
+        idx[torch.rand(Q, k, device="cuda") < 0.2] = -1
+        if step % 3 == 0:
+            idx[:, 1] = idx[:, 0]  # duplicate rows inside a record set
+        nbr = torch.zeros((Q, k, 4), dtype=torch.float32, device="cuda")
+        nbr.view(torch.int32)[..., 3] = idx.to(torch.int32)
+        valid = torch.unique(idx[idx >= 0])
+        lazy.catch_up(nbr, pl, gl, ml, vl, step)
+        assert torch.equal(pl[valid].view(torch.int32), pd[valid].view(torch.int32)), step  # what the forward pass reads
+        g = torch.zeros_like(p0)
+        g[valid] = torch.randn(valid.numel(), 8, device="cuda")
+        gd.copy_(g); gl.copy_(g)
+        ops.adam_step(pd, gd, md, vd, step, 0.01, eps=1e-15)
+        lazy.step(nbr, pl, gl, ml, vl, step)
+        assert not gl.any()
+        touched[valid] = True
+    lazy.flush(pl, ml, vl)
+    assert torch.equal(pd.view(torch.int32), pl.view(torch.int32))
+    assert torch.equal(md[touched].view(torch.int32), ml[touched].view(torch.int32))
+    assert torch.equal(vd[touched].view(torch.int32), vl[touched].view(torch.int32))
+    assert 0.05 < float(touched.float().mean()) and not torch.equal(pd, p0)
