@@ -18,7 +18,7 @@
 // within one tile.  The weight image is staged once per block.
 #pragma once
 #include "brick.h"
-#include "mlp_quad.h"
+#include "mlp_bf3.h"
 
 namespace pin {
 
@@ -105,12 +105,12 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
 }
 
 // decoder on the matrix cores -> chain rule -> Gauss-Newton terms of the tile; tot[j] += sum 4j + g
-template <int H, bool ORIENT>
-__device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_params& gp, const float* __restrict__ lds,
+template <int H, bool ORIENT, bool BF = false>
+__device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_params& gp, const unsigned char* __restrict__ lds,
                                             const QuadIn<ORIENT>& in, int nn, float px, float py, float pz, bool active, int qi,
                                             int g, const float* __restrict__ labels, float* __restrict__ sdf_out,
                                             float* __restrict__ grad_out, float (&tot)[8]) {
-    using Q = QuadDecoder<H>;
+    using Q = QuadDec<H, BF>;
     const float s = f.sdf_scale;
     const float (&z)[4] = in.z;
     const float (&Y)[3][4] = in.Y;
@@ -178,7 +178,12 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
     }
 }
 
-template <int H, bool ORIENT>
+__host__ __device__ constexpr int gq_red_offset(int image_bytes) { return (image_bytes + 15) & ~15; }
+__host__ __device__ constexpr int gq_lds_bytes(int image_bytes) {
+    return gq_red_offset(image_bytes) + (GQ_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+}
+
+template <int H, bool ORIENT, bool BF>
 __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_field f, pin_gn_params gp,
                                                                          const float* __restrict__ query,
                                                                          const float4* __restrict__ nbr,
@@ -187,9 +192,10 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
                                                                          double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                          float* __restrict__ grad_out,
                                                                          const double* __restrict__ state) {
-    using Q = QuadDecoder<H>;
-    __shared__ __attribute__((aligned(16))) float lds[Q::TOTAL];
-    __shared__ float red[GQ_BLOCK / 64][PIN_GN_NSUMS];
+    using Q = QuadDec<H, BF>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];  // decoder image, then the block reduction
+    unsigned char* const lds = gq_smem;
+    float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
     Q::stage(f.dec, f.levels, lds, threadIdx.x, GQ_BLOCK);  // visible after the barrier that follows the first gather
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
             staged = true;
             if (!work) break;
         }
-        quad_finish<H, ORIENT>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
+        quad_finish<H, ORIENT, BF>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
     }
     __builtin_amdgcn_s_setprio(0);
     // wave: sum over the 16 queries of the row; lane (0, g) then holds sums 4j + g
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_iteration_kernel(pin_field f, 
             quad_gather<false>(f, rp, knn_k, __float_as_int(qc.w), qc.x, qc.y, qc.z, g, in);
             __threadfence_block();
             if (lane == 0) done[slot] = i + 1;  // records are in registers: the slot can be refilled
-            quad_finish<H, false>(f, gp, lds, in, __float_as_int(qc.w), qc.x, qc.y, qc.z, qi < n_q, qi, g, labels, nullptr, nullptr,
+            quad_finish<H, false, false>(f, gp, reinterpret_cast<const unsigned char*>(lds), in, __float_as_int(qc.w), qc.x, qc.y, qc.z, qi < n_q, qi, g, labels, nullptr, nullptr,
                                   tot);
         }
 #pragma unroll

@@ -723,18 +723,35 @@ static int gq_cu_count() {
     return n_cu;
 }
 
+template <int H, bool ORIENT, bool BF>
+static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                            const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                            float* grad_out, const double* state, hipStream_t s) {
+    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, BF>::bytes(MLP_MAX_LEVELS));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, BF>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+    if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
+    const int tiles = cdiv(n, 16);
+    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, BF>), grid, block, gq_lds_bytes(QuadDec<H, BF>::bytes(f->levels)), s,
+                       *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state);
+    return 0;
+}
+
 static int launch_quad(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                        const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                        float* grad_out, const double* state, hipStream_t s) {
-    const int tiles = cdiv(n, 16);
-    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
-#define PIN_LQ(HH, OO) \
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<HH, OO>), grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, \
-                       sdf_out, grad_out, state)
-    if (f->hidden == 64) { if (f->orient) PIN_LQ(64, true); else PIN_LQ(64, false); }
-    else { if (f->orient) PIN_LQ(32, true); else PIN_LQ(32, false); }
+#define PIN_LQ(HH, OO, BB) \
+    return launch_quad_inst<HH, OO, BB>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
+    const bool bf = use_bf3_decoder();
+    if (f->hidden == 64) {
+        if (f->orient) { if (bf) PIN_LQ(64, true, true); else PIN_LQ(64, true, false); }
+        else { if (bf) PIN_LQ(64, false, true); else PIN_LQ(64, false, false); }
+    } else {
+        if (f->orient) { if (bf) PIN_LQ(32, true, true); else PIN_LQ(32, true, false); }
+        else { if (bf) PIN_LQ(32, false, true); else PIN_LQ(32, false, false); }
+    }
 #undef PIN_LQ
-    return 0;
 }
 
 template <int H, int R>

@@ -1,41 +1,84 @@
-// QuadDecoder<64>::run in isolation: 12 waves per CU, T tiles per wave, synthetic inputs.
+// QuadDecoder<64>::run (fp32 MFMA) vs QuadDecoderB<64>::run (bf16x3) in isolation: agreement + time per tile.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <vector>
 #include "pin_abi.h"
-#include "mlp_quad.h"
+#include "mlp_bf3.h"
 using namespace pin;
-template <typename F> float timeit(F f, int n = 50) { for (int i = 0; i < 5; ++i) f(); hipDeviceSynchronize(); hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a); for (int i = 0; i < n; ++i) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); return ms * 1000.f / n; }
+template <typename F> float timeit(F f, int n = 30) { for (int i = 0; i < 5; ++i) f(); hipDeviceSynchronize(); hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a); for (int i = 0; i < n; ++i) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); return ms * 1000.f / n; }
 
-template <int MODE>
-__global__ __launch_bounds__(GQ_BLOCK, 1) void k_dec(const float* dec, int L, int tiles, float* out) {
-    using Q = QuadDecoder<64>;
-    __shared__ __attribute__((aligned(16))) float lds[Q::TOTAL];
-    Q::stage(dec, L, lds, threadIdx.x, blockDim.x);
+template <int H, int MODE>
+__global__ __launch_bounds__(GQ_BLOCK, 1) void k_dec(const float* dec, int L, int tiles, const float* zin, float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (MODE == 0) QuadDecoder<H>::stage(dec, L, reinterpret_cast<float*>(smem), threadIdx.x, blockDim.x);
+    else QuadDecoderB<H>::stage(dec, L, smem, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    float z[4] = {lane * 1e-3f, 0.1f, 0.2f, -0.3f};
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    float z[4];
+    for (int r = 0; r < 4; ++r) z[r] = 4 * g + r < 11 ? zin[n * 11 + 4 * g + r] : 0.f;
     float s = 0.f;
     for (int t = 0; t < tiles; ++t) {
-        float a[4];
-        const float x = Q::run(lds, L, z, a);
+        float a[4], x;
+        if (MODE == 0) x = QuadDecoder<H>::run(reinterpret_cast<const float*>(smem), L, z, a);
+        else x = QuadDecoderB<H>::run(smem, L, z, a);
+        if (t == 0 && out && blockIdx.x == 0 && threadIdx.x < 64) {
+            out[lane * 5] = x;
+            for (int r = 0; r < 4; ++r) out[lane * 5 + 1 + r] = a[r];
+        }
         s += x + a[0] + a[1] + a[2] + a[3];
         z[0] += 1e-3f * x;
     }
     if (s == 123.456f) out[0] = s;
 }
-int main() {
-    const int L = 4, H = 64;
-    const int n = 4 * (H * 11 + H) + 3 * (H * H + H) + H + 1 + 4096;
-    std::vector<float> h(n);
-    for (int i = 0; i < n; ++i) h[i] = ((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
-    float *d, *o; hipMalloc(&d, n * 4); hipMalloc(&o, 1024); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
-    for (int waves : {4, 8, 12}) {
-        const int tiles = 40;
-        float t = timeit([&] { hipLaunchKernelGGL(k_dec<0>, dim3(256), dim3(waves * 64), 0, 0, d, L, tiles, o); });
-        float t0 = timeit([&] { hipLaunchKernelGGL(k_dec<0>, dim3(256), dim3(waves * 64), 0, 0, d, L, 0, o); });
-        const double per = (t - t0) / (tiles * waves / 4.0);
-        printf("waves/CU=%2d: %.1f us (empty %.1f) -> %.2f us per tile per SIMD, MFMA share %.0f%%\n", waves, t, t0, per, 100.0 * 416 * 32 / 2400.0 / per);
+template <int H>
+void run(int L) {
+    const int n = H * 11 + H + (L - 1) * (H * H + H) + H + 1;
+    std::vector<float> h(n), z(16 * 11);
+    unsigned s = 777;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (auto& v : h) v = rnd() * 0.6f;
+    for (auto& v : z) v = rnd() * 2.f;
+    float *d, *dz, *o0, *o1;
+    hipMalloc(&d, n * 4); hipMalloc(&dz, z.size() * 4); hipMalloc(&o0, 64 * 5 * 4); hipMalloc(&o1, 64 * 5 * 4);
+    hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dz, z.data(), z.size() * 4, hipMemcpyHostToDevice);
+    const int b0 = QuadDecoder<H>::TOTAL * 4, b1 = QuadDecoderB<H>::bytes(L);
+    hipFuncSetAttribute((const void*)k_dec<H, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b0);
+    hipError_t e = hipFuncSetAttribute((const void*)k_dec<H, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b1);
+    printf("H=%d L=%d: LDS fp32 %d B, bf16x3 %d B (%s)\n", H, L, b0, b1, hipGetErrorString(e));
+    hipLaunchKernelGGL((k_dec<H, 0>), dim3(1), dim3(64), b0, 0, d, L, 1, dz, o0);
+    hipLaunchKernelGGL((k_dec<H, 1>), dim3(1), dim3(64), b1, 0, d, L, 1, dz, o1);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return; }
+    std::vector<float> r0(320), r1(320);
+    hipMemcpy(r0.data(), o0, 1280, hipMemcpyDeviceToHost); hipMemcpy(r1.data(), o1, 1280, hipMemcpyDeviceToHost);
+    // double reference on the host
+    double ex0 = 0, ex1 = 0, ea0 = 0, ea1 = 0, mx = 0, ma = 0;
+    for (int q = 0; q < 16; ++q) {
+        std::vector<double> act(H), pre(H); std::vector<std::vector<char>> mask(L, std::vector<char>(H));
+        const float* P = h.data();
+        for (int u = 0; u < H; ++u) { double t = P[H * 11 + u]; for (int c = 0; c < 11; ++c) t += (double)P[u * 11 + c] * z[q * 11 + c]; mask[0][u] = t > 0; act[u] = t > 0 ? t : 0; }
+        const float* Pl = P + H * 11 + H;
+        for (int l = 1; l < L; ++l) { for (int u = 0; u < H; ++u) { double t = Pl[H * H + u]; for (int k = 0; k < H; ++k) t += (double)Pl[u * H + k] * act[k]; pre[u] = t; }
+            for (int u = 0; u < H; ++u) { mask[l][u] = pre[u] > 0; act[u] = pre[u] > 0 ? pre[u] : 0; } Pl += H * H + H; }
+        double x = Pl[H]; for (int u = 0; u < H; ++u) x += (double)Pl[u] * act[u];
+        std::vector<double> gr(H); for (int u = 0; u < H; ++u) gr[u] = mask[L - 1][u] ? Pl[u] : 0.0;
+        for (int l = L - 1; l >= 1; --l) { const float* W = P + H * 11 + H + (l - 1) * (H * H + H); std::vector<double> g2(H, 0.0);
+            for (int k = 0; k < H; ++k) { double t = 0; for (int u = 0; u < H; ++u) t += (double)W[u * H + k] * gr[u]; g2[k] = mask[l - 1][k] ? t : 0.0; } gr = g2; }
+        for (int c = 0; c < 11; ++c) { double t = 0; for (int u = 0; u < H; ++u) t += (double)P[u * 11 + c] * gr[u];
+            const int lane = q + 16 * (c / 4), r = c % 4;
+            ea0 = fmax(ea0, fabs(t - r0[lane * 5 + 1 + r])); ea1 = fmax(ea1, fabs(t - r1[lane * 5 + 1 + r])); ma = fmax(ma, fabs(t)); }
+        ex0 = fmax(ex0, fabs(x - r0[q * 5])); ex1 = fmax(ex1, fabs(x - r1[q * 5])); mx = fmax(mx, fabs(x));
     }
-    return 0;
+    printf("  max abs err vs double:  out fp32 %.3g  bf16x3 %.3g (|out| <= %.3g);  jac fp32 %.3g  bf16x3 %.3g (|jac| <= %.3g)\n", ex0, ex1, mx, ea0, ea1, ma);
+    for (int waves : {4, 12}) {
+        const int tiles = 40;
+        float t0 = timeit([&] { hipLaunchKernelGGL((k_dec<H, 0>), dim3(256), dim3(waves * 64), b0, 0, d, L, tiles, dz, (float*)nullptr); });
+        float e0 = timeit([&] { hipLaunchKernelGGL((k_dec<H, 0>), dim3(256), dim3(waves * 64), b0, 0, d, L, 0, dz, (float*)nullptr); });
+        float t1 = timeit([&] { hipLaunchKernelGGL((k_dec<H, 1>), dim3(256), dim3(waves * 64), b1, 0, d, L, tiles, dz, (float*)nullptr); });
+        float e1 = timeit([&] { hipLaunchKernelGGL((k_dec<H, 1>), dim3(256), dim3(waves * 64), b1, 0, d, L, 0, dz, (float*)nullptr); });
+        const double den = tiles * waves / 4.0;
+        printf("  waves/CU=%2d: per tile per SIMD  fp32 %.2f us (stage %.1f)   bf16x3 %.2f us (stage %.1f)\n", waves, (t0 - e0) / den, e0, (t1 - e1) / den, e1);
+    }
 }
+int main() { run<64>(4); run<64>(2); run<32>(2); return 0; }
