@@ -62,31 +62,49 @@ struct QuadDecoderB {
     // dec: flat state_dict order (W0 [H][11], b0, hidden (W [H][H], b)*, lout.weight [OD][H], lout.bias [OD])
     __device__ static void stage(const float* __restrict__ dec, int L, unsigned char* __restrict__ w, int tid, int nthreads,
                                  int OD = 1) {
-        // hidden layers, both directions: one 16-byte slot = 8 k-values of one lane, three pieces
-        const float* P = dec + H * MLP_IN + H;
-        for (int l = 1; l < L; ++l) {
-            for (int e = tid; e < 2 * MT * NJ * 64; e += nthreads) {
-                const int lane = e & 63, j = (e >> 6) % NJ, mt = (e / (64 * NJ)) % MT, dir = e / (64 * NJ * MT);
-                const int m = lane & 15, g = lane >> 4;
-                v4u_t ph, pm, pl;
+        // hidden layers, both directions: one 16-byte slot = 8 k-values of one lane, three pieces.  One flat
+        // loop over (layer, direction, tile, K-block, lane), two slots per thread and trip so that 16 loads are
+        // in flight per thread: the staging is a chain of memory round trips, not arithmetic.
+        constexpr int SLOTS = 2 * MT * NJ * 64;  // per layer
+        const float* const P1 = dec + H * MLP_IN + H;
+        const int n_slots = (L - 1) * SLOTS;
+        auto fetch = [&](int e, float (&x)[8]) {
+            const int l1 = e / SLOTS, s = e % SLOTS;
+            const int lane = s & 63, j = (s >> 6) % NJ, mt = (s / (64 * NJ)) % MT, dir = s / (64 * NJ * MT);
+            const int row = 16 * mt + (lane & 15), g = lane >> 4;
+            const float* __restrict__ P = P1 + (size_t)l1 * (H * H + H);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int u0 = unit_of(j, g, 2 * p), u1 = unit_of(j, g, 2 * p + 1);
-                    const int row = 16 * mt + m;
-                    const float x0 = dir == 0 ? P[row * H + u0] : P[u0 * H + row];
-                    const float x1 = dir == 0 ? P[row * H + u1] : P[u1 * H + row];
-                    unsigned int a, b, c;
-                    bf_split2(x0, x1, a, b, c);
-                    ph[p] = a; pm[p] = b; pl[p] = c;
-                }
-                unsigned char* base = w + (dir == 0 ? off_hidf(L, l) : off_hidb(L, l)) + ((mt * NJ + j) * 64 + lane) * 16;
-                *reinterpret_cast<v4u_t*>(base) = ph;
-                *reinterpret_cast<v4u_t*>(base + HID_PIECE) = pm;
-                *reinterpret_cast<v4u_t*>(base + 2 * HID_PIECE) = pl;
+            for (int i = 0; i < 8; ++i) {
+                const int u = unit_of(j, g, i);
+                x[i] = dir == 0 ? P[row * H + u] : P[u * H + row];
             }
-            for (int e = tid; e < H; e += nthreads) reinterpret_cast<float*>(w + off_bias(L))[l * H + e] = P[H * H + e];
-            P += H * H + H;
+        };
+        auto emit = [&](int e, const float (&x)[8]) {
+            const int l1 = e / SLOTS, s = e % SLOTS;
+            const int dir = s / (64 * NJ * MT), rest = s % (64 * NJ * MT);
+            v4u_t ph, pm, pl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned int a, b, c;
+                bf_split2(x[2 * p], x[2 * p + 1], a, b, c);
+                ph[p] = a; pm[p] = b; pl[p] = c;
+            }
+            unsigned char* base = w + (dir == 0 ? off_hidf(L, l1 + 1) : off_hidb(L, l1 + 1)) + rest * 16;
+            *reinterpret_cast<v4u_t*>(base) = ph;
+            *reinterpret_cast<v4u_t*>(base + HID_PIECE) = pm;
+            *reinterpret_cast<v4u_t*>(base + 2 * HID_PIECE) = pl;
+        };
+        for (int e0 = tid; e0 < n_slots; e0 += 2 * nthreads) {
+            const int e1 = e0 + nthreads;
+            float x0[8], x1[8];
+            fetch(e0, x0);
+            fetch(e1 < n_slots ? e1 : e0, x1);
+            emit(e0, x0);
+            if (e1 < n_slots) emit(e1, x1);
         }
+        for (int e = tid; e < (L - 1) * H; e += nthreads)
+            reinterpret_cast<float*>(w + off_bias(L))[H + e] = P1[(size_t)(e / H) * (H * H + H) + H * H + e % H];
+        const float* P = P1 + (size_t)(L - 1) * (H * H + H);
         // layer 0 forward: lane (m, g) holds W0[16 mt + m][4g + i], i = 0..3 (zero beyond the 11 inputs)
         for (int e = tid; e < MT * 64; e += nthreads) {
             const int lane = e & 63, mt = e >> 6, m = lane & 15, g = lane >> 4;

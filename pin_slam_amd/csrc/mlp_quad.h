@@ -224,9 +224,14 @@ struct QuadDecoder {
                                                           float (&dz)[4]) {
         const int lane = threadIdx.x & 63, g = lane >> 4;
         v4f_t h[MT], acc[MT];
-        auto mask_of = [&](int l) {
-            return (unsigned int)reinterpret_cast<const unsigned short*>(mws + (size_t)l * mask_stride + q)[g];
-        };
+        // the ReLU masks of all layers are fetched up front (one round trip instead of one per layer) and kept
+        // as one 64-bit word: a register array indexed by the runtime layer would go to scratch memory
+        unsigned long long all = 0;
+#pragma unroll
+        for (int l = 0; l < MLP_MAX_LEVELS; ++l)
+            all |= (unsigned long long)reinterpret_cast<const unsigned short*>(mws + (size_t)(l < L ? l : 0) * mask_stride + q)[g]
+                   << (16 * l);
+        auto mask_of = [&](int l) { return (unsigned int)(all >> (16 * l)) & 0xffffu; };
         auto put = [&](int l) {
             if (!store) return;
 #pragma unroll

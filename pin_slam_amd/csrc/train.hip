@@ -105,27 +105,28 @@ struct NbrW {
 __device__ __forceinline__ void neighbor_weights(const float4* __restrict__ nbr, int nn, int qi, int k, NbrW& nb,
                                                  float (&vx)[PIN_MAX_K], float (&vy)[PIN_MAX_K],
                                                  float (&vz)[PIN_MAX_K], bool (&quirk)[PIN_MAX_K]) {
+    // straight-line: the k record loads are issued together (one memory round trip, not k)
+    float4 e[PIN_MAX_K];
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t) e[t] = nbr[(size_t)qi * k + (t < k ? t : 0)];
     float u[PIN_MAX_K];
     float S = 0.f;
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t) {
-        nb.idx[t] = -1; nb.w[t] = 0.f; u[t] = 0.f; quirk[t] = false; vx[t] = vy[t] = vz[t] = 0.f;
-        if (t < k) {
-            const float4 e = nbr[(size_t)qi * k + t];
-            const int raw = __float_as_int(e.w);
-            if (raw >= 0) {
-                nb.idx[t] = raw & ~PIN_NBR_QUIRK_BIT;
-                quirk[t] = (raw & PIN_NBR_QUIRK_BIT) != 0;
-                vx[t] = e.x; vy[t] = e.y; vz[t] = e.z;
-                u[t] = 1.0f / (dist2_exact(e.x, e.y, e.z) + IDW_EPS);
-            }
-            if (nn == 0) u[t] = IDW_EPS;
-            S += u[t];
-        }
+        const int raw = __float_as_int(e[t].w);
+        const bool val = t < k && raw >= 0;
+        nb.idx[t] = val ? (raw & ~PIN_NBR_QUIRK_BIT) : -1;
+        nb.w[t] = 0.f;
+        quirk[t] = val && (raw & PIN_NBR_QUIRK_BIT) != 0;
+        vx[t] = val ? e[t].x : 0.f; vy[t] = val ? e[t].y : 0.f; vz[t] = val ? e[t].z : 0.f;
+        float ut = val ? 1.0f / (dist2_exact(vx[t], vy[t], vz[t]) + IDW_EPS) : 0.f;
+        if (nn == 0 && t < k) ut = IDW_EPS;
+        u[t] = ut;
+        S += ut;
     }
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t)
-        if (t < k && nb.idx[t] >= 0) nb.w[t] = u[t] / S;
+        if (nb.idx[t] >= 0) nb.w[t] = u[t] / S;
 }
 
 template <int H>
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
 // As in gn_quad.h a wave carries one 16-query tile and lane (n, g) owns input components 4g..4g+3, so the
 // batch spreads over four times as many waves, the input / its gradient never go through LDS, and the
 // blocks are persistent (weights staged once per CU).
-constexpr int TQ_BLOCK = GQ_BLOCK;
+constexpr int TQ_BLOCK = 512;  // 8 waves per CU = 2048 tile slots for the ~1640 tiles of an iteration, 256 VGPRs per lane
 
 template <int H>
 __global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f, const float* __restrict__ query,
@@ -722,25 +723,39 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f
                                                                      int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
     using QD = QuadDecoder<H>;
     __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
-    QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
-    __syncthreads();
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (Q + 15) >> 4;
     const int n_waves = gridDim.x * (TQ_BLOCK / 64);
-    for (int tile = blockIdx.x + gridDim.x * wave; tile < n_tiles; tile += n_waves) {
+    bool staged = false;  // the weights are staged behind the first tile's gather loads (a wave has ~1 tile)
+    for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
+        const bool work = tile < n_tiles;
+        if (!work && staged) break;
         // the row stride is re-read per tile behind an optimisation barrier: hoisted out of the loop, the ~70
         // row addresses of the activation stores become live 64-bit values and spill to scratch memory
         int qst32 = ws.QsT;
         asm volatile("" : "+s"(qst32));
         const size_t QsT = (size_t)qst32;
-        const int qi = tile * 16 + nq;  // < ws.Qs: the padded column count is a multiple of 64
-        const bool active = qi < Q;
-        const int qq = active ? qi : Q - 1;
+        const int qi = (work ? tile : 0) * 16 + nq;  // < ws.Qs: the padded column count is a multiple of 64
+        const bool active = work && qi < Q;
+        const int qq = qi < Q ? qi : Q - 1;
         const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
         NbrW nb;
         float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
         bool quirk[PIN_MAX_K];
         neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
+        // one row load per neighbour and lane, all in flight together (the lanes g >= 2 re-read a feature quarter)
+        float4 row[PIN_MAX_K];
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            const size_t id = nb.idx[t] >= 0 ? (size_t)nb.idx[t] : 0;
+            row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
+        }
+        if (!staged) {
+            QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
+            __syncthreads();
+            staged = true;
+            if (!work) break;
+        }
         // training-mode side effects first (neural_points.py:685-710), so the neighbour arrays die before the decoder
         if (g == 3 && active && qi < n_main && cert_rw != nullptr) {
 #pragma unroll
@@ -753,12 +768,11 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f
         float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < PIN_MAX_K; ++t) {
-            if (nb.idx[t] < 0) continue;
+            const bool val = nb.idx[t] >= 0;  // invalid neighbours: weight 0 and a zeroed row add exact zeros
             float y[4] = {0.f, 0.f, 0.f, 0.f};
             if (g < 2) {
-                const float4 ft = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM)[g];
-                y[0] = ft.x; y[1] = ft.y; y[2] = ft.z; y[3] = ft.w;
-            } else if (g == 2) {
+                if (val) { y[0] = row[t].x; y[1] = row[t].y; y[2] = row[t].z; y[3] = row[t].w; }
+            } else if (g == 2 && val) {
                 float v[3];
                 neighbor_vector_only(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, v);
                 y[0] = v[0]; y[1] = v[1]; y[2] = v[2];
@@ -782,25 +796,23 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f
     using QD = QuadDecoder<H>;
     __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
     __shared__ float xch[TQ_BLOCK / 64][3 * 16 * 8];  // per wave: dz [16][8], w [16][8], idx [16][8]
-    QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
-    __syncthreads();
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (Q + 15) >> 4;
     const int n_waves = gridDim.x * (TQ_BLOCK / 64);
     float* sdz = xch[wave];
     float* sw = sdz + 16 * 8;
     int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
-    for (int tile = blockIdx.x + gridDim.x * wave; tile < n_tiles; tile += n_waves) {
+    bool staged = false;  // staging runs behind the first tile's loads (see train_fwd_quad_kernel)
+    for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
+        const bool work = tile < n_tiles;
+        if (!work && staged) break;
         int qst32 = ws.QsT;  // see train_fwd_quad_kernel
         asm volatile("" : "+s"(qst32));
         const size_t QsT = (size_t)qst32;
-        const int qi = tile * 16 + nq;
-        const bool active = qi < Q;
-        const int qq = active ? qi : Q - 1;
+        const int qi = (work ? tile : 0) * 16 + nq;
+        const bool active = work && qi < Q;
+        const int qq = qi < Q ? qi : Q - 1;
         const float dx = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // the prediction is sdf_scale * head
-        if (want_dec && g == 0) ws.d[(size_t)(f.levels * H) * QsT + qi] = dx;
-        float dz[4];
-        QD::backward_store(lds, f.levels, dx, ws.mask, QsT, ws.d, QsT, (size_t)qi, want_dec != 0, dz);
         // Feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature dims,
         // whole 32-byte rows per instruction; see train_bwd_mfma_kernel): exchange through the wave's LDS patch
         NbrW nb;
@@ -809,6 +821,15 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f
             bool quirk[PIN_MAX_K];
             neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
         }
+        if (!staged) {
+            QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
+            __syncthreads();
+            staged = true;
+            if (!work) break;
+        }
+        if (want_dec && g == 0) ws.d[(size_t)(f.levels * H) * QsT + qi] = dx;
+        float dz[4];
+        QD::backward_store(lds, f.levels, dx, ws.mask, QsT, ws.d, QsT, (size_t)qi, want_dec != 0, dz);
         const bool live = active && dx != 0.f;
         if (g < 2) {
 #pragma unroll
