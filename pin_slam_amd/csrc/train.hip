@@ -720,9 +720,11 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f
                                                                      const float4* __restrict__ nbr,
                                                                      const int* __restrict__ nn_count, int Q, int n_main,
                                                                      TrainWs ws, float* __restrict__ cert_rw,
-                                                                     int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
+                                                                     int* __restrict__ ts_rw, const int* __restrict__ sample_ts,
+                                                                     double* __restrict__ loss_zero) {
     using QD = QuadDecoder<H>;
     __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { loss_zero[0] = 0.0; loss_zero[1] = 0.0; }  // the loss kernel accumulates next
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (Q + 15) >> 4;
     const int n_waves = gridDim.x * (TQ_BLOCK / 64);
@@ -1041,7 +1043,6 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     carve_ws(ws, reinterpret_cast<float*>(workspace), H, L);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
-    PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
 #define PIN_TRAIN_MFMA(KERNEL, ...)                                                                      \
     do {                                                                                                 \
@@ -1059,9 +1060,10 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         return v;
     }();
     const dim3 qgrid(min(n_cu, cdiv(Q, 16))), qblock(TQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
+    if (!quad) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the tile kernel clears it itself)
     if (quad) {
-        if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
-        else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
+        else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
     } else if (mfma) {
         PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     } else {
