@@ -1,0 +1,44 @@
+"""Worker of tests/test_gpu_variants.py: one kNN + GN pass on a small synthetic map under the environment it is
+started with (kernel variants are chosen by environment variables read once per process); writes an .npz."""
+import os, sys
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pin_slam_amd import ops, synth  # noqa: E402
+from pin_slam_amd._lib import GnParams  # noqa: E402
+
+
+def main(out, hidden, levels, orient):
+    m = synth.build_map(layers=2, radius=20.0, raw_per_layer=120_000)
+    P = len(m.positions)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pos = dev(m.positions)
+    pos4 = torch.empty((P, 4), dtype=torch.float32, device="cuda")
+    ops.pack_positions(pos, torch.zeros(P, dtype=torch.int32, device="cuda"), pos4)
+    dx, mv = ops.search_neighborhood(2, 0.5, 0.4)
+    g2l = torch.arange(P + 1, dtype=torch.int32, device="cuda"); g2l[-1] = -1
+    st = ops.SearchState(table=dev(m.table), pos4=pos4, cand_off=dev(ops.candidate_offsets(dx, m.buffer_size)), n_points=P,
+                         resolution=0.4, max_valid_dist2=mv, travel_dist=torch.zeros(1, device="cuda"), cur_ts=0,
+                         diff_travel_dist_local=410.0, global2local=g2l)
+    rng = np.random.default_rng(5)
+    quat = None
+    if orient:
+        q = rng.standard_normal((P + 1, 4)).astype(np.float32)
+        quat = dev(q / np.linalg.norm(q, axis=1, keepdims=True))
+    fs = ops.FieldState(feats=dev(m.features), dec=dev(synth.init_decoder(hidden, levels)), k=8, hidden=hidden, levels=levels,
+                        weighted_first=True, sdf_scale=0.055, certainty=torch.zeros(P, device="cuda"), pos=pos, orient=quat)
+    scan = dev(synth.make_scan(m, n=20_011, radius=18.0))
+    gp = GnParams(); gp.valid_nn_k = 6; gp.min_grad_norm = 1e-5; gp.max_grad_norm = 1e3; gp.max_sdf_std = 0.25  # random-init decoder: tiny gradients
+    gp.gm_dist = 0.3; gp.gm_grad = 0.1
+    T = np.eye(4); T[:3, 3] = (0.03, -0.02, 0.01)
+    bricks = ops.BrickCache(dx, 2).build(st, wait=True)
+    nbr, nn, cur = ops.knn_query(st, scan, 8, pose=T, bricks=bricks)
+    sums, sdf, grad = ops.gn_accumulate(fs, gp, cur, nbr, nn, want_points=True)
+    torch.cuda.synchronize()
+    np.savez(out, nbr=nbr.cpu().numpy().view(np.int32), nn=nn.cpu().numpy(), cur=cur.cpu().numpy(),
+             sums=sums.cpu().numpy().sum(0), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
