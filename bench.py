@@ -46,6 +46,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA rate
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def parse():
@@ -248,6 +249,10 @@ def main():
     # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian
     flops_q = 2 * 2 * (11 * H + (L - 1) * H * H + H)
     gn_tflops = flops_q * n_reg / (gn_ms * 1e-3) / 1e12
+    # what the matrix cores execute: every fp32 product as six bf16 piece products (mlp_bf3.h), layer 0 padded to K = 16
+    split_bf16 = os.environ.get("PIN_MLP", "") != "f32"
+    exec_flops_q = 6 * 2 * 2 * (16 * H + (L - 1) * H * H) if split_bf16 else 2 * 2 * (16 * H + (L - 1) * H * H)
+    exec_tflops = exec_flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     Kc = int(npts.neighbor_K)
     rho = nn_mean / Kc  # measured fraction of candidate cells holding an accepted neural point
     # algorithmic bytes of one kNN launch (DESIGN.md "kernel: knn_query"): query in + out,
@@ -289,7 +294,13 @@ def main():
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
                      "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "avg_launch_ms": round(gn_ms, 4),
                      "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,
-                     "share_of_frame": round(gn_ms * args.reg_iters / ms_step, 3)},
+                     "share_of_frame": round(gn_ms * args.reg_iters / ms_step, 3),
+                     "arithmetic": ("fp32 factors split exactly into 3 bf16 pieces, 6 piece products per fp32 product on "
+                                    "v_mfma_f32_16x16x32_bf16, fp32 accumulate; `achieved`/`peak` are fp32-equivalent")
+                                   if split_bf16 else "v_mfma_f32_16x16x4_f32",
+                     "executed": {"flops_per_query": exec_flops_q, "tflops": round(exec_tflops, 1),
+                                  "peak": BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS,
+                                  "frac": round(exec_tflops / (BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS), 4)}},
         "roofline_knn": {"kernel": "knn_brick_kernel" if npts._bricks is not None else "knn_query_kernel", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_data.get("knn_brick_hbm_bytes_per_launch"),

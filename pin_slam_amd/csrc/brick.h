@@ -95,8 +95,7 @@ __device__ __forceinline__ BrickInfo dir_lookup(const pin_brick_cache& bc, unsig
 __device__ __forceinline__ bool lookup_cell(const pin_search_params& sp, long long cx, long long cy, long long cz,
                                             float d_cur, float4& P, int& l) {
     const long long h = cx * PRIME0 + cy * PRIME1 + cz * PRIME2;
-    long long m = h % sp.buffer_size;
-    if (m < 0) m += sp.buffer_size;
+    const long long m = mod_nonneg(h, sp.buffer_size);
     const int j = sp.table[m];
     if (j < 0) return false;
     P = reinterpret_cast<const float4*>(sp.pos4)[j];

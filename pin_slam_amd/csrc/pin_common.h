@@ -55,13 +55,23 @@ __device__ __forceinline__ long long voxel_coord(float p, float res) {
     return (long long)floorf(__fdiv_rn(p, res));
 }
 
+// h mod B in [0, B) for |h| < 2^62, 0 < B < 2^40.  The 64-bit signed `%` is ~200 emulated vector instructions;
+// here the quotient is estimated in fp64 (exact to +-1: the estimate errs by < 2^-40 of itself) and the
+// remainder fixed up in exact integer arithmetic.
+__device__ __forceinline__ long long mod_nonneg(long long h, long long B) {
+    const double inv = 1.0 / (double)B;  // loop-invariant at every call site
+    const long long q = (long long)floor((double)h * inv);
+    long long r = h - q * B;
+    if (r < 0) r += B;
+    if (r >= B) r -= B;
+    return r;
+}
+
 // Mathematical (non-negative) modulus of the spatial hash = fmod + negative-index wrap of
 // the reference (neural_points.py:972-978).
 __device__ __forceinline__ uint32_t hash_base(float x, float y, float z, float res, long long B) {
-    long long h = voxel_coord(x, res) * PRIME0 + voxel_coord(y, res) * PRIME1 + voxel_coord(z, res) * PRIME2;
-    long long m = h % B;
-    if (m < 0) m += B;
-    return (uint32_t)m;
+    const long long h = voxel_coord(x, res) * PRIME0 + voxel_coord(y, res) * PRIME1 + voxel_coord(z, res) * PRIME2;
+    return (uint32_t)mod_nonneg(h, B);
 }
 
 // (dx*dx + dy*dy) + dz*dz with one rounding per operation -- never contracted to FMA, so
