@@ -244,6 +244,20 @@ def main():
     barrier()
     elapsed_ds = time.perf_counter() - t0
 
+    # achievable HBM ceiling on this box: a 1 GiB device-to-device copy (read + write), outside the timed regions
+    ca = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    cb = torch.empty_like(ca)
+    for _ in range(2):
+        cb.copy_(ca)
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(5):
+        cb.copy_(ca)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * ca.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del ca, cb
     knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
     gn_ms = float(np.mean([a.elapsed_time(b) for a, b in gn_pairs])) if gn_pairs else float("nan")
     # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian
@@ -306,6 +320,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_data.get("knn_brick_hbm_bytes_per_launch"),
                          "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
                          "algorithmic_bytes_per_query": round(bytes_q, 1),
+                         "measured_copy_gbs": round(copy_gbs, 1),
                          "share_of_frame": round(knn_ms * args.reg_iters / ms_step, 3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
