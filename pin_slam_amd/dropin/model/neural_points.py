@@ -18,6 +18,7 @@ Differences, by design:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -297,7 +298,29 @@ class NeuralPoints(nn.Module):
         if self._brick_cache is None or self._brick_cache.cand_dx.shape[0] != self.neighbor_K:
             self._brick_cache = ops.BrickCache(self.neighbor_dx.cpu().numpy(), int(self.config.num_nei_cells), self.device)
         tf = self.temporal_local_map_on and self.travel_dist is not None
-        self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
+        # The build (~0.4 ms of GPU time) runs on a side stream: the rest of Mapper.process_frame (pool filter,
+        # certainty query, new-sample index) is a chain of small kernels and count read-backs that leaves the GPU
+        # mostly idle and does not touch the cache.  Consumers go through _use_bricks(), which orders their stream
+        # behind the build.
+        if os.environ.get("PIN_BRICKS_ASYNC", "1") == "0":
+            self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
+            self._bricks_event = None
+            return
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side, main = self._side_stream, torch.cuda.current_stream()
+        side.wait_stream(main)  # the local map it reads was written on the caller's stream
+        with torch.cuda.stream(side):
+            self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
+            self._bricks_event = side.record_event()
+
+    def _use_bricks(self):
+        """The current brick cache (or None), with the caller's stream ordered behind its build."""
+        ev = getattr(self, "_bricks_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._bricks_event = None
+        return self._bricks
 
     # ------------------------------------------------------------------ K10
     def assign_local_to_global(self):
@@ -317,7 +340,7 @@ class NeuralPoints(nn.Module):
     def knn(self, points: torch.Tensor, query_locally: bool = True, pose=None, out=None):
         """kNN record of the hot path (pin_knn_query)."""
         tf = self.temporal_local_map_on and query_locally and self.travel_dist is not None
-        b = self._bricks
+        b = self._use_bricks()
         if b is not None and (not query_locally or b.mode[:2] != (bool(tf), True) or self.neighbor_K != b.cand_dx.shape[0]):
             b = None  # global queries / a temporarily changed neighbourhood use the direct probe
         return ops.knn_query(self.search_state(), points, self.config.query_nn_k, time_filtering=tf,
@@ -436,6 +459,7 @@ class NeuralPoints(nn.Module):
         self._g2l = None
         self._ws = None
         self._bricks = self._brick_cache = None
+        self._side_stream = self._bricks_event = None  # (stream / event handles do not pickle)
         # shrink to size so the pickled map holds only live rows
         n = self._n
         self._g = {k: (None if t is None else t[:(n + 1 if k in ("geo", "color") else n)].clone())

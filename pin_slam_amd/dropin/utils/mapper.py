@@ -310,7 +310,7 @@ class Mapper(_Base):
                         train_decoder=bool(self.color_mlp.lout.weight.requires_grad))
         else:
             t.set_color(None)
-        b = npts._bricks
+        b = npts._use_bricks()
         tf = bool(npts.temporal_local_map_on and npts.travel_dist is not None)
         t.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
         return t

@@ -47,7 +47,7 @@ class Tracker:
         g = self._gn
         g.st, g.fs, g.gp, g.lm_lambda = st, fs, gp, lm_lambda
         tf = bool(npts.temporal_local_map_on and self.reg_local_map and npts.travel_dist is not None)
-        b = npts._bricks if self.reg_local_map else None
+        b = npts._use_bricks() if self.reg_local_map else None
         g.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
         g.local = self.reg_local_map
         return g
