@@ -30,7 +30,7 @@ def test_knn_group_sizes_agree_bitwise(tmp_path):
     assert int((a["nn"] >= 6).sum()) > 10_000  # a real search, not an empty one
 
 
-@pytest.mark.parametrize("hidden,levels,orient", [(64, 4, 0), (64, 4, 1), (32, 2, 0), (64, 2, 1)])
+@pytest.mark.parametrize("hidden,levels,orient", [(64, 4, 0), (64, 4, 1), (32, 2, 0), (64, 2, 1), (64, 1, 0), (32, 3, 1)])
 def test_split_bf16_decoder_matches_fp32_mfma(tmp_path, hidden, levels, orient):
     a = _run(tmp_path, "f32", {"PIN_MLP": "f32"}, hidden, levels, orient)
     b = _run(tmp_path, "bf3", {"PIN_MLP": "bf3"}, hidden, levels, orient)
