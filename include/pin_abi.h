@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 4
+#define PIN_ABI_VERSION 5
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -126,7 +126,16 @@ typedef struct pin_field {
     int32_t weighted_first;  /* config.weighted_first (utils/config.py:93) */
     float   sdf_scale;       /* logistic_gaussian_ratio * sigma_sigmoid_m (decoder.py:54-56) */
     int32_t out_dim;         /* decoder heads: 1 (sdf; 0 means 1) or 3 (colour, Decoder.regress_color) */
+    int32_t dec_image_bytes; /* size of dec_image, 0 if none */
+    const void* dec_image;   /* optional: the decoder as the Gauss-Newton tile kernel lays it out in LDS (split-bf16
+                                pieces, both directions), written by pin_stage_decoder for THIS dec / hidden / levels.
+                                The kernel then copies it instead of re-splitting `dec` in every block of every launch;
+                                restage whenever the decoder parameters change.  NULL = stage from `dec`. */
 } pin_field;
+
+/* pin_field.dec_image: size for a decoder shape (0 if that shape has no staged form), and the staging launch. */
+int64_t pin_decoder_image_bytes(int32_t hidden, int32_t levels);
+int pin_stage_decoder(const pin_field* f, void* image_out, int64_t image_bytes, void* stream);
 
 /* ---- Gauss-Newton registration (Tracker.registration_step + implicit_reg,
  * utils/tracker.py:409-524, 615-695) --------------------------------------------- */

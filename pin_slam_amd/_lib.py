@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 64
-PIN_ABI_VERSION = 4
+PIN_ABI_VERSION = 5
 
 vp = C.c_void_p
 
@@ -44,7 +44,7 @@ class Field(C.Structure):
     _fields_ = [
         ("feats", vp), ("certainty", vp), ("orient", vp), ("pos", vp), ("dec", vp),
         ("k", C.c_int32), ("hidden", C.c_int32), ("levels", C.c_int32), ("weighted_first", C.c_int32),
-        ("sdf_scale", C.c_float), ("out_dim", C.c_int32),
+        ("sdf_scale", C.c_float), ("out_dim", C.c_int32), ("dec_image_bytes", C.c_int32), ("dec_image", vp),
     ]
 
 
@@ -134,6 +134,8 @@ SIGNATURES = {
     "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),
     "pin_knn_query": (i32, [P(SearchParams), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_gn_state_init": (i32, [vp, vp, i32, vp]),
+    "pin_decoder_image_bytes": (i64, [i32, i32]),
+    "pin_stage_decoder": (i32, [P(Field), vp, i64, vp]),
     "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_gn_iteration": (i32, [P(SearchParams), P(BrickCacheC), P(Field), P(GnParams), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

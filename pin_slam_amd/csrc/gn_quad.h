@@ -197,7 +197,17 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
     unsigned char* const lds = gq_smem;
     float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
-    Q::stage(f.dec, f.levels, lds, threadIdx.x, GQ_BLOCK);  // visible after the barrier that follows the first gather
+    // weights: copy the image staged once per registration (pin_stage_decoder) or split them here; either way the
+    // image is visible after the barrier that follows the first gather
+    if (BF && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        const int n16 = f.dec_image_bytes >> 4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n16; i += GQ_BLOCK) dst[i] = src[i];
+    } else {
+        Q::stage(f.dec, f.levels, lds, threadIdx.x, GQ_BLOCK);
+    }
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (n_q + 15) >> 4;
     const int n_simd = gridDim.x * 4;

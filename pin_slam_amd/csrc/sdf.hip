@@ -900,6 +900,35 @@ extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32
     return 0;
 }
 
+// ---- decoder image for the GN tile kernel (pin_field.dec_image) ------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(GQ_BLOCK) void stage_decoder_kernel(pin_field f, unsigned char* __restrict__ out) {
+    QuadDecoderB<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK);
+}
+
+extern "C" int64_t pin_decoder_image_bytes(int32_t hidden, int32_t levels) {
+    if (!use_bf3_decoder() || levels < 1 || levels > MLP_MAX_LEVELS) return 0;
+    if (hidden == 64) return QuadDecoderB<64>::bytes(levels);
+    if (hidden == 32) return QuadDecoderB<32>::bytes(levels);
+    return 0;
+}
+
+extern "C" int pin_stage_decoder(const pin_field* f, void* image_out, int64_t image_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(f && f->dec && image_out, "NULL pointer");
+    PIN_CHECK_ARG(image_bytes > 0 && image_bytes == pin_decoder_image_bytes(f->hidden, f->levels),
+                  "image size does not match pin_decoder_image_bytes(hidden, levels)");
+    PIN_CHECK_ARG(((uintptr_t)image_out & 15) == 0, "image must be 16-byte aligned");
+    pin_field g = *f;
+    g.dec_image = nullptr;
+    g.dec_image_bytes = 0;
+    unsigned char* out = reinterpret_cast<unsigned char*>(image_out);
+    if (f->hidden == 64) hipLaunchKernelGGL(stage_decoder_kernel<64>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out);
+    else hipLaunchKernelGGL(stage_decoder_kernel<32>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
                           const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, void* stream) {
     PIN_ENTER();

@@ -69,6 +69,9 @@ class GNTracker:
         check(L.pin_gn_state_init(self.state.data_ptr(), T0.ctypes.data, n, stream), "pin_gn_state_init")
         self.sums.zero_()
         sp = self.st.params(time_filtering=time_filtering, local=local)
+        # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder)
+        if self.fs.weighted_first and color is None and os.environ.get("PIN_DEC_IMAGE", "1") != "0":
+            self.fs.stage_decoder()
         f = self.fs.params()
         bc = None
         if self.bricks is not None:

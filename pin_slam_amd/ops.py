@@ -225,6 +225,21 @@ class FieldState:
     orient: Optional[torch.Tensor] = None   # only after PGO
     pos: Optional[torch.Tensor] = None      # [M,3]
     out_dim: int = 1                        # 1 = sdf head, 3 = colour heads
+    dec_image: Optional[torch.Tensor] = None  # staged decoder (stage_decoder), valid for the current `dec` contents
+
+    def stage_decoder(self):
+        """Stage the decoder once for the launches that follow (pin_stage_decoder); call again after the decoder
+        parameters change.  No-op for decoder shapes without a staged form."""
+        nbytes = int(_lib.lib().pin_decoder_image_bytes(int(self.hidden), int(self.levels)))
+        if nbytes == 0 or self.dec is None:
+            self.dec_image = None
+            return
+        if self.dec_image is None or self.dec_image.numel() != nbytes:
+            self.dec_image = torch.empty((nbytes,), dtype=torch.uint8, device=self.feats.device)
+        img, self.dec_image = self.dec_image, None
+        f = self.params()
+        check(_lib.lib().pin_stage_decoder(C.byref(f), img.data_ptr(), nbytes, _stream()), "pin_stage_decoder")
+        self.dec_image = img
 
     def params(self) -> Field:
         f = Field()
@@ -237,6 +252,8 @@ class FieldState:
         f.weighted_first = int(bool(self.weighted_first))
         f.sdf_scale = float(self.sdf_scale)
         f.out_dim = int(self.out_dim)
+        if self.dec_image is not None:
+            f.dec_image, f.dec_image_bytes = self.dec_image.data_ptr(), self.dec_image.numel()
         return f
 
 

@@ -367,3 +367,31 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
     assert torch.equal(md[touched].view(torch.int32), ml[touched].view(torch.int32))
     assert torch.equal(vd[touched].view(torch.int32), vl[touched].view(torch.int32))
     assert 0.05 < float(touched.float().mean()) and not torch.equal(pd, p0)
+
+
+def test_staged_decoder_image_changes_no_bit():
+    """pin_stage_decoder + pin_field.dec_image (the GN tile kernel copies the staged image instead of splitting the
+    decoder in every block): SDF and gradient of every point are bit-identical with and without it, and a restaged
+    image follows a changed decoder."""
+    from pin_slam_amd import _lib, ops
+    from tests import golden_util as G
+    from tests import gpu_util as U
+    for case in ("c2_wf", "c3_bigtable"):
+        d = G.load(case)
+        st, fs = U.search_state(d), U.field_state(d, local=True)
+        if not fs.weighted_first or _lib.lib().pin_decoder_image_bytes(fs.hidden, fs.levels) == 0:
+            continue
+        gp = _gn_params(d)
+        q = U.dev(d["query"])
+        nbr, nn, _ = ops.knn_query(st, q, fs.k)
+        _, sdf0, g0 = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+        fs.stage_decoder()
+        assert fs.dec_image is not None and fs.params().dec_image_bytes == fs.dec_image.numel()
+        _, sdf1, g1 = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+        assert torch.equal(sdf0.view(torch.int32), sdf1.view(torch.int32)) and torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+        fs.dec = fs.dec * 1.01  # a changed decoder needs a new image
+        fs.stage_decoder()
+        _, sdf2, _ = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+        img, fs.dec_image = fs.dec_image, None
+        _, sdf3, _ = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+        assert torch.equal(sdf2.view(torch.int32), sdf3.view(torch.int32)) and not torch.equal(sdf2, sdf0)
