@@ -494,10 +494,15 @@ int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg
  *           steps l+1 .. t-1;  phase 1 (after the backward pass): step t with the row's gradient (cleared).
  * `stamp` must grow with every call of one optimiser lifetime (it elects one owner per row and call).
  * pin_adam_lazy_flush replays the skipped steps of every touched row up to t_final (end of Mapper.mapping). */
+typedef struct pin_adam_dense {   /* a dense tensor (the decoder) stepped in the same launch as the rows' step */
+    float* param; float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;
+} pin_adam_dense;
 int pin_adam_lazy_records(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
                           float* exp_avg_sq, int32_t* last_step, int32_t* claim, int32_t step, int32_t phase,
                           int32_t stamp, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                          void* stream);
+                          const pin_adam_dense* dense /* NULL, or (phase 1) = pin_adam_step(dense, step) with the
+                          table's coefficients and zero_grad */, void* stream);
 int pin_adam_lazy_flush(float* param, float* exp_avg, float* exp_avg_sq, const int32_t* last_step, int64_t n_rows,
                         int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
                         void* stream);

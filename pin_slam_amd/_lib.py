@@ -48,6 +48,10 @@ class Field(C.Structure):
     ]
 
 
+class AdamDense(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", C.c_int64)]
+
+
 class ColorTerm(C.Structure):
     _fields_ = [("field", C.POINTER(Field)), ("colors", vp), ("mode", C.c_int32), ("photo_weight", C.c_float)]
 
@@ -163,7 +167,7 @@ SIGNATURES = {
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),
     "pin_adam_step_rows": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, f32, i32, vp]),
-    "pin_adam_lazy_records": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, f32, f32, f32, vp]),
+    "pin_adam_lazy_records": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
     "pin_adam_lazy_flush": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, vp]),
     "pin_pool_workspace_bytes": (i64, [i64]),
     "pin_sample_rays": (i32, [P(SampleParams), vp, vp, i32, i32, vp, vp, vp, P(PoolArrays), vp]),

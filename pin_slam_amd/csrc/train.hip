@@ -915,7 +915,18 @@ __global__ __launch_bounds__(256) void adam_lazy_records_kernel(const float4* __
                                                                 float* __restrict__ m, float* __restrict__ v,
                                                                 int* __restrict__ last, int* __restrict__ claim, int step,
                                                                 int phase, int stamp, const float* __restrict__ coef, int t_max,
-                                                                float b1, float b2, float eps) {
+                                                                float b1, float b2, float eps, int rec_blocks,
+                                                                pin_adam_dense dense) {
+    if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `step`
+        const long e = (long)((int)blockIdx.x - rec_blocks) * 256 + threadIdx.x;
+        if (e < dense.n) {
+            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
+            adam_elem(pi, mi, vi, dense.grad[e], coef[step], coef[t_max + 1 + step], b1, b2, eps);
+            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
+            dense.grad[e] = 0.f;
+        }
+        return;
+    }
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long rec = tid >> 3;
     const int j = (int)(tid & 7), lane = threadIdx.x & 63;
@@ -1201,14 +1212,22 @@ extern "C" int pin_adam_step_rows(float* param, float* grad, float* exp_avg, flo
 extern "C" int pin_adam_lazy_records(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
                                      float* exp_avg_sq, int32_t* last_step, int32_t* claim, int32_t step, int32_t phase,
                                      int32_t stamp, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                                     void* stream) {
+                                     const pin_adam_dense* dense, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max && (phase == 0 || phase == 1), "bad step / phase");
-    if (n_records == 0) return 0;
-    PIN_CHECK_ARG(nbr && param && grad && exp_avg && exp_avg_sq && last_step && claim && coef, "NULL pointer");
-    hipLaunchKernelGGL(adam_lazy_records_kernel, dim3(cdiv(n_records * 8, 256)), dim3(256), 0, as_stream(stream),
+    pin_adam_dense d;
+    memset(&d, 0, sizeof(d));
+    if (dense != nullptr && dense->n > 0) {
+        PIN_CHECK_ARG(phase == 1, "a dense tensor rides along with the step (phase 1) only");
+        PIN_CHECK_ARG(dense->param && dense->grad && dense->exp_avg && dense->exp_avg_sq && coef, "dense tensor: NULL pointer");
+        d = *dense;
+    }
+    if (n_records == 0 && d.n == 0) return 0;
+    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && last_step && claim && coef), "NULL pointer");
+    const int rec_blocks = (int)cdiv(n_records * 8, 256), dense_blocks = (int)cdiv(d.n, 256);
+    hipLaunchKernelGGL(adam_lazy_records_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, last_step, claim,
-                       step, phase, stamp, coef, t_max, beta1, beta2, eps);
+                       step, phase, stamp, coef, t_max, beta1, beta2, eps, rec_blocks, d);
     PIN_CHECK_LAUNCH();
     return 0;
 }

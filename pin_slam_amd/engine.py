@@ -220,24 +220,26 @@ class MapTrainer:
                                  self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
                                  weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
             if lazy:
-                self.lazy_c.step(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step)
+                cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
+                self.lazy_c.step(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
             else:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
                                    eps=self.adam_eps)
-            if self.c_train_dec:
+            if self.c_train_dec and not lazy:
                 ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grad if self.train_decoder else self.gfeat)
-        if lazy:
-            self.lazy.step(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step)
+        if lazy:  # (the decoder's dense step rides along in the same launch)
+            dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
+            self.lazy.step(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)
         elif self.world == 1:
             ops.mark_rows(self.buf.nbr, self.dirty)
             ops.adam_step_rows(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], self.dirty, step, self.lr, eps=self.adam_eps)
         else:  # rows touched by the other ranks' shards arrive through the all-reduce: dense update
             ops.adam_step(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, self.lr, eps=self.adam_eps)
-        if self.train_decoder:
+        if self.train_decoder and not lazy:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
 

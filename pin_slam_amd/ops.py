@@ -484,21 +484,28 @@ class LazyAdam:
         self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
         self.t, self.stamp = 0, 0
 
-    def _records(self, nbr, param, grad, m, v, step, phase):
+    def _records(self, nbr, param, grad, m, v, step, phase, dense=None):
         self.stamp += 1
+        d = None
+        if dense is not None:  # (param, grad, exp_avg, exp_avg_sq) of a dense tensor stepped in the same launch
+            d = _lib.AdamDense()
+            d.param, d.grad, d.exp_avg, d.exp_avg_sq = (_ptr(t, torch.float32) for t in dense)
+            d.n = dense[0].numel()
         check(_lib.lib().pin_adam_lazy_records(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
                                                _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
                                                self.state[0].data_ptr(), self.state[1].data_ptr(), int(step), phase,
                                                self.stamp, _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
-                                               _stream()), "pin_adam_lazy_records")
+                                               C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_records")
 
     def catch_up(self, nbr, param, grad, m, v, step):
         if step > self.t_max:
             raise ValueError("more iterations than reset() was sized for")
         self._records(nbr, param, grad, m, v, step, 0)
 
-    def step(self, nbr, param, grad, m, v, step):
-        self._records(nbr, param, grad, m, v, step, 1)
+    def step(self, nbr, param, grad, m, v, step, dense=None):
+        """`dense` = (param, grad, exp_avg, exp_avg_sq): the same Adam step on a dense tensor (the decoder) in the
+        same launch, identical to adam_step(..., step, lr) with zero_grad."""
+        self._records(nbr, param, grad, m, v, step, 1, dense)
         self.t = int(step)
 
     def flush(self, param, m, v):

@@ -345,6 +345,9 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
     lazy = ops.LazyAdam(0.01, eps=1e-15)
     lazy.reset(rows + 1, steps, "cuda")
     touched = torch.zeros(rows + 1, dtype=torch.bool, device="cuda")
+    d0 = torch.randn(1337, device="cuda")
+    dec_a = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
+    dec_b = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
     for step in range(1, steps + 1):
         idx = torch.randint(0, rows, (Q, k), device="cuda")
         idx[torch.rand(Q, k, device="cuda") < 0.2] = -1
@@ -359,8 +362,14 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
         g[valid] = torch.randn(valid.numel(), 8, device="cuda")
         gd.copy_(g); gl.copy_(g)
         ops.adam_step(pd, gd, md, vd, step, 0.01, eps=1e-15)
-        lazy.step(nbr, pl, gl, ml, vl, step)
-        assert not gl.any()
+        # a dense tensor (the decoder) rides along with the step launch: same bits as its own adam_step
+        gdec = torch.randn(1337, device="cuda")
+        ga, gb = gdec.clone(), gdec.clone()
+        ops.adam_step(dec_a[0], ga, dec_a[1], dec_a[2], step, 0.01, eps=1e-15)
+        lazy.step(nbr, pl, gl, ml, vl, step, dense=(dec_b[0], gb, dec_b[1], dec_b[2]))
+        assert not gl.any() and not gb.any()
+        for x, y in zip(dec_a, dec_b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
         touched[valid] = True
     lazy.flush(pl, ml, vl)
     assert torch.equal(pd.view(torch.int32), pl.view(torch.int32))
