@@ -463,6 +463,35 @@ __global__ __launch_bounds__(MF_BLOCK) void train_bwd_mfma_kernel(pin_field f, c
 }
 
 // ---- loss --------------------------------------------------------------------------------
+// d loss / d prediction of query qi with the arithmetic of train_loss_kernel below (same bits), for kernels that
+// fold the loss into their own prologue; l_bce / l_eik receive this query's loss terms (the Eikonal term of a
+// sample is reported by its first query).
+__device__ __forceinline__ float loss_dpred(const pin_train_params& tp, const float* __restrict__ label,
+                                            const float* __restrict__ weight, const float* __restrict__ pred, int qi,
+                                            double& l_bce, double& l_eik) {
+    l_bce = 0.0; l_eik = 0.0;
+    if (qi < tp.n_main) {
+        const float xl = pred[qi] / tp.sigma;
+        const float y = 1.f / (1.f + expf(-label[qi] / tp.sigma));
+        float l = fmaxf(xl, 0.f) - xl * y + log1pf(expf(-fabsf(xl)));
+        float g = 1.f / (1.f + expf(-xl)) - y;
+        if (tp.loss_weight_on) { const float w = fabsf(weight[qi]); l *= w; g *= w; }
+        l_bce = (double)l;
+        return g * tp.inv_n_main / tp.sigma;
+    }
+    const int e = qi - tp.n_main, s = e / 6, a = e - 6 * s;
+    if (s >= tp.n_eik) return 0.f;
+    const float* P = pred + tp.n_main + 6 * s;
+    const float two_eps = 2.f * tp.eik_eps;
+    const float gx = (P[0] - P[1]) / two_eps, gy = (P[2] - P[3]) / two_eps, gz = (P[4] - P[5]) / two_eps;
+    const float n = sqrtf(gx * gx + gy * gy + gz * gz);
+    const float r = n - 1.f;
+    if (a == 0) l_eik = (double)(r * r);
+    const float c = n > 0.f ? tp.weight_e * 2.f * r * tp.inv_n_eik / (n * two_eps) : 0.f;
+    const float ga = a < 2 ? gx : (a < 4 ? gy : gz);
+    return (a & 1) ? -c * ga : c * ga;
+}
+
 __global__ __launch_bounds__(256) void train_loss_kernel(pin_train_params tp, const float* __restrict__ label,
                                                          const float* __restrict__ weight, TrainWs ws,
                                                          double* __restrict__ loss_out) {
@@ -794,10 +823,15 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f
 template <int H>
 __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f, const float4* __restrict__ nbr,
                                                                      const int* __restrict__ nn_count, int Q, TrainWs ws,
-                                                                     float* __restrict__ feat_grad, int want_dec) {
+                                                                     float* __restrict__ feat_grad, int want_dec,
+                                                                     pin_train_params tp, const float* __restrict__ label,
+                                                                     const float* __restrict__ weight,
+                                                                     double* __restrict__ loss_out) {
     using QD = QuadDecoder<H>;
     __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
     __shared__ float xch[TQ_BLOCK / 64][3 * 16 * 8];  // per wave: dz [16][8], w [16][8], idx [16][8]
+    __shared__ double lred[TQ_BLOCK / 64][2];
+    double acc_bce = 0.0, acc_eik = 0.0;  // the loss (BCE + Eikonal, loss.py:31-63) is folded in: no separate launch
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (Q + 15) >> 4;
     const int n_waves = gridDim.x * (TQ_BLOCK / 64);
@@ -814,7 +848,10 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f
         const int qi = (work ? tile : 0) * 16 + nq;
         const bool active = work && qi < Q;
         const int qq = qi < Q ? qi : Q - 1;
-        const float dx = active ? ws.dpred[qi] * f.sdf_scale : 0.f;  // the prediction is sdf_scale * head
+        double l_bce, l_eik;
+        const float dp = loss_dpred(tp, label, weight, ws.pred, qq, l_bce, l_eik);
+        if (active && g == 0) { acc_bce += l_bce; acc_eik += l_eik; }
+        const float dx = active ? dp * f.sdf_scale : 0.f;  // the prediction is sdf_scale * head
         // Feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature dims,
         // whole 32-byte rows per instruction; see train_bwd_mfma_kernel): exchange through the wave's LDS patch
         NbrW nb;
@@ -847,6 +884,17 @@ __global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f
             if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
         }
         wave_lds_sync();
+    }
+    // loss values: one pair of atomics per block (same-address f64 atomics serialise)
+    acc_bce = wave_sum(acc_bce);
+    acc_eik = wave_sum(acc_eik);
+    if (lane == 0) { lred[wave][0] = acc_bce; lred[wave][1] = acc_eik; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TQ_BLOCK / 64; ++w) t += lred[w][threadIdx.x];
+        if (t != 0.0) atomicAdd(loss_out + threadIdx.x, t);
     }
 }
 
@@ -1082,13 +1130,15 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     }
     PIN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
-                       sample_weight, ws, loss_out);
-    PIN_CHECK_LAUNCH();
+    if (!quad) {  // (the tile backward kernel computes the loss gradient itself)
+        hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
+                           sample_weight, ws, loss_out);
+        PIN_CHECK_LAUNCH();
+    }
     const int want_dec = dec_grad != nullptr;
     if (quad) {
-        if (H == 64) hipLaunchKernelGGL((train_bwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
-        else hipLaunchKernelGGL((train_bwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        if (H == 64) hipLaunchKernelGGL((train_bwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
+        else hipLaunchKernelGGL((train_bwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
     } else if (mfma) {
         PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     } else {
