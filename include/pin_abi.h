@@ -389,12 +389,15 @@ int pin_gather_batch(const float* pool_coord, const float* pool_label, const flo
 /* All of Mapper.get_batch after its two torch.randint draws (utils/mapper.py:462-500) in one launch:
  * output row i < n_history is pool row index_history[i]; the remaining n - n_history rows are pool rows
  * new_idx[index_new_batch[i - n_history]] (the newly observed samples).  Indices are torch's int64 draws.
- * pool_color / color_out [..][color_channels] are optional (color_channels = 0). */
+ * pool_color / color_out [..][color_channels] are optional (color_channels = 0).
+ * query_out (optional): also write the training queries of pin_train_make_queries(coord_out, n, n_eik, decimation,
+ * first, eps, query_out) in the same launch ([n + 6 n_eik][3]). */
 int pin_gather_batch_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
                            const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
                            const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
                            const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
-                           float* weight_out, int32_t* ts_out, float* color_out, void* stream);
+                           float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
+                           int32_t n_eik, int32_t decimation, int32_t first, float eps, void* stream);
 
 /* K6a: query points of one training iteration: the batch itself followed by the six
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,

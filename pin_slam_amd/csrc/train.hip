@@ -84,15 +84,32 @@ __global__ void gather_batch_drawn_kernel(const float* __restrict__ pc, const fl
                                           int n_hist, const long long* __restrict__ index_new_batch,
                                           const long long* __restrict__ new_idx, int n, float* __restrict__ coord,
                                           float* __restrict__ label, float* __restrict__ weight, int* __restrict__ ts,
-                                          float* __restrict__ color) {
+                                          float* __restrict__ color, float* __restrict__ q, int n_eik, int dec, int first,
+                                          float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t s = (size_t)(i < n_hist ? index_hist[i] : new_idx[index_new_batch[i - n_hist]]);
-    coord[3 * i] = pc[3 * s]; coord[3 * i + 1] = pc[3 * s + 1]; coord[3 * i + 2] = pc[3 * s + 2];
+    const float x = pc[3 * s], y = pc[3 * s + 1], z = pc[3 * s + 2];
+    coord[3 * i] = x; coord[3 * i + 1] = y; coord[3 * i + 2] = z;
     label[i] = pl[s];
     weight[i] = pw[s];
     ts[i] = pt[s];
     for (int c = 0; c < cw; ++c) color[(size_t)i * cw + c] = pcol[s * cw + c];
+    if (q == nullptr) return;
+    // the training queries of make_queries_kernel in the same pass: the sample itself, and for every dec-th
+    // sample the six +-eps probes of the numerical gradient
+    q[3 * i] = x; q[3 * i + 1] = y; q[3 * i + 2] = z;
+    const int r = i - first;
+    if (r >= 0 && r % dec == 0 && r / dec < n_eik) {
+        float* e = q + 3 * ((size_t)n + 6 * (size_t)(r / dec));
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const float d = (a & 1) ? -eps : eps;  // order x+, x-, y+, y-, z+, z-
+            e[3 * a] = (a >> 1) == 0 ? x + d : x;
+            e[3 * a + 1] = (a >> 1) == 1 ? y + d : y;
+            e[3 * a + 2] = (a >> 1) == 2 ? z + d : z;
+        }
+    }
 }
 
 // ---- forward -----------------------------------------------------------------------------
@@ -1045,7 +1062,8 @@ extern "C" int pin_gather_batch_drawn(const float* pool_coord, const float* pool
                                       const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
                                       const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
                                       const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
-                                      float* weight_out, int32_t* ts_out, float* color_out, void* stream) {
+                                      float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
+                                      int32_t n_eik, int32_t decimation, int32_t first, float eps, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && color_channels >= 0, "bad sizes");
     if (n == 0) return 0;
@@ -1053,10 +1071,14 @@ extern "C" int pin_gather_batch_drawn(const float* pool_coord, const float* pool
     PIN_CHECK_ARG(n_history == 0 || index_history, "index_history NULL");
     PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
     PIN_CHECK_ARG(color_channels == 0 || (pool_color && color_out), "colour pool / output NULL");
+    PIN_CHECK_ARG(query_out == nullptr || (n_eik >= 0 && decimation >= 1 && first >= 0 &&
+                                           (n_eik == 0 || first + (long)(n_eik - 1) * decimation < n)),
+                  "query_out: n_eik / first too large for decimation");
     hipLaunchKernelGGL(gather_batch_drawn_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
                        pool_weight, pool_ts, pool_color, color_channels, reinterpret_cast<const long long*>(index_history),
                        n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
-                       n, coord_out, label_out, weight_out, ts_out, color_out);
+                       n, coord_out, label_out, weight_out, ts_out, color_out, query_out, n_eik, decimation < 1 ? 1 : decimation,
+                       first, eps);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -243,8 +243,10 @@ class Mapper(_Base):
 
     def get_batch(self, global_coord=False):
         """Mapper.get_batch (mapper.py:452-503): the same torch.randint draws in the same order,
-        gathers by the pool kernels."""
+        gathers by the pool kernels.  While `mapping` runs, `self._queries_for` (a TrainBuffers) makes the same
+        launch write that iteration's training queries as well."""
         c = self.config
+        _queries_for = getattr(self, "_queries_for", None)
         p = self._pool()
         n = self.pool_sample_count
         new_idx = self.new_idx
@@ -268,7 +270,12 @@ class Mapper(_Base):
             b["ts"].data_ptr(), b["color"].data_ptr() if p.C else None, p.C, index_history.data_ptr(), index_history.shape[0],
             None if index_new_batch is None else index_new_batch.data_ptr(), None if index_new_batch is None else new_idx.data_ptr(),
             c.bs, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-            None if color is None else color.data_ptr(), torch.cuda.current_stream().cuda_stream), "pin_gather_batch_drawn")
+            None if color is None else color.data_ptr(),
+            None if _queries_for is None else _queries_for.query.data_ptr(),
+            0 if _queries_for is None else _queries_for.n_eik, 1 if _queries_for is None else _queries_for.dec,
+            0 if _queries_for is None else _queries_for.eik_first,
+            0.0 if _queries_for is None else float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
+            torch.cuda.current_stream().cuda_stream), "pin_gather_batch_drawn")
         return out[0], out[1], out[3], None, None, color, out[2]
 
     # ------------------------------------------------------------------ hot loop
@@ -327,12 +334,19 @@ class Mapper(_Base):
         if self.dp_world > 1:
             cert0 = t.fs.certainty.clone()
         for it in range(iter_count):
-            coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
+            # one GPU: the gather also writes the iteration's queries (the sample + the Eikonal probes)
+            fused_q = t.buf if (self.dp_world == 1 and t.buf.n_main == self.config.bs) else None
+            self._queries_for = fused_q
+            try:
+                coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
+            finally:
+                self._queries_for = None
             if t.fc is not None and color_label is None:
                 raise RuntimeError("color_on but the data pool holds no colour labels")
             t.step_batch(coord[sh].to(torch.float32).contiguous(), sdf_label[sh].to(torch.float32).contiguous(),
                          weight[sh].to(torch.float32).contiguous(), ts[sh].to(torch.int32).contiguous(), it + 1,
-                         color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous())
+                         color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous(),
+                         queries_ready=fused_q is not None)
             self.total_iter += 1
         t.finish_optimizer()
         if self.dp_world > 1:  # certainty / ts side effects of the other ranks' shards (engine.MapTrainer.mapping)

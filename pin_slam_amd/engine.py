@@ -202,8 +202,9 @@ class MapTrainer:
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
         self.step_batch(self.coord, self.label, self.weight, self.ts, step)
 
-    def step_batch(self, coord, label, weight, ts, step: int, color_label=None):
-        """One iteration on an explicit (already gathered) batch shard."""
+    def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False):
+        """One iteration on an explicit (already gathered) batch shard.  queries_ready: buf.query already holds this
+        batch's queries (written by the gather launch)."""
         nd = self.gdec.numel()
         lazy = self.lazy_on
         pre = (lambda: self.lazy.catch_up(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step)) if lazy else None
@@ -211,7 +212,7 @@ class MapTrainer:
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
-                       bricks=self.bricks, before_forward=pre)
+                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             if lazy:

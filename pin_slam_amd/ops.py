@@ -381,15 +381,17 @@ class TrainBuffers:
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
-               global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None):
+               global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None,
+               queries_ready=False):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
     `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up)."""
     L = _lib.lib()
     s = _stream()
-    check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
-                                   float(np.float32(eik_eps)),
-                                   _ptr(buf.query), s), "pin_train_make_queries")
+    if not queries_ready:  # (pin_gather_batch_drawn can write them in its own launch)
+        check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
+                                       float(np.float32(eik_eps)),
+                                       _ptr(buf.query), s), "pin_train_make_queries")
     knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None), bricks=bricks)
     if before_forward is not None:
         before_forward()
