@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--pool", type=int, default=2_000_000, help="samples in the pool (= pool_capacity)")
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "dp"],
+                    help="N > 1: 'replicas' = N independent frame streams, no data-path collective; 'dp' = the mapper "
+                         "shards a global batch of N x bs and all-reduces [decoder | feature] gradients over RCCL every "
+                         "iteration (SURVEY 8e); auto = dp from a per-rank batch of 2^17 up, where the sharded compute "
+                         "outweighs the 71 MB gradient exchange, replicas below")
     ap.add_argument("--events", default="all", choices=["none", "knn", "all"],
                     help="HIP events around the tracker's kNN / GN launches inside the timed region")
     ap.add_argument("--stages", default="all", choices=["all", "hot"],
@@ -105,10 +110,12 @@ def main():
 
     wl = WORKLOADS[args.workload]
     H, L, k = wl["hidden"], wl["levels"], 8
+    mapper_dp = world > 1 and (args.parallel == "dp" or (args.parallel == "auto" and args.bs >= (1 << 17)))
+    dp_world = world if mapper_dp else 1
     res = 0.4
     n_frames = args.warmup + 2 * args.steps + 4
     cfg = PinConfig(voxel_size_m=res, search_alpha=0.5, num_nei_cells=2, query_nn_k=k, buffer_size=int(5e7),
-                    feature_std=0.1, bs=args.bs * world, iters=args.map_iters, max_range=80.0, local_map_radius=82.0,
+                    feature_std=0.1, bs=args.bs * dp_world, iters=args.map_iters, max_range=80.0, local_map_radius=82.0,
                     window_radius=80.0, local_map_travel_dist_ratio=5.0, vox_down_m=0.08, source_vox_down_m=0.8,
                     min_range=2.5, min_z=-5.0, max_z=80.0, deskew=True, pool_capacity=args.pool, pool_filter_freq=1,
                     bs_new_sample=2048, geo_mlp_level=L, geo_mlp_hidden_dim=H, reg_iter_n=args.reg_iters)
@@ -124,7 +131,7 @@ def main():
     decoders = {"sdf": dec, "semantic": None, "color": None}
     ds = Dataset(n_frames + 1)
     mp = Mapper(cfg, ds, npts, decoders)
-    mp.dp_rank, mp.dp_world = rank, world
+    mp.dp_rank, mp.dp_world = (rank, world) if mapper_dp else (0, 1)
     trk = Tracker(cfg, npts, decoders)
     pool_c, pool_l = synth.make_pool(m, n=args.pool)
     mp.coord_pool = torch.from_numpy(pool_c).cuda()
@@ -298,7 +305,11 @@ def main():
                    "candidate_cells": Kc, "decoder": f"{L}x{H}", "occupancy_rho": round(rho, 4),
                    "pool_samples": pool_now, "new_samples": new_now, "brick_cache": npts._bricks is not None,
                    "stages": args.stages,
-                   "parallelism": "1 GPU" if world == 1 else f"preprocess/odometry/map-prep replicas x{world}, mapper dp{world} (RCCL all-reduce)"},
+                   "parallelism": "1 GPU" if world == 1 else
+                                  (f"preprocess/odometry/map-prep replicas x{world}, mapper dp{world} (global batch {args.bs * world}, "
+                                   f"RCCL all-reduce of decoder + feature gradients per iteration)" if mapper_dp else
+                                   f"{world} independent replicas (one frame stream per GPU, no data-path collective; "
+                                   f"--parallel dp selects the data-parallel mapper)")},
         "stage_ms_per_frame": stage_ms,
         "mapper_samples_per_sec": round(world * args.bs * args.map_iters / (1e-3 * stage_ms["mapping"]), 1),
         "frames_per_sec_source_downsampled": round(world * args.steps / elapsed_ds, 3),
