@@ -323,6 +323,8 @@ def main():
                      "arithmetic": ("fp32 factors split exactly into 3 bf16 pieces, 6 piece products per fp32 product on "
                                     "v_mfma_f32_16x16x32_bf16, fp32 accumulate; `achieved`/`peak` are fp32-equivalent")
                                    if split_bf16 else "v_mfma_f32_16x16x4_f32",
+                     "limiter": "vector-ALU + MFMA issue, additive on gfx950 (PMC: ~16.7 M vector instructions = 27 us and "
+                                "13 us of MFMA per launch and SIMD, profiles/r01_pmc.json; scripts/mfma_valu_overlap.hip)",
                      "executed": {"flops_per_query": exec_flops_q, "tflops": round(exec_tflops, 1),
                                   "peak": BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS,
                                   "frac": round(exec_tflops / (BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS), 4)}},
@@ -332,6 +334,8 @@ def main():
                          "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
                          "algorithmic_bytes_per_query": round(bytes_q, 1),
                          "measured_copy_gbs": round(copy_gbs, 1),
+                         "limiter": "vector-ALU instruction count (PMC: ~17.3 M vector instructions = 28 us per launch and "
+                                    "SIMD, profiles/r01_pmc.json), not HBM: fabric traffic is 0.43x the algorithmic bytes",
                          "share_of_frame": round(knn_ms * args.reg_iters / ms_step, 3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
