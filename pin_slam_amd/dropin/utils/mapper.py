@@ -252,9 +252,17 @@ class Mapper(_Base):
         new_idx = self.new_idx
         ds = self.dataset
         index_new_batch = None
-        if (c.bs_new_sample > 0 and new_idx is not None and not getattr(ds, "lose_track", False)
-                and not getattr(ds, "stop_status", False) and new_idx.shape[0] > 0):
-            bs_new = min(new_idx.shape[0], c.bs_new_sample)
+        use_new = (c.bs_new_sample > 0 and new_idx is not None and not getattr(ds, "lose_track", False)
+                   and not getattr(ds, "stop_status", False) and new_idx.shape[0] > 0)
+        bs_new = min(new_idx.shape[0], c.bs_new_sample) if use_new else 0
+        drawn = getattr(self, "_drawn", None)
+        if drawn is not None and drawn["key"] == (n, c.bs - bs_new, bs_new, 0 if not use_new else new_idx.shape[0]):
+            # mapping() drew the indices of all its iterations in two launches (same distribution, iid uniform)
+            i = drawn["next"]
+            drawn["next"] = i + 1
+            index_history = drawn["hist"][i]
+            index_new_batch = drawn["new"][i] if use_new else None
+        elif use_new:
             index_history = torch.randint(0, n, (c.bs - bs_new,), device=self.device)
             index_new_batch = torch.randint(0, new_idx.shape[0], (bs_new,), device=self.device)
         else:
@@ -277,6 +285,19 @@ class Mapper(_Base):
             0.0 if _queries_for is None else float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
             torch.cuda.current_stream().cuda_stream), "pin_gather_batch_drawn")
         return out[0], out[1], out[3], None, None, color, out[2]
+
+    def _draw_all(self, iters):
+        """The batch indices of `iters` get_batch calls in two torch.randint launches instead of 2 x iters (the
+        reference draws per iteration, mapper.py:462-480; the draws are iid uniform either way)."""
+        c, ds, new_idx, n = self.config, self.dataset, self.new_idx, self.pool_sample_count
+        use_new = (c.bs_new_sample > 0 and new_idx is not None and not getattr(ds, "lose_track", False)
+                   and not getattr(ds, "stop_status", False) and new_idx.shape[0] > 0)
+        bs_new = min(new_idx.shape[0], c.bs_new_sample) if use_new else 0
+        if n <= 0 or iters <= 0:
+            return None
+        hist = torch.randint(0, n, (iters, c.bs - bs_new), device=self.device)
+        new = torch.randint(0, new_idx.shape[0], (iters, bs_new), device=self.device) if use_new else None
+        return dict(key=(n, c.bs - bs_new, bs_new, 0 if not use_new else new_idx.shape[0]), hist=hist, new=new, next=0)
 
     # ------------------------------------------------------------------ hot loop
     def _check_supported(self):
@@ -333,6 +354,7 @@ class Mapper(_Base):
         sh = slice(lo, hi)
         if self.dp_world > 1:
             cert0 = t.fs.certainty.clone()
+        self._drawn = self._draw_all(iter_count)
         for it in range(iter_count):
             # one GPU: the gather also writes the iteration's queries (the sample + the Eikonal probes)
             fused_q = t.buf if (self.dp_world == 1 and t.buf.n_main == self.config.bs) else None
@@ -348,6 +370,7 @@ class Mapper(_Base):
                          color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous(),
                          queries_ready=fused_q is not None)
             self.total_iter += 1
+        self._drawn = None
         t.finish_optimizer()
         if self.dp_world > 1:  # certainty / ts side effects of the other ranks' shards (engine.MapTrainer.mapping)
             import torch.distributed as dist
