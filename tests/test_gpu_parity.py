@@ -404,3 +404,34 @@ def test_staged_decoder_image_changes_no_bit():
         img, fs.dec_image = fs.dec_image, None
         _, sdf3, _ = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
         assert torch.equal(sdf2.view(torch.int32), sdf3.view(torch.int32)) and not torch.equal(sdf2, sdf0)
+
+
+def test_gather_batch_writes_the_same_queries_as_make_queries():
+    """pin_gather_batch_drawn(query_out=...) against pin_train_make_queries on its own coord output: same bits,
+    history + new-sample rows, a decimation phase, and a batch whose last Eikonal sample is the last row."""
+    from pin_slam_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(3)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_pool, n, n_hist, dec, first = 5000, 1000, 700, 10, 3
+    n_eik = (n - first + dec - 1) // dec
+    pool_c = torch.randn(n_pool, 3, device="cuda") * 20
+    pool_l, pool_w = torch.randn(n_pool, device="cuda"), torch.rand(n_pool, device="cuda")
+    pool_t = torch.randint(0, 50, (n_pool,), device="cuda", dtype=torch.int32)
+    ih = torch.randint(0, n_pool, (n_hist,), device="cuda")
+    new_idx = torch.randint(0, n_pool, (400,), device="cuda")
+    inb = torch.randint(0, 400, (n - n_hist,), device="cuda")
+    coord = torch.empty(n, 3, device="cuda"); lab = torch.empty(n, device="cuda"); w = torch.empty(n, device="cuda")
+    ts = torch.empty(n, dtype=torch.int32, device="cuda")
+    q1 = torch.full((n + 6 * n_eik, 3), float("nan"), device="cuda")
+    q2 = torch.full_like(q1, float("nan"))
+    eps = float(np.float32(0.08))
+    _lib.check(L.pin_gather_batch_drawn(pool_c.data_ptr(), pool_l.data_ptr(), pool_w.data_ptr(), pool_t.data_ptr(), None, 0,
+                                        ih.data_ptr(), n_hist, inb.data_ptr(), new_idx.data_ptr(), n, coord.data_ptr(),
+                                        lab.data_ptr(), w.data_ptr(), ts.data_ptr(), None, q1.data_ptr(), n_eik, dec, first,
+                                        eps, stream), "gather")
+    _lib.check(L.pin_train_make_queries(coord.data_ptr(), n, n_eik, dec, first, eps, q2.data_ptr(), stream), "make_queries")
+    src = torch.cat([ih, new_idx[inb]])
+    assert torch.equal(coord, pool_c[src]) and torch.equal(lab, pool_l[src]) and torch.equal(ts, pool_t[src])
+    assert not torch.isnan(q2).any()
+    assert torch.equal(q1.view(torch.int32), q2.view(torch.int32))
