@@ -156,7 +156,7 @@ typedef struct pin_color_term {
     float photo_weight;      /* photometric_loss_weight */
 } pin_color_term;
 #define PIN_GN_NSUMS 32
-#define PIN_GN_REPLICAS 64
+#define PIN_GN_REPLICAS 16
 /* Device-resident state of one Tracker.tracking call (utils/tracker.py:114-184), doubles:
  * [0..15] current pose T (row-major 4x4)   [16] last_sdf_residual_cm   [17] sdf_residual_cm
  * [18] valid point count   [19] valid_flag   [20] converged   [21] done (loop has ended)

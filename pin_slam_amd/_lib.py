@@ -17,7 +17,7 @@ PIN_FEATURE_DIM = 8
 PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
-PIN_GN_REPLICAS = 64
+PIN_GN_REPLICAS = 16
 PIN_ABI_VERSION = 5
 
 vp = C.c_void_p

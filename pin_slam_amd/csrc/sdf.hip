@@ -13,7 +13,7 @@
 namespace pin {
 
 constexpr int SDF_BLOCK = 128;
-constexpr int GN_REPLICAS = PIN_GN_REPLICAS;  // sums are scattered over 64 replicas to spread atomics
+constexpr int GN_REPLICAS = PIN_GN_REPLICAS;  // sums are scattered over a few replicas to spread the atomics (the solve reads them all)
 
 struct Nbrs {
     float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];  // q - P (global position)
