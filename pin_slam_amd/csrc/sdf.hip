@@ -487,15 +487,22 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
                                                       pin_gn_loop_params lp) {
     __shared__ double s[PIN_GN_NSUMS];
     const int lane = threadIdx.x;
-    if (st[PIN_GN_STATE_DONE] != 0.0) return;
-    {   // replica sum: two lanes per sum, 32 independent loads each
+    // this kernel is a chain of memory round trips around ~1 us of arithmetic: everything it reads is requested up
+    // front (the stop flag, the sums, the loop state the end of the kernel needs)
+    const double done = st[PIN_GN_STATE_DONE];
+    const double st_pre = st[lane < PIN_GN_STATE_MSE ? lane : 0];  // pose (0..15) and loop scalars (16..22), one per lane
+    const double nsrc = st[PIN_GN_STATE_NSRC];
+    {   // replica sum: two lanes per sum, GN_REPLICAS / 2 independent loads each
         const int i = lane & 31, h = lane >> 5;
         double a = 0.0;
 #pragma unroll 8
         for (int r = 0; r < GN_REPLICAS / 2; ++r) a += sums[(h * (GN_REPLICAS / 2) + r) * PIN_GN_NSUMS + i];
         a += __shfl_xor(a, 32, 64);
+        if (done != 0.0) return;  // (uniform)
         if (h == 0) s[i] = a;
     }
+    __shared__ double stv[PIN_GN_STATE_MSE];
+    if (lane < PIN_GN_STATE_MSE) stv[lane] = st_pre;
     __syncthreads();
     for (int i = lane; i < GN_REPLICAS * PIN_GN_NSUMS; i += 64) sums[i] = 0.0;  // ready for the next iteration
     if (lane != 0) return;
@@ -578,23 +585,22 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
         for (int b = 0; b < 4; ++b) {
             double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc += dT[a * 4 + c] * st[c * 4 + b];
+            for (int c = 0; c < 4; ++c) acc += dT[a * 4 + c] * stv[c * 4 + b];
             Tn[a * 4 + b] = acc;
         }
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = Tn[i];
     st[PIN_GN_STATE_RES] = res_cm;
     st[PIN_GN_STATE_CNT] = cnt;
-    const double last = st[PIN_GN_STATE_LAST_RES];
-    bool valid = st[PIN_GN_STATE_VALID] != 0.0;
+    const double last = stv[PIN_GN_STATE_LAST_RES];
+    bool valid = stv[PIN_GN_STATE_VALID] != 0.0;
     if ((res_cm - last) / last > lp.max_increment_ratio) valid = false;  // tracker.py:150-159
     else st[PIN_GN_STATE_LAST_RES] = res_cm;
-    const double nsrc = st[PIN_GN_STATE_NSRC];
     if (cnt < lp.min_valid_points || cnt / nsrc < lp.min_valid_ratio) valid = false;  // :161-169
     st[PIN_GN_STATE_VALID] = valid ? 1.0 : 0.0;
-    const int i = (int)st[PIN_GN_STATE_ITERS];
+    const int i = (int)stv[PIN_GN_STATE_ITERS];
     st[PIN_GN_STATE_ITERS] = i + 1;
-    const bool converged = st[PIN_GN_STATE_CONVERGED] != 0.0;
+    const bool converged = stv[PIN_GN_STATE_CONVERGED] != 0.0;
     if (!valid || converged || i + 1 >= lp.iter_n) { st[PIN_GN_STATE_DONE] = 1.0; return; }  // :171-172
     const double rot_deg = acos((dT[0] + dT[5] + dT[10] - 1.0) / 2.0) * 180.0 / 3.14159265358979323846;
     const double tran = sqrt(dT[3] * dT[3] + dT[7] * dT[7] + dT[11] * dT[11]);
