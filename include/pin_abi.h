@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 5
+#define PIN_ABI_VERSION 6
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -600,6 +600,42 @@ int pin_intrinsic_correct(float* points, int32_t width, int32_t n, double correc
  * (row-major 4x4).  workspace >= 64 bytes. */
 int pin_deskew(float* points, int32_t width, int32_t n, const float* ts, const double* pose, double ts_mid_pose,
                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- data-parallel mapper collectives ---------------------------------------------
+ * The reference trains on one GPU (pin_slam.py:8).  Mapper.mapping optimises the local feature
+ * table AND the decoder (neural_points.parameters() + decoder parameters, utils/mapper.py:604;
+ * setup_optimizer utils/tools.py:153-203), so a batch sharded over ranks needs the SUM of the
+ * per-rank gradients of both before the (replicated) Adam step, and the training-mode side effects of
+ * query_feature (certainty += w, ts_update = max; neural_points.py:660-683) merged once per mapping call.
+ * RCCL (xGMI) is bound at run time: pin_comm_load dlopens the librccl the host process already uses. */
+#define PIN_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+
+/* dlopen RCCL (rccl_path, else librccl.so.1 / librccl.so on the loader path).  Idempotent. */
+int pin_comm_load(const char* rccl_path);
+/* HOST: rank 0 fills id_out_host[PIN_COMM_ID_BYTES] (ncclGetUniqueId); the caller hands it to the other ranks. */
+int pin_comm_unique_id(void* id_out_host);
+/* HOST, collective over `world` processes (one per GPU, current device = the rank's GPU): ncclCommInitRank.
+ * *comm_out_host is an opaque communicator handle. */
+int pin_comm_init_rank(const void* id_host, int32_t rank, int32_t world, void** comm_out_host);
+int pin_comm_destroy(void* comm);
+
+/* In-place SUM all-reduce of the flat fp32 gradient buffer [decoder grads | feature grads] on `stream`
+ * (ncclAllReduce, ncclFloat32, ncclSum): one call per Mapper.mapping iteration, between the backward pass
+ * (pin_train_step) and the optimiser step (pin_adam_step). */
+int pin_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
+
+/* Start of a data-parallel Mapper.mapping call: certainty0_out <- certainty (device copy on `stream`). */
+int pin_dp_cert_snapshot(const float* certainty, float* certainty0_out, int32_t n, void* stream);
+/* The two element-wise halves of the certainty merge, usable with any transport:
+ * delta_out = certainty - certainty0;  certainty = certainty0 + delta_sum. */
+int pin_dp_cert_delta(const float* certainty, const float* certainty0, float* delta_out, int32_t n, void* stream);
+int pin_dp_cert_apply(float* certainty, const float* certainty0, const float* delta_sum, int32_t n, void* stream);
+
+/* End of a data-parallel Mapper.mapping call: certainty <- certainty0 + SUM_ranks(certainty - certainty0)
+ * (certainty0 = the values before the call) and ts_update <- MAX_ranks(ts_update), the two all-reduces fused in
+ * one RCCL group.  scratch [n] floats. */
+int pin_dp_sync_side_effects(void* comm, float* certainty, const float* certainty0, float* scratch,
+                             int32_t* ts_update, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

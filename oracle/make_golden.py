@@ -50,6 +50,34 @@ def t2n(t):
     return t.detach().cpu().numpy().copy()
 
 
+class LossSpy:
+    """Record the scalar losses of every Mapper.mapping iteration of the reference: the BCE term returned by
+    utils.loss.sdf_bce_loss (mapper.py:733) and the total `cur_loss` at its backward() call (mapper.py:817)."""
+
+    def __init__(self, mapper_mod):
+        self.mod, self.sdf, self.total = mapper_mod, [], []
+
+    def __enter__(self):
+        self._bce, self._bwd = self.mod.sdf_bce_loss, torch.Tensor.backward
+
+        def bce(*a, **k):
+            v = self._bce(*a, **k)
+            self.sdf.append(float(v.detach()))
+            return v
+
+        def backward(t, *a, **k):
+            if t.dim() == 0:
+                self.total.append(float(t.detach()))
+            return self._bwd(t, *a, **k)
+
+        self.mod.sdf_bce_loss, torch.Tensor.backward = bce, backward
+        return self
+
+    def __exit__(self, *exc):
+        self.mod.sdf_bce_loss, torch.Tensor.backward = self._bce, self._bwd
+        return False
+
+
 def build(case):
     m = R.load()
     over, (levels, hidden) = CASES[case]
@@ -247,9 +275,11 @@ def gen_case(case):
     out["map_lr"] = np.float64(cfg.lr); out["map_adam_eps"] = np.float64(cfg.adam_eps)
     out["map_loss_weight_on"] = np.bool_(cfg.loss_weight_on)
     try:
-        mp.mapping(2)
+        with LossSpy(m["mapper_mod"]) as spy:
+            mp.mapping(2)
     finally:
         m["mapper_mod"].setup_optimizer = real_setup
+    out["map_loss_sdf"] = np.asarray(spy.sdf, np.float64); out["map_loss_total"] = np.asarray(spy.total, np.float64)
     for it, g in enumerate(grads):
         out[f"map_gfeat{it}"] = g["feat"]; out[f"map_gdec{it}"] = g["dec"]
     out["map_feat_after"] = t2n(npts.local_geo_features.data)
@@ -380,9 +410,11 @@ def gen_color_case():
     out["map_dec"] = np.int64(cfg.gradient_decimation); out["map_weight_e"] = np.float64(cfg.weight_e)
     out["map_lr"] = np.float64(cfg.lr); out["map_adam_eps"] = np.float64(cfg.adam_eps)
     try:
-        mp.mapping(2)
+        with LossSpy(m["mapper_mod"]) as spy:
+            mp.mapping(2)
     finally:
         m["mapper_mod"].setup_optimizer = real_setup
+    out["map_loss_sdf"] = np.asarray(spy.sdf, np.float64); out["map_loss_total"] = np.asarray(spy.total, np.float64)
     for it, g in enumerate(grads):
         for kk, v in g.items():
             out[f"map_{kk}{it}"] = v

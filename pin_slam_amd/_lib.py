@@ -18,7 +18,8 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 5
+PIN_ABI_VERSION = 6
+PIN_COMM_ID_BYTES = 128
 
 vp = C.c_void_p
 
@@ -129,7 +130,7 @@ i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 P = C.POINTER
 
 # name -> (restype, argtypes).  Every symbol declared in include/pin_abi.h is listed here;
-# tests/test_abi_symbols.py checks the header, this table and the built library agree.
+# tests/test_abi_and_dropin_surface.py checks the header, this table and the built library agree.
 SIGNATURES = {
     "pin_version": (i32, []),
     "pin_last_error": (C.c_char_p, []),
@@ -184,6 +185,15 @@ SIGNATURES = {
     "pin_deskew": (i32, [vp, i32, i32, vp, vp, f64, vp, i64, vp]),
     "pin_transform_by_frame": (i32, [vp, i32, vp, vp, i32, vp, vp, vp]),
     "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
+    "pin_comm_load": (i32, [C.c_char_p]),
+    "pin_comm_unique_id": (i32, [vp]),
+    "pin_comm_init_rank": (i32, [vp, i32, i32, P(vp)]),
+    "pin_comm_destroy": (i32, [vp]),
+    "pin_allreduce_grads": (i32, [vp, vp, i64, vp]),
+    "pin_dp_cert_snapshot": (i32, [vp, vp, i32, vp]),
+    "pin_dp_cert_delta": (i32, [vp, vp, vp, i32, vp]),
+    "pin_dp_cert_apply": (i32, [vp, vp, vp, i32, vp]),
+    "pin_dp_sync_side_effects": (i32, [vp, vp, vp, vp, vp, i32, vp]),
 }
 
 _lib = None

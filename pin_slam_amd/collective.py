@@ -1,0 +1,108 @@
+"""Transports of the data-parallel mapper's two exchanges:
+
+* ``allreduce_grads(flat)``  -- in-place SUM of the flat fp32 buffer [decoder grads | feature grads], once per
+  Mapper.mapping iteration (the parameters of utils/mapper.py:604 are the feature table and the decoder);
+* ``sync_side_effects(certainty, certainty0, scratch, ts_update)`` -- once per mapping call: certainty becomes
+  certainty0 + SUM_ranks(certainty - certainty0), ts_update the MAX over ranks (query_feature's training-mode
+  side effects, model/neural_points.py:660-683).
+
+:class:`RcclComm` is the product transport: RCCL over xGMI through the C ABI (pin_allreduce_grads,
+pin_dp_sync_side_effects) on the caller's HIP stream, no torch op involved.  The communicator is created from a
+``torch.distributed`` process group only in the sense that the group carries the 128-byte ncclUniqueId from rank 0
+to the others (set-up, once).
+
+:class:`HostStagedComm` exists for ranks that SHARE one device (RCCL refuses two ranks on one GPU): tests on the
+single-GPU box run two processes on cuda:0 and exchange through pinned host buffers over a gloo group.  It uses
+the same element-wise kernels (pin_dp_cert_delta / pin_dp_cert_apply); it is never selected implicitly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rccl_library_path() -> str:
+    """The librccl that ships with the torch in this process (one RCCL, one HIP runtime per process)."""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else ""
+
+
+class RcclComm:
+    def __init__(self, rank: int, world: int, group=None):
+        import torch.distributed as dist
+        L = _lib.lib()
+        check(L.pin_comm_load(rccl_library_path().encode()), "pin_comm_load")
+        uid = C.create_string_buffer(_lib.PIN_COMM_ID_BYTES)
+        if rank == 0:
+            check(L.pin_comm_unique_id(uid), "pin_comm_unique_id")
+        if world > 1:
+            box = [bytes(uid.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = C.create_string_buffer(box[0], _lib.PIN_COMM_ID_BYTES)
+        handle = C.c_void_p()
+        check(L.pin_comm_init_rank(uid, rank, world, C.byref(handle)), "pin_comm_init_rank")
+        self._h, self.rank, self.world = handle, rank, world
+        self.kind = "rccl"
+
+    def allreduce_grads(self, flat: torch.Tensor):
+        check(_lib.lib().pin_allreduce_grads(self._h, flat.data_ptr(), flat.numel(), _stream()), "pin_allreduce_grads")
+
+    def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
+        n = certainty.shape[0]
+        check(_lib.lib().pin_dp_sync_side_effects(self._h, certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(),
+                                                  ts_update.data_ptr(), n, _stream()), "pin_dp_sync_side_effects")
+
+    def close(self):
+        if self._h:
+            check(_lib.lib().pin_comm_destroy(self._h), "pin_comm_destroy")
+            self._h = C.c_void_p()
+
+
+class HostStagedComm:
+    """gloo over pinned host buffers, for ranks sharing one device (tests)."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self._host = {}
+        self.kind = "host-staged gloo"
+
+    def _stage(self, t: torch.Tensor):
+        key = (t.dtype, t.numel())
+        h = self._host.get(key)
+        if h is None:
+            h = self._host[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+        return h
+
+    def _allreduce(self, t: torch.Tensor, op):
+        import torch.distributed as dist
+        h = self._stage(t)
+        h.copy_(t.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        dist.all_reduce(h, op=op, group=self.group)
+        t.reshape(-1).copy_(h, non_blocking=True)
+
+    def allreduce_grads(self, flat: torch.Tensor):
+        import torch.distributed as dist
+        self._allreduce(flat, dist.ReduceOp.SUM)
+
+    def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
+        import torch.distributed as dist
+        L, n = _lib.lib(), certainty.shape[0]
+        check(L.pin_dp_cert_delta(certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(), n, _stream()),
+              "pin_dp_cert_delta")
+        self._allreduce(scratch[:n], dist.ReduceOp.SUM)
+        self._allreduce(ts_update[:n], dist.ReduceOp.MAX)
+        check(L.pin_dp_cert_apply(certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(), n, _stream()),
+              "pin_dp_cert_apply")
+
+    def close(self):
+        pass

@@ -94,6 +94,7 @@ class Mapper(_Base):
         # data-parallel mapping: config.bs is the GLOBAL batch, every rank draws the same
         # batch (same seed) and trains on its contiguous shard; set by the launcher, 1 rank by default
         self.dp_rank, self.dp_world = 0, 1
+        self.dp_comm = None  # pin_slam_amd.collective.RcclComm when dp_world > 1
         self.static_mask = None
         self.cur_sample_count = 0
         self.cur_new_point_ratio = 0.0
@@ -242,8 +243,8 @@ class Mapper(_Base):
         self._publish_pool()
 
     def get_batch(self, global_coord=False):
-        """Mapper.get_batch (mapper.py:452-503): the same torch.randint draws in the same order,
-        gathers by the pool kernels.  While `mapping` runs, `self._queries_for` (a TrainBuffers) makes the same
+        """Mapper.get_batch (mapper.py:452-503): called on its own, the reference's per-call torch.randint draws
+        (history, then new samples); gathers by the pool kernels.  While `mapping` runs, `self._queries_for` (a TrainBuffers) makes the same
         launch write that iteration's training queries as well."""
         c = self.config
         _queries_for = getattr(self, "_queries_for", None)
@@ -269,15 +270,23 @@ class Mapper(_Base):
             index_history = torch.randint(0, n, (c.bs,), device=self.device)
         b = p.bufs[0]
         dev = self.device
-        out = (torch.empty((c.bs, 3), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.float32, device=dev),
-               torch.empty((c.bs,), dtype=torch.float32, device=dev), torch.empty((c.bs,), dtype=torch.int32, device=dev))
-        color = torch.empty((c.bs, p.C), dtype=torch.float32, device=dev) if p.C else None
+        # data-parallel mapping: this rank gathers rows [lo, hi) of the global batch only (the index draws are
+        # identical on every rank); the shard may straddle the history / new-sample boundary
+        lo, hi = getattr(self, "_shard", None) or (0, c.bs)
+        nb = hi - lo
+        n_hist = index_history.shape[0]
+        h_lo, h_hi = min(lo, n_hist), min(hi, n_hist)
+        n_lo = max(lo, n_hist) - n_hist
+        out = (torch.empty((nb, 3), dtype=torch.float32, device=dev), torch.empty((nb,), dtype=torch.float32, device=dev),
+               torch.empty((nb,), dtype=torch.float32, device=dev), torch.empty((nb,), dtype=torch.int32, device=dev))
+        color = torch.empty((nb, p.C), dtype=torch.float32, device=dev) if p.C else None
         L = _lib.lib()
         _lib.check(L.pin_gather_batch_drawn(
             (b["global_coord"] if global_coord else b["coord"]).data_ptr(), b["sdf_label"].data_ptr(), b["weight"].data_ptr(),
-            b["ts"].data_ptr(), b["color"].data_ptr() if p.C else None, p.C, index_history.data_ptr(), index_history.shape[0],
-            None if index_new_batch is None else index_new_batch.data_ptr(), None if index_new_batch is None else new_idx.data_ptr(),
-            c.bs, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+            b["ts"].data_ptr(), b["color"].data_ptr() if p.C else None, p.C, index_history.data_ptr() + 8 * h_lo, h_hi - h_lo,
+            None if index_new_batch is None else index_new_batch.data_ptr() + 8 * n_lo,
+            None if index_new_batch is None else new_idx.data_ptr(),
+            nb, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
             None if color is None else color.data_ptr(),
             None if _queries_for is None else _queries_for.query.data_ptr(),
             0 if _queries_for is None else _queries_for.n_eik, 1 if _queries_for is None else _queries_for.dec,
@@ -328,7 +337,8 @@ class Mapper(_Base):
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,
                                   weight_e=c.weight_e if eik else 0.0,
                                   eik_eps=c.voxel_size_m * c.num_grad_step_ratio, lr=c.lr, adam_eps=c.adam_eps,
-                                  loss_weight_on=c.loss_weight_on, eikonal=eik, rank=self.dp_rank, world=self.dp_world)
+                                  loss_weight_on=c.loss_weight_on, eikonal=eik, rank=self.dp_rank, world=self.dp_world,
+                                  comm=self.dp_comm)
             self._trainer = t
         t.resize(fs)  # the local map changes size every frame: same buffers, new views
         t.st, t.ts_update, t.train_decoder = st, npts.local_point_ts_update, train_dec
@@ -350,34 +360,27 @@ class Mapper(_Base):
         t = self._get_trainer()
         t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
         from ...sharding import shard_range
-        lo, hi = shard_range(self.config.bs, self.dp_rank, self.dp_world)
-        sh = slice(lo, hi)
-        if self.dp_world > 1:
-            cert0 = t.fs.certainty.clone()
+        self._shard = shard_range(self.config.bs, self.dp_rank, self.dp_world)
+        t.begin_side_effects()
         self._drawn = self._draw_all(iter_count)
-        for it in range(iter_count):
-            # one GPU: the gather also writes the iteration's queries (the sample + the Eikonal probes)
-            fused_q = t.buf if (self.dp_world == 1 and t.buf.n_main == self.config.bs) else None
-            self._queries_for = fused_q
-            try:
+        # the gather launch also writes the iteration's queries (the samples of this rank's shard + their Eikonal probes)
+        fused_q = t.buf if t.buf.n_main == self._shard[1] - self._shard[0] else None
+        try:
+            for it in range(iter_count):
+                self._queries_for = fused_q
                 coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
-            finally:
                 self._queries_for = None
-            if t.fc is not None and color_label is None:
-                raise RuntimeError("color_on but the data pool holds no colour labels")
-            t.step_batch(coord[sh].to(torch.float32).contiguous(), sdf_label[sh].to(torch.float32).contiguous(),
-                         weight[sh].to(torch.float32).contiguous(), ts[sh].to(torch.int32).contiguous(), it + 1,
-                         color_label=None if t.fc is None else color_label[sh, :3].to(torch.float32).contiguous(),
-                         queries_ready=fused_q is not None)
-            self.total_iter += 1
-        self._drawn = None
+                if t.fc is not None and color_label is None:
+                    raise RuntimeError("color_on but the data pool holds no colour labels")
+                t.step_batch(coord, sdf_label, weight, ts, it + 1,
+                             color_label=None if t.fc is None else
+                             (color_label if color_label.shape[1] == 3 else color_label[:, :3].contiguous()),
+                             queries_ready=fused_q is not None)
+                self.total_iter += 1
+        finally:
+            self._queries_for = self._drawn = self._shard = None
         t.finish_optimizer()
-        if self.dp_world > 1:  # certainty / ts side effects of the other ranks' shards (engine.MapTrainer.mapping)
-            import torch.distributed as dist
-            delta = t.fs.certainty - cert0
-            dist.all_reduce(delta)
-            t.fs.certainty.copy_(cert0 + delta)
-            dist.all_reduce(t.ts_update, op=dist.ReduceOp.MAX)
+        t.merge_side_effects()  # dp: certainty / ts side effects of the other ranks' shards, one exchange per call
         self.neural_points.assign_local_to_global()
 
     def sdf(self, x, get_std=False, min_nn_count=1, accumulate_stability=False):

@@ -1,10 +1,11 @@
 """Host-side drivers of the two hot loops, on top of the C ABI (pin_slam_amd.ops):
 
 * :class:`GNTracker`  -- Tracker.tracking / registration_step (utils/tracker.py:43-225, 367-611):
-  per Gauss-Newton iteration one kNN launch (pose applied in-kernel), one fused
-  SDF+Jacobian+normal-equation launch, one 16 KiB read-back and a 6x6 float64 solve.
+  `track` is device-resident: per Gauss-Newton iteration one kNN launch (pose read from the device state), one
+  fused SDF+Jacobian+normal-equation launch and a one-wave 6x6 solve, ONE 512-byte read-back per call; `step`
+  (registration_step) is host-driven: one read-back of the sums and a float64 solve on the host per call.
 * :class:`MapTrainer` -- Mapper.mapping (utils/mapper.py:600-844): per iteration batch gather,
-  query generation, kNN, fused forward/loss/backward, (optional RCCL all-reduce), Adam.
+  query generation, kNN, fused forward/loss/backward, (world > 1: RCCL all-reduce through the C ABI), Adam.
 
 The drop-in classes in ``pin_slam_amd.dropin`` wrap these with the reference's signatures.
 """
@@ -131,7 +132,7 @@ class MapTrainer:
     def __init__(self, st: ops.SearchState, fs: ops.FieldState, pool_coord, pool_label, pool_weight, pool_ts,
                  ts_update, *, bs: int, decimation: int, sigma: float, weight_e: float, eik_eps: float,
                  lr: float = 0.01, adam_eps: float = 1e-15, loss_weight_on: bool = False, train_decoder: bool = True,
-                 eikonal: bool = True, rank: int = 0, world: int = 1):
+                 eikonal: bool = True, rank: int = 0, world: int = 1, comm=None):
         self.st, self.fs = st, fs
         self.pool = (pool_coord, pool_label, pool_weight, pool_ts)
         self.ts_update = ts_update
@@ -140,6 +141,13 @@ class MapTrainer:
         self.lr, self.adam_eps, self.loss_weight_on = lr, adam_eps, loss_weight_on
         self.train_decoder = train_decoder
         self.rank, self.world = rank, world
+        # data-parallel: the transport of the two exchanges (collective.RcclComm: RCCL through the C ABI).  A
+        # communicator of one rank is allowed (the same code path, used to exercise RCCL on a single-GPU box).
+        self.comm = comm
+        if world > 1 and comm is None:
+            raise ValueError("MapTrainer(world > 1) needs a collective (pin_slam_amd.collective.RcclComm)")
+        self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
+        self._cert0 = self._cert_scratch = None
         assert self.bs % world == 0, "global batch must divide over the ranks"
         self.bs_local = self.bs // world
         dev = fs.feats.device
@@ -190,7 +198,7 @@ class MapTrainer:
         if fc is None:
             self.fc = None
             return
-        if self.world > 1:
+        if self.comm is not None:
             raise NotImplementedError("colour training is single-GPU for now (the geometry all-reduce buffer excludes it)")
         nf, nd = fc.feats.numel(), fc.dec.numel()
         if self.fc is None or self.cgrad.numel() != nf + nd:
@@ -229,13 +237,14 @@ class MapTrainer:
                                    eps=self.adam_eps)
             if self.c_train_dec and not lazy:
                 ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad if self.train_decoder else self.gfeat)
+        if self.comm is not None:  # SUM of the per-rank gradients of [decoder | features] (pin_allreduce_grads)
+            self.comm.allreduce_grads(self.grad if self.train_decoder else self.gfeat)
+        if self.on_grads is not None:
+            self.on_grads(self.grad)
         if lazy:  # (the decoder's dense step rides along in the same launch)
             dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
             self.lazy.step(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)
-        elif self.world == 1:
+        elif self.comm is None:
             ops.mark_rows(self.buf.nbr, self.dirty)
             ops.adam_step_rows(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], self.dirty, step, self.lr, eps=self.adam_eps)
         else:  # rows touched by the other ranks' shards arrive through the all-reduce: dense update
@@ -248,7 +257,7 @@ class MapTrainer:
         """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615).  With the iteration count
         known (and one GPU) the feature tables use the lazy exact Adam: call finish_optimizer() after the last
         iteration; without it, the row-flagged / dense step."""
-        self.lazy_on = bool(iters) and self.world == 1
+        self.lazy_on = bool(iters) and self.comm is None
         nd = self.gdec.numel()
         if self.lazy_on:
             dev = self.fs.feats.device
@@ -286,14 +295,27 @@ class MapTrainer:
         """One Mapper.mapping call: a fresh Adam state (mapper.py:615) and len(index_batches)
         iterations.  index_batches[i] is this rank's int32 shard of the i-th global batch."""
         self.reset_optimizer(len(index_batches))
-        if self.world > 1:
-            cert0 = self.fs.certainty.clone()
+        self.begin_side_effects()
         for i, idx in enumerate(index_batches):
             self.iteration(idx, i + 1)
         self.finish_optimizer()
-        if self.world > 1:  # certainty / ts side effects of the other ranks' shards
-            import torch.distributed as dist
-            delta = self.fs.certainty - cert0
-            dist.all_reduce(delta)
-            self.fs.certainty.copy_(cert0 + delta)
-            dist.all_reduce(self.ts_update, op=dist.ReduceOp.MAX)
+        self.merge_side_effects()
+
+    def begin_side_effects(self):
+        """Data-parallel: remember the certainties before the call (pin_dp_cert_snapshot)."""
+        if self.comm is None:
+            return
+        n = self.fs.certainty.shape[0]
+        if self._cert0 is None or self._cert0.shape[0] < n:
+            dev = self.fs.certainty.device
+            self._cert0 = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32, device=dev)
+            self._cert_scratch = torch.empty_like(self._cert0)
+        check(_lib.lib().pin_dp_cert_snapshot(self.fs.certainty.data_ptr(), self._cert0.data_ptr(), n,
+                                              torch.cuda.current_stream().cuda_stream), "pin_dp_cert_snapshot")
+
+    def merge_side_effects(self):
+        """world > 1: certainty / ts_update side effects of the other ranks' shards, once per mapping call
+        (pin_dp_sync_side_effects)."""
+        if self.comm is None:
+            return
+        self.comm.sync_side_effects(self.fs.certainty, self._cert0, self._cert_scratch, self.ts_update)

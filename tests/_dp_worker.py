@@ -1,0 +1,53 @@
+"""Worker of tests/test_gpu_dp.py: one rank of engine.MapTrainer on cuda:0, two mapping iterations on a golden
+fixture's fixed batches (its shard of them).  transport: none | host (gloo over pinned host buffers, for ranks that
+share the device) | rccl (RCCL through the C ABI; one rank per GPU, so world must be 1 on a single-GPU box)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pin_slam_amd import collective, engine, sharding  # noqa: E402
+from tests import golden_util as G  # noqa: E402
+from tests import gpu_util as U  # noqa: E402
+
+
+def main(rank, world, port, case, transport, out):
+    torch.cuda.set_device(0)
+    comm = None
+    if transport != "none":
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = collective.RcclComm(rank, world) if transport == "rccl" else collective.HostStagedComm(rank, world)
+    d = G.load(case)
+    st, fs = U.search_state(d), U.field_state(d)
+    tsu = U.dev(d["local_point_ts_update"], torch.int32)
+    bs = d["map_coord0"].shape[0]
+    t = engine.MapTrainer(st, fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
+                          weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
+                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm)
+    grads = []
+    t.on_grads = lambda g: grads.append(g.cpu().numpy().copy())
+    t.reset_optimizer(2 if transport == "none" else None)  # one GPU: the lazy exact Adam, as Mapper.mapping runs it
+    t.begin_side_effects()
+    a, b = sharding.shard_range(bs, rank, world)
+    for it in range(2):
+        t.step_batch(U.dev(d[f"map_coord{it}"][a:b]), U.dev(d[f"map_label{it}"][a:b]), U.dev(d[f"map_w{it}"][a:b]),
+                     U.dev(d[f"map_ts{it}"][a:b], torch.int32), it + 1)
+    t.finish_optimizer()
+    t.merge_side_effects()
+    torch.cuda.synchronize()
+    nd = fs.dec.numel()
+    np.savez(out, feats=fs.feats.cpu().numpy(), dec=fs.dec.cpu().numpy(), cert=fs.certainty.cpu().numpy(),
+             tsu=tsu.cpu().numpy(), gdec0=grads[0][:nd], gfeat0=grads[0][nd:], gdec1=grads[1][:nd], gfeat1=grads[1][nd:],
+             kind=np.array(getattr(comm, "kind", "none")))
+    if comm is not None:
+        comm.close()
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6])

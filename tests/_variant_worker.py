@@ -40,5 +40,27 @@ def main(out, hidden, levels, orient):
              sums=sums.cpu().numpy().sum(0), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy())
 
 
+def fixture(out, case):
+    """Per-point outputs and sums of the GN tile kernel on a golden fixture's query set (local index space)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tests import golden_util as G
+    from tests import gpu_util as U
+    d = G.load(case)
+    st, fs = U.search_state(d), U.field_state(d)
+    q = U.dev(d["query"])
+    nbr, nn, _ = ops.knn_query(st, q, int(d["query_nn_k"]))
+    gp = GnParams()
+    gp.valid_nn_k = int(d["track_mask_query_nn_k"])
+    gp.min_grad_norm, gp.max_grad_norm = d["cfg_reg_min_grad_norm"], d["cfg_reg_max_grad_norm"]
+    gp.max_sdf_std = d["cfg_surface_sample_range_m"] * d["cfg_max_sdf_std_ratio"]
+    gp.gm_dist, gp.gm_grad = d["cfg_reg_GM_dist_m"], d["cfg_reg_GM_grad"]
+    sums, sdf, grad = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+    torch.cuda.synchronize()
+    np.savez(out, nn=nn.cpu().numpy(), sums=sums.cpu().numpy().sum(0), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy())
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    if sys.argv[2] == "fixture":
+        fixture(sys.argv[1], sys.argv[3])
+    else:
+        main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))

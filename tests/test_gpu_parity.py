@@ -229,21 +229,32 @@ def test_mapping_two_iterations(gold):
     md, vd = torch.zeros_like(dec), torch.zeros_like(dec)
     bs = d["map_coord0"].shape[0]
     buf = ops.TrainBuffers(bs, int(d["map_dec"]), k, H, L, weighted_first=bool(d["weighted_first"]))
+    from pin_slam_amd import sharding
+    n_eik = sharding.n_eik_global(bs, int(d["map_dec"]))
+    gfs, gds = [], []
     for it in range(2):
         loss = ops.train_step(d["st"], fs, buf, U.dev(d[f"map_coord{it}"]), U.dev(d[f"map_label{it}"]),
                               U.dev(d[f"map_w{it}"]), U.dev(d[f"map_ts{it}"], torch.int32), cert, tsu, gfeat, gdec,
                               sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"],
                               loss_weight_on=bool(d["map_loss_weight_on"]))
         gf, gd = d[f"map_gfeat{it}"], d[f"map_gdec{it}"]
-        assert np.max(np.abs(gfeat.cpu().numpy() - gf)) < 3e-4 * np.abs(gf).max()
-        assert np.max(np.abs(gdec.cpu().numpy() - gd)) < 3e-4 * np.abs(gd).max()
+        gfs.append(gfeat.cpu().numpy()); gds.append(gdec.cpu().numpy())
+        assert np.max(np.abs(gfs[-1] - gf)) < 1e-4 * np.abs(gf).max()
+        assert np.max(np.abs(gds[-1] - gd)) < 1e-4 * np.abs(gd).max()
+        # the reference's scalar losses: BCE term (loss.py:45-63) and the total at backward() (mapper.py:817)
+        l_bce, l_eik = loss.cpu().numpy()
+        l_bce, l_eik = l_bce / bs, l_eik / n_eik
+        assert abs(l_bce - d["map_loss_sdf"][it]) < 1e-4 * abs(d["map_loss_sdf"][it])
+        total = l_bce + d["map_weight_e"] * l_eik
+        assert abs(total - d["map_loss_total"][it]) < 1e-4 * abs(d["map_loss_total"][it])
         ops.adam_step(feats, gfeat, mf, vf, it + 1, d["map_lr"], eps=d["map_adam_eps"])
         ops.adam_step(dec, gdec, md, vd, it + 1, d["map_lr"], eps=d["map_adam_eps"])
         assert float(gfeat.abs().max()) == 0.0  # zero_grad in the same pass
-    df = np.abs(feats.cpu().numpy() - d["map_feat_after"])
-    assert np.mean(df < 1e-4) > 0.995
-    dd = np.abs(dec.cpu().numpy() - d["map_dec_after"])
-    assert np.mean(dd < 1e-4) > 0.99
+    # post-Adam parameters: within 1e-4 wherever the reference gradient is above the measured rounding noise of
+    # the gradient; the noise-dominated entries (Adam, eps = 1e-15, steps by ~lr whatever |g|) are bounded
+    ff, _ = G.adam_outliers(feats.cpu().numpy(), d["map_feat_after"], gfs, [d["map_gfeat0"], d["map_gfeat1"]], d["map_lr"])
+    fd, _ = G.adam_outliers(dec.cpu().numpy(), d["map_dec_after"], gds, [d["map_gdec0"], d["map_gdec1"]], d["map_lr"])
+    assert ff < 0.2 and fd < 0.2
     np.testing.assert_allclose(cert.cpu().numpy(), d["map_cert_after"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(tsu.cpu().numpy(), d["map_ts_after"])
 

@@ -145,6 +145,7 @@ def test_mapping_two_iterations(gold):
     mf, vf = np.zeros_like(feats), np.zeros_like(feats)
     md, vd = np.zeros_like(flat), np.zeros_like(flat)
     shape = (11, int(d["dec_hidden"]), int(d["dec_levels"]))
+    gfs, gds = [], []
     for it in range(2):
         coord = d[f"map_coord{it}"]
 
@@ -167,14 +168,17 @@ def test_mapping_two_iterations(gold):
         gf, gd = d[f"map_gfeat{it}"], d[f"map_gdec{it}"]
         assert np.max(np.abs(r["feat_grad"] - gf)) < 2e-4 * np.abs(gf).max()
         assert np.max(np.abs(r["dec_grad"] - gd)) < 2e-4 * np.abs(gd).max()
+        # the scalar losses of the reference (BCE term, and the total at its backward() call)
+        assert abs(r["sdf_loss"] - d["map_loss_sdf"][it]) < 1e-5 * abs(d["map_loss_sdf"][it])
+        assert abs(r["loss"] - d["map_loss_total"][it]) < 1e-5 * abs(d["map_loss_total"][it])
+        gfs.append(r["feat_grad"]); gds.append(r["dec_grad"])
         feats, mf, vf = O.adam_step(feats, r["feat_grad"], mf, vf, it + 1, d["map_lr"], eps=d["map_adam_eps"])
         flat, md, vd = O.adam_step(flat, r["dec_grad"], md, vd, it + 1, d["map_lr"], eps=d["map_adam_eps"])
-    # Adam normalises every touched entry to a +-lr sized step; entries whose gradient is at
-    # float32-noise level can flip sign between implementations -> compare the bulk tightly.
-    df = np.abs(feats - d["map_feat_after"])
-    assert np.mean(df < 1e-4) > 0.995 and df.max() <= 2.1 * d["map_lr"] * 2
-    dd = np.abs(flat - d["map_dec_after"])
-    assert np.mean(dd < 1e-4) > 0.99
+    # post-Adam parameters: tight wherever the gradient is above its measured rounding noise (golden_util.adam_outliers)
+    frac_f, _ = G.adam_outliers(feats, d["map_feat_after"], gfs, [d["map_gfeat0"], d["map_gfeat1"]], d["map_lr"])
+    frac_d, _ = G.adam_outliers(flat, d["map_dec_after"], gds, [d["map_gdec0"], d["map_gdec1"]], d["map_lr"])
+    print(d.get("name"), "noise-dominated entries: features", frac_f, "decoder", frac_d)
+    assert frac_f < 0.2 and frac_d < 0.2
     np.testing.assert_allclose(cert, d["map_cert_after"], rtol=1e-4, atol=1e-5)
     assert np.array_equal(tsu, d["map_ts_after"])
 
