@@ -14,14 +14,21 @@ preprocess + odometry + mapping preparation + mapping), on the synthetic workloa
                    reset_local_map (+ brick cache), pool window / capacity filter over ~2.7M
                    samples, query_certainty, new-sample index;
   * mapping      : Mapper.mapping = 12 iterations, batch 16384 (+ 6*1639 Eikonal queries), BCE +
-                   Eikonal, backward to features and decoder, dense Adam over all local features.
+                   Eikonal, backward to features and decoder, Adam (exact lazy form: only the rows an
+                   iteration reads are visited, bit-identical to the dense step).
 Everything runs through the drop-in classes (pin_slam_amd.dropin) on libpinhip.  Inputs (raw
 scan, timestamps) are resident in HBM before the timed region.
 
-N > 1 (torchrun, one rank per GPU): preprocess / odometry / map prep are replicas (every rank
-keeps the identical map: same scan, same seed); the mapper batch is N x 16384, sharded, with one
-RCCL all-reduce of [decoder grads | feature grads] per iteration (weak scaling).
-value = N * frames / time.
+N > 1 (torchrun, one rank per GPU) measures what the north star asks for at 2/4/8 GPUs: the
+data-parallel MAPPER (config C4).  A step = one Mapper.mapping call of `--map-iters` iterations on
+a GLOBAL batch of 2^20 samples (`--global-bs`), cut into N contiguous shards; every iteration ends
+with one RCCL all-reduce (through the C ABI, pin_allreduce_grads) of the flat fp32 buffer
+[decoder grads | feature grads] and the replicated dense Adam step; certainty / ts side effects are
+merged once per call.  metric = mapper_samples_per_sec, value = steps * iters * 2^20 / time
+(strong scaling: the global batch is fixed).  The N = 1 line carries the same measurement on one
+GPU in `c4_single_gpu`, the N = 1 point of that curve.  Registration is single-GPU by nature
+(sequential GN iterations); `--parallel replicas` runs N independent frame streams instead
+(no data-path collective; value = N * frames / time).
 
 Prints ONE JSON line (rank 0).
 """
@@ -62,11 +69,19 @@ def parse():
     ap.add_argument("--pool", type=int, default=2_000_000, help="samples in the pool (= pool_capacity)")
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "dp"],
-                    help="N > 1: 'replicas' = N independent frame streams, no data-path collective; 'dp' = the mapper "
-                         "shards a global batch of N x bs and all-reduces [decoder | feature] gradients over RCCL every "
-                         "iteration (SURVEY 8e); auto = dp from a per-rank batch of 2^17 up, where the sharded compute "
-                         "outweighs the 71 MB gradient exchange, replicas below")
+    ap.add_argument("--parallel", default="dp", choices=["dp", "replicas"],
+                    help="N > 1: 'dp' (default) = the data-parallel mapper of config C4: a global batch of --global-bs "
+                         "samples sharded over the ranks, one RCCL all-reduce of [decoder | feature] gradients per "
+                         "iteration (SURVEY 8e); 'replicas' = N independent frame streams, no data-path collective")
+    ap.add_argument("--global-bs", type=int, default=1 << 20, help="global mapper batch of the dp / C4 measurement")
+    ap.add_argument("--c4-iters", type=int, default=4, help="N = 1: iterations per timed Mapper.mapping call of the "
+                                                             "single-GPU C4 leg (0 = skip it)")
+    ap.add_argument("--skip-downsampled", action="store_true",
+                    help="skip the second timed leg (registering the source-down-sampled subset): profiles of this "
+                         "command then hold one launch shape per tracker kernel")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel mapper measurement with whatever world size there is (a one-rank RCCL "
+                         "communicator on a single-GPU box: exercises the N > 1 code path end to end)")
     ap.add_argument("--events", default="all", choices=["none", "knn", "all"],
                     help="HIP events around the tracker's kNN / GN launches inside the timed region")
     ap.add_argument("--stages", default="all", choices=["all", "hot"],
@@ -110,16 +125,15 @@ def main():
 
     wl = WORKLOADS[args.workload]
     H, L, k = wl["hidden"], wl["levels"], 8
-    mapper_dp = world > 1 and (args.parallel == "dp" or (args.parallel == "auto" and args.bs >= (1 << 17)))
-    dp_world = world if mapper_dp else 1
+    mapper_dp = (world > 1 or args.force_dp) and args.parallel == "dp"
     res = 0.4
     n_frames = args.warmup + 2 * args.steps + 4
     cfg = PinConfig(voxel_size_m=res, search_alpha=0.5, num_nei_cells=2, query_nn_k=k, buffer_size=int(5e7),
-                    feature_std=0.1, bs=args.bs * dp_world, iters=args.map_iters, max_range=80.0, local_map_radius=82.0,
-                    window_radius=80.0, local_map_travel_dist_ratio=5.0, vox_down_m=0.08, source_vox_down_m=0.8,
-                    min_range=2.5, min_z=-5.0, max_z=80.0, deskew=True, pool_capacity=args.pool, pool_filter_freq=1,
-                    bs_new_sample=2048, geo_mlp_level=L, geo_mlp_hidden_dim=H, reg_iter_n=args.reg_iters)
-    torch.manual_seed(42)  # identical on every rank: the replicas must keep identical maps and batches
+                    feature_std=0.1, bs=args.global_bs if mapper_dp else args.bs, iters=args.map_iters, max_range=80.0,
+                    local_map_radius=82.0, window_radius=80.0, local_map_travel_dist_ratio=5.0, vox_down_m=0.08,
+                    source_vox_down_m=0.8, min_range=2.5, min_z=-5.0, max_z=80.0, deskew=True, pool_capacity=args.pool,
+                    pool_filter_freq=1, bs_new_sample=2048, geo_mlp_level=L, geo_mlp_hidden_dim=H, reg_iter_n=args.reg_iters)
+    torch.manual_seed(42)  # identical on every rank: the ranks must keep identical maps and draw identical batches
 
     # ---------------- synthetic map / scan / pool (identical on every rank) ----------------
     m = synth.build_map(layers=wl["layers"], resolution=res)
@@ -131,7 +145,9 @@ def main():
     decoders = {"sdf": dec, "semantic": None, "color": None}
     ds = Dataset(n_frames + 1)
     mp = Mapper(cfg, ds, npts, decoders)
-    mp.dp_rank, mp.dp_world = (rank, world) if mapper_dp else (0, 1)
+    if mapper_dp:  # RCCL through the C ABI; torch.distributed only carries the ncclUniqueId (and this script's barriers)
+        from pin_slam_amd import collective
+        mp.dp_rank, mp.dp_world, mp.dp_comm = rank, world, collective.RcclComm(rank, world)
     trk = Tracker(cfg, npts, decoders)
     pool_c, pool_l = synth.make_pool(m, n=args.pool)
     mp.coord_pool = torch.from_numpy(pool_c).cuda()
@@ -142,6 +158,31 @@ def main():
     mp.pool_sample_count = len(pool_l)
     mp._pool()          # adopt the tensors into the device pool
     mp._publish_pool()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    if mapper_dp:
+        out = bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        mp.dp_comm.close()
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
     scan_np = synth.make_scan(m, n=args.scan, seed=1)
     rng = np.random.default_rng(5)
     raw = torch.from_numpy(np.concatenate([scan_np, rng.random((args.scan, 1), dtype=np.float32)], 1)).cuda()
@@ -217,12 +258,6 @@ def main():
             stage_events.append(ev)
         stats["last"] = (T, cnt, res_cm, its, reg.shape[0], gn)
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         frame(False)
     barrier()
@@ -230,12 +265,7 @@ def main():
     for i in range(args.steps):
         frame(True, hooks=(on_knn, on_gn) if i < ev_frames else (None, None))
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     T, cnt, res_cm, its, n_reg, gn = stats["last"]
     nn_mean = float(gn.nn[:n_reg].float().mean().item())
     names = ("preprocess", "odometry", "map_prep", "mapping")
@@ -243,13 +273,22 @@ def main():
     pool_now, new_now, n_src = mp.pool_sample_count, (0 if mp.new_idx is None else int(mp.new_idx.shape[0])), int(state["src"].shape[0])
 
     # the reference's own odometry workload: register the source-down-sampled subset (reported, not `value`)
-    frame(False, source_downsampled=True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    elapsed_ds = None
+    if not args.skip_downsampled:
         frame(False, source_downsampled=True)
-    barrier()
-    elapsed_ds = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            frame(False, source_downsampled=True)
+        barrier()
+        elapsed_ds = time.perf_counter() - t0
+
+    # the GPU side of the parity check (the oracle side runs in cpu_baseline_and_parity, outside every timed region):
+    # the benchmarked kernels -- brick kNN + the GN tile kernel -- on a sub-sample of the timed scan, against the
+    # map as it stands after the timed frames
+    parity_in = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k)
 
     # achievable HBM ceiling on this box: a 1 GiB device-to-device copy (read + write), outside the timed regions
     ca = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
@@ -265,6 +304,12 @@ def main():
     torch.cuda.synchronize()
     copy_gbs = 5 * 2 * ca.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
     del ca, cb
+
+    # config C4 on ONE GPU (the N = 1 point of the data-parallel mapper curve): Mapper.mapping on a 2^20 batch
+    c4 = None
+    if world == 1 and args.c4_iters > 0:
+        c4 = c4_single_gpu(args, cfg, mp)
+
     knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
     gn_ms = float(np.mean([a.elapsed_time(b) for a, b in gn_pairs])) if gn_pairs else float("nan")
     # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian
@@ -280,13 +325,17 @@ def main():
     # one 4-byte slot per candidate cell, one 16-byte position per occupied cell, kNN record out
     bytes_q = 12 + 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4
     achieved = bytes_q * n_reg / (knn_ms * 1e-3) / 1e9
-    pmc_data = {}
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            pmc_data = json.load(open(pmc))
-        except Exception:
-            pmc_data = {}
+    pmc_data, pmc_src = {}, None
+    for name in ("r02_pmc.json", "r01_pmc.json"):  # PMC passes of THIS command (scripts/pmc_bench.sh) when present
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                pmc_data, pmc_src = json.load(open(path)), "profiles/" + name
+                break
+            except Exception:
+                pass
+    gnk = pmc_data.get("kernels", {}).get("gn", {})
+    knk = pmc_data.get("kernels", {}).get("knn_brick", {})
 
     frames_per_s = world * args.steps / elapsed
     ms_step = 1e3 * elapsed / args.steps
@@ -306,42 +355,53 @@ def main():
                    "pool_samples": pool_now, "new_samples": new_now, "brick_cache": npts._bricks is not None,
                    "stages": args.stages,
                    "parallelism": "1 GPU" if world == 1 else
-                                  (f"preprocess/odometry/map-prep replicas x{world}, mapper dp{world} (global batch {args.bs * world}, "
-                                   f"RCCL all-reduce of decoder + feature gradients per iteration)" if mapper_dp else
-                                   f"{world} independent replicas (one frame stream per GPU, no data-path collective; "
-                                   f"--parallel dp selects the data-parallel mapper)")},
+                                  f"{world} independent replicas (one frame stream per GPU, no data-path collective; "
+                                  f"the default --parallel dp measures the data-parallel mapper instead)"},
         "stage_ms_per_frame": stage_ms,
         "mapper_samples_per_sec": round(world * args.bs * args.map_iters / (1e-3 * stage_ms["mapping"]), 1),
-        "frames_per_sec_source_downsampled": round(world * args.steps / elapsed_ds, 3),
+        "frames_per_sec_source_downsampled": None if elapsed_ds is None else round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,
-        "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
+        "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
+        "c4_single_gpu": c4,
         "roofline": {"kernel": "gn_accumulate_quad_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
-                     "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "avg_launch_ms": round(gn_ms, 4),
+                     "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                     "avg_launch_ms": round(gn_ms, 4),
                      "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,
                      "share_of_frame": round(gn_ms * args.reg_iters / ms_step, 3),
                      "arithmetic": ("fp32 factors split exactly into 3 bf16 pieces, 6 piece products per fp32 product on "
                                     "v_mfma_f32_16x16x32_bf16, fp32 accumulate; `achieved`/`peak` are fp32-equivalent")
                                    if split_bf16 else "v_mfma_f32_16x16x4_f32",
-                     "limiter": "vector-ALU + MFMA issue, additive on gfx950 (PMC: ~16.7 M vector instructions = 27 us and "
-                                "13 us of MFMA per launch and SIMD, profiles/r01_pmc.json; scripts/mfma_valu_overlap.hip)",
+                     "limiter": "vector-ALU + MFMA issue, additive on gfx950 (scripts/mfma_valu_overlap.hip)",
+                     "valu_insts_per_launch": gnk.get("SQ_INSTS_VALU"),
+                     "mfma_busy_cycles_per_launch": gnk.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                      "executed": {"flops_per_query": exec_flops_q, "tflops": round(exec_tflops, 1),
                                   "peak": BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS,
                                   "frac": round(exec_tflops / (BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS), 4)}},
-        "roofline_knn": {"kernel": "knn_brick_kernel" if npts._bricks is not None else "knn_query_kernel", "bound": "hbm",
+        "roofline_knn": {"kernel": "knn_brick_kernel" if npts._bricks is not None else "knn_query_kernel",
+                         "bound": "valu", "bound_note": "vector-ALU instruction issue (PMC), not HBM: the fabric traffic "
+                                                        "is below the algorithmic bytes; the GB/s figure is the "
+                                                        "algorithmic rate, stated against HBM for scale only",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_data.get("knn_brick_hbm_bytes_per_launch"),
+                         "traffic_source": pmc_src,
                          "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
                          "algorithmic_bytes_per_query": round(bytes_q, 1),
+                         "valu_insts_per_query": None if not knk.get("SQ_INSTS_VALU") else
+                                                 round(64.0 * knk["SQ_INSTS_VALU"] / n_reg, 1),
                          "measured_copy_gbs": round(copy_gbs, 1),
-                         "limiter": "vector-ALU instruction count (PMC: ~17.3 M vector instructions = 28 us per launch and "
-                                    "SIMD, profiles/r01_pmc.json), not HBM: fabric traffic is 0.43x the algorithmic bytes",
                          "share_of_frame": round(knn_ms * args.reg_iters / ms_step, 3)},
     }
+    ref_cpu = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
+    if os.path.exists(ref_cpu):  # the real reference (torch CPU) timed by scripts/ref_cpu_baseline.py, see the file
+        try:
+            out["cpu_baseline_reference"] = json.load(open(ref_cpu))
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(m, cfg, scan_np, raw.cpu().numpy(), raw_ts.cpu().numpy(), pool_c, pool_l,
-                                           m.features, dec.flat_params().cpu().numpy(), H, L, k,
-                                           dec.sdf_scale, args)
+        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(
+            m, cfg, scan_np, raw.cpu().numpy(), raw_ts.cpu().numpy(), pool_c, pool_l, m.features,
+            dec.flat_params().cpu().numpy(), H, L, k, dec.sdf_scale, args, parity_in)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -349,7 +409,120 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k, sdf_scale, args):
+def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096):
+    """Device side of bench.py's parity line: the timed kernels (brick kNN as the tracker launches it, then the
+    GN tile kernel with per-point outputs) on `n` points of the timed scan, plus a host copy of the map state
+    the oracle needs to answer the same queries."""
+    from pin_slam_amd import ops
+    q = xyz[:n].contiguous()
+    nbr, nn, _ = npts.knn(q, True)
+    fs = npts.field_state(dec, query_locally=True)
+    _, sdf, grad = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+    torch.cuda.synchronize()
+    raw = nbr.cpu().numpy()[..., 3].view(np.int32)
+    idx = np.where(raw >= 0, raw & ~0x40000000, raw)
+    td = npts._travel()
+    return dict(q=q.cpu().numpy(), idx=idx, nn=nn.cpu().numpy(), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy(),
+                table=npts.buffer_pt_index.cpu().numpy().astype(np.int64), pos=npts.neural_points.cpu().numpy(),
+                ts_create=npts.point_ts_create.cpu().numpy(), travel=None if td is None else td.cpu().numpy(),
+                cur_ts=int(npts.cur_ts), diff=float(npts.diff_travel_dist_local), g2l=npts.global2local.cpu().numpy(),
+                lfeat=npts.local_geo_features.data.cpu().numpy(), lpos=npts.local_neural_points.cpu().numpy(),
+                dec=dec.flat_params().cpu().numpy(), dx=npts.neighbor_dx.cpu().numpy(), mv=float(npts.max_valid_dist2),
+                res=float(npts.resolution), valid_nn_k=int(gp.valid_nn_k))
+
+
+def c4_single_gpu(args, cfg, mp):
+    """Config C4 on one GPU: Mapper.mapping on a global batch of --global-bs samples (the quantity
+    `bench.py --gpus N` reports for N > 1), timed with the host clock around synchronised calls."""
+    bs0 = cfg.bs
+    cfg.bs = args.global_bs
+    try:
+        mp.mapping(2)  # builds the trainer / workspace for this batch size
+        torch.cuda.synchronize()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mp.mapping(args.c4_iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        cfg.bs = bs0
+        mp._trainer = None  # drop the 2^20-sample workspace
+    it = reps * args.c4_iters
+    return {"global_batch": args.global_bs, "iterations_timed": it, "ms_per_iteration": round(1e3 * dt / it, 4),
+            "mapper_samples_per_sec": round(args.global_bs * it / dt, 1), "optimizer": "lazy exact Adam (single GPU)"}
+
+
+def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P):
+    """N > 1: the data-parallel mapper (config C4).  Step = one Mapper.mapping call of --map-iters iterations on the
+    global batch; every rank evaluates its contiguous shard, one RCCL all-reduce of [decoder | feature] gradients per
+    iteration through the C ABI, identical dense Adam step on every rank."""
+    H, L = wl["hidden"], wl["levels"]
+    gbs, iters = args.global_bs, args.map_iters
+    for _ in range(max(1, args.pretrain_iters // 50)):
+        mp.mapping(10)
+    t = mp._get_trainer()
+    ar_pairs, cur = [], {}
+    n_ev = 2 * iters
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+
+    def on_ar(start):
+        if start:
+            if len(ar_pairs) < n_ev:
+                cur["p"] = evs[len(ar_pairs)]
+                cur["p"][0].record()
+            else:
+                cur["p"] = None
+        elif cur.get("p") is not None:
+            cur["p"][1].record()
+            ar_pairs.append(cur["p"])
+
+    for _ in range(args.warmup):
+        mp.mapping(iters)
+    barrier()
+    mp._get_trainer().on_allreduce = on_ar
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        mp.mapping(iters)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    t = mp._get_trainer()
+    t.on_allreduce = None
+    ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_pairs])) if ar_pairs else float("nan")
+    ar_bytes = 4 * int(t.grad.numel())
+    ms_it = 1e3 * elapsed / (args.steps * iters)
+    value = args.steps * iters * gbs / elapsed
+    return {
+        "metric": "mapper_samples_per_sec", "value": round(value, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c4: Mapper.mapping, global batch {gbs} (+{(gbs + 9) // 10}x6 Eikonal probes) sharded over "
+                               f"{world} GPUs, {iters} iterations per step, {wl['desc']}",
+                   "neural_points": P, "local_points": int(npts.local_count()), "decoder": f"{L}x{H}",
+                   "global_batch": gbs, "per_rank_batch": gbs // world,
+                   "parallelism": f"mapper dp{world}: contiguous batch shards, map + decoder replicated, one RCCL all-reduce "
+                                  f"(pin_allreduce_grads, in place on the compute stream) of [decoder | feature] "
+                                  f"gradients per iteration, replicated dense Adam; certainty / ts merged once per call",
+                   "n1_reference": "the N = 1 bench line reports the same workload on one GPU as c4_single_gpu"},
+        "ms_per_iteration": round(ms_it, 4),
+        "allreduce": {"transport": getattr(mp.dp_comm, "kind", None), "bytes_per_iteration": ar_bytes,
+                      "avg_ms": round(ar_ms, 4), "launches_timed": len(ar_pairs),
+                      "algbw_GBs": round(ar_bytes / (ar_ms * 1e-3) / 1e9, 1) if ar_ms == ar_ms and ar_ms > 0 else None,
+                      "busbw_GBs": round(2 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9, 1)
+                                   if ar_ms == ar_ms and ar_ms > 0 else None,
+                      "share_of_iteration": round(ar_ms / ms_it, 3) if ar_ms == ar_ms else None},
+        "roofline": {"kernel": "ncclAllReduce (xGMI) + train_fwd/bwd_quad_kernel", "bound": "xgmi-link + mfma",
+                     "achieved": round(2 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9, 1)
+                                 if ar_ms == ar_ms and ar_ms > 0 else None,
+                     "peak": 7 * 153.0, "unit": "GB/s",
+                     "frac": round(2 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9 / (7 * 153.0), 4)
+                             if ar_ms == ar_ms and ar_ms > 0 else None,
+                     "traffic": None,
+                     "note": "bus bandwidth of the gradient all-reduce per GPU against 7 xGMI links x 153 GB/s"},
+    }
+
+
+def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k, sdf_scale, args, parity_in=None):
     """The numpy oracle (a port of the reference's torch-CPU chain) timed on a bounded sample of
     the same workload on this host; odometry and mapping are extrapolated linearly in the query
     count, the preprocess / map-prep stages are timed at full size (they are cheap)."""
@@ -413,12 +586,34 @@ def cpu_baseline(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k,
     frame_s = args.reg_iters * t_reg * (args.scan / n_s) + args.map_iters * t_tr * (args.bs / bs_s)
     if args.stages == "all":
         frame_s += t_prep
-    return {"value": round(1.0 / frame_s, 5), "unit": "frames/s", "cores": 1, "kind": "port",
+    base = {"value": round(1.0 / frame_s, 5), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"numpy oracle: {reps} registration steps on {n_s} scan points ({t_reg*1e3:.0f} ms each) and "
                       f"{reps2} mapping iterations of batch {bs_s} ({t_tr*1e3:.0f} ms each), extrapolated linearly to "
                       f"{args.reg_iters}x{args.scan} + {args.map_iters}x{args.bs}; preprocess + map-prep stages once at "
                       f"full size ({t_prep:.1f} s); one host thread (host has {os.cpu_count()} cores)",
             "registration_queries_per_sec": round(n_s / t_reg, 1), "mapper_samples_per_sec": round(bs_s / t_tr, 1)}
+    return base, (None if parity_in is None else parity_vs_oracle(O, parity_in, H, L, k, sdf_scale))
+
+
+def parity_vs_oracle(O, g, H, L, k, sdf_scale):
+    """The oracle's answer to the queries of gpu_parity_sample() on the same map state (the checker; never timed)."""
+    s = O.radius_search(g["q"], g["table"], g["pos"], g["res"], g["dx"], g["mv"], ts_create=g["ts_create"],
+                        travel_dist=g["travel"], cur_ts=g["cur_ts"], diff_travel_dist_local=g["diff"])
+    qf = O.query_feature(g["q"], s, g["lfeat"], g["lpos"], None, k, global2local=g["g2l"])
+    params = O.unpack_decoder(g["dec"], 11, H, L)
+    rs, rg, _, rnn, _ = O.query_sdf(g["q"], s, g["lfeat"], g["lpos"], params, sdf_scale, k, global2local=g["g2l"])
+    has = rnn >= g["valid_nn_k"]
+    scale = float(np.abs(rs[has]).max()) if has.any() else 1.0
+    gscale = np.abs(rg).max(1, keepdims=True) + 1e-6
+    return {"n_checked": int(len(g["q"])), "n_with_neighbours": int(has.sum()),
+            "idx_mismatch": int((g["idx"] != qf["knn_idx"].astype(np.int32)).sum()),
+            "nn_count_mismatch": int((g["nn"] != rnn).sum()),
+            "sdf_max_abs": float(np.abs(g["sdf"] - rs)[has].max()) if has.any() else None,
+            "sdf_max_rel": float(np.abs(g["sdf"] - rs)[has].max() / scale) if has.any() else None,
+            "grad_max_rel": float((np.abs(g["grad"] - rg) / gscale)[has].max()) if has.any() else None,
+            "definition": "brick kNN + GN tile kernel (the timed kernels) vs the numpy oracle (float64 decoder) on the first "
+                          "n_checked points of the timed scan and the map after the timed frames; sdf_max_rel = max |sdf - ref| "
+                          "/ max |ref|, grad_max_rel = max over points of |grad - ref| / max-component of ref; target 1e-4"}
 
 
 if __name__ == "__main__":

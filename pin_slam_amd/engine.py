@@ -147,6 +147,7 @@ class MapTrainer:
         if world > 1 and comm is None:
             raise ValueError("MapTrainer(world > 1) needs a collective (pin_slam_amd.collective.RcclComm)")
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
+        self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
         self._cert0 = self._cert_scratch = None
         assert self.bs % world == 0, "global batch must divide over the ranks"
         self.bs_local = self.bs // world
@@ -238,7 +239,11 @@ class MapTrainer:
             if self.c_train_dec and not lazy:
                 ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.comm is not None:  # SUM of the per-rank gradients of [decoder | features] (pin_allreduce_grads)
+            if self.on_allreduce is not None:
+                self.on_allreduce(True)
             self.comm.allreduce_grads(self.grad if self.train_decoder else self.gfeat)
+            if self.on_allreduce is not None:
+                self.on_allreduce(False)
         if self.on_grads is not None:
             self.on_grads(self.grad)
         if lazy:  # (the decoder's dense step rides along in the same launch)
