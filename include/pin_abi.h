@@ -239,14 +239,40 @@ typedef struct pin_update_params {
 } pin_update_params;
 
 typedef struct pin_local_params {
-    const float* travel_dist;  /* NULL = temporal_local_map_on False: no time mask */
+    const float* travel_dist;  /* use_travel_dist: accumulated travel distance per frame (:451-455) */
     int32_t n_points;
     int32_t cur_ts;
     int32_t reboot_ts;         /* >= 0 only when reboot_map (:465-466), else -1 */
     float diff_travel_dist_local;
-    float sensor[3];
-    float radius2;             /* local_map_radius^2 */
+    int32_t time_mode;         /* 0 = no time mask (temporal_local_map_on False), 1 = travel distance window
+                                  |travel[cur_ts] - travel[ts]| < diff_travel_dist_local (:451-455), 2 = frame window
+                                  |cur_ts - ts| < diff_ts_local (use_travel_dist False, :456-458) */
+    int32_t diff_ts_local;
+    int32_t use_mid_ts;        /* config.use_mid_ts: ts = ((ts_create + ts_update) / 2).int() (:443-447) */
+    int32_t sensor_f64;        /* the caller's sensor_position is float64: `neural_points - sensor_position` promotes,
+                                  the radius test runs in float64 (:476-479); 0 = float32 arithmetic */
+    double sensor[3];
+    double radius2;            /* local_map_radius ** 2 (rounded to float32 by the library when sensor_f64 == 0) */
 } pin_local_params;
+
+/* recreate_hash / prune_map (model/neural_points.py:748-789, 819-908) */
+typedef struct pin_rehash_params {
+    int64_t buffer_size;
+    int32_t n_points;
+    int32_t cur_ts;
+    int32_t with_ts;           /* 1: voxel winner = smallest |ts - cur_ts| (:843-851); 0: largest certainty (:853-858) */
+    int32_t use_mid_ts;
+    float resolution;
+} pin_rehash_params;
+
+typedef struct pin_prune_params {
+    const float* travel_dist;  /* used unless global_prune */
+    int32_t n_points;
+    int32_t cur_ts;
+    int32_t global_prune;
+    float certainty_thre;
+    float diff_travel_dist_local;
+} pin_prune_params;
 
 typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapper.py:668-675, 804-812) */
     int32_t n_main;          /* batch size */
@@ -623,6 +649,28 @@ int pin_comm_destroy(void* comm);
  * (ncclAllReduce, ncclFloat32, ncclSum): one call per Mapper.mapping iteration, between the backward pass
  * (pin_train_step) and the optimiser step (pin_adam_step). */
 int pin_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
+
+/* ---- post-loop map maintenance on the device ------------------------------------ */
+
+/* NeuralPoints.recreate_hash (model/neural_points.py:819-908) with voxel_down_sample_min_value_torch
+ * (utils/tools.py:629-668) inside: per voxel of size `resolution` the index of the point with the smallest value
+ * (|ts - cur_ts| or max(certainty) - certainty, quantised to 1000 levels, lowest index on ties; the reference's
+ * `grid.max()` stride of the voxel id is reproduced), sel_out [<= n_points] in voxel-id order, *count_out of them.
+ * dst == NULL (kept_points = True): the table is cleared and re-filled with table[hash(pos[sel[r]])] = sel[r];
+ * when several samples share a slot the last in sample order stays (the reference's index_put_ leaves that
+ * unspecified).  dst != NULL (kept_points = False, the final merge): rows sel[r] of every array of `src` are
+ * gathered to row r of `dst` (feature padding row appended, pos4 mirror written) and the table, which both structs
+ * share, is rebuilt over the new indices.  Workspace: pin_maint_workspace_bytes(n_points) + 4 * n_points bytes. */
+int pin_hash_rebuild(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_rehash_params* rp,
+                     int32_t* sel_out, int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* NeuralPoints.prune_map (model/neural_points.py:748-789): rows with certainty < certainty_thre (and, unless
+ * global_prune, |travel[cur_ts] - travel[ts_update]| > diff_travel_dist_local) are dropped; the kept rows of `src`
+ * are written to `dst` in order (ordered compaction, feature padding row appended, pos4 mirror written);
+ * *n_keep_out = rows kept.  The caller adopts `dst` when n_points - n_keep exceeds min_prune_count, as the
+ * reference does.  Workspace: pin_maint_workspace_bytes(n_points). */
+int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_prune_params* pp,
+                  int32_t* n_keep_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Start of a data-parallel Mapper.mapping call: certainty0_out <- certainty (device copy on `stream`). */
 int pin_dp_cert_snapshot(const float* certainty, float* certainty0_out, int32_t n, void* stream);

@@ -442,6 +442,25 @@ def gen_update():
         out[f"count{ts}"] = np.int64(npts.count())
         out[f"local_mask{ts}"] = t2n(npts.local_mask)
         out[f"global2local{ts}"] = t2n(npts.global2local)
+    # reset_local_map variants on the final map: a window of FRAMES instead of travel distance (pin_slam.py:287 passes
+    # config.loop_local_map_by_travel_dist = False), a float64 sensor position (dataset.cur_pose_torch[:3, 3]: the radius
+    # test promotes to float64), use_mid_ts
+    npts.point_ts_update = torch.randint(0, 4, (npts.count(),), generator=gen).int().maximum(npts.point_ts_create)
+    out["point_ts_update"] = t2n(npts.point_ts_update)
+    sp64 = torch.tensor([13.37, 0.21, -0.4], dtype=torch.float64)
+    out["var_sensor"] = t2n(sp64)
+    npts.reset_local_map(sp64.float(), None, 2, False, 2)
+    out["var_ts_mask"], out["var_ts_g2l"] = t2n(npts.local_mask), t2n(npts.global2local)
+    npts.reset_local_map(sp64, None, 3, True)
+    out["var_f64_mask"] = t2n(npts.local_mask)
+    npts.reset_local_map(sp64.float(), None, 3, True)
+    out["var_f32_mask"] = t2n(npts.local_mask)
+    cfg.use_mid_ts = True
+    npts.reset_local_map(sp64.float(), None, 3, True)
+    out["var_mid_mask"] = t2n(npts.local_mask)
+    npts.reset_local_map(sp64.float(), None, 2, False, 1)
+    out["var_mid_ts_mask"] = t2n(npts.local_mask)
+    cfg.use_mid_ts = False
     tab = npts.buffer_pt_index
     slots = torch.nonzero(tab >= 0).flatten()
     out.update(table_slots=t2n(slots), table_vals=t2n(tab[slots]), neural_points=t2n(npts.neural_points),
@@ -722,6 +741,27 @@ def gen_postloop():
         tab = npts.buffer_pt_index
         slots = torch.nonzero(tab >= 0).flatten()
         out[f"rehash_{name}_slots"], out[f"rehash_{name}_vals"] = t2n(slots), t2n(tab[slots])
+    # use_mid_ts: the timestamp of a point is ((ts_create + ts_update) / 2).int() (adjust_map / recreate_hash)
+    import copy
+    cfg.use_mid_ts = True
+    q = copy.deepcopy(npts)
+    q.config = cfg
+    q.neural_points, q.point_orientations = torch.from_numpy(out["neural_points"]), torch.from_numpy(out["point_orientations"])
+    q.adjust_map(pd_t)
+    out["mid_adj_points"], out["mid_adj_orient"] = t2n(q.neural_points), t2n(q.point_orientations)
+    q.recreate_hash(None, None, True, True, 3)
+    slots = torch.nonzero(q.buffer_pt_index >= 0).flatten()
+    out["rehash_mid_slots"], out["rehash_mid_vals"] = t2n(slots), t2n(q.buffer_pt_index[slots])
+    cfg.use_mid_ts = False
+    # the final merge of a run (pin_slam.py:520-521): prune_map(..., 0, True) then recreate_hash(None, None, False, False)
+    q = copy.deepcopy(npts)
+    q.silence = True
+    q.prune_map(1.0, 0, True)
+    q.recreate_hash(None, None, False, False)
+    slots = torch.nonzero(q.buffer_pt_index >= 0).flatten()
+    out.update(merge_points=t2n(q.neural_points), merge_orient=t2n(q.point_orientations), merge_geo=t2n(q.geo_features),
+               merge_ts_create=t2n(q.point_ts_create), merge_ts_update=t2n(q.point_ts_update),
+               merge_cert=t2n(q.point_certainties), merge_slots=t2n(slots), merge_vals=t2n(q.buffer_pt_index[slots]))
     return out
 
 

@@ -637,28 +637,46 @@ def map_update(state, points, cur_ts, resolution, travel_dist=None, diff_travel_
     return added
 
 
+def mid_ts(ts_create, ts_update):
+    """((point_ts_create + point_ts_update) / 2).int() (neural_points.py:443-447, 803-806, 845-848): true division in
+    float32, truncated."""
+    return ((np.asarray(ts_create, np.int32) + np.asarray(ts_update, np.int32)).astype(F32) / F32(2)).astype(np.int32)
+
+
 def local_map_mask(positions, ts_used, sensor_position, radius, travel_dist=None, cur_ts=0,
-                   diff_travel_dist_local=None, reboot_ts=None):
+                   diff_travel_dist_local=None, reboot_ts=None, diff_ts_local=None):
     """NeuralPoints.reset_local_map (neural_points.py:448-507): (local_mask [P] bool,
-    global2local [P+1] int64).
+    global2local [P+1] int64).  travel_dist given: travel-distance window (use_travel_dist, :451-455);
+    diff_ts_local given instead: window of frames (:456-458); neither: no time mask.  The radius test runs
+    in the dtype of ``sensor_position`` (float32 points - float64 position promotes, :475-479).
 
     Reference quirk, reproduced on purpose: ``torch.full_like(local_mask, -1).long()``
     (neural_points.py:498) is taken of a *bool* tensor, so the fill value is True -> 1,
     i.e. NON-LOCAL points map to local index 1, not -1; only the padding entry is -1
     (neural_points.py:505)."""
     P = positions.shape[0]
-    if travel_dist is not None:
-        td = np.asarray(travel_dist, F32)
-        tm = np.abs(td[cur_ts] - td[ts_used]) < F32(diff_travel_dist_local)
+    ts_used = np.asarray(ts_used)
+    if travel_dist is not None or diff_ts_local is not None:
+        if travel_dist is not None:
+            td = np.asarray(travel_dist, F32)
+            tm = np.abs(td[cur_ts] - td[ts_used]) < F32(diff_travel_dist_local)
+        else:
+            tm = np.abs(int(cur_ts) - ts_used.astype(np.int64)) < int(diff_ts_local)
         if reboot_ts is not None:
             tm &= ts_used >= reboot_ts
         if tm.sum() < 100:
             tm = np.ones(P, bool)
     else:
         tm = np.ones(P, bool)
-    d = (positions - np.asarray(sensor_position, F32)).astype(F32) ** 2
-    dist2 = ((d[:, 0] + d[:, 1]).astype(F32) + d[:, 2]).astype(F32)
-    mask = tm & (dist2 < F32(radius ** 2))
+    sp = np.asarray(sensor_position)
+    if sp.dtype == np.float64:
+        d = (np.asarray(positions, np.float64) - sp) ** 2
+        near = ((d[:, 0] + d[:, 1]) + d[:, 2]) < float(radius) ** 2
+    else:
+        d = (positions - np.asarray(sensor_position, F32)).astype(F32) ** 2
+        dist2 = ((d[:, 0] + d[:, 1]).astype(F32) + d[:, 2]).astype(F32)
+        near = dist2 < F32(radius ** 2)
+    mask = tm & near
     g2l = np.full(P + 1, 1, np.int64)
     g2l[:P][mask] = np.arange(int(mask.sum()))
     g2l[P] = -1
@@ -868,9 +886,10 @@ def quat_multiply(q1, q2):
                      w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1).astype(F32)
 
 
-def adjust_map(positions, orientations, ts_create, pose_diff):
-    """NeuralPoints.adjust_map (neural_points.py:791-817): per-point SE(3) by creation frame."""
-    used = np.asarray(ts_create, np.int64)
+def adjust_map(positions, orientations, ts_create, pose_diff, ts_update=None):
+    """NeuralPoints.adjust_map (neural_points.py:791-817): per-point SE(3) by creation frame (ts_update given:
+    config.use_mid_ts, by the mid timestamp)."""
+    used = np.asarray(ts_create, np.int64) if ts_update is None else mid_ts(ts_create, ts_update).astype(np.int64)
     pd = np.asarray(pose_diff)
     pos = transform_batch(positions, pd[used])
     dq = rotmat_to_quat(pd[:, :3, :3].astype(F32))
@@ -896,10 +915,12 @@ def voxel_down_sample_min_value(points, voxel_size, value):
     return out % off
 
 
-def recreate_hash(positions, ts_create, cur_ts, resolution, buffer_size, certainties=None, with_ts=True):
-    """NeuralPoints.recreate_hash(kept_points=True) (neural_points.py:819-870): the rebuilt table."""
+def recreate_hash(positions, ts_create, cur_ts, resolution, buffer_size, certainties=None, with_ts=True, ts_update=None):
+    """NeuralPoints.recreate_hash(kept_points=True) (neural_points.py:819-870): the rebuilt table (ts_update given:
+    config.use_mid_ts)."""
     if with_ts:
-        value = np.abs(np.asarray(ts_create, np.int64) - cur_ts).astype(F32)
+        ts = np.asarray(ts_create, np.int64) if ts_update is None else mid_ts(ts_create, ts_update).astype(np.int64)
+        value = np.abs(ts - cur_ts).astype(F32)
     else:
         c = np.asarray(certainties, F32)
         value = (c.max() - c).astype(F32)
@@ -907,6 +928,19 @@ def recreate_hash(positions, ts_create, cur_ts, resolution, buffer_size, certain
     table = np.full(buffer_size, -1, np.int64)
     table[hash_slots(grid_coords(np.asarray(positions, F32)[sel], resolution), buffer_size)] = sel
     return table, sel
+
+
+def merge_map(arrays, cur_ts, resolution, buffer_size, with_ts=False):
+    """NeuralPoints.recreate_hash(kept_points=False) (neural_points.py:872-898): the map merged down to one point per
+    voxel.  arrays = dict(positions, orientations, ts_create, ts_update, certainties, geo_features [P+1, F]); returns
+    (merged dict in the same keys, table over the NEW indices)."""
+    _, sel = recreate_hash(arrays["positions"], arrays["ts_create"], cur_ts, resolution, buffer_size,
+                           certainties=arrays["certainties"], with_ts=with_ts)
+    out = {k: np.asarray(arrays[k])[sel] for k in ("positions", "orientations", "ts_create", "ts_update", "certainties")}
+    out["geo_features"] = np.asarray(arrays["geo_features"])[np.concatenate([sel, [-1]])]
+    table = np.full(buffer_size, -1, np.int64)
+    table[hash_slots(grid_coords(out["positions"], resolution), buffer_size)] = np.arange(len(sel))
+    return out, table
 
 
 def prune_mask(certainties, ts_update, travel_dist, cur_ts, diff_travel_dist_local, thre, global_prune=False):

@@ -95,8 +95,19 @@ class UpdateParams(C.Structure):
 class LocalParams(C.Structure):
     _fields_ = [
         ("travel_dist", vp), ("n_points", C.c_int32), ("cur_ts", C.c_int32), ("reboot_ts", C.c_int32),
-        ("diff_travel_dist_local", C.c_float), ("sensor", C.c_float * 3), ("radius2", C.c_float),
+        ("diff_travel_dist_local", C.c_float), ("time_mode", C.c_int32), ("diff_ts_local", C.c_int32),
+        ("use_mid_ts", C.c_int32), ("sensor_f64", C.c_int32), ("sensor", C.c_double * 3), ("radius2", C.c_double),
     ]
+
+
+class RehashParams(C.Structure):
+    _fields_ = [("buffer_size", C.c_int64), ("n_points", C.c_int32), ("cur_ts", C.c_int32), ("with_ts", C.c_int32),
+                ("use_mid_ts", C.c_int32), ("resolution", C.c_float)]
+
+
+class PruneParams(C.Structure):
+    _fields_ = [("travel_dist", vp), ("n_points", C.c_int32), ("cur_ts", C.c_int32), ("global_prune", C.c_int32),
+                ("certainty_thre", C.c_float), ("diff_travel_dist_local", C.c_float)]
 
 
 class TrainParams(C.Structure):
@@ -185,6 +196,8 @@ SIGNATURES = {
     "pin_deskew": (i32, [vp, i32, i32, vp, vp, f64, vp, i64, vp]),
     "pin_transform_by_frame": (i32, [vp, i32, vp, vp, i32, vp, vp, vp]),
     "pin_gather_rows": (i32, [vp, i32, vp, i32, vp, vp]),
+    "pin_hash_rebuild": (i32, [P(MapArrays), P(MapArrays), P(RehashParams), vp, vp, vp, i64, vp]),
+    "pin_prune_map": (i32, [P(MapArrays), P(MapArrays), P(PruneParams), vp, vp, i64, vp]),
     "pin_comm_load": (i32, [C.c_char_p]),
     "pin_comm_unique_id": (i32, [vp]),
     "pin_comm_init_rank": (i32, [vp, i32, i32, P(vp)]),

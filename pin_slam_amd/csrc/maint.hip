@@ -18,8 +18,9 @@ namespace pin {
 struct VdsStats {
     unsigned int minx, miny, minz;  // order-preserving encodings of float minima
     int gmax;                       // max voxel coordinate (all axes) after the offset
-    unsigned int dmax;              // bits of the max centre distance (>= 0)
+    unsigned int dmax;              // bits of the max centre distance / max rehash value (>= 0)
     int nseg;
+    unsigned int nseg_cmax;         // recreate_hash: order-preserving encoding of max(certainty)
 };
 
 __device__ __forceinline__ unsigned int enc_f(float f) {
@@ -32,7 +33,7 @@ __device__ __forceinline__ float dec_f(unsigned int e) {
 
 __global__ void vds_init_kernel(VdsStats* st) {
     st->minx = st->miny = st->minz = 0xffffffffu;
-    st->gmax = 0; st->dmax = 0u; st->nseg = 0;
+    st->gmax = 0; st->dmax = 0u; st->nseg = 0; st->nseg_cmax = 0u;
 }
 
 // Reductions to a handful of global words: same-address atomics serialise (~10 ns each), so every BLOCK
@@ -218,15 +219,27 @@ __global__ __launch_bounds__(MB) void update_append_kernel(pin_map_arrays ma, pi
 }
 
 // ---- K9: reset_local_map ------------------------------------------------------------------------
+// the timestamp reset_local_map / adjust_map / recreate_hash associate with a point (neural_points.py:443-447):
+// ((ts_create + ts_update) / 2).int() = true division in float32, truncated; exact as (a + b) >> 1 for frame ids
+__device__ __forceinline__ int point_ts_used(const pin_map_arrays& ma, int i, int use_mid_ts) {
+    const int tc = ma.ts_create[i];
+    return use_mid_ts ? ((tc + ma.ts_update[i]) >> 1) : tc;
+}
+
+// time mask of reset_local_map (neural_points.py:449-466)
+__device__ __forceinline__ bool local_time_mask(const pin_local_params& lp, int ts) {
+    bool t;
+    if (lp.time_mode == 1) t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
+    else t = abs(lp.cur_ts - ts) < lp.diff_ts_local;
+    if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
+    return t;
+}
+
 __global__ __launch_bounds__(MB) void local_time_count_kernel(pin_map_arrays ma, pin_local_params lp, int* __restrict__ cnt) {
     __shared__ int red[MB / 64];
     int c = 0;
-    for (int i = blockIdx.x * MB + threadIdx.x; i < lp.n_points; i += gridDim.x * MB) {
-        const int ts = ma.ts_create[i];
-        bool t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
-        if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
-        c += t ? 1 : 0;
-    }
+    for (int i = blockIdx.x * MB + threadIdx.x; i < lp.n_points; i += gridDim.x * MB)
+        c += local_time_mask(lp, point_ts_used(ma, i, lp.use_mid_ts)) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -242,18 +255,23 @@ __global__ __launch_bounds__(MB) void local_time_count_kernel(pin_map_arrays ma,
 __global__ __launch_bounds__(MB) void local_flags_kernel(pin_map_arrays ma, pin_local_params lp,
                                                          const int* __restrict__ time_cnt,
                                                          unsigned char* __restrict__ flags) {
+#pragma clang fp contract(off)
     const int i = blockIdx.x * MB + threadIdx.x;
     if (i > lp.n_points) return;
     if (i == lp.n_points) { flags[i] = 1; return; }  // padding entry (neural_points.py:492-494)
     bool t = true;
-    if (lp.travel_dist != nullptr && *time_cnt >= 100) {  // < 100 points in the window -> all true (:468)
-        const int ts = ma.ts_create[i];
-        t = fabsf(lp.travel_dist[lp.cur_ts] - lp.travel_dist[ts]) < lp.diff_travel_dist_local;
-        if (lp.reboot_ts >= 0) t = t && ts >= lp.reboot_ts;
-    }
+    if (lp.time_mode != 0 && *time_cnt >= 100)  // < 100 points in the window -> all true (:468)
+        t = local_time_mask(lp, point_ts_used(ma, i, lp.use_mid_ts));
     const float* P = ma.pos + 3 * (size_t)i;
-    const float d2 = dist2_exact(P[0] - lp.sensor[0], P[1] - lp.sensor[1], P[2] - lp.sensor[2]);
-    flags[i] = (t && d2 < lp.radius2) ? 1 : 0;
+    bool near;
+    if (lp.sensor_f64) {  // float32 points - float64 sensor position promotes: the test runs in float64 (:476-479)
+        const double dx = (double)P[0] - lp.sensor[0], dy = (double)P[1] - lp.sensor[1], dz = (double)P[2] - lp.sensor[2];
+        near = ((dx * dx + dy * dy) + dz * dz) < lp.radius2;
+    } else {
+        near = dist2_exact(P[0] - (float)lp.sensor[0], P[1] - (float)lp.sensor[1], P[2] - (float)lp.sensor[2]) <
+               (float)lp.radius2;
+    }
+    flags[i] = (t && near) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(MB) void local_scatter_kernel(pin_map_arrays ma, pin_local_arrays la, pin_local_params lp,
@@ -313,6 +331,154 @@ __global__ __launch_bounds__(MB) void assign_local_kernel(pin_map_arrays ma, pin
         ma.ts_update[i] = la.ts_update[l];
     }
 }
+
+// ---- recreate_hash / prune_map (neural_points.py:748-789, 819-908; utils/tools.py:629-668) -------------------
+// value of voxel_down_sample_min_value_torch: |ts - cur_ts| as float (:843-851) or max(certainty) - certainty
+// (:853-858); its maximum goes to st->dmax (values are >= 0: their bit patterns order like the floats)
+__global__ __launch_bounds__(MB) void rh_cmax_kernel(const float* __restrict__ cert, int n, VdsStats* st) {
+    __shared__ unsigned int red[MB / 64];
+    unsigned int m = 0u;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) m = max(m, enc_f(cert[i]));
+    m = block_reduce_u32<false>(m, red);
+    if (threadIdx.x == 0) atomicMax(&st->nseg_cmax, m);
+}
+
+__global__ __launch_bounds__(MB) void rh_value_kernel(pin_map_arrays ma, pin_rehash_params rp, VdsStats* st,
+                                                      float* __restrict__ value) {
+#pragma clang fp contract(off)
+    __shared__ unsigned int red[MB / 64];
+    unsigned int vm = 0u;
+    const float cmax = rp.with_ts ? 0.f : dec_f(st->nseg_cmax);
+    for (int i = blockIdx.x * MB + threadIdx.x; i < rp.n_points; i += gridDim.x * MB) {
+        const float v = rp.with_ts ? (float)abs(point_ts_used(ma, i, rp.use_mid_ts) - rp.cur_ts) : cmax - ma.certainty[i];
+        value[i] = v;
+        vm = max(vm, __float_as_uint(fmaxf(v, 0.f)));
+    }
+    vm = block_reduce_u32<false>(vm, red);
+    if (threadIdx.x == 0) atomicMax(&st->dmax, vm);
+}
+
+__device__ __forceinline__ void rh_grid(const float* __restrict__ p, int i, float vs, const VdsStats* st, long long (&g)[3]) {
+#pragma clang fp contract(off)
+    const unsigned int mn[3] = {st->minx, st->miny, st->minz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        g[a] = (long long)floorf(__fdiv_rn(p[3 * i + a], vs)) - (long long)floorf(__fdiv_rn(dec_f(mn[a]), vs));
+}
+
+__global__ __launch_bounds__(MB) void rh_gmax_kernel(const float* __restrict__ p, int n, float vs, VdsStats* st) {
+    __shared__ unsigned int red[MB / 64];
+    int gm = 0;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) {
+        long long g[3];
+        rh_grid(p, i, vs, st, g);
+        gm = max(gm, (int)max(g[0], max(g[1], g[2])));
+    }
+    gm = (int)block_reduce_u32<false>((unsigned int)gm, red);
+    if (threadIdx.x == 0) atomicMax(&st->gmax, gm);
+}
+
+// voxel id with the reference's stride (v = grid.max(), NOT max + 1: distinct voxels can share an id, tools.py:645-647)
+// and the (quantised value, index) key whose per-voxel minimum picks the sample (:655-660)
+__global__ __launch_bounds__(MB) void rh_keys_kernel(const float* __restrict__ p, int n, float vs, const VdsStats* st,
+                                                     const float* __restrict__ value, long long off10,
+                                                     unsigned long long* __restrict__ keys,
+                                                     unsigned long long* __restrict__ vals) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    long long g[3];
+    rh_grid(p, i, vs, st, g);
+    const long long v = st->gmax;
+    keys[i] = (unsigned long long)(g[0] + g[1] * v + g[2] * v * v);
+    const float vmax = __uint_as_float(st->dmax);
+    // value / value.max() * 999 -> .long(); all-zero values give NaN there, whose conversion (INT64_MIN on the CPU
+    // reference) times the even decimal offset wraps to 0: the index alone decides
+    const long long q = vmax > 0.f ? (long long)(__fdiv_rn(value[i], vmax) * 999.0f) : 0;
+    vals[i] = (unsigned long long)((long long)i + q * off10);
+}
+
+// buffer_pt_index[hash] = idx (neural_points.py:866 / :895) over the selected points in order: the last writer of a
+// slot stays (claim with atomicMin(-(r + 2)), the winner publishes -- as update_claim_kernel)
+__global__ __launch_bounds__(MB) void rh_claim_kernel(int* __restrict__ table, const float* __restrict__ pos,
+                                                      const int* __restrict__ sel, const int* __restrict__ n_sel,
+                                                      float res, long long B, unsigned int* __restrict__ slots) {
+    const int r = blockIdx.x * MB + threadIdx.x;
+    if (r >= *n_sel) return;
+    const int i = sel ? sel[r] : r;
+    const unsigned int slot = hash_base(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], res, B);
+    slots[r] = slot;
+    atomicMin(table + slot, -(r + 2));
+}
+
+__global__ __launch_bounds__(MB) void rh_publish_kernel(int* __restrict__ table, const int* __restrict__ sel,
+                                                        const int* __restrict__ n_sel,
+                                                        const unsigned int* __restrict__ slots) {
+    const int r = blockIdx.x * MB + threadIdx.x;
+    if (r >= *n_sel) return;
+    if (table[slots[r]] == -(r + 2)) table[slots[r]] = sel ? sel[r] : r;
+}
+
+__device__ __forceinline__ void copy_map_row(const pin_map_arrays& src, const pin_map_arrays& dst, int i, int j) {
+    const float x = src.pos[3 * (size_t)i], y = src.pos[3 * (size_t)i + 1], z = src.pos[3 * (size_t)i + 2];
+    dst.pos[3 * (size_t)j] = x; dst.pos[3 * (size_t)j + 1] = y; dst.pos[3 * (size_t)j + 2] = z;
+    const int tc = src.ts_create[i];
+    reinterpret_cast<float4*>(dst.pos4)[j] = make_float4(x, y, z, __int_as_float(tc));
+    reinterpret_cast<float4*>(dst.orient)[j] = reinterpret_cast<const float4*>(src.orient)[i];
+    dst.ts_create[j] = tc;
+    dst.ts_update[j] = src.ts_update[i];
+    dst.certainty[j] = src.certainty[i];
+}
+__device__ __forceinline__ void copy_feature_row(const pin_map_arrays& src, const pin_map_arrays& dst, int i, int j) {
+    const float4* s = reinterpret_cast<const float4*>(src.geo + (size_t)i * PIN_FEATURE_DIM);
+    float4* d = reinterpret_cast<float4*>(dst.geo + (size_t)j * PIN_FEATURE_DIM);
+    d[0] = s[0]; d[1] = s[1];
+    if (src.color && dst.color) {
+        const float4* sc = reinterpret_cast<const float4*>(src.color + (size_t)i * PIN_FEATURE_DIM);
+        float4* dc = reinterpret_cast<float4*>(dst.color + (size_t)j * PIN_FEATURE_DIM);
+        dc[0] = sc[0]; dc[1] = sc[1];
+    }
+}
+
+// the merge of recreate_hash(kept_points=False) (neural_points.py:872-890): row r of dst = row sel[r] of src,
+// the feature tables keep their padding row (sample_idx_pad ends in -1 = the last row)
+__global__ __launch_bounds__(MB) void rh_gather_kernel(pin_map_arrays src, pin_map_arrays dst, const int* __restrict__ sel,
+                                                       const int* __restrict__ n_sel, int n_old) {
+    const int r = blockIdx.x * MB + threadIdx.x;
+    const int n = *n_sel;
+    if (r > n) return;
+    if (r == n) { copy_feature_row(src, dst, n_old, n); return; }
+    const int i = sel[r];
+    copy_map_row(src, dst, i, r);
+    copy_feature_row(src, dst, i, r);
+}
+
+// prune_map (neural_points.py:757-768): flag = KEPT
+__global__ __launch_bounds__(MB) void prune_flags_kernel(pin_map_arrays ma, pin_prune_params pp,
+                                                         unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i > pp.n_points) return;
+    if (i == pp.n_points) { flags[i] = 1; return; }  // the feature padding row is always kept (:779-781)
+    bool prune = ma.certainty[i] < pp.certainty_thre;
+    if (!pp.global_prune)
+        prune = prune && fabsf(pp.travel_dist[pp.cur_ts] - pp.travel_dist[ma.ts_update[i]]) > pp.diff_travel_dist_local;
+    flags[i] = prune ? 0 : 1;
+}
+
+__global__ __launch_bounds__(MB) void prune_compact_kernel(pin_map_arrays src, pin_map_arrays dst, int n_points,
+                                                           const unsigned char* __restrict__ flags,
+                                                           const int* __restrict__ block_off) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    const bool f = i <= n_points && flags[i] != 0;
+    const int ex = block_flag_scan(f, total);
+    if (!f) return;
+    const int j = block_off[blockIdx.x] + ex;
+    if (i < n_points) copy_map_row(src, dst, i, j);
+    copy_feature_row(src, dst, i, j);
+}
+
+__global__ void dec_count_kernel(int* c) { *c -= 1; }
 
 static size_t sort_temp_bytes(int n) {
     size_t bytes = 0;
@@ -407,7 +573,8 @@ extern "C" int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arr
     int* time_cnt = c.take<int>(1);
     PIN_CHECK_ARG(time_cnt != nullptr, "workspace carve failed");
     PIN_CHECK_HIP(hipMemsetAsync(time_cnt, 0, sizeof(int), s));
-    if (lp->travel_dist != nullptr)
+    PIN_CHECK_ARG(lp->time_mode >= 0 && lp->time_mode <= 2 && (lp->time_mode != 1 || lp->travel_dist), "bad time_mode");
+    if (lp->time_mode != 0)
         hipLaunchKernelGGL(local_time_count_kernel, dim3(min(nb, REDUCE_BLOCKS)), dim3(MB), 0, s, *ma, *lp, time_cnt);
     hipLaunchKernelGGL(local_flags_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt, local_mask_out);
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, local_mask_out, n1, block_off);
@@ -423,6 +590,91 @@ extern "C" int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_lo
     PIN_CHECK_ARG(ma && la && n_points >= 0 && n_local >= 0, "bad arguments");
     hipLaunchKernelGGL(assign_local_kernel, dim3(cdiv(n_points + 1, MB)), dim3(MB), 0, as_stream(stream), *ma, *la,
                        n_points, n_local);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_hash_rebuild(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_rehash_params* rp,
+                                int32_t* sel_out, int32_t* count_out, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(src && rp && sel_out && count_out && workspace, "NULL pointer");
+    const int n = rp->n_points;
+    PIN_CHECK_ARG(n > 0 && rp->buffer_size > 0, "empty map");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n) + (int64_t)n * 4, "workspace too small");
+    PIN_CHECK_ARG(src->table && src->pos && src->ts_create && src->ts_update && src->certainty, "NULL map array");
+    PIN_CHECK_ARG(!dst || (dst->pos && dst->pos4 && dst->orient && dst->geo && dst->ts_create && dst->ts_update &&
+                           dst->certainty && dst->table == src->table && src->orient && src->geo), "bad merge destination");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    VdsStats* st = c.take<VdsStats>(1);
+    unsigned long long* keys = c.take<unsigned long long>(n);
+    unsigned long long* vals = c.take<unsigned long long>(n);
+    unsigned long long* keys2 = c.take<unsigned long long>(n);
+    unsigned long long* vals2 = c.take<unsigned long long>(n);
+    unsigned long long* segmin = c.take<unsigned long long>(n);
+    unsigned char* flags = c.take<unsigned char>(n + 1);
+    const int nb = cdiv(n, MB), rb = min(nb, REDUCE_BLOCKS);
+    int* block_off = c.take<int>(nb + 1);
+    size_t tb = sort_temp_bytes(n);
+    void* temp = c.take<char>(tb);
+    float* value = c.take<float>(n);
+    PIN_CHECK_ARG(value != nullptr, "workspace carve failed");
+    unsigned int* slots = reinterpret_cast<unsigned int*>(keys);  // (the sort keys are dead by then)
+    long long off10 = 1;  // 10 ** len(str(n - 1))  (utils/tools.py:653)
+    for (long long v = n - 1; ; v /= 10) { off10 *= 10; if (v < 10) break; }
+    // voxel_down_sample_min_value_torch
+    hipLaunchKernelGGL(vds_init_kernel, dim3(1), dim3(1), 0, s, st);
+    if (!rp->with_ts) hipLaunchKernelGGL(rh_cmax_kernel, dim3(rb), dim3(MB), 0, s, src->certainty, n, st);
+    hipLaunchKernelGGL(rh_value_kernel, dim3(rb), dim3(MB), 0, s, *src, *rp, st, value);
+    hipLaunchKernelGGL(vds_min_kernel, dim3(rb), dim3(MB), 0, s, src->pos, n, st);
+    hipLaunchKernelGGL(rh_gmax_kernel, dim3(rb), dim3(MB), 0, s, src->pos, n, rp->resolution, st);
+    hipLaunchKernelGGL(rh_keys_kernel, dim3(nb), dim3(MB), 0, s, src->pos, n, rp->resolution, st, value, off10, keys, vals);
+    PIN_CHECK_LAUNCH();
+    PIN_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (size_t)n, 0, 64, s));
+    hipLaunchKernelGGL(vds_heads_kernel, dim3(nb), dim3(MB), 0, s, keys2, n, flags);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, n, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, count_out);
+    PIN_CHECK_HIP(hipMemsetAsync(segmin, 0xff, (size_t)n * 8, s));
+    hipLaunchKernelGGL(vds_segmin_kernel, dim3(nb), dim3(MB), 0, s, flags, block_off, vals2, n, segmin);
+    hipLaunchKernelGGL(vds_final_kernel, dim3(nb), dim3(MB), 0, s, segmin, count_out, off10, sel_out);
+    // the table
+    PIN_CHECK_HIP(hipMemsetAsync(src->table, 0xff, (size_t)rp->buffer_size * sizeof(int32_t), s));
+    const float* pos = src->pos;
+    const int* sel = sel_out;
+    if (dst) {  // merge: gather the kept rows, then index the NEW rows
+        hipLaunchKernelGGL(rh_gather_kernel, dim3(cdiv(n + 1, MB)), dim3(MB), 0, s, *src, *dst, sel_out, count_out, n);
+        pos = dst->pos;
+        sel = nullptr;
+    }
+    hipLaunchKernelGGL(rh_claim_kernel, dim3(nb), dim3(MB), 0, s, src->table, pos, sel, count_out, rp->resolution,
+                       (long long)rp->buffer_size, slots);
+    hipLaunchKernelGGL(rh_publish_kernel, dim3(nb), dim3(MB), 0, s, src->table, sel, count_out, slots);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_prune_params* pp,
+                             int32_t* n_keep_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(src && dst && pp && n_keep_out && workspace, "NULL pointer");
+    const int n = pp->n_points;
+    PIN_CHECK_ARG(n > 0, "empty map");
+    PIN_CHECK_ARG(pp->global_prune || pp->travel_dist, "travel_dist NULL");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
+    PIN_CHECK_ARG(src->pos && src->orient && src->geo && src->ts_create && src->ts_update && src->certainty && dst->pos &&
+                  dst->pos4 && dst->orient && dst->geo && dst->ts_create && dst->ts_update && dst->certainty, "NULL map array");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    const int n1 = n + 1, nb = cdiv(n1, MB);
+    unsigned char* flags = c.take<unsigned char>(n1);
+    int* block_off = c.take<int>(nb + 1);
+    PIN_CHECK_ARG(block_off != nullptr, "workspace carve failed");
+    hipLaunchKernelGGL(prune_flags_kernel, dim3(nb), dim3(MB), 0, s, *src, *pp, flags);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, n1, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_keep_out);
+    hipLaunchKernelGGL(prune_compact_kernel, dim3(nb), dim3(MB), 0, s, *src, *dst, n, flags, block_off);
+    hipLaunchKernelGGL(dec_count_kernel, dim3(1), dim3(1), 0, s, n_keep_out);  // the padding entry was counted
     PIN_CHECK_LAUNCH();
     return 0;
 }

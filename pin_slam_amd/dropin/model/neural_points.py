@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib, ops
-from ..._lib import PIN_NONLOCAL, LocalArrays, LocalParams, MapArrays, UpdateParams, check
+from ..._lib import PIN_NONLOCAL, LocalArrays, LocalParams, MapArrays, PruneParams, RehashParams, UpdateParams, check
 
 
 def _p(t):
@@ -84,14 +84,18 @@ class NeuralPoints(nn.Module):
         self.set_search_neighborhood(num_nei_cells=config.num_nei_cells, search_alpha=config.search_alpha)
 
     # ------------------------------------------------------------------ storage
-    def _alloc(self, cap):
+    def _new_arrays(self, cap):
         dev, f32, i32 = self.device, torch.float32, torch.int32
-        new = dict(pos=torch.empty((cap, 3), dtype=f32, device=dev), pos4=torch.empty((cap, 4), dtype=f32, device=dev),
-                   orient=torch.empty((cap, 4), dtype=f32, device=dev),
-                   geo=torch.zeros((cap + 1, 8), dtype=f32, device=dev),
-                   color=torch.zeros((cap + 1, 8), dtype=f32, device=dev) if self.color_on else None,
-                   ts_create=torch.empty((cap,), dtype=i32, device=dev), ts_update=torch.empty((cap,), dtype=i32, device=dev),
-                   cert=torch.empty((cap,), dtype=f32, device=dev))
+        return dict(pos=torch.empty((cap, 3), dtype=f32, device=dev), pos4=torch.empty((cap, 4), dtype=f32, device=dev),
+                    orient=torch.empty((cap, 4), dtype=f32, device=dev),
+                    geo=torch.zeros((cap + 1, 8), dtype=f32, device=dev),
+                    color=torch.zeros((cap + 1, 8), dtype=f32, device=dev) if self.color_on else None,
+                    ts_create=torch.empty((cap,), dtype=i32, device=dev), ts_update=torch.empty((cap,), dtype=i32, device=dev),
+                    cert=torch.empty((cap,), dtype=f32, device=dev))
+
+    def _alloc(self, cap):
+        new = self._new_arrays(cap)
+        self._spare = None
         if self._cap:
             n = self._n
             for k, t in new.items():
@@ -116,8 +120,15 @@ class NeuralPoints(nn.Module):
             self._ws = torch.empty((int(need * 1.25),), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def _map_arrays(self) -> MapArrays:
-        g, ma = self._g, MapArrays()
+    def _spare_arrays(self):
+        """A second set of map arrays of the current capacity: destination of the out-of-place compactions
+        (prune_map, the merge of recreate_hash); the two sets swap roles when a result is adopted."""
+        if getattr(self, "_spare", None) is None or self._spare["pos"].shape[0] != self._cap:
+            self._spare = self._new_arrays(self._cap)
+        return self._spare
+
+    def _map_arrays(self, g=None) -> MapArrays:
+        g, ma = (self._g if g is None else g), MapArrays()
         ma.table, ma.pos, ma.pos4, ma.orient = _p(self._table), _p(g["pos"]), _p(g["pos4"]), _p(g["orient"])
         ma.geo, ma.color = _p(g["geo"]), _p(g["color"])
         ma.ts_create, ma.ts_update, ma.certainty = _p(g["ts_create"]), _p(g["ts_update"]), _p(g["cert"])
@@ -223,6 +234,7 @@ class NeuralPoints(nn.Module):
     # ------------------------------------------------------------------ K8: update
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
         L = _lib.lib()
+        self._wait_bricks()
         points = points.to(device=self.device, dtype=torch.float32).contiguous()
         n = points.shape[0]
         ws = self._workspace(max(n, self._n + 1))
@@ -257,10 +269,7 @@ class NeuralPoints(nn.Module):
     # ------------------------------------------------------------------ K9: reset_local_map
     def reset_local_map(self, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int,
                         use_travel_dist: bool = True, diff_ts_local: int = 50, reboot_map: bool = False):
-        if not use_travel_dist:
-            raise NotImplementedError("reset_local_map(use_travel_dist=False) is unused by the reference")
-        if self.config.use_mid_ts:
-            raise NotImplementedError("use_mid_ts=True (config.py:97 default False)")
+        self._wait_bricks()
         self.cur_ts = cur_ts
         self.max_ts = max(self.max_ts, cur_ts)
         n = self._n
@@ -270,14 +279,26 @@ class NeuralPoints(nn.Module):
             self._g2l = torch.empty((int((n + 1) * 1.5),), dtype=torch.int32, device=self.device)
             self._local_mask = torch.empty((int((n + 1) * 1.5),), dtype=torch.uint8, device=self.device)
         lp = LocalParams()
-        temporal = self.temporal_local_map_on and self.travel_dist is not None
-        lp.travel_dist = _p(self._travel()) if temporal else None
+        # time mask (neural_points.py:442-472): travel-distance window, or a window of frames when the caller says so
+        # (pin_slam.py:287 passes config.loop_local_map_by_travel_dist, False by default, for the loop-closure context)
+        lp.time_mode = 0
+        if self.temporal_local_map_on:
+            if use_travel_dist:
+                if self.travel_dist is not None:  # (pin_slam.py:273 sets it every frame before any map call)
+                    lp.time_mode, lp.travel_dist = 1, _p(self._travel())
+            else:
+                lp.time_mode, lp.diff_ts_local = 2, int(diff_ts_local)
+        lp.use_mid_ts = int(bool(self.config.use_mid_ts))
         lp.n_points, lp.cur_ts = n, int(cur_ts)
         lp.reboot_ts = int(self.reboot_ts) if reboot_map else -1
         lp.diff_travel_dist_local = float(self.diff_travel_dist_local)
-        sp = sensor_position.detach().to("cpu", torch.float32).numpy()
-        lp.sensor[0], lp.sensor[1], lp.sensor[2] = float(sp[0]), float(sp[1]), float(sp[2])
-        lp.radius2 = float(np.float32(self.local_map_radius ** 2))
+        # `neural_points - sensor_position` promotes to the dtype of the position the caller hands in (float64 for
+        # dataset.cur_pose_torch, float32 after a pose-graph update): the radius test runs in that type (:476-479)
+        sp = sensor_position.detach().to("cpu")
+        lp.sensor_f64 = int(sp.dtype == torch.float64)
+        spn = sp.to(torch.float64).numpy()
+        lp.sensor[0], lp.sensor[1], lp.sensor[2] = float(spn[0]), float(spn[1]), float(spn[2])
+        lp.radius2 = float(self.local_map_radius ** 2)
         ws = self._workspace(n + 1)
         ma, la = self._map_arrays(), self._local_arrays()
         check(_lib.lib().pin_reset_local_map(C.byref(ma), C.byref(la), C.byref(lp), _p(self._local_mask),
@@ -313,6 +334,13 @@ class NeuralPoints(nn.Module):
         with torch.cuda.stream(side):
             self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
             self._bricks_event = side.record_event()
+
+    def _wait_bricks(self):
+        """Order the caller's stream behind a brick build that may still be reading the map arrays on the side stream
+        (before anything rewrites the table / positions / global2local)."""
+        ev = getattr(self, "_bricks_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _use_bricks(self):
         """The current brick cache (or None), with the caller's stream ordered behind its build."""
@@ -393,62 +421,83 @@ class NeuralPoints(nn.Module):
 
     # ------------------------------------------------------------------ post-loop maintenance (next-tier rows)
     def _rebuild_mirror(self):
+        self._wait_bricks()
         ops.pack_positions(self._g["pos"], self._g["ts_create"], self._g["pos4"], 0, self._n)
 
     def prune_map(self, prune_certainty_thre, min_prune_count=500, global_prune=False):
-        """neural_points.py:748-789 (host-side torch, not a hot-path kernel)."""
-        certainty_mask = self.point_certainties < prune_certainty_thre
-        if global_prune:
-            prune_mask = certainty_mask
-        else:
-            td = self._travel()
-            diff = torch.abs(td[self.cur_ts] - td[self.point_ts_update.long()])
-            prune_mask = (diff > self.diff_travel_dist_local) & certainty_mask
-        if int(prune_mask.sum().item()) <= min_prune_count:
+        """neural_points.py:748-789 on the device (pin_prune_map: flags + ordered compaction into the spare arrays);
+        the one read-back is the count the reference reads as well (`.item()`, :770)."""
+        n = self._n
+        if n == 0:
             return False
-        keep = ~prune_mask
-        n_new = int(keep.sum().item())
-        g = self._g
-        for k in ("pos", "orient", "ts_create", "ts_update", "cert"):
-            g[k][:n_new] = g[k][:self._n][keep]
-        keep1 = torch.cat((keep, torch.ones(1, dtype=torch.bool, device=self.device)))
-        g["geo"][:n_new + 1] = g["geo"][:self._n + 1][keep1]
-        if self.color_on:
-            g["color"][:n_new + 1] = g["color"][:self._n + 1][keep1]
-        self._n = n_new
-        self._rebuild_mirror()
+        self._wait_bricks()
+        pp = PruneParams()
+        pp.travel_dist = None if global_prune else _p(self._travel())
+        pp.n_points, pp.cur_ts, pp.global_prune = n, int(self.cur_ts), int(bool(global_prune))
+        pp.certainty_thre, pp.diff_travel_dist_local = float(prune_certainty_thre), float(self.diff_travel_dist_local)
+        dst = self._spare_arrays()
+        ws = self._workspace(n + 1)
+        src_a, dst_a = self._map_arrays(), self._map_arrays(dst)
+        check(_lib.lib().pin_prune_map(C.byref(src_a), C.byref(dst_a), C.byref(pp), _p(self._cnt[3:4]), _p(ws), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream), "pin_prune_map")
+        n_keep = int(self._cnt[3].item())
+        if n - n_keep <= min_prune_count:
+            return False
+        if not self.silence:
+            print("# Prune neural points: ", n - n_keep)
+        self._g, self._spare = dst, self._g  # the compacted set becomes the map (recreate the hash next, as the reference says)
+        self._n = n_keep
         return True
 
     def adjust_map(self, pose_diff_torch):
         """neural_points.py:791-817: per-point SE(3) by creation frame + orientation update, one kernel."""
-        if self.config.use_mid_ts:
-            raise NotImplementedError("use_mid_ts")
         self.after_pgo = True
         from ..quat import rotmat_to_quat
+        self._wait_bricks()
         pd = pose_diff_torch.detach().to(device=self.device)
         dq = rotmat_to_quat(pd[:, :3, :3].to(torch.float32)).contiguous()
-        ops.transform_by_frame(self._g["pos"][:self._n], self._g["ts_create"][:self._n], pd, quat=self._g["orient"][:self._n],
-                               dquat=dq)
+        used_ts = self._g["ts_create"][:self._n]
+        if self.config.use_mid_ts:  # ((ts_create + ts_update) / 2).int()  (neural_points.py:803-806; once per loop closure)
+            used_ts = torch.div(used_ts + self._g["ts_update"][:self._n], 2, rounding_mode="floor").to(torch.int32)
+        ops.transform_by_frame(self._g["pos"][:self._n], used_ts, pd, quat=self._g["orient"][:self._n], dquat=dq)
         self._rebuild_mirror()
 
     def recreate_hash(self, sensor_position, sensor_orientation, kept_points: bool = True, with_ts: bool = True, cur_ts=0):
-        """neural_points.py:819-908, kept_points=True path: rebuild the table from all points
-        (voxel winner = smallest |ts - cur_ts| or largest certainty).  Host-side torch, next-tier."""
-        if not kept_points:
-            raise NotImplementedError("recreate_hash(kept_points=False) (merge) is not on the SLAM path")
-        self._table.fill_(-1)
-        value = (torch.abs(self.point_ts_create - cur_ts).float() if with_ts
-                 else self.point_certainties.max() - self.point_certainties)
-        from ..voxel import voxel_down_sample_min_value
-        sample_idx = voxel_down_sample_min_value(self.neural_points, self.resolution, value)
-        sp = self.neural_points[sample_idx]
-        grid = torch.floor(sp / np.float32(self.resolution)).long()
-        primes = torch.tensor(ops.PRIMES, dtype=torch.int64, device=self.device)
-        h = torch.remainder((grid * primes).sum(-1), self.buffer_size)
-        self._table[h] = sample_idx.to(torch.int32)
-        self._rebuild_mirror()
+        """neural_points.py:819-908 on the device (pin_hash_rebuild): per voxel the point closest in time to `cur_ts`
+        (or the most certain one) owns the table slot; kept_points=False additionally MERGES the map down to those
+        points (the end of a run, pin_slam.py:521)."""
+        n = self._n
+        if n > 0:
+            self._wait_bricks()
+            rp = RehashParams()
+            rp.buffer_size, rp.n_points, rp.cur_ts = self.buffer_size, n, int(cur_ts)
+            rp.with_ts, rp.use_mid_ts = int(bool(with_ts)), int(bool(self.config.use_mid_ts))
+            rp.resolution = float(np.float32(self.resolution))
+            need = _lib.lib().pin_maint_workspace_bytes(n) + 4 * n
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty((int(need * 1.25),), dtype=torch.uint8, device=self.device)
+            ws = self._ws
+            sel = torch.empty((n,), dtype=torch.int32, device=self.device)
+            src_a = self._map_arrays()
+            dst = dst_a = None
+            if not kept_points:
+                if not self.silence:
+                    print("Filter duplicated neural points")
+                dst = self._spare_arrays()
+                dst_a = self._map_arrays(dst)
+            check(_lib.lib().pin_hash_rebuild(C.byref(src_a), None if dst_a is None else C.byref(dst_a), C.byref(rp), _p(sel),
+                                              _p(self._cnt[3:4]), _p(ws), ws.numel(),
+                                              torch.cuda.current_stream().cuda_stream), "pin_hash_rebuild")
+            if not kept_points:
+                self._n = int(self._cnt[3].item())
+                self._g, self._spare = dst, self._g
+            self._bricks = None  # the cache mirrors the table that was just rewritten
+        else:
+            self._table.fill_(-1)
         if sensor_position is not None:
             self.reset_local_map(sensor_position, sensor_orientation, cur_ts)
+        if not kept_points:
+            self.record_memory(verbose=(not self.silence))
 
     def clear_temp(self, clean_more: bool = False):
         """Drop everything that is rebuilt on load (neural_points.py:1035-1055) before pickling."""
@@ -460,6 +509,7 @@ class NeuralPoints(nn.Module):
         self._ws = None
         self._bricks = self._brick_cache = None
         self._side_stream = self._bricks_event = None  # (stream / event handles do not pickle)
+        self._spare = None
         # shrink to size so the pickled map holds only live rows
         n = self._n
         self._g = {k: (None if t is None else t[:(n + 1 if k in ("geo", "color") else n)].clone())
@@ -474,7 +524,20 @@ class NeuralPoints(nn.Module):
             self._table = torch.full((self.buffer_size,), -1, dtype=torch.int32, device=self.device)
 
     def compute_feature_principle_components(self, down_rate: int = 1):
-        raise NotImplementedError("visualisation helper (gui only), out of scope")
+        """neural_points.py:175-179: PCA bases of the local feature tables for the GUI's feature colouring
+        (visualisation only; the reference's own helper, a handful of torch ops when the decoder freezes)."""
+        from utils.tools import feature_pca_torch
+        _, self.geo_feature_pca = feature_pca_torch((self.local_geo_features.detach())[:-1], down_rate=down_rate,
+                                                    project_data=False)
+        if self.color_on:
+            _, self.color_feature_pca = feature_pca_torch((self.local_color_features.detach())[:-1], down_rate=down_rate,
+                                                          project_data=False)
 
-    def get_neural_points_o3d(self, *a, **k):
-        raise NotImplementedError("visualisation helper (open3d), out of scope")
+    def get_neural_points_o3d(self, query_global: bool = True, color_mode: int = -1, random_down_ratio: int = 1):
+        """neural_points.py:1073-1171, positions only: the open3d cloud pin_slam.py asks for at the end of a run (map
+        bounding box, chunking for meshing, neural_points.ply).  The colour modes are GUI features: uncoloured here."""
+        import open3d as o3d
+        pts = (self.neural_points if query_global else self.local_neural_points)[::max(1, int(random_down_ratio))]
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(pts.detach().cpu().numpy().astype(np.float64))
+        return pcd

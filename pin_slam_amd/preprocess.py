@@ -78,13 +78,16 @@ def intrinsic_correct(points: torch.Tensor, correct_deg=0.0):
 def deskewing(points: torch.Tensor, ts: Optional[torch.Tensor], pose: torch.Tensor, ts_mid_pose=0.5):
     if ts is None:
         return points
-    if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()):
-        raise RuntimeError("deskewing works in place on a contiguous float32 device tensor")
+    # in place on rows of a float32 device tensor; a column slice of wider rows (the reference hands in
+    # cur_source_torch[:, :3], slam_dataset.py:478) is fine: the row stride is passed on
+    if not (points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] >= 3
+            and points.stride(1) == 1):
+        raise RuntimeError("deskewing works in place on float32 device rows (xyz first, unit column stride)")
     t32 = _dev_f32(ts).reshape(-1).contiguous()
     T = np.ascontiguousarray(pose.detach().to("cpu", torch.float64).numpy() if isinstance(pose, torch.Tensor)
                              else np.asarray(pose, np.float64))
     ws = _ws(64, points.device)
-    check(_lib.lib().pin_deskew(points.data_ptr(), points.shape[1], points.shape[0], t32.data_ptr(), T.ctypes.data,
+    check(_lib.lib().pin_deskew(points.data_ptr(), points.stride(0), points.shape[0], t32.data_ptr(), T.ctypes.data,
                                 float(ts_mid_pose), ws.data_ptr(), ws.numel(), ops._stream()), "pin_deskew")
     return points
 
@@ -105,9 +108,12 @@ class ScanPreprocessor:
     def __call__(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None,
                  frame_id: int = 1, lose_track: bool = False):
         c = self.config
-        if getattr(c, "adaptive_range_on", False):
-            raise NotImplementedError("adaptive_range_on")
         crop_max = c.max_range
+        scan = _dev_f32(scan)
+        if getattr(c, "adaptive_range_on", False):  # slam_dataset.py:399-407: crop range from the scan's own extent
+            lo, hi = torch.aminmax(scan[:, :2], dim=0)
+            (x0, y0), (x1, y1) = lo.abs().tolist(), hi.abs().tolist()
+            crop_max = min(c.max_range, 2.0 * max(min(x1, x0), min(y1, y0)))
         train_vox = (crop_max / c.max_range) * c.vox_down_m
         source_vox = (crop_max / c.max_range) * c.source_vox_down_m
         scan = _dev_f32(scan).contiguous()

@@ -324,6 +324,91 @@ def test_post_loop_maintenance_matches_reference():
     assert np.array_equal(mp.coord_pool.cpu().numpy(), pl["pool_global"])
 
 
+def test_final_merge_and_mid_ts_match_reference():
+    """recreate_hash(None, None, False, False) after prune_map(thre, 0, True) -- the end of every pin_slam.py run
+    (pin_slam.py:520-521) -- and the use_mid_ts variants of adjust_map / recreate_hash, on the device kernels
+    (pin_prune_map, pin_hash_rebuild), against the reference fixture."""
+    import dataclasses
+    pl = G.load("postloop")
+    B = 40009
+    cfg = _cfg(buffer_size=B, local_map_radius=20.0, local_map_travel_dist_ratio=1.0, feature_std=0.05)
+    npts = _postloop_map(pl, cfg)
+    npts.cur_ts = 3
+    npts._g["pos"][:npts.count()] = torch.from_numpy(pl["adj_points"]).cuda()
+    npts._g["orient"][:npts.count()] = torch.from_numpy(pl["adj_orient"]).cuda()
+    assert npts.prune_map(1.0, 0, True)
+    npts.recreate_hash(None, None, False, False)
+    n = npts.count()
+    assert n == len(pl["merge_points"]) and n < 0.9 * len(pl["neural_points"])
+    for got, key in ((npts.neural_points, "merge_points"), (npts.point_orientations, "merge_orient"),
+                     (npts.geo_features, "merge_geo"), (npts.point_ts_create, "merge_ts_create"),
+                     (npts.point_ts_update, "merge_ts_update"), (npts.point_certainties, "merge_cert")):
+        assert np.array_equal(got.cpu().numpy(), pl[key]), key
+    tab = npts.buffer_pt_index.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.nonzero(tab >= 0)[0], pl["merge_slots"])
+    ref = np.full(B, -1, np.int64); ref[pl["merge_slots"]] = pl["merge_vals"]
+    slot_of = O.hash_slots(O.grid_coords(pl["merge_points"], pl["resolution"]), B)
+    writers = np.bincount(slot_of, minlength=B)
+    assert np.array_equal(tab[writers == 1], ref[writers == 1])
+    for sl in np.nonzero(writers > 1)[0][:200]:  # colliding slots keep the last writer in index order
+        assert tab[sl] == np.nonzero(slot_of == sl)[0][-1]
+    # the search mirror was rebuilt: a kNN query over the merged map answers with merged indices
+    npts.reset_local_map(torch.tensor([13.0, 0.0, 0.0]), None, 3)
+    pos4 = npts._g["pos4"][:n].cpu().numpy()
+    assert np.array_equal(pos4[:, :3], pl["merge_points"]) and np.array_equal(pos4[:, 3].view(np.int32), pl["merge_ts_create"])
+    # use_mid_ts
+    cfg2 = dataclasses.replace(cfg, use_mid_ts=True) if dataclasses.is_dataclass(cfg) else cfg
+    if cfg2 is cfg:
+        cfg.use_mid_ts = True
+    q = _postloop_map(pl, cfg2)
+    q.adjust_map(torch.from_numpy(pl["pose_diff"]).cuda())
+    np.testing.assert_allclose(q.neural_points.cpu().numpy(), pl["mid_adj_points"], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(q.point_orientations.cpu().numpy(), pl["mid_adj_orient"], rtol=0, atol=1e-6)
+    q._g["pos"][:q.count()] = torch.from_numpy(pl["mid_adj_points"]).cuda()
+    q.recreate_hash(None, None, True, True, 3)
+    tab = q.buffer_pt_index.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.nonzero(tab >= 0)[0], pl["rehash_mid_slots"])
+    _, sel = O.recreate_hash(pl["mid_adj_points"], pl["point_ts_create"], 3, pl["resolution"], B, ts_update=pl["point_ts_update"])
+    writers = np.bincount(O.hash_slots(O.grid_coords(pl["mid_adj_points"][sel], pl["resolution"]), B), minlength=B)
+    ref = np.full(B, -1, np.int64); ref[pl["rehash_mid_slots"]] = pl["rehash_mid_vals"]
+    assert np.array_equal(tab[writers == 1], ref[writers == 1])
+    cfg.use_mid_ts = False
+
+
+def test_local_map_variants_match_reference():
+    """reset_local_map by a window of frames (pin_slam.py:287, loop_local_map_by_travel_dist = False), with a float64
+    sensor position (dataset.cur_pose_torch) and with use_mid_ts, against the `update` fixture."""
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    d = G.load("update")
+    cfg = _cfg(buffer_size=int(d["buffer_size"]), local_map_radius=float(d["local_map_radius"]), local_map_travel_dist_ratio=1.0)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.from_numpy(d["travel_dist"]).cuda()
+    P = len(d["neural_points"])
+    npts._alloc(P + 64)
+    g = npts._g
+    g["pos"][:P] = torch.from_numpy(d["neural_points"]).cuda()
+    g["ts_create"][:P] = torch.from_numpy(d["point_ts_create"]).cuda()
+    g["ts_update"][:P] = torch.from_numpy(d["point_ts_update"]).cuda()
+    g["cert"][:P] = 0
+    g["orient"][:P] = 0
+    npts._n = P
+    npts._rebuild_mirror()
+    sp64 = torch.from_numpy(d["var_sensor"])
+    npts.reset_local_map(sp64.float(), None, 2, False, 2)
+    assert np.array_equal(npts.local_mask.cpu().numpy(), d["var_ts_mask"])
+    assert np.array_equal(npts.global2local.cpu().numpy(), d["var_ts_g2l"])
+    npts.reset_local_map(sp64, None, 3, True)
+    assert np.array_equal(npts.local_mask.cpu().numpy(), d["var_f64_mask"])
+    npts.reset_local_map(sp64.float(), None, 3, True)
+    assert np.array_equal(npts.local_mask.cpu().numpy(), d["var_f32_mask"])
+    cfg.use_mid_ts = True
+    npts.reset_local_map(sp64.float(), None, 3, True)
+    assert np.array_equal(npts.local_mask.cpu().numpy(), d["var_mid_mask"])
+    npts.reset_local_map(sp64.float(), None, 2, False, 1)
+    assert np.array_equal(npts.local_mask.cpu().numpy(), d["var_mid_ts_mask"])
+    cfg.use_mid_ts = False
+
+
 def test_map_pickles_like_the_reference_saves_it():
     """tools.py:295-317 saves {"neural_points": <module>, "sdf": state_dict}: the drop-in module must pickle
     (no ctypes handles in its state) and come back usable after recreate_hash, as vis_pin_map.py does."""

@@ -208,6 +208,33 @@ def test_update_and_local_map():
     assert np.array_equal(st["table"][slots], d["table_vals"])
 
 
+def local_map_variants(d):
+    """(name, oracle arguments) of the reset_local_map variants recorded in the `update` fixture."""
+    P, tc, tu = d["neural_points"], d["point_ts_create"], d["point_ts_update"]
+    sp64, sp32 = d["var_sensor"], d["var_sensor"].astype(np.float32)
+    td = dict(travel_dist=d["travel_dist"], diff_travel_dist_local=d["diff_travel_dist_local"])
+    mid = O.mid_ts(tc, tu)
+    return [("var_ts_mask", (P, tc, sp32, d["local_map_radius"]), dict(cur_ts=2, diff_ts_local=2)),
+            ("var_f64_mask", (P, tc, sp64, d["local_map_radius"]), dict(cur_ts=3, **td)),
+            ("var_f32_mask", (P, tc, sp32, d["local_map_radius"]), dict(cur_ts=3, **td)),
+            ("var_mid_mask", (P, mid, sp32, d["local_map_radius"]), dict(cur_ts=3, **td)),
+            ("var_mid_ts_mask", (P, mid, sp32, d["local_map_radius"]), dict(cur_ts=2, diff_ts_local=1))]
+
+
+def test_local_map_variants():
+    """reset_local_map by a window of frames (use_travel_dist=False, pin_slam.py:287), with a float64 sensor position,
+    with config.use_mid_ts."""
+    d = G.load("update")
+    seen = []
+    for name, a, kw in local_map_variants(d):
+        mask, g2l = O.local_map_mask(*a, **kw)
+        assert np.array_equal(mask, d[name][:-1]), name
+        seen.append(mask)
+        if name == "var_ts_mask":
+            assert np.array_equal(g2l, d["var_ts_g2l"])
+    assert not np.array_equal(seen[0], seen[4]) and not np.array_equal(seen[2], seen[3])  # the variants matter
+
+
 # ---------------------------------------------------------------- colour path (C5, run_replica.yaml)
 @pytest.fixture(scope="module")
 def cgold():
