@@ -332,18 +332,6 @@ int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const pin
                           int32_t n, double* sums, const double* state, void* stream);
 int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream);
 
-/* One Gauss-Newton iteration as ONE kernel: pin_gn_knn (through the brick cache) fused with
- * pin_gn_accumulate_dev -- search waves hand the kNN records of each 16-query tile to decoder
- * waves of the same CU through LDS.  Experimental: measured slower than the two separate calls on
- * the benchmark map, which stay the default.  Same results: identical kNN
- * records, sums within float32 summation order.  Requirements: weighted_first SDF field without
- * after-PGO orientations, k == f->k, at most 84 candidate cells; returns -3 otherwise (use the
- * separate entry points).  cur_out [n][3], nbr_out [n][k][4], nn_count_out [n] are optional
- * dumps of the transformed points / the kNN records (NULL in the hot loop). */
-int pin_gn_iteration(const pin_search_params* sp, const pin_brick_cache* bc, const pin_field* f,
-                     const pin_gn_params* gp, const float* src, int32_t n, int32_t k, const float* sdf_labels,
-                     double* sums, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
-                     void* stream);
 int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
                             const pin_gn_loop_params* lp, const float* cur, const float* nbr,
                             const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,

@@ -38,6 +38,11 @@ __device__ __forceinline__ void bf_split2(float x0, float x1, unsigned int& h, u
     const float s0 = r0 - bf_top(r0), s1 = r1 - bf_top(r1);
     l = bf_pack(s0, s1);
 }
+// max(x, 0) as ONE instruction: fmaxf() first canonicalises its operand (a second v_max_f32) because the compiler
+// cannot know that an MFMA result is never a signalling NaN; the signed-integer maximum of the bit pattern with 0 is
+// the same function on floats (a negative float is a negative integer) and needs no such step.  (Inline assembly is
+// not an option: the hazard recogniser does not see an MFMA -> VALU dependency through it.)
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ v8bf_t as_bf8(v4u_t v) { return __builtin_bit_cast(v8bf_t, v); }
 __device__ __forceinline__ v4s_t as_s4(v2u_t v) { return __builtin_bit_cast(v4s_t, v); }
 
@@ -255,73 +260,68 @@ struct QuadDecoderB {
         }
     }
 
-    __device__ __forceinline__ static unsigned int relu16(const v4f_t (&acc)[MT], v4f_t (&h)[MT]) {
-        return QuadDecoder<H>::relu16(acc, h);
-    }
-
-    __device__ __forceinline__ static void hidden_forward(const unsigned char* __restrict__ w, int L, int l, const v4f_t (&h)[MT],
-                                                          v4f_t (&acc)[MT]) {
-        v4u_t bh[NJ], bm[NJ], bl[NJ];
-        split_acts(h, bh, bm, bl);
-        load_bias(w, L, l, acc);
-        matmul(w + off_hidf(L, l), bh, bm, bl, acc);
-    }
-
-    // h <- mask .* (W_l^T h)
-    __device__ __forceinline__ static void hidden_backward(const unsigned char* __restrict__ w, int L, int l, unsigned int mm,
-                                                           v4f_t (&h)[MT]) {
-        v4u_t bh[NJ], bm[NJ], bl[NJ];
-        split_acts(h, bh, bm, bl);
-        v4f_t acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
-        matmul(w + off_hidb(L, l), bh, bm, bl, acc);
+    // ReLU pattern of a layer, read back from the packed bf16 hi pieces of its (post-ReLU, hence >= 0) activations:
+    // element (mj, r) sits in word [mj / 2][2 (mj % 2) + r / 2], half r % 2 (split_acts); a positive fp32 value has a
+    // non-zero upper half.  h <- pattern .* acc
+    __device__ __forceinline__ static void mask_by_pieces(const v4u_t (&sg)[NJ], const v4f_t (&acc)[MT], v4f_t (&h)[MT]) {
 #pragma unroll
         for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[mj][r] = ((mm >> (mj * 4 + r)) & 1u) ? acc[mj][r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const unsigned int word = sg[mj >> 1][2 * (mj & 1) + (r >> 1)];
+                const bool on = (r & 1) ? (word > 0xffffu) : ((word & 0xffffu) != 0u);
+                h[mj][r] = on ? acc[mj][r] : 0.f;
+            }
     }
 
-    // forward + input Jacobian of one 16-query tile (same contract as QuadDecoder<H>::run)
-    __device__ __forceinline__ static float run(const unsigned char* __restrict__ w, int L, const float (&z)[4], float (&a)[4]) {
+    // forward + input Jacobian of one 16-query tile (same contract as QuadDecoder<H>::run) with the number of layers
+    // known at compile time: both sweeps fully unrolled, and no mask words -- the hi pieces of every layer's
+    // activations (the B operand of the next layer anyway) stay in registers until the transposed sweep has used them
+    template <int L>
+    __device__ __forceinline__ static float run(const unsigned char* __restrict__ w, const float (&z)[4], float (&a)[4]) {
+        static_assert(L >= 1 && L <= MLP_MAX_LEVELS, "1..4 layers");
         const int g = (threadIdx.x & 63) >> 4;
         v4f_t h[MT], acc[MT];
-        unsigned int masks[MLP_MAX_LEVELS];
+        v4u_t sg[L > 1 ? L - 1 : 1][NJ];
         layer0(w, L, z, acc);
-        masks[0] = relu16(acc, h);
 #pragma unroll
-        for (int l = 1; l < MLP_MAX_LEVELS; ++l) masks[l] = 0;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+#pragma unroll
         for (int l = 1; l < L; ++l) {
-            hidden_forward(w, L, l, h, acc);
-            const unsigned int mm = relu16(acc, h);
+            v4u_t bm[NJ], bl[NJ];
+            split_acts(h, sg[l - 1], bm, bl);
+            load_bias(w, L, l, acc);
+            matmul(w + off_hidf(L, l), sg[l - 1], bm, bl, acc);
 #pragma unroll
-            for (int q = 1; q < MLP_MAX_LEVELS; ++q) masks[q] = q == l ? mm : masks[q];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
         }
+        // output head, and the seed of the transposed sweep: the output weights under the last ReLU pattern
         const float* __restrict__ O = reinterpret_cast<const float*>(w + off_out(L));
         float x = 0.f;
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
+            for (int r = 0; r < 4; ++r) {
+                x = fmaf(wo[r], h[kt][r], x);
+                h[kt][r] = h[kt][r] > 0.f ? wo[r] : 0.f;
+            }
         }
         x += __shfl_xor(x, 16, 64);
         x += __shfl_xor(x, 32, 64);
         x += O[MF_OD_MAX * H];
-        unsigned int mlast = masks[0];
 #pragma unroll
-        for (int q = 1; q < MLP_MAX_LEVELS; ++q) mlast = q == L - 1 ? masks[q] : mlast;
-#pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[kt][r] = ((mlast >> (kt * 4 + r)) & 1u) ? wo[r] : 0.f;
-        }
         for (int l = L - 1; l >= 1; --l) {
-            unsigned int mm = masks[0];
+            v4u_t bh[NJ], bm[NJ], bl[NJ];
+            split_acts(h, bh, bm, bl);
 #pragma unroll
-            for (int q = 1; q < MLP_MAX_LEVELS; ++q) mm = q == l - 1 ? masks[q] : mm;
-            hidden_backward(w, L, l, mm, h);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+            matmul(w + off_hidb(L, l), bh, bm, bl, acc);
+            mask_by_pieces(sg[l - 1], acc, h);
         }
         input_backward(w, L, h, a);
         return x;
@@ -339,6 +339,7 @@ struct QuadDec<H, false> {
     __device__ __forceinline__ static void stage(const float* __restrict__ dec, int L, unsigned char* smem, int tid, int nthreads) {
         Q::stage(dec, L, reinterpret_cast<float*>(smem), tid, nthreads);
     }
+    template <int LC>  // (LC unused: the fp32 image takes the layer count at run time)
     __device__ __forceinline__ static float run(const unsigned char* smem, int L, const float (&z)[4], float (&a)[4]) {
         return Q::run(reinterpret_cast<const float*>(smem), L, z, a);
     }
@@ -350,8 +351,9 @@ struct QuadDec<H, true> {
     __device__ __forceinline__ static void stage(const float* __restrict__ dec, int L, unsigned char* smem, int tid, int nthreads) {
         Q::stage(dec, L, smem, tid, nthreads);
     }
-    __device__ __forceinline__ static float run(const unsigned char* smem, int L, const float (&z)[4], float (&a)[4]) {
-        return Q::run(smem, L, z, a);
+    template <int LC>
+    __device__ __forceinline__ static float run(const unsigned char* smem, int, const float (&z)[4], float (&a)[4]) {
+        return Q::template run<LC>(smem, z, a);
     }
 };
 

@@ -35,14 +35,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int MF_BLOCK = 256;  // 4 waves share one LDS image of the weights
 constexpr int MF_OD_MAX = 3;   // output heads: 1 (sdf) or 3 (colour)
 
-// PIN_DECODER=valu selects the thread-per-query vector decoder (A/B runs); default: matrix cores
-static inline bool use_mfma_decoder() {
-    static const int on = [] {
-        const char* e = getenv("PIN_DECODER");
-        return (e != nullptr && strcmp(e, "valu") == 0) ? 0 : 1;
-    }();
-    return on != 0;
-}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 

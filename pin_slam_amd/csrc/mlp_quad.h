@@ -6,7 +6,7 @@
 
 namespace pin {
 
-constexpr int GQ_BLOCK = 768;
+constexpr int GQ_BLOCK = 512;  // 2 waves per SIMD: up to 256 VGPRs each (the tile kernels are bound by instruction issue, not occupancy)
 
 template <int H>
 struct QuadDecoder {

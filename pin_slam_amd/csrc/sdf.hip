@@ -97,29 +97,22 @@ struct Kappa {
     float k[MF_OD_MAX];  // value = sum_c k[c] * sigmoid(out_c) for the colour decoder
 };
 
-// The fused per-query evaluation shared by pin_sdf_query and pin_gn_accumulate.
-// decoder back-ends: VALU (thread-private LDS column `col`) or MFMA (block weights `col`, wave scratch `xb`)
+// The fused per-query evaluation shared by pin_sdf_query and pin_gn_accumulate: decoder on the matrix cores
+// (block weights `col`, wave scratch `xb`).
 template <int H, bool GRAD, bool MFMA, int OD = 1>
 __device__ __forceinline__ float decode(const pin_field& f, const float (&z)[MLP_IN], float (&a)[MLP_IN], float* col,
                                         float* xb, const Kappa& kap, float (&p)[MF_OD_MAX]) {
-    if constexpr (MFMA) {
-        float kk[OD], pp[OD];
+    static_assert(MFMA, "the thread-per-query vector decoder was removed in round 2");
+    float kk[OD], pp[OD];
 #pragma unroll
-        for (int c = 0; c < OD; ++c) kk[c] = kap.k[c];
-        const float v = MfmaDecoder<H>::template run_heads<GRAD, 2, OD>(col, f.levels, xb, z, kk, pp, a);
+    for (int c = 0; c < OD; ++c) kk[c] = kap.k[c];
+    const float v = MfmaDecoder<H>::template run_heads<GRAD, 2, OD>(col, f.levels, xb, z, kk, pp, a);
 #pragma unroll
-        for (int c = 0; c < OD; ++c) p[c] = pp[c];
-        return v;
-    } else {
-        static_assert(OD == 1, "the vector decoder has one output head");
-        MlpMasks mk;
-        const float x = mlp_forward<H, SDF_BLOCK>(as_const(f.dec), f.levels, z, col, mk);
-        if (GRAD) mlp_input_jacobian<H, SDF_BLOCK>(as_const(f.dec), f.levels, mk, col, a);
-        return x;
-    }
+    for (int c = 0; c < OD; ++c) p[c] = pp[c];
+    return v;
 }
 
-template <int H, bool WF, bool GRAD, bool MFMA = false, int OD = 1>
+template <int H, bool WF, bool GRAD, bool MFMA = true, int OD = 1>
 __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4* __restrict__ nbr,
                                                 const int* __restrict__ nn_count, int qi, float qx, float qy,
                                                 float qz, float* col, float* xb = nullptr, Kappa kap = Kappa()) {
@@ -279,76 +272,8 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
     return r;
 }
 
-template <int H, bool WF>
-__global__ __launch_bounds__(SDF_BLOCK) void sdf_query_kernel(pin_field f, const float* __restrict__ query,
-                                                              const float4* __restrict__ nbr,
-                                                              const int* __restrict__ nn_count, int n,
-                                                              float* __restrict__ sdf_out, float* __restrict__ grad_out,
-                                                              float* __restrict__ std_out, float* __restrict__ cert_out) {
-    __shared__ float lds[H * SDF_BLOCK];
-    const int qi = blockIdx.x * SDF_BLOCK + threadIdx.x;
-    if (qi >= n) return;
-    const float qx = query[3 * qi], qy = query[3 * qi + 1], qz = query[3 * qi + 2];
-    SdfResult r;
-    if (grad_out != nullptr) r = eval_query<H, WF, true>(f, nbr, nn_count, qi, qx, qy, qz, lds + threadIdx.x);
-    else r = eval_query<H, WF, false>(f, nbr, nn_count, qi, qx, qy, qz, lds + threadIdx.x);
-    if (sdf_out) sdf_out[qi] = r.sdf;
-    if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
-    if (std_out) std_out[qi] = r.std;
-    if (cert_out) cert_out[qi] = r.cert;
-}
-
-template <int H, bool WF>
-__global__ __launch_bounds__(SDF_BLOCK) void gn_accumulate_kernel(pin_field f, pin_gn_params gp,
-                                                                  const float* __restrict__ query,
-                                                                  const float4* __restrict__ nbr,
-                                                                  const int* __restrict__ nn_count,
-                                                                  const float* __restrict__ labels, int n,
-                                                                  double* __restrict__ sums, float* __restrict__ sdf_out,
-                                                                  float* __restrict__ grad_out,
-                                                                  const double* __restrict__ state) {
-    __shared__ float lds[H * SDF_BLOCK];
-    if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
-    const int qi = blockIdx.x * SDF_BLOCK + threadIdx.x;
-    float v[PIN_GN_NSUMS];
-#pragma unroll
-    for (int i = 0; i < PIN_GN_NSUMS; ++i) v[i] = 0.f;
-    if (qi < n) {
-        const float px = query[3 * qi], py = query[3 * qi + 1], pz = query[3 * qi + 2];
-        const SdfResult r = eval_query<H, WF, true>(f, nbr, nn_count, qi, px, py, pz, lds + threadIdx.x);
-        if (sdf_out) sdf_out[qi] = r.sdf;
-        if (grad_out) { grad_out[3 * qi] = r.gx; grad_out[3 * qi + 1] = r.gy; grad_out[3 * qi + 2] = r.gz; }
-        const float gn = sqrtf(r.gx * r.gx + r.gy * r.gy + r.gz * r.gz);
-        const bool valid = nn_count[qi] >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm &&
-                           r.std < gp.max_sdf_std;  // tracker.py:419-425
-        if (valid) {
-            const float res = r.sdf - (labels ? labels[qi] : 0.f);
-            float w = 1.f;
-            if (gp.gm_grad > 0.f) { const float a = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + a * a); w *= t * t; }
-            if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); w *= t * t; }
-            float J[6];  // [p x g, g]  (tracker.py:652-655)
-            J[0] = py * r.gz - pz * r.gy; J[1] = pz * r.gx - px * r.gz; J[2] = px * r.gy - py * r.gx;
-            J[3] = r.gx; J[4] = r.gy; J[5] = r.gz;
-            int o = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) v[o++] = w * J[a] * J[b];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) v[21 + a] = w * J[a] * res;
-            v[27] = w; v[28] = fabsf(res); v[29] = 1.f; v[30] = w * res * res;
-        }
-    }
-    double* dst = sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 31; ++i) {
-        const double t = (double)wave_sum_f32(v[i]);
-        if (lane == 0 && t != 0.0) atomicAdd(dst + i, t);
-    }
-}
-
-// ---- the same two kernels with the decoder on the fp32 matrix cores (mlp_mfma.h) -----------
+// ---- the fused query / Gauss-Newton kernels, 64 queries per wave, decoder on the fp32 matrix cores (mlp_mfma.h):
+// per-neighbour decoding (weighted_first = False), the colour term and plain forward queries -----------
 
 template <int H, bool WF, int OD = 1>
 __global__ __launch_bounds__(MF_BLOCK, 2) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
@@ -709,13 +634,8 @@ using namespace pin;
 
 #define PIN_DISPATCH_FIELD(f, KERNEL, n, stream, ...)                                               \
     do {                                                                                            \
-        if (use_mfma_decoder()) {                                                                   \
-            const dim3 grid_(cdiv(n, MF_BLOCK)), block_(MF_BLOCK);                                  \
-            PIN_DISPATCH_HW(f, KERNEL##_mfma_kernel, grid_, block_, 0, stream, __VA_ARGS__);        \
-        } else {                                                                                    \
-            const dim3 grid_(cdiv(n, SDF_BLOCK)), block_(SDF_BLOCK);                                \
-            PIN_DISPATCH_HW(f, KERNEL##_kernel, grid_, block_, 0, stream, __VA_ARGS__);             \
-        }                                                                                           \
+        const dim3 grid_(cdiv(n, MF_BLOCK)), block_(MF_BLOCK);                                      \
+        PIN_DISPATCH_HW(f, KERNEL##_mfma_kernel, grid_, block_, 0, stream, __VA_ARGS__);            \
     } while (0)
 
 // persistent blocks, one per CU (gn_quad.h)
@@ -729,53 +649,46 @@ static int gq_cu_count() {
     return n_cu;
 }
 
-template <int H, bool ORIENT, bool BF>
+template <int H, bool ORIENT, bool BF, int LC>
 static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                             const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                             float* grad_out, const double* state, hipStream_t s) {
-    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, BF>::bytes(MLP_MAX_LEVELS));
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, BF>),
+    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, BF>::bytes(LC > 0 ? LC : MLP_MAX_LEVELS));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, BF, LC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 16);
     const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, BF>), grid, block, gq_lds_bytes(QuadDec<H, BF>::bytes(f->levels)), s,
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, BF, LC>), grid, block, gq_lds_bytes(QuadDec<H, BF>::bytes(f->levels)), s,
                        *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state);
     return 0;
+}
+
+template <int H, bool ORIENT>
+static int launch_quad_ho(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                          const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                          float* grad_out, const double* state, hipStream_t s) {
+#define PIN_LQ(BB, LL) \
+    return launch_quad_inst<H, ORIENT, BB, LL>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
+    if (!use_bf3_decoder()) PIN_LQ(false, 0);  // PIN_MLP=f32: the fp32 MFMA image (A/B runs)
+    switch (f->levels) {
+        case 1: PIN_LQ(true, 1);
+        case 2: PIN_LQ(true, 2);
+        case 3: PIN_LQ(true, 3);
+        default: PIN_LQ(true, 4);
+    }
+#undef PIN_LQ
 }
 
 static int launch_quad(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                        const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                        float* grad_out, const double* state, hipStream_t s) {
-#define PIN_LQ(HH, OO, BB) \
-    return launch_quad_inst<HH, OO, BB>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
-    const bool bf = use_bf3_decoder();
     if (f->hidden == 64) {
-        if (f->orient) { if (bf) PIN_LQ(64, true, true); else PIN_LQ(64, true, false); }
-        else { if (bf) PIN_LQ(64, false, true); else PIN_LQ(64, false, false); }
-    } else {
-        if (f->orient) { if (bf) PIN_LQ(32, true, true); else PIN_LQ(32, true, false); }
-        else { if (bf) PIN_LQ(32, false, true); else PIN_LQ(32, false, false); }
+        if (f->orient) return launch_quad_ho<64, true>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
+        return launch_quad_ho<64, false>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
     }
-#undef PIN_LQ
-}
-
-template <int H, int R>
-static int launch_iteration_inst(const pin_field* f, const pin_gn_params* gp, const pin_search_params* sp,
-                                 const pin_brick_cache* bc, const float* src, const float* labels, int32_t n, int k,
-                                 double* sums, const double* state, float* cur_out, float4* nbr_out, int32_t* nn_out,
-                                 hipStream_t s) {
-    constexpr int lds_bytes = gi_lds_floats<H>() * (int)sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_iteration_kernel<H, R>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (attr != hipSuccess) return fail(-2, "gn iteration kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
-    QuadPose pose;
-    memset(&pose, 0, sizeof(pose));
-    const int tiles = cdiv(n, 16);
-    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);
-    hipLaunchKernelGGL((gn_iteration_kernel<H, R>), grid, block, lds_bytes, s, *f, *gp, *sp, *bc, src, labels, n, k, sums, state,
-                       pose, cur_out, nbr_out, nn_out);
-    return 0;
+    if (f->orient) return launch_quad_ho<32, true>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
+    return launch_quad_ho<32, false>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
 }
 
 static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color, const float* pts,
@@ -784,7 +697,6 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
     ColorTerm ct;
     memset(&ct, 0, sizeof(ct));
     if (color != nullptr && color->mode != 0) {
-        PIN_CHECK_ARG(use_mfma_decoder(), "the colour term needs the MFMA decoder (unset PIN_DECODER)");
         PIN_CHECK_ARG(color->field && color->colors, "colour term: field / colors NULL");
         if (int e = check_field(color->field)) return e;
         PIN_CHECK_ARG(color->field->out_dim == 3 && color->field->hidden == f->hidden && color->field->k == f->k &&
@@ -796,16 +708,12 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
         ct.photo_weight = color->photo_weight;
     }
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
-    if (use_mfma_decoder() && use_quad_gn() && f->weighted_first && ct.mode == 0) {
+    if (f->weighted_first && ct.mode == 0) {  // four lanes per query, persistent blocks (gn_quad.h)
         if (int e = launch_quad(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
-    } else if (use_mfma_decoder()) {
+    } else {  // per-neighbour decoding / colour term: 64 queries per wave
         const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
         PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
                         sdf_out, grad_out, state, ct);
-    } else {
-        const dim3 grid(cdiv(n, SDF_BLOCK)), block(SDF_BLOCK);
-        PIN_DISPATCH_HW(f, gn_accumulate_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out,
-                        grad_out, state);
     }
     return 0;
 }
@@ -952,34 +860,6 @@ extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp
     PIN_CHECK_ARG(cur && nbr && nn_count && f->feats, "NULL pointer");
     hipStream_t s = as_stream(stream);
     if (int e = launch_gn(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, nullptr, nullptr, state, s)) return e;
-    PIN_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int pin_gn_iteration(const pin_search_params* sp, const pin_brick_cache* bc, const pin_field* f,
-                                const pin_gn_params* gp, const float* src, int32_t n, int32_t k, const float* sdf_labels,
-                                double* sums, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
-                                void* stream) {
-    PIN_ENTER();
-    if (int e = check_field(f)) return e;
-    PIN_CHECK_ARG(sp && bc && gp && sums && state && src && n > 0, "bad arguments");
-    PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K && k == f->k, "k must equal the field's neighbour count (<= 8)");
-    PIN_CHECK_ARG(f->weighted_first && (f->out_dim == 0 || f->out_dim == 1), "fused iteration: weighted_first SDF field only");
-    PIN_CHECK_ARG(use_mfma_decoder(), "fused iteration needs the MFMA decoder (unset PIN_DECODER)");
-    PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && bc->cand_dx && bc->entries && f->feats, "empty map / NULL pointer");
-    const int per_lane = cdiv(sp->n_cand, 4);
-    if (f->orient != nullptr || per_lane > 21)
-        return fail(-3, "fused GN iteration: after-PGO fields / more than 84 candidate cells use the separate kernels");
-    hipStream_t s = as_stream(stream);
-    float4* nb4 = reinterpret_cast<float4*>(nbr_out);
-    int e;
-    if (f->hidden == 64)
-        e = per_lane <= 9 ? launch_iteration_inst<64, 9>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s)
-                          : launch_iteration_inst<64, 21>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s);
-    else
-        e = per_lane <= 9 ? launch_iteration_inst<32, 9>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s)
-                          : launch_iteration_inst<32, 21>(f, gp, sp, bc, src, sdf_labels, n, k, sums, state, cur_out, nb4, nn_count_out, s);
-    if (e) return e;
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -15,7 +15,6 @@
 
 namespace pin {
 
-constexpr int TR_BLOCK = 128;
 
 struct TrainWs {
     float* z;      // [12][Qs]  interpolated decoder input (row 11 unused)
@@ -144,104 +143,6 @@ __device__ __forceinline__ void neighbor_weights(const float4* __restrict__ nbr,
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t)
         if (nb.idx[t] >= 0) nb.w[t] = u[t] / S;
-}
-
-template <int H>
-__global__ __launch_bounds__(TR_BLOCK) void train_fwd_kernel(pin_field f, const float* __restrict__ query,
-                                                             const float4* __restrict__ nbr,
-                                                             const int* __restrict__ nn_count, int Q, int n_main,
-                                                             TrainWs ws, float* __restrict__ cert_rw,
-                                                             int* __restrict__ ts_rw, const int* __restrict__ sample_ts) {
-    __shared__ float lds[H * TR_BLOCK];
-    const int qi = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (qi >= Q) return;
-    float* col = lds + threadIdx.x;
-    NbrW nb;
-    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
-    bool quirk[PIN_MAX_K];
-    neighbor_weights(nbr, nn_count[qi], qi, f.k, nb, vx, vy, vz, quirk);
-    const float qx = query[3 * qi], qy = query[3 * qi + 1], qz = query[3 * qi + 2];
-    float z[MLP_IN], Rm[9];
-#pragma unroll
-    for (int j = 0; j < MLP_IN; ++j) z[j] = 0.f;
-#pragma unroll
-    for (int t = 0; t < PIN_MAX_K; ++t)
-        if (nb.idx[t] >= 0) {
-            const float4* row = reinterpret_cast<const float4*>(f.feats + (size_t)nb.idx[t] * PIN_FEATURE_DIM);
-            const float4 a = row[0], b = row[1];
-            float v[3] = {vx[t], vy[t], vz[t]};
-            if (quirk[t]) {
-                const float* p = f.pos + 3 * (size_t)nb.idx[t];
-                v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
-            }
-            if (f.orient != nullptr) {
-                const float4 q4 = reinterpret_cast<const float4*>(f.orient)[nb.idx[t]];
-                const float q0 = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
-                Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[3] = 2 * (q1 * q2 - q0 * q3); Rm[6] = 2 * (q1 * q3 + q0 * q2);
-                Rm[1] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[7] = 2 * (q2 * q3 - q0 * q1);
-                Rm[2] = 2 * (q1 * q3 - q0 * q2); Rm[5] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
-                const float x = v[0], y = v[1], zz = v[2];
-                v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * zz;
-                v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * zz;
-                v[2] = Rm[6] * x + Rm[7] * y + Rm[8] * zz;
-            }
-            const float w = nb.w[t];
-            z[0] = fmaf(w, a.x, z[0]); z[1] = fmaf(w, a.y, z[1]); z[2] = fmaf(w, a.z, z[2]); z[3] = fmaf(w, a.w, z[3]);
-            z[4] = fmaf(w, b.x, z[4]); z[5] = fmaf(w, b.y, z[5]); z[6] = fmaf(w, b.z, z[6]); z[7] = fmaf(w, b.w, z[7]);
-            z[8] = fmaf(w, v[0], z[8]); z[9] = fmaf(w, v[1], z[9]); z[10] = fmaf(w, v[2], z[10]);
-        }
-    const int Qs = ws.Qs;
-#pragma unroll
-    for (int j = 0; j < MLP_IN; ++j) ws.z[(size_t)j * Qs + qi] = z[j];
-    ws.z[(size_t)11 * Qs + qi] = 0.f;
-
-    // decoder forward, activations streamed to the workspace (unit-major)
-    cfloatp P = as_const(f.dec);
-    const int L = f.levels;
-    {
-        cfloatp W = P;
-        cfloatp b = P + H * MLP_IN;
-        for (int i = 0; i < H; ++i) {
-            float acc = b[i];
-#pragma unroll
-            for (int j = 0; j < MLP_IN; ++j) acc = fmaf(W[i * MLP_IN + j], z[j], acc);
-            acc = fmaxf(acc, 0.f);
-            col[i * TR_BLOCK] = acc;
-            ws.h[(size_t)i * Qs + qi] = acc;
-        }
-        P += H * MLP_IN + H;
-    }
-    float h[H];
-    for (int l = 1; l < L; ++l) {
-#pragma unroll
-        for (int j = 0; j < H; ++j) h[j] = col[j * TR_BLOCK];
-        cfloatp W = P;
-        cfloatp b = P + H * H;
-        for (int i = 0; i < H; ++i) {
-            float acc = b[i];
-#pragma unroll
-            for (int j = 0; j < H; ++j) acc = fmaf(W[i * H + j], h[j], acc);
-            acc = fmaxf(acc, 0.f);
-            col[i * TR_BLOCK] = acc;
-            ws.h[((size_t)l * H + i) * Qs + qi] = acc;
-        }
-        P += H * H + H;
-    }
-    float out = P[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) out = fmaf(P[j], col[j * TR_BLOCK], out);
-    ws.pred[qi] = f.sdf_scale * out;
-
-    // training-mode side effects of query_feature for the batch samples (neural_points.py:685-710);
-    // the central-difference queries run with training_mode=False (mapper.py:941)
-    if (qi < n_main && cert_rw != nullptr) {
-#pragma unroll
-        for (int t = 0; t < PIN_MAX_K; ++t)
-            if (nb.idx[t] >= 0) {
-                atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
-                if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
-            }
-    }
 }
 
 // ---- forward / backward with the decoder on the matrix cores (mlp_mfma.h) -------------------
@@ -541,69 +442,6 @@ __global__ __launch_bounds__(256) void train_loss_kernel(pin_train_params tp, co
         if (l_bce != 0.0) atomicAdd(loss_out + 0, l_bce);
         if (l_eik != 0.0) atomicAdd(loss_out + 1, l_eik);
     }
-}
-
-// ---- backward: layer deltas + feature-gradient scatter ------------------------------------
-template <int H>
-__global__ __launch_bounds__(TR_BLOCK) void train_bwd_kernel(pin_field f, const float4* __restrict__ nbr,
-                                                             const int* __restrict__ nn_count, int Q, TrainWs ws,
-                                                             float* __restrict__ feat_grad, int want_dec) {
-    __shared__ float lds[H * TR_BLOCK];
-    const int qi = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (qi >= Q) return;
-    float* col = lds + threadIdx.x;
-    const int Qs = ws.Qs;
-    const int L = f.levels;
-    cfloatp P = as_const(f.dec);
-    cfloatp Wo = P + H * MLP_IN + H + (L - 1) * (H * H + H);
-    const float dx = ws.dpred[qi] * f.sdf_scale;  // d loss / d mlp_out
-    if (want_dec) ws.d[(size_t)(L * H) * Qs + qi] = dx;
-    // delta of the last hidden layer
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-        const float on = ws.h[((size_t)(L - 1) * H + j) * Qs + qi] > 0.f ? 1.f : 0.f;
-        const float dl = dx * Wo[j] * on;
-        col[j * TR_BLOCK] = dl;
-        if (want_dec) ws.d[((size_t)(L - 1) * H + j) * Qs + qi] = dl;
-    }
-    for (int l = L - 1; l >= 1; --l) {
-        cfloatp W = P + H * MLP_IN + H + (l - 1) * (H * H + H);
-        float ap[H];
-#pragma unroll
-        for (int j = 0; j < H; ++j) ap[j] = 0.f;
-        for (int i = 0; i < H; ++i) {
-            const float am = col[i * TR_BLOCK];
-#pragma unroll
-            for (int j = 0; j < H; ++j) ap[j] = fmaf(W[i * H + j], am, ap[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const float on = ws.h[((size_t)(l - 1) * H + j) * Qs + qi] > 0.f ? 1.f : 0.f;
-            const float dl = ap[j] * on;
-            col[j * TR_BLOCK] = dl;
-            if (want_dec) ws.d[((size_t)(l - 1) * H + j) * Qs + qi] = dl;
-        }
-    }
-    float dz[PIN_FEATURE_DIM];
-#pragma unroll
-    for (int j = 0; j < PIN_FEATURE_DIM; ++j) dz[j] = 0.f;
-    for (int i = 0; i < H; ++i) {
-        const float am = col[i * TR_BLOCK];
-#pragma unroll
-        for (int j = 0; j < PIN_FEATURE_DIM; ++j) dz[j] = fmaf(P[i * MLP_IN + j], am, dz[j]);
-    }
-    if (dx == 0.f) return;
-    NbrW nb;
-    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
-    bool quirk[PIN_MAX_K];
-    neighbor_weights(nbr, nn_count[qi], qi, f.k, nb, vx, vy, vz, quirk);
-#pragma unroll
-    for (int t = 0; t < PIN_MAX_K; ++t)
-        if (nb.idx[t] >= 0) {
-            float* g = feat_grad + (size_t)nb.idx[t] * PIN_FEATURE_DIM;
-#pragma unroll
-            for (int j = 0; j < PIN_FEATURE_DIM; ++j) atomicAdd(g + j, nb.w[t] * dz[j]);
-        }
 }
 
 // ---- colour loss: weight_i * mean over surface samples and channels of |pred - label| ---------
@@ -1108,8 +946,6 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
     PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
     PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
-    const bool mfma = use_mfma_decoder();
-    PIN_CHECK_ARG(f->weighted_first || mfma, "weighted_first=False training needs the MFMA decoder (unset PIN_DECODER)");
     const int expand = f->weighted_first ? 1 : f->k;
     PIN_CHECK_ARG(tp->n_main > 0 && tp->n_eik >= 0, "bad batch sizes");
     const int Q = tp->n_main + 6 * tp->n_eik;
@@ -1123,7 +959,6 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     ws.QsT = ws.Qs * expand;
     carve_ws(ws, reinterpret_cast<float*>(workspace), H, L);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
-    const dim3 grid(cdiv(Q, TR_BLOCK)), block(TR_BLOCK);
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
 #define PIN_TRAIN_MFMA(KERNEL, ...)                                                                      \
     do {                                                                                                 \
@@ -1132,9 +967,8 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         else { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
                else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__); }          \
     } while (0)
-    // weighted_first: four lanes per query on persistent blocks (PIN_TRAIN=wave keeps 64 queries per wave)
-    static const bool quad_on = [] { const char* e = getenv("PIN_TRAIN"); return !(e && strcmp(e, "wave") == 0); }();
-    const bool quad = mfma && quad_on && f->weighted_first;
+    // weighted_first: four lanes per query on persistent blocks; per-neighbour decoding: 64 queries per wave
+    const bool quad = f->weighted_first != 0;
     static const int n_cu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
@@ -1145,11 +979,8 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     if (quad) {
         if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
         else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
-    } else if (mfma) {
-        PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     } else {
-        if (H == 64) hipLaunchKernelGGL(train_fwd_kernel<64>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
-        else hipLaunchKernelGGL(train_fwd_kernel<32>, grid, block, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+        PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     }
     PIN_CHECK_LAUNCH();
     if (!quad) {  // (the tile backward kernel computes the loss gradient itself)
@@ -1161,11 +992,8 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     if (quad) {
         if (H == 64) hipLaunchKernelGGL((train_bwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
         else hipLaunchKernelGGL((train_bwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
-    } else if (mfma) {
-        PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     } else {
-        if (H == 64) hipLaunchKernelGGL(train_bwd_kernel<64>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
-        else hipLaunchKernelGGL(train_bwd_kernel<32>, grid, block, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
+        PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     }
     PIN_CHECK_LAUNCH();
     if (want_dec) {
@@ -1190,7 +1018,6 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
                                     void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(fc && tp, "NULL params");
-    PIN_CHECK_ARG(use_mfma_decoder(), "the colour term needs the MFMA decoder (unset PIN_DECODER)");
     PIN_CHECK_ARG(fc->out_dim == 3, "colour field must have 3 output heads");
     PIN_CHECK_ARG(fc->k >= 1 && fc->k <= PIN_MAX_K && (fc->hidden == 32 || fc->hidden == 64) && fc->levels >= 1 &&
                       fc->levels <= MLP_MAX_LEVELS, "bad colour field");

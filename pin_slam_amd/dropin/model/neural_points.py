@@ -323,10 +323,6 @@ class NeuralPoints(nn.Module):
         # certainty query, new-sample index) is a chain of small kernels and count read-backs that leaves the GPU
         # mostly idle and does not touch the cache.  Consumers go through _use_bricks(), which orders their stream
         # behind the build.
-        if os.environ.get("PIN_BRICKS_ASYNC", "1") == "0":
-            self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
-            self._bricks_event = None
-            return
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         side, main = self._side_stream, torch.cuda.current_stream()

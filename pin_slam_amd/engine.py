@@ -71,7 +71,7 @@ class GNTracker:
         self.sums.zero_()
         sp = self.st.params(time_filtering=time_filtering, local=local)
         # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder)
-        if self.fs.weighted_first and color is None and os.environ.get("PIN_DEC_IMAGE", "1") != "0":
+        if self.fs.weighted_first and color is None:
             self.fs.stage_decoder()
         f = self.fs.params()
         bc = None
@@ -91,21 +91,7 @@ class GNTracker:
         sums_p, st_p = self.sums.data_ptr(), self.state.data_ptr()
         lab_p = None if labels is None else labels.data_ptr()
         k = self.fs.k
-        # opt-in: one kernel per iteration (search producers + decoder consumers, gn_quad.h); measured slower
-        # than the two separate kernels on C3, so the default stays kNN launch + GN launch
-        fused = (bc is not None and self.fs.weighted_first and color is None and self.fs.orient is None
-                 and self.st.cand_off.shape[0] <= 84 and os.environ.get("PIN_GN_FUSED", "0") == "1")
         for _ in range(iters):
-            if fused:
-                if self.on_gn:
-                    self.on_gn(True)
-                rc = L.pin_gn_iteration(sp_r, bc_r, f_r, gp_r, src_p, n, k, lab_p, sums_p, st_p, None, None, nn_p, stream)
-                if self.on_gn:
-                    self.on_gn(False)
-                rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
-                if rc:
-                    check(rc, "pin_gn_iteration / pin_gn_solve")
-                continue
             if self.on_knn:
                 self.on_knn(True)
             rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)

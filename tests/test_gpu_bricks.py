@@ -88,46 +88,3 @@ def test_bricks_large_synthetic_map():
     for pts in (scan, pool):
         nbr, nn, _ = _same(st, U.dev(pts), 8, bricks)
     assert float(nn.float().mean()) > 20
-
-
-def test_fused_gn_iteration_matches_separate_kernels():
-    """pin_gn_iteration (search with 4 lanes per query fused with the decoder) against
-    pin_knn_query_bricks + pin_gn_accumulate: kNN records, counts and transformed points are
-    bit-identical, the Gauss-Newton sums agree to float32 summation order."""
-    import ctypes as C
-    from pin_slam_amd import _lib, ops
-    from pin_slam_amd._lib import GnParams
-    from tests import gpu_util as U
-    L = _lib.lib()
-    for case in ("c2_wf", "c3_bigtable"):
-        d = G.load(case)
-        st, fs = U.search_state(d), U.field_state(d, local=True)
-        bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st, wait=True)
-        k = int(d["query_nn_k"])
-        rng = np.random.default_rng(3)
-        src = torch.from_numpy(np.concatenate([d["query"], d["query"] + rng.normal(0, 0.3, d["query"].shape).astype(np.float32)])).cuda()
-        n = src.shape[0]
-        a = 0.02
-        T = np.eye(4); T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]; T[:3, 3] = [0.05, -0.1, 0.02]
-        gp = GnParams(); gp.valid_nn_k = k; gp.min_grad_norm = 0.3; gp.max_grad_norm = 3.0; gp.max_sdf_std = 0.5; gp.gm_dist = 0.3; gp.gm_grad = 0.1
-        # separate kernels
-        nbr, nn, cur = ops.knn_query(st, src, k, pose=T, bricks=bricks)
-        sums_ref, _, _ = ops.gn_accumulate(fs, gp, cur, nbr, nn)
-        # fused kernel, pose through the device state
-        state = torch.zeros(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device="cuda")
-        T0 = np.ascontiguousarray(T)
-        stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(L.pin_gn_state_init(state.data_ptr(), T0.ctypes.data, n, stream), "init")
-        sums = torch.zeros((_lib.PIN_GN_REPLICAS, _lib.PIN_GN_NSUMS), dtype=torch.float64, device="cuda")
-        nbr2, nn2, cur2 = torch.empty_like(nbr), torch.empty_like(nn), torch.empty_like(cur)
-        sp, f, bc = st.params(time_filtering=True, local=True), fs.params(), bricks.params()
-        _lib.check(L.pin_gn_iteration(C.byref(sp), C.byref(bc), C.byref(f), C.byref(gp), src.data_ptr(), n, k, None,
-                                      sums.data_ptr(), state.data_ptr(), cur2.data_ptr(), nbr2.data_ptr(), nn2.data_ptr(), stream),
-                   "pin_gn_iteration")
-        assert torch.equal(cur2, cur)
-        assert torch.equal(nn2, nn)
-        assert torch.equal(nbr2.view(torch.int32), nbr.view(torch.int32))
-        got, ref = sums.sum(0).cpu().numpy(), sums_ref.cpu().numpy().reshape(-1, _lib.PIN_GN_NSUMS).sum(0)
-        assert ref[29] > 0.3 * n
-        assert got[29] == ref[29]
-        np.testing.assert_allclose(got[:31], ref[:31], rtol=2e-5, atol=2e-5 * np.abs(ref[:31]).max())
