@@ -46,10 +46,27 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LIDAR_CFG = dict(voxel_size_m=0.4, search_alpha=0.5, num_nei_cells=2, query_nn_k=8, max_range=80.0, local_map_radius=82.0,
+                 window_radius=80.0, vox_down_m=0.08, source_vox_down_m=0.8, min_range=2.5, min_z=-5.0, max_z=80.0, deskew=True)
 WORKLOADS = {
-    # name: layers, hidden, levels
-    "c3": dict(layers=16, hidden=64, levels=4, desc="100k-pt scan, ~2.2M neural points, kNN=8, Kc=81, decoder 4x64"),
-    "c2": dict(layers=4, hidden=32, levels=2, desc="100k-pt scan, ~0.56M neural points, kNN=8, Kc=81, decoder 2x32"),
+    # BASELINE.json configs 2 / 3: LiDAR scan on wavy sheets 0.8 m apart in an 80 m disc
+    "c3": dict(layers=16, hidden=64, levels=4, scan=100_000, cfg=LIDAR_CFG, map=dict(),
+               desc="100k-pt scan, ~2.2M neural points, kNN=8, Kc=81, decoder 4x64"),
+    "c2": dict(layers=4, hidden=32, levels=2, scan=100_000, cfg=LIDAR_CFG, map=dict(),
+               desc="100k-pt scan, ~0.56M neural points, kNN=8, Kc=81, decoder 2x32"),
+    # BASELINE.json config 5 (config/rgbd_slam/run_replica.yaml): RGB-D frames, 5 cm voxels, colour + SDF decoders (1x64, the
+    # class defaults), k = 6, Kc = 33 (search_alpha 0.2), photometric registration, colour L1 in mapping; sheets 0.1 m apart
+    # in a 10 m room until ~5 M neural points
+    "c5": dict(layers=128, hidden=64, levels=1, scan=300_000, color=True,
+               map=dict(radius=5.64, raw_per_layer=200_000, sheets=(-6.4, 0.1, 0.03, 2.0)), scan_noise=0.005, pool_sigma=0.03,
+               cfg=dict(voxel_size_m=0.05, search_alpha=0.2, num_nei_cells=2, query_nn_k=6, max_range=10.0, local_map_radius=12.0,
+                        window_radius=10.0, vox_down_m=0.02, source_vox_down_m=0.06, min_range=0.05, min_z=-10.0, max_z=80.0,
+                        deskew=False, color_on=True, color_channel=3, photometric_loss_on=True, photometric_loss_weight=0.01,
+                        surface_sample_range_m=0.03, free_sample_end_dist_m=0.1, free_front_n=1, sigma_sigmoid_m=0.01,
+                        weight_e=0.2, reg_min_grad_norm=0.4, reg_max_grad_norm=2.5, reg_GM_grad=0.3, reg_GM_dist_m=0.05,
+                        eigenvalue_check=False),
+               desc="300k-pt RGB-D frame, ~5.3M neural points, 5 cm voxels, kNN=6, Kc=33, SDF + colour decoders 1x64, "
+                    "photometric registration, colour L1 in mapping"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA rate
@@ -65,7 +82,7 @@ def parse():
     ap.add_argument("--reg-iters", type=int, default=50)
     ap.add_argument("--map-iters", type=int, default=12)
     ap.add_argument("--bs", type=int, default=16384)
-    ap.add_argument("--scan", type=int, default=100_000)
+    ap.add_argument("--scan", type=int, default=None, help="points in the raw scan (default: the workload's, 100k / 300k)")
     ap.add_argument("--pool", type=int, default=2_000_000, help="samples in the pool (= pool_capacity)")
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,32 +141,38 @@ def main():
     from pin_slam_amd.dropin.utils.tracker import Tracker
 
     wl = WORKLOADS[args.workload]
-    H, L, k = wl["hidden"], wl["levels"], 8
+    H, L, k = wl["hidden"], wl["levels"], int(wl["cfg"]["query_nn_k"])
+    colour = bool(wl.get("color", False))
+    if args.scan is None:
+        args.scan = wl["scan"]
     mapper_dp = (world > 1 or args.force_dp) and args.parallel == "dp"
-    res = 0.4
+    res = wl["cfg"]["voxel_size_m"]
     n_frames = args.warmup + 2 * args.steps + 4
-    cfg = PinConfig(voxel_size_m=res, search_alpha=0.5, num_nei_cells=2, query_nn_k=k, buffer_size=int(5e7),
-                    feature_std=0.1, bs=args.global_bs if mapper_dp else args.bs, iters=args.map_iters, max_range=80.0,
-                    local_map_radius=82.0, window_radius=80.0, local_map_travel_dist_ratio=5.0, vox_down_m=0.08,
-                    source_vox_down_m=0.8, min_range=2.5, min_z=-5.0, max_z=80.0, deskew=True, pool_capacity=args.pool,
-                    pool_filter_freq=1, bs_new_sample=2048, geo_mlp_level=L, geo_mlp_hidden_dim=H, reg_iter_n=args.reg_iters)
+    cfg = PinConfig(buffer_size=int(5e7), feature_std=0.1, bs=args.global_bs if mapper_dp else args.bs, iters=args.map_iters,
+                    local_map_travel_dist_ratio=5.0, pool_capacity=args.pool, pool_filter_freq=1, bs_new_sample=2048,
+                    geo_mlp_level=L, geo_mlp_hidden_dim=H, color_mlp_level=L, color_mlp_hidden_dim=H,
+                    reg_iter_n=args.reg_iters, **wl["cfg"])
     torch.manual_seed(42)  # identical on every rank: the ranks must keep identical maps and draw identical batches
 
     # ---------------- synthetic map / scan / pool (identical on every rank) ----------------
-    m = synth.build_map(layers=wl["layers"], resolution=res)
+    m = synth.build_map(layers=wl["layers"], resolution=res, **wl["map"])
     npts = NeuralPoints(cfg)
     npts.travel_dist = torch.zeros(n_frames + 1, dtype=torch.float32, device="cuda")
     npts.update(torch.from_numpy(m.positions).cuda(), torch.zeros(3), torch.eye(3), 0)
     P = npts.count()
     dec = Decoder(cfg, H, L, 1)
-    decoders = {"sdf": dec, "semantic": None, "color": None}
+    cdec = Decoder(cfg, H, L, 3) if colour else None
+    decoders = {"sdf": dec, "semantic": None, "color": cdec}
     ds = Dataset(n_frames + 1)
     mp = Mapper(cfg, ds, npts, decoders)
     if mapper_dp:  # RCCL through the C ABI; torch.distributed only carries the ncclUniqueId (and this script's barriers)
         from pin_slam_amd import collective
         mp.dp_rank, mp.dp_world, mp.dp_comm = rank, world, collective.RcclComm(rank, world)
     trk = Tracker(cfg, npts, decoders)
-    pool_c, pool_l = synth.make_pool(m, n=args.pool)
+    pool_c, pool_l = synth.make_pool(m, n=args.pool, sigma=wl.get("pool_sigma", 0.25))
+    crng = np.random.default_rng(9)
+    if colour:
+        mp.color_pool = torch.from_numpy(crng.random((len(pool_l), 3), dtype=np.float32)).cuda()
     mp.coord_pool = torch.from_numpy(pool_c).cuda()
     mp.global_coord_pool = mp.coord_pool.clone()  # poses are identity in this workload
     mp.sdf_label_pool = torch.from_numpy(pool_l).cuda()
@@ -183,9 +206,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    scan_np = synth.make_scan(m, n=args.scan, seed=1)
+    scan_np = synth.make_scan(m, n=args.scan, seed=1, noise=wl.get("scan_noise", 0.02))
     rng = np.random.default_rng(5)
-    raw = torch.from_numpy(np.concatenate([scan_np, rng.random((args.scan, 1), dtype=np.float32)], 1)).cuda()
+    # rows of the raw scan: xyz + intensity (LiDAR) or xyz + rgb (RGB-D)
+    raw = torch.from_numpy(np.concatenate([scan_np, rng.random((args.scan, 3 if colour else 1), dtype=np.float32)], 1)).cuda()
     raw_ts = torch.from_numpy(rng.random(args.scan, dtype=np.float32)).cuda()
     last_odom = np.eye(4)
     last_odom[:3, 3] = [0.5, 0.0, 0.0]
@@ -196,7 +220,7 @@ def main():
     ang = 0.003
     T_init = np.eye(4)
     T_init[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
-    T_init[:3, 3] = [0.05, -0.04, 0.02]
+    T_init[:3, 3] = np.array([0.05, -0.04, 0.02]) * (res / 0.4)  # an eighth of a voxel off
     gp = trk._gn_params(cfg.reg_min_grad_norm, cfg.reg_max_grad_norm, cfg.reg_GM_dist_m, cfg.reg_GM_grad)
     prep = preprocess.ScanPreprocessor(cfg)
     pose_t = torch.eye(4, dtype=torch.float64, device="cuda")
@@ -238,15 +262,19 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
         if ev: ev[0].record()
         if args.stages == "all" or state["cloud"] is None:
-            pc, _, src, _ = prep(raw, raw_ts, last_odom_tran=last_odom, frame_id=fid)
+            _ = prep(raw, raw_ts, last_odom_tran=last_odom, frame_id=fid)
+            pc, src = _[0], _[2]
             state["cloud"], state["src"] = pc, src
             state["xyz"] = pc[:, :3].contiguous()
+            state["rgb"], state["src_rgb"] = (pc[:, 3:6].contiguous(), _[3]) if colour else (None, None)
         pc = state["cloud"]
         reg = state["src"] if source_downsampled else state["xyz"]
         if ev: ev[1].record()
         gn = trk._engine(reg.shape[0], gp, cfg.reg_lm_lambda)
         gn.on_knn, gn.on_gn = hooks
-        T, cnt, res_cm, its, _, _ = gn.track(reg, T_init, args.reg_iters, early_exit=False)
+        # colour term of the registration (photometric rows / consistency weights, tracker.py:492-518)
+        ct, _keep = trk._color_term(state["src_rgb"] if source_downsampled else state["rgb"]) if colour else (None, None)
+        T, cnt, res_cm, its, _, _ = gn.track(reg, T_init, args.reg_iters, early_exit=False, color=ct)
         gn.on_knn = gn.on_gn = None
         if ev: ev[2].record()
         if args.stages == "all":
@@ -288,7 +316,7 @@ def main():
     # map as it stands after the timed frames
     parity_in = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k)
+        parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k, rgb=state["rgb"])
 
     # achievable HBM ceiling on this box: a 1 GiB device-to-device copy (read + write), outside the timed regions
     ca = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
@@ -307,17 +335,18 @@ def main():
 
     # config C4 on ONE GPU (the N = 1 point of the data-parallel mapper curve): Mapper.mapping on a 2^20 batch
     c4 = None
-    if world == 1 and args.c4_iters > 0:
+    if world == 1 and args.c4_iters > 0 and not colour:
         c4 = c4_single_gpu(args, cfg, mp)
 
     knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
     gn_ms = float(np.mean([a.elapsed_time(b) for a, b in gn_pairs])) if gn_pairs else float("nan")
-    # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian
-    flops_q = 2 * 2 * (11 * H + (L - 1) * H * H + H)
+    # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian (colour: + the 3-head decoder)
+    flops_q = 2 * 2 * (11 * H + (L - 1) * H * H + H) + (2 * 2 * (11 * H + (L - 1) * H * H + 3 * H) if colour else 0)
     gn_tflops = flops_q * n_reg / (gn_ms * 1e-3) / 1e12
-    # what the matrix cores execute: every fp32 product as six bf16 piece products (mlp_bf3.h), layer 0 padded to K = 16
-    split_bf16 = os.environ.get("PIN_MLP", "") != "f32"
-    exec_flops_q = 6 * 2 * 2 * (16 * H + (L - 1) * H * H) if split_bf16 else 2 * 2 * (16 * H + (L - 1) * H * H)
+    # what the matrix cores execute: every fp32 product as six bf16 piece products (mlp_bf3.h), layer 0 padded to K = 16;
+    # the colour / per-neighbour kernel (64 queries per wave) stays on the fp32 MFMA
+    split_bf16 = os.environ.get("PIN_MLP", "") != "f32" and not colour
+    exec_flops_q = (6 if split_bf16 else 1) * (2 if colour else 1) * 2 * 2 * (16 * H + (L - 1) * H * H)
     exec_tflops = exec_flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     Kc = int(npts.neighbor_K)
     rho = nn_mean / Kc  # measured fraction of candidate cells holding an accepted neural point
@@ -363,7 +392,8 @@ def main():
         "source_points": n_src,
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
         "c4_single_gpu": c4,
-        "roofline": {"kernel": "gn_accumulate_quad_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
+        "roofline": {"kernel": "gn_accumulate_mfma_kernel (SDF + colour decoders, photometric rows; 64 queries per wave)"
+                               if colour else "gn_accumulate_quad_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
                      "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "traffic_source": pmc_src,
                      "avg_launch_ms": round(gn_ms, 4),
@@ -409,7 +439,7 @@ def main():
         dist.destroy_process_group()
 
 
-def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096):
+def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None):
     """Device side of bench.py's parity line: the timed kernels (brick kNN as the tracker launches it, then the
     GN tile kernel with per-point outputs) on `n` points of the timed scan, plus a host copy of the map state
     the oracle needs to answer the same queries."""
@@ -417,7 +447,8 @@ def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096):
     q = xyz[:n].contiguous()
     nbr, nn, _ = npts.knn(q, True)
     fs = npts.field_state(dec, query_locally=True)
-    _, sdf, grad = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True)
+    ct, _keep = trk._color_term(rgb[:n]) if rgb is not None else (None, None)
+    _, sdf, grad = ops.gn_accumulate(fs, gp, q, nbr, nn, want_points=True, color=ct)
     torch.cuda.synchronize()
     raw = nbr.cpu().numpy()[..., 3].view(np.int32)
     idx = np.where(raw >= 0, raw & ~0x40000000, raw)
@@ -530,7 +561,7 @@ def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, de
     n_s, bs_s = 20000, 4096
     # the oracle works on the synthetic map arrays directly (same voxels / hash as the device map)
     params = O.unpack_decoder(dec, 11, H, L)
-    dx, mv = O.search_neighborhood(2, 0.5, m.resolution)
+    dx, mv = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, m.resolution)
     q = scan[:n_s]
     table64 = m.table.astype(np.int64)
 
@@ -544,7 +575,8 @@ def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, de
             s = O.radius_search(p, table64, m.positions, m.resolution, dx, mv)
             return O.query_feature(p, s, feats, m.positions, None, k, weighted_first=False)
         O.train_step(pool_c[:bs_s], pool_l[:bs_s], np.ones(bs_s, np.float32), searcher, feats, m.positions, dec,
-                     (11, H, L), sdf_scale, k, dec=10, eps=0.08, dtype=np.float32)
+                     (11, H, L), sdf_scale, k, dec=10, eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, weight_e=cfg.weight_e,
+                     dtype=np.float32)
 
     def prep_and_map_prep():
         i1 = O.voxel_down_sample(raw[:, :3], cfg.vox_down_m)
@@ -556,16 +588,18 @@ def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, de
         O.deskewing(pc[i2][:, :3], ts[i2], T)
         n = len(pc)
         g = np.random.default_rng(0)
-        coord, label, _, w = O.sample_rays(pc[:, :3], None, g.standard_normal(3 * n, dtype=np.float32),
-                                           g.random(2 * n, dtype=np.float32), g.random(n, dtype=np.float32),
-                                           surface_range=cfg.surface_sample_range_m, surface_n=3, front_n=2, behind_n=1,
+        coord, label, _, w = O.sample_rays(pc[:, :3], None, g.standard_normal(cfg.surface_sample_n * n, dtype=np.float32),
+                                           g.random(cfg.free_front_n * n, dtype=np.float32),
+                                           g.random(cfg.free_behind_n * n, dtype=np.float32),
+                                           surface_range=cfg.surface_sample_range_m, surface_n=cfg.surface_sample_n,
+                                           front_n=cfg.free_front_n, behind_n=cfg.free_behind_n,
                                            free_begin_ratio=cfg.free_sample_begin_ratio, free_end_dist=cfg.free_sample_end_dist_m,
                                            max_range=cfg.max_range)
         glob = np.concatenate([pool_c, coord])
         O.pool_filter_mask(glob, np.zeros(3), cfg.window_radius)
         st = dict(table=table64.copy(), positions=m.positions, ts_create=np.zeros(len(m.positions), np.int32),
                   ts_update=np.zeros(len(m.positions), np.int32))
-        O.map_update(st, coord[np.abs(label) < 0.125], 1, m.resolution, temporal=False)
+        O.map_update(st, coord[np.abs(label) < cfg.surface_sample_range_m * cfg.map_surface_ratio], 1, m.resolution, temporal=False)
         O.query_certainty(coord, table64, m.positions, np.zeros(len(m.positions), np.float32), m.resolution)
 
     from threadpoolctl import threadpool_limits

@@ -12,6 +12,9 @@ from pin_slam_amd import ops, synth  # noqa: E402
 from pin_slam_amd._lib import GnParams  # noqa: E402
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+# optional: one query count and a repeat count (profiling runs: one launch shape per kernel), e.g. `16 98756 50`
+only_n = int(sys.argv[2]) if len(sys.argv) > 2 else None
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 H, L = (64, 4) if layers >= 16 else (32, 2)
 m = synth.build_map(layers=layers)
 P = len(m.positions)
@@ -34,7 +37,7 @@ bricks = ops.BrickCache(dx, 2).build(st, wait=True)
 fs.stage_decoder()  # as the tracker does once per registration
 
 
-def timeit(fn, n=30):
+def timeit(fn, n=reps):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -48,7 +51,7 @@ def timeit(fn, n=30):
 
 
 print("lib", _L.LIB_PATH)
-for n in (16 * 3072, 16 * 6144, 98756, 16 * 9216):
+for n in ((only_n,) if only_n else (16 * 3072, 16 * 6144, 98756, 16 * 9216)):
     s = torch.cat([scan, scan[: n - scan.shape[0]]]).contiguous() if n > scan.shape[0] else scan[:n].contiguous()
     nbr, nn, cur = ops.knn_query(st, s, 8, pose=np.eye(4), bricks=bricks)
     t_k = timeit(lambda: ops.knn_query(st, s, 8, pose=np.eye(4), out=(nbr, nn, cur), bricks=bricks))
