@@ -98,7 +98,8 @@ typedef struct pin_brick_cache {
     uint64_t* brick_keys;    /* [max_bricks] */
     uint64_t* brick_mask;    /* [max_bricks] occupancy of the 4x4x4 cells, bit = (x&3)<<4|(y&3)<<2|(z&3) */
     int32_t*  brick_base;    /* [max_bricks] first entry of the brick */
-    float*    entries;       /* [max_entries][4] x, y, z, neighbour-index bits (as in the kNN record) */
+    float*    entries;       /* [max_entries + 1][4] x, y, z, neighbour-index bits (as in the kNN record); row max_entries is
+                                a sentinel (+inf coordinates) written by pin_brick_build: what an empty cell reads */
     const int32_t* cand_dx;  /* [n_cand][3] candidate cell offsets (neighbor_dx, neural_points.py:919-932) */
     uint32_t dir_mask;       /* directory size - 1 (size is a power of two) */
     int32_t max_bricks;

@@ -144,10 +144,12 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin
     }
 }
 
-__global__ void brick_clear_kernel(unsigned long long* keys, int n, int* counters) {
+__global__ void brick_clear_kernel(unsigned long long* keys, int n, int* counters, float4* entries, int max_entries) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = BRICK_EMPTY;
     if (i < 4) counters[i] = 0;
+    // the sentinel entry behind the last real one: what an empty cell reads in the query kernel (rejected by distance)
+    if (i == 0) entries[max_entries] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(-1));
 }
 
 // ---- query ----------------------------------------------------------------------------------
@@ -174,19 +176,72 @@ __global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) 
     pack[2 * (size_t)h + 1] = make_ulonglong2(base, 0ull);
 }
 
-// G lanes per query (8 or 16), R = ceil(n_cand / G) candidates per lane
-template <int R, int G>
+// T = tx | ty << 3 | tz << 6 (t = position of a candidate cell inside the query's 2x2x2-brick window, 0..7 per axis)
+//   -> byte offset of the window brick's header row entry (select * 16) << 6 | bit of the cell in the brick's mask
+struct KnnLut {
+    unsigned short v[512];
+    constexpr KnnLut() : v() {
+        for (int i = 0; i < 512; ++i) {
+            const int tx = i & 7, ty = (i >> 3) & 7, tz = i >> 6;
+            const int sel = ((tx >> 2) << 2) | ((ty >> 2) << 1) | (tz >> 2);
+            v[i] = (unsigned short)(((sel * 16) << 6) | ((tx & 3) << 4) | ((ty & 3) << 2) | (tz & 3));
+        }
+    }
+};
+__device__ const KnnLut KNN_LUT;
+
+// one candidate cell of the cached path: header row of its brick -> offset of its entry, or of the sentinel entry
+// (at index max_entries: +inf coordinates, rejected by the distance test) when the cell holds nothing
+__device__ __forceinline__ unsigned int knn_cell_offset(const unsigned short* __restrict__ lut, const char* __restrict__ hrow,
+                                                       unsigned int T, unsigned int sentinel) {
+    const unsigned int v = lut[T];
+    const uint4 h = *reinterpret_cast<const uint4*>(hrow + (v >> 6));  // (base, mask lo, mask hi, base + popc(lo))
+    const unsigned int bit = v & 63u;
+    const bool upper = bit >= 32u;
+    const unsigned int word = upper ? h.z : h.y;
+    const unsigned int below = word & __builtin_amdgcn_ubfe(0xffffffffu, 0u, bit);  // (v_bfe_u32 takes the width mod 32)
+    const unsigned int off = (upper ? h.w : h.x) + (unsigned int)__popc(below);
+    return __builtin_amdgcn_ubfe(word, bit, 1u) != 0u ? off : sentinel;
+}
+
+// EIGHT lanes per query, R = ceil(n_cand / 8) candidate cells per lane.
+//
+// The kernel is bound by its vector-instruction count (PMC r01 / r02: 17 M per 98.7k-query launch = 28 of 32 us of every
+// SIMD), so the candidate pass is written for few instructions per cell:
+//   * the cell arithmetic is ONE add per candidate: with p = (cell(q) - n_dilate) & 3 per axis (per query) and the
+//     candidate's offset + n_dilate (0..4), t = p + d in 0..7 gives the window brick (t >> 2) and the position inside it
+//     (t & 3) for all three axes from one packed word T = P + D (3-bit fields, no carries);
+//   * (header offset, mask bit) of T come from a 512-entry table, the candidate's packed offset D from another, the 8
+//     window bricks of the query (base, 64-bit occupancy, base + popcount(low word)) from a per-query LDS row the 8
+//     lanes fill once: one 16-byte LDS read per candidate instead of three cross-lane shuffles;
+//   * an empty cell reads a sentinel entry with +inf coordinates: no occupancy bits to carry to the distance pass;
+//   * cells of window bricks that are not cached (absent from the directory, or dropped) need the reference's exact
+//     probe: that pass runs only in waves that hold such a brick.
+// Results are the same bits as before (tests: bricks == direct probe == reference on the fixtures and at 2.2 M points).
+// (Measured and not kept: per-lane pre-extraction of the three smallest distances so that a selection round only
+// compares heads -- 26.2 vs 26.8 us, not worth the refill logic.)
+template <int R>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,
                                                                 float* __restrict__ query_out, float4* __restrict__ nbr,
                                                                 int* __restrict__ nn_count, const double* __restrict__ state) {
+    constexpr int G = 8;
+    __shared__ unsigned short lut[512];
+    __shared__ unsigned int cpack[128];                 // candidate -> (dx + nd) | (dy + nd) << 3 | (dz + nd) << 6
+    __shared__ uint4 hdr[BRICK_BLOCK / G][8];           // per query: its 2x2x2 window bricks
     if (state != nullptr) {
-        if (state[PIN_GN_STATE_DONE] != 0.0) return;
+        if (state[PIN_GN_STATE_DONE] != 0.0) return;  // (block-uniform)
 #pragma unroll
         for (int i = 0; i < 12; ++i) pose.m[i] = (float)state[i];
         pose.on = 1;
     }
-    const int sub = threadIdx.x & (G - 1);
+    const int nd = bc.n_dilate;
+    reinterpret_cast<unsigned int*>(lut)[threadIdx.x] = reinterpret_cast<const unsigned int*>(KNN_LUT.v)[threadIdx.x];
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x < sp.n_cand ? threadIdx.x : 0;
+        cpack[threadIdx.x] = (unsigned int)((bc.cand_dx[3 * c] + nd) | ((bc.cand_dx[3 * c + 1] + nd) << 3) | ((bc.cand_dx[3 * c + 2] + nd) << 6));
+    }
+    const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
     const bool active = qi < n;
     const int qq = active ? qi : n - 1;
@@ -201,75 +256,67 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
             query_out[3 * qi + 0] = qx; query_out[3 * qi + 1] = qy; query_out[3 * qi + 2] = qz;
         }
     }
-    const long long gx = voxel_coord(qx, sp.resolution), gy = voxel_coord(qy, sp.resolution),
-                    gz = voxel_coord(qz, sp.resolution);
-    const int nd = bc.n_dilate;
-    // the cached path works on 32-bit cell coordinates; anything farther than 2^29 cells from the
-    // origin (never the case for a metric map) takes the exact 64-bit probe for every candidate
-    const long long lim = 1LL << 29;
-    const bool far = gx >= lim || gx < -lim || gy >= lim || gy < -lim || gz >= lim || gz < -lim;
-    const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
-    const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
-    // lanes 0..7 resolve the 2x2x2 bricks that cover the candidate window
-    int my_base = -1;  // -1: brick not cached
-    unsigned int my_lo = 0, my_hi = 0;
-    if (sub < 8 && !far) {  // (every lane when G == 8)
-        const int bx = b0x + (sub >> 2), by = b0y + ((sub >> 1) & 1), bz = b0z + (sub & 1);
-        const BrickInfo bi = dir_lookup(bc, brick_key(bx, by, bz));
-        my_base = bi.base; my_lo = bi.lo; my_hi = bi.hi;
+    // floor(q / res) as in voxel_coord (IEEE division); the cached path works on 32-bit cell coordinates, anything
+    // farther than 2^29 cells from the origin (never the case for a metric map) takes the exact 64-bit probe
+    float fx, fy, fz;
+    {
+#pragma clang fp contract(off)
+        fx = floorf(__fdiv_rn(qx, sp.resolution)); fy = floorf(__fdiv_rn(qy, sp.resolution)); fz = floorf(__fdiv_rn(qz, sp.resolution));
     }
-    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+    const float lim = 536870912.f;  // 2^29
+    const bool far = !(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim);
+    const int ix = far ? 0 : (int)fx, iy = far ? 0 : (int)fy, iz = far ? 0 : (int)fz;
+    const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
+    const unsigned int P = (unsigned int)(((ix - nd) & 3) | (((iy - nd) & 3) << 3) | (((iz - nd) & 3) << 6));
+    bool uncached;
+    {   // lane `sub` resolves window brick (sub >> 2, (sub >> 1) & 1, sub & 1) with one 32-byte directory load
+        BrickInfo bi;
+        bi.base = -1; bi.lo = 0; bi.hi = 0;
+        if (!far) bi = dir_lookup(bc, brick_key(b0x + (sub >> 2), b0y + ((sub >> 1) & 1), b0z + (sub & 1)));
+        uncached = bi.base < 0;
+        if (uncached) { bi.lo = 0; bi.hi = 0; }  // its cells miss in the cached pass and are probed exactly below
+        hdr[grp][sub] = make_uint4((unsigned int)bi.base, bi.lo, bi.hi, (unsigned int)bi.base + (unsigned int)__popc(bi.lo));
+    }
+    const bool general = __builtin_amdgcn_ballot_w64(uncached) != 0ull;  // some window brick of the wave is not cached
+    __syncthreads();
     const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+    const char* const hrow = reinterpret_cast<const char*>(&hdr[grp][0]);
+    const unsigned int sentinel = (unsigned int)bc.max_entries;
 
     // accepted candidates: only the distance bits stay (registers); the k winners' entries are fetched
     // again at the end (cache hits), one winner per lane.  The candidate pass is straight-line: every lane
-    // issues its R entry loads back to back (an empty cell reads a dummy slot), so a wave pays one memory
-    // round trip for all rounds instead of one per round; cells of uncached bricks are left to a second,
-    // rarely taken pass with the reference's exact probe.
+    // issues its R entry loads back to back, so a wave pays one memory round trip for all of them.
     unsigned int d2b[R];
     float4 E[R];
-    unsigned int occ = 0, slow = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int c = r * G + sub;
-        const bool has = c < sp.n_cand;
-        const int cc = has ? c : 0;
-        const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
-        const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
-        const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
-        // all 16 lanes take part in the shuffles
-        const int base = __shfl(my_base, sel & 7, G);
-        const unsigned int lo = __shfl(my_lo, sel & 7, G);
-        const unsigned int hi = __shfl(my_hi, sel & 7, G);
-        const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
-        const unsigned int word = bit < 32 ? lo : hi;
-        const bool hit = has && base >= 0 && ((word >> (bit & 31)) & 1u);
-        const unsigned int below = word & ((1u << (bit & 31)) - 1u);
-        const int off = base + __popc(below) + (bit < 32 ? 0 : __popc(lo));
-        const float4* src = hit ? entries + off : reinterpret_cast<const float4*>(bc.dir_pack);
-        E[r] = *src;
-        occ |= (hit ? 1u : 0u) << r;
-        slow |= ((has && base < 0) ? 1u : 0u) << r;
+        unsigned int off = knn_cell_offset(lut, hrow, P + cpack[c & 127], sentinel);
+        if (r == R - 1) off = c < sp.n_cand ? off : sentinel;  // (only the last round can run past the candidate list)
+        E[r] = entries[off];
     }
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
         const float d2 = dist2_exact(dx, dy, dz);
-        const bool acc = ((occ >> r) & 1u) && !(d2 > sp.max_valid_dist2);
+        const bool acc = !(d2 > sp.max_valid_dist2);  // (the sentinel gives +inf)
         d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;  // d2 >= 0: the bit pattern orders like the value
         cnt += acc ? 1 : 0;
     }
-    if (slow != 0) {  // exact slow path for uncached bricks
+    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+    const long long gx = (long long)fx, gy = (long long)fy, gz = (long long)fz;  // (used by the exact probe only)
+    if (general) {  // exact probe for the cells of uncached window bricks (rare: map border, a cache that overflowed)
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
-            if (!((slow >> r) & 1u)) continue;
             const int c = r * G + sub;
+            if (c >= sp.n_cand) continue;
+            if (!far && (int)hdr[grp][lut[P + cpack[c]] >> 10].x >= 0) continue;  // cached brick: done above
             const int dxc = bc.cand_dx[3 * c], dyc = bc.cand_dx[3 * c + 1], dzc = bc.cand_dx[3 * c + 2];
-            float4 P;
+            float4 Pp;
             int l = -1;
-            if (!lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, P, l)) continue;
-            const float dx = P.x - qx, dy = P.y - qy, dz = P.z - qz;
+            if (!lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, Pp, l)) continue;
+            const float dx = Pp.x - qx, dy = Pp.y - qy, dz = Pp.z - qz;
             const float d2 = dist2_exact(dx, dy, dz);
             if (d2 > sp.max_valid_dist2) continue;
 #pragma unroll
@@ -280,7 +327,7 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     cnt = (int)group_sum_u32<G>((unsigned int)cnt);
     if (active && sub == 0) nn_count[qi] = cnt;
 
-    // k rounds of a 16-lane tournament on (d2 bits, candidate order): two 32-bit row reductions
+    // k rounds of an 8-lane tournament on (d2 bits, candidate order): two 32-bit group reductions
     // on the DPP path per round (no LDS crossbar, no 64-bit keys); lane t remembers winner t
     int mine = -1;
     for (int t = 0; t < k; ++t) {
@@ -293,7 +340,7 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         if (wd == 0xffffffffu) break;
         const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
         const unsigned int wc = group_min_u32<G>(myc);
-        if (myc == wc) {  // exactly one lane of the row
+        if (myc == wc) {  // exactly one lane of the group
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (r == br) d2b[r] = 0xffffffffu;
@@ -303,26 +350,18 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     // lane t < k publishes record t: the winner's entry again (same bits as in the candidate pass)
     {
         const int cc = mine >= 0 ? mine : 0;
-        const int dxc = bc.cand_dx[3 * cc], dyc = bc.cand_dx[3 * cc + 1], dzc = bc.cand_dx[3 * cc + 2];
-        const int cx = ix + dxc, cy = iy + dyc, cz = iz + dzc;
-        const int sel = (((cx >> 2) - b0x) << 2) | (((cy >> 2) - b0y) << 1) | ((cz >> 2) - b0z);
-        const int base = __shfl(my_base, sel & 7, G);
-        const unsigned int lo = __shfl(my_lo, sel & 7, G);
-        const unsigned int hi = __shfl(my_hi, sel & 7, G);
+        const unsigned int T = P + cpack[cc];
         float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (mine >= 0) {
-            float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 Ew = make_float4(0.f, 0.f, 0.f, 0.f);
             int l = -1;
-            if (base >= 0) {
-                const int bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
-                const unsigned int word = bit < 32 ? lo : hi;
-                const unsigned int below = word & ((1u << (bit & 31)) - 1u);
-                E = entries[base + __popc(below) + (bit < 32 ? 0 : __popc(lo))];
-                l = __float_as_int(E.w);
+            if (!far && (int)hdr[grp][lut[T] >> 10].x >= 0) {
+                Ew = entries[knn_cell_offset(lut, hrow, T, sentinel)];
+                l = __float_as_int(Ew.w);
             } else {
-                lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, E, l);
+                lookup_cell(sp, gx + bc.cand_dx[3 * cc], gy + bc.cand_dx[3 * cc + 1], gz + bc.cand_dx[3 * cc + 2], d_cur, Ew, l);
             }
-            const float dx = E.x - qx, dy = E.y - qy, dz = E.z - qz;
+            const float dx = Ew.x - qx, dy = Ew.y - qy, dz = Ew.z - qz;
             rec = make_float4(-dx, -dy, -dz, __int_as_float(l));
         }
         if (active && sub < k) nbr[(size_t)qq * k + sub] = rec;
@@ -340,11 +379,12 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     PIN_CHECK_ARG(bc->dir_keys && bc->dir_vals && bc->brick_keys && bc->brick_mask && bc->brick_base && bc->entries && bc->dir_pack,
                   "brick cache buffers NULL");
     PIN_CHECK_ARG((bc->dir_mask & (bc->dir_mask + 1)) == 0 && bc->dir_mask > 0, "directory size must be a power of two");
-    PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 3, "n_dilate must be in [0, 3]");
+    PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 2, "n_dilate must be in [0, 2]");
     hipStream_t s = as_stream(stream);
     const int D = (int)bc->dir_mask + 1;
     hipLaunchKernelGGL(brick_clear_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s,
-                       reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out);
+                       reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out,
+                       reinterpret_cast<float4*>(bc->entries), bc->max_entries);
     hipLaunchKernelGGL(brick_mark_kernel, dim3(cdiv(sp->n_points, 256)), dim3(256), 0, s, *bc, *sp, bc->n_dilate,
                        counters_out);
     // a probing query sits within (n+1) cells (per axis) of the cell centre and accepts points
@@ -390,25 +430,17 @@ static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, co
     if (pose.on) memcpy(pose.m, pose_host, sizeof(pose.m));
     float4* nbr = reinterpret_cast<float4*>(nbr_out);
     hipStream_t s = as_stream(stream);
-    // Eight lanes per query while a lane's candidate list stays short: the per-query setup and the k rounds of
-    // the selection tournament are shared by twice as many queries per wave (the kernel is VALU-bound).
-    static const int forced = [] { const char* e = getenv("PIN_KNN_GROUP"); return e ? atoi(e) : 0; }();
-    const int G = sp->n_cand > 128 ? 16 : (forced == 8 || forced == 16 ? forced : 8);
-    const dim3 grid(cdiv((long)n * G, BRICK_BLOCK)), block(BRICK_BLOCK);
-    const int rounds = cdiv(sp->n_cand, G);
-#define PIN_LAUNCH_KB(R, GG) \
-    hipLaunchKernelGGL((knn_brick_kernel<R, GG>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
-    if (G == 8) {
-        if (rounds <= 4) PIN_LAUNCH_KB(4, 8);
-        else if (rounds <= 8) PIN_LAUNCH_KB(8, 8);
-        else if (rounds <= 11) PIN_LAUNCH_KB(11, 8);
-        else PIN_LAUNCH_KB(16, 8);
-    } else {
-        if (rounds <= 3) PIN_LAUNCH_KB(3, 16);
-        else if (rounds <= 6) PIN_LAUNCH_KB(6, 16);
-        else if (rounds <= 10) PIN_LAUNCH_KB(10, 16);
-        else PIN_LAUNCH_KB(16, 16);
-    }
+    // eight lanes per query (the per-query setup and the k selection rounds are shared by 8 queries per wave)
+    PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 2 && sp->n_cand <= 125, "the brick cache covers num_nei_cells <= 2");
+    const dim3 grid(cdiv((long)n * 8, BRICK_BLOCK)), block(BRICK_BLOCK);
+    const int rounds = cdiv(sp->n_cand, 8);
+#define PIN_LAUNCH_KB(R) \
+    hipLaunchKernelGGL((knn_brick_kernel<R>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
+    if (rounds <= 4) PIN_LAUNCH_KB(4);
+    else if (rounds <= 5) PIN_LAUNCH_KB(5);
+    else if (rounds <= 8) PIN_LAUNCH_KB(8);
+    else if (rounds <= 11) PIN_LAUNCH_KB(11);
+    else PIN_LAUNCH_KB(16);
 #undef PIN_LAUNCH_KB
     PIN_CHECK_LAUNCH();
     return 0;

@@ -130,7 +130,7 @@ class BrickCache:
         self.brick_keys = torch.empty(max_bricks, dtype=torch.int64, device=d)
         self.brick_mask = torch.empty(max_bricks, dtype=torch.int64, device=d)
         self.brick_base = torch.empty(max_bricks, dtype=torch.int32, device=d)
-        self.entries = torch.empty((max_entries, 4), dtype=torch.float32, device=d)
+        self.entries = torch.empty((max_entries + 1, 4), dtype=torch.float32, device=d)  # + the sentinel row (pin_brick_build)
         self.max_bricks, self.max_entries, self.dsize = max_bricks, max_entries, dsize
 
     def params(self) -> "_lib.BrickCacheC":
