@@ -54,6 +54,12 @@ WORKLOADS = {
                desc="100k-pt scan, ~2.2M neural points, kNN=8, Kc=81, decoder 4x64"),
     "c2": dict(layers=4, hidden=32, levels=2, scan=100_000, cfg=LIDAR_CFG, map=dict(),
                desc="100k-pt scan, ~0.56M neural points, kNN=8, Kc=81, decoder 2x32"),
+    # config/lidar_slam/run_kitti.yaml style: per-neighbour decoding (weighted_first False: the decoder runs k times per
+    # query and the spread of the k predictions gates the registration), class-default 1x64 decoder, k = 6, Kc = 33
+    "kitti": dict(layers=16, hidden=64, levels=1, scan=100_000, map=dict(),
+                  cfg=dict(LIDAR_CFG, query_nn_k=6, search_alpha=0.2, weighted_first=False),
+                  desc="100k-pt scan, ~2.2M neural points, weighted_first=False (per-neighbour decoding), kNN=6, Kc=33, "
+                       "decoder 1x64"),
     # BASELINE.json config 5 (config/rgbd_slam/run_replica.yaml): RGB-D frames, 5 cm voxels, colour + SDF decoders (1x64, the
     # class defaults), k = 6, Kc = 33 (search_alpha 0.2), photometric registration, colour L1 in mapping; sheets 0.1 m apart
     # in a 10 m room until ~5 M neural points
@@ -342,10 +348,12 @@ def main():
     gn_ms = float(np.mean([a.elapsed_time(b) for a, b in gn_pairs])) if gn_pairs else float("nan")
     # fused SDF + Jacobian + GN kernel: decoder flops per query, forward + input Jacobian (colour: + the 3-head decoder)
     flops_q = 2 * 2 * (11 * H + (L - 1) * H * H + H) + (2 * 2 * (11 * H + (L - 1) * H * H + 3 * H) if colour else 0)
+    if not cfg.weighted_first:
+        flops_q *= k  # the decoder runs once per neighbour
     gn_tflops = flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     # what the matrix cores execute: every fp32 product as six bf16 piece products (mlp_bf3.h), layer 0 padded to K = 16;
     # the colour / per-neighbour kernel (64 queries per wave) stays on the fp32 MFMA
-    split_bf16 = os.environ.get("PIN_MLP", "") != "f32" and not colour
+    split_bf16 = os.environ.get("PIN_MLP", "") != "f32" and not colour and cfg.weighted_first
     exec_flops_q = (6 if split_bf16 else 1) * (2 if colour else 1) * 2 * 2 * (16 * H + (L - 1) * H * H)
     exec_tflops = exec_flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     Kc = int(npts.neighbor_K)
@@ -393,7 +401,9 @@ def main():
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
         "c4_single_gpu": c4,
         "roofline": {"kernel": "gn_accumulate_mfma_kernel (SDF + colour decoders, photometric rows; 64 queries per wave)"
-                               if colour else "gn_accumulate_quad_kernel", "bound": "mfma", "achieved": round(gn_tflops, 2),
+                               if colour else ("gn_accumulate_quad_kernel" if cfg.weighted_first else
+                                               "gn_accumulate_mfma_kernel (per-neighbour decoding; 64 queries per wave)"),
+                     "bound": "mfma", "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
                      "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "traffic_source": pmc_src,
                      "avg_launch_ms": round(gn_ms, 4),

@@ -286,4 +286,189 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
 }
 
 
+
+// ---- per-neighbour decoding (weighted_first = False: run_kitti.yaml and eight more shipped configs) ---------------
+// The decoder runs once per NEIGHBOUR (k times the work of the interpolate-first mode) and the spread of the k
+// predictions gates the registration (tracker.py:317-328).  In the quad layout a decoder column is a (query, neighbour)
+// pair: a 16-column tile holds 2 queries x 8 neighbour slots, lane (n, g) = column n = 8 * (query of the tile) + t,
+// component group g.  No interpolation before the decoder: the lane's input components ARE its neighbour's feature
+// half-row / relative position.  Everything that mixes the neighbours of a query -- IDW normalisation, the weighted
+// mean / spread of the predictions, the gradient terms -- is a sum over the 8 consecutive lanes of the query inside a
+// DPP row (three DPP steps, no LDS).  The 32 lanes of a query hold its result; lane (t, g) keeps Gauss-Newton sum
+// 4 t + g, picked by a per-lane selector that is built once.
+__device__ __forceinline__ float octet_sum(float v) {  // over aligned groups of 8 lanes
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    return v;
+}
+
+constexpr int NWF_BLOCK = 512;  // 2 waves per SIMD (up to 256 VGPRs: the two-deep prefetch state needs ~190)
+
+template <int H, bool ORIENT, bool BF, int LC>
+__global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pin_field f, pin_gn_params gp,
+                                                                             const float* __restrict__ query,
+                                                                             const float4* __restrict__ nbr,
+                                                                             const int* __restrict__ nn_count,
+                                                                             const float* __restrict__ labels, int n_q,
+                                                                             double* __restrict__ sums, float* __restrict__ sdf_out,
+                                                                             float* __restrict__ grad_out,
+                                                                             const double* __restrict__ state) {
+    using Q = QuadDec<H, BF>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];
+    unsigned char* const lds = gq_smem;
+    float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));  // [NWF_BLOCK / 64]
+    if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
+    if (BF && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        const int n16 = f.dec_image_bytes >> 4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n16; i += NWF_BLOCK) dst[i] = src[i];
+    } else {
+        Q::stage(f.dec, f.levels, lds, threadIdx.x, NWF_BLOCK);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int q2 = nq >> 3, t = nq & 7;
+    const int kk = f.k;
+    const float s = f.sdf_scale;
+    // which Gauss-Newton sum this lane keeps: i = 4 t + g.  v_i = W * A * B with (tracker.py:652-671)
+    //   i < 21: J_a J_b (upper triangle, row-major), W = w      21..26: J_a * res, W = w      27: w      28: |res|
+    //   29: 1 (count)      30: w res^2      31: unused
+    const int si = 4 * t + g;
+    float ea[6], eb[6];
+    float ea_res = 0.f, ea_one = 0.f, eb_res = 0.f, eb_abs = 0.f, eb_one = 0.f, wsel = 0.f;
+    {
+        int a = -1, b = -1;
+        if (si < 21) {
+            int o = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j, ++o)
+                    if (o == si) { a = i; b = j; }
+            wsel = 1.f;
+        } else if (si < 27) { a = si - 21; eb_res = 1.f; wsel = 1.f; }
+        else if (si == 27) { ea_one = 1.f; eb_one = 1.f; wsel = 1.f; }
+        else if (si == 28) { ea_one = 1.f; eb_abs = 1.f; }
+        else if (si == 29) { ea_one = 1.f; eb_one = 1.f; }
+        else if (si == 30) { ea_res = 1.f; eb_res = 1.f; wsel = 1.f; }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { ea[j] = a == j ? 1.f : 0.f; eb[j] = b == j ? 1.f : 0.f; }
+    }
+    const float4* __restrict__ rows = reinterpret_cast<const float4*>(f.feats) + (g & 1);
+    const bool is_feat = g < 2;
+    const float mv = g == 2 ? 1.f : 0.f;
+    const int n_tiles = (n_q + 1) >> 1;
+    const int n_simd = gridDim.x * 4;
+    const int simd = blockIdx.x * 4 + (wave & 3);
+    float tot = 0.f;
+    // A tile is two dependent memory round trips (record -> feature row) followed by ~0.2 us of arithmetic: the loop is
+    // software-pipelined two tiles deep (records of tile i + 2 and the feature rows of tile i + 1 are in flight while
+    // tile i is decoded), otherwise the kernel is bound by memory latency (measured: 58.7 us -> see DESIGN).
+    const int stride = n_simd * (NWF_BLOCK / 256);
+    struct Head { float px, py, pz; int nn, qi; float4 e; bool active; };
+    auto fetch_head = [&](int tile, Head& h) {
+        h.qi = tile * 2 + q2;
+        h.active = tile < n_tiles && h.qi < n_q;
+        const int qq = h.active ? h.qi : n_q - 1;
+        h.px = query[3 * qq]; h.py = query[3 * qq + 1]; h.pz = query[3 * qq + 2];
+        h.nn = nn_count[qq];
+        h.e = nbr[(size_t)qq * kk + (t < kk ? t : 0)];
+    };
+    auto row_of = [&](const Head& h) -> float4 {
+        const int raw = __float_as_int(h.e.w);
+        const int id = (t < kk && raw >= 0) ? (raw & ~PIN_NBR_QUIRK_BIT) : 0;
+        return rows[2 * (size_t)(unsigned int)id];
+    };
+    const int tile0 = simd + n_simd * (wave >> 2);
+    Head h0, h1, h2;
+    fetch_head(tile0, h0);
+    fetch_head(tile0 + stride, h1);
+    float4 ft0 = row_of(h0), ft1;
+    for (int tile = tile0; tile < n_tiles; tile += stride) {
+        fetch_head(tile + 2 * stride, h2);
+        ft1 = row_of(h1);
+        const int qi = h0.qi;
+        const bool active = h0.active;
+        const float px = h0.px, py = h0.py, pz = h0.pz;
+        const int nn = h0.nn;
+        const float4 e = h0.e;
+        const float4 ft = ft0;
+        h0 = h1; h1 = h2; ft0 = ft1;
+        const int raw = __float_as_int(e.w);
+        const bool val = t < kk && raw >= 0;
+        const int id = val ? (raw & ~PIN_NBR_QUIRK_BIT) : 0;
+        const float u = val ? __builtin_amdgcn_rcpf(dist2_exact(e.x, e.y, e.z) + IDW_EPS) : 0.f;
+        const float S = octet_sum((nn == 0 && t < kk) ? IDW_EPS : u);
+        const float invS = 1.0f / S;
+        const float wt = u * invS;
+        float v[3] = {e.x, e.y, e.z};
+        float Rm[9];
+        const bool flagged = val && (raw & PIN_NBR_QUIRK_BIT) != 0;
+        if (ORIENT || __builtin_amdgcn_ballot_w64(flagged) != 0ull) {  // after PGO / a flagged neighbour in the wave (rare)
+            if (val) neighbor_vector(f, id, flagged, e.x, e.y, e.z, px, py, pz, v, Rm);
+        }
+        float z[4], a[4];
+        z[0] = is_feat ? ft.x : mv * v[0];
+        z[1] = is_feat ? ft.y : mv * v[1];
+        z[2] = is_feat ? ft.z : mv * v[2];
+        z[3] = is_feat ? ft.w : 0.f;
+        const float x = Q::template run<LC>(lds, f.levels, z, a);  // this neighbour's prediction, d x / d its input
+        // ---- across the neighbours of the query (eval_query, weighted_first = False)
+        const float st = s * x;
+        const float mean = octet_sum(wt * st);
+        const float dv = st - mean;
+        const float sd = sqrtf(octet_sum(wt * dv * dv));  // tracker.py:317-322
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // w_t * d x_t / d q through the relative position (lane g == 2)
+        if (g == 2) {
+            if constexpr (ORIENT) {
+                if (val) {
+                    d0 = wt * (Rm[0] * a[0] + Rm[3] * a[1] + Rm[6] * a[2]);
+                    d1 = wt * (Rm[1] * a[0] + Rm[4] * a[1] + Rm[7] * a[2]);
+                    d2 = wt * (Rm[2] * a[0] + Rm[5] * a[1] + Rm[8] * a[2]);
+                }
+            } else { d0 = wt * a[0]; d1 = wt * a[1]; d2 = wt * a[2]; }
+        }
+        d0 = quad_lanes_sum(octet_sum(d0)); d1 = quad_lanes_sum(octet_sum(d1)); d2 = quad_lanes_sum(octet_sum(d2));
+        const float cg = -2.f * u * u;  // d u_t / d q = cg * (q - P_t); through the weights: sum_t (s_t - mean) d w_t
+        const float cs = cg * st;
+        const float ax = octet_sum(cs * e.x), ay = octet_sum(cs * e.y), az = octet_sum(cs * e.z);
+        const float Gx = octet_sum(cg * e.x), Gy = octet_sum(cg * e.y), Gz = octet_sum(cg * e.z);
+        const float gx = s * d0 + (ax - mean * Gx) * invS;
+        const float gy = s * d1 + (ay - mean * Gy) * invS;
+        const float gz = s * d2 + (az - mean * Gz) * invS;
+        if (active) {
+            if (t == 0 && g == 0) {
+                if (sdf_out) sdf_out[qi] = mean;
+                if (grad_out) { grad_out[3 * qi] = gx; grad_out[3 * qi + 1] = gy; grad_out[3 * qi + 2] = gz; }
+            }
+            const float gn = sqrtf(gx * gx + gy * gy + gz * gz);
+            const bool valid = nn >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm && sd < gp.max_sdf_std;
+            if (valid) {
+                const float res = mean - (labels ? labels[qi] : 0.f);
+                float wgt = 1.f;
+                if (gp.gm_grad > 0.f) { const float d = gn - 1.f; const float tt = gp.gm_grad / (gp.gm_grad + d * d); wgt *= tt * tt; }
+                if (gp.gm_dist > 0.f) { const float tt = gp.gm_dist / (gp.gm_dist + res * res); wgt *= tt * tt; }
+                float J[6];
+                J[0] = py * gz - pz * gy; J[1] = pz * gx - px * gz; J[2] = px * gy - py * gx;
+                J[3] = gx; J[4] = gy; J[5] = gz;
+                float A = fmaf(ea_res, res, ea_one), B = fmaf(eb_res, res, fmaf(eb_abs, fabsf(res), eb_one));
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { A = fmaf(ea[j], J[j], A); B = fmaf(eb[j], J[j], B); }
+                tot += (wsel != 0.f ? wgt : 1.f) * A * B;
+            }
+        }
+    }
+    // the two queries of a tile sit in lanes n and n ^ 8: add them, lane (q2 = 0, t, g) then holds sum 4 t + g of the wave
+    tot += dpp_mov<0x128>(tot);  // row_ror:8
+    if (q2 == 0) red[wave][si] = tot;
+    __syncthreads();
+    if (threadIdx.x < PIN_GN_NSUMS) {
+        double tt = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWF_BLOCK / 64; ++w) tt += (double)red[w][threadIdx.x];
+        if (tt != 0.0) atomicAdd(sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS + threadIdx.x, tt);
+    }
+}
+
 }  // namespace pin

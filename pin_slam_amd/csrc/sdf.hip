@@ -680,6 +680,35 @@ static int launch_quad_ho(const pin_field* f, const pin_gn_params* gp, const flo
 #undef PIN_LQ
 }
 
+// weighted_first = False: a decoder column per (query, neighbour) pair, 2 queries per 16-column tile (gn_quad.h)
+template <int H, bool ORIENT, bool BF, int LC>
+static int launch_quad_nwf_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                                const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                                float* grad_out, const double* state, hipStream_t s) {
+    constexpr int lds_bytes = gq_red_offset(QuadDec<H, BF>::bytes(1)) + (NWF_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_nwf_kernel<H, ORIENT, BF, LC>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    const int tiles = cdiv(n, 2);
+    const dim3 grid(min(gq_cu_count(), cdiv(tiles, NWF_BLOCK / 64))), block(NWF_BLOCK);
+    hipLaunchKernelGGL((gn_accumulate_quad_nwf_kernel<H, ORIENT, BF, LC>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
+                       labels, n, sums, sdf_out, grad_out, state);
+    return 0;
+}
+
+// one H-wide layer only (the class default 1x64 that every shipped weighted_first = False config uses); deeper
+// decoders with per-neighbour decoding stay on the 64-queries-per-wave kernel
+static int launch_quad_nwf(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                           const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                           float* grad_out, const double* state, hipStream_t s) {
+#define PIN_LQ(HH, OO) \
+    return use_bf3_decoder() ? launch_quad_nwf_inst<HH, OO, true, 1>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s) \
+                             : launch_quad_nwf_inst<HH, OO, false, 0>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
+    if (f->hidden == 64) { if (f->orient) PIN_LQ(64, true); else PIN_LQ(64, false); }
+    if (f->orient) PIN_LQ(32, true); else PIN_LQ(32, false);
+#undef PIN_LQ
+}
+
 static int launch_quad(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                        const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                        float* grad_out, const double* state, hipStream_t s) {
@@ -710,7 +739,9 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     if (f->weighted_first && ct.mode == 0) {  // four lanes per query, persistent blocks (gn_quad.h)
         if (int e = launch_quad(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
-    } else {  // per-neighbour decoding / colour term: 64 queries per wave
+    } else if (!f->weighted_first && ct.mode == 0 && f->levels == 1) {  // per-neighbour decoding: a column per (query, neighbour) pair
+        if (int e = launch_quad_nwf(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
+    } else {  // colour term, per-neighbour decoding with a deeper decoder: 64 queries per wave
         const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
         PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
                         sdf_out, grad_out, state, ct);

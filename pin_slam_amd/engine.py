@@ -71,7 +71,7 @@ class GNTracker:
         self.sums.zero_()
         sp = self.st.params(time_filtering=time_filtering, local=local)
         # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder)
-        if self.fs.weighted_first and color is None:
+        if color is None:  # (the colour term runs on the 64-queries-per-wave kernel, which stages for itself)
             self.fs.stage_decoder()
         f = self.fs.params()
         bc = None
