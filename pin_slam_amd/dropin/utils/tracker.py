@@ -1,7 +1,9 @@
 """Drop-in for the reference's ``utils.tracker.Tracker`` (utils/tracker.py:21): same constructor
 and ``tracking`` / ``registration_step`` / ``query_source_points`` signatures, executed by the
-fused HIP kernels (kNN with the pose applied in-kernel, SDF + analytic Jacobian + Gauss-Newton
-sums) with one 16 KiB read-back and a float64 6x6 solve per iteration."""
+fused HIP kernels.  ``tracking`` runs the whole Gauss-Newton loop on the device (per iteration: kNN with the pose
+read from the device state, SDF + analytic Jacobian + normal-equation sums, a one-wave 6x6 solve with the
+reference's validity / convergence rules) and reads back 512 bytes once per call; ``registration_step`` is the
+host-driven single step (one read-back of the sums, float64 solve on the host)."""
 from __future__ import annotations
 
 import math
