@@ -806,25 +806,34 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
 }
 
 // Lazy exact Adam for the feature tables.  The dense step moves every row that has been touched since the
-// optimiser reset (momentum), but a row's values only matter when a query reads it.  So per iteration only the
-// rows in the kNN records are visited: (phase 0, before the forward pass) a row last advanced at step l < t-1
-// replays the gradient-free steps l+1 .. t-1 it skipped; (phase 1, after the backward pass) it takes step t with
-// its gradient; rows that were touched and then left alone are replayed to the final step once, at the end
-// (adam_lazy_flush_kernel).  Every element goes through the same sequence of adam_elem calls as in the dense
-// schedule, hence bit-identical tables (tests/test_gpu_parity.py); first-touch rows start from m = v = 0
-// without the state arrays ever being cleared.  One owner per row and phase via an atomicMax stamp.
-__global__ __launch_bounds__(256) void adam_lazy_records_kernel(const float4* __restrict__ nbr, long n_records,
+// optimiser reset (momentum), but a row's values only matter when a query reads it -- and its own step can wait
+// until then as well.  Per iteration ONE launch visits the rows in the kNN records, before the forward pass
+// (adam_lazy_prepare_kernel): a row that was last read at iteration a still owes step a (its gradient is sitting
+// in `g`); it takes that step now, then replays the gradient-free steps a+1 .. t-1, and is marked as owing step t.
+// Rows that were touched and then left alone settle their pending step and the replay up to the final step once,
+// at the end (adam_lazy_flush_kernel).  Every element goes through the same sequence of adam_elem calls as in the
+// dense schedule, hence bit-identical tables (tests/test_gpu_parity.py); first-touch rows start from m = v = 0
+// without the state arrays ever being cleared.  One owner per row and launch via an atomicMax stamp.
+// pend[row]: 0 = untouched since the reset; -a = owes step a, moment arrays not valid yet (first step); +a = owes step a.
+__device__ __forceinline__ void lazy_settle(float& pi, float& mi, float& vi, float gi, int pend, int upto,
+                                            const float* __restrict__ coef, int t_max, float b1, float b2, float eps) {
+    const int a = pend < 0 ? -pend : pend;
+    adam_elem(pi, mi, vi, gi, coef[a], coef[t_max + 1 + a], b1, b2, eps);
+    for (int s = a + 1; s <= upto; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
+}
+
+__global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __restrict__ nbr, long n_records,
                                                                 float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
-                                                                int* __restrict__ last, int* __restrict__ claim, int step,
-                                                                int phase, int stamp, const float* __restrict__ coef, int t_max,
+                                                                int* __restrict__ pend, int* __restrict__ claim, int step,
+                                                                int stamp, const float* __restrict__ coef, int t_max,
                                                                 float b1, float b2, float eps, int rec_blocks,
-                                                                pin_adam_dense dense) {
-    if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `step`
+                                                                pin_adam_dense dense, int dense_step) {
+    if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
         const long e = (long)((int)blockIdx.x - rec_blocks) * 256 + threadIdx.x;
         if (e < dense.n) {
             float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
-            adam_elem(pi, mi, vi, dense.grad[e], coef[step], coef[t_max + 1 + step], b1, b2, eps);
+            adam_elem(pi, mi, vi, dense.grad[e], coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
             dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
             dense.grad[e] = 0.f;
         }
@@ -841,37 +850,43 @@ __global__ __launch_bounds__(256) void adam_lazy_records_kernel(const float4* __
     if (row >= 0 && j == 0) own = atomicMax(claim + row, stamp) < stamp ? 1 : 0;
     own = __shfl(own, lane & ~7, 64);  // the 8 lanes of a record follow their leader
     if (!own) return;
-    const int l = last[row];
-    const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
-    if (phase == 0) {
-        if (l >= 1 && l < step - 1) {
-            float pi = p[i], mi = m[i], vi = v[i];
-            for (int s = l + 1; s <= step - 1; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
-            p[i] = pi; m[i] = mi; v[i] = vi;
-            if (j == 0) last[row] = step - 1;
-        }
-    } else {
+    const int n = pend[row];
+    if (n != 0) {
+        const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
         float pi = p[i], mi = 0.f, vi = 0.f;
-        if (l != 0) { mi = m[i]; vi = v[i]; }  // first touch since the reset: the state starts at zero
-        adam_elem(pi, mi, vi, g[i], coef[step], coef[t_max + 1 + step], b1, b2, eps);
+        if (n > 0) { mi = m[i]; vi = v[i]; }
+        lazy_settle(pi, mi, vi, g[i], n, step - 1, coef, t_max, b1, b2, eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
         g[i] = 0.f;
-        if (j == 0) last[row] = step;
     }
+    if (j == 0) pend[row] = n == 0 ? -step : step;
 }
 
-__global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ m,
-                                                              float* __restrict__ v, const int* __restrict__ last, long n,
-                                                              int t_final, const float* __restrict__ coef, int t_max, float b1,
-                                                              float b2, float eps) {
+__global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              const int* __restrict__ pend, long n, int t_final,
+                                                              const float* __restrict__ coef, int t_max, float b1, float b2,
+                                                              float eps, int row_blocks, pin_adam_dense dense) {
+    if ((int)blockIdx.x >= row_blocks) {  // the dense tensor's last step
+        const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (e < dense.n) {
+            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
+            adam_elem(pi, mi, vi, dense.grad[e], coef[t_final], coef[t_max + 1 + t_final], b1, b2, eps);
+            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
+            dense.grad[e] = 0.f;
+        }
+        return;
+    }
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
+    const long stride = (long)row_blocks * 256;
     for (; i < n; i += stride) {
-        const int l = last[i / PIN_FEATURE_DIM];
-        if (l < 1 || l >= t_final) continue;
-        float pi = p[i], mi = m[i], vi = v[i];
-        for (int s = l + 1; s <= t_final; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
+        const int nn = pend[i / PIN_FEATURE_DIM];
+        if (nn == 0) continue;
+        float pi = p[i], mi = 0.f, vi = 0.f;
+        if (nn > 0) { mi = m[i]; vi = v[i]; }
+        lazy_settle(pi, mi, vi, g[i], nn, t_final, coef, t_max, b1, b2, eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        g[i] = 0.f;
     }
 }
 
@@ -1108,40 +1123,47 @@ extern "C" int pin_adam_step_rows(float* param, float* grad, float* exp_avg, flo
     return 0;
 }
 
-extern "C" int pin_adam_lazy_records(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
-                                     float* exp_avg_sq, int32_t* last_step, int32_t* claim, int32_t step, int32_t phase,
-                                     int32_t stamp, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                                     const pin_adam_dense* dense, void* stream) {
-    PIN_ENTER();
-    PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max && (phase == 0 || phase == 1), "bad step / phase");
-    pin_adam_dense d;
+static int lazy_dense(const pin_adam_dense* dense, const float* coef, pin_adam_dense& d) {
     memset(&d, 0, sizeof(d));
     if (dense != nullptr && dense->n > 0) {
-        PIN_CHECK_ARG(phase == 1, "a dense tensor rides along with the step (phase 1) only");
         PIN_CHECK_ARG(dense->param && dense->grad && dense->exp_avg && dense->exp_avg_sq && coef, "dense tensor: NULL pointer");
         d = *dense;
     }
+    return 0;
+}
+
+extern "C" int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
+                                     float* exp_avg_sq, int32_t* pending, int32_t* claim, int32_t step, int32_t stamp,
+                                     const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                                     const pin_adam_dense* dense, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max, "bad step");
+    pin_adam_dense d;
+    if (int e = lazy_dense(step > 1 ? dense : nullptr, coef, d)) return e;  // (nothing to step before the first iteration)
     if (n_records == 0 && d.n == 0) return 0;
-    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && last_step && claim && coef), "NULL pointer");
+    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && pending && claim && coef), "NULL pointer");
     const int rec_blocks = (int)cdiv(n_records * 8, 256), dense_blocks = (int)cdiv(d.n, 256);
-    hipLaunchKernelGGL(adam_lazy_records_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, last_step, claim,
-                       step, phase, stamp, coef, t_max, beta1, beta2, eps, rec_blocks, d);
+    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, pending, claim,
+                       step, stamp, coef, t_max, beta1, beta2, eps, rec_blocks, d, step - 1);
     PIN_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int pin_adam_lazy_flush(float* param, float* exp_avg, float* exp_avg_sq, const int32_t* last_step, int64_t n_rows,
-                                   int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                                   void* stream) {
+extern "C" int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* pending,
+                                   int64_t n_rows, int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2,
+                                   float eps, const pin_adam_dense* dense, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n_rows >= 0 && t_final >= 0 && t_final <= t_max, "bad sizes");
-    if (n_rows == 0 || t_final == 0) return 0;
-    PIN_CHECK_ARG(param && exp_avg && exp_avg_sq && last_step && coef, "NULL pointer");
+    if (t_final == 0) return 0;
+    pin_adam_dense d;
+    if (int e = lazy_dense(dense, coef, d)) return e;
+    if (n_rows == 0 && d.n == 0) return 0;
+    PIN_CHECK_ARG(n_rows == 0 || (param && grad && exp_avg && exp_avg_sq && pending && coef), "NULL pointer");
     const long n = (long)n_rows * PIN_FEATURE_DIM;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, exp_avg, exp_avg_sq,
-                       last_step, n, t_final, coef, t_max, beta1, beta2, eps);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), dense_blocks = (int)cdiv(d.n, 256);
+    hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks + dense_blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg,
+                       exp_avg_sq, pending, n, t_final, coef, t_max, beta1, beta2, eps, blocks, d);
     PIN_CHECK_LAUNCH();
     return 0;
 }

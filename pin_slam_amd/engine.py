@@ -202,7 +202,11 @@ class MapTrainer:
         batch's queries (written by the gather launch)."""
         nd = self.gdec.numel()
         lazy = self.lazy_on
-        pre = (lambda: self.lazy.catch_up(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step)) if lazy else None
+        # lazy exact Adam: ONE launch per iteration, before the forward pass -- the rows this iteration reads settle the
+        # step they still owe from the iteration that last read them (+ the gradient-free steps since), and the decoder's
+        # step of the previous iteration rides along in the same launch
+        dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
+        pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
@@ -210,20 +214,18 @@ class MapTrainer:
                        bricks=self.bricks, before_forward=pre, queries_ready=queries_ready)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
+            cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
             if lazy:
-                self.lazy_c.catch_up(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step)
+                self.lazy_c.prepare(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
             ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                  self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
                                  weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
-            if lazy:
-                cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
-                self.lazy_c.step(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
-            else:
+            if not lazy:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
                                    eps=self.adam_eps)
-            if self.c_train_dec and not lazy:
-                ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
+                if self.c_train_dec:
+                    ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.comm is not None:  # SUM of the per-rank gradients of [decoder | features] (pin_allreduce_grads)
             if self.on_allreduce is not None:
                 self.on_allreduce(True)
@@ -232,9 +234,8 @@ class MapTrainer:
                 self.on_allreduce(False)
         if self.on_grads is not None:
             self.on_grads(self.grad)
-        if lazy:  # (the decoder's dense step rides along in the same launch)
-            dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
-            self.lazy.step(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)
+        if lazy:
+            pass  # (this iteration's steps are taken by the next prepare() / by finish_optimizer())
         elif self.comm is None:
             ops.mark_rows(self.buf.nbr, self.dirty)
             ops.adam_step_rows(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], self.dirty, step, self.lr, eps=self.adam_eps)
@@ -259,7 +260,11 @@ class MapTrainer:
             self.m.zero_()
             self.v.zero_()
             self.dirty.zero_()
-        self.grad.zero_()
+        # after a lazy mapping() call the gradient buffer is already clean: every settled step clears its gradient and
+        # the final flush settles every touched row and the decoder
+        if not getattr(self, "_grad_clean", False):
+            self.grad.zero_()
+        self._grad_clean = False
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             if self.lazy_on:
@@ -276,10 +281,13 @@ class MapTrainer:
         if not self.lazy_on:
             return
         nd = self.gdec.numel()
-        self.lazy.flush(self.fs.feats, self.m[nd:], self.v[nd:])
+        dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
+        self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
-            self.lazy_c.flush(self.fc.feats, self.cm[cnd:], self.cv[cnd:])
+            cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
+            self.lazy_c.flush(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], dense=cdense)
+        self._grad_clean = self.train_decoder  # (a frozen decoder's gradient slot is never written either, but keep it simple)
         self.lazy_on = False
 
     def mapping(self, index_batches):

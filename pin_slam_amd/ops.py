@@ -471,7 +471,8 @@ def adam_coef(lr, t_max, beta1=0.9, beta2=0.99, device="cuda"):
 class LazyAdam:
     """Exact Adam over an 8-wide feature table that only visits the rows an iteration reads (pin_adam_lazy_*):
     bit-identical to adam_step over the whole table every iteration.  reset() per Mapper.mapping call,
-    catch_up(records, t) before the forward pass, step(records, t) after the backward pass, flush() at the end."""
+    prepare(records, t) before the forward pass of iteration t (a row settles the step it still owes from the iteration
+    that last read it, then the gradient-free steps in between), flush() at the end."""
 
     def __init__(self, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15):
         self.lr, self.b1, self.b2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
@@ -486,36 +487,38 @@ class LazyAdam:
         self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
         self.t, self.stamp = 0, 0
 
-    def _records(self, nbr, param, grad, m, v, step, phase, dense=None):
-        self.stamp += 1
-        d = None
-        if dense is not None:  # (param, grad, exp_avg, exp_avg_sq) of a dense tensor stepped in the same launch
-            d = _lib.AdamDense()
-            d.param, d.grad, d.exp_avg, d.exp_avg_sq = (_ptr(t, torch.float32) for t in dense)
-            d.n = dense[0].numel()
-        check(_lib.lib().pin_adam_lazy_records(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
-                                               _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
-                                               self.state[0].data_ptr(), self.state[1].data_ptr(), int(step), phase,
-                                               self.stamp, _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
-                                               C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_records")
+    @staticmethod
+    def _dense(dense):
+        if dense is None:
+            return None
+        d = _lib.AdamDense()
+        d.param, d.grad, d.exp_avg, d.exp_avg_sq = (_ptr(t, torch.float32) for t in dense)
+        d.n = dense[0].numel()
+        return d
 
-    def catch_up(self, nbr, param, grad, m, v, step):
+    def prepare(self, nbr, param, grad, m, v, step, dense=None):
+        """`dense` = (param, grad, exp_avg, exp_avg_sq) of a dense tensor (the decoder): its step `step - 1` rides along
+        in the same launch (identical to adam_step(..., step - 1, lr) with zero_grad); nothing at step 1."""
         if step > self.t_max:
             raise ValueError("more iterations than reset() was sized for")
-        self._records(nbr, param, grad, m, v, step, 0)
-
-    def step(self, nbr, param, grad, m, v, step, dense=None):
-        """`dense` = (param, grad, exp_avg, exp_avg_sq): the same Adam step on a dense tensor (the decoder) in the
-        same launch, identical to adam_step(..., step, lr) with zero_grad."""
-        self._records(nbr, param, grad, m, v, step, 1, dense)
+        self.stamp += 1
+        d = self._dense(dense)
+        check(_lib.lib().pin_adam_lazy_prepare(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
+                                               _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
+                                               self.state[0].data_ptr(), self.state[1].data_ptr(), int(step), self.stamp,
+                                               _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
+                                               C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_prepare")
         self.t = int(step)
 
-    def flush(self, param, m, v):
+    def flush(self, param, grad, m, v, dense=None):
+        """Settle every touched row (and the dense tensor's last step) at the step of the last prepare()."""
         if self.t == 0:
             return
-        check(_lib.lib().pin_adam_lazy_flush(_ptr(param, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
-                                             self.state[0].data_ptr(), param.shape[0], self.t, _ptr(self.coef), self.t_max,
-                                             self.b1, self.b2, self.eps, _stream()), "pin_adam_lazy_flush")
+        d = self._dense(dense)
+        check(_lib.lib().pin_adam_lazy_flush(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(m, torch.float32),
+                                             _ptr(v, torch.float32), self.state[0].data_ptr(), param.shape[0], self.t,
+                                             _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
+                                             C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_flush")
         self.t = 0
 
 

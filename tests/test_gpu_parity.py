@@ -341,10 +341,12 @@ def test_sparse_adam_is_bit_identical_to_dense():
 
 @pytest.mark.parametrize("steps", [1, 12, 70])
 def test_lazy_adam_is_bit_identical_to_dense(steps):
-    """ops.LazyAdam (catch-up before the forward pass, step after the backward pass, flush at the end)
-    against the dense pin_adam_step every iteration: the parameter table is equal bit for bit at the end,
-    and at every iteration the rows about to be read hold their dense values.  The m / v arrays start
-    as garbage on the lazy side (it never clears them); 70 steps goes beyond the default table size."""
+    """ops.LazyAdam (ONE launch per iteration, before the forward pass: the rows about to be read settle the step they
+    still owe and the gradient-free steps since; flush at the end) against the dense pin_adam_step every iteration:
+    at every iteration the rows about to be read hold their dense values, and after the flush the parameter table and
+    the moments of every touched row are equal bit for bit.  The m / v arrays start as garbage on the lazy side (it
+    never clears them); 70 steps goes beyond the default table size.  A dense tensor (the decoder) rides along: after
+    prepare(t) it holds its value of step t - 1, after the flush that of the last step."""
     from pin_slam_amd import ops
     torch.manual_seed(steps)
     rows, k, Q = 30_000, 8, 1500
@@ -359,6 +361,7 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
     d0 = torch.randn(1337, device="cuda")
     dec_a = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
     dec_b = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
+    gb = torch.zeros_like(d0)
     for step in range(1, steps + 1):
         idx = torch.randint(0, rows, (Q, k), device="cuda")
         idx[torch.rand(Q, k, device="cuda") < 0.2] = -1
@@ -367,22 +370,26 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
         nbr = torch.zeros((Q, k, 4), dtype=torch.float32, device="cuda")
         nbr.view(torch.int32)[..., 3] = idx.to(torch.int32)
         valid = torch.unique(idx[idx >= 0])
-        lazy.catch_up(nbr, pl, gl, ml, vl, step)
+        lazy.prepare(nbr, pl, gl, ml, vl, step, dense=(dec_b[0], gb, dec_b[1], dec_b[2]))
         assert torch.equal(pl[valid].view(torch.int32), pd[valid].view(torch.int32)), step  # what the forward pass reads
+        assert not gl[valid].any()  # the settled gradients were cleared
+        for x, y in zip(dec_a, dec_b):  # the dense tensor: its step of the previous iteration was taken
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        # "backward pass": this iteration's gradients of the rows it read
         g = torch.zeros_like(p0)
         g[valid] = torch.randn(valid.numel(), 8, device="cuda")
-        gd.copy_(g); gl.copy_(g)
+        gd.copy_(g)
+        gl += g  # (rows read earlier and not since still hold their own pending gradient)
         ops.adam_step(pd, gd, md, vd, step, 0.01, eps=1e-15)
-        # a dense tensor (the decoder) rides along with the step launch: same bits as its own adam_step
         gdec = torch.randn(1337, device="cuda")
-        ga, gb = gdec.clone(), gdec.clone()
+        ga = gdec.clone()
+        gb.copy_(gdec)
         ops.adam_step(dec_a[0], ga, dec_a[1], dec_a[2], step, 0.01, eps=1e-15)
-        lazy.step(nbr, pl, gl, ml, vl, step, dense=(dec_b[0], gb, dec_b[1], dec_b[2]))
-        assert not gl.any() and not gb.any()
-        for x, y in zip(dec_a, dec_b):
-            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
         touched[valid] = True
-    lazy.flush(pl, ml, vl)
+    lazy.flush(pl, gl, ml, vl, dense=(dec_b[0], gb, dec_b[1], dec_b[2]))
+    assert not gl.any() and not gb.any()
+    for x, y in zip(dec_a, dec_b):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     assert torch.equal(pd.view(torch.int32), pl.view(torch.int32))
     assert torch.equal(md[touched].view(torch.int32), ml[touched].view(torch.int32))
     assert torch.equal(vd[touched].view(torch.int32), vl[touched].view(torch.int32))
