@@ -76,7 +76,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA rate
-BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 
 
 def parse():
@@ -351,10 +351,10 @@ def main():
     if not cfg.weighted_first:
         flops_q *= k  # the decoder runs once per neighbour
     gn_tflops = flops_q * n_reg / (gn_ms * 1e-3) / 1e12
-    # what the matrix cores execute: every fp32 product as six bf16 piece products (mlp_bf3.h), layer 0 padded to K = 16;
+    # what the matrix cores execute: every fp32 product as three fp16 piece products (mlp_h2.h), layer 0 padded to K = 16;
     # the colour / per-neighbour kernel (64 queries per wave) stays on the fp32 MFMA
-    split_bf16 = os.environ.get("PIN_MLP", "") != "f32" and not colour and cfg.weighted_first
-    exec_flops_q = (6 if split_bf16 else 1) * (2 if colour else 1) * 2 * 2 * (16 * H + (L - 1) * H * H)
+    split_f16 = os.environ.get("PIN_MLP", "") != "f32" and not colour and cfg.weighted_first
+    exec_flops_q = (3 if split_f16 else 1) * (2 if colour else 1) * 2 * 2 * (16 * H + (L - 1) * H * H)
     exec_tflops = exec_flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     Kc = int(npts.neighbor_K)
     rho = nn_mean / Kc  # measured fraction of candidate cells holding an accepted neural point
@@ -409,15 +409,16 @@ def main():
                      "avg_launch_ms": round(gn_ms, 4),
                      "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,
                      "share_of_frame": round(gn_ms * args.reg_iters / ms_step, 3),
-                     "arithmetic": ("fp32 factors split exactly into 3 bf16 pieces, 6 piece products per fp32 product on "
-                                    "v_mfma_f32_16x16x32_bf16, fp32 accumulate; `achieved`/`peak` are fp32-equivalent")
-                                   if split_bf16 else "v_mfma_f32_16x16x4_f32",
+                     "arithmetic": ("fp32 factors split into 2 fp16 pieces (hi + 2^-11 lo, representation error <= 2^-24), 3 piece "
+                                    "products per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulate; "
+                                    "`achieved`/`peak` are fp32-equivalent")
+                                   if split_f16 else "v_mfma_f32_16x16x4_f32",
                      "limiter": "vector-ALU + MFMA issue, additive on gfx950 (scripts/mfma_valu_overlap.hip)",
                      "valu_insts_per_launch": gnk.get("SQ_INSTS_VALU"),
                      "mfma_busy_cycles_per_launch": gnk.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                      "executed": {"flops_per_query": exec_flops_q, "tflops": round(exec_tflops, 1),
-                                  "peak": BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS,
-                                  "frac": round(exec_tflops / (BF16_PEAK_TFLOPS if split_bf16 else FP32_PEAK_TFLOPS), 4)}},
+                                  "peak": F16_PEAK_TFLOPS if split_f16 else FP32_PEAK_TFLOPS,
+                                  "frac": round(exec_tflops / (F16_PEAK_TFLOPS if split_f16 else FP32_PEAK_TFLOPS), 4)}},
         "roofline_knn": {"kernel": "knn_brick_kernel" if npts._bricks is not None else "knn_query_kernel",
                          "bound": "valu", "bound_note": "vector-ALU instruction issue (PMC), not HBM: the fabric traffic "
                                                         "is below the algorithmic bytes; the GB/s figure is the "

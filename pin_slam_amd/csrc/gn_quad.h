@@ -18,7 +18,7 @@
 // within one tile.  The weight image is staged once per block.
 #pragma once
 #include "brick.h"
-#include "mlp_bf3.h"
+#include "mlp_h2.h"
 
 namespace pin {
 
@@ -130,12 +130,12 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
 }
 
 // decoder on the matrix cores -> chain rule -> Gauss-Newton terms of the tile; tot[j] += sum 4j + g
-template <int H, bool ORIENT, bool BF = false, int LC = 0>
+template <int H, bool ORIENT, bool SPLIT = false, int LC = 0>
 __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_params& gp, const unsigned char* __restrict__ lds,
                                             const QuadIn<ORIENT>& in, int nn, float px, float py, float pz, bool active, int qi,
                                             int g, const float* __restrict__ labels, float* __restrict__ sdf_out,
                                             float* __restrict__ grad_out, float (&tot)[8]) {
-    using Q = QuadDec<H, BF>;
+    using Q = QuadDec<H, SPLIT>;
     const float s = f.sdf_scale;
     const float (&z)[4] = in.z;
     const float (&Y)[3][4] = in.Y;
@@ -208,9 +208,9 @@ __host__ __device__ constexpr int gq_lds_bytes(int image_bytes) {
     return gq_red_offset(image_bytes) + (GQ_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
 }
 
-// LC: the number of H-wide layers when the split-bf16 decoder is used (compile time: both sweeps unrolled);
+// LC: the number of H-wide layers when the split-fp16 decoder is used (compile time: both sweeps unrolled);
 // 0 with the fp32 image, which reads it from the field
-template <int H, bool ORIENT, bool BF, int LC>
+template <int H, bool ORIENT, bool SPLIT, int LC>
 __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_field f, pin_gn_params gp,
                                                                          const float* __restrict__ query,
                                                                          const float4* __restrict__ nbr,
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
                                                                          double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                          float* __restrict__ grad_out,
                                                                          const double* __restrict__ state) {
-    using Q = QuadDec<H, BF>;
+    using Q = QuadDec<H, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];  // decoder image, then the block reduction
     unsigned char* const lds = gq_smem;
     float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
     // weights: copy the image staged once per registration (pin_stage_decoder) or split them here; either way the
     // image is visible after the barrier that follows the first gather
-    if (BF && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+    if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         const int n16 = f.dec_image_bytes >> 4;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
             staged = true;
             if (!work) break;
         }
-        quad_finish<H, ORIENT, BF, LC>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
+        quad_finish<H, ORIENT, SPLIT, LC>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
     }
     __builtin_amdgcn_s_setprio(0);
     // wave: sum over the 16 queries of the row; lane (0, g) then holds sums 4j + g
@@ -305,7 +305,7 @@ __device__ __forceinline__ float octet_sum(float v) {  // over aligned groups of
 
 constexpr int NWF_BLOCK = 512;  // 2 waves per SIMD (up to 256 VGPRs: the two-deep prefetch state needs ~190)
 
-template <int H, bool ORIENT, bool BF, int LC>
+template <int H, bool ORIENT, bool SPLIT, int LC>
 __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pin_field f, pin_gn_params gp,
                                                                              const float* __restrict__ query,
                                                                              const float4* __restrict__ nbr,
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
                                                                              double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                              float* __restrict__ grad_out,
                                                                              const double* __restrict__ state) {
-    using Q = QuadDec<H, BF>;
+    using Q = QuadDec<H, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];
     unsigned char* const lds = gq_smem;
     float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));  // [NWF_BLOCK / 64]
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
-    if (BF && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+    if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         const int n16 = f.dec_image_bytes >> 4;

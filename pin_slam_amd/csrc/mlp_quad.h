@@ -1,6 +1,6 @@
 // The shallow-MLP decoder on the fp32 matrix cores for ONE 16-query tile per wave, four lanes per query:
-// lane (n, g) owns decoder-input components 4g..4g+3 of query n (see gn_quad.h for why).  Shared by the
-// Gauss-Newton tile kernel (gn_quad.h) and the training kernels (train.hip).
+// lane (n, g) owns decoder-input components 4g..4g+3 of query n (see gn_quad.h for why).  The fp32 image is the
+// A/B reference (PIN_MLP=f32) of the split-fp16 decoder in mlp_h2.h.
 #pragma once
 #include "mlp_mfma.h"
 
@@ -173,88 +173,6 @@ struct QuadDecoder {
         }
         input_backward(w, h, a);
         return x;
-    }
-
-    // ---------------------------------------------------------------- training: forward with stores
-    // Post-ReLU activations go to the workspace unit-major (row l*H + unit, column = query) for the
-    // weight-gradient GEMM; the ReLU mask of a query and layer is one 64-bit word, 16 bits per lane g.
-    __device__ __forceinline__ static float forward_store(const float* __restrict__ w, int L, const float (&z)[4],
-                                                          float* __restrict__ hws, size_t Qs, size_t q,
-                                                          unsigned long long* __restrict__ mws, size_t mask_stride) {
-        const int lane = threadIdx.x & 63, g = lane >> 4;
-        v4f_t h[MT], acc[MT];
-        auto store = [&](int l, unsigned int mm) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hws[((size_t)l * H + 16 * mt + 4 * g + r) * Qs + q] = h[mt][r];
-            reinterpret_cast<unsigned short*>(mws + (size_t)l * mask_stride + q)[g] = (unsigned short)mm;
-        };
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = *reinterpret_cast<const v4f_t*>(w + D::OFF_B0 + 16 * mt + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[OFF_A0Q + (mt * 4 + r) * 64 + lane], z[r], acc[mt], 0, 0, 0);
-        store(0, relu16(acc, h));
-        for (int l = 1; l < L; ++l) {
-            hidden_forward(w + D::OFF_HID + (l - 1) * D::HID_SZ, h, acc);
-            store(l, relu16(acc, h));
-        }
-        const float* __restrict__ O = w + D::off_out(L);
-        float x = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
-        }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
-        return x + O[MF_OD_MAX * H];
-    }
-
-    // ------------------------------------------------------------------- training: backward with stores
-    // dx = d loss / d head output of this lane's query; layer deltas are written unit-major for the
-    // weight-gradient GEMM; dz[r] = d loss / d z[4g + r].
-    __device__ __forceinline__ static void backward_store(const float* __restrict__ w, int L, float dx,
-                                                          const unsigned long long* __restrict__ mws, size_t mask_stride,
-                                                          float* __restrict__ dws, size_t Qs, size_t q, bool store,
-                                                          float (&dz)[4]) {
-        const int lane = threadIdx.x & 63, g = lane >> 4;
-        v4f_t h[MT], acc[MT];
-        // the ReLU masks of all layers are fetched up front (one round trip instead of one per layer) and kept
-        // as one 64-bit word: a register array indexed by the runtime layer would go to scratch memory
-        unsigned long long all = 0;
-#pragma unroll
-        for (int l = 0; l < MLP_MAX_LEVELS; ++l)
-            all |= (unsigned long long)reinterpret_cast<const unsigned short*>(mws + (size_t)(l < L ? l : 0) * mask_stride + q)[g]
-                   << (16 * l);
-        auto mask_of = [&](int l) { return (unsigned int)(all >> (16 * l)) & 0xffffu; };
-        auto put = [&](int l) {
-            if (!store) return;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dws[((size_t)l * H + 16 * mt + 4 * g + r) * Qs + q] = h[mt][r];
-        };
-        const float* __restrict__ O = w + D::off_out(L);
-        {
-            const unsigned int mm = mask_of(L - 1);
-#pragma unroll
-            for (int kt = 0; kt < MT; ++kt) {
-                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[kt][r] = ((mm >> (kt * 4 + r)) & 1u) ? dx * wo[r] : 0.f;
-            }
-        }
-        put(L - 1);
-        for (int l = L - 1; l >= 1; --l) {
-            hidden_backward(w + D::OFF_HID + (l - 1) * D::HID_SZ, mask_of(l - 1), h, acc);
-            put(l - 1);
-        }
-        input_backward(w, h, dz);
     }
 };
 

@@ -649,17 +649,17 @@ static int gq_cu_count() {
     return n_cu;
 }
 
-template <int H, bool ORIENT, bool BF, int LC>
+template <int H, bool ORIENT, bool SPLIT, int LC>
 static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                             const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                             float* grad_out, const double* state, hipStream_t s) {
-    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, BF>::bytes(LC > 0 ? LC : MLP_MAX_LEVELS));
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, BF, LC>),
+    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, SPLIT>::bytes(LC > 0 ? LC : MLP_MAX_LEVELS));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 16);
     const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, BF, LC>), grid, block, gq_lds_bytes(QuadDec<H, BF>::bytes(f->levels)), s,
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC>), grid, block, gq_lds_bytes(QuadDec<H, SPLIT>::bytes(f->levels)), s,
                        *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state);
     return 0;
 }
@@ -670,7 +670,7 @@ static int launch_quad_ho(const pin_field* f, const pin_gn_params* gp, const flo
                           float* grad_out, const double* state, hipStream_t s) {
 #define PIN_LQ(BB, LL) \
     return launch_quad_inst<H, ORIENT, BB, LL>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
-    if (!use_bf3_decoder()) PIN_LQ(false, 0);  // PIN_MLP=f32: the fp32 MFMA image (A/B runs)
+    if (!use_split_decoder()) PIN_LQ(false, 0);  // PIN_MLP=f32: the fp32 MFMA image (A/B runs)
     switch (f->levels) {
         case 1: PIN_LQ(true, 1);
         case 2: PIN_LQ(true, 2);
@@ -681,17 +681,17 @@ static int launch_quad_ho(const pin_field* f, const pin_gn_params* gp, const flo
 }
 
 // weighted_first = False: a decoder column per (query, neighbour) pair, 2 queries per 16-column tile (gn_quad.h)
-template <int H, bool ORIENT, bool BF, int LC>
+template <int H, bool ORIENT, bool SPLIT, int LC>
 static int launch_quad_nwf_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                                 const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                                 float* grad_out, const double* state, hipStream_t s) {
-    constexpr int lds_bytes = gq_red_offset(QuadDec<H, BF>::bytes(1)) + (NWF_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_nwf_kernel<H, ORIENT, BF, LC>),
+    constexpr int lds_bytes = gq_red_offset(QuadDec<H, SPLIT>::bytes(1)) + (NWF_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_nwf_kernel<H, ORIENT, SPLIT, LC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 2);
     const dim3 grid(min(gq_cu_count(), cdiv(tiles, NWF_BLOCK / 64))), block(NWF_BLOCK);
-    hipLaunchKernelGGL((gn_accumulate_quad_nwf_kernel<H, ORIENT, BF, LC>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
+    hipLaunchKernelGGL((gn_accumulate_quad_nwf_kernel<H, ORIENT, SPLIT, LC>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
                        labels, n, sums, sdf_out, grad_out, state);
     return 0;
 }
@@ -702,7 +702,7 @@ static int launch_quad_nwf(const pin_field* f, const pin_gn_params* gp, const fl
                            const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                            float* grad_out, const double* state, hipStream_t s) {
 #define PIN_LQ(HH, OO) \
-    return use_bf3_decoder() ? launch_quad_nwf_inst<HH, OO, true, 1>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s) \
+    return use_split_decoder() ? launch_quad_nwf_inst<HH, OO, true, 1>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s) \
                              : launch_quad_nwf_inst<HH, OO, false, 0>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
     if (f->hidden == 64) { if (f->orient) PIN_LQ(64, true); else PIN_LQ(64, false); }
     if (f->orient) PIN_LQ(32, true); else PIN_LQ(32, false);
@@ -848,13 +848,13 @@ extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32
 // ---- decoder image for the GN tile kernel (pin_field.dec_image) ------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(GQ_BLOCK) void stage_decoder_kernel(pin_field f, unsigned char* __restrict__ out) {
-    QuadDecoderB<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK);
+    QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK);
 }
 
 extern "C" int64_t pin_decoder_image_bytes(int32_t hidden, int32_t levels) {
-    if (!use_bf3_decoder() || levels < 1 || levels > MLP_MAX_LEVELS) return 0;
-    if (hidden == 64) return QuadDecoderB<64>::bytes(levels);
-    if (hidden == 32) return QuadDecoderB<32>::bytes(levels);
+    if (!use_split_decoder() || levels < 1 || levels > MLP_MAX_LEVELS) return 0;
+    if (hidden == 64) return QuadDecoderH<64>::bytes(levels);
+    if (hidden == 32) return QuadDecoderH<32>::bytes(levels);
     return 0;
 }
 

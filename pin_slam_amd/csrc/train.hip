@@ -16,6 +16,9 @@
 namespace pin {
 
 
+constexpr int DW_SLOTS = 32;            // (train_fused.h)
+constexpr int FUSED_NDEC_MAX = 16384;   // >= parameters of the largest decoder (4 x 64: 13 313)
+
 struct TrainWs {
     float* z;      // [12][Qs]  interpolated decoder input (row 11 unused)
     float* h;      // [L*H][Qs] post-ReLU activations
@@ -31,7 +34,12 @@ struct TrainWs {
 __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L, int expand) {
     const size_t Qs = (size_t)((Q + 63) / 64) * 64;
     const size_t QsT = Qs * (size_t)expand;
-    return QsT * (12 + (size_t)L * H + (size_t)L * H + MF_OD_MAX + 2 * (size_t)L + MF_OD_MAX) + 2 * MF_OD_MAX * Qs;
+    const size_t unit_major = QsT * (12 + (size_t)L * H + (size_t)L * H + MF_OD_MAX + 2 * (size_t)L + MF_OD_MAX) + 2 * MF_OD_MAX * Qs;
+    // operand stream of the fused path (train_fused.h): two streams of (L * H / 16 + 1) blocks of 1 KiB per 16-query tile
+    // (tiles <= Q / 14 + 1 whatever the main / Eikonal split, see fused_tiles)
+    const size_t stream = ((size_t)(Q + 11) / 12 + 4) * 128 * ((size_t)L * (H / 16) + 1) * 2 * 2 +
+                          (size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048;  // + slot partials of the weight gradient, per-block loss sums
+    return unit_major > stream ? unit_major : stream;
 }
 
 static void carve_ws(TrainWs& ws, float* w, int H, int L) {
@@ -592,166 +600,9 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
     }
 }
 
-// ---- the same forward / backward with FOUR LANES PER QUERY (weighted_first, one SDF head) ---------------------
-// A training iteration has only ~26k queries: with 64 queries per wave that is 410 waves for 1024 SIMDs.
-// As in gn_quad.h a wave carries one 16-query tile and lane (n, g) owns input components 4g..4g+3, so the
-// batch spreads over four times as many waves, the input / its gradient never go through LDS, and the
-// blocks are persistent (weights staged once per CU).
-constexpr int TQ_BLOCK = 512;  // 8 waves per CU = 2048 tile slots for the ~1640 tiles of an iteration, 256 VGPRs per lane
-
-template <int H>
-__global__ __launch_bounds__(TQ_BLOCK, 1) void train_fwd_quad_kernel(pin_field f, const float* __restrict__ query,
-                                                                     const float4* __restrict__ nbr,
-                                                                     const int* __restrict__ nn_count, int Q, int n_main,
-                                                                     TrainWs ws, float* __restrict__ cert_rw,
-                                                                     int* __restrict__ ts_rw, const int* __restrict__ sample_ts,
-                                                                     double* __restrict__ loss_zero) {
-    using QD = QuadDecoder<H>;
-    __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { loss_zero[0] = 0.0; loss_zero[1] = 0.0; }  // the loss kernel accumulates next
-    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-    const int n_tiles = (Q + 15) >> 4;
-    const int n_waves = gridDim.x * (TQ_BLOCK / 64);
-    bool staged = false;  // the weights are staged behind the first tile's gather loads (a wave has ~1 tile)
-    for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
-        const bool work = tile < n_tiles;
-        if (!work && staged) break;
-        // the row stride is re-read per tile behind an optimisation barrier: hoisted out of the loop, the ~70
-        // row addresses of the activation stores become live 64-bit values and spill to scratch memory
-        int qst32 = ws.QsT;
-        asm volatile("" : "+s"(qst32));
-        const size_t QsT = (size_t)qst32;
-        const int qi = (work ? tile : 0) * 16 + nq;  // < ws.Qs: the padded column count is a multiple of 64
-        const bool active = work && qi < Q;
-        const int qq = qi < Q ? qi : Q - 1;
-        const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
-        NbrW nb;
-        float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
-        bool quirk[PIN_MAX_K];
-        neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
-        // one row load per neighbour and lane, all in flight together (the lanes g >= 2 re-read a feature quarter)
-        float4 row[PIN_MAX_K];
-#pragma unroll
-        for (int t = 0; t < PIN_MAX_K; ++t) {
-            const size_t id = nb.idx[t] >= 0 ? (size_t)nb.idx[t] : 0;
-            row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
-        }
-        if (!staged) {
-            QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
-            __syncthreads();
-            staged = true;
-            if (!work) break;
-        }
-        // training-mode side effects first (neural_points.py:685-710), so the neighbour arrays die before the decoder
-        if (g == 3 && active && qi < n_main && cert_rw != nullptr) {
-#pragma unroll
-            for (int t = 0; t < PIN_MAX_K; ++t)
-                if (nb.idx[t] >= 0) {
-                    atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
-                    if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
-                }
-        }
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < PIN_MAX_K; ++t) {
-            const bool val = nb.idx[t] >= 0;  // invalid neighbours: weight 0 and a zeroed row add exact zeros
-            float y[4] = {0.f, 0.f, 0.f, 0.f};
-            if (g < 2) {
-                if (val) { y[0] = row[t].x; y[1] = row[t].y; y[2] = row[t].z; y[3] = row[t].w; }
-            } else if (g == 2 && val) {
-                float v[3];
-                neighbor_vector_only(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, v);
-                y[0] = v[0]; y[1] = v[1]; y[2] = v[2];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = fmaf(nb.w[t], y[r], z[r]);
-        }
-        if (g < 3) {  // rows 0..11 of the input block (row 11 = 0 comes from lane g == 2, r == 3)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ws.z[(size_t)(4 * g + r) * QsT + qi] = z[r];
-        }
-        const float x = QD::forward_store(lds, f.levels, z, ws.h, QsT, (size_t)qi, ws.mask, QsT);
-        if (g == 0) ws.pred[qi] = f.sdf_scale * x;
-    }
-}
-
-template <int H>
-__global__ __launch_bounds__(TQ_BLOCK, 1) void train_bwd_quad_kernel(pin_field f, const float4* __restrict__ nbr,
-                                                                     const int* __restrict__ nn_count, int Q, TrainWs ws,
-                                                                     float* __restrict__ feat_grad, int want_dec,
-                                                                     pin_train_params tp, const float* __restrict__ label,
-                                                                     const float* __restrict__ weight,
-                                                                     double* __restrict__ loss_out) {
-    using QD = QuadDecoder<H>;
-    __shared__ __attribute__((aligned(16))) float lds[QD::TOTAL];
-    __shared__ float xch[TQ_BLOCK / 64][3 * 16 * 8];  // per wave: dz [16][8], w [16][8], idx [16][8]
-    __shared__ double lred[TQ_BLOCK / 64][2];
-    double acc_bce = 0.0, acc_eik = 0.0;  // the loss (BCE + Eikonal, loss.py:31-63) is folded in: no separate launch
-    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-    const int n_tiles = (Q + 15) >> 4;
-    const int n_waves = gridDim.x * (TQ_BLOCK / 64);
-    float* sdz = xch[wave];
-    float* sw = sdz + 16 * 8;
-    int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
-    bool staged = false;  // staging runs behind the first tile's loads (see train_fwd_quad_kernel)
-    for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
-        const bool work = tile < n_tiles;
-        if (!work && staged) break;
-        int qst32 = ws.QsT;  // see train_fwd_quad_kernel
-        asm volatile("" : "+s"(qst32));
-        const size_t QsT = (size_t)qst32;
-        const int qi = (work ? tile : 0) * 16 + nq;
-        const bool active = work && qi < Q;
-        const int qq = qi < Q ? qi : Q - 1;
-        double l_bce, l_eik;
-        const float dp = loss_dpred(tp, label, weight, ws.pred, qq, l_bce, l_eik);
-        if (active && g == 0) { acc_bce += l_bce; acc_eik += l_eik; }
-        const float dx = active ? dp * f.sdf_scale : 0.f;  // the prediction is sdf_scale * head
-        // Feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature dims,
-        // whole 32-byte rows per instruction; see train_bwd_mfma_kernel): exchange through the wave's LDS patch
-        NbrW nb;
-        {
-            float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
-            bool quirk[PIN_MAX_K];
-            neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
-        }
-        if (!staged) {
-            QD::stage(f.dec, f.levels, lds, threadIdx.x, TQ_BLOCK);
-            __syncthreads();
-            staged = true;
-            if (!work) break;
-        }
-        if (want_dec && g == 0) ws.d[(size_t)(f.levels * H) * QsT + qi] = dx;
-        float dz[4];
-        QD::backward_store(lds, f.levels, dx, ws.mask, QsT, ws.d, QsT, (size_t)qi, want_dec != 0, dz);
-        const bool live = active && dx != 0.f;
-        if (g < 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r];
-        } else if (g == 2) {
-#pragma unroll
-            for (int t = 0; t < PIN_MAX_K; ++t) { sw[nq * 8 + t] = nb.w[t]; sidx[nq * 8 + t] = live ? nb.idx[t] : -1; }
-        }
-        wave_lds_sync();
-        const int t = lane >> 3, j = lane & 7;
-        for (int i = 0; i < 16; ++i) {
-            const int idx = sidx[i * 8 + t];
-            if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
-        }
-        wave_lds_sync();
-    }
-    // loss values: one pair of atomics per block (same-address f64 atomics serialise)
-    acc_bce = wave_sum(acc_bce);
-    acc_eik = wave_sum(acc_eik);
-    if (lane == 0) { lred[wave][0] = acc_bce; lred[wave][1] = acc_eik; }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < TQ_BLOCK / 64; ++w) t += lred[w][threadIdx.x];
-        if (t != 0.0) atomicAdd(loss_out + threadIdx.x, t);
-    }
-}
+}  // namespace pin
+#include "train_fused.h"
+namespace pin {
 
 // ---- Adam --------------------------------------------------------------------------------
 // One element, one step (torch.optim.Adam, tools.py:198-199).  Contraction is off so that every kernel
@@ -951,6 +802,63 @@ extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_
     return 0;
 }
 
+// weighted_first, one SDF head: fused tile kernel + streamed weight gradient (train_fused.h)
+template <int H, int L>
+static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
+                          const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
+                          float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
+                          float* pred_out, void* workspace, int n_cu, hipStream_t s) {
+    using G = DwGeom<H>;
+    constexpr int lds_bytes = train_fused_lds_bytes<H>(L);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_fused_kernel<H, L>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "training tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    DwStream ws;
+    ws.n_tiles = fused_tiles(tp->n_main, tp->n_eik);
+    ws.d = reinterpret_cast<uint2*>(workspace);
+    ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
+    // power of two that maps a unit loss gradient to ~1 (see train_fused.h "Scaling")
+    const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
+    const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
+    const float dscale = exp2f(-ceilf(log2f(fmaxf(fmaxf(unit_main, unit_eik), 1e-30f))));
+    const int want_dec = dec_grad != nullptr;
+    const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + H + 1;
+    float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
+    double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
+    const int grid = min(n_cu, ws.n_tiles);
+    hipLaunchKernelGGL((train_fused_kernel<H, L>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, dw_partial,
+                       n_dec, loss_partial);
+    PIN_CHECK_LAUNCH();
+    if (want_dec) {
+        int per_chunk = DW_TILES_PER_WAVE;
+        while ((long)cdiv(ws.n_tiles, per_chunk) > 2048) per_chunk *= 2;
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, per_chunk), L + 1), dim3(256), 0, s, ws, L, per_chunk,
+                           n_dec, dw_partial);
+        PIN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
+                       dec_grad, loss_partial, grid, loss_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int H>
+static int launch_fused(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
+                        const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
+                        float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
+                        float* pred_out, void* workspace, int n_cu, hipStream_t s) {
+#define PIN_LF(LL) return launch_fused_l<H, LL>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, \
+                                                ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
+    switch (f->levels) {
+        case 1: PIN_LF(1);
+        case 2: PIN_LF(2);
+        case 3: PIN_LF(3);
+        default: PIN_LF(4);
+    }
+#undef PIN_LF
+}
+
 extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
                               const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
                               const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
@@ -982,34 +890,26 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
         else { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
                else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__); }          \
     } while (0)
-    // weighted_first: four lanes per query on persistent blocks; per-neighbour decoding: 64 queries per wave
     const bool quad = f->weighted_first != 0;
     static const int n_cu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         return v;
     }();
-    const dim3 qgrid(min(n_cu, cdiv(Q, 16))), qblock(TQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
-    if (!quad) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the tile kernel clears it itself)
-    if (quad) {
-        if (H == 64) hipLaunchKernelGGL((train_fwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
-        else hipLaunchKernelGGL((train_fwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts, loss_out);
-    } else {
-        PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
-    }
-    PIN_CHECK_LAUNCH();
-    if (!quad) {  // (the tile backward kernel computes the loss gradient itself)
-        hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
-                           sample_weight, ws, loss_out);
-        PIN_CHECK_LAUNCH();
-    }
     const int want_dec = dec_grad != nullptr;
-    if (quad) {
-        if (H == 64) hipLaunchKernelGGL((train_bwd_quad_kernel<64>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
-        else hipLaunchKernelGGL((train_bwd_quad_kernel<32>), qgrid, qblock, 0, s, *f, nb4, nn_count, Q, ws, feat_grad, want_dec, *tp, sdf_label, sample_weight, loss_out);
-    } else {
-        PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
-    }
+    if (!quad) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the fused path sums per-block partials)
+    if (quad)  // weighted_first: the fused tile kernel + the streamed weight gradient (train_fused.h)
+        return H == 64 ? launch_fused<64>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
+                                          feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
+                       : launch_fused<32>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
+                                          feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s);
+    // per-neighbour decoding: 64 queries per wave, activations and deltas through the unit-major workspace
+    PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
+    PIN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,
+                       sample_weight, ws, loss_out);
+    PIN_CHECK_LAUNCH();
+    PIN_TRAIN_MFMA(train_bwd_mfma_kernel, *f, nb4, nn_count, Q, ws, feat_grad, want_dec);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
         DwLayers dl;

@@ -1,0 +1,462 @@
+// One training iteration of Mapper.mapping (utils/mapper.py:645-818) as TWO launches (weighted_first, one SDF head):
+//
+//   train_fused_kernel<H, L>   gather + IDW interpolation (neural_points.py:590-746), decoder forward, BCE-with-logits +
+//                              Eikonal loss and its gradient (utils/loss.py:45-63, mapper.py:732-780), decoder backward,
+//                              feature-gradient scatter, training-mode side effects -- per 16-query tile, four lanes per
+//                              query as in gn_quad.h, decoder on the split-fp16 matrix cores (mlp_h2.h).  Nothing of a
+//                              tile goes through memory between forward and backward; what leaves the kernel for the
+//                              decoder's weight gradient is the OPERAND STREAM of the second launch:
+//   train_dw_stream_kernel<H>  dW_l = sum_q delta_{l+1}[q] (x) a_l[q]: a 16x16x16 MFMA per (16 out units, 16 in units,
+//                              16 queries of a tile) and piece product, operands read exactly as the instruction wants them.
+//
+// r01-r02a had three launches (forward with activation stores, backward with delta stores, a K = 4 fp32 MFMA GEMM over
+// unit-major fp32 rows) of ~30 us each at the reference's batch of 16k samples: 2.1 kB per query written with 64-byte
+// granularity, read back twice, the decoder staged twice, the neighbours gathered twice.
+//
+// Tile -> query map.  The six +-eps probes of an Eikonal sample must sit in one tile (the loss gradient of a probe
+// needs the other five predictions): a MIXED tile carries 2 samples x 6 probes in columns 0..11 and four main samples
+// in columns 12..15; the remaining main samples fill plain tiles of 16.  n_tiles = ceil(Q / 16) up to rounding: no
+// padded columns to decode.
+//
+// Transposing without data movement.  The quad layout holds a 16-query x 16-unit block as "query in the lane, four
+// units in the registers" -- which IS the A operand of v_mfma_f32_16x16x16_f16 (M = query, K = unit).  Multiplying
+// it by the identity returns the block in the D layout, "unit in the lane, four queries in the registers": the operand
+// layout with K = query that the weight gradient needs.  fp16 pieces pass through the fp32 result exactly.
+//
+// Scaling.  Loss gradients are ~1 / batch (1e-5): far below the fp16 normal range.  The backward sweep is linear in
+// d loss / d prediction, so it runs on gradients multiplied by a power of two (`dscale`, chosen by the host from the
+// loss normalisation so that a unit loss gradient maps to ~1); feature gradients and weight gradients are multiplied
+// by 1 / dscale on the way out -- exact.
+#pragma once
+#include "mlp_h2.h"
+
+namespace pin {
+
+constexpr int TF_BLOCK = 512;  // 8 waves per CU, 2 per SIMD (<= 256 VGPRs)
+// (DW_SLOTS partial weight gradients, train.hip: chunk c of the streamed product adds into slot c % DW_SLOTS)
+
+// operand stream of the weight-gradient launch.  Layer index lam = 0..L: delta_{lam+1} (x) a_lam, with a_0 = z (one
+// 16-input block), a_l = post-ReLU activations (MT blocks), delta_{L+1} = d loss / d head (one block, unit 0).
+// One block and piece = 64 lanes x 8 bytes (four fp16 of consecutive queries for the lane's unit).
+struct DwStream {
+    uint2* d;     // [lam][tile][block][piece][lane]
+    uint2* a;
+    int n_tiles;
+};
+template <int H>
+struct DwGeom {
+    static constexpr int MT = H / 16;
+    __host__ __device__ static constexpr int d_blocks(int L, int lam) { return lam < L ? MT : 1; }
+    __host__ __device__ static constexpr int a_blocks(int lam) { return lam == 0 ? 1 : MT; }
+    // offsets in uint2 units (128 per block: 2 pieces x 64 lanes)
+    __host__ __device__ static size_t d_off(size_t n_tiles, int lam) { return n_tiles * 128 * (size_t)(lam * MT); }
+    __host__ __device__ static size_t a_off(size_t n_tiles, int lam) { return lam == 0 ? 0 : n_tiles * 128 * (size_t)(1 + (lam - 1) * MT); }
+    __host__ __device__ static size_t total(size_t n_tiles, int L) { return n_tiles * 128 * (size_t)(L * MT + 1); }  // of each stream
+};
+
+__host__ __device__ inline int fused_mixed_tiles(int n_eik) { return (n_eik + 1) >> 1; }
+__host__ __device__ inline int fused_tiles(int n_main, int n_eik) {
+    const int nm = fused_mixed_tiles(n_eik);
+    const int rest = n_main - 4 * nm;
+    return nm + (rest > 0 ? (rest + 15) >> 4 : 0);
+}
+
+typedef _Float16 v4h_raw __attribute__((ext_vector_type(4)));
+
+// a 16 x 16 block of packed fp16 (quad layout, words w0 w1 = units 4g..4g+3 of the lane's query) -> D layout
+__device__ __forceinline__ uint2 transpose_block(unsigned int w0, unsigned int w1, v4h_t ident) {
+    const v2u_t a = {w0, w1};
+    const v4f_t t = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(a), ident, (v4f_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const v2h_t lo = {(_Float16)t[0], (_Float16)t[1]}, hi = {(_Float16)t[2], (_Float16)t[3]};  // exact: t holds fp16 values
+    return make_uint2(__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi));
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, pin_train_params tp,
+                                                                  const float* __restrict__ query,
+                                                                  const float4* __restrict__ nbr,
+                                                                  const int* __restrict__ nn_count,
+                                                                  const float* __restrict__ label,
+                                                                  const float* __restrict__ weight,
+                                                                  const int* __restrict__ sample_ts,
+                                                                  float* __restrict__ cert_rw, int* __restrict__ ts_rw,
+                                                                  float* __restrict__ feat_grad, float* __restrict__ pred_out,
+                                                                  DwStream ws, int want_dec, float dscale,
+                                                                  float* __restrict__ dw_partial, int n_dec,
+                                                                  double* __restrict__ loss_partial) {
+    using Q = QuadDecoderH<H>;
+    using G = DwGeom<H>;
+    constexpr int MT = Q::MT, NJ = Q::NJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];  // decoder image, scatter patches, loss sums
+    unsigned char* const lds = tf_smem;
+    constexpr int IMG = (Q::bytes(L) + 15) & ~15;
+    float* const xch = reinterpret_cast<float*>(lds + IMG) + (threadIdx.x >> 6) * (3 * 16 * 8);  // per wave: dz, w, idx [16][8]
+    double (*lred)[2] = reinterpret_cast<double (*)[2]>(lds + IMG + (TF_BLOCK / 64) * 3 * 16 * 8 * 4);
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int n_main = tp.n_main, n_eik = tp.n_eik;
+    const int n_mixed = fused_mixed_tiles(n_eik);
+    const int n_tiles = ws.n_tiles;
+    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const float inv_dscale = 1.0f / dscale;
+    // identity operand of the transposing MFMA: B[k = 4 (lane >> 4) + r][n = lane & 15]
+    v4h_t ident;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ident[r] = (nq == 4 * g + r) ? (_Float16)1.0f : (_Float16)0.0f;
+    float* sdz = xch;
+    float* sw = sdz + 16 * 8;
+    int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
+    double acc_bce = 0.0, acc_eik = 0.0;
+    if (want_dec) {  // the slot partials of the weight-gradient launch start from zero (it runs after this kernel)
+        const int n = DW_SLOTS * n_dec;
+        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+    }
+    bool staged = false;  // the weights are split and staged behind the first tile's gather loads
+    for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
+        const bool work = tile < n_tiles;
+        if (!work && staged) break;
+        // ---- which query this column is
+        const int tl = work ? tile : 0;
+        bool is_probe = false;
+        int qi, probe_a = 0;
+        bool valid;
+        if (tl < n_mixed) {
+            if (nq < 12) {
+                const int s = 2 * tl + (nq >= 6 ? 1 : 0);
+                probe_a = nq >= 6 ? nq - 6 : nq;
+                is_probe = true;
+                valid = s < n_eik;
+                qi = n_main + 6 * s + probe_a;
+            } else {
+                qi = 4 * tl + (nq - 12);
+                valid = qi < n_main;
+            }
+        } else {
+            qi = 4 * n_mixed + 16 * (tl - n_mixed) + nq;
+            valid = qi < n_main;
+        }
+        const bool active = work && valid;
+        const int qq = valid ? qi : 0;
+        const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+        NbrW nb;
+        float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+        bool quirk[PIN_MAX_K];
+        neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk);
+        float4 row[PIN_MAX_K];
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            const size_t id = nb.idx[t] >= 0 ? (size_t)nb.idx[t] : 0;
+            row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
+        }
+        if (!staged) {
+            Q::stage(f.dec, L, lds, threadIdx.x, TF_BLOCK);
+            __syncthreads();
+            staged = true;
+            if (!work) break;
+        }
+        // training-mode side effects (neural_points.py:685-710)
+        if (g == 3 && active && !is_probe && cert_rw != nullptr) {
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t)
+                if (nb.idx[t] >= 0) {
+                    atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                    if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
+                }
+        }
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            const bool val = nb.idx[t] >= 0;  // invalid neighbours: weight 0 and a zeroed row add exact zeros
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g < 2) {
+                if (val) { y[0] = row[t].x; y[1] = row[t].y; y[2] = row[t].z; y[3] = row[t].w; }
+            } else if (g == 2 && val) {
+                float v[3];
+                neighbor_vector_only(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, v);
+                y[0] = v[0]; y[1] = v[1]; y[2] = v[2];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = fmaf(nb.w[t], y[r], z[r]);
+        }
+        // the scatter at the end needs the weights and indices: park them in the wave's LDS patch now (lane g == 2)
+        // (the previous tile's scatter has finished reading the patch: wave_lds_sync at the end of the loop body)
+        if (g == 2) {
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t) { sw[nq * 8 + t] = nb.w[t]; sidx[nq * 8 + t] = nb.idx[t]; }
+        }
+        // ---- forward; the pieces of every layer's input stay in registers for the weight gradient
+        v2u_t zh, zl;
+        Q::split_input(z, zh, zl);
+        v4f_t h[MT], acc[MT];
+        v4u_t ph[L][NJ], pl[L][NJ];  // pieces of a_1 .. a_L
+        Q::layer0(lds, L, zh, zl, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            Q::split_acts(h, ph[l - 1], pl[l - 1]);
+            Q::load_bias(lds, L, l, acc);
+            Q::matmul(lds + Q::off_hidf(L, l), ph[l - 1], pl[l - 1], acc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+        }
+        const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
+        float x = 0.f;
+        v4f_t wo[MT];
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            wo[kt] = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = fmaf(wo[kt][r], h[kt][r], x);
+        }
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        x += O[MF_OD_MAX * H];
+        const float pred = f.sdf_scale * x;
+        if (active && !is_probe && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
+        // ---- loss and d loss / d prediction (train_loss_kernel's arithmetic)
+        float dp = 0.f;
+        {
+            const int c0 = (lane & 48) + (nq >= 6 ? 6 : 0);
+            float P[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) P[j] = __shfl(pred, c0 + j, 64);
+            if (is_probe) {
+                const float two_eps = 2.f * tp.eik_eps;
+                const float gx = (P[0] - P[1]) / two_eps, gy = (P[2] - P[3]) / two_eps, gz = (P[4] - P[5]) / two_eps;
+                const float n = sqrtf(gx * gx + gy * gy + gz * gz);
+                const float r = n - 1.f;
+                if (active && probe_a == 0 && g == 0) acc_eik += (double)(r * r);
+                const float c = n > 0.f ? tp.weight_e * 2.f * r * tp.inv_n_eik / (n * two_eps) : 0.f;
+                const float ga = probe_a < 2 ? gx : (probe_a < 4 ? gy : gz);
+                dp = (probe_a & 1) ? -c * ga : c * ga;
+            } else {
+                const float xl = pred / tp.sigma;
+                const float y = 1.f / (1.f + expf(-label[qq] / tp.sigma));
+                float l = fmaxf(xl, 0.f) - xl * y + log1pf(expf(-fabsf(xl)));
+                float gg = 1.f / (1.f + expf(-xl)) - y;
+                if (tp.loss_weight_on) { const float w = fabsf(weight[qq]); l *= w; gg *= w; }
+                if (active && g == 0) acc_bce += (double)l;
+                dp = gg * tp.inv_n_main / tp.sigma;
+            }
+        }
+        const float dx = active ? dp * f.sdf_scale * dscale : 0.f;  // the prediction is sdf_scale * head
+        // ---- backward
+        size_t tbase = (size_t)tile * 128 + lane;
+        if (want_dec) {  // out layer: delta = dx in unit 0 of a 16-unit block, input a_L
+            Q::split_acts(h, ph[L - 1], pl[L - 1]);
+            unsigned int dh, dl;
+            h2_split2((g == 0) ? dx : 0.f, 0.f, dh, dl);
+            uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
+            D[0] = transpose_block(dh, 0u, ident);
+            D[64] = transpose_block(dl, 0u, ident);
+            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, L) + (size_t)tile * 128 * (MT - 1) + tbase;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                A[mt * 128] = transpose_block(ph[L - 1][mt >> 1][2 * (mt & 1)], ph[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                A[mt * 128 + 64] = transpose_block(pl[L - 1][mt >> 1][2 * (mt & 1)], pl[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[kt][r] = h[kt][r] > 0.f ? dx * wo[kt][r] : 0.f;
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            // h = delta_{l+1} (H units); its pieces feed the transposed product and the weight-gradient stream
+            v4u_t bh[NJ], bl[NJ];
+            Q::split_acts(h, bh, bl);
+            if (want_dec) {
+                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + (size_t)tile * 128 * (MT - 1) + tbase;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
+                    D[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
+                }
+                if (l > 0) {
+                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + (size_t)tile * 128 * (MT - 1) + tbase;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        A[mt * 128] = transpose_block(ph[l - 1][mt >> 1][2 * (mt & 1)], ph[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                        A[mt * 128 + 64] = transpose_block(pl[l - 1][mt >> 1][2 * (mt & 1)], pl[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                    }
+                } else {
+                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
+                    A[0] = transpose_block(zh[0], zh[1], ident);
+                    A[64] = transpose_block(zl[0], zl[1], ident);
+                }
+            }
+            if (l > 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                Q::matmul(lds + Q::off_hidb(L, l), bh, bl, acc);
+                // ReLU pattern of a_l out of its pieces: a positive activation has a non-zero piece (down to 2^-36:
+                // far inside the rounding noise of the pre-activation; the Gauss-Newton kernel keeps exact patterns)
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned int word = ph[l - 1][mj >> 1][2 * (mj & 1) + (r >> 1)] | pl[l - 1][mj >> 1][2 * (mj & 1) + (r >> 1)];
+                        const bool on = (r & 1) ? ((word & 0x7fff0000u) != 0u) : ((word & 0x7fffu) != 0u);
+                        h[mj][r] = on ? acc[mj][r] : 0.f;
+                    }
+            } else {
+                float dz[4];
+                Q::input_backward(lds, L, bh, bl, dz);
+                // ---- feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature
+                // dims, whole 32-byte rows per instruction): exchange through the wave's LDS patch
+                const bool live = active && dx != 0.f;
+                if (g < 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r] * inv_dscale;
+                } else if (g == 3) {
+                    if (!live) {
+#pragma unroll
+                        for (int t = 0; t < PIN_MAX_K; ++t) sidx[nq * 8 + t] = -1;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        {
+            const int t = lane >> 3, j = lane & 7;
+            for (int i = 0; i < 16; ++i) {
+                const int idx = sidx[i * 8 + t];
+                if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
+            }
+        }
+        wave_lds_sync();
+    }
+    // loss values: one pair per block, summed by train_finalize_kernel (no atomics, no clearing launch)
+    acc_bce = wave_sum(acc_bce);
+    acc_eik = wave_sum(acc_eik);
+    if (lane == 0) { lred[wave][0] = acc_bce; lred[wave][1] = acc_eik; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TF_BLOCK / 64; ++w) t += lred[w][threadIdx.x];
+        loss_partial[2 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
+template <int H>
+constexpr int train_fused_lds_bytes(int L) {
+    return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (TF_BLOCK / 64) * 3 * 16 * 8 * 4 + (TF_BLOCK / 64) * 2 * 8;
+}
+
+// ---- weight gradient over the operand stream ----------------------------------------------------------------------
+// grid (chunks of tiles, L + 1 layers), 4 waves.  A wave owns one 16-unit block of OUTPUT units of its layer (or, when
+// the layer has fewer than 4 such blocks, a phase of the tiles) and all input blocks: per tile 2 + 2 * AB operand
+// loads of 8 bytes per lane (512 contiguous bytes per wave and load) and 3 * AB + 2 MFMAs; hi*hi into the main
+// accumulators, the two cross products into a second set folded in with 2^-11 at the end; the bias gradient is the
+// product with a block of ones.
+constexpr int DW_TILES_PER_WAVE = 8;
+
+template <int H>
+__global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L, int tiles_per_chunk, int n_dec,
+                                                              float* __restrict__ partial) {
+    using G = DwGeom<H>;
+    constexpr int MT = G::MT;
+    const int lam = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int DB = G::d_blocks(L, lam), AB = G::a_blocks(lam);
+    const int ob = wave % DB, phase = wave / DB, phases = 4 / DB;
+    const size_t n_tiles = (size_t)ws.n_tiles;
+    const uint2* __restrict__ D = ws.d + G::d_off(n_tiles, lam) + (size_t)ob * 128 + lane;
+    const uint2* __restrict__ A = ws.a + G::a_off(n_tiles, lam) + lane;
+    const int t0 = blockIdx.x * tiles_per_chunk, t1 = min(t0 + tiles_per_chunk, ws.n_tiles);
+    v4f_t mainv[MT], cross[MT], bmain = (v4f_t){0.f, 0.f, 0.f, 0.f}, bcross = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ib = 0; ib < MT; ++ib) { mainv[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; cross[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; }
+    const v4h_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    auto as4 = [](uint2 v) { const v2u_t u = {v.x, v.y}; return as_h4(u); };
+    for (int t = t0 + phase; t < t1; t += 2 * phases) {
+        // two tiles per trip: all operand loads are issued before the first MFMA
+        const int ta = t, tb = t + phases;
+        const bool has_b = tb < t1;
+        uint2 dh[2], dl[2], ah[2][MT], al[2][MT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t tt = (size_t)(u == 0 ? ta : (has_b ? tb : ta));
+            dh[u] = D[tt * 128 * DB];
+            dl[u] = D[tt * 128 * DB + 64];
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib) {
+                const int bb = ib < AB ? ib : 0;
+                ah[u][ib] = A[(tt * AB + bb) * 128];
+                al[u][ib] = A[(tt * AB + bb) * 128 + 64];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !has_b) break;
+            const v4h_t d_h = as4(dh[u]), d_l = as4(dl[u]);
+            bmain = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, ones, bmain, 0, 0, 0);
+            bcross = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, ones, bcross, 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib) {
+                if (ib >= AB) continue;
+                const v4h_t a_h = as4(ah[u][ib]), a_l = as4(al[u][ib]);
+                mainv[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_h, mainv[ib], 0, 0, 0);
+                cross[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_l, cross[ib], 0, 0, 0);
+                cross[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, cross[ib], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: element [o = 4 g + r][i = n] of block (ob, ib).  state_dict order: W0 [H][11], b0, (W [H][H], b)*, lout.
+    // Every wave adds into the partial gradient of its chunk SLOT (chunk % DW_SLOTS): a few waves per address instead of
+    // one per chunk -- at the reference's batch the atomics on the 12.5k decoder gradients themselves took 33 of 47 us.
+    // train_finalize_kernel sums the slots.
+    const int rows = lam < L ? H : 1;
+    const int cols_out = lam == 0 ? MLP_IN : H;
+    size_t off = 0;
+    for (int u = 0; u < lam; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
+    float* __restrict__ gW = partial + (size_t)(blockIdx.x % DW_SLOTS) * n_dec + off;
+    float* __restrict__ gb = gW + (size_t)rows * cols_out;
+#pragma unroll
+    for (int ib = 0; ib < MT; ++ib) {
+        if (ib >= AB) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ob + 4 * g + r, i = 16 * ib + n;
+            const float v = fmaf(cross[ib][r], H2_DOWN, mainv[ib][r]);
+            if (o < rows && i < cols_out && v != 0.f) atomicAdd(gW + (size_t)o * cols_out + i, v);
+        }
+    }
+    if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ob + 4 * g + r;
+            const float v = fmaf(bcross[r], H2_DOWN, bmain[r]);
+            if (o < rows && v != 0.f) atomicAdd(gb + o, v);
+        }
+    }
+}
+
+// dec_grad += (sum of the slot partials) / dscale; block 0 adds up the per-block loss sums of the tile kernel
+__global__ __launch_bounds__(256) void train_finalize_kernel(const float* __restrict__ partial, int n_dec, float inv_dscale,
+                                                             float* __restrict__ dec_grad,
+                                                             const double* __restrict__ loss_partial, int n_loss,
+                                                             double* __restrict__ loss_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        double b = 0.0, e = 0.0;
+        for (int i = threadIdx.x; i < n_loss; i += 64) { b += loss_partial[2 * i]; e += loss_partial[2 * i + 1]; }
+        b = wave_sum(b); e = wave_sum(e);
+        if (threadIdx.x == 0) { loss_out[0] = b; loss_out[1] = e; }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (dec_grad == nullptr || i >= n_dec) return;
+    float v[DW_SLOTS];
+#pragma unroll
+    for (int c = 0; c < DW_SLOTS; ++c) v[c] = partial[(size_t)c * n_dec + i];
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < DW_SLOTS; ++c) t += v[c];
+    dec_grad[i] += t * inv_dscale;
+}
+
+}  // namespace pin

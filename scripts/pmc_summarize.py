@@ -22,7 +22,7 @@ hbm = lambda k: int((raw[k]["FETCH_SIZE"]["mean"] + raw[k]["WRITE_SIZE"]["mean"]
 out["knn_hbm_bytes_per_launch"] = hbm("knn")
 out["knn_brick_hbm_bytes_per_launch"] = hbm("knn_brick")
 out["gn_hbm_bytes_per_launch"] = hbm("gn")
-out["gn_kernel"] = "gn_accumulate_quad_kernel<64,false,true> (four lanes per query, persistent blocks, split-bf16 decoder)"
+out["gn_kernel"] = "gn_accumulate_quad_kernel<64,false,true> (four lanes per query, persistent blocks, split-fp16 decoder)"
 out["gn_mfma_busy_cycles_per_launch"] = raw["gn"]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]
 out["knn_algorithmic_bytes_per_launch"] = 118770000
 json.dump(out, open(os.path.join(root, "profiles", "r01_pmc.json"), "w"), indent=1)

@@ -1,6 +1,6 @@
 """Parity of the BENCHMARKED kernels, and parity at BASELINE scale:
 
-* the four-lanes-per-query GN tile kernel (gn_accumulate_quad_kernel, split-bf16 default and PIN_MLP=f32) against
+* the four-lanes-per-query GN tile kernel (gn_accumulate_quad_kernel, split-fp16 default and PIN_MLP=f32) against
   the REFERENCE's per-point SDF / gradient / validity mask on the fixtures (it was only checked through its sums);
 * the HIP path against the numpy oracle on the bench workload itself: 2.2 M neural points, a 5e7-slot table,
   Kc = 81, k = 8, decoder 4x64 -- neighbour indices bit-exact, SDF / gradient 1e-4, one Gauss-Newton step,
@@ -30,7 +30,7 @@ def _check_points(d, sdf, grad, nn):
 
 
 @pytest.mark.parametrize("case", ["c2_wf", "c3_bigtable"])
-@pytest.mark.parametrize("mlp", ["bf3", "f32"])
+@pytest.mark.parametrize("mlp", ["h2", "f32"])
 def test_gn_tile_kernel_points_vs_reference(tmp_path, case, mlp):
     """pin_gn_accumulate(want_points) -> gn_accumulate_quad_kernel: per-point outputs vs Tracker.query_source_points
     of the reference (tracker.py:297-354).  The decoder arithmetic is an environment choice read once per process,

@@ -1,6 +1,6 @@
 """Kernel variants against each other (the variant is an environment variable read once per process, so every
 case runs tests/_variant_worker.py in a subprocess):
-  * PIN_MLP=f32 (fp32 MFMA) vs the default split-bf16 decoder: SDF / gradient within 2e-6 absolute (both are
+  * PIN_MLP=f32 (fp32 MFMA) vs the default split-fp16 decoder: SDF / gradient within 2e-6 absolute (both are
     ~1e-7 from a double reference, scripts/decoder_bench.hip), Gauss-Newton sums within 1e-5 relative."""
 import os
 import subprocess
@@ -23,9 +23,9 @@ def _run(tmp_path, name, env, hidden=64, levels=4, orient=0):
 
 
 @pytest.mark.parametrize("hidden,levels,orient", [(64, 4, 0), (64, 4, 1), (32, 2, 0), (64, 2, 1), (64, 1, 0), (32, 3, 1)])
-def test_split_bf16_decoder_matches_fp32_mfma(tmp_path, hidden, levels, orient):
+def test_split_fp16_decoder_matches_fp32_mfma(tmp_path, hidden, levels, orient):
     a = _run(tmp_path, "f32", {"PIN_MLP": "f32"}, hidden, levels, orient)
-    b = _run(tmp_path, "bf3", {"PIN_MLP": "bf3"}, hidden, levels, orient)
+    b = _run(tmp_path, "h2", {"PIN_MLP": "h2"}, hidden, levels, orient)
     assert np.array_equal(a["nbr"], b["nbr"])
     assert np.abs(a["sdf"] - b["sdf"]).max() < 2e-6 * max(1.0, np.abs(a["sdf"]).max())
     assert np.abs(a["grad"] - b["grad"]).max() < 2e-6 * max(1.0, np.abs(a["grad"]).max())
