@@ -472,6 +472,14 @@ int64_t pin_maint_workspace_bytes(int32_t n);
 int pin_voxel_downsample(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
                          int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Spatial (Morton) order of a point set: out[i] = points[perm[i]], ascending 30-bit Morton code of floor(p / cell)
+ * (10 bits per axis, wrapping).  Not a function of the reference: Tracker.tracking (utils/tracker.py:114-184) sums over
+ * the source points, so their order is free, and the per-iteration kNN and the Gauss-Newton tile kernel run ~20 %
+ * faster on a spatially coherent scan than on the down-sampler's x-fastest voxel order.  `out` must not alias
+ * `points`; perm_out [n] optional.  Workspace: pin_maint_workspace_bytes(n). */
+int pin_spatial_sort(const float* points, int32_t n, float cell, float* out, int32_t* perm_out, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
 /* NeuralPoints.update (neural_points.py:334-416) for the down-sampled points points[sel[i]],
  * i < *n_sel: probe the hash table, decide which samples become new neural points, append
  * them (positions, packed mirror, identity orientation, timestamps, zero certainty) in sample

@@ -165,6 +165,7 @@ SIGNATURES = {
     "pin_sdf_query": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_gn_accumulate": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "pin_maint_workspace_bytes": (i64, [i32]),
+    "pin_spatial_sort": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_voxel_downsample": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_map_update": (i32, [P(MapArrays), P(UpdateParams), vp, vp, vp, vp, vp, i64, vp]),
     "pin_reset_local_map": (i32, [P(MapArrays), P(LocalArrays), P(LocalParams), vp, vp, vp, i64, vp]),

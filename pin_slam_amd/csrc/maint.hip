@@ -480,6 +480,32 @@ __global__ __launch_bounds__(MB) void prune_compact_kernel(pin_map_arrays src, p
 
 __global__ void dec_count_kernel(int* c) { *c -= 1; }
 
+// ---- spatial order of the registration points (pin_spatial_sort) -------------------------------------------------
+__device__ __forceinline__ unsigned int spread3(unsigned int v) {  // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    return (v | (v << 2)) & 0x09249249u;
+}
+__global__ __launch_bounds__(256) void morton_keys_kernel(const float* __restrict__ p, int n, float inv_cell,
+                                                          unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int x = ((int)floorf(p[3 * i] * inv_cell) + 512) & 1023;
+    const unsigned int y = ((int)floorf(p[3 * i + 1] * inv_cell) + 512) & 1023;
+    const unsigned int z = ((int)floorf(p[3 * i + 2] * inv_cell) + 512) & 1023;
+    keys[i] = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+    vals[i] = (unsigned int)i;
+}
+__global__ __launch_bounds__(256) void permute_points_kernel(const float* __restrict__ p, const unsigned int* __restrict__ perm,
+                                                             int n, float* __restrict__ out, int* __restrict__ perm_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int j = perm[i];
+    out[3 * i] = p[3 * (size_t)j]; out[3 * i + 1] = p[3 * (size_t)j + 1]; out[3 * i + 2] = p[3 * (size_t)j + 2];
+    if (perm_out != nullptr) perm_out[i] = (int)j;
+}
+
 static size_t sort_temp_bytes(int n) {
     size_t bytes = 0;
     unsigned long long* k = nullptr;
@@ -495,6 +521,29 @@ extern "C" int64_t pin_maint_workspace_bytes(int32_t n) {
     const size_t nb = (size_t)cdiv(n + 1, MB) + 8;
     return (int64_t)(sizeof(VdsStats) + 4096 + (size_t)n * 8 * 5 + (size_t)(n + 1) * 5 + nb * 4 + sort_temp_bytes(n) +
                      256 * 16);
+}
+
+extern "C" int pin_spatial_sort(const float* points, int32_t n, float cell, float* out, int32_t* perm_out, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n > 0 && points && out && workspace && cell > 0.f && points != out, "bad arguments");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    unsigned int* keys = c.take<unsigned int>(n);
+    unsigned int* vals = c.take<unsigned int>(n);
+    unsigned int* keys2 = c.take<unsigned int>(n);
+    unsigned int* vals2 = c.take<unsigned int>(n);
+    size_t tb = 0;
+    PIN_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0, 30, s));
+    void* temp = c.take<char>(tb);
+    PIN_CHECK_ARG(temp != nullptr, "workspace carve failed");
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, n, 1.0f / cell, keys, vals);
+    PIN_CHECK_LAUNCH();
+    PIN_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (size_t)n, 0, 30, s));
+    hipLaunchKernelGGL(permute_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, vals2, n, out, perm_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pin_voxel_downsample(const float* points, int32_t n, float voxel_size, int32_t* sel_out,

@@ -78,8 +78,10 @@ struct QuadDecoderH {
 
     // ------------------------------------------------------------------------------------ staging
     // dec: flat state_dict order (W0 [H][11], b0, hidden (W [H][H], b)*, lout.weight [OD][H], lout.bias [OD])
+    // `part` selects one of the four independent pieces of work (0 hidden layers, 1 layer 0 forward, 2 layer 0 transposed,
+    // 3 biases and output head) so that a multi-block launch can run them side by side; -1 = everything
     __device__ static void stage(const float* __restrict__ dec, int L, unsigned char* __restrict__ w, int tid, int nthreads,
-                                 int OD = 1) {
+                                 int OD = 1, int part = -1) {
         // hidden layers, both directions: one 16-byte slot = 8 k-values of one lane, two pieces.  One flat
         // loop over (layer, direction, tile, K-block, lane), four slots per thread and trip so that 32 loads are
         // in flight per thread: the staging is a chain of memory round trips, not arithmetic.
@@ -111,7 +113,7 @@ struct QuadDecoderH {
             *reinterpret_cast<v4u_t*>(base) = ph;
             *reinterpret_cast<v4u_t*>(base + HID_PIECE) = pl;
         };
-        for (int e0 = tid; e0 < n_slots; e0 += 4 * nthreads) {
+        for (int e0 = tid; e0 < ((part < 0 || part == 0) ? n_slots : 0); e0 += 4 * nthreads) {
             float x[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) fetch(e0 + u * nthreads < n_slots ? e0 + u * nthreads : e0, x[u]);
@@ -119,11 +121,11 @@ struct QuadDecoderH {
             for (int u = 0; u < 4; ++u)
                 if (e0 + u * nthreads < n_slots) emit(e0 + u * nthreads, x[u]);
         }
-        for (int e = tid; e < (L - 1) * H; e += nthreads)
+        for (int e = tid; e < ((part < 0 || part == 3) ? (L - 1) * H : 0); e += nthreads)
             reinterpret_cast<float*>(w + off_bias(L))[H + e] = P1[(size_t)(e / H) * (H * H + H) + H * H + e % H];
         const float* P = P1 + (size_t)(L - 1) * (H * H + H);
         // layer 0 forward: lane (m, g) holds W0[16 mt + m][4g + i], i = 0..3 (zero beyond the 11 inputs)
-        for (int e = tid; e < MT * 64; e += nthreads) {
+        for (int e = tid; e < ((part < 0 || part == 1) ? MT * 64 : 0); e += nthreads) {
             const int lane = e & 63, mt = e >> 6, m = lane & 15, g = lane >> 4;
             float x[4];
 #pragma unroll
@@ -140,7 +142,7 @@ struct QuadDecoderH {
             *reinterpret_cast<v2u_t*>(base + MT * 64 * 8) = pl;
         }
         // layer 0 transposed: lane (c, g) holds W0[u(j, g, i)][c]
-        for (int e = tid; e < NJ * 64; e += nthreads) {
+        for (int e = tid; e < ((part < 0 || part == 2) ? NJ * 64 : 0); e += nthreads) {
             const int lane = e & 63, j = e >> 6, c = lane & 15, g = lane >> 4;
             v4u_t ph, pl;
 #pragma unroll
@@ -155,6 +157,7 @@ struct QuadDecoderH {
             *reinterpret_cast<v4u_t*>(base) = ph;
             *reinterpret_cast<v4u_t*>(base + NJ * 64 * 16) = pl;
         }
+        if (part >= 0 && part != 3) return;
         for (int e = tid; e < H; e += nthreads) reinterpret_cast<float*>(w + off_bias(L))[e] = dec[H * MLP_IN + e];
         // lout.weight [OD][H] then lout.bias [OD]  ->  Wo at O[c*H + u], bias at O[3H + c]
         float* O = reinterpret_cast<float*>(w + off_out(L));

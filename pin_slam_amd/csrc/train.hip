@@ -38,7 +38,7 @@ __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L, int expan
     // operand stream of the fused path (train_fused.h): two streams of (L * H / 16 + 1) blocks of 1 KiB per 16-query tile
     // (tiles <= Q / 14 + 1 whatever the main / Eikonal split, see fused_tiles)
     const size_t stream = ((size_t)(Q + 11) / 12 + 4) * 128 * ((size_t)L * (H / 16) + 1) * 2 * 2 +
-                          (size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048;  // + slot partials of the weight gradient, per-block loss sums
+                          (size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768;  // + slot partials of the weight gradient, per-block loss sums, decoder image
     return unit_major > stream ? unit_major : stream;
 }
 
@@ -690,6 +690,11 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
         }
         return;
     }
+    // the step coefficients go through LDS: lazy_settle indexes them per lane inside its replay loop, and a global
+    // load there is a dependent ~1 us round trip per replayed step
+    extern __shared__ float lazy_coef[];
+    for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
+    __syncthreads();
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long rec = tid >> 3;
     const int j = (int)(tid & 7), lane = threadIdx.x & 63;
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
         const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
         float pi = p[i], mi = 0.f, vi = 0.f;
         if (n > 0) { mi = m[i]; vi = v[i]; }
-        lazy_settle(pi, mi, vi, g[i], n, step - 1, coef, t_max, b1, b2, eps);
+        lazy_settle(pi, mi, vi, g[i], n, step - 1, lazy_coef, t_max, b1, b2, eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
         g[i] = 0.f;
     }
@@ -728,6 +733,9 @@ __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict_
         }
         return;
     }
+    extern __shared__ float lazy_coef[];  // (see adam_lazy_prepare_kernel)
+    for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
+    __syncthreads();
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)row_blocks * 256;
     for (; i < n; i += stride) {
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict_
         if (nn == 0) continue;
         float pi = p[i], mi = 0.f, vi = 0.f;
         if (nn > 0) { mi = m[i]; vi = v[i]; }
-        lazy_settle(pi, mi, vi, g[i], nn, t_final, coef, t_max, b1, b2, eps);
+        lazy_settle(pi, mi, vi, g[i], nn, t_final, lazy_coef, t_max, b1, b2, eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
         g[i] = 0.f;
     }
@@ -825,16 +833,16 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + H + 1;
     float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
+    unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, ws.n_tiles);
+    hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
     hipLaunchKernelGGL((train_fused_kernel<H, L>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
-                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, dw_partial,
+                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
                        n_dec, loss_partial);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        int per_chunk = DW_TILES_PER_WAVE;
-        while ((long)cdiv(ws.n_tiles, per_chunk) > 2048) per_chunk *= 2;
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, per_chunk), L + 1), dim3(256), 0, s, ws, L, per_chunk,
-                           n_dec, dw_partial);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, n_dec,
+                           dw_partial);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
@@ -1037,13 +1045,13 @@ extern "C" int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float*
                                      const float* coef, int32_t t_max, float beta1, float beta2, float eps,
                                      const pin_adam_dense* dense, void* stream) {
     PIN_ENTER();
-    PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max, "bad step");
+    PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max && t_max < 4096, "bad step (t_max < 4096: the coefficient table is staged in LDS)");
     pin_adam_dense d;
     if (int e = lazy_dense(step > 1 ? dense : nullptr, coef, d)) return e;  // (nothing to step before the first iteration)
     if (n_records == 0 && d.n == 0) return 0;
     PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && pending && claim && coef), "NULL pointer");
     const int rec_blocks = (int)cdiv(n_records * 8, 256), dense_blocks = (int)cdiv(d.n, 256);
-    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), as_stream(stream),
                        reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, pending, claim,
                        step, stamp, coef, t_max, beta1, beta2, eps, rec_blocks, d, step - 1);
     PIN_CHECK_LAUNCH();
@@ -1054,7 +1062,7 @@ extern "C" int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, fl
                                    int64_t n_rows, int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2,
                                    float eps, const pin_adam_dense* dense, void* stream) {
     PIN_ENTER();
-    PIN_CHECK_ARG(n_rows >= 0 && t_final >= 0 && t_final <= t_max, "bad sizes");
+    PIN_CHECK_ARG(n_rows >= 0 && t_final >= 0 && t_final <= t_max && t_max < 4096, "bad sizes (t_max < 4096)");
     if (t_final == 0) return 0;
     pin_adam_dense d;
     if (int e = lazy_dense(dense, coef, d)) return e;
@@ -1062,7 +1070,7 @@ extern "C" int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, fl
     PIN_CHECK_ARG(n_rows == 0 || (param && grad && exp_avg && exp_avg_sq && pending && coef), "NULL pointer");
     const long n = (long)n_rows * PIN_FEATURE_DIM;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), dense_blocks = (int)cdiv(d.n, 256);
-    hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks + dense_blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg,
+    hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), as_stream(stream), param, grad, exp_avg,
                        exp_avg_sq, pending, n, t_final, coef, t_max, beta1, beta2, eps, blocks, d);
     PIN_CHECK_LAUNCH();
     return 0;

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                                                                   float* __restrict__ cert_rw, int* __restrict__ ts_rw,
                                                                   float* __restrict__ feat_grad, float* __restrict__ pred_out,
                                                                   DwStream ws, int want_dec, float dscale,
+                                                                  const unsigned char* __restrict__ dec_image,
                                                                   float* __restrict__ dw_partial, int n_dec,
                                                                   double* __restrict__ loss_partial) {
     using Q = QuadDecoderH<H>;
@@ -110,7 +111,15 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
         const int n = DW_SLOTS * n_dec;
         for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
     }
-    bool staged = false;  // the weights are split and staged behind the first tile's gather loads
+    {   // the decoder image, split and permuted once per call by train_stage_kernel: a linear copy per block, in
+        // flight behind the first tile's gather loads
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        constexpr int n16 = Q::bytes(L) >> 4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+    }
+    bool staged = false;
     for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
         const bool work = tile < n_tiles;
         if (!work && staged) break;
@@ -148,18 +157,20 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
             row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
         }
         if (!staged) {
-            Q::stage(f.dec, L, lds, threadIdx.x, TF_BLOCK);
             __syncthreads();
             staged = true;
             if (!work) break;
         }
         // training-mode side effects (neural_points.py:685-710)
         if (g == 3 && active && !is_probe && cert_rw != nullptr) {
+            const int my_ts = sample_ts != nullptr ? sample_ts[qi] : 0;
 #pragma unroll
             for (int t = 0; t < PIN_MAX_K; ++t)
                 if (nb.idx[t] >= 0) {
                     atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
-                    if (ts_rw != nullptr && sample_ts != nullptr) atomicMax(ts_rw + nb.idx[t], sample_ts[qi]);
+                    // (ts_update only grows: a row that already shows a later frame needs no atomic -- a stale read
+                    // can only be smaller than the truth, in which case the atomic is issued anyway)
+                    if (ts_rw != nullptr && sample_ts != nullptr && ts_rw[nb.idx[t]] < my_ts) atomicMax(ts_rw + nb.idx[t], my_ts);
                 }
         }
         float z[4] = {0.f, 0.f, 0.f, 0.f};
@@ -343,45 +354,59 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
     }
 }
 
+// the decoder image of train_fused_kernel, once per call: the hidden layers over blocks 0 .. STAGE_BLOCKS - 4 (the split
+// is a chain of memory round trips, one trip per thread here), the three small parts on a block each
+constexpr int STAGE_BLOCKS = 15;
+template <int H>
+__global__ __launch_bounds__(512) void train_stage_kernel(pin_field f, unsigned char* __restrict__ out) {
+    constexpr int NB0 = STAGE_BLOCKS - 3;
+    if ((int)blockIdx.x < NB0) QuadDecoderH<H>::stage(f.dec, f.levels, out, blockIdx.x * 512 + threadIdx.x, NB0 * 512, 1, 0);
+    else QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, 512, 1, (int)blockIdx.x - NB0 + 1);
+}
+
 template <int H>
 constexpr int train_fused_lds_bytes(int L) {
     return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (TF_BLOCK / 64) * 3 * 16 * 8 * 4 + (TF_BLOCK / 64) * 2 * 8;
 }
 
 // ---- weight gradient over the operand stream ----------------------------------------------------------------------
-// grid (chunks of tiles, L + 1 layers), 4 waves.  A wave owns one 16-unit block of OUTPUT units of its layer (or, when
-// the layer has fewer than 4 such blocks, a phase of the tiles) and all input blocks: per tile 2 + 2 * AB operand
-// loads of 8 bytes per lane (512 contiguous bytes per wave and load) and 3 * AB + 2 MFMAs; hi*hi into the main
-// accumulators, the two cross products into a second set folded in with 2^-11 at the end; the bias gradient is the
-// product with a block of ones.
-constexpr int DW_TILES_PER_WAVE = 8;
+// grid (chunks of DW_CHUNK tiles, L + 1 layers), 16 waves.  A wave owns one 16-unit block of OUTPUT units of its layer
+// and a PHASE of the chunk's tiles (layers with fewer output blocks have more phases), and all input blocks: per tile
+// 2 + 2 * AB operand loads of 8 bytes per lane (512 contiguous bytes per wave and load), issued four tiles ahead of
+// the 3 * AB + 2 MFMAs that consume them; hi*hi into the main accumulators, the two cross products into a second set
+// folded in with 2^-11; the bias gradient is the product with a block of ones.  The phases of a block are added up
+// through LDS (two halving steps), and one wave per output block adds the result into the partial gradient of the
+// chunk's SLOT (chunk % DW_SLOTS, train_finalize_kernel sums the slots): at the reference's batch of 16k samples a
+// version with one wave per 8 tiles adding straight into the 13k decoder gradients spent 33 of its 47 us on atomics.
+constexpr int DW_CHUNK = 32;   // tiles per block
+constexpr int DW_WAVES = 16;
+constexpr int DW_VALS = 20;    // per lane: 4 input blocks x 4 + 4 bias sums
 
 template <int H>
-__global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L, int tiles_per_chunk, int n_dec,
-                                                              float* __restrict__ partial) {
+__global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream ws, int L, int n_dec, float* __restrict__ partial) {
     using G = DwGeom<H>;
     constexpr int MT = G::MT;
+    __shared__ float red[DW_WAVES / 2][DW_VALS][64];
     const int lam = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const int DB = G::d_blocks(L, lam), AB = G::a_blocks(lam);
-    const int ob = wave % DB, phase = wave / DB, phases = 4 / DB;
+    const int DB = G::d_blocks(L, lam), AB = G::a_blocks(lam);  // DB in {1, 2, 4}
+    const int ob = wave % DB, phase = wave / DB, phases = DW_WAVES / DB;
     const size_t n_tiles = (size_t)ws.n_tiles;
     const uint2* __restrict__ D = ws.d + G::d_off(n_tiles, lam) + (size_t)ob * 128 + lane;
     const uint2* __restrict__ A = ws.a + G::a_off(n_tiles, lam) + lane;
-    const int t0 = blockIdx.x * tiles_per_chunk, t1 = min(t0 + tiles_per_chunk, ws.n_tiles);
+    const int t0 = blockIdx.x * DW_CHUNK, t1 = min(t0 + DW_CHUNK, ws.n_tiles);
     v4f_t mainv[MT], cross[MT], bmain = (v4f_t){0.f, 0.f, 0.f, 0.f}, bcross = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ib = 0; ib < MT; ++ib) { mainv[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; cross[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; }
     const v4h_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     auto as4 = [](uint2 v) { const v2u_t u = {v.x, v.y}; return as_h4(u); };
-    for (int t = t0 + phase; t < t1; t += 2 * phases) {
-        // two tiles per trip: all operand loads are issued before the first MFMA
-        const int ta = t, tb = t + phases;
-        const bool has_b = tb < t1;
-        uint2 dh[2], dl[2], ah[2][MT], al[2][MT];
+    constexpr int TPT = 4;  // tiles per trip: all their operand loads are issued before the first MFMA
+    for (int t = t0 + phase; t < t1; t += TPT * phases) {
+        uint2 dh[TPT], dl[TPT], ah[TPT][MT], al[TPT][MT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const size_t tt = (size_t)(u == 0 ? ta : (has_b ? tb : ta));
+        for (int u = 0; u < TPT; ++u) {
+            const int tu = t + u * phases;
+            const size_t tt = (size_t)(tu < t1 ? tu : t);
             dh[u] = D[tt * 128 * DB];
             dl[u] = D[tt * 128 * DB + 64];
 #pragma unroll
@@ -392,8 +417,8 @@ __global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !has_b) break;
+        for (int u = 0; u < TPT; ++u) {
+            if (t + u * phases >= t1) break;
             const v4h_t d_h = as4(dh[u]), d_l = as4(dl[u]);
             bmain = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, ones, bmain, 0, 0, 0);
             bcross = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, ones, bcross, 0, 0, 0);
@@ -407,10 +432,32 @@ __global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L
             }
         }
     }
-    // D layout: element [o = 4 g + r][i = n] of block (ob, ib).  state_dict order: W0 [H][11], b0, (W [H][H], b)*, lout.
-    // Every wave adds into the partial gradient of its chunk SLOT (chunk % DW_SLOTS): a few waves per address instead of
-    // one per chunk -- at the reference's batch the atomics on the 12.5k decoder gradients themselves took 33 of 47 us.
-    // train_finalize_kernel sums the slots.
+    // fold the cross sums in; add the phases up: waves [half, 2 half) park, waves [0, half) add, until DB waves are left
+    float val[DW_VALS];
+#pragma unroll
+    for (int ib = 0; ib < MT; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[4 * ib + r] = fmaf(cross[ib][r], H2_DOWN, mainv[ib][r]);
+#pragma unroll
+    for (int ib = MT; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[4 * ib + r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) val[16 + r] = fmaf(bcross[r], H2_DOWN, bmain[r]);
+    for (int half = DW_WAVES / 2; half >= DB; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int c = 0; c < DW_VALS; ++c) red[wave - half][c][lane] = val[c];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int c = 0; c < DW_VALS; ++c) val[c] += red[wave][c][lane];
+        }
+        __syncthreads();
+    }
+    if (wave >= DB) return;
+    // D layout: element [o = 4 g + r][i = n] of block (ob, ib).  state_dict order: W0 [H][11], b0, (W [H][H], b)*, lout
     const int rows = lam < L ? H : 1;
     const int cols_out = lam == 0 ? MLP_IN : H;
     size_t off = 0;
@@ -423,7 +470,7 @@ __global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = 16 * ob + 4 * g + r, i = 16 * ib + n;
-            const float v = fmaf(cross[ib][r], H2_DOWN, mainv[ib][r]);
+            const float v = val[4 * ib + r];
             if (o < rows && i < cols_out && v != 0.f) atomicAdd(gW + (size_t)o * cols_out + i, v);
         }
     }
@@ -431,7 +478,7 @@ __global__ __launch_bounds__(256) void train_dw_stream_kernel(DwStream ws, int L
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = 16 * ob + 4 * g + r;
-            const float v = fmaf(bcross[r], H2_DOWN, bmain[r]);
+            const float v = val[16 + r];
             if (o < rows && v != 0.f) atomicAdd(gb + o, v);
         }
     }

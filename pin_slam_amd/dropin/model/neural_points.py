@@ -294,9 +294,12 @@ class NeuralPoints(nn.Module):
         lp.diff_travel_dist_local = float(self.diff_travel_dist_local)
         # `neural_points - sensor_position` promotes to the dtype of the position the caller hands in (float64 for
         # dataset.cur_pose_torch, float32 after a pose-graph update): the radius test runs in that type (:476-479)
-        sp = sensor_position.detach().to("cpu")
-        lp.sensor_f64 = int(sp.dtype == torch.float64)
-        spn = sp.to(torch.float64).numpy()
+        hint = getattr(self, "_sensor_hint", None)  # (Mapper.process_frame already holds this position on the host)
+        if hint is not None and hint[0] is sensor_position:
+            spn = np.asarray(hint[1], np.float64)
+        else:
+            spn = sensor_position.detach().to("cpu").to(torch.float64).numpy()
+        lp.sensor_f64 = int(sensor_position.dtype == torch.float64)
         lp.sensor[0], lp.sensor[1], lp.sensor[2] = float(spn[0]), float(spn[1]), float(spn[2])
         lp.radius2 = float(self.local_map_radius ** 2)
         ws = self._workspace(n + 1)
@@ -304,12 +307,23 @@ class NeuralPoints(nn.Module):
         check(_lib.lib().pin_reset_local_map(C.byref(ma), C.byref(la), C.byref(lp), _p(self._local_mask),
                                              _p(self._cnt[2:3]), _p(ws), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream), "pin_reset_local_map")
-        self._m = int(self._cnt[2].item()) - 1  # the padding entry is counted
+        self.local_orientation = sensor_orientation
         self._rebuild_bricks()
+        if getattr(self, "_defer_local_count", False):
+            # Mapper.process_frame reads the local-map size back together with its last count (one synchronisation
+            # less per frame); nothing it runs in between looks at the local tables
+            self._local_count_pending = True
+            return
+        self._finish_local_map(int(self._cnt[2].item()))
+
+    def _finish_local_map(self, counted: int):
+        """Adopt the size of the local map that pin_reset_local_map counted on the device (`counted` includes the
+        padding entry) and publish the feature tables as the reference's Parameters."""
+        self._local_count_pending = False
+        self._m = int(counted) - 1
         self.local_geo_features = nn.Parameter(self._l["geo"][:self._m + 1])
         if self.color_on:
             self.local_color_features = nn.Parameter(self._l["color"][:self._m + 1])
-        self.local_orientation = sensor_orientation
 
     def _rebuild_bricks(self):
         """Per-frame cell-coherent cache of the hash lookups for local, time-filtered queries."""

@@ -17,7 +17,7 @@ import torch
 
 import numpy as np
 
-from ... import _lib, engine, ops
+from ... import _lib, engine, hostcache, ops
 from ... import pool as pool_mod
 
 
@@ -159,9 +159,10 @@ class Mapper(_Base):
             raise NotImplementedError("process_frame after bundle adjustment (pool re-projection with per-frame poses)")
         if c.color_on and c.color_channel not in (1, 3):
             raise NotImplementedError("colour pool with color_channel not in (1, 3)")
-        pose = cur_pose_torch.detach().to("cpu", torch.float64)
-        pose_np = pose.numpy()
+        # the pose on the host: the tracker wrote this tensor from host numbers a moment ago (hostcache), so no copy back
+        pose_np = np.ascontiguousarray(hostcache.to_host(cur_pose_torch), dtype=np.float64)
         origin, orientation = cur_pose_torch[:3, 3], cur_pose_torch[:3, :3]
+        npts._sensor_hint = (origin, pose_np[:3, 3].copy())  # reset_local_map(origin, ...) needs it on the host as well
         scan = point_cloud_torch.detach()
         if scan.dtype != torch.float32 or not scan.is_cuda or scan.stride(1) != 1:
             scan = scan.to(device=self.device, dtype=torch.float32).contiguous()
@@ -205,8 +206,15 @@ class Mapper(_Base):
         if c.prune_map_on and ((frame_id + 1) % c.prune_freq_frame == 0):
             if npts.prune_map(c.max_prune_certainty):
                 npts.recreate_hash(None, None, True, True, frame_id)
-        self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
-        npts.record_memory(verbose=(not self.silence))
+        # (the size of the new local map is read back together with the last count of this function)
+        defer = c.bs_new_sample > 0 and self.silence
+        npts._defer_local_count = defer
+        try:
+            self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
+        finally:
+            npts._defer_local_count = False
+        if not defer:
+            npts.record_memory(verbose=(not self.silence))
         self.determine_used_pose()
 
         # K13: pool window + capacity (mapper.py:303-360); the discard draw comes after update's, as in the reference
@@ -223,7 +231,12 @@ class Mapper(_Base):
             cert = npts._query_certainty(p.bufs[0]["global_coord"][first:first + cur], own_cell=True)
             idx, cnt = ops.new_sample_index(cert, p.bufs[0]["sdf_label"][first:first + cur], c.new_certainty_thre,
                                             np.float32(c.surface_sample_range_m * 3.0), offset=first)
-            new_count = int(cnt.item())
+            if getattr(npts, "_local_count_pending", False):
+                new_count, counted = (int(v) for v in torch.stack((cnt[0], npts._cnt[2])).tolist())
+                npts._finish_local_map(counted)
+                npts.record_memory(verbose=False)
+            else:
+                new_count = int(cnt.item())
             self.new_idx = idx[:new_count]
             self.adaptive_iter_offset = 0
             if c.adaptive_iters and cur > 0:

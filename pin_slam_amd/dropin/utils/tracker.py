@@ -11,7 +11,7 @@ import math
 import numpy as np
 import torch
 
-from ... import engine, ops
+from ... import engine, hostcache, ops
 from ..._lib import GnParams
 
 
@@ -113,6 +113,7 @@ class Tracker:
                 valid_flag = False
             cov_mat = np.linalg.inv(N_raw) * extra["mse"]
         T_out = torch.tensor(T, dtype=torch.float64, device=self.device)
+        hostcache.remember(T_out, T)  # (Mapper.process_frame reads this pose on the host again a moment later)
         if not valid_flag and i < 10:
             T_out, cov_mat = init_pose, None
         return T_out, cov_mat, None, valid_flag

@@ -35,6 +35,9 @@ class GNTracker:
         self.on_gn = None
         self.bricks = None  # ops.BrickCache built for (time_filtering, local) of the calls below
         self.state = self.state_host = None
+        # device loop: Morton-order the source points once per registration (pin_spatial_sort); cell ~ voxel / 4
+        self.sort_points, self.sort_cell, self.sort_min_points = True, max(float(st.resolution) / 4.0, 1e-3), 4096
+        self._sorted = self._sort_ws = None
 
     def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None,
              color=None):
@@ -63,6 +66,19 @@ class GNTracker:
         L = _lib.lib()
         n = src.shape[0]
         stream = torch.cuda.current_stream().cuda_stream
+        # The loop sums over the source points, so their order is free; the down-sampler hands them over ordered by an
+        # x-fastest voxel id, and both per-iteration kernels are ~20 % faster on a Morton-ordered scan (30 -> 25 us
+        # kNN, 37 -> 34.5 us GN per 98.7k points, scripts/knn_order_probe.py): one sort per registration pays after
+        # the second iteration.  Per-point inputs (labels, colours) would have to follow: those calls keep the order.
+        if self.sort_points and labels is None and color is None and n >= self.sort_min_points and iters > 2:
+            if self._sorted is None or self._sorted.shape[0] < n:
+                self._sorted = torch.empty((n, 3), dtype=torch.float32, device=src.device)
+                nb = int(L.pin_maint_workspace_bytes(n))
+                self._sort_ws = torch.empty((nb,), dtype=torch.uint8, device=src.device)
+            out = self._sorted[:n]
+            check(L.pin_spatial_sort(src.data_ptr(), n, float(self.sort_cell), out.data_ptr(), None, self._sort_ws.data_ptr(),
+                                     self._sort_ws.numel(), stream), "pin_spatial_sort")
+            src = out
         if self.state is None:
             self.state = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device=src.device)
             self.state_host = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64).pin_memory()

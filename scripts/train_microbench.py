@@ -35,6 +35,12 @@ print("lib", _L.LIB_PATH)
 for bs in sizes:
     idx = torch.randint(0, scan.shape[0], (bs,), device="cuda", generator=gen)
     coord = (scan[idx] + 0.05 * torch.randn((bs, 3), device="cuda", generator=gen)).contiguous()
+    if os.environ.get("SORT_BATCH"):  # probe: a spatially ordered batch (what sorting the drawn pool indices would give)
+        kk = (torch.floor(coord / 0.1).long() + 512) & 1023
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        coord = coord[torch.argsort(spread(kk[:, 0]) | (spread(kk[:, 1]) << 1) | (spread(kk[:, 2]) << 2))].contiguous()
     label = (0.05 * torch.randn((bs,), device="cuda", generator=gen)).contiguous()
     w = torch.ones(bs, device="cuda"); ts = torch.zeros(bs, dtype=torch.int32, device="cuda")
     buf = ops.TrainBuffers(bs, 10, 8, H, L)
@@ -66,6 +72,7 @@ for bs in sizes:
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n * 1e3
 
+    t_knn = timeit(lambda: ops.knn_query(st, buf.query, 8, out=(buf.nbr, buf.nn, None), bricks=bricks))
     t_full, t_frozen = timeit(lambda: step(gdec)), timeit(lambda: step(None))
-    print(f"bs={bs:8d} queries={buf.Q:8d}  train_step {t_full:8.1f} us ({bs / t_full:7.1f} samples/us)   frozen decoder {t_frozen:8.1f} us"
+    print(f"bs={bs:8d} queries={buf.Q:8d}  train_step {t_full:8.1f} us ({bs / t_full:7.1f} samples/us)   frozen decoder {t_frozen:8.1f} us   kNN {t_knn:6.1f} us"
           f"   loss {buf.loss.cpu().numpy()}")

@@ -123,6 +123,56 @@ def test_tiny_training_batch_matches_oracle(gd):
     assert np.max(np.abs(gdec.cpu().numpy() - gd_)) < 3e-4 * np.abs(gd_).max()
 
 
+@pytest.mark.parametrize("bs,dec,eikonal", [(37, 3, True), (5, 1, True), (64, 1000, True), (33, 10, False), (212, 7, True)])
+def test_fused_training_tile_map(gd, bs, dec, eikonal):
+    """Tile -> query map of the fused training kernel (train_fused.h): mixed tiles of 2 x 6 probes + 4 main samples,
+    odd Eikonal counts, more probe tiles than main samples to fill them (dec = 1), one Eikonal sample, Eikonal off,
+    a frozen decoder -- feature / decoder gradients and both loss sums against the oracle."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = gd
+    k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
+    coord, label, w, ts = d["map_coord0"][:bs], d["map_label0"][:bs], d["map_w0"][:bs], d["map_ts0"][:bs]
+    assert len(coord) == bs
+    feats, decf = U.dev(d["local_geo_features"]), U.dev(d["dec_flat"])
+    fs = dataclasses.replace(d["fs"], feats=feats, dec=decf, certainty=U.dev(d["local_point_certainties"]))
+    buf = ops.TrainBuffers(bs, dec, k, H, L, eikonal=eikonal)
+    assert buf.n_eik == (len(range(0, bs, dec)) if eikonal else 0)
+    kw = dict(sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"])
+
+    def run(with_dec):
+        cert, tsu = U.dev(d["local_point_certainties"]), U.dev(d["local_point_ts_update"], torch.int32)
+        gfeat, gdec = torch.zeros_like(feats), (torch.zeros_like(decf) if with_dec else None)
+        pred = torch.empty(bs, device="cuda")
+        loss = ops.train_step(d["st"], fs, buf, U.dev(coord), U.dev(label), U.dev(w), U.dev(ts, torch.int32), cert, tsu, gfeat,
+                              gdec, pred_out=pred, **kw).cpu().numpy().copy()
+        return gfeat.cpu().numpy(), None if gdec is None else gdec.cpu().numpy(), loss, pred.cpu().numpy(), cert.cpu().numpy()
+
+    def searcher(p):
+        s = O.radius_search(p, d["table"], d["neural_points"], d["resolution"], d["neighbor_dx"], d["max_valid_dist2"],
+                            ts_create=d["point_ts_create"], travel_dist=d["travel_dist"], cur_ts=int(d["cur_ts"]),
+                            diff_travel_dist_local=d["diff_travel_dist_local"])
+        return O.query_feature(p, s, d["local_geo_features"], d["local_neural_points"], None, k, global2local=d["global2local"],
+                               weighted_first=False)
+    ref = O.train_step(coord, label, w, searcher, d["local_geo_features"], d["local_neural_points"], d["dec_flat"], (11, H, L),
+                       d["sdf_scale"], k, dec=dec, eps=d["map_eps"], weight_e=d["map_weight_e"], ekional=eikonal)
+    gfeat, gdec, loss, pred, cert = run(True)
+    gf, gd_ = ref["feat_grad"], ref["dec_grad"]
+    assert np.max(np.abs(gfeat - gf)) < 1e-4 * np.abs(gf).max()
+    assert np.max(np.abs(gdec - gd_)) < 1e-4 * np.abs(gd_).max()
+    np.testing.assert_allclose(pred, ref["sdf_pred"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(loss[0] / bs, ref["sdf_loss"], rtol=1e-5)
+    if eikonal:
+        np.testing.assert_allclose(loss[1] / buf.n_eik, ref["eik_loss"], rtol=2e-4)
+    else:
+        assert loss[1] == 0.0
+    gfeat2, none, loss2, pred2, cert2 = run(False)  # frozen decoder: same feature gradient (atomics: not bit for bit), same side effects
+    assert none is None
+    assert np.max(np.abs(gfeat2 - gfeat)) < 1e-6 * np.abs(gf).max()
+    np.testing.assert_allclose(loss2, loss, rtol=1e-12)
+    assert np.array_equal(pred2, pred) and np.allclose(cert2, cert, rtol=1e-6, atol=1e-7)
+
+
 def test_one_point_scan_through_the_sampler_and_voxel_filter():
     from pin_slam_amd import pool as P, preprocess as PP
     from pin_slam_amd.config import PinConfig

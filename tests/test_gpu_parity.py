@@ -308,6 +308,42 @@ def test_tracking_device_loop(gold, use_bricks):
     np.testing.assert_allclose(dT, d["reg_dT"], rtol=0, atol=1e-5)
 
 
+def test_tracking_on_morton_ordered_points(gold):
+    """The device loop registers the source points in Morton order (pin_spatial_sort, engine.GNTracker.track): the
+    permutation is a permutation, and pose / count / iterations are those of the unsorted run and of the reference."""
+    from pin_slam_amd import _lib, engine
+    from tests import gpu_util as U
+    d = gold
+    src = U.dev(d["reg_src"])
+    n = src.shape[0]
+    out, perm = torch.empty_like(src), torch.empty(n, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(_lib.lib().pin_maint_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().pin_spatial_sort(src.data_ptr(), n, 0.1, out.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           torch.cuda.current_stream().cuda_stream), "pin_spatial_sort")
+    pm = perm.cpu().numpy()
+    assert np.array_equal(np.sort(pm), np.arange(n)) and np.array_equal(out.cpu().numpy(), d["reg_src"][pm])
+    cell = np.floor(out.cpu().numpy() / np.float32(0.1)).astype(np.int64) + 512
+
+    def spread(v):
+        r = np.zeros_like(v)
+        for b in range(10):
+            r |= ((v >> b) & 1) << (3 * b)
+        return r
+    key = spread(cell[:, 0] & 1023) | (spread(cell[:, 1] & 1023) << 1) | (spread(cell[:, 2] & 1023) << 2)
+    assert (np.diff(key) >= 0).all()
+    res = []
+    for sort in (False, True):
+        gn = engine.GNTracker(d["st"], d["fs_loc"], _gn_params(d), d["cfg_reg_lm_lambda"], n)
+        gn.sort_points, gn.sort_min_points = sort, 1
+        res.append(gn.track(src, d["reg_Tinit"], int(d["cfg_reg_iter_n"]), term_deg=d["cfg_reg_term_thre_deg"],
+                            term_m=d["cfg_reg_term_thre_m"]))
+    (T0, c0, r0, i0, v0, _), (T1, c1, r1, i1, v1, _) = res
+    # (the sums are taken in another order: points on a validity threshold may flip, the pose moves by rounding noise)
+    assert abs(c0 - c1) <= 2 and i0 == i1 and v0 == v1, (c0, c1, i0, i1, v0, v1)
+    np.testing.assert_allclose(T1, T0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(T1[:3, 3], d["trk_T"][:3, 3], rtol=0, atol=1e-4)
+
+
 def test_sparse_adam_is_bit_identical_to_dense():
     """pin_adam_step_rows + pin_mark_rows against the dense pin_adam_step over three iterations that touch
     different row subsets (state reset before, as Mapper.mapping does): every bit of p, m, v equal."""
