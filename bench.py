@@ -353,7 +353,7 @@ def main():
     gn_tflops = flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     # what the matrix cores execute: every fp32 product as three fp16 piece products (mlp_h2.h), layer 0 padded to K = 16;
     # the colour / per-neighbour kernel (64 queries per wave) stays on the fp32 MFMA
-    split_f16 = os.environ.get("PIN_MLP", "") != "f32" and not colour and cfg.weighted_first
+    split_f16 = os.environ.get("PIN_MLP", "") != "f32" and cfg.weighted_first and (not colour or L <= 2)
     exec_flops_q = (3 if split_f16 else 1) * (2 if colour else 1) * 2 * 2 * (16 * H + (L - 1) * H * H)
     exec_tflops = exec_flops_q * n_reg / (gn_ms * 1e-3) / 1e12
     Kc = int(npts.neighbor_K)
@@ -400,7 +400,9 @@ def main():
         "source_points": n_src,
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
         "c4_single_gpu": c4,
-        "roofline": {"kernel": "gn_accumulate_mfma_kernel (SDF + colour decoders, photometric rows; 64 queries per wave)"
+        "roofline": {"kernel": ("gn_accumulate_quad_kernel<COLOR> (SDF + colour decoders on two split-fp16 images, photometric rows)"
+                                if cfg.weighted_first and L <= 2 and os.environ.get("PIN_MLP", "") != "f32" else
+                                "gn_accumulate_mfma_kernel (SDF + colour decoders, photometric rows; 64 queries per wave)")
                                if colour else ("gn_accumulate_quad_kernel" if cfg.weighted_first else
                                                "gn_accumulate_mfma_kernel (per-neighbour decoding; 64 queries per wave)"),
                      "bound": "mfma", "achieved": round(gn_tflops, 2),

@@ -219,7 +219,9 @@ __device__ __forceinline__ unsigned int knn_cell_offset(const unsigned short* __
 //     probe: that pass runs only in waves that hold such a brick.
 // Results are the same bits as before (tests: bricks == direct probe == reference on the fixtures and at 2.2 M points).
 // (Measured and not kept: per-lane pre-extraction of the three smallest distances so that a selection round only
-// compares heads -- 26.2 vs 26.8 us, not worth the refill logic.)
+// compares heads -- 26.2 vs 26.8 us, not worth the refill logic; FOUR lanes per query with 21 candidates each -- 35 %
+// fewer instructions per query on paper, 30.6 vs 26.3 us measured: at 104 registers the kernel keeps too few waves
+// in flight for its entry gathers.)
 template <int R>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,

@@ -97,15 +97,18 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
     }
 }
 
-template <bool ORIENT>
+// COLOR: the same neighbours and weights over a second feature table (the colour features, `feats_c`) -> inc
+template <bool ORIENT, bool COLOR = false>
 __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __restrict__ rp, int kk, int nn, float px, float py,
-                                            float pz, int g, QuadIn<ORIENT>& in) {
+                                            float pz, int g, QuadIn<ORIENT>& in, const float* __restrict__ feats_c = nullptr,
+                                            QuadIn<ORIENT>* inc = nullptr) {
     float4 e[PIN_MAX_K];
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t) e[t] = rp[t < kk ? t : 0];
     const float4* __restrict__ rows = reinterpret_cast<const float4*>(f.feats) + (g & 1);
     float u[PIN_MAX_K];
     float4 ft[PIN_MAX_K];
+    float4 fc[COLOR ? PIN_MAX_K : 1];  // (all row loads of a tile are issued together)
     int raw[PIN_MAX_K];
     float S = 0.f;
     bool any_flag = false;
@@ -115,6 +118,7 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
         const bool val = t < kk && raw[t] >= 0;
         const int id = val ? (raw[t] & ~PIN_NBR_QUIRK_BIT) : 0;
         ft[t] = rows[2 * (size_t)(unsigned int)id];
+        if constexpr (COLOR) fc[t] = (reinterpret_cast<const float4*>(feats_c) + (g & 1))[2 * (size_t)(unsigned int)id];
         const float ut = val ? __builtin_amdgcn_rcpf(dist2_exact(e[t].x, e[t].y, e[t].z) + IDW_EPS) : 0.f;
         u[t] = ut;  // (an invalid neighbour contributes nothing)
         S += (nn == 0 && t < kk) ? IDW_EPS : ut;  // no neighbour at all: S = k * eps, as the reference's weights then are
@@ -123,28 +127,26 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
     }
     if constexpr (ORIENT) {
         quad_gather_pass<true, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
+        if constexpr (COLOR) quad_gather_pass<true, true>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
     } else {
-        if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);  // rare
-        else quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
+        if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) {  // rare
+            quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
+            if constexpr (COLOR) quad_gather_pass<false, true>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
+        } else {
+            quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
+            if constexpr (COLOR) quad_gather_pass<false, false>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
+        }
     }
 }
 
-// decoder on the matrix cores -> chain rule -> Gauss-Newton terms of the tile; tot[j] += sum 4j + g
-template <int H, bool ORIENT, bool SPLIT = false, int LC = 0>
-__device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_params& gp, const unsigned char* __restrict__ lds,
-                                            const QuadIn<ORIENT>& in, int nn, float px, float py, float pz, bool active, int qi,
-                                            int g, const float* __restrict__ labels, float* __restrict__ sdf_out,
-                                            float* __restrict__ grad_out, float (&tot)[8]) {
-    using Q = QuadDec<H, SPLIT>;
-    const float s = f.sdf_scale;
+// chain rule from the decoder's input Jacobian a (d value / d z, this lane's four components) back to the query position
+// (see eval_query): value gradient = scale * (direct term through the relative positions + (sum_t Y_t a - (a . z) G) / S)
+template <bool ORIENT>
+__device__ __forceinline__ void quad_chain(const QuadIn<ORIENT>& in, const float (&a)[4], int g, float scale, float& gx, float& gy,
+                                           float& gz) {
     const float (&z)[4] = in.z;
     const float (&Y)[3][4] = in.Y;
-    const float Gx = in.Gx, Gy = in.Gy, Gz = in.Gz, wsum = in.wsum, S = in.S;
     const float (&M)[ORIENT ? 9 : 1] = in.M;
-    // ---- decoder on the matrix cores
-    float a[4];
-    const float x = Q::template run<LC>(lds, f.levels, z, a);
-    // ---- chain rule back to the query position (see eval_query)
     float cbar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -157,16 +159,43 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
             dxs = M[0] * a[0] + M[1] * a[1] + M[2] * a[2];
             dys = M[3] * a[0] + M[4] * a[1] + M[5] * a[2];
             dzs = M[6] * a[0] + M[7] * a[1] + M[8] * a[2];
-        } else { dxs = a[0] * wsum; dys = a[1] * wsum; dzs = a[2] * wsum; }
+        } else { dxs = a[0] * in.wsum; dys = a[1] * in.wsum; dzs = a[2] * in.wsum; }
     }
     cbar = quad_lanes_sum(cbar);
     ax = quad_lanes_sum(ax); ay = quad_lanes_sum(ay); az = quad_lanes_sum(az);
     dxs = quad_lanes_sum(dxs); dys = quad_lanes_sum(dys); dzs = quad_lanes_sum(dzs);
-    const float invS = 1.0f / S;
+    const float invS = 1.0f / in.S;
+    gx = scale * (dxs + (ax - cbar * in.Gx) * invS);
+    gy = scale * (dys + (ay - cbar * in.Gy) * invS);
+    gz = scale * (dzs + (az - cbar * in.Gz) * invS);
+}
+
+// decoder on the matrix cores -> chain rule -> Gauss-Newton terms of the tile; tot[j] += sum 4j + g.
+// COLOR: the colour term of the registration (tracker.py:493-542, 699-744) from the colour decoder's image `lds_c`
+// over the colour inputs `inc`: intensity = 0.299 R + 0.587 G + 0.114 B of the regressed colour (tools.py:408) against
+// the measured one -- a consistency weight exp(-|dI|) (mode 1) or the photometric rows J_c = [p x dI, dI] (mode 2).
+template <int H, bool ORIENT, bool SPLIT = false, int LC = 0, bool COLOR = false>
+__device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_params& gp, const unsigned char* __restrict__ lds,
+                                            const QuadIn<ORIENT>& in, int nn, float px, float py, float pz, bool active, int qi,
+                                            int g, const float* __restrict__ labels, float* __restrict__ sdf_out,
+                                            float* __restrict__ grad_out, float (&tot)[8],
+                                            const unsigned char* __restrict__ lds_c = nullptr,
+                                            const QuadIn<ORIENT>* inc = nullptr, const ColorTerm* ct = nullptr) {
+    using Q = QuadDec<H, SPLIT>;
+    const float s = f.sdf_scale;
+    // ---- decoder on the matrix cores
+    float a[4];
+    const float x = Q::template run<LC>(lds, f.levels, in.z, a);
     const float sdf = s * x;
-    const float gx = s * (dxs + (ax - cbar * Gx) * invS);
-    const float gy = s * (dys + (ay - cbar * Gy) * invS);
-    const float gz = s * (dzs + (az - cbar * Gz) * invS);
+    float gx, gy, gz;
+    quad_chain<ORIENT>(in, a, g, s, gx, gy, gz);
+    float ipred = 0.f, igx = 0.f, igy = 0.f, igz = 0.f;
+    if constexpr (COLOR) {
+        const float kappa[3] = {0.299f, 0.587f, 0.114f};
+        float ac[4];
+        ipred = QuadDecoderH<H>::template run_color<LC>(lds_c, inc->z, kappa, ct->mode == 2, ac);
+        if (ct->mode == 2) quad_chain<ORIENT>(*inc, ac, g, 1.0f, igx, igy, igz);
+    }
     // ---- Gauss-Newton terms (tracker.py:409-524, 652-671).  All four lanes of a query hold the
     // result; each accumulates its quarter of the 31 sums (index i = 4j + g), no cross-lane work here.
     if (active) {
@@ -181,6 +210,13 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
             float wgt = 1.f;
             if (gp.gm_grad > 0.f) { const float d = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + d * d); wgt *= t * t; }
             if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); wgt *= t * t; }
+            float cres = 0.f;
+            if constexpr (COLOR) {
+                const float* cm = ct->colors + 3 * (size_t)qi;
+                const float imeas = 0.299f * cm[0] + 0.587f * cm[1] + 0.114f * cm[2];
+                cres = ipred - imeas;
+                if (ct->mode == 1) wgt *= expf(-fabsf(cres));  // consistency weight (tracker.py:509-514)
+            }
             float J[6];
             J[0] = py * gz - pz * gy; J[1] = pz * gx - px * gz; J[2] = px * gy - py * gx;
             J[3] = gx; J[4] = gy; J[5] = gz;
@@ -193,6 +229,22 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[21 + i] = wgt * J[i] * res;
             v[27] = wgt; v[28] = fabsf(res); v[29] = 1.f; v[30] = wgt * res * res; v[31] = 0.f;
+            if constexpr (COLOR) {
+                if (ct->mode == 2) {  // implicit_color_reg (tracker.py:699-744): + w_photo * Jc^T W Jc, Jc^T W rc
+                    float Jc[6];
+                    Jc[0] = py * igz - pz * igy; Jc[1] = pz * igx - px * igz; Jc[2] = px * igy - py * igx;
+                    Jc[3] = igx; Jc[4] = igy; Jc[5] = igz;
+                    const float wp = wgt * ct->photo_weight;
+                    o = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = i; j < 6; ++j) v[o++] += wp * Jc[i] * Jc[j];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) v[21 + i] += wp * Jc[i] * cres;
+                    v[31] = fabsf(cres);
+                }
+            }
             // lane g keeps sums 4j + g.  Written as masked FMAs: a select chain over v[] is turned into a
             // dynamically indexed private array (scratch memory) by the compiler
             const float m0 = g == 0 ? 1.f : 0.f, m1 = g == 1 ? 1.f : 0.f, m2 = g == 2 ? 1.f : 0.f, m3 = g == 3 ? 1.f : 0.f;
@@ -210,7 +262,8 @@ __host__ __device__ constexpr int gq_lds_bytes(int image_bytes) {
 
 // LC: the number of H-wide layers when the split-fp16 decoder is used (compile time: both sweeps unrolled);
 // 0 with the fp32 image, which reads it from the field
-template <int H, bool ORIENT, bool SPLIT, int LC>
+// COLOR: + the colour term (a second image of LC layers and 3 heads behind the first, staged per block from ct.fc.dec)
+template <int H, bool ORIENT, bool SPLIT, int LC, bool COLOR = false>
 __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_field f, pin_gn_params gp,
                                                                          const float* __restrict__ query,
                                                                          const float4* __restrict__ nbr,
@@ -218,12 +271,15 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
                                                                          const float* __restrict__ labels, int n_q,
                                                                          double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                          float* __restrict__ grad_out,
-                                                                         const double* __restrict__ state) {
+                                                                         const double* __restrict__ state, ColorTerm ct) {
     using Q = QuadDec<H, SPLIT>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];  // decoder image, then the block reduction
+    static_assert(!COLOR || (SPLIT && LC >= 1), "the colour term runs on the split-fp16 images");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];  // decoder image(s), then the block reduction
     unsigned char* const lds = gq_smem;
-    float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + gq_red_offset(Q::bytes(f.levels)));
+    unsigned char* const lds_c = lds + gq_red_offset(Q::bytes(f.levels));  // (COLOR)
+    float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + (COLOR ? 2 : 1) * gq_red_offset(Q::bytes(f.levels)));
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
+    if constexpr (COLOR) QuadDecoderH<H>::stage(ct.fc.dec, LC, lds_c, threadIdx.x, GQ_BLOCK, 3);
     // weights: copy the image staged once per registration (pin_stage_decoder) or split them here; either way the
     // image is visible after the barrier that follows the first gather
     if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
@@ -260,13 +316,19 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
         const float px = query[3 * qq], py = query[3 * qq + 1], pz = query[3 * qq + 2];
         const int nn = nn_count[qq];
         QuadIn<ORIENT> in;
-        quad_gather<ORIENT>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in);
+        QuadIn<ORIENT> inc;  // (COLOR)
+        if constexpr (COLOR) quad_gather<ORIENT, true>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in, ct.fc.feats, &inc);
+        else quad_gather<ORIENT>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in);
         if (!staged) {  // the first gather overlaps the weight staging of the block
             __syncthreads();
             staged = true;
             if (!work) break;
         }
-        quad_finish<H, ORIENT, SPLIT, LC>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
+        if constexpr (COLOR)
+            quad_finish<H, ORIENT, SPLIT, LC, true>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot,
+                                                    lds_c, &inc, &ct);
+        else
+            quad_finish<H, ORIENT, SPLIT, LC>(f, gp, lds, in, nn, px, py, pz, active, qi, g, labels, sdf_out, grad_out, tot);
     }
     __builtin_amdgcn_s_setprio(0);
     // wave: sum over the 16 queries of the row; lane (0, g) then holds sums 4j + g

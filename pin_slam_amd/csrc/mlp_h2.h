@@ -356,6 +356,83 @@ struct QuadDecoderH {
         input_backward(w, L, h, a);
         return x;
     }
+
+    // The colour decoder (3 sigmoid heads, Decoder.regress_color, model/decoder.py:112) on the same tile layout:
+    // returns value = sum_c kappa[c] sigmoid(head_c) (complete in the four lanes of the query) and, when `grad`,
+    // a[r] = d value / d z[4g + r]: ONE transposed sweep seeded with sum_c kappa[c] s_c (1 - s_c) wo_c under the last
+    // ReLU pattern.  The image is staged with OD = 3 (stage(dec, L, w, tid, nthreads, 3)).
+    template <int L>
+    __device__ __forceinline__ static float run_color(const unsigned char* __restrict__ w, const float (&z)[4],
+                                                      const float (&kappa)[3], bool grad, float (&a)[4]) {
+        static_assert(L >= 1 && L <= MLP_MAX_LEVELS, "1..4 layers");
+        const int g = (threadIdx.x & 63) >> 4;
+        v4f_t h[MT], acc[MT];
+        v4u_t sg[L > 1 ? L - 1 : 1][NJ];
+        layer0(w, L, z, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            v4u_t bh[NJ], bl[NJ];
+            pattern_of(h, sg[l - 1]);
+            split_acts(h, bh, bl);
+            load_bias(w, L, l, acc);
+            matmul(w + off_hidf(L, l), bh, bl, acc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+        }
+        const float* __restrict__ O = reinterpret_cast<const float*>(w + off_out(L));
+        float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + c * H + 16 * kt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[c] = fmaf(wo[r], h[kt][r], o[c]);
+            }
+            o[c] += __shfl_xor(o[c], 16, 64);
+            o[c] += __shfl_xor(o[c], 32, 64);
+            o[c] += O[MF_OD_MAX * H + c];
+        }
+        float value = 0.f, coef[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sgm = 1.f / (1.f + expf(-o[c]));
+            value = fmaf(kappa[c], sgm, value);
+            coef[c] = kappa[c] * sgm * (1.f - sgm);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = 0.f;
+        if (!grad) return value;  // (wave-uniform)
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            v4f_t sd = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + c * H + 16 * kt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sd[r] = fmaf(coef[c], wo[r], sd[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[kt][r] = h[kt][r] > 0.f ? sd[r] : 0.f;
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+            v4u_t bh[NJ], bl[NJ];
+            split_acts(h, bh, bl);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+            matmul(w + off_hidb(L, l), bh, bl, acc);
+            mask_by_pieces(sg[l - 1], acc, h);
+        }
+        input_backward(w, L, h, a);
+        return value;
+    }
 };
 
 // One interface over the two decoder images, for kernels templated on the arithmetic: SPLIT = false is the fp32

@@ -659,9 +659,44 @@ static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const f
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 16);
     const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
+    ColorTerm none;
+    memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC>), grid, block, gq_lds_bytes(QuadDec<H, SPLIT>::bytes(f->levels)), s,
-                       *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state);
+                       *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, none);
     return 0;
+}
+
+// the same kernel with the colour term of the registration: two split-fp16 images (sdf, colour) of LC layers each
+constexpr int GQ_COLOR_MAX_LEVELS = 2;  // (2 x 42 KB at 2 x 64; three layers each would not fit the 160 KB of a CU)
+template <int H, bool ORIENT, int LC>
+static int launch_quad_color_inst(const pin_field* f, const pin_gn_params* gp, const ColorTerm& ct, const float* pts,
+                                  const float4* nb4, const int32_t* nn_count, const float* labels, int32_t n, double* sums,
+                                  float* sdf_out, float* grad_out, const double* state, hipStream_t s) {
+    constexpr int lds_bytes = 2 * gq_red_offset(QuadDecoderH<H>::bytes(LC)) + (GQ_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, true, LC, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    const dim3 grid(min(gq_cu_count(), cdiv(n, 16))), block(GQ_BLOCK);
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, true, LC, true>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
+                       labels, n, sums, sdf_out, grad_out, state, ct);
+    return 0;
+}
+
+static bool quad_color_ok(const pin_field* f, const ColorTerm& ct) {
+    return f->weighted_first && use_split_decoder() && ct.mode != 0 && ct.fc.levels == f->levels && ct.fc.hidden == f->hidden &&
+           f->levels <= GQ_COLOR_MAX_LEVELS;
+}
+
+static int launch_quad_color(const pin_field* f, const pin_gn_params* gp, const ColorTerm& ct, const float* pts, const float4* nb4,
+                             const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                             float* grad_out, const double* state, hipStream_t s) {
+#define PIN_LQC(HH, OO, LL) \
+    return launch_quad_color_inst<HH, OO, LL>(f, gp, ct, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)
+#define PIN_LQC_L(HH, OO) do { if (f->levels == 1) PIN_LQC(HH, OO, 1); else PIN_LQC(HH, OO, 2); } while (0)
+    if (f->hidden == 64) { if (f->orient) PIN_LQC_L(64, true); else PIN_LQC_L(64, false); }
+    if (f->orient) PIN_LQC_L(32, true); else PIN_LQC_L(32, false);
+#undef PIN_LQC_L
+#undef PIN_LQC
 }
 
 template <int H, bool ORIENT>
@@ -739,9 +774,11 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     if (f->weighted_first && ct.mode == 0) {  // four lanes per query, persistent blocks (gn_quad.h)
         if (int e = launch_quad(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
+    } else if (quad_color_ok(f, ct)) {  // the same with the colour term (shallow decoders: both images in LDS)
+        if (int e = launch_quad_color(f, gp, ct, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
     } else if (!f->weighted_first && ct.mode == 0 && f->levels == 1) {  // per-neighbour decoding: a column per (query, neighbour) pair
         if (int e = launch_quad_nwf(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s)) return e;
-    } else {  // colour term, per-neighbour decoding with a deeper decoder: 64 queries per wave
+    } else {  // colour term with deeper decoders, per-neighbour decoding with a deeper decoder: 64 queries per wave
         const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
         PIN_DISPATCH_HW(f, gn_accumulate_mfma_kernel, grid, block, 0, s, *f, *gp, pts, nb4, nn_count, labels, n, sums,
                         sdf_out, grad_out, state, ct);

@@ -59,8 +59,36 @@ def fixture(out, case):
     np.savez(out, nn=nn.cpu().numpy(), sums=sums.cpu().numpy().sum(0), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy())
 
 
+def color(out):
+    """Sums of the GN kernel with the colour term (photometric rows / consistency weight) on the replica_color fixture."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tests import golden_util as G
+    from tests import gpu_util as U
+    d = G.load("replica_color")
+    import dataclasses
+    st, fs = U.search_state(d), U.field_state(d)
+    fc = dataclasses.replace(fs, feats=U.dev(d["local_color_features"]), dec=U.dev(d["cdec_flat"]),
+                             hidden=int(d["cdec_hidden"]), levels=int(d["cdec_levels"]), out_dim=3)
+    src = U.dev(d["reg_src"])
+    nbr, nn, cur = ops.knn_query(st, src, int(d["query_nn_k"]), pose=d["reg_Tinit"])
+    gp = GnParams()
+    gp.valid_nn_k = int(d["track_mask_query_nn_k"])
+    gp.min_grad_norm, gp.max_grad_norm = d["cfg_reg_min_grad_norm"], d["cfg_reg_max_grad_norm"]
+    gp.max_sdf_std = d["surface_sample_range_m"] * d["cfg_max_sdf_std_ratio"]
+    gp.gm_dist, gp.gm_grad = d["cfg_reg_GM_dist_m"], d["cfg_reg_GM_grad"]
+    res = {}
+    for tag in ("photo", "consist"):
+        ct, keep = ops.color_term(fc, U.dev(d["reg_colors"]), photometric=(tag == "photo"), photo_weight=d["photometric_loss_weight"])
+        sums, _, _ = ops.gn_accumulate(fs, gp, cur, nbr, nn, color=ct)
+        res[tag] = sums.cpu().numpy().sum(0)
+    torch.cuda.synchronize()
+    np.savez(out, **res)
+
+
 if __name__ == "__main__":
-    if sys.argv[2] == "fixture":
+    if sys.argv[2] == "color":
+        color(sys.argv[1])
+    elif sys.argv[2] == "fixture":
         fixture(sys.argv[1], sys.argv[3])
     else:
         main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))

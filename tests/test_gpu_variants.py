@@ -33,3 +33,20 @@ def test_split_fp16_decoder_matches_fp32_mfma(tmp_path, hidden, levels, orient):
     assert n_valid > 5_000 and abs(n_valid - b["sums"][29]) <= 2  # validity thresholds sit on the gradient norm
     scale = np.abs(a["sums"]).max()
     assert np.abs(a["sums"] - b["sums"]).max() < 1e-5 * scale
+
+
+def test_colour_term_quad_kernel_matches_the_64_per_wave_kernel(tmp_path):
+    """Registration with the colour term: the four-lanes-per-query kernel with two split-fp16 images (default for
+    decoders of up to two layers) against the 64-queries-per-wave fp32 kernel that deeper colour decoders still take
+    (PIN_MLP=f32 routes there): all 32 Gauss-Newton sums, photometric and consistency-weight mode."""
+    outs = {}
+    for name, env in (("quad", {"PIN_MLP": "h2"}), ("wave", {"PIN_MLP": "f32"})):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, os.path.join(HERE, "_variant_worker.py"), out, "color"], check=True, env=e, timeout=600)
+        outs[name] = np.load(out)
+    for tag in ("photo", "consist"):
+        a, b = outs["quad"][tag], outs["wave"][tag]
+        assert abs(a[29] - b[29]) <= 2 and a[29] > 100
+        assert np.abs(a - b).max() < 2e-5 * np.abs(b).max(), (tag, np.abs(a - b).max() / np.abs(b).max())
