@@ -810,54 +810,61 @@ extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_
     return 0;
 }
 
-// weighted_first, one SDF head: fused tile kernel + streamed weight gradient (train_fused.h)
-template <int H, int L>
-static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
-                          const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
-                          float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
-                          float* pred_out, void* workspace, int n_cu, hipStream_t s) {
+// weighted_first: fused tile kernel + streamed weight gradient (train_fused.h); OD = 1 the SDF term, OD = 3 the colour term
+template <int H, int L, int OD>
+static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const FusedColor& fcol, const float* query,
+                          const float4* nb4, const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
+                          const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad,
+                          double* loss_out, float* pred_out, void* workspace, int n_cu, hipStream_t s) {
     using G = DwGeom<H>;
     constexpr int lds_bytes = train_fused_lds_bytes<H>(L);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_fused_kernel<H, L>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_fused_kernel<H, L, OD>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (attr != hipSuccess) return fail(-2, "training tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
     DwStream ws;
     ws.n_tiles = fused_tiles(tp->n_main, tp->n_eik);
     ws.d = reinterpret_cast<uint2*>(workspace);
     ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
-    // power of two that maps a unit loss gradient to ~1 (see train_fused.h "Scaling")
-    const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
-    const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
-    const float dscale = exp2f(-ceilf(log2f(fmaxf(fmaxf(unit_main, unit_eik), 1e-30f))));
+    // power of two that maps a unit loss gradient to ~1 (see train_fused.h "Scaling"); the colour loss is normalised by
+    // the number of surface samples, known on the device only: unit = its smallest value (every sample on the surface)
+    float unit;
+    if (OD == 1) {
+        const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
+        const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
+        unit = fmaxf(unit_main, unit_eik);
+    } else {
+        unit = 8.f * fcol.weight_i / (3.f * (float)tp->n_main);
+    }
+    const float dscale = exp2f(-ceilf(log2f(fmaxf(unit, 1e-30f))));
     const int want_dec = dec_grad != nullptr;
-    const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + H + 1;
+    const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + OD * H + OD;
     float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, ws.n_tiles);
     hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
-    hipLaunchKernelGGL((train_fused_kernel<H, L>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+    hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                        sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
-                       n_dec, loss_partial);
+                       n_dec, loss_partial, fcol);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, n_dec,
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
                            dw_partial);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
-                       dec_grad, loss_partial, grid, loss_out);
+                       dec_grad, loss_partial, grid, loss_out, OD == 1 ? 2 : 1);
     PIN_CHECK_LAUNCH();
     return 0;
 }
 
-template <int H>
-static int launch_fused(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
+template <int H, int OD>
+static int launch_fused(const pin_field* f, const pin_train_params* tp, const FusedColor& fcol, const float* query, const float4* nb4,
                         const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
                         float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
                         float* pred_out, void* workspace, int n_cu, hipStream_t s) {
-#define PIN_LF(LL) return launch_fused_l<H, LL>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, \
-                                                ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
+#define PIN_LF(LL) return launch_fused_l<H, LL, OD>(f, tp, fcol, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, \
+                                                    ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
     switch (f->levels) {
         case 1: PIN_LF(1);
         case 2: PIN_LF(2);
@@ -865,6 +872,15 @@ static int launch_fused(const pin_field* f, const pin_train_params* tp, const fl
         default: PIN_LF(4);
     }
 #undef PIN_LF
+}
+
+static int cu_count() {
+    static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n_cu;
 }
 
 extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
@@ -891,26 +907,23 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     carve_ws(ws, reinterpret_cast<float*>(workspace), H, L);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
-#define PIN_TRAIN_MFMA(KERNEL, ...)                                                                      \
-    do {                                                                                                 \
-        if (H == 64) { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<64, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
-                       else hipLaunchKernelGGL((KERNEL<64, false>), mgrid, mblock, 0, s, __VA_ARGS__); }  \
-        else { if (f->weighted_first) hipLaunchKernelGGL((KERNEL<32, true>), mgrid, mblock, 0, s, __VA_ARGS__); \
-               else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__); }          \
+    // (per-neighbour decoding only: weighted_first takes the fused path below)
+#define PIN_TRAIN_MFMA(KERNEL, ...)                                                                  \
+    do {                                                                                             \
+        if (H == 64) hipLaunchKernelGGL((KERNEL<64, false>), mgrid, mblock, 0, s, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<32, false>), mgrid, mblock, 0, s, __VA_ARGS__);              \
     } while (0)
     const bool quad = f->weighted_first != 0;
-    static const int n_cu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
     const int want_dec = dec_grad != nullptr;
     if (!quad) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the fused path sums per-block partials)
-    if (quad)  // weighted_first: the fused tile kernel + the streamed weight gradient (train_fused.h)
-        return H == 64 ? launch_fused<64>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
-                                          feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
-                       : launch_fused<32>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
-                                          feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s);
+    if (quad) {  // weighted_first: the fused tile kernel + the streamed weight gradient (train_fused.h)
+        FusedColor none;
+        memset(&none, 0, sizeof(none));
+        return H == 64 ? launch_fused<64, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
+                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s)
+                       : launch_fused<32, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
+                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s);
+    }
     // per-neighbour decoding: 64 queries per wave, activations and deltas through the unit-major workspace
     PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     PIN_CHECK_LAUNCH();
@@ -959,14 +972,25 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
     int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)train_ws_floats(Q, H, L, expand) * 4);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
-    PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, sizeof(double), s));
     PIN_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
-#define PIN_TRAIN_C(KERNEL, ...)                                                                          \
-    do {                                                                                                  \
-        if (H == 64) { if (fc->weighted_first) hipLaunchKernelGGL((KERNEL<64, true, 3>), mgrid, mblock, 0, s, __VA_ARGS__); \
-                       else hipLaunchKernelGGL((KERNEL<64, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__); } \
-        else { if (fc->weighted_first) hipLaunchKernelGGL((KERNEL<32, true, 3>), mgrid, mblock, 0, s, __VA_ARGS__); \
-               else hipLaunchKernelGGL((KERNEL<32, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__); }        \
+    if (fc->weighted_first) {  // the fused tile kernel with three heads + the streamed weight gradient (train_fused.h)
+        hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
+        pin_train_params sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.n_main = Q;  // plain tiles of 16 samples, no probes
+        FusedColor fcol;
+        fcol.color = color_label; fcol.count = count; fcol.surface_range = tp->surface_range; fcol.weight_i = tp->weight_i;
+        fcol.loss_weight_on = tp->loss_weight_on;
+        return H == 64 ? launch_fused<64, 3>(fc, &sp, fcol, query, nb4, nn_count, sdf_label, sample_weight, nullptr, nullptr, nullptr,
+                                             feat_grad, dec_grad, loss_out, nullptr, workspace, cu_count(), s)
+                       : launch_fused<32, 3>(fc, &sp, fcol, query, nb4, nn_count, sdf_label, sample_weight, nullptr, nullptr, nullptr,
+                                             feat_grad, dec_grad, loss_out, nullptr, workspace, cu_count(), s);
+    }
+    PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, sizeof(double), s));
+#define PIN_TRAIN_C(KERNEL, ...)                                                                    \
+    do {                                                                                            \
+        if (H == 64) hipLaunchKernelGGL((KERNEL<64, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<32, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__);          \
     } while (0)
     PIN_TRAIN_C(train_fwd_mfma_kernel, *fc, query, nb4, nn_count, Q, Q, ws, (float*)nullptr, (int*)nullptr, (const int*)nullptr);
     hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);

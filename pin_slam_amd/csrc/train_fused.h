@@ -27,10 +27,21 @@
 // d loss / d prediction, so it runs on gradients multiplied by a power of two (`dscale`, chosen by the host from the
 // loss normalisation so that a unit loss gradient maps to ~1); feature gradients and weight gradients are multiplied
 // by 1 / dscale on the way out -- exact.
+//
+// OD = 3: the colour term of the iteration (regress_color + L1 on the surface samples, mapper.py:668-675, 804-812;
+// color_diff_loss, utils/loss.py:31-42) through the same kernels: plain tiles of 16 samples over the colour feature
+// table, three sigmoid heads, one backward sweep seeded with sum_c dL/dh_c wo_c.
 #pragma once
 #include "mlp_h2.h"
 
 namespace pin {
+
+struct FusedColor {          // OD = 3 only
+    const float* color;      // [n_main][3] measured colours
+    const int* count;        // [1] surface samples in the batch (color_count_kernel)
+    float surface_range, weight_i;
+    int loss_weight_on;
+};
 
 constexpr int TF_BLOCK = 512;  // 8 waves per CU, 2 per SIMD (<= 256 VGPRs)
 // (DW_SLOTS partial weight gradients, train.hip: chunk c of the streamed product adds into slot c % DW_SLOTS)
@@ -71,7 +82,7 @@ __device__ __forceinline__ uint2 transpose_block(unsigned int w0, unsigned int w
     return make_uint2(__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi));
 }
 
-template <int H, int L>
+template <int H, int L, int OD = 1>
 __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, pin_train_params tp,
                                                                   const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                                                                   DwStream ws, int want_dec, float dscale,
                                                                   const unsigned char* __restrict__ dec_image,
                                                                   float* __restrict__ dw_partial, int n_dec,
-                                                                  double* __restrict__ loss_partial) {
+                                                                  double* __restrict__ loss_partial, FusedColor fcol) {
     using Q = QuadDecoderH<H>;
     using G = DwGeom<H>;
     constexpr int MT = Q::MT, NJ = Q::NJ;
@@ -215,22 +226,22 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                 for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
         }
         const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
-        float x = 0.f;
-        v4f_t wo[MT];
+        float dxc[OD];  // d loss / d head c of this column, times dscale
+        if constexpr (OD == 1) {
+            float x = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            wo[kt] = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+            for (int kt = 0; kt < MT; ++kt) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = fmaf(wo[kt][r], h[kt][r], x);
-        }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
-        x += O[MF_OD_MAX * H];
-        const float pred = f.sdf_scale * x;
-        if (active && !is_probe && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
-        // ---- loss and d loss / d prediction (train_loss_kernel's arithmetic)
-        float dp = 0.f;
-        {
+                for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
+            }
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            x += O[MF_OD_MAX * H];
+            const float pred = f.sdf_scale * x;
+            if (active && !is_probe && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
+            // ---- loss and d loss / d prediction (train_loss_kernel's arithmetic)
+            float dp = 0.f;
             const int c0 = (lane & 48) + (nq >= 6 ? 6 : 0);
             float P[6];
 #pragma unroll
@@ -253,17 +264,42 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                 if (active && g == 0) acc_bce += (double)l;
                 dp = gg * tp.inv_n_main / tp.sigma;
             }
+            dxc[0] = active ? dp * f.sdf_scale * dscale : 0.f;  // the prediction is sdf_scale * head
+        } else {
+            // colour heads: p_c = sigmoid(head_c); L1 against the measured colour on the surface samples
+            // (train_color_loss_kernel's arithmetic), then through the sigmoid
+            const bool on = fabsf(label[qq]) < fcol.surface_range;
+            const float wt = fcol.loss_weight_on ? fabsf(weight[qq]) : 1.f;
+            const float scale = fcol.weight_i * wt / fmaxf((float)(*fcol.count) * 3.f, 1.f);
+#pragma unroll
+            for (int c = 0; c < OD; ++c) {
+                float o = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + c * H + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = fmaf(wo[r], h[kt][r], o);
+                }
+                o += __shfl_xor(o, 16, 64);
+                o += __shfl_xor(o, 32, 64);
+                o += O[MF_OD_MAX * H + c];
+                const float pc = sigmoidf_(o);
+                const float diff = pc - fcol.color[3 * (size_t)qq + c];
+                const float dpred = on ? (diff > 0.f ? scale : (diff < 0.f ? -scale : 0.f)) : 0.f;
+                if (active && on && g == 0) acc_bce += (double)(wt * fabsf(diff));
+                dxc[c] = active ? dpred * pc * (1.f - pc) * dscale : 0.f;
+            }
         }
-        const float dx = active ? dp * f.sdf_scale * dscale : 0.f;  // the prediction is sdf_scale * head
         // ---- backward
         size_t tbase = (size_t)tile * 128 + lane;
-        if (want_dec) {  // out layer: delta = dx in unit 0 of a 16-unit block, input a_L
+        if (want_dec) {  // out layer: delta = d loss / d heads in units 0 .. OD - 1 of a 16-unit block, input a_L
             Q::split_acts(h, ph[L - 1], pl[L - 1]);
-            unsigned int dh, dl;
-            h2_split2((g == 0) ? dx : 0.f, 0.f, dh, dl);
+            unsigned int dh0, dl0, dh1 = 0u, dl1 = 0u;
+            h2_split2((g == 0) ? dxc[0] : 0.f, (g == 0 && OD > 1) ? dxc[OD > 1 ? 1 : 0] : 0.f, dh0, dl0);
+            if constexpr (OD > 2) h2_split2((g == 0) ? dxc[2] : 0.f, 0.f, dh1, dl1);
             uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
-            D[0] = transpose_block(dh, 0u, ident);
-            D[64] = transpose_block(dl, 0u, ident);
+            D[0] = transpose_block(dh0, dh1, ident);
+            D[64] = transpose_block(dl0, dl1, ident);
             uint2* __restrict__ A = ws.a + G::a_off(n_tiles, L) + (size_t)tile * 128 * (MT - 1) + tbase;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -271,10 +307,21 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                 A[mt * 128 + 64] = transpose_block(pl[L - 1][mt >> 1][2 * (mt & 1)], pl[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
             }
         }
+        bool any_dx = false;
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt)
+        for (int c = 0; c < OD; ++c) any_dx = any_dx || dxc[c] != 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[kt][r] = h[kt][r] > 0.f ? dx * wo[kt][r] : 0.f;
+        for (int kt = 0; kt < MT; ++kt) {
+            v4f_t sd = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < OD; ++c) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + c * H + 16 * kt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sd[r] = fmaf(dxc[c], wo[r], sd[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[kt][r] = h[kt][r] > 0.f ? sd[r] : 0.f;
+        }
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             // h = delta_{l+1} (H units); its pieces feed the transposed product and the weight-gradient stream
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                 Q::input_backward(lds, L, bh, bl, dz);
                 // ---- feature-gradient scatter, one atomic instruction per QUERY (64 lanes = 8 neighbours x 8 feature
                 // dims, whole 32-byte rows per instruction): exchange through the wave's LDS patch
-                const bool live = active && dx != 0.f;
+                const bool live = active && any_dx;
                 if (g < 2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r] * inv_dscale;
@@ -360,8 +407,9 @@ constexpr int STAGE_BLOCKS = 15;
 template <int H>
 __global__ __launch_bounds__(512) void train_stage_kernel(pin_field f, unsigned char* __restrict__ out) {
     constexpr int NB0 = STAGE_BLOCKS - 3;
-    if ((int)blockIdx.x < NB0) QuadDecoderH<H>::stage(f.dec, f.levels, out, blockIdx.x * 512 + threadIdx.x, NB0 * 512, 1, 0);
-    else QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, 512, 1, (int)blockIdx.x - NB0 + 1);
+    const int OD = f.out_dim > 1 ? f.out_dim : 1;
+    if ((int)blockIdx.x < NB0) QuadDecoderH<H>::stage(f.dec, f.levels, out, blockIdx.x * 512 + threadIdx.x, NB0 * 512, OD, 0);
+    else QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, 512, OD, (int)blockIdx.x - NB0 + 1);
 }
 
 template <int H>
@@ -383,7 +431,8 @@ constexpr int DW_WAVES = 16;
 constexpr int DW_VALS = 20;    // per lane: 4 input blocks x 4 + 4 bias sums
 
 template <int H>
-__global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream ws, int L, int n_dec, float* __restrict__ partial) {
+__global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream ws, int L, int OD, int n_dec,
+                                                                        float* __restrict__ partial) {
     using G = DwGeom<H>;
     constexpr int MT = G::MT;
     __shared__ float red[DW_WAVES / 2][DW_VALS][64];
@@ -458,7 +507,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
     }
     if (wave >= DB) return;
     // D layout: element [o = 4 g + r][i = n] of block (ob, ib).  state_dict order: W0 [H][11], b0, (W [H][H], b)*, lout
-    const int rows = lam < L ? H : 1;
+    const int rows = lam < L ? H : OD;
     const int cols_out = lam == 0 ? MLP_IN : H;
     size_t off = 0;
     for (int u = 0; u < lam; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
@@ -488,12 +537,12 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
 __global__ __launch_bounds__(256) void train_finalize_kernel(const float* __restrict__ partial, int n_dec, float inv_dscale,
                                                              float* __restrict__ dec_grad,
                                                              const double* __restrict__ loss_partial, int n_loss,
-                                                             double* __restrict__ loss_out) {
+                                                             double* __restrict__ loss_out, int n_loss_out) {
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         double b = 0.0, e = 0.0;
         for (int i = threadIdx.x; i < n_loss; i += 64) { b += loss_partial[2 * i]; e += loss_partial[2 * i + 1]; }
         b = wave_sum(b); e = wave_sum(e);
-        if (threadIdx.x == 0) { loss_out[0] = b; loss_out[1] = e; }
+        if (threadIdx.x == 0) { loss_out[0] = b; if (n_loss_out > 1) loss_out[1] = e; }
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (dec_grad == nullptr || i >= n_dec) return;

@@ -35,6 +35,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def spatial_sort(points: torch.Tensor, cell: float, return_perm: bool = False):
+    """points [n,3] in ascending Morton order of floor(p / cell) (pin_spatial_sort); optionally the permutation."""
+    L = _lib.lib()
+    n = points.shape[0]
+    out = torch.empty_like(points)
+    perm = torch.empty((n,), dtype=torch.int32, device=points.device) if return_perm else None
+    if n == 0:
+        return (out, perm) if return_perm else out
+    ws = torch.empty((int(L.pin_maint_workspace_bytes(n)),), dtype=torch.uint8, device=points.device)
+    check(L.pin_spatial_sort(_ptr(points, torch.float32), n, float(cell), _ptr(out), _ptr(perm), _ptr(ws), ws.numel(), _stream()),
+          "pin_spatial_sort")
+    return (out, perm) if return_perm else out
+
+
 def search_neighborhood(num_nei_cells: int, search_alpha: float, resolution: float):
     """neighbor_dx [Kc,3] (meshgrid 'ij', x slowest) and max_valid_dist2
     (NeuralPoints.set_search_neighborhood, model/neural_points.py:910-948)."""

@@ -30,8 +30,7 @@ st = ops.SearchState(table=dev(m.table), pos4=pos4, cand_off=dev(ops.candidate_o
 fs = ops.FieldState(feats=dev(m.features), dec=dev(synth.init_decoder(H, L)), k=8, hidden=H, levels=L,
                     weighted_first=True, sdf_scale=0.055, certainty=torch.zeros(P, device="cuda"), pos=pos)
 scan = dev(synth.make_scan(m))
-key = torch.floor(scan / 0.4).long()
-scan = scan[torch.argsort((key[:, 0] + 4096) + ((key[:, 1] + 4096) << 14) + ((key[:, 2] + 4096) << 28))].contiguous()
+scan = ops.spatial_sort(scan.contiguous(), 0.1)  # the order Tracker.tracking registers its points in (engine.GNTracker.track)
 gp = GnParams(); gp.valid_nn_k = 8; gp.min_grad_norm = 0.5; gp.max_grad_norm = 2.0; gp.max_sdf_std = 0.25; gp.gm_dist = 0.3; gp.gm_grad = 0.1
 bricks = ops.BrickCache(dx, 2).build(st, wait=True)
 fs.stage_decoder()  # as the tracker does once per registration
