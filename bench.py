@@ -204,12 +204,15 @@ def main():
 
     if mapper_dp:
         out = bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P)
-        if rank == 0:
-            print(json.dumps(out), flush=True)
         mp.dp_comm.close()
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
+        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C runtime's buffer until exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         return
 
     scan_np = synth.make_scan(m, n=args.scan, seed=1, noise=wl.get("scan_noise", 0.02))
@@ -404,6 +407,8 @@ def main():
                                 if cfg.weighted_first and L <= 2 and os.environ.get("PIN_MLP", "") != "f32" else
                                 "gn_accumulate_mfma_kernel (SDF + colour decoders, photometric rows; 64 queries per wave)")
                                if colour else ("gn_accumulate_quad_kernel" if cfg.weighted_first else
+                                               "gn_accumulate_quad_nwf_kernel (per-neighbour decoding: a column per (query, neighbour) pair)"
+                                               if L == 1 else
                                                "gn_accumulate_mfma_kernel (per-neighbour decoding; 64 queries per wave)"),
                      "bound": "mfma", "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
@@ -555,7 +560,7 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
                       "busbw_GBs": round(2 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9, 1)
                                    if ar_ms == ar_ms and ar_ms > 0 else None,
                       "share_of_iteration": round(ar_ms / ms_it, 3) if ar_ms == ar_ms else None},
-        "roofline": {"kernel": "ncclAllReduce (xGMI) + train_fwd/bwd_quad_kernel", "bound": "xgmi-link + mfma",
+        "roofline": {"kernel": "ncclAllReduce (xGMI) + train_fused_kernel / train_dw_stream_kernel", "bound": "xgmi-link + mfma",
                      "achieved": round(2 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9, 1)
                                  if ar_ms == ar_ms and ar_ms > 0 else None,
                      "peak": 7 * 153.0, "unit": "GB/s",

@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 7
+PIN_ABI_VERSION = 8
 PIN_COMM_ID_BYTES = 128
 
 vp = C.c_void_p
