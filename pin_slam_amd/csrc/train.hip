@@ -5,12 +5,13 @@
 //   scatter) and decoder parameters, and Adam (utils/tools.py:198-199).
 //
 // Structure (one C-ABI call = one stream-ordered sequence of launches):
-//   make_queries -> [pin_knn_query by the caller] -> train_fwd -> train_loss -> train_bwd
-//   -> train_dw (one launch per decoder layer, fp32 MFMA 16x16x4 over the batch dimension).
-// Activations and layer deltas go through a caller-provided workspace laid out unit-major
-// ([row][Q], query contiguous) so that thread-per-query kernels write coalesced and the
-// weight-gradient GEMM reads K-contiguous operands.  At the batch sizes of the reference
-// (16k samples + 10k Eikonal queries) the workspace stays in L2 / Infinity Cache.
+//   weighted_first (class default):  [queries + kNN by the caller] -> train_stage -> train_fused -> train_dw_stream ->
+//       train_finalize   (train_fused.h: one tile kernel from the gather to the gradients, decoder on the split-fp16
+//       matrix cores, weight gradient streamed over identity-MFMA-transposed operands)
+//   per-neighbour decoding (weighted_first = False):  train_fwd_mfma -> train_loss -> train_bwd_mfma -> train_dw
+//       (this file: 64 queries per wave, fp32 MFMA 16x16x4, activations and layer deltas through a caller-provided
+//       workspace laid out unit-major ([row][Q], query contiguous))
+// followed by the optimiser kernels (dense / row-flagged / exact lazy Adam).
 #include "mlp_quad.h"
 
 namespace pin {

@@ -1,13 +1,17 @@
-// One training iteration of Mapper.mapping (utils/mapper.py:645-818) as TWO launches (weighted_first, one SDF head):
+// One training iteration of Mapper.mapping (utils/mapper.py:645-818), weighted_first, behind pin_train_step /
+// pin_train_color_step:
 //
-//   train_fused_kernel<H, L>   gather + IDW interpolation (neural_points.py:590-746), decoder forward, BCE-with-logits +
+//   train_stage_kernel<H>      the decoder as the tile kernel reads it from LDS (split fp16 pieces, both directions,
+//                              MFMA operand order), once per call; every block of the tile kernel copies it linearly
+//   train_fused_kernel<H,L,OD> gather + IDW interpolation (neural_points.py:590-746), decoder forward, BCE-with-logits +
 //                              Eikonal loss and its gradient (utils/loss.py:45-63, mapper.py:732-780), decoder backward,
 //                              feature-gradient scatter, training-mode side effects -- per 16-query tile, four lanes per
 //                              query as in gn_quad.h, decoder on the split-fp16 matrix cores (mlp_h2.h).  Nothing of a
 //                              tile goes through memory between forward and backward; what leaves the kernel for the
-//                              decoder's weight gradient is the OPERAND STREAM of the second launch:
+//                              decoder's weight gradient is the OPERAND STREAM of the next launch:
 //   train_dw_stream_kernel<H>  dW_l = sum_q delta_{l+1}[q] (x) a_l[q]: a 16x16x16 MFMA per (16 out units, 16 in units,
-//                              16 queries of a tile) and piece product, operands read exactly as the instruction wants them.
+//                              16 queries of a tile) and piece product, operands read exactly as the instruction wants them
+//   train_finalize_kernel      sums the slot copies of the weight gradient into dec_grad and the per-block loss sums
 //
 // r01-r02a had three launches (forward with activation stores, backward with delta stores, a K = 4 fp32 MFMA GEMM over
 // unit-major fp32 rows) of ~30 us each at the reference's batch of 16k samples: 2.1 kB per query written with 64-byte
