@@ -358,12 +358,6 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
 // mean / spread of the predictions, the gradient terms -- is a sum over the 8 consecutive lanes of the query inside a
 // DPP row (three DPP steps, no LDS).  The 32 lanes of a query hold its result; lane (t, g) keeps Gauss-Newton sum
 // 4 t + g, picked by a per-lane selector that is built once.
-__device__ __forceinline__ float octet_sum(float v) {  // over aligned groups of 8 lanes
-    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);  // row_half_mirror
-    return v;
-}
 
 constexpr int NWF_BLOCK = 512;  // 2 waves per SIMD (up to 256 VGPRs: the two-deep prefetch state needs ~190)
 

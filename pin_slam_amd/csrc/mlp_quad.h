@@ -184,6 +184,12 @@ __device__ __forceinline__ float row_sum_f32(float v) {
     v += dpp_mov<0x140>(v);
     return v;
 }
+__device__ __forceinline__ float octet_sum(float v) {  // over aligned groups of 8 lanes (result in every lane of the group)
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ float quad_lanes_sum(float v) {  // over the four lanes (n, g = 0..3) of a query
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);

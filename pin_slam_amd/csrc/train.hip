@@ -8,7 +8,9 @@
 //   weighted_first (class default):  [queries + kNN by the caller] -> train_stage -> train_fused -> train_dw_stream ->
 //       train_finalize   (train_fused.h: one tile kernel from the gather to the gradients, decoder on the split-fp16
 //       matrix cores, weight gradient streamed over identity-MFMA-transposed operands)
-//   per-neighbour decoding (weighted_first = False):  train_fwd_mfma -> train_loss -> train_bwd_mfma -> train_dw
+//   per-neighbour decoding (weighted_first = False), one-layer decoder:  train_stage -> train_fused_nwf -> train_dw_stream
+//       -> train_finalize
+//   per-neighbour decoding, deeper decoders:  train_fwd_mfma -> train_loss -> train_bwd_mfma -> train_dw
 //       (this file: 64 queries per wave, fp32 MFMA 16x16x4, activations and layer deltas through a caller-provided
 //       workspace laid out unit-major ([row][Q], query contiguous))
 // followed by the optimiser kernels (dense / row-flagged / exact lazy Adam).
@@ -36,10 +38,11 @@ __host__ __device__ inline size_t train_ws_floats(int Q, int H, int L, int expan
     const size_t Qs = (size_t)((Q + 63) / 64) * 64;
     const size_t QsT = Qs * (size_t)expand;
     const size_t unit_major = QsT * (12 + (size_t)L * H + (size_t)L * H + MF_OD_MAX + 2 * (size_t)L + MF_OD_MAX) + 2 * MF_OD_MAX * Qs;
-    // operand stream of the fused path (train_fused.h): two streams of (L * H / 16 + 1) blocks of 1 KiB per 16-query tile
-    // (tiles <= Q / 14 + 1 whatever the main / Eikonal split, see fused_tiles)
-    const size_t stream = ((size_t)(Q + 11) / 12 + 4) * 128 * ((size_t)L * (H / 16) + 1) * 2 * 2 +
-                          (size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768;  // + slot partials of the weight gradient, per-block loss sums, decoder image
+    // operand stream of the fused paths (train_fused.h): two streams of (L * H / 16 + 1) blocks of 1 KiB per tile + slot
+    // partials of the weight gradient, per-block loss sums, decoder image.  Tiles: <= Q / 14 + 1 of 16 queries whatever the
+    // main / Eikonal split (fused_tiles); per-neighbour decoding: <= Q / 2 + 3 tiles of 2 queries x 8 neighbours
+    const size_t tiles = expand == 1 ? (size_t)(Q + 11) / 12 + 4 : (size_t)Q / 2 + 4;
+    const size_t stream = tiles * 128 * ((size_t)L * (H / 16) + 1) * 2 * 2 + (size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768;
     return unit_major > stream ? unit_major : stream;
 }
 
@@ -875,6 +878,47 @@ static int launch_fused(const pin_field* f, const pin_train_params* tp, const Fu
 #undef PIN_LF
 }
 
+// weighted_first = False with a one-layer decoder: groups of three (query, neighbour)-column tiles (train_fused.h)
+template <int H>
+static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
+                            const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
+                            float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
+                            float* pred_out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t s) {
+    using G = DwGeom<H>;
+    constexpr int L = 1;
+    constexpr int lds_bytes = train_fused_nwf_lds_bytes<H>();
+    DwStream ws;
+    const int n_groups = (tp->n_main + 5) / 6 + tp->n_eik;
+    ws.n_tiles = 3 * n_groups;
+    const size_t need = 2 * G::total((size_t)ws.n_tiles, L) * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
+    PIN_CHECK_ARG((size_t)workspace_bytes >= need, "workspace too small");
+    ws.d = reinterpret_cast<uint2*>(workspace);
+    ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
+    const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
+    const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
+    const float dscale = exp2f(-ceilf(log2f(fmaxf(fmaxf(unit_main, unit_eik), 1e-30f))));
+    const int want_dec = dec_grad != nullptr;
+    const int n_dec = H * MLP_IN + H + H + 1;
+    float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
+    double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
+    unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
+    const int grid = min(n_cu, cdiv(n_groups, TF_BLOCK / 64));
+    hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
+    hipLaunchKernelGGL((train_fused_nwf_kernel<H>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image,
+                       dw_partial, n_dec, loss_partial);
+    PIN_CHECK_LAUNCH();
+    if (want_dec) {
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec,
+                           dw_partial);
+        PIN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
+                       dec_grad, loss_partial, grid, loss_out, 2);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 static int cu_count() {
     static const int n_cu = [] {
         int dev = 0, v = 0;
@@ -925,7 +969,14 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
                        : launch_fused<32, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s);
     }
-    // per-neighbour decoding: 64 queries per wave, activations and deltas through the unit-major workspace
+    if (L == 1 && use_split_decoder())  // per-neighbour decoding, one-layer decoder: (query, neighbour)-column tiles
+        return H == 64 ? launch_fused_nwf<64>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
+                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes,
+                                              cu_count(), s)
+                       : launch_fused_nwf<32>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
+                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes,
+                                              cu_count(), s);
+    // deeper per-neighbour decoders: 64 queries per wave, activations and deltas through the unit-major workspace
     PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     PIN_CHECK_LAUNCH();
     hipLaunchKernelGGL(train_loss_kernel, dim3(cdiv(tp->n_main + tp->n_eik, 256)), dim3(256), 0, s, *tp, sdf_label,

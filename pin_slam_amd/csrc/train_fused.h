@@ -405,6 +405,228 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
     }
 }
 
+// ---- per-neighbour decoding (weighted_first = False; run_kitti.yaml and eight more shipped configs), one H-wide layer
+// The decoder runs once per NEIGHBOUR and the predictions are weighted afterwards (mapper.py:658-662).  As in
+// gn_accumulate_quad_nwf_kernel a decoder column is a (query, neighbour) pair: a tile = 2 queries x 8 neighbour slots,
+// everything that mixes the neighbours of a query is a sum over 8 consecutive lanes of a DPP row.  The six probes of an
+// Eikonal sample are THREE tiles (tile j = the +- pair of axis j): a wave works on groups of three tiles -- forward x 3
+// (a one-layer decoder leaves 20 piece words per tile to keep), loss, backward x 3 -- and main samples go through the
+// same code six at a time.  Feature gradients: a column owns one row, 8 columns x 8 dims per atomic instruction.
+template <int H>
+__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field f, pin_train_params tp,
+                                                                      const float* __restrict__ query,
+                                                                      const float4* __restrict__ nbr,
+                                                                      const int* __restrict__ nn_count,
+                                                                      const float* __restrict__ label,
+                                                                      const float* __restrict__ weight,
+                                                                      const int* __restrict__ sample_ts,
+                                                                      float* __restrict__ cert_rw, int* __restrict__ ts_rw,
+                                                                      float* __restrict__ feat_grad, float* __restrict__ pred_out,
+                                                                      DwStream ws, int want_dec, float dscale,
+                                                                      const unsigned char* __restrict__ dec_image,
+                                                                      float* __restrict__ dw_partial, int n_dec,
+                                                                      double* __restrict__ loss_partial) {
+    using Q = QuadDecoderH<H>;
+    using G = DwGeom<H>;
+    constexpr int MT = Q::MT, NJ = Q::NJ, L = 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
+    unsigned char* const lds = tf_smem;
+    constexpr int IMG = (Q::bytes(L) + 15) & ~15;
+    float* const sdz = reinterpret_cast<float*>(lds + IMG) + (threadIdx.x >> 6) * (16 * 8 + 16);  // per wave: dz [16][8], idx [16]
+    int* const sidx = reinterpret_cast<int*>(sdz + 16 * 8);
+    double (*lred)[2] = reinterpret_cast<double (*)[2]>(lds + IMG + (TF_BLOCK / 64) * (16 * 8 + 16) * 4);
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int q2 = nq >> 3, t = nq & 7;
+    const int n_main = tp.n_main, n_eik = tp.n_eik, kk = f.k;
+    const int n_main_groups = (n_main + 5) / 6, n_groups = n_main_groups + n_eik;
+    const int n_tiles = ws.n_tiles;  // 3 * n_groups
+    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const float inv_dscale = 1.0f / dscale, s = f.sdf_scale;
+    v4h_t ident;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ident[r] = (nq == 4 * g + r) ? (_Float16)1.0f : (_Float16)0.0f;
+    double acc_bce = 0.0, acc_eik = 0.0;
+    if (want_dec) {
+        const int n = DW_SLOTS * n_dec;
+        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+    }
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        constexpr int n16 = Q::bytes(L) >> 4;
+        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
+    v4f_t wo[MT];
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt) wo[kt] = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+    const float bo = O[MF_OD_MAX * H];
+    const float4* __restrict__ rows = reinterpret_cast<const float4*>(f.feats) + (g & 1);
+    for (int grp = blockIdx.x + gridDim.x * wave; grp < n_groups; grp += n_waves) {
+        const bool eik = grp >= n_main_groups;
+        // ---- forward of the three tiles
+        v2u_t zh[3], zl[3];
+        v4u_t ph[3][NJ], pl[3][NJ];
+        float wt[3], pred[3];
+        int id[3], qidx[3];
+        bool act[3], valn[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int a = 2 * j + q2;  // query of the group: main sample 6 grp + a / probe a of Eikonal sample grp - n_main_groups
+            const int qi = eik ? n_main + 6 * (grp - n_main_groups) + a : 6 * grp + a;
+            const bool valid = eik || qi < n_main;
+            const int qq = valid ? qi : 0;
+            qidx[j] = qq; act[j] = valid;
+            const float4 e = nbr[(size_t)qq * kk + (t < kk ? t : 0)];
+            const int nn = nn_count[qq];
+            const int raw = __float_as_int(e.w);
+            const bool val = t < kk && raw >= 0;
+            const int idn = val ? (raw & ~PIN_NBR_QUIRK_BIT) : 0;
+            const float4 ft = rows[2 * (size_t)(unsigned int)idn];
+            float ut = val ? 1.0f / (dist2_exact(e.x, e.y, e.z) + IDW_EPS) : 0.f;  // (neighbor_weights' arithmetic)
+            if (nn == 0 && t < kk) ut = IDW_EPS;
+            const float S = octet_sum(ut);
+            const float w = val ? ut / S : 0.f;
+            float v[3] = {e.x, e.y, e.z};
+            const bool quirk = val && (raw & PIN_NBR_QUIRK_BIT) != 0;
+            if (f.orient != nullptr || __builtin_amdgcn_ballot_w64(quirk) != 0ull) {  // after PGO / a flagged neighbour (rare)
+                const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+                if (val) neighbor_vector_only(f, idn, quirk, e.x, e.y, e.z, qx, qy, qz, v);
+            }
+            float z[4];
+            z[0] = !val ? 0.f : (g < 2 ? ft.x : (g == 2 ? v[0] : 0.f));
+            z[1] = !val ? 0.f : (g < 2 ? ft.y : (g == 2 ? v[1] : 0.f));
+            z[2] = !val ? 0.f : (g < 2 ? ft.z : (g == 2 ? v[2] : 0.f));
+            z[3] = !val ? 0.f : (g < 2 ? ft.w : 0.f);
+            Q::split_input(z, zh[j], zl[j]);
+            v4f_t h[MT], acc[MT];
+            Q::layer0(lds, L, zh[j], zl[j], acc);
+            float x = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { h[mt][r] = relu1(acc[mt][r]); x = fmaf(wo[mt][r], h[mt][r], x); }
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            x += bo;
+            Q::split_acts(h, ph[j], pl[j]);
+            wt[j] = w; id[j] = idn; valn[j] = val;
+            pred[j] = octet_sum(w * (s * x));  // mapper.py:658-662
+            if (!eik && valid && t == 0 && g == 0 && pred_out != nullptr) pred_out[qi] = pred[j];
+            // training-mode side effects (neural_points.py:685-710), main samples only
+            if (!eik && valid && val && g == 3 && cert_rw != nullptr) {
+                atomicAdd(cert_rw + idn, w);
+                if (ts_rw != nullptr && sample_ts != nullptr) {
+                    const int my_ts = sample_ts[qi];
+                    if (ts_rw[idn] < my_ts) atomicMax(ts_rw + idn, my_ts);
+                }
+            }
+        }
+        // ---- loss and d loss / d prediction of this lane's query in each tile (train_loss_kernel's arithmetic)
+        float dp[3];
+        if (eik) {
+            float ga[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {  // tile j holds the + (q2 = 0) and - (q2 = 1) probe of axis j
+                const float other = __shfl_xor(pred[j], 8, 64);
+                const float pp = q2 == 0 ? pred[j] : other, pm = q2 == 0 ? other : pred[j];
+                ga[j] = (pp - pm) / (2.f * tp.eik_eps);
+            }
+            const float n = sqrtf(ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2]);
+            const float r = n - 1.f;
+            if (lane == 0) acc_eik += (double)(r * r);
+            const float c = n > 0.f ? tp.weight_e * 2.f * r * tp.inv_n_eik / (n * 2.f * tp.eik_eps) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dp[j] = q2 == 0 ? c * ga[j] : -c * ga[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int qq = qidx[j];
+                const float xl = pred[j] / tp.sigma;
+                const float y = 1.f / (1.f + expf(-label[qq] / tp.sigma));
+                float l = fmaxf(xl, 0.f) - xl * y + log1pf(expf(-fabsf(xl)));
+                float gg = 1.f / (1.f + expf(-xl)) - y;
+                if (tp.loss_weight_on) { const float w = fabsf(weight[qq]); l *= w; gg *= w; }
+                if (act[j] && t == 0 && g == 0) acc_bce += (double)l;
+                dp[j] = act[j] ? gg * tp.inv_n_main / tp.sigma : 0.f;
+            }
+        }
+        // ---- backward of the three tiles
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t tile = (size_t)3 * grp + j;
+            const size_t tbase = tile * 128 + lane;
+            const float dx = (act[j] && valn[j]) ? dp[j] * wt[j] * s * dscale : 0.f;  // pred = sum_t w_t * sdf_scale * head_t
+            v4f_t h[MT];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned int word = ph[j][mj >> 1][2 * (mj & 1) + (r >> 1)] | pl[j][mj >> 1][2 * (mj & 1) + (r >> 1)];
+                    const bool on = (r & 1) ? ((word & 0x7fff0000u) != 0u) : ((word & 0x7fffu) != 0u);
+                    h[mj][r] = on ? dx * wo[mj][r] : 0.f;
+                }
+            v4u_t bh[NJ], bl[NJ];
+            Q::split_acts(h, bh, bl);
+            if (want_dec) {
+                unsigned int dh0, dl0;
+                h2_split2((g == 0) ? dx : 0.f, 0.f, dh0, dl0);
+                uint2* __restrict__ D1 = ws.d + G::d_off(n_tiles, 1) + tbase;
+                D1[0] = transpose_block(dh0, 0u, ident);
+                D1[64] = transpose_block(dl0, 0u, ident);
+                uint2* __restrict__ A1 = ws.a + G::a_off(n_tiles, 1) + tile * 128 * (MT - 1) + tbase;
+                uint2* __restrict__ D0 = ws.d + G::d_off(n_tiles, 0) + tile * 128 * (MT - 1) + tbase;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    A1[mt * 128] = transpose_block(ph[j][mt >> 1][2 * (mt & 1)], ph[j][mt >> 1][2 * (mt & 1) + 1], ident);
+                    A1[mt * 128 + 64] = transpose_block(pl[j][mt >> 1][2 * (mt & 1)], pl[j][mt >> 1][2 * (mt & 1) + 1], ident);
+                    D0[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
+                    D0[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
+                }
+                uint2* __restrict__ A0 = ws.a + G::a_off(n_tiles, 0) + tbase;
+                A0[0] = transpose_block(zh[j][0], zh[j][1], ident);
+                A0[64] = transpose_block(zl[j][0], zl[j][1], ident);
+            }
+            float dz[4];
+            Q::input_backward(lds, L, bh, bl, dz);
+            // feature-gradient scatter: this column's row gets d loss / d (its feature row) = dz[0..7]
+            if (g < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r] * inv_dscale;
+            } else if (g == 2) {
+                sidx[nq] = dx != 0.f ? id[j] : -1;
+            }
+            wave_lds_sync();
+            {
+                const int cc = lane >> 3, jd = lane & 7;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int col = half * 8 + cc;
+                    const int idx = sidx[col];
+                    if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + jd, sdz[col * 8 + jd]);
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+    acc_bce = wave_sum(acc_bce);
+    acc_eik = wave_sum(acc_eik);
+    if (lane == 0) { lred[wave][0] = acc_bce; lred[wave][1] = acc_eik; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double tt = 0.0;
+#pragma unroll
+        for (int w = 0; w < TF_BLOCK / 64; ++w) tt += lred[w][threadIdx.x];
+        loss_partial[2 * blockIdx.x + threadIdx.x] = tt;
+    }
+}
+
+template <int H>
+constexpr int train_fused_nwf_lds_bytes() {
+    return ((QuadDecoderH<H>::bytes(1) + 15) & ~15) + (TF_BLOCK / 64) * (16 * 8 + 16) * 4 + (TF_BLOCK / 64) * 2 * 8;
+}
+
 // the decoder image of train_fused_kernel, once per call: the hidden layers over blocks 0 .. STAGE_BLOCKS - 4 (the split
 // is a chain of memory round trips, one trip per thread here), the three small parts on a block each
 constexpr int STAGE_BLOCKS = 15;

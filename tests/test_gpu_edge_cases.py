@@ -123,20 +123,34 @@ def test_tiny_training_batch_matches_oracle(gd):
     assert np.max(np.abs(gdec.cpu().numpy() - gd_)) < 3e-4 * np.abs(gd_).max()
 
 
+@pytest.fixture(scope="module")
+def gd_nwf():
+    """kitti_nwf: weighted_first = False, decoder 1 x 64, k = 6 -- the per-neighbour fused training kernel."""
+    from tests import gpu_util as U
+    d = G.load("kitti_nwf")
+    d["st"], d["fs"] = U.search_state(d), U.field_state(d)
+    d["table"] = G.dense_table(d)
+    return d
+
+
+@pytest.mark.parametrize("mode", ["wf", "nwf"])
 @pytest.mark.parametrize("bs,dec,eikonal", [(37, 3, True), (5, 1, True), (64, 1000, True), (33, 10, False), (212, 7, True)])
-def test_fused_training_tile_map(gd, bs, dec, eikonal):
-    """Tile -> query map of the fused training kernel (train_fused.h): mixed tiles of 2 x 6 probes + 4 main samples,
-    odd Eikonal counts, more probe tiles than main samples to fill them (dec = 1), one Eikonal sample, Eikonal off,
-    a frozen decoder -- feature / decoder gradients and both loss sums against the oracle."""
+def test_fused_training_tile_map(gd, gd_nwf, mode, bs, dec, eikonal):
+    """Tile -> query map of the fused training kernels (train_fused.h).  Interpolate-first: mixed tiles of 2 x 6 probes +
+    4 main samples; per-neighbour decoding: groups of three (query, neighbour) tiles, six main samples or the six probes
+    of an Eikonal sample.  Odd Eikonal counts, more probes than main samples to fill tiles (dec = 1), one Eikonal sample,
+    Eikonal off, ragged last groups, a frozen decoder -- feature / decoder gradients and both loss sums vs the oracle."""
     from pin_slam_amd import ops
     from tests import gpu_util as U
-    d = gd
+    d = gd if mode == "wf" else gd_nwf
+    wf = mode == "wf"
+    assert bool(d["fs"].weighted_first) == wf
     k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
     coord, label, w, ts = d["map_coord0"][:bs], d["map_label0"][:bs], d["map_w0"][:bs], d["map_ts0"][:bs]
     assert len(coord) == bs
     feats, decf = U.dev(d["local_geo_features"]), U.dev(d["dec_flat"])
     fs = dataclasses.replace(d["fs"], feats=feats, dec=decf, certainty=U.dev(d["local_point_certainties"]))
-    buf = ops.TrainBuffers(bs, dec, k, H, L, eikonal=eikonal)
+    buf = ops.TrainBuffers(bs, dec, k, H, L, eikonal=eikonal, weighted_first=wf)
     assert buf.n_eik == (len(range(0, bs, dec)) if eikonal else 0)
     kw = dict(sigma=d["sdf_scale"], weight_e=d["map_weight_e"], eik_eps=d["map_eps"])
 
@@ -155,7 +169,7 @@ def test_fused_training_tile_map(gd, bs, dec, eikonal):
         return O.query_feature(p, s, d["local_geo_features"], d["local_neural_points"], None, k, global2local=d["global2local"],
                                weighted_first=False)
     ref = O.train_step(coord, label, w, searcher, d["local_geo_features"], d["local_neural_points"], d["dec_flat"], (11, H, L),
-                       d["sdf_scale"], k, dec=dec, eps=d["map_eps"], weight_e=d["map_weight_e"], ekional=eikonal)
+                       d["sdf_scale"], k, dec=dec, eps=d["map_eps"], weight_e=d["map_weight_e"], ekional=eikonal, weighted_first=wf)
     gfeat, gdec, loss, pred, cert = run(True)
     gf, gd_ = ref["feat_grad"], ref["dec_grad"]
     assert np.max(np.abs(gfeat - gf)) < 1e-4 * np.abs(gf).max()
