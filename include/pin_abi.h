@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 8
+#define PIN_ABI_VERSION 9
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -512,14 +512,15 @@ int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg
                        float beta2, float eps, int32_t zero_grad, void* stream);
 
 /* Lazy exact Adam for the 8-wide feature tables (bit-identical to running pin_adam_step over the whole
- * table every iteration, as the reference does).  State: pending [rows] and claim [rows] (int32, both
- * cleared when the optimiser is reset; exp_avg / exp_avg_sq need no clearing), coef [2][t_max+1] =
+ * table every iteration, as the reference does).  State: pending [rows] (int32, cleared when the optimiser is
+ * reset; exp_avg / exp_avg_sq need no clearing), coef [2][t_max+1] =
  * lr/(1-beta1^t) and 1/sqrt(1-beta2^t) for t = 0..t_max (entry 0 unused), computed once on the host.
  * pin_adam_lazy_prepare, once per iteration t BEFORE the forward pass, over the kNN records of that iteration
  * ([n_records][4]): a row last read at iteration a takes the step it still owes (step a, with the gradient the
  * backward pass of iteration a left in `grad`, which is cleared), replays the gradient-free steps a+1 .. t-1 and
- * is marked as owing step t.  `stamp` must grow with every call of one optimiser lifetime (it elects one owner
- * per row and call).  pin_adam_lazy_flush (end of Mapper.mapping) settles every touched row up to t_final.
+ * is marked as owing step t (one owner per row and call, elected by a compare-and-swap on its `pending` word; every
+ * call of one optimiser lifetime must carry a different `step`).  pin_adam_lazy_flush (end of Mapper.mapping)
+ * settles every touched row up to t_final.
  * A dense tensor (the decoder) can ride along: prepare(t) applies its step t-1, flush its step t_final
  * (= pin_adam_step with the table's coefficients and zero_grad). */
 typedef struct pin_adam_dense {
@@ -527,9 +528,8 @@ typedef struct pin_adam_dense {
     int64_t n;
 } pin_adam_dense;
 int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
-                          float* exp_avg_sq, int32_t* pending, int32_t* claim, int32_t step, int32_t stamp,
-                          const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                          const pin_adam_dense* dense, void* stream);
+                          float* exp_avg_sq, int32_t* pending, int32_t step, const float* coef, int32_t t_max,
+                          float beta1, float beta2, float eps, const pin_adam_dense* dense, void* stream);
 int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* pending,
                         int64_t n_rows, int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2,
                         float eps, const pin_adam_dense* dense, void* stream);

@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 8
+PIN_ABI_VERSION = 9
 PIN_COMM_ID_BYTES = 128
 
 vp = C.c_void_p
@@ -180,7 +180,7 @@ SIGNATURES = {
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),
     "pin_adam_step_rows": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, f32, i32, vp]),
-    "pin_adam_lazy_prepare": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
+    "pin_adam_lazy_prepare": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
     "pin_adam_lazy_flush": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
     "pin_pool_workspace_bytes": (i64, [i64]),
     "pin_sample_rays": (i32, [P(SampleParams), vp, vp, i32, i32, vp, vp, vp, P(PoolArrays), vp]),

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
 // Rows that were touched and then left alone settle their pending step and the replay up to the final step once,
 // at the end (adam_lazy_flush_kernel).  Every element goes through the same sequence of adam_elem calls as in the
 // dense schedule, hence bit-identical tables (tests/test_gpu_parity.py); first-touch rows start from m = v = 0
-// without the state arrays ever being cleared.  One owner per row and launch via an atomicMax stamp.
+// without the state arrays ever being cleared.  One owner per row and launch via a compare-and-swap on pend[row].
 // pend[row]: 0 = untouched since the reset; -a = owes step a, moment arrays not valid yet (first step); +a = owes step a.
 __device__ __forceinline__ void lazy_settle(float& pi, float& mi, float& vi, float gi, int pend, int upto,
                                             const float* __restrict__ coef, int t_max, float b1, float b2, float eps) {
@@ -680,8 +680,8 @@ __device__ __forceinline__ void lazy_settle(float& pi, float& mi, float& vi, flo
 __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __restrict__ nbr, long n_records,
                                                                 float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
-                                                                int* __restrict__ pend, int* __restrict__ claim, int step,
-                                                                int stamp, const float* __restrict__ coef, int t_max,
+                                                                int* __restrict__ pend, int step,
+                                                                const float* __restrict__ coef, int t_max,
                                                                 float b1, float b2, float eps, int rec_blocks,
                                                                 pin_adam_dense dense, int dense_step) {
     if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
@@ -702,24 +702,31 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long rec = tid >> 3;
     const int j = (int)(tid & 7), lane = threadIdx.x & 63;
-    int row = -1, own = 0;
+    int row = -1, own = 0, n = 0;
     if (rec < n_records) {
         const int raw = __float_as_int(nbr[rec].w);
         if (raw >= 0) row = raw & ~PIN_NBR_QUIRK_BIT;
     }
-    if (row >= 0 && j == 0) own = atomicMax(claim + row, stamp) < stamp ? 1 : 0;
-    own = __shfl(own, lane & ~7, 64);  // the 8 lanes of a record follow their leader
-    if (!own) return;
-    const int n = pend[row];
-    if (n != 0) {
-        const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
-        float pi = p[i], mi = 0.f, vi = 0.f;
-        if (n > 0) { mi = m[i]; vi = v[i]; }
-        lazy_settle(pi, mi, vi, g[i], n, step - 1, lazy_coef, t_max, b1, b2, eps);
-        p[i] = pi; m[i] = mi; v[i] = vi;
-        g[i] = 0.f;
+    // One owner per row and launch: the first record of a row to swap its `pend` entry to "owes step `step`" settles it;
+    // the other records of the row find +-step there (or lose the compare-and-swap) and leave.  No separate claim array:
+    // the election rides on the word the owner has to update anyway (r02a: an atomicMax stamp on a second int per row --
+    // 210k more random line updates per iteration, which the tile kernel that follows could feel).
+    if (row >= 0 && j == 0) {
+        const int cur = pend[row];  // (a stale value only makes the compare-and-swap fail)
+        if (cur != step && cur != -step) {
+            const int want = cur == 0 ? -step : step;
+            if (atomicCAS(pend + row, cur, want) == cur) { own = 1; n = cur; }
+        }
     }
-    if (j == 0) pend[row] = n == 0 ? -step : step;
+    own = __shfl(own, lane & ~7, 64);  // the 8 lanes of a record follow their leader
+    n = __shfl(n, lane & ~7, 64);
+    if (!own || n == 0) return;  // (a first touch has nothing to settle: its moments start from zero at its first step)
+    const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
+    float pi = p[i], mi = 0.f, vi = 0.f;
+    if (n > 0) { mi = m[i]; vi = v[i]; }
+    lazy_settle(pi, mi, vi, g[i], n, step - 1, lazy_coef, t_max, b1, b2, eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    g[i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -1117,19 +1124,18 @@ static int lazy_dense(const pin_adam_dense* dense, const float* coef, pin_adam_d
 }
 
 extern "C" int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
-                                     float* exp_avg_sq, int32_t* pending, int32_t* claim, int32_t step, int32_t stamp,
-                                     const float* coef, int32_t t_max, float beta1, float beta2, float eps,
-                                     const pin_adam_dense* dense, void* stream) {
+                                     float* exp_avg_sq, int32_t* pending, int32_t step, const float* coef, int32_t t_max,
+                                     float beta1, float beta2, float eps, const pin_adam_dense* dense, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n_records >= 0 && step >= 1 && step <= t_max && t_max < 4096, "bad step (t_max < 4096: the coefficient table is staged in LDS)");
     pin_adam_dense d;
     if (int e = lazy_dense(step > 1 ? dense : nullptr, coef, d)) return e;  // (nothing to step before the first iteration)
     if (n_records == 0 && d.n == 0) return 0;
-    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && pending && claim && coef), "NULL pointer");
+    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && pending && coef), "NULL pointer");
     const int rec_blocks = (int)cdiv(n_records * 8, 256), dense_blocks = (int)cdiv(d.n, 256);
     hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), as_stream(stream),
-                       reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, pending, claim,
-                       step, stamp, coef, t_max, beta1, beta2, eps, rec_blocks, d, step - 1);
+                       reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, pending, step, coef,
+                       t_max, beta1, beta2, eps, rec_blocks, d, step - 1);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -494,12 +494,12 @@ class LazyAdam:
         self.t = 0
 
     def reset(self, rows, t_max, device):
-        if self.state is None or self.state.shape[1] < rows:
-            self.state = torch.zeros((2, int(rows * 1.25) + 1024), dtype=torch.int32, device=device)
+        if self.state is None or self.state.shape[0] < rows:
+            self.state = torch.zeros((int(rows * 1.25) + 1024,), dtype=torch.int32, device=device)  # pending step per row
         else:
             self.state.zero_()
         self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
-        self.t, self.stamp = 0, 0
+        self.t = 0
 
     @staticmethod
     def _dense(dense):
@@ -515,11 +515,12 @@ class LazyAdam:
         in the same launch (identical to adam_step(..., step - 1, lr) with zero_grad); nothing at step 1."""
         if step > self.t_max:
             raise ValueError("more iterations than reset() was sized for")
-        self.stamp += 1
+        if step <= self.t:
+            raise ValueError("steps must grow within one optimiser lifetime (the step elects one owner per row and call)")
         d = self._dense(dense)
         check(_lib.lib().pin_adam_lazy_prepare(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
                                                _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
-                                               self.state[0].data_ptr(), self.state[1].data_ptr(), int(step), self.stamp,
+                                               self.state.data_ptr(), int(step),
                                                _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
                                                C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_prepare")
         self.t = int(step)
@@ -530,7 +531,7 @@ class LazyAdam:
             return
         d = self._dense(dense)
         check(_lib.lib().pin_adam_lazy_flush(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(m, torch.float32),
-                                             _ptr(v, torch.float32), self.state[0].data_ptr(), param.shape[0], self.t,
+                                             _ptr(v, torch.float32), self.state.data_ptr(), param.shape[0], self.t,
                                              _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
                                              C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_flush")
         self.t = 0
