@@ -7,15 +7,16 @@ preprocess + odometry + mapping preparation + mapping), on the synthetic workloa
   * preprocess   : SLAMDataset.preprocess_frame data path -- voxel down-sampling (vox_down_m),
                    crop_frame, source down-sampling (source_vox_down_m), deskewing;
   * odometry     : Tracker.tracking = `reg_iters` Gauss-Newton iterations (reference default 50,
-                   NO early exit => worst case) registering the WHOLE cropped scan (~100k points;
-                   the reference registers only the source-down-sampled subset -- that cheaper
-                   variant is reported beside it as frames_per_sec_source_downsampled);
+                   NO early exit => worst case) registering the WHOLE cropped scan (~100k points, put in
+                   Morton order once per frame; the reference registers only the source-down-sampled
+                   subset -- that cheaper variant is reported beside it as frames_per_sec_source_downsampled);
   * map prep     : Mapper.process_frame -- 7 samples per ray into the pool, NeuralPoints.update +
                    reset_local_map (+ brick cache), pool window / capacity filter over ~2.7M
                    samples, query_certainty, new-sample index;
   * mapping      : Mapper.mapping = 12 iterations, batch 16384 (+ 6*1639 Eikonal queries), BCE +
-                   Eikonal, backward to features and decoder, Adam (exact lazy form: only the rows an
-                   iteration reads are visited, bit-identical to the dense step).
+                   Eikonal, backward to features and decoder (one fused tile kernel + a streamed MFMA weight
+                   gradient per iteration), Adam (exact lazy form: only the rows an iteration reads are
+                   visited, bit-identical to the dense step).
 Everything runs through the drop-in classes (pin_slam_amd.dropin) on libpinhip.  Inputs (raw
 scan, timestamps) are resident in HBM before the timed region.
 
