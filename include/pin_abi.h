@@ -129,7 +129,7 @@ typedef struct pin_field {
     int32_t out_dim;         /* decoder heads: 1 (sdf; 0 means 1) or 3 (colour, Decoder.regress_color) */
     int32_t dec_image_bytes; /* size of dec_image, 0 if none */
     const void* dec_image;   /* optional: the decoder as the Gauss-Newton tile kernel lays it out in LDS (split-fp16
-                                pieces, both directions), written by pin_stage_decoder for THIS dec / hidden / levels.
+                                pieces, both directions), written by pin_stage_decoder for THIS dec / hidden / levels / out_dim.
                                 The kernel then copies it instead of re-splitting `dec` in every block of every launch;
                                 restage whenever the decoder parameters change.  NULL = stage from `dec`. */
 } pin_field;

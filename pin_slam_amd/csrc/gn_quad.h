@@ -279,10 +279,17 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
     unsigned char* const lds_c = lds + gq_red_offset(Q::bytes(f.levels));  // (COLOR)
     float (*red)[PIN_GN_NSUMS] = reinterpret_cast<float (*)[PIN_GN_NSUMS]>(lds + (COLOR ? 2 : 1) * gq_red_offset(Q::bytes(f.levels)));
     if (state != nullptr && state[PIN_GN_STATE_DONE] != 0.0) return;
-    if constexpr (COLOR) QuadDecoderH<H>::stage(ct.fc.dec, LC, lds_c, threadIdx.x, GQ_BLOCK, 3);
     // weights: copy the image staged once per registration (pin_stage_decoder) or split them here; either way the
-    // image is visible after the barrier that follows the first gather
-    if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+    // image is visible after the barrier that follows the first gather.  COLOR: both images are staged by the caller
+    // (the launcher takes another kernel otherwise), two linear copies
+    if constexpr (COLOR) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
+        const uint4* __restrict__ src_c = reinterpret_cast<const uint4*>(ct.fc.dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        uint4* __restrict__ dst_c = reinterpret_cast<uint4*>(lds_c);
+        constexpr int n16 = Q::bytes(LC) >> 4;
+        for (int i = threadIdx.x; i < n16; i += GQ_BLOCK) { dst[i] = src[i]; dst_c[i] = src_c[i]; }
+    } else if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         const int n16 = f.dec_image_bytes >> 4;

@@ -683,8 +683,12 @@ static int launch_quad_color_inst(const pin_field* f, const pin_gn_params* gp, c
 }
 
 static bool quad_color_ok(const pin_field* f, const ColorTerm& ct) {
-    return f->weighted_first && use_split_decoder() && ct.mode != 0 && ct.fc.levels == f->levels && ct.fc.hidden == f->hidden &&
-           f->levels <= GQ_COLOR_MAX_LEVELS;
+    if (!(f->weighted_first && use_split_decoder() && ct.mode != 0 && ct.fc.levels == f->levels && ct.fc.hidden == f->hidden &&
+          f->levels <= GQ_COLOR_MAX_LEVELS))
+        return false;
+    // both decoders staged by the caller (pin_stage_decoder on the sdf and on the colour field): the kernel only copies
+    const int64_t bytes = pin_decoder_image_bytes(f->hidden, f->levels);
+    return f->dec_image != nullptr && ct.fc.dec_image != nullptr && f->dec_image_bytes == bytes && ct.fc.dec_image_bytes == bytes;
 }
 
 static int launch_quad_color(const pin_field* f, const pin_gn_params* gp, const ColorTerm& ct, const float* pts, const float4* nb4,
@@ -885,7 +889,7 @@ extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32
 // ---- decoder image for the GN tile kernel (pin_field.dec_image) ------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(GQ_BLOCK) void stage_decoder_kernel(pin_field f, unsigned char* __restrict__ out) {
-    QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK);
+    QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK, f.out_dim > 1 ? f.out_dim : 1);  // (1 or 3 heads)
 }
 
 extern "C" int64_t pin_decoder_image_bytes(int32_t hidden, int32_t levels) {

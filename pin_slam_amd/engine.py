@@ -43,6 +43,8 @@ class GNTracker:
              color=None):
         n = src.shape[0]
         out = (self.nbr[:n], self.nn[:n], self.cur[:n])
+        if color is not None:  # the tile kernel with the colour term copies both decoder images (the colour one: ops.color_term)
+            self.fs.stage_decoder()
         if self.on_knn:
             self.on_knn(True)
         ops.knn_query(self.st, src, self.fs.k, time_filtering=time_filtering, local=local, pose=T, out=out,
@@ -86,9 +88,9 @@ class GNTracker:
         check(L.pin_gn_state_init(self.state.data_ptr(), T0.ctypes.data, n, stream), "pin_gn_state_init")
         self.sums.zero_()
         sp = self.st.params(time_filtering=time_filtering, local=local)
-        # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder)
-        if color is None:  # (the colour term runs on the 64-queries-per-wave kernel, which stages for itself)
-            self.fs.stage_decoder()
+        # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder; the
+        # colour decoder was staged by ops.color_term)
+        self.fs.stage_decoder()
         f = self.fs.params()
         bc = None
         if self.bricks is not None:

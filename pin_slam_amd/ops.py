@@ -318,6 +318,7 @@ def color_term(fc: Optional[FieldState], colors: Optional[torch.Tensor], photome
     mode = 2 if photometric else (1 if consist_weight else 0)
     if mode == 0:
         return None, None
+    fc.stage_decoder()  # the colour image of the tile kernel, once per colour term (the decoder does not change under it)
     f = fc.params()
     ct = _lib.ColorTerm()
     ct.field = C.pointer(f)
@@ -336,6 +337,8 @@ def gn_accumulate(fs: FieldState, gp: GnParams, query, nbr, nn, sdf_labels=None,
         sums = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64, device=dev)
     sdf = torch.empty((n,), dtype=torch.float32, device=dev) if want_points else None
     g = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_points else None
+    if color is not None and fs.dec_image is None:
+        fs.stage_decoder()  # the tile kernel with the colour term copies both decoder images (the colour one: color_term)
     f = fs.params()
     check(_lib.lib().pin_gn_accumulate(C.byref(f), C.byref(gp), C.byref(color) if color is not None else None,
                                        _ptr(query, torch.float32), _ptr(nbr),
