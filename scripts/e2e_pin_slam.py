@@ -127,7 +127,7 @@ sampler:
 neuralpoints:
   voxel_size_m: 0.4
   search_alpha: 0.5
-continual:
+{neural_extra}continual:
   batch_size_new_sample: 1000
   pool_capacity: 2e6
   pool_filter_freq: 10
@@ -230,7 +230,10 @@ def run(args):
     pc_dir, gt = write_sequence(work, args.frames)
     cfg_path = os.path.join(work, "e2e.yaml")
     with open(cfg_path, "w") as f:
-        f.write(CONFIG_YAML.format(out=os.path.join(work, "experiments"), pc=pc_dir, iters=args.iters, deskew=bool(args.deskew)))
+        # --per-neighbour: decode every neighbour and weight the predictions (run_kitti.yaml: weighted_first False, 6 neighbours)
+        extra = "  weighted_first: False\n  query_nn_k: 6\n" if args.per_neighbour else ""
+        f.write(CONFIG_YAML.format(out=os.path.join(work, "experiments"), pc=pc_dir, iters=args.iters, deskew=bool(args.deskew),
+                                   neural_extra=extra))
     # setup_experiment records `git rev-parse HEAD` (utils/tools.py:105-107): give it a repository to stand in
     subprocess.run("git init -q . && git -c user.email=e2e@x -c user.name=e2e commit -q --allow-empty -m e2e", shell=True,
                    cwd=work, check=True)
@@ -317,6 +320,7 @@ def main():
     r.add_argument("--impl", choices=["dropin", "reference"], default="dropin")
     r.add_argument("--frames", type=int, default=10)
     r.add_argument("--iters", type=int, default=15)
+    r.add_argument("--per-neighbour", action="store_true", help="weighted_first: False, query_nn_k: 6 (run_kitti.yaml style)")
     r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
     r.add_argument("--reference", default=None)
     r.add_argument("--tol-cm", type=float, default=8.0,
