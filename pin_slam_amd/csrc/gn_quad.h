@@ -290,11 +290,22 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
         constexpr int n16 = Q::bytes(LC) >> 4;
         for (int i = threadIdx.x; i < n16; i += GQ_BLOCK) { dst[i] = src[i]; dst_c[i] = src_c[i]; }
     } else if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
+        // all loads of the copy in flight at once (the image size is a compile-time constant with the split decoder):
+        // one memory round trip instead of one per unrolled chunk
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
-        const int n16 = f.dec_image_bytes >> 4;
-#pragma unroll 4
-        for (int i = threadIdx.x; i < n16; i += GQ_BLOCK) dst[i] = src[i];
+        constexpr int N16 = Q::bytes(LC > 0 ? LC : 1) >> 4, TRIPS = (N16 + GQ_BLOCK - 1) / GQ_BLOCK;
+        uint4 v[TRIPS];
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = it * GQ_BLOCK + threadIdx.x;
+            v[it] = src[i < N16 ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = it * GQ_BLOCK + threadIdx.x;
+            if (i < N16) dst[i] = v[it];
+        }
     } else {
         Q::stage(f.dec, f.levels, lds, threadIdx.x, GQ_BLOCK);
     }

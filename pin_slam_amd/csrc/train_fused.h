@@ -130,9 +130,18 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
         // flight behind the first tile's gather loads
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
-        constexpr int n16 = Q::bytes(L) >> 4;
-#pragma unroll 4
-        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+        constexpr int N16 = Q::bytes(L) >> 4, TRIPS = (N16 + TF_BLOCK - 1) / TF_BLOCK;
+        uint4 v[TRIPS];  // (all loads of the copy in flight at once)
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = it * TF_BLOCK + threadIdx.x;
+            v[it] = src[i < N16 ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < TRIPS; ++it) {
+            const int i = it * TF_BLOCK + threadIdx.x;
+            if (i < N16) dst[i] = v[it];
+        }
     }
     bool staged = false;
     for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
