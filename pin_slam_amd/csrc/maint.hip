@@ -624,7 +624,9 @@ extern "C" int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arr
     PIN_CHECK_HIP(hipMemsetAsync(time_cnt, 0, sizeof(int), s));
     PIN_CHECK_ARG(lp->time_mode >= 0 && lp->time_mode <= 2 && (lp->time_mode != 1 || lp->travel_dist), "bad time_mode");
     if (lp->time_mode != 0)
-        hipLaunchKernelGGL(local_time_count_kernel, dim3(min(nb, REDUCE_BLOCKS)), dim3(MB), 0, s, *ma, *lp, time_cnt);
+        // (a count over the whole map with a dependent travel-distance gather per point: enough blocks to hide it --
+        // 128 blocks took 37 us per 2.2 M points)
+        hipLaunchKernelGGL(local_time_count_kernel, dim3(min(nb, 16 * REDUCE_BLOCKS)), dim3(MB), 0, s, *ma, *lp, time_cnt);
     hipLaunchKernelGGL(local_flags_kernel, dim3(nb), dim3(MB), 0, s, *ma, *lp, time_cnt, local_mask_out);
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, local_mask_out, n1, block_off);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_local_out);
