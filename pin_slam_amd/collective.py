@@ -22,12 +22,12 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return ops._stream()
 
 
 def rccl_library_path() -> str:

@@ -238,7 +238,7 @@ class NeuralPoints(nn.Module):
         points = points.to(device=self.device, dtype=torch.float32).contiguous()
         n = points.shape[0]
         ws = self._workspace(max(n, self._n + 1))
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         sel = torch.empty((n,), dtype=torch.int32, device=self.device)
         check(L.pin_voxel_downsample(_p(points), n, float(np.float32(self.resolution)), _p(sel), _p(self._cnt[0:1]),
                                      _p(ws), ws.numel(), stream), "pin_voxel_downsample")
@@ -306,7 +306,7 @@ class NeuralPoints(nn.Module):
         ma, la = self._map_arrays(), self._local_arrays()
         check(_lib.lib().pin_reset_local_map(C.byref(ma), C.byref(la), C.byref(lp), _p(self._local_mask),
                                              _p(self._cnt[2:3]), _p(ws), ws.numel(),
-                                             torch.cuda.current_stream().cuda_stream), "pin_reset_local_map")
+                                             ops._stream()), "pin_reset_local_map")
         self.local_orientation = sensor_orientation
         self._rebuild_bricks()
         if getattr(self, "_defer_local_count", False):
@@ -367,7 +367,7 @@ class NeuralPoints(nn.Module):
         if self.color_on:
             la.color = _p(self.local_color_features.data)
         check(_lib.lib().pin_assign_local_to_global(C.byref(ma), C.byref(la), self._n, self._m,
-                                                    torch.cuda.current_stream().cuda_stream),
+                                                    ops._stream()),
               "pin_assign_local_to_global")
 
     # ------------------------------------------------------------------ K1 / K2 tensor API
@@ -449,7 +449,7 @@ class NeuralPoints(nn.Module):
         ws = self._workspace(n + 1)
         src_a, dst_a = self._map_arrays(), self._map_arrays(dst)
         check(_lib.lib().pin_prune_map(C.byref(src_a), C.byref(dst_a), C.byref(pp), _p(self._cnt[3:4]), _p(ws), ws.numel(),
-                                       torch.cuda.current_stream().cuda_stream), "pin_prune_map")
+                                       ops._stream()), "pin_prune_map")
         n_keep = int(self._cnt[3].item())
         if n - n_keep <= min_prune_count:
             return False
@@ -497,7 +497,7 @@ class NeuralPoints(nn.Module):
                 dst_a = self._map_arrays(dst)
             check(_lib.lib().pin_hash_rebuild(C.byref(src_a), None if dst_a is None else C.byref(dst_a), C.byref(rp), _p(sel),
                                               _p(self._cnt[3:4]), _p(ws), ws.numel(),
-                                              torch.cuda.current_stream().cuda_stream), "pin_hash_rebuild")
+                                              ops._stream()), "pin_hash_rebuild")
             if not kept_points:
                 self._n = int(self._cnt[3].item())
                 self._g, self._spare = dst, self._g

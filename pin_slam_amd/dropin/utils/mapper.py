@@ -305,7 +305,7 @@ class Mapper(_Base):
             0 if _queries_for is None else _queries_for.n_eik, 1 if _queries_for is None else _queries_for.dec,
             0 if _queries_for is None else _queries_for.eik_first,
             0.0 if _queries_for is None else float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
-            torch.cuda.current_stream().cuda_stream), "pin_gather_batch_drawn")
+            ops._stream()), "pin_gather_batch_drawn")
         return out[0], out[1], out[3], None, None, color, out[2]
 
     def _draw_all(self, iters):

@@ -67,7 +67,7 @@ class GNTracker:
         extra) with extra = dict(N_raw, mse, converged)."""
         L = _lib.lib()
         n = src.shape[0]
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         # The loop sums over the source points, so their order is free; the down-sampler hands them over ordered by an
         # x-fastest voxel id, and both per-iteration kernels are ~20 % faster on a Morton-ordered scan (30 -> 25 us
         # kNN, 37 -> 34.5 us GN per 98.7k points, scripts/knn_order_probe.py): one sort per registration pays after
@@ -328,7 +328,7 @@ class MapTrainer:
             self._cert0 = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32, device=dev)
             self._cert_scratch = torch.empty_like(self._cert0)
         check(_lib.lib().pin_dp_cert_snapshot(self.fs.certainty.data_ptr(), self._cert0.data_ptr(), n,
-                                              torch.cuda.current_stream().cuda_stream), "pin_dp_cert_snapshot")
+                                              ops._stream()), "pin_dp_cert_snapshot")
 
     def merge_side_effects(self):
         """world > 1: certainty / ts_update side effects of the other ranks' shards, once per mapping call
