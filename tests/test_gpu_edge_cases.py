@@ -206,3 +206,28 @@ def test_one_point_scan_through_the_sampler_and_voxel_filter():
     assert idx.tolist() == [0]
     kept, _ = PP.crop_frame(scan, None, min_range=10.0)  # 5.1 m < 10 m: cropped away
     assert kept.shape[0] == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000])
+def test_spatial_sort_small_and_degenerate_inputs(n):
+    """pin_spatial_sort on tiny inputs, duplicated points, negative coordinates and points beyond the 1024-cell wrap:
+    always a permutation of the input, keys ascending."""
+    from pin_slam_amd import ops
+    rng = np.random.default_rng(n)
+    p = (rng.standard_normal((n, 3)) * 40.0).astype(np.float32)
+    if n >= 63:
+        p[10:20] = p[5]            # duplicates
+        p[20] = (900.0, -700.0, 3.0)  # beyond +-512 cells of 0.5 m: the code wraps
+    out, perm = ops.spatial_sort(torch.from_numpy(p).cuda(), 0.5, return_perm=True)
+    pm = perm.cpu().numpy()
+    assert np.array_equal(np.sort(pm), np.arange(n))
+    assert np.array_equal(out.cpu().numpy(), p[pm])
+    cell = (np.floor(out.cpu().numpy() / np.float32(0.5)).astype(np.int64) + 512) & 1023
+
+    def spread(v):
+        r = np.zeros_like(v)
+        for b in range(10):
+            r |= ((v >> b) & 1) << (3 * b)
+        return r
+    key = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
+    assert (np.diff(key) >= 0).all()
