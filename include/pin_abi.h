@@ -434,7 +434,12 @@ int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t lev
  * utils/tools.py:263-292).  Applies the training-mode side effects of query_feature for the
  * batch samples (certainty_rw += w, ts_update_rw = max(., sample_ts); neural_points.py:685-710).
  * loss_out: double[2] = (sum of BCE terms, sum of (|g|-1)^2) -- divide by the global counts.
- * pred_out (optional): sdf prediction of the batch samples [n_main]. */
+ * pred_out (optional): sdf prediction of the batch samples [n_main].
+ * Launch sequence (one stream): weighted_first, and per-neighbour decoding with a one-layer decoder: decoder image ->
+ * fused tile kernel (gather, forward, loss, backward, feature scatter) -> streamed weight gradient -> finalize;
+ * deeper per-neighbour decoders: forward / loss / backward / weight-gradient kernels over a unit-major workspace.
+ * The workspace (pin_train_workspace_bytes) carries the operand stream of the weight gradient, slot copies of the
+ * decoder gradient, per-block loss sums and the decoder image; its contents are scratch. */
 int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query,
                    const float* nbr, const int32_t* nn_count, const float* sdf_label,
                    const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,
