@@ -684,7 +684,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
     for (int ib = 0; ib < MT; ++ib) { mainv[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; cross[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; }
     const v4h_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     auto as4 = [](uint2 v) { const v2u_t u = {v.x, v.y}; return as_h4(u); };
-    constexpr int TPT = 4;  // tiles per trip: all their operand loads are issued before the first MFMA
+    constexpr int TPT = MT >= 4 ? 3 : 4;  // tiles per trip (all their operand loads are issued before the first MFMA; 128 VGPRs at 16 waves)
     for (int t = t0 + phase; t < t1; t += TPT * phases) {
         uint2 dh[TPT], dl[TPT], ah[TPT][MT], al[TPT][MT];
 #pragma unroll
