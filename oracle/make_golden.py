@@ -158,6 +158,69 @@ def map_arrays(npts, cfg, dec):
     return d
 
 
+def mapping_section(m, cfg, dec, npts, gen, out, iters=2, tag="map"):
+    """Mapper.mapping on FIXED batches (get_batch RNG bypassed): inputs, per-iteration autograd gradients and scalar
+    losses, parameters and side effects afterwards, under the keys `tag`_*."""
+    ds = R.FakeDataset(n_frames=3)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": None})
+    mp.determine_used_pose()
+    bs = cfg.bs
+    batches = []
+    for it in range(iters):
+        coord, label = surface_samples(gen, bs, 12.0, (16.0, 0.0), sigma=0.2)
+        label = (label + 0.02 * torch.randn(bs, generator=gen)).float()
+        ts = torch.randint(0, 3, (bs,), generator=gen).int()
+        w = (0.6 + 0.8 * torch.rand(bs, generator=gen)).float() * torch.where(
+            torch.rand(bs, generator=gen) < 0.5, 1.0, -1.0)
+        batches.append((coord, label, ts, w))
+        out[f"{tag}_coord{it}"] = t2n(coord); out[f"{tag}_label{it}"] = t2n(label)
+        out[f"{tag}_ts{it}"] = t2n(ts); out[f"{tag}_w{it}"] = t2n(w)
+    it_box = {"i": 0}
+
+    def fake_get_batch(global_coord=False):
+        c, l, t, w = batches[it_box["i"]]
+        it_box["i"] += 1
+        return c.clone(), l.clone(), t.clone(), None, None, None, w.clone()
+
+    mp.get_batch = fake_get_batch
+    grads = []
+    real_setup = m["mapper_mod"].setup_optimizer
+
+    def spy_setup(*a, **k):
+        opt = real_setup(*a, **k)
+        real_step = opt.step
+
+        def step(*aa, **kk):
+            g = {}
+            g["feat"] = t2n(npts.local_geo_features.grad)
+            g["dec"] = np.concatenate([t2n(p.grad).ravel() for p in dec.parameters()])
+            grads.append(g)
+            return real_step(*aa, **kk)
+
+        opt.step = step
+        return opt
+
+    m["mapper_mod"].setup_optimizer = spy_setup
+    out[f"{tag}_eps"] = np.float64(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    out[f"{tag}_dec"] = np.int64(cfg.gradient_decimation)
+    out[f"{tag}_weight_e"] = np.float64(cfg.weight_e)
+    out[f"{tag}_lr"] = np.float64(cfg.lr); out[f"{tag}_adam_eps"] = np.float64(cfg.adam_eps)
+    out[f"{tag}_loss_weight_on"] = np.bool_(cfg.loss_weight_on)
+    try:
+        with LossSpy(m["mapper_mod"]) as spy:
+            mp.mapping(iters)
+    finally:
+        m["mapper_mod"].setup_optimizer = real_setup
+    out[f"{tag}_loss_sdf"] = np.asarray(spy.sdf, np.float64); out[f"{tag}_loss_total"] = np.asarray(spy.total, np.float64)
+    for it, g in enumerate(grads):
+        out[f"{tag}_gfeat{it}"] = g["feat"]; out[f"{tag}_gdec{it}"] = g["dec"]
+    out[f"{tag}_feat_after"] = t2n(npts.local_geo_features.data)
+    out[f"{tag}_dec_after"] = flat_decoder(dec)
+    out[f"{tag}_cert_after"] = t2n(npts.local_point_certainties)
+    out[f"{tag}_ts_after"] = t2n(npts.local_point_ts_update)
+    out[f"{tag}_global_feat_after"] = t2n(npts.geo_features)
+
+
 def gen_case(case):
     m, cfg, dec, npts, gen = build(case)
     out = map_arrays(npts, cfg, dec)
@@ -228,65 +291,42 @@ def gen_case(case):
                   "eigenvalue_ratio_thre"):
         out["cfg_" + kname] = np.float64(getattr(cfg, kname))
 
-    # (6) Mapper.mapping: two iterations on FIXED batches (get_batch RNG bypassed)
-    ds = R.FakeDataset(n_frames=3)
-    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": None, "color": None})
-    mp.determine_used_pose()
-    bs = cfg.bs
-    batches = []
-    for it in range(2):
-        coord, label = surface_samples(gen, bs, 12.0, (16.0, 0.0), sigma=0.2)
-        label = (label + 0.02 * torch.randn(bs, generator=gen)).float()
-        ts = torch.randint(0, 3, (bs,), generator=gen).int()
-        w = (0.6 + 0.8 * torch.rand(bs, generator=gen)).float() * torch.where(
-            torch.rand(bs, generator=gen) < 0.5, 1.0, -1.0)
-        batches.append((coord, label, ts, w))
-        out[f"map_coord{it}"] = t2n(coord); out[f"map_label{it}"] = t2n(label)
-        out[f"map_ts{it}"] = t2n(ts); out[f"map_w{it}"] = t2n(w)
-    it_box = {"i": 0}
+    # (6) Mapper.mapping: two iterations on FIXED batches
+    mapping_section(m, cfg, dec, npts, gen, out)
+    return out
 
-    def fake_get_batch(global_coord=False):
-        c, l, t, w = batches[it_box["i"]]
-        it_box["i"] += 1
-        return c.clone(), l.clone(), t.clone(), None, None, None, w.clone()
 
-    mp.get_batch = fake_get_batch
-    grads = []
-    real_setup = m["mapper_mod"].setup_optimizer
+# config/lidar_slam/run_livox.yaml: numerical_grad_on False (analytic Eikonal on every sample), weighted_first False, k = 8
+ANALYTIC = (dict(voxel_size_m=0.4, search_alpha=0.5, query_nn_k=8, weighted_first=False, buffer_size=40009), (1, 64))
 
-    def spy_setup(*a, **k):
-        opt = real_setup(*a, **k)
-        real_step = opt.step
 
-        def step(*aa, **kk):
-            g = {}
-            g["feat"] = t2n(npts.local_geo_features.grad)
-            g["dec"] = np.concatenate([t2n(p.grad).ravel() for p in dec.parameters()])
-            grads.append(g)
-            return real_step(*aa, **kk)
-
-        opt.step = step
-        return opt
-
-    m["mapper_mod"].setup_optimizer = spy_setup
-    out["map_eps"] = np.float64(cfg.voxel_size_m * cfg.num_grad_step_ratio)
-    out["map_dec"] = np.int64(cfg.gradient_decimation)
-    out["map_weight_e"] = np.float64(cfg.weight_e)
-    out["map_lr"] = np.float64(cfg.lr); out["map_adam_eps"] = np.float64(cfg.adam_eps)
-    out["map_loss_weight_on"] = np.bool_(cfg.loss_weight_on)
+def gen_analytic():
+    """Mapper.mapping with the Eikonal term on the AUTOGRAD gradient (mapper.py:642-643, 677-678 with
+    numerical_grad False, config.py:437-439): the map of the other cases, then three short runs from recorded
+    states -- per-neighbour decoding (run_livox.yaml), the same after a pose-graph correction (neighbour vectors
+    rotated by the point orientations), and weighted-first decoding."""
+    CASES["analytic_eik"] = ANALYTIC
     try:
-        with LossSpy(m["mapper_mod"]) as spy:
-            mp.mapping(2)
+        m, cfg, dec, npts, gen = build("analytic_eik")
     finally:
-        m["mapper_mod"].setup_optimizer = real_setup
-    out["map_loss_sdf"] = np.asarray(spy.sdf, np.float64); out["map_loss_total"] = np.asarray(spy.total, np.float64)
-    for it, g in enumerate(grads):
-        out[f"map_gfeat{it}"] = g["feat"]; out[f"map_gdec{it}"] = g["dec"]
-    out["map_feat_after"] = t2n(npts.local_geo_features.data)
-    out["map_dec_after"] = flat_decoder(dec)
-    out["map_cert_after"] = t2n(npts.local_point_certainties)
-    out["map_ts_after"] = t2n(npts.local_point_ts_update)
-    out["map_global_feat_after"] = t2n(npts.geo_features)
+        del CASES["analytic_eik"]
+    cfg.numerical_grad, cfg.gradient_decimation, cfg.weight_e = False, 1, 0.5
+    out = map_arrays(npts, cfg, dec)
+    for tag, iters in (("nwf", 2), ("pgo", 1), ("wf", 1)):
+        if tag == "pgo":
+            quat = torch.randn(npts.local_point_orientations.shape, generator=gen)
+            npts.local_point_orientations, npts.after_pgo = (quat / quat.norm(dim=1, keepdim=True)).float(), True
+            out["pgo_quat"] = t2n(npts.local_point_orientations)
+        cfg.weighted_first = tag == "wf"
+        out[f"{tag}_feat_before"] = t2n(npts.local_geo_features.data)
+        out[f"{tag}_dec_before"] = flat_decoder(dec)
+        out[f"{tag}_cert_before"] = t2n(npts.local_point_certainties)
+        out[f"{tag}_tsu_before"] = t2n(npts.local_point_ts_update)
+        mapping_section(m, cfg, dec, npts, gen, out, iters=iters, tag=tag)
+        for key in ("global_feat_after", "feat_after", "dec_after"):  # (the next run's *_before; not compared)
+            del out[f"{tag}_{key}"]
+        if tag == "pgo":
+            npts.after_pgo = False
     return out
 
 
@@ -777,6 +817,11 @@ def main():
         np.savez_compressed(path, **d)
         print(case, "->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "P =", d["neural_points"].shape[0],
               "M =", d["local_neural_points"].shape[0])
+    if only in (None, "analytic_eik"):
+        d = gen_analytic()
+        path = os.path.join(OUT, "analytic_eik.npz")
+        np.savez_compressed(path, **d)
+        print("analytic_eik ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "losses", d["nwf_loss_total"], d["pgo_loss_total"], d["wf_loss_total"])
     if only in (None, "replica_color"):
         d = gen_color_case()
         path = os.path.join(OUT, "replica_color.npz")

@@ -440,6 +440,34 @@ def mlp_backward(acts, params, dout):
     return dh.reshape(acts[0].shape), np.concatenate(flat)
 
 
+def mlp_tangent_backward(acts, params, t0, dout):
+    """Gradient of sum(dout * D_t0 out) w.r.t. the decoder parameters, where D_t0 out is the directional derivative
+    of Decoder.mlp's output along the input direction t0 at the point the forward pass `acts` was taken: what
+    autograd's double backward (tools.py:247-260 with create_graph=True, then mapper.py:817) gives for a
+    Linear+ReLU stack -- the ReLU patterns are constants almost everywhere, so the derivative network is the
+    same weights without biases behind fixed masks."""
+    Ws, bs, Wo, bo = params
+    masks = [(acts[li + 1].reshape(-1, acts[li + 1].shape[-1]) > 0) for li in range(len(Ws))]
+    t = t0.reshape(-1, t0.shape[-1])
+    ts = [t]
+    for li in range(len(Ws)):
+        t = (t @ Ws[li].T) * masks[li]
+        ts.append(t)
+    d = dout.reshape(-1, dout.shape[-1])
+    gWo = d.T @ ts[-1]
+    dh = d @ Wo
+    flat_w = [None] * len(Ws)
+    for li in range(len(Ws) - 1, -1, -1):
+        dh = dh * masks[li]
+        flat_w[li] = dh.T @ ts[li]
+        dh = dh @ Ws[li]
+    flat = []
+    for li, a in enumerate(flat_w):
+        flat += [a.ravel(), np.zeros(Ws[li].shape[0], a.dtype)]
+    flat += [gWo.ravel(), np.zeros(Wo.shape[0], gWo.dtype)]
+    return np.concatenate(flat)
+
+
 def eikonal_queries(coord, dec, eps, first=0):
     """mapper.py:682-686 + 986-1008: the 6*n_e central-difference query points in the
     reference's concatenation order (x+, x-, y+, y-, z+, z-), each block [n_e,3].
@@ -453,7 +481,7 @@ def eikonal_queries(coord, dec, eps, first=0):
 def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat_params,
                dec_shape, sdf_scale, k, *, weighted_first=True, dec=10, eps=0.08, weight_e=0.5,
                loss_weight_on=False, ekional=True, dtype=np.float64, eik_first=0, n_main_global=None,
-               n_eik_global=None):
+               n_eik_global=None, analytic=False, orientations=None):
     """One iteration of Mapper.mapping (utils/mapper.py:645-817) on a FIXED batch:
     forward (K1-K3), BCE + Eikonal(numerical gradient) loss, backward.
 
@@ -463,7 +491,14 @@ def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat
     losses normalised by the global counts: gradients of the shards then add up to
     the whole-batch gradient.  Returns dict(loss, sdf_loss, eik_loss, feat_grad [M+1,F],
     dec_grad [n_param], sdf_pred); with shard arguments the loss terms are the shard's SUMS
-    divided by the global counts."""
+    divided by the global counts.
+
+    ``analytic`` (numerical_grad_on: False, config.py:437-439 -> gradient_decimation 1; config/lidar_slam/
+    run_livox.yaml:27): the Eikonal term is taken on the autograd gradient of EVERY sample
+    (mapper.py:642-643, 677-678: get_gradient(coord, sdf_pred) with create_graph=True) and the loss is
+    differentiated through it.  With c = d loss / d g, the scalar c.g is linear in the per-neighbour
+    predictions (through the IDW-weight derivative) and in the derivative network along the direction
+    d(decoder input)/dq . c (mlp_tangent_backward); the ReLU patterns contribute nothing."""
     T = dtype
     in_dim, hidden, levels = dec_shape
     params = unpack_decoder(np.asarray(flat_params, T), in_dim, hidden, levels)
@@ -511,7 +546,46 @@ def train_step(coord, sdf_label, sample_weight, searcher, feats, positions, flat
         dxl = dxl * wt
     dec_grad = backward(fw, dxl / sigma)
     eik_loss = 0.0
-    if ekional and weight_e > 0:
+    if ekional and weight_e > 0 and analytic:
+        qf = fw["qf"]
+        valid, w = fw["valid"], fw["w"]
+        gather = np.where(valid, qf["knn_idx"], 0)
+        diff = np.asarray(coord, T)[:, None, :] - positions[gather].astype(T)
+        u = np.where(valid, 1.0 / (qf["knn_d2"].astype(T) + T(1e-15)), 0.0)
+        u = np.where((qf["nn_count"] == 0)[:, None], T(1e-15), u)
+        S = u.sum(1, keepdims=True)
+        g_u = np.where(valid[..., None], -2.0 * (u ** 2)[..., None] * diff, 0.0)
+        dw = np.where(valid[..., None], g_u / S[..., None] - (u / S ** 2)[..., None] * g_u.sum(1, keepdims=True), 0.0)
+        if orientations is not None:
+            _, R = quat_rotate(orientations[gather].astype(T), diff)
+        else:
+            R = np.broadcast_to(np.eye(3, dtype=T), diff.shape[:2] + (3, 3))
+        a = mlp_input_jacobian(fw["acts"], params)  # [N,(k,)F+3]
+        fv = qf["geo_feat"].astype(T)
+        if weighted_first:
+            g = s * (np.einsum("nk,nkij,ni->nj", w, R, a[:, F:]) + np.einsum("nk,nkj->nj", np.einsum("nf,nkf->nk", a, fv), dw))
+        else:
+            g = np.einsum("nk,nkj->nj", s * fw["x"], dw) + s * np.einsum("nk,nkij,nki->nj", w, R, a[..., F:])
+        ne = n_eik_global or len(coord)
+        nrm = np.linalg.norm(g, axis=-1)
+        eik_loss = ((nrm - 1.0) ** 2).sum() / ne
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = np.where(nrm[:, None] > 0, g / nrm[:, None], 0.0) * (2.0 * (nrm - 1.0) * weight_e / ne)[:, None]
+        cdw = np.einsum("nj,nkj->nk", c, dw)  # c . d w_t / d q
+        chat = np.einsum("nkij,nj->nki", R, c)  # d (neighbour vector) / d q . c
+        if weighted_first:
+            zdot = np.einsum("nk,nkf->nf", cdw, fv)
+            zdot[:, F:] += np.einsum("nk,nki->ni", w, chat)
+            dec_grad = dec_grad + mlp_tangent_backward(fw["acts"], params, zdot, np.full((len(coord), 1), s, T))
+            dfeat = np.where(valid[..., None], s * cdw[..., None] * a[:, None, :F], 0.0)
+            np.add.at(feat_grad, gather.reshape(-1), dfeat.reshape(-1, F))
+        else:
+            dz, gflat = mlp_backward(fw["acts"], params, (s * cdw)[..., None])
+            dfeat = np.where(valid[..., None], dz[..., :F], 0.0)
+            np.add.at(feat_grad, gather.reshape(-1), dfeat.reshape(-1, F))
+            t0 = np.concatenate([np.zeros(chat.shape[:2] + (F,), T), chat], -1)
+            dec_grad = dec_grad + gflat + mlp_tangent_backward(fw["acts"], params, t0, (s * w)[..., None])
+    elif ekional and weight_e > 0:
         qe = eikonal_queries(coord, dec, eps, eik_first)
         fe = forward(qe)
         ne_local = len(qe) // 6

@@ -306,3 +306,45 @@ def test_color_mapping_gradients(cgold):
     for got, ref in ((r["feat_grad"], d["map_gfeat0"]), (r["dec_grad"], d["map_gdec0"]),
                      (rc["feat_grad"], d["map_cfeat0"]), (rc["dec_grad"], d["map_cdec0"])):
         assert np.max(np.abs(got - ref)) < 3e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tag", ["nwf", "pgo", "wf"])
+def test_analytic_eikonal_mapping(tag):
+    """Mapper.mapping with numerical_grad_on False (run_livox.yaml:27): the Eikonal term on the autograd gradient of every
+    sample, differentiated a second time (mapper.py:642-643, 677-678, 760-782).  Per-neighbour decoding, the same with
+    rotated neighbour vectors (after a pose-graph correction), and weighted-first decoding: gradients and scalar losses
+    of every iteration against the reference's double backward."""
+    d = G.load("analytic_eik")
+    d["table"] = G.dense_table(d)
+    k, wf = int(d["query_nn_k"]), tag == "wf"
+    orient = d["pgo_quat"] if tag in ("pgo", "wf") else None  # (the wf run comes after the pgo run in the generator)
+    if tag == "wf":
+        orient = None  # after_pgo was switched off again
+    feats = d[f"{tag}_feat_before"].astype(np.float64).copy()
+    flat = d[f"{tag}_dec_before"].astype(np.float64).copy()
+    cert, tsu = d[f"{tag}_cert_before"].copy(), d[f"{tag}_tsu_before"].copy()
+    mf, vf, md, vd = np.zeros_like(feats), np.zeros_like(feats), np.zeros_like(flat), np.zeros_like(flat)
+    shape = (11, int(d["dec_hidden"]), int(d["dec_levels"]))
+    n_it = len(d[f"{tag}_loss_total"])
+    for it in range(n_it):
+        def searcher(points):
+            s = _search(d, points, tf=True)
+            return O.query_feature(points, s, feats.astype(np.float32), d["local_neural_points"], cert, k,
+                                   global2local=d["global2local"], orientations=orient, weighted_first=False,
+                                   training_mode=True, query_ts=d[f"{tag}_ts{it}"], ts_update=tsu)
+
+        r = O.train_step(d[f"{tag}_coord{it}"], d[f"{tag}_label{it}"], d[f"{tag}_w{it}"], searcher, feats,
+                         d["local_neural_points"], flat, shape, d["sdf_scale"], k, weighted_first=wf, dec=1,
+                         weight_e=d[f"{tag}_weight_e"], loss_weight_on=bool(d[f"{tag}_loss_weight_on"]), analytic=True,
+                         orientations=orient)
+        gf, gd = d[f"{tag}_gfeat{it}"], d[f"{tag}_gdec{it}"]
+        assert np.max(np.abs(r["feat_grad"] - gf)) < 2e-4 * np.abs(gf).max()
+        assert np.max(np.abs(r["dec_grad"] - gd)) < 2e-4 * np.abs(gd).max()
+        assert r["eik_loss"] > 0.01  # the term is live
+        assert abs(r["sdf_loss"] - d[f"{tag}_loss_sdf"][it]) < 1e-5 * abs(d[f"{tag}_loss_sdf"][it])
+        assert abs(r["loss"] - d[f"{tag}_loss_total"][it]) < 1e-5 * abs(d[f"{tag}_loss_total"][it])
+        cert, tsu = r["fw"]["qf"]["certainties_after"], r["fw"]["qf"]["ts_update_after"]
+        feats, mf, vf = O.adam_step(feats, r["feat_grad"], mf, vf, it + 1, d[f"{tag}_lr"], eps=d[f"{tag}_adam_eps"])
+        flat, md, vd = O.adam_step(flat, r["dec_grad"], md, vd, it + 1, d[f"{tag}_lr"], eps=d[f"{tag}_adam_eps"])
+    np.testing.assert_allclose(cert, d[f"{tag}_cert_after"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(tsu, d[f"{tag}_ts_after"])
