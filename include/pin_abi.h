@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 9
+#define PIN_ABI_VERSION 10
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -200,6 +200,10 @@ typedef struct pin_train_params {
     float eik_eps;           /* voxel_size_m * num_grad_step_ratio (mapper.py:685) */
     float inv_n_main;        /* 1 / GLOBAL batch size  (the loss means; sharded batches pass */
     float inv_n_eik;         /* 1 / GLOBAL Eikonal count  the global counts)      */
+    int32_t eik_analytic;    /* numerical_grad_on False (config.py:437-439, run_livox.yaml:27): the Eikonal term on the
+                              * autograd gradient of EVERY main sample (mapper.py:642-643, 677-678, 760-782) and its second
+                              * derivative; n_eik = 0 (no probes), inv_n_eik = 1 / GLOBAL batch size, the workspace sized
+                              * for 2 * n_main queries.  Built for weighted_first = 0 with a one-layer decoder. */
 } pin_train_params;
 
 /* ---- map maintenance (NeuralPoints.update / reset_local_map / assign_local_to_global,
@@ -439,7 +443,11 @@ int64_t pin_train_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t lev
  * fused tile kernel (gather, forward, loss, backward, feature scatter) -> streamed weight gradient -> finalize;
  * deeper per-neighbour decoders: forward / loss / backward / weight-gradient kernels over a unit-major workspace.
  * The workspace (pin_train_workspace_bytes) carries the operand stream of the weight gradient, slot copies of the
- * decoder gradient, per-block loss sums and the decoder image; its contents are scratch. */
+ * decoder gradient, per-block loss sums and the decoder image; its contents are scratch.
+ * tp->eik_analytic (numerical_grad_on False, mapper.py:642-643, 677-678): the queries are the n_main batch samples alone
+ * (pin_train_make_queries with n_eik = 0); the Eikonal term is taken on d pred / d q of every sample (tools.py:247-260)
+ * and differentiated through it, as autograd's create_graph = True does; loss_out[1] = sum over the batch of
+ * (|g|-1)^2; workspace of pin_train_workspace_bytes(2 * n_main, ...).  Built for weighted_first = 0 with a one-layer decoder; other shapes return an error. */
 int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query,
                    const float* nbr, const int32_t* nn_count, const float* sdf_label,
                    const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,

@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 9
+PIN_ABI_VERSION = 10
 PIN_COMM_ID_BYTES = 128
 
 vp = C.c_void_p
@@ -114,7 +114,7 @@ class TrainParams(C.Structure):
     _fields_ = [
         ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
         ("sigma", C.c_float), ("weight_e", C.c_float), ("eik_eps", C.c_float),
-        ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float),
+        ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float), ("eik_analytic", C.c_int32),
     ]
 
 

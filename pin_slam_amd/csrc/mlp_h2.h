@@ -241,8 +241,12 @@ struct QuadDecoderH {
         }
     }
     __device__ __forceinline__ static void layer0(const unsigned char* __restrict__ w, int L, v2u_t zh, v2u_t zl, v4f_t (&acc)[MT]) {
-        const int lane = threadIdx.x & 63;
         load_bias(w, L, 0, acc);
+        layer0_add(w, L, zh, zl, acc);
+    }
+    // acc += W0 z (no bias: the derivative network of the analytic Eikonal term, train_fused.h)
+    __device__ __forceinline__ static void layer0_add(const unsigned char* __restrict__ w, int L, v2u_t zh, v2u_t zl, v4f_t (&acc)[MT]) {
+        const int lane = threadIdx.x & 63;
         const v2u_t* __restrict__ A = reinterpret_cast<const v2u_t*>(w + off_l0f(L)) + lane;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {

@@ -860,7 +860,7 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     PIN_CHECK_LAUNCH();
     if (want_dec) {
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
-                           dw_partial);
+                           dw_partial, 0);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
@@ -885,8 +885,9 @@ static int launch_fused(const pin_field* f, const pin_train_params* tp, const Fu
 #undef PIN_LF
 }
 
-// weighted_first = False with a one-layer decoder: groups of three (query, neighbour)-column tiles (train_fused.h)
-template <int H>
+// weighted_first = False with a one-layer decoder: groups of three (query, neighbour)-column tiles (train_fused.h);
+// AN = the Eikonal term on the analytic gradient of every sample (a second operand stream for the derivative network)
+template <int H, bool AN>
 static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
                             const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
                             float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
@@ -894,30 +895,35 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     using G = DwGeom<H>;
     constexpr int L = 1;
     constexpr int lds_bytes = train_fused_nwf_lds_bytes<H>();
-    DwStream ws;
+    DwStream ws, ws2;
     const int n_groups = (tp->n_main + 5) / 6 + tp->n_eik;
-    ws.n_tiles = 3 * n_groups;
-    const size_t need = 2 * G::total((size_t)ws.n_tiles, L) * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
+    ws.n_tiles = ws2.n_tiles = 3 * n_groups;
+    const size_t per_stream = 2 * G::total((size_t)ws.n_tiles, L);
+    const size_t need = (AN ? 2 : 1) * per_stream * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
     PIN_CHECK_ARG((size_t)workspace_bytes >= need, "workspace too small");
     ws.d = reinterpret_cast<uint2*>(workspace);
     ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
+    ws2.d = ws.d + (AN ? per_stream : 0);
+    ws2.a = ws.a + (AN ? per_stream : 0);
     const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
-    const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
+    const float unit_eik = AN ? 2.f * tp->weight_e * tp->inv_n_eik
+                              : (tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f);
     const float dscale = exp2f(-ceilf(log2f(fmaxf(fmaxf(unit_main, unit_eik), 1e-30f))));
     const int want_dec = dec_grad != nullptr;
     const int n_dec = H * MLP_IN + H + H + 1;
-    float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
+    float* dw_partial = reinterpret_cast<float*>(ws.d + (AN ? 2 : 1) * per_stream);
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, cdiv(n_groups, TF_BLOCK / 64));
     hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
-    hipLaunchKernelGGL((train_fused_nwf_kernel<H>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
-                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image,
+    hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
                        dw_partial, n_dec, loss_partial);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec,
-                           dw_partial);
+        const dim3 dgrid(cdiv(ws.n_tiles, DW_CHUNK), L + 1);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0);
+        if (AN) hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
@@ -947,9 +953,13 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     PIN_CHECK_ARG(f->levels >= 1 && f->levels <= MLP_MAX_LEVELS, "levels must be in [1, 4]");
     const int expand = f->weighted_first ? 1 : f->k;
     PIN_CHECK_ARG(tp->n_main > 0 && tp->n_eik >= 0, "bad batch sizes");
+    const bool analytic = tp->eik_analytic != 0;
+    PIN_CHECK_ARG(!analytic || tp->n_eik == 0, "analytic Eikonal term: no probe samples (n_eik = 0)");
+    PIN_CHECK_ARG(!analytic || f->weighted_first == 0,
+                  "analytic Eikonal term: built for per-neighbour decoding with a one-layer decoder (run_livox.yaml)");
     const int Q = tp->n_main + 6 * tp->n_eik;
     const int H = f->hidden, L = f->levels;
-    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(Q, H, L, expand) * 4, "workspace too small");
+    PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(analytic ? 2 * Q : Q, H, L, expand) * 4, "workspace too small");
     PIN_CHECK_ARG(query && nbr && nn_count && sdf_label && feat_grad && loss_out && f->feats && f->dec, "NULL pointer");
     PIN_CHECK_ARG(!tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
     hipStream_t s = as_stream(stream);
@@ -976,13 +986,15 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
                        : launch_fused<32, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s);
     }
-    if (L == 1 && use_split_decoder())  // per-neighbour decoding, one-layer decoder: (query, neighbour)-column tiles
-        return H == 64 ? launch_fused_nwf<64>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
-                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes,
-                                              cu_count(), s)
-                       : launch_fused_nwf<32>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
-                                              ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes,
-                                              cu_count(), s);
+    if (L == 1 && use_split_decoder()) {  // per-neighbour decoding, one-layer decoder: (query, neighbour)-column tiles
+#define PIN_NWF(HH, ANALYTIC)                                                                                                   \
+    launch_fused_nwf<HH, ANALYTIC>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw, \
+                                   feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, cu_count(), s)
+        if (analytic) return H == 64 ? PIN_NWF(64, true) : PIN_NWF(32, true);
+        return H == 64 ? PIN_NWF(64, false) : PIN_NWF(32, false);
+#undef PIN_NWF
+    }
+    PIN_CHECK_ARG(!analytic, "analytic Eikonal term: built for per-neighbour decoding with a one-layer decoder (run_livox.yaml)");
     // deeper per-neighbour decoders: 64 queries per wave, activations and deltas through the unit-major workspace
     PIN_TRAIN_MFMA(train_fwd_mfma_kernel, *f, query, nb4, nn_count, Q, tp->n_main, ws, certainty_rw, ts_update_rw, sample_ts);
     PIN_CHECK_LAUNCH();

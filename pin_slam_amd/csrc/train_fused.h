@@ -421,7 +421,39 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
 // Eikonal sample are THREE tiles (tile j = the +- pair of axis j): a wave works on groups of three tiles -- forward x 3
 // (a one-layer decoder leaves 20 piece words per tile to keep), loss, backward x 3 -- and main samples go through the
 // same code six at a time.  Feature gradients: a column owns one row, 8 columns x 8 dims per atomic instruction.
-template <int H>
+//
+// AN: the Eikonal term on the ANALYTIC gradient of every main sample (numerical_grad_on False: run_livox.yaml:27;
+// mapper.py:642-643, 677-678, 760-782 -- autograd differentiates the loss through get_gradient a second time).  No
+// probes.  The forward pass also takes g = d pred / d q (the Jacobian of gn_accumulate_quad_nwf_kernel: through the
+// neighbour vectors and through the IDW weights).  With c = d loss / d g, the scalar c . g is
+//     sum_t  s x_t (c . d w_t / d q)  +  s w_t (W0^T (pattern_t .* wo)) . chat_t,      chat_t = d (input of column t) / d q  c,
+// linear in the predictions x_t -- so the first term only adds (c . d w_t / d q) to the upstream of column t -- and in
+// the DERIVATIVE network of column t along chat_t (same weights, no biases, the ReLU pattern of the forward pass as a
+// fixed mask; the pattern itself contributes nothing almost everywhere).  Its weight gradient is a second operand
+// stream (ws2) of the same geometry: d W0 += (s w_t pattern_t .* wo) (x) chat_t, d wo += s w_t (pattern_t .* W0 chat_t);
+// no bias and no feature gradient comes from it.
+__device__ __forceinline__ void neighbor_vector_rot(const pin_field& f, int idx, bool quirk, float vgx, float vgy, float vgz,
+                                                    float qx, float qy, float qz, float (&v)[3], float (&Rm)[9]) {
+    v[0] = vgx; v[1] = vgy; v[2] = vgz;
+    if (quirk) {  // the reference gathers local point #1 for non-local neighbours
+        const float* p = f.pos + 3 * (size_t)idx;
+        v[0] = qx - p[0]; v[1] = qy - p[1]; v[2] = qz - p[2];
+    }
+    Rm[0] = 1.f; Rm[1] = 0.f; Rm[2] = 0.f; Rm[3] = 0.f; Rm[4] = 1.f; Rm[5] = 0.f; Rm[6] = 0.f; Rm[7] = 0.f; Rm[8] = 1.f;
+    if (f.orient != nullptr) {  // apply_quaternion_rotation (utils/tools.py:428-437): v_i = sum_j Rm[3 i + j] x_j
+        const float4 q = reinterpret_cast<const float4*>(f.orient)[idx];
+        const float q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w;
+        Rm[0] = 1 - 2 * (q2 * q2 + q3 * q3); Rm[3] = 2 * (q1 * q2 - q0 * q3); Rm[6] = 2 * (q1 * q3 + q0 * q2);
+        Rm[1] = 2 * (q1 * q2 + q0 * q3); Rm[4] = 1 - 2 * (q1 * q1 + q3 * q3); Rm[7] = 2 * (q2 * q3 - q0 * q1);
+        Rm[2] = 2 * (q1 * q3 - q0 * q2); Rm[5] = 2 * (q2 * q3 + q0 * q1); Rm[8] = 1 - 2 * (q1 * q1 + q2 * q2);
+        const float x = v[0], y = v[1], z = v[2];
+        v[0] = Rm[0] * x + Rm[1] * y + Rm[2] * z;
+        v[1] = Rm[3] * x + Rm[4] * y + Rm[5] * z;
+        v[2] = Rm[6] * x + Rm[7] * y + Rm[8] * z;
+    }
+}
+
+template <int H, bool AN>
 __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field f, pin_train_params tp,
                                                                       const float* __restrict__ query,
                                                                       const float4* __restrict__ nbr,
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                                                                       const int* __restrict__ sample_ts,
                                                                       float* __restrict__ cert_rw, int* __restrict__ ts_rw,
                                                                       float* __restrict__ feat_grad, float* __restrict__ pred_out,
-                                                                      DwStream ws, int want_dec, float dscale,
+                                                                      DwStream ws, DwStream ws2, int want_dec, float dscale,
                                                                       const unsigned char* __restrict__ dec_image,
                                                                       float* __restrict__ dw_partial, int n_dec,
                                                                       double* __restrict__ loss_partial) {
@@ -480,6 +512,9 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
         float wt[3], pred[3];
         int id[3], qidx[3];
         bool act[3], valn[3];
+        // (AN) per column: q - P_t, d u_t / d q = cg (q - P_t); per query: 1 / S, sum_t cg (q - P_t), d pred / d q
+        float ex[3], ey[3], ez[3], cgn[3], invS[3], Gx[3], Gy[3], Gz[3], gx[3], gy[3], gz[3];
+        bool rot[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int a = 2 * j + q2;  // query of the group: main sample 6 grp + a / probe a of Eikonal sample grp - n_main_groups
@@ -498,10 +533,16 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
             const float S = octet_sum(ut);
             const float w = val ? ut / S : 0.f;
             float v[3] = {e.x, e.y, e.z};
+            float Rm[9];
             const bool quirk = val && (raw & PIN_NBR_QUIRK_BIT) != 0;
-            if (f.orient != nullptr || __builtin_amdgcn_ballot_w64(quirk) != 0ull) {  // after PGO / a flagged neighbour (rare)
+            const bool special = f.orient != nullptr || __builtin_amdgcn_ballot_w64(quirk) != 0ull;  // after PGO / a flagged neighbour (rare)
+            if (special) {
                 const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
-                if (val) neighbor_vector_only(f, idn, quirk, e.x, e.y, e.z, qx, qy, qz, v);
+                if constexpr (AN) {
+                    if (val) neighbor_vector_rot(f, idn, quirk, e.x, e.y, e.z, qx, qy, qz, v, Rm);
+                } else {
+                    if (val) neighbor_vector_only(f, idn, quirk, e.x, e.y, e.z, qx, qy, qz, v);
+                }
             }
             float z[4];
             z[0] = !val ? 0.f : (g < 2 ? ft.x : (g == 2 ? v[0] : 0.f));
@@ -522,6 +563,32 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
             Q::split_acts(h, ph[j], pl[j]);
             wt[j] = w; id[j] = idn; valn[j] = val;
             pred[j] = octet_sum(w * (s * x));  // mapper.py:658-662
+            if constexpr (AN) {  // d pred / d q (tools.py:247-260 through Decoder.mlp, the neighbour vectors and the weights)
+                v4f_t hb[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hb[mt][r] = h[mt][r] > 0.f ? wo[mt][r] : 0.f;
+                float a4[4];
+                Q::input_backward(lds, L, hb, a4);  // d x_t / d (input of column t); the position part sits in the g == 2 lanes
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                if (g == 2 && val) {
+                    if (special) {
+                        d0 = w * (Rm[0] * a4[0] + Rm[3] * a4[1] + Rm[6] * a4[2]);
+                        d1 = w * (Rm[1] * a4[0] + Rm[4] * a4[1] + Rm[7] * a4[2]);
+                        d2 = w * (Rm[2] * a4[0] + Rm[5] * a4[1] + Rm[8] * a4[2]);
+                    } else { d0 = w * a4[0]; d1 = w * a4[1]; d2 = w * a4[2]; }
+                }
+                d0 = quad_lanes_sum(octet_sum(d0)); d1 = quad_lanes_sum(octet_sum(d1)); d2 = quad_lanes_sum(octet_sum(d2));
+                const float uv = val ? ut : 0.f;
+                const float cg = -2.f * uv * uv, cs = cg * (s * x), iS = 1.0f / S;
+                const float ax = octet_sum(cs * e.x), ay = octet_sum(cs * e.y), az = octet_sum(cs * e.z);
+                Gx[j] = octet_sum(cg * e.x); Gy[j] = octet_sum(cg * e.y); Gz[j] = octet_sum(cg * e.z);
+                gx[j] = s * d0 + (ax - pred[j] * Gx[j]) * iS;
+                gy[j] = s * d1 + (ay - pred[j] * Gy[j]) * iS;
+                gz[j] = s * d2 + (az - pred[j] * Gz[j]) * iS;
+                ex[j] = e.x; ey[j] = e.y; ez[j] = e.z; cgn[j] = cg; invS[j] = iS; rot[j] = special && val;
+            }
             if (!eik && valid && t == 0 && g == 0 && pred_out != nullptr) pred_out[qi] = pred[j];
             // training-mode side effects (neural_points.py:685-710), main samples only
             if (!eik && valid && val && g == 3 && cert_rw != nullptr) {
@@ -561,12 +628,26 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                 dp[j] = act[j] ? gg * tp.inv_n_main / tp.sigma : 0.f;
             }
         }
+        float cx[3], cy[3], cz[3];  // (AN) d loss / d g of this lane's query
+        if constexpr (AN) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float n = sqrtf(gx[j] * gx[j] + gy[j] * gy[j] + gz[j] * gz[j]);
+                const float r = n - 1.f;  // mapper.py:778-781, every sample (gradient_decimation = 1, config.py:438-439)
+                if (act[j] && t == 0 && g == 0) acc_eik += (double)(r * r);
+                const float cf = (act[j] && n > 0.f) ? tp.weight_e * 2.f * r * tp.inv_n_eik / n : 0.f;
+                cx[j] = cf * gx[j]; cy[j] = cf * gy[j]; cz[j] = cf * gz[j];
+            }
+        }
         // ---- backward of the three tiles
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const size_t tile = (size_t)3 * grp + j;
             const size_t tbase = tile * 128 + lane;
-            const float dx = (act[j] && valn[j]) ? dp[j] * wt[j] * s * dscale : 0.f;  // pred = sum_t w_t * sdf_scale * head_t
+            float up = dp[j] * wt[j];  // pred = sum_t w_t * sdf_scale * head_t
+            if constexpr (AN)  // c . d w_t / d q,  d w_t / d q = (d u_t / d q - w_t sum_t' d u_t' / d q) / S
+                up += (cgn[j] * (cx[j] * ex[j] + cy[j] * ey[j] + cz[j] * ez[j]) - wt[j] * (cx[j] * Gx[j] + cy[j] * Gy[j] + cz[j] * Gz[j])) * invS[j];
+            const float dx = (act[j] && valn[j]) ? up * s * dscale : 0.f;
             v4f_t h[MT];
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj)
@@ -596,6 +677,59 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                 uint2* __restrict__ A0 = ws.a + G::a_off(n_tiles, 0) + tbase;
                 A0[0] = transpose_block(zh[j][0], zh[j][1], ident);
                 A0[64] = transpose_block(zl[j][0], zl[j][1], ident);
+                if constexpr (AN) {  // the derivative network along chat_t (x dscale), upstream tau_t = s w_t
+                    float ch[4] = {0.f, 0.f, 0.f, 0.f};
+                    const bool on_col = act[j] && valn[j];
+                    if (g == 2 && on_col) {
+                        float c0 = cx[j], c1 = cy[j], c2 = cz[j];
+                        if (rot[j]) {
+                            const int qq = qidx[j];
+                            float v[3], Rm[9];
+                            neighbor_vector_rot(f, id[j], false, ex[j], ey[j], ez[j], query[3 * qq], query[3 * qq + 1], query[3 * qq + 2], v, Rm);
+                            c0 = Rm[0] * cx[j] + Rm[1] * cy[j] + Rm[2] * cz[j];
+                            c1 = Rm[3] * cx[j] + Rm[4] * cy[j] + Rm[5] * cz[j];
+                            c2 = Rm[6] * cx[j] + Rm[7] * cy[j] + Rm[8] * cz[j];
+                        }
+                        ch[0] = c0 * dscale; ch[1] = c1 * dscale; ch[2] = c2 * dscale;
+                    }
+                    v2u_t th, tl;
+                    Q::split_input(ch, th, tl);
+                    v4f_t tacc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) tacc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                    Q::layer0_add(lds, L, th, tl, tacc);
+                    const float tau = on_col ? s * wt[j] : 0.f;
+                    v4f_t tm[MT], tb[MT];
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned int word = ph[j][mj >> 1][2 * (mj & 1) + (r >> 1)] | pl[j][mj >> 1][2 * (mj & 1) + (r >> 1)];
+                            const bool on = (r & 1) ? ((word & 0x7fff0000u) != 0u) : ((word & 0x7fffu) != 0u);
+                            tm[mj][r] = on ? tacc[mj][r] : 0.f;
+                            tb[mj][r] = on ? tau * wo[mj][r] : 0.f;
+                        }
+                    v4u_t mh[NJ], ml[NJ], th2[NJ], tl2[NJ];
+                    Q::split_acts(tm, mh, ml);
+                    Q::split_acts(tb, th2, tl2);
+                    unsigned int eh0, el0;
+                    h2_split2((g == 0) ? tau : 0.f, 0.f, eh0, el0);
+                    uint2* __restrict__ E1 = ws2.d + G::d_off(n_tiles, 1) + tbase;
+                    E1[0] = transpose_block(eh0, 0u, ident);
+                    E1[64] = transpose_block(el0, 0u, ident);
+                    uint2* __restrict__ B1 = ws2.a + G::a_off(n_tiles, 1) + tile * 128 * (MT - 1) + tbase;
+                    uint2* __restrict__ E0 = ws2.d + G::d_off(n_tiles, 0) + tile * 128 * (MT - 1) + tbase;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        B1[mt * 128] = transpose_block(mh[mt >> 1][2 * (mt & 1)], mh[mt >> 1][2 * (mt & 1) + 1], ident);
+                        B1[mt * 128 + 64] = transpose_block(ml[mt >> 1][2 * (mt & 1)], ml[mt >> 1][2 * (mt & 1) + 1], ident);
+                        E0[mt * 128] = transpose_block(th2[mt >> 1][2 * (mt & 1)], th2[mt >> 1][2 * (mt & 1) + 1], ident);
+                        E0[mt * 128 + 64] = transpose_block(tl2[mt >> 1][2 * (mt & 1)], tl2[mt >> 1][2 * (mt & 1) + 1], ident);
+                    }
+                    uint2* __restrict__ B0 = ws2.a + G::a_off(n_tiles, 0) + tbase;
+                    B0[0] = transpose_block(th[0], th[1], ident);
+                    B0[64] = transpose_block(tl[0], tl[1], ident);
+                }
             }
             float dz[4];
             Q::input_backward(lds, L, bh, bl, dz);
@@ -667,7 +801,7 @@ constexpr int DW_VALS = 20;    // per lane: 4 input blocks x 4 + 4 bias sums
 
 template <int H>
 __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream ws, int L, int OD, int n_dec,
-                                                                        float* __restrict__ partial) {
+                                                                        float* __restrict__ partial, int no_bias) {
     using G = DwGeom<H>;
     constexpr int MT = G::MT;
     __shared__ float red[DW_WAVES / 2][DW_VALS][64];
@@ -758,7 +892,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
             if (o < rows && i < cols_out && v != 0.f) atomicAdd(gW + (size_t)o * cols_out + i, v);
         }
     }
-    if (n == 0) {
+    if (n == 0 && !no_bias) {  // (the derivative-network stream of the analytic Eikonal term has no bias gradient)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = 16 * ob + 4 * g + r;

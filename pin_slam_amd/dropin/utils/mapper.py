@@ -329,7 +329,8 @@ class Mapper(_Base):
         if getattr(c, "color_on", False) and c.weight_i > 0 and c.color_channel != 3: bad.append("color_channel != 3")
         if c.main_loss_type != "bce": bad.append("main_loss_type != bce")
         if c.proj_correction_on or c.consistency_loss_on: bad.append("proj_correction / consistency loss")
-        if c.ekional_loss_on and not c.numerical_grad: bad.append("analytic Eikonal (numerical_grad=False)")
+        if c.ekional_loss_on and c.weight_e > 0 and not c.numerical_grad and (c.weighted_first or self.sdf_mlp.hidden_level != 1):
+            bad.append("analytic Eikonal (numerical_grad_on False) outside per-neighbour decoding with a one-layer decoder")
         if c.ekional_loss_on and c.ekional_add_to != "all": bad.append("ekional_add_to != all")
         if not c.opt_adam: bad.append("SGD")
         if c.weight_decay != 0.0: bad.append("weight_decay")
@@ -343,8 +344,10 @@ class Mapper(_Base):
         fs = npts.field_state(self.sdf_mlp, query_locally=True)
         train_dec = bool(self.sdf_mlp.lout.weight.requires_grad)  # freeze_decoders (tools.py:263-292)
         eik = bool(c.ekional_loss_on and c.weight_e > 0)
+        if eik and not c.numerical_grad:  # run_livox.yaml: the autograd gradient of every sample (mapper.py:677-678)
+            eik = "analytic"
         t = self._trainer
-        if (t is None or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel() or (t.buf.n_eik > 0) != eik
+        if (t is None or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel() or t.eikonal != eik
                 or t.fs.weighted_first != fs.weighted_first or (t.rank, t.world) != (self.dp_rank, self.dp_world)):
             t = engine.MapTrainer(st, fs, None, None, None, None, npts.local_point_ts_update, bs=c.bs,
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,

@@ -167,7 +167,8 @@ class MapTrainer:
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.ts = torch.empty((self.bs_local,), dtype=torch.int32, device=dev)
         # Eikonal samples are the global batch's coord[::dec]; each rank owns those in its shard
-        self.n_eik_global = n_eik_global(self.bs, self.dec) if eikonal else 0
+        self.n_eik_global = (self.bs if eikonal == "analytic" else n_eik_global(self.bs, self.dec)) if eikonal else 0
+        self.eikonal = eikonal
         self.total_iter = 0
         self.bricks = None
         self.fc = None  # colour field (set_color)

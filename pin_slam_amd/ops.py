@@ -386,19 +386,26 @@ from ._lib import TrainParams  # noqa: E402
 
 
 class TrainBuffers:
-    """Caller-owned scratch for one training iteration of `n_main` samples (+ Eikonal)."""
+    """Caller-owned scratch for one training iteration of `n_main` samples (+ Eikonal).  eikonal: True = central
+    differences on every `decimation`-th sample (6 probes each), "analytic" = the autograd gradient of every sample
+    (numerical_grad_on False, run_livox.yaml:27: no probes), False = off."""
 
     def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda",
                  shard_start: int = 0, weighted_first: bool = True):
         from .sharding import eikonal_shard
         self.n_main = int(n_main)
         self.dec = int(decimation)
-        self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if eikonal else (0, 0)
+        self.analytic = eikonal == "analytic"
+        if self.analytic and (weighted_first or levels != 1):
+            raise NotImplementedError("analytic Eikonal term (numerical_grad_on False) is built for weighted_first False "
+                                      "with a one-layer decoder (config/lidar_slam/run_livox.yaml)")
+        self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if (eikonal and not self.analytic) else (0, 0)
         self.Q = self.n_main + 6 * self.n_eik
         self.query = torch.empty((self.Q, 3), dtype=torch.float32, device=device)
         self.nbr = torch.empty((self.Q, k, 4), dtype=torch.float32, device=device)
         self.nn = torch.empty((self.Q,), dtype=torch.int32, device=device)
-        nbytes = _lib.lib().pin_train_workspace_bytes(self.Q, hidden, levels, 1 if weighted_first else k)
+        # (the analytic term keeps a second operand stream: sized as for twice the queries)
+        nbytes = _lib.lib().pin_train_workspace_bytes(self.Q * (2 if self.analytic else 1), hidden, levels, 1 if weighted_first else k)
         self.ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
         self.loss = torch.zeros((2,), dtype=torch.float64, device=device)
         self.color_ws = self.color_loss = None
@@ -425,6 +432,9 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     tp.sigma, tp.weight_e, tp.eik_eps = float(sigma), float(weight_e), float(np.float32(eik_eps))
     tp.inv_n_main = 1.0 / float(global_n_main or buf.n_main)
     tp.inv_n_eik = 1.0 / float(global_n_eik or max(buf.n_eik, 1))
+    tp.eik_analytic = int(buf.analytic)
+    if buf.analytic:  # mean over every sample of the (global) batch, mapper.py:778-781
+        tp.inv_n_eik = tp.inv_n_main
     f = fs.params()
     check(L.pin_train_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
                            _ptr(sdf_label, torch.float32), _ptr(sample_weight), _ptr(sample_ts), _ptr(certainty_rw),

@@ -127,7 +127,7 @@ sampler:
 neuralpoints:
   voxel_size_m: 0.4
   search_alpha: 0.5
-{neural_extra}continual:
+{neural_extra}{loss_extra}continual:
   batch_size_new_sample: 1000
   pool_capacity: 2e6
   pool_filter_freq: 10
@@ -232,8 +232,12 @@ def run(args):
     with open(cfg_path, "w") as f:
         # --per-neighbour: decode every neighbour and weight the predictions (run_kitti.yaml: weighted_first False, 6 neighbours)
         extra = "  weighted_first: False\n  query_nn_k: 6\n" if args.per_neighbour else ""
+        loss = ""
+        if args.livox_style:  # run_livox.yaml: per-neighbour decoding with 8 neighbours, Eikonal term on the autograd gradient
+            extra = "  weighted_first: False\n  query_nn_k: 8\n"
+            loss = "loss:\n  loss_weight_on: True\n  dist_weight_scale: 0.5\n  ekional_loss_on: True\n  weight_e: 0.5\n  numerical_grad_on: False\n"
         f.write(CONFIG_YAML.format(out=os.path.join(work, "experiments"), pc=pc_dir, iters=args.iters, deskew=bool(args.deskew),
-                                   neural_extra=extra))
+                                   neural_extra=extra, loss_extra=loss))
     # setup_experiment records `git rev-parse HEAD` (utils/tools.py:105-107): give it a repository to stand in
     subprocess.run("git init -q . && git -c user.email=e2e@x -c user.name=e2e commit -q --allow-empty -m e2e", shell=True,
                    cwd=work, check=True)
@@ -321,6 +325,8 @@ def main():
     r.add_argument("--frames", type=int, default=10)
     r.add_argument("--iters", type=int, default=15)
     r.add_argument("--per-neighbour", action="store_true", help="weighted_first: False, query_nn_k: 6 (run_kitti.yaml style)")
+    r.add_argument("--livox-style", action="store_true", help="run_livox.yaml style: weighted_first False, query_nn_k 8, "
+                                                              "numerical_grad_on False (analytic Eikonal term)")
     r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
     r.add_argument("--reference", default=None)
     r.add_argument("--tol-cm", type=float, default=8.0,

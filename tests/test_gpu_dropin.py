@@ -157,6 +157,54 @@ def test_mini_slam_loop_update_map_track():
     assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 0.01
 
 
+def test_mapper_with_analytic_eikonal_term():
+    """run_livox.yaml's training mode through the drop-in Mapper: per-neighbour decoding, 8 neighbours, the Eikonal term
+    on the autograd gradient of every sample (numerical_grad False -> gradient_decimation 1).  Training lowers the SDF
+    error and pulls the gradient norm of the field to 1; configurations the analytic term is not built for raise."""
+    from pin_slam_amd import ops, synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    torch.manual_seed(0)
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=4096, local_map_radius=40.0, local_map_travel_dist_ratio=5.0,
+               weighted_first=False, numerical_grad=False, gradient_decimation=1, weight_e=0.5, loss_weight_on=True)
+    rng = np.random.default_rng(0)
+    pts, _ = synth.disc_points(rng, 120_000, 25.0, 2)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.zeros(1, device="cuda")
+    npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+    dec = Decoder(cfg, 64, 1, 1)
+    mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
+    base, _ = synth.disc_points(rng, 400_000, 24.0, 2)
+    nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
+    dd = 0.15 * rng.standard_normal(len(base))
+    mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
+    mp.coord_pool = mp.global_coord_pool
+    mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+    mp.weight_pool = torch.ones(len(base), device="cuda")
+    mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+    mp.pool_sample_count = len(base)
+    probe, lab = mp.global_coord_pool[:20000], mp.sdf_label_pool[:20000]
+
+    def grad_norm():
+        nbr, nn, _ = npts.knn(probe, True)
+        fs = npts.field_state(dec, query_locally=True)
+        _, g, _, _ = ops.sdf_query(fs, probe, nbr, nn, grad=True, std=False)
+        return g.norm(dim=1)[nn >= 4]
+
+    err0, n0 = (mp.sdf(probe)[0] - lab).abs().mean().item(), grad_norm()
+    mp.mapping(300)
+    assert mp._trainer.eikonal == "analytic" and mp._trainer.buf.n_eik == 0
+    err1, n1 = (mp.sdf(probe)[0] - lab).abs().mean().item(), grad_norm()
+    assert err1 < 0.35 * err0 and err1 < 0.05, (err0, err1)
+    assert (n1 - 1).abs().mean().item() < 0.2 and (n1 - 1).abs().mean().item() < 0.5 * (n0 - 1).abs().mean().item()
+    cfg.weighted_first = True
+    mp2 = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
+    with pytest.raises(NotImplementedError):
+        mp2.mapping(1)
+    cfg.weighted_first = False
+
+
 def test_mini_slam_loop_with_colour():
     """colour_on through the drop-in classes: Mapper.mapping trains the colour field next to the
     SDF (mapper.py:668-671, 802-812), Tracker.query_source_points returns colour + per-channel

@@ -259,6 +259,65 @@ def test_mapping_two_iterations(gold):
     assert np.array_equal(tsu.cpu().numpy(), d["map_ts_after"])
 
 
+@pytest.mark.parametrize("tag", ["nwf", "pgo"])
+def test_analytic_eikonal_mapping(tag):
+    """numerical_grad_on False (config/lidar_slam/run_livox.yaml:27): the Eikonal term on the autograd gradient of every
+    sample, differentiated a second time (mapper.py:642-643, 677-678, 760-782) -- per-iteration gradients, scalar losses
+    and side effects against the reference's run (fixture analytic_eik: per-neighbour decoding, k = 8, decoder 1x64;
+    `pgo` = neighbour vectors rotated by the point orientations)."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = G.load("analytic_eik")
+    st = U.search_state(d)
+    k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
+    feats, dec = U.dev(d[f"{tag}_feat_before"]), U.dev(d[f"{tag}_dec_before"])
+    cert, tsu = U.dev(d[f"{tag}_cert_before"]), U.dev(d[f"{tag}_tsu_before"], torch.int32)
+    fs = ops.FieldState(feats=feats, dec=dec, k=k, hidden=H, levels=L, weighted_first=False, sdf_scale=d["sdf_scale"],
+                        certainty=cert, orient=U.dev(d["pgo_quat"]) if tag == "pgo" else None,
+                        pos=U.dev(d["local_neural_points"]))
+    gfeat, gdec = torch.zeros_like(feats), torch.zeros_like(dec)
+    mf, vf, md, vd = torch.zeros_like(feats), torch.zeros_like(feats), torch.zeros_like(dec), torch.zeros_like(dec)
+    bs = d[f"{tag}_coord0"].shape[0]
+    buf = ops.TrainBuffers(bs, 1, k, H, L, eikonal="analytic", weighted_first=False)
+    assert buf.n_eik == 0 and buf.Q == bs
+    for it in range(len(d[f"{tag}_loss_total"])):
+        loss = ops.train_step(st, fs, buf, U.dev(d[f"{tag}_coord{it}"]), U.dev(d[f"{tag}_label{it}"]),
+                              U.dev(d[f"{tag}_w{it}"]), U.dev(d[f"{tag}_ts{it}"], torch.int32), cert, tsu, gfeat, gdec,
+                              sigma=d["sdf_scale"], weight_e=d[f"{tag}_weight_e"], eik_eps=d[f"{tag}_eps"],
+                              loss_weight_on=bool(d[f"{tag}_loss_weight_on"]))
+        gf, gd = d[f"{tag}_gfeat{it}"], d[f"{tag}_gdec{it}"]
+        assert np.max(np.abs(gfeat.cpu().numpy() - gf)) < 1e-4 * np.abs(gf).max()
+        assert np.max(np.abs(gdec.cpu().numpy() - gd)) < 1e-4 * np.abs(gd).max()
+        l_bce, l_eik = (loss.cpu().numpy() / bs).tolist()
+        assert l_eik > 0.01
+        assert abs(l_bce - d[f"{tag}_loss_sdf"][it]) < 1e-4 * abs(d[f"{tag}_loss_sdf"][it])
+        total = l_bce + d[f"{tag}_weight_e"] * l_eik
+        assert abs(total - d[f"{tag}_loss_total"][it]) < 1e-4 * abs(d[f"{tag}_loss_total"][it])
+        ops.adam_step(feats, gfeat, mf, vf, it + 1, d[f"{tag}_lr"], eps=d[f"{tag}_adam_eps"])
+        ops.adam_step(dec, gdec, md, vd, it + 1, d[f"{tag}_lr"], eps=d[f"{tag}_adam_eps"])
+    np.testing.assert_allclose(cert.cpu().numpy(), d[f"{tag}_cert_after"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(tsu.cpu().numpy(), d[f"{tag}_ts_after"])
+    # a frozen decoder (freeze_model, tools.py:263-292): same feature gradients, no decoder stream
+    ops.train_step(st, fs, buf, U.dev(d[f"{tag}_coord0"]), U.dev(d[f"{tag}_label0"]), U.dev(d[f"{tag}_w0"]),
+                   U.dev(d[f"{tag}_ts0"], torch.int32), None, None, gfeat, gdec, sigma=d["sdf_scale"],
+                   weight_e=d[f"{tag}_weight_e"], eik_eps=d[f"{tag}_eps"])
+    g_both = gfeat.clone(); gfeat.zero_()
+    ops.train_step(st, fs, buf, U.dev(d[f"{tag}_coord0"]), U.dev(d[f"{tag}_label0"]), U.dev(d[f"{tag}_w0"]),
+                   U.dev(d[f"{tag}_ts0"], torch.int32), None, None, gfeat, None, sigma=d["sdf_scale"],
+                   weight_e=d[f"{tag}_weight_e"], eik_eps=d[f"{tag}_eps"])
+    torch.testing.assert_close(gfeat, g_both, rtol=1e-5, atol=1e-9)
+
+
+def test_analytic_eikonal_unsupported_shapes_raise():
+    """The analytic term is built for the shipped use (run_livox.yaml: per-neighbour decoding, decoder 1x64); the other
+    shapes fail loudly, in Python and at the C ABI."""
+    from pin_slam_amd import ops
+    with pytest.raises(NotImplementedError):
+        ops.TrainBuffers(512, 1, 8, 64, 1, eikonal="analytic", weighted_first=True)
+    with pytest.raises(NotImplementedError):
+        ops.TrainBuffers(512, 1, 8, 64, 2, eikonal="analytic", weighted_first=False)
+
+
 def test_sharded_train_step_sums_to_full_batch(gold):
     """Two contiguous shards of the batch (as two ranks would run them), normalised by the
     global counts, accumulate to the reference's whole-batch gradient."""
