@@ -204,6 +204,8 @@ typedef struct pin_train_params {
                               * autograd gradient of EVERY main sample (mapper.py:642-643, 677-678, 760-782) and its second
                               * derivative; n_eik = 0 (no probes), inv_n_eik = 1 / GLOBAL batch size, the workspace sized
                               * for 2 * n_main queries.  Built for weighted_first = 0 with a one-layer decoder. */
+    int32_t dec_image_current;/* pin_field.dec_image holds THIS decoder's current parameters (staged by pin_stage_decoder
+                              * and kept current by pin_adam_dense.image): skip the staging launch */
 } pin_train_params;
 
 /* ---- map maintenance (NeuralPoints.update / reset_local_map / assign_local_to_global,
@@ -284,6 +286,7 @@ typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapp
     int32_t loss_weight_on;  /* config.loss_weight_on */
     float surface_range;     /* surface_sample_range_m: samples with |sdf_label| below it carry colour */
     float weight_i;          /* config.weight_i */
+    int32_t dec_image_current;/* as in pin_train_params, for the colour field's dec_image */
 } pin_train_color_params;
 
 /* ---- library ------------------------------------------------------------------- */
@@ -535,10 +538,14 @@ int pin_adam_step_rows(float* param, float* grad, float* exp_avg, float* exp_avg
  * call of one optimiser lifetime must carry a different `step`).  pin_adam_lazy_flush (end of Mapper.mapping)
  * settles every touched row up to t_final.
  * A dense tensor (the decoder) can ride along: prepare(t) applies its step t-1, flush its step t_final
- * (= pin_adam_step with the table's coefficients and zero_grad). */
+ * (= pin_adam_step with the table's coefficients and zero_grad).  With `image` (a decoder image of pin_stage_decoder for
+ * this decoder: hidden x levels, out_dim heads) every updated parameter is written through to its image entries, so the
+ * image stays current and pin_train_step (pin_train_params.dec_image_current) needs no staging launch per iteration. */
 typedef struct pin_adam_dense {
     float* param; float* grad; float* exp_avg; float* exp_avg_sq;
     int64_t n;
+    void* image;                       /* or NULL */
+    int32_t hidden, levels, out_dim;   /* decoder shape of `image` */
 } pin_adam_dense;
 int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
                           float* exp_avg_sq, int32_t* pending, int32_t step, const float* coef, int32_t t_max,

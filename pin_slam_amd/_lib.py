@@ -50,7 +50,8 @@ class Field(C.Structure):
 
 
 class AdamDense(C.Structure):
-    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", C.c_int64)]
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", C.c_int64), ("image", vp),
+                ("hidden", C.c_int32), ("levels", C.c_int32), ("out_dim", C.c_int32)]
 
 
 class ColorTerm(C.Structure):
@@ -115,12 +116,13 @@ class TrainParams(C.Structure):
         ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
         ("sigma", C.c_float), ("weight_e", C.c_float), ("eik_eps", C.c_float),
         ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float), ("eik_analytic", C.c_int32),
+        ("dec_image_current", C.c_int32),
     ]
 
 
 class TrainColorParams(C.Structure):
     _fields_ = [("n_main", C.c_int32), ("loss_weight_on", C.c_int32), ("surface_range", C.c_float),
-                ("weight_i", C.c_float)]
+                ("weight_i", C.c_float), ("dec_image_current", C.c_int32)]
 
 
 class PoolArrays(C.Structure):

@@ -165,6 +165,46 @@ struct QuadDecoderH {
         for (int e = tid; e < OD; e += nthreads) O[MF_OD_MAX * H + e] = P[OD * H + e];
     }
 
+    // The image entries of ONE parameter (flat state_dict index e, new value x): what stage() writes for it, parameter-major.
+    // The optimiser's decoder step calls this for every parameter it updates (train.hip: pin_adam_dense.image), so an image
+    // staged once stays current without a staging launch per training iteration.  Padding entries never change.
+    __device__ __forceinline__ static void stage_param(int e, float x, int L, int OD, unsigned char* __restrict__ w) {
+        unsigned int ph, pl;
+        h2_split2(x, 0.f, ph, pl);
+        const unsigned short hi = (unsigned short)(ph & 0xffffu), lo = (unsigned short)(pl & 0xffffu);
+        auto put = [&](unsigned char* at, int piece_stride) {
+            *reinterpret_cast<unsigned short*>(at) = hi;
+            *reinterpret_cast<unsigned short*>(at + piece_stride) = lo;
+        };
+        if (e < H * MLP_IN) {  // W0[r][c]: forward image lane (r % 16, c / 4) of tile r / 16, transposed image lane (c, g(r))
+            const int r = e / MLP_IN, c = e % MLP_IN;
+            put(w + off_l0f(L) + ((r >> 4) * 64 + (r & 15) + 16 * (c >> 2)) * 8 + 2 * (c & 3), MT * 64 * 8);
+            const int t = r >> 4;
+            put(w + off_l0b(L) + ((t >> 1) * 64 + c + 16 * ((r >> 2) & 3)) * 16 + 2 * (4 * (t & 1) + (r & 3)), NJ * 64 * 16);
+            return;
+        }
+        e -= H * MLP_IN;
+        if (e < H) { reinterpret_cast<float*>(w + off_bias(L))[e] = x; return; }
+        e -= H;
+        for (int l1 = 0; l1 < L - 1; ++l1) {
+            if (e < H * H) {  // hidden W[r][c]: forward image (row r, k slot of unit c), transposed image (row c, k slot of unit r)
+                const int r = e / H, c = e % H;
+                const int tc = c >> 4, tr = r >> 4;
+                const int sf = (((r >> 4) * NJ) + (tc >> 1)) * 64 + (r & 15) + 16 * ((c >> 2) & 3);
+                put(w + off_hidf(L, l1 + 1) + sf * 16 + 2 * (4 * (tc & 1) + (c & 3)), HID_PIECE);
+                const int sb = (((c >> 4) * NJ) + (tr >> 1)) * 64 + (c & 15) + 16 * ((r >> 2) & 3);
+                put(w + off_hidb(L, l1 + 1) + sb * 16 + 2 * (4 * (tr & 1) + (r & 3)), HID_PIECE);
+                return;
+            }
+            e -= H * H;
+            if (e < H) { reinterpret_cast<float*>(w + off_bias(L))[H * (l1 + 1) + e] = x; return; }
+            e -= H;
+        }
+        float* O = reinterpret_cast<float*>(w + off_out(L));
+        if (e < OD * H) O[e] = x;
+        else if (e < OD * H + OD) O[MF_OD_MAX * H + (e - OD * H)] = x;
+    }
+
     // ------------------------------------------------------------------------------ building blocks
     // ReLU pattern words of a layer's post-ReLU activations, in the word order of split_acts
     __device__ __forceinline__ static void pattern_of(const v4f_t (&h)[MT], v4u_t (&sg)[NJ]) {

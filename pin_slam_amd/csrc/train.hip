@@ -677,6 +677,14 @@ __device__ __forceinline__ void lazy_settle(float& pi, float& mi, float& vi, flo
     for (int s = a + 1; s <= upto; ++s) adam_elem(pi, mi, vi, 0.f, coef[s], coef[t_max + 1 + s], b1, b2, eps);
 }
 
+// the decoder image (mlp_h2.h) follows the decoder's step: parameter e just became x
+__device__ __forceinline__ void dense_image_entry(const pin_adam_dense& d, int e, float x) {
+    if (d.image == nullptr) return;
+    unsigned char* w = reinterpret_cast<unsigned char*>(d.image);
+    if (d.hidden == 64) QuadDecoderH<64>::stage_param(e, x, d.levels, d.out_dim, w);
+    else QuadDecoderH<32>::stage_param(e, x, d.levels, d.out_dim, w);
+}
+
 __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __restrict__ nbr, long n_records,
                                                                 float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
             adam_elem(pi, mi, vi, dense.grad[e], coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
             dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
             dense.grad[e] = 0.f;
+            dense_image_entry(dense, (int)e, pi);
         }
         return;
     }
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict_
             adam_elem(pi, mi, vi, dense.grad[e], coef[t_final], coef[t_max + 1 + t_final], b1, b2, eps);
             dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
             dense.grad[e] = 0.f;
+            dense_image_entry(dense, (int)e, pi);
         }
         return;
     }
@@ -851,9 +861,12 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + OD * H + OD;
     float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
-    unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
+    const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, ws.n_tiles);
-    hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
+    if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
+        image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+    else
+        hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
     hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                        sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
                        n_dec, loss_partial, fcol);
@@ -913,9 +926,12 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     const int n_dec = H * MLP_IN + H + H + 1;
     float* dw_partial = reinterpret_cast<float*>(ws.d + (AN ? 2 : 1) * per_stream);
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
-    unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
+    const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, cdiv(n_groups, TF_BLOCK / 64));
-    hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, image);
+    if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
+        image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+    else
+        hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
     hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                        sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
                        dw_partial, n_dec, loss_partial);
@@ -1049,6 +1065,7 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
         pin_train_params sp;
         memset(&sp, 0, sizeof(sp));
         sp.n_main = Q;  // plain tiles of 16 samples, no probes
+        sp.dec_image_current = tp->dec_image_current;
         FusedColor fcol;
         fcol.color = color_label; fcol.count = count; fcol.surface_range = tp->surface_range; fcol.weight_i = tp->weight_i;
         fcol.loss_weight_on = tp->loss_weight_on;
@@ -1130,6 +1147,12 @@ static int lazy_dense(const pin_adam_dense* dense, const float* coef, pin_adam_d
     memset(&d, 0, sizeof(d));
     if (dense != nullptr && dense->n > 0) {
         PIN_CHECK_ARG(dense->param && dense->grad && dense->exp_avg && dense->exp_avg_sq && coef, "dense tensor: NULL pointer");
+        if (dense->image != nullptr) {
+            const int H = dense->hidden, L = dense->levels, OD = dense->out_dim;
+            PIN_CHECK_ARG((H == 32 || H == 64) && L >= 1 && L <= MLP_MAX_LEVELS && (OD == 1 || OD == 3) &&
+                              dense->n == (int64_t)H * MLP_IN + H + (int64_t)(L - 1) * (H * H + H) + OD * H + OD,
+                          "dense tensor: the image's decoder shape does not match the parameter count");
+        }
         d = *dense;
     }
     return 0;

@@ -224,21 +224,21 @@ class MapTrainer:
         # lazy exact Adam: ONE launch per iteration, before the forward pass -- the rows this iteration reads settle the
         # step they still owe from the iteration that last read them (+ the gradient-free steps since), and the decoder's
         # step of the previous iteration rides along in the same launch
-        dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
+        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], lazy) if self.train_decoder else None
         pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
-                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready)
+                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
-            cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
+            cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
             if lazy:
                 self.lazy_c.prepare(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
             ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                  self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
-                                 weight_i=self.c_weight, loss_weight_on=self.loss_weight_on)
+                                 weight_i=self.c_weight, loss_weight_on=self.loss_weight_on, image_current=lazy)
             if not lazy:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
@@ -264,6 +264,24 @@ class MapTrainer:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
 
+    @staticmethod
+    def _dense(fs: ops.FieldState, grad, m, v, lazy: bool):
+        """The decoder as the dense rider of the lazy optimiser, with its staged image when there is one."""
+        if lazy and fs.dec_image is not None:
+            return (fs.dec, grad, m, v, fs.dec_image, fs.hidden, fs.levels, fs.out_dim)
+        return (fs.dec, grad, m, v)
+
+    def _stage_images(self):
+        """One staging launch per Mapper.mapping call and decoder: from then on the lazy optimiser writes every parameter it
+        updates through to the image (pin_adam_dense.image) and the training launches skip their staging kernel."""
+        for name, fs in (("_img", self.fs), ("_img_c", self.fc)):
+            if fs is None:
+                continue
+            if fs.dec_image is None:
+                fs.dec_image = getattr(self, name, None)  # (a FieldState is rebuilt every frame: keep the buffer)
+            fs.stage_decoder()
+            setattr(self, name, fs.dec_image)
+
     def reset_optimizer(self, iters: Optional[int] = None):
         """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615).  With the iteration count
         known (and one GPU) the feature tables use the lazy exact Adam: call finish_optimizer() after the last
@@ -275,6 +293,7 @@ class MapTrainer:
             self.m[:nd].zero_()
             self.v[:nd].zero_()
             self.lazy.reset(self.fs.feats.shape[0], iters, dev)
+            self._stage_images()
         else:
             self.m.zero_()
             self.v.zero_()
@@ -300,11 +319,11 @@ class MapTrainer:
         if not self.lazy_on:
             return
         nd = self.gdec.numel()
-        dense = (self.fs.dec, self.gdec, self.m[:nd], self.v[:nd]) if self.train_decoder else None
+        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], True) if self.train_decoder else None
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
-            cdense = (self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd]) if self.c_train_dec else None
+            cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], True) if self.c_train_dec else None
             self.lazy_c.flush(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], dense=cdense)
         self._grad_clean = self.train_decoder  # (a frozen decoder's gradient slot is never written either, but keep it simple)
         self.lazy_on = False

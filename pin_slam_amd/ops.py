@@ -414,10 +414,12 @@ class TrainBuffers:
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
                global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None,
-               queries_ready=False):
+               queries_ready=False, image_current=False):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
-    `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up)."""
+    `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up).
+    image_current: fs.dec_image holds the decoder's current parameters (LazyAdam keeps it so when it is handed the
+    image) -- the launch sequence then has no staging kernel."""
     L = _lib.lib()
     s = _stream()
     if not queries_ready:  # (pin_gather_batch_drawn can write them in its own launch)
@@ -433,6 +435,7 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     tp.inv_n_main = 1.0 / float(global_n_main or buf.n_main)
     tp.inv_n_eik = 1.0 / float(global_n_eik or max(buf.n_eik, 1))
     tp.eik_analytic = int(buf.analytic)
+    tp.dec_image_current = int(bool(image_current) and fs.dec_image is not None)
     if buf.analytic:  # mean over every sample of the (global) batch, mapper.py:778-781
         tp.inv_n_eik = tp.inv_n_main
     f = fs.params()
@@ -444,7 +447,7 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
 
 
 def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
-                     surface_range, weight_i=1.0, loss_weight_on=False):
+                     surface_range, weight_i=1.0, loss_weight_on=False, image_current=False):
     """Colour term of a training iteration; call after train_step (reuses its queries / kNN)."""
     if buf.color_ws is None:
         nbytes = _lib.lib().pin_train_workspace_bytes(buf.n_main, fc.hidden, fc.levels, 1 if fc.weighted_first else fc.k) + 256
@@ -453,6 +456,7 @@ def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, 
     tp = _lib.TrainColorParams()
     tp.n_main, tp.loss_weight_on = buf.n_main, int(bool(loss_weight_on))
     tp.surface_range, tp.weight_i = float(surface_range), float(weight_i)
+    tp.dec_image_current = int(bool(image_current) and fc.dec_image is not None)
     f = fc.params()
     check(_lib.lib().pin_train_color_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
                                           _ptr(sdf_label, torch.float32), _ptr(color_label, torch.float32),
@@ -527,13 +531,17 @@ class LazyAdam:
         if dense is None:
             return None
         d = _lib.AdamDense()
-        d.param, d.grad, d.exp_avg, d.exp_avg_sq = (_ptr(t, torch.float32) for t in dense)
+        d.param, d.grad, d.exp_avg, d.exp_avg_sq = (_ptr(t, torch.float32) for t in dense[:4])
         d.n = dense[0].numel()
+        if len(dense) > 4 and dense[4] is not None:  # (image, hidden, levels, out_dim): the staged decoder follows the step
+            d.image, d.hidden, d.levels, d.out_dim = dense[4].data_ptr(), int(dense[5]), int(dense[6]), int(dense[7])
         return d
 
     def prepare(self, nbr, param, grad, m, v, step, dense=None):
-        """`dense` = (param, grad, exp_avg, exp_avg_sq) of a dense tensor (the decoder): its step `step - 1` rides along
-        in the same launch (identical to adam_step(..., step - 1, lr) with zero_grad); nothing at step 1."""
+        """`dense` = (param, grad, exp_avg, exp_avg_sq[, image, hidden, levels, out_dim]) of a dense tensor (the decoder):
+        its step `step - 1` rides along in the same launch (identical to adam_step(..., step - 1, lr) with zero_grad);
+        nothing at step 1.  With the decoder's staged image (FieldState.stage_decoder) every updated parameter is written
+        through to it."""
         if step > self.t_max:
             raise ValueError("more iterations than reset() was sized for")
         if step <= self.t:

@@ -491,6 +491,47 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
     assert 0.05 < float(touched.float().mean()) and not torch.equal(pd, p0)
 
 
+@pytest.mark.parametrize("H,L,OD", [(64, 4, 1), (64, 1, 1), (32, 2, 1), (64, 1, 3), (32, 3, 3)])
+def test_decoder_image_follows_the_optimiser(H, L, OD):
+    """pin_adam_dense.image: the lazy optimiser writes every decoder parameter it updates through to the staged image
+    (parameter-major restatement of the staging layout), in the prepare launches and in the flush -- the image stays
+    bit-identical to a fresh pin_stage_decoder of the updated decoder, so the training launches need no staging kernel."""
+    from pin_slam_amd import ops
+    torch.manual_seed(H + L + OD)
+    n = H * 11 + H + (L - 1) * (H * H + H) + OD * H + OD
+    dec = torch.randn(n, device="cuda") * 0.3
+    feats = torch.randn(101, 8, device="cuda")
+    from pin_slam_amd import _lib
+    nbytes = int(_lib.lib().pin_decoder_image_bytes(H, L))
+    assert nbytes > 0
+    # (zero-filled buffers: the image has padding bytes that staging never writes)
+    fs = ops.FieldState(feats=feats, dec=dec, k=8, hidden=H, levels=L, weighted_first=True, sdf_scale=0.05, out_dim=OD,
+                        dec_image=torch.zeros(nbytes, dtype=torch.uint8, device="cuda"))
+    fs.stage_decoder()
+    img = fs.dec_image
+    g, m, v = torch.zeros_like(dec), torch.zeros_like(dec), torch.zeros_like(dec)
+    gf, mf, vf = torch.zeros_like(feats), torch.zeros_like(feats), torch.zeros_like(feats)
+    lazy = ops.LazyAdam(0.01, eps=1e-15)
+    lazy.reset(feats.shape[0], 5, "cuda")
+    nbr = torch.zeros((16, 8, 4), dtype=torch.float32, device="cuda")
+    nbr.view(torch.int32)[..., 3] = torch.randint(0, 100, (16, 8), device="cuda", dtype=torch.int32)
+    dense = (dec, g, m, v, img, H, L, OD)
+
+    def fresh():
+        f2 = ops.FieldState(feats=feats, dec=dec, k=8, hidden=H, levels=L, weighted_first=True, sdf_scale=0.05, out_dim=OD,
+                            dec_image=torch.zeros(nbytes, dtype=torch.uint8, device="cuda"))
+        f2.stage_decoder()
+        return f2.dec_image
+
+    for step in range(1, 5):
+        lazy.prepare(nbr, feats, gf, mf, vf, step, dense=dense)
+        assert torch.equal(img, fresh()), step
+        g.copy_(torch.randn(n, device="cuda") * (10.0 ** -step))
+    before = dec.clone()
+    lazy.flush(feats, gf, mf, vf, dense=dense)
+    assert not torch.equal(before, dec) and torch.equal(img, fresh())
+
+
 def test_staged_decoder_image_changes_no_bit():
     """pin_stage_decoder + pin_field.dec_image (the GN tile kernel copies the staged image instead of splitting the
     decoder in every block): SDF and gradient of every point are bit-identical with and without it, and a restaged
