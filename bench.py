@@ -264,12 +264,14 @@ def main():
     state = {"fid": 1, "cloud": None, "src": None}
 
     stage_events = []  # per timed frame: 5 events at the stage boundaries (no host sync between the stages)
+    host_marks = []    # per timed frame: host clock at the same boundaries (how long the host takes to ENQUEUE a stage)
 
     def frame(timed, hooks=(None, None), source_downsampled=False):
         fid = state["fid"]
         state["fid"] += 1
         ds.processed_frame = fid
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        hm = [time.perf_counter()]
         if ev: ev[0].record()
         if args.stages == "all" or state["cloud"] is None:
             _ = prep(raw, raw_ts, last_odom_tran=last_odom, frame_id=fid)
@@ -279,6 +281,7 @@ def main():
             state["rgb"], state["src_rgb"] = (pc[:, 3:6].contiguous(), _[3]) if colour else (None, None)
         pc = state["cloud"]
         reg = state["src"] if source_downsampled else state["xyz"]
+        hm.append(time.perf_counter())
         if ev: ev[1].record()
         gn = trk._engine(reg.shape[0], gp, cfg.reg_lm_lambda)
         gn.on_knn, gn.on_gn = hooks
@@ -286,14 +289,18 @@ def main():
         ct, _keep = trk._color_term(state["src_rgb"] if source_downsampled else state["rgb"]) if colour else (None, None)
         T, cnt, res_cm, its, _, _ = gn.track(reg, T_init, args.reg_iters, early_exit=False, color=ct)
         gn.on_knn = gn.on_gn = None
+        hm.append(time.perf_counter())
         if ev: ev[2].record()
         if args.stages == "all":
             mp.process_frame(pc, None, pose_t, fid)
+        hm.append(time.perf_counter())
         if ev: ev[3].record()
         mp.mapping(args.map_iters)
+        hm.append(time.perf_counter())
         if ev:
             ev[4].record()
             stage_events.append(ev)
+            host_marks.append(hm)
         stats["last"] = (T, cnt, res_cm, its, reg.shape[0], gn)
 
     for i in range(args.warmup):
@@ -308,6 +315,7 @@ def main():
     nn_mean = float(gn.nn[:n_reg].float().mean().item())
     names = ("preprocess", "odometry", "map_prep", "mapping")
     stage_ms = {n: round(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in stage_events])), 3) for i, n in enumerate(names)}
+    host_ms = {n: round(1e3 * float(np.mean([h[i + 1] - h[i] for h in host_marks])), 3) for i, n in enumerate(names)}
     pool_now, new_now, n_src = mp.pool_sample_count, (0 if mp.new_idx is None else int(mp.new_idx.shape[0])), int(state["src"].shape[0])
 
     # the reference's own odometry workload: register the source-down-sampled subset (reported, not `value`)
@@ -399,6 +407,7 @@ def main():
                                   f"{world} independent replicas (one frame stream per GPU, no data-path collective; "
                                   f"the default --parallel dp measures the data-parallel mapper instead)"},
         "stage_ms_per_frame": stage_ms,
+        "host_enqueue_ms_per_frame": host_ms,
         "mapper_samples_per_sec": round(world * args.bs * args.map_iters / (1e-3 * stage_ms["mapping"]), 1),
         "frames_per_sec_source_downsampled": None if elapsed_ds is None else round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,

@@ -421,6 +421,18 @@ int pin_gather_batch_drawn(const float* pool_coord, const float* pool_label, con
                            float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
                            int32_t n_eik, int32_t decimation, int32_t first, float eps, void* stream);
 
+/* The same for n_batches batches in ONE launch (the iterations of a Mapper.mapping call: their index draws do not depend
+ * on the training): batch b reads index_history + b * hist_stride and index_new_batch + b * new_stride and writes rows
+ * [b * n, (b + 1) * n) of the outputs, queries [b * (n + 6 n_eik), ...).  One kNN launch over all the queries can follow:
+ * the neural point positions do not change while the map trains. */
+int pin_gather_batches_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                             const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
+                             const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                             const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
+                             float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
+                             int32_t n_eik, int32_t decimation, int32_t first, float eps, int32_t n_batches,
+                             int64_t hist_stride, int64_t new_stride, void* stream);
+
 /* K6a: query points of one training iteration: the batch itself followed by the six
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
  * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with

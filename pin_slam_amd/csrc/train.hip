@@ -96,9 +96,17 @@ __global__ void gather_batch_drawn_kernel(const float* __restrict__ pc, const fl
                                           const long long* __restrict__ new_idx, int n, float* __restrict__ coord,
                                           float* __restrict__ label, float* __restrict__ weight, int* __restrict__ ts,
                                           float* __restrict__ color, float* __restrict__ q, int n_eik, int dec, int first,
-                                          float eps) {
+                                          float eps, long hist_stride, long new_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    {   // blockIdx.y = which of the batches of one launch (pin_gather_batches_drawn: the iterations of a mapping call)
+        const size_t b = blockIdx.y;
+        index_hist += b * hist_stride;
+        if (index_new_batch != nullptr) index_new_batch += b * new_stride;
+        coord += b * 3 * (size_t)n; label += b * (size_t)n; weight += b * (size_t)n; ts += b * (size_t)n;
+        if (color != nullptr) color += b * (size_t)n * cw;
+        if (q != nullptr) q += b * 3 * ((size_t)n + 6 * (size_t)n_eik);
+    }
     const size_t s = (size_t)(i < n_hist ? index_hist[i] : new_idx[index_new_batch[i - n_hist]]);
     const float x = pc[3 * s], y = pc[3 * s + 1], z = pc[3 * s + 2];
     coord[3 * i] = x; coord[3 * i + 1] = y; coord[3 * i + 2] = z;
@@ -791,6 +799,31 @@ extern "C" int pin_gather_batch(const float* pool_coord, const float* pool_label
     return 0;
 }
 
+static int gather_batches(const float* pool_coord, const float* pool_label, const float* pool_weight, const int32_t* pool_ts,
+                          const float* pool_color, int32_t color_channels, const int64_t* index_history, int32_t n_history,
+                          const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
+                          float* weight_out, int32_t* ts_out, float* color_out, float* query_out, int32_t n_eik,
+                          int32_t decimation, int32_t first, float eps, int32_t n_batches, int64_t hist_stride,
+                          int64_t new_stride, void* stream) {
+    PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && color_channels >= 0 && n_batches >= 0 && n_batches <= 65535, "bad sizes");
+    if (n == 0 || n_batches == 0) return 0;
+    PIN_CHECK_ARG(pool_coord && pool_label && pool_weight && pool_ts && coord_out && label_out && weight_out && ts_out, "NULL pointer");
+    PIN_CHECK_ARG(n_history == 0 || index_history, "index_history NULL");
+    PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
+    PIN_CHECK_ARG(color_channels == 0 || (pool_color && color_out), "colour pool / output NULL");
+    PIN_CHECK_ARG(n_batches == 1 || (hist_stride >= n_history && new_stride >= n - n_history), "index strides shorter than a batch");
+    PIN_CHECK_ARG(query_out == nullptr || (n_eik >= 0 && decimation >= 1 && first >= 0 &&
+                                           (n_eik == 0 || first + (long)(n_eik - 1) * decimation < n)),
+                  "query_out: n_eik / first too large for decimation");
+    hipLaunchKernelGGL(gather_batch_drawn_kernel, dim3(cdiv(n, 256), n_batches), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
+                       pool_weight, pool_ts, pool_color, color_channels, reinterpret_cast<const long long*>(index_history),
+                       n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
+                       n, coord_out, label_out, weight_out, ts_out, color_out, query_out, n_eik, decimation < 1 ? 1 : decimation,
+                       first, eps, (long)hist_stride, (long)new_stride);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_gather_batch_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
                                       const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
                                       const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
@@ -798,22 +831,22 @@ extern "C" int pin_gather_batch_drawn(const float* pool_coord, const float* pool
                                       float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
                                       int32_t n_eik, int32_t decimation, int32_t first, float eps, void* stream) {
     PIN_ENTER();
-    PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && color_channels >= 0, "bad sizes");
-    if (n == 0) return 0;
-    PIN_CHECK_ARG(pool_coord && pool_label && pool_weight && pool_ts && coord_out && label_out && weight_out && ts_out, "NULL pointer");
-    PIN_CHECK_ARG(n_history == 0 || index_history, "index_history NULL");
-    PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
-    PIN_CHECK_ARG(color_channels == 0 || (pool_color && color_out), "colour pool / output NULL");
-    PIN_CHECK_ARG(query_out == nullptr || (n_eik >= 0 && decimation >= 1 && first >= 0 &&
-                                           (n_eik == 0 || first + (long)(n_eik - 1) * decimation < n)),
-                  "query_out: n_eik / first too large for decimation");
-    hipLaunchKernelGGL(gather_batch_drawn_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pool_coord, pool_label,
-                       pool_weight, pool_ts, pool_color, color_channels, reinterpret_cast<const long long*>(index_history),
-                       n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
-                       n, coord_out, label_out, weight_out, ts_out, color_out, query_out, n_eik, decimation < 1 ? 1 : decimation,
-                       first, eps);
-    PIN_CHECK_LAUNCH();
-    return 0;
+    return gather_batches(pool_coord, pool_label, pool_weight, pool_ts, pool_color, color_channels, index_history, n_history,
+                          index_new_batch, new_idx, n, coord_out, label_out, weight_out, ts_out, color_out, query_out, n_eik,
+                          decimation, first, eps, 1, 0, 0, stream);
+}
+
+extern "C" int pin_gather_batches_drawn(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                                        const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
+                                        const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                                        const int64_t* new_idx, int32_t n, float* coord_out, float* label_out,
+                                        float* weight_out, int32_t* ts_out, float* color_out, float* query_out,
+                                        int32_t n_eik, int32_t decimation, int32_t first, float eps, int32_t n_batches,
+                                        int64_t hist_stride, int64_t new_stride, void* stream) {
+    PIN_ENTER();
+    return gather_batches(pool_coord, pool_label, pool_weight, pool_ts, pool_color, color_channels, index_history, n_history,
+                          index_new_batch, new_idx, n, coord_out, label_out, weight_out, ts_out, color_out, query_out, n_eik,
+                          decimation, first, eps, n_batches, hist_stride, new_stride, stream);
 }
 
 extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,

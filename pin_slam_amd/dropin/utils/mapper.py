@@ -308,6 +308,30 @@ class Mapper(_Base):
             ops._stream()), "pin_gather_batch_drawn")
         return out[0], out[1], out[3], None, None, color, out[2]
 
+    def _gather_group(self, t, it0, gn, global_coord):
+        """get_batch for iterations it0 .. it0 + gn - 1 in ONE launch (pin_gather_batches_drawn): the drawn index rows of
+        _draw_all, outputs [gn][bs][...] and the training queries of every iteration into t.buf.query_all."""
+        c, p, drawn, buf = self.config, self._pool(), self._drawn, t.buf
+        hist, new = drawn["hist"], drawn["new"]
+        nb, n_hist = c.bs, hist.shape[1]
+        key = (buf.group, nb, p.C)
+        if getattr(self, "_group_key", None) != key:
+            dev, G = self.device, buf.group
+            self._group_out = (torch.empty((G, nb, 3), dtype=torch.float32, device=dev), torch.empty((G, nb), dtype=torch.float32, device=dev),
+                               torch.empty((G, nb), dtype=torch.float32, device=dev), torch.empty((G, nb), dtype=torch.int32, device=dev),
+                               torch.empty((G, nb, p.C), dtype=torch.float32, device=dev) if p.C else None)
+            self._group_key = key
+        coord, label, weight, ts, color = self._group_out
+        b = p.bufs[0]
+        _lib.check(_lib.lib().pin_gather_batches_drawn(
+            (b["global_coord"] if global_coord else b["coord"]).data_ptr(), b["sdf_label"].data_ptr(), b["weight"].data_ptr(),
+            b["ts"].data_ptr(), b["color"].data_ptr() if p.C else None, p.C, hist.data_ptr() + 8 * it0 * n_hist, n_hist,
+            None if new is None else new.data_ptr() + 8 * it0 * new.shape[1], None if new is None else self.new_idx.data_ptr(),
+            nb, coord.data_ptr(), label.data_ptr(), weight.data_ptr(), ts.data_ptr(), None if color is None else color.data_ptr(),
+            buf.query_all.data_ptr(), buf.n_eik, buf.dec, buf.eik_first, float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
+            gn, n_hist, 0 if new is None else new.shape[1], ops._stream()), "pin_gather_batches_drawn")
+        return coord, label, weight, ts, color
+
     def _draw_all(self, iters):
         """The batch indices of `iters` get_batch calls in two torch.randint launches instead of 2 x iters (the
         reference draws per iteration, mapper.py:462-480; the draws are iid uniform either way)."""
@@ -381,8 +405,28 @@ class Mapper(_Base):
         self._drawn = self._draw_all(iter_count)
         # the gather launch also writes the iteration's queries (the samples of this rank's shard + their Eikonal probes)
         fused_q = t.buf if t.buf.n_main == self._shard[1] - self._shard[0] else None
+        grouped = fused_q is not None and self.dp_world == 1 and self._drawn is not None
         try:
-            for it in range(iter_count):
+            if grouped:
+                # one GPU: the batches were all drawn above and the neural points do not move while the map trains, so one
+                # gather launch and one kNN launch serve a whole group of iterations (TrainBuffers.group)
+                G = t.buf.group
+                for it0 in range(0, iter_count, G):
+                    gn = min(G, iter_count - it0)
+                    outs = self._gather_group(t, it0, gn, global_coord=not self.ba_done_flag)
+                    t.knn_group(gn)
+                    for j in range(gn):
+                        coord, sdf_label, weight, ts, color_label = (None if o is None else o[j] for o in outs)
+                        if t.fc is not None and color_label is None:
+                            raise RuntimeError("color_on but the data pool holds no colour labels")
+                        t.buf.select(j)
+                        t.step_batch(coord, sdf_label, weight, ts, it0 + j + 1,
+                                     color_label=None if t.fc is None else
+                                     (color_label if color_label.shape[1] == 3 else color_label[:, :3].contiguous()),
+                                     queries_ready=True, knn_ready=True)
+                        self.total_iter += 1
+                t.buf.select(0)
+            for it in range(0 if not grouped else iter_count, iter_count):
                 self._queries_for = fused_q
                 coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
                 self._queries_for = None

@@ -160,8 +160,11 @@ class MapTrainer:
         self.resize(fs)
         from .sharding import n_eik_global, shard_range
         start, _ = shard_range(self.bs, rank, world)
+        # one gather + one kNN launch per GROUP of iterations on one GPU (their inputs do not depend on the training)
+        q_iter = self.bs_local + 6 * (0 if eikonal in (False, "analytic") else (self.bs_local + self.dec - 1) // self.dec)
+        group = max(1, min(16, (1 << 22) // max(q_iter, 1))) if world == 1 else 1
         self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
-                                    shard_start=start, weighted_first=fs.weighted_first)
+                                    shard_start=start, weighted_first=fs.weighted_first, group=group)
         self.coord = torch.empty((self.bs_local, 3), dtype=torch.float32, device=dev)
         self.label = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
@@ -216,9 +219,16 @@ class MapTrainer:
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
         self.step_batch(self.coord, self.label, self.weight, self.ts, step)
 
-    def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False):
+    def knn_group(self, n_iters: int):
+        """Neighbour search of the first `n_iters` iterations' queries of the group buffers in one launch."""
+        n = n_iters * self.buf.Q
+        ops.knn_query(self.st, self.buf.query_all[:n], self.fs.k, out=(self.buf.nbr_all[:n], self.buf.nn_all[:n], None),
+                      bricks=self.bricks)
+
+    def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False,
+                   knn_ready: bool = False):
         """One iteration on an explicit (already gathered) batch shard.  queries_ready: buf.query already holds this
-        batch's queries (written by the gather launch)."""
+        batch's queries (written by the gather launch); knn_ready: buf.nbr / buf.nn hold their neighbours (knn_group)."""
         nd = self.gdec.numel()
         lazy = self.lazy_on
         # lazy exact Adam: ONE launch per iteration, before the forward pass -- the rows this iteration reads settle the
@@ -230,7 +240,8 @@ class MapTrainer:
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
-                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy)
+                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
+                       knn_ready=knn_ready)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None

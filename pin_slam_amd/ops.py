@@ -391,7 +391,7 @@ class TrainBuffers:
     (numerical_grad_on False, run_livox.yaml:27: no probes), False = off."""
 
     def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda",
-                 shard_start: int = 0, weighted_first: bool = True):
+                 shard_start: int = 0, weighted_first: bool = True, group: int = 1):
         from .sharding import eikonal_shard
         self.n_main = int(n_main)
         self.dec = int(decimation)
@@ -401,20 +401,30 @@ class TrainBuffers:
                                       "with a one-layer decoder (config/lidar_slam/run_livox.yaml)")
         self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if (eikonal and not self.analytic) else (0, 0)
         self.Q = self.n_main + 6 * self.n_eik
-        self.query = torch.empty((self.Q, 3), dtype=torch.float32, device=device)
-        self.nbr = torch.empty((self.Q, k, 4), dtype=torch.float32, device=device)
-        self.nn = torch.empty((self.Q,), dtype=torch.int32, device=device)
+        # `group` iterations' worth of queries / kNN records: the batches of a Mapper.mapping call are drawn up front and
+        # the neural point positions do not move while the map trains, so ONE gather launch and ONE kNN launch serve
+        # `group` iterations (select(j) points query / nbr / nn at iteration j of the group)
+        self.group = max(1, int(group))
+        self.query_all = torch.empty((self.group * self.Q, 3), dtype=torch.float32, device=device)
+        self.nbr_all = torch.empty((self.group * self.Q, k, 4), dtype=torch.float32, device=device)
+        self.nn_all = torch.empty((self.group * self.Q,), dtype=torch.int32, device=device)
+        self._views = [(self.query_all[j * self.Q:(j + 1) * self.Q], self.nbr_all[j * self.Q:(j + 1) * self.Q],
+                        self.nn_all[j * self.Q:(j + 1) * self.Q]) for j in range(self.group)]
+        self.select(0)
         # (the analytic term keeps a second operand stream: sized as for twice the queries)
         nbytes = _lib.lib().pin_train_workspace_bytes(self.Q * (2 if self.analytic else 1), hidden, levels, 1 if weighted_first else k)
         self.ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
         self.loss = torch.zeros((2,), dtype=torch.float64, device=device)
         self.color_ws = self.color_loss = None
 
+    def select(self, j: int):
+        self.query, self.nbr, self.nn = self._views[j]
+
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
                global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None,
-               queries_ready=False, image_current=False):
+               queries_ready=False, image_current=False, knn_ready=False):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
     `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up).
@@ -426,7 +436,8 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
         check(L.pin_train_make_queries(_ptr(coord, torch.float32), buf.n_main, buf.n_eik, buf.dec, buf.eik_first,
                                        float(np.float32(eik_eps)),
                                        _ptr(buf.query), s), "pin_train_make_queries")
-    knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None), bricks=bricks)
+    if not knn_ready:  # (a group of iterations can be searched in one launch, TrainBuffers.group)
+        knn_query(st, buf.query, fs.k, out=(buf.nbr, buf.nn, None), bricks=bricks)
     if before_forward is not None:
         before_forward()
     tp = TrainParams()
