@@ -15,8 +15,10 @@ preprocess + odometry + mapping preparation + mapping), on the synthetic workloa
                    samples, query_certainty, new-sample index;
   * mapping      : Mapper.mapping = 12 iterations, batch 16384 (+ 6*1639 Eikonal queries), BCE +
                    Eikonal, backward to features and decoder (one fused tile kernel + a streamed MFMA weight
-                   gradient per iteration), Adam (exact lazy form: only the rows an iteration reads are
-                   visited, bit-identical to the dense step).
+                   gradient per iteration; ONE gather and ONE kNN launch for all twelve iterations -- their
+                   inputs do not depend on the training), Adam (exact lazy form: only the rows an iteration
+                   reads are visited, bit-identical to the dense step; the decoder's step keeps its staged
+                   image current).
 Everything runs through the drop-in classes (pin_slam_amd.dropin) on libpinhip.  Inputs (raw
 scan, timestamps) are resident in HBM before the timed region.
 

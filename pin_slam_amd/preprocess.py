@@ -35,6 +35,11 @@ def _dev_f32(t: torch.Tensor) -> torch.Tensor:
 
 def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
     """Index (int64, ordered by voxel id) of the point closest to its voxel centre, per voxel."""
+    return _voxel_down_sample_i32(points, voxel_size).long()
+
+
+def _voxel_down_sample_i32(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """The same as the int32 tensor the kernel wrote (ScanPreprocessor feeds it straight to the row gather)."""
     L = _lib.lib()
     pts = _dev_f32(points).contiguous()
     n = pts.shape[0]
@@ -43,7 +48,7 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Te
     cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)
     check(L.pin_voxel_downsample(pts.data_ptr(), n, float(np.float32(voxel_size)), sel.data_ptr(), cnt.data_ptr(),
                                  ws.data_ptr(), ws.numel(), ops._stream()), "pin_voxel_downsample")
-    return sel[:int(cnt.item())].long()
+    return sel[:int(cnt.item())]
 
 
 def crop_frame(points: torch.Tensor, ts: Optional[torch.Tensor], min_z_th=-3.0, max_z_th=100.0, min_range=2.75,
@@ -94,7 +99,7 @@ def deskewing(points: torch.Tensor, ts: Optional[torch.Tensor], pose: torch.Tens
 
 def gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """points[idx] for [n, w] float32 rows through pin_gather_rows."""
-    return ops.gather_rows(points, idx.to(torch.int32))
+    return ops.gather_rows(points, idx if idx.dtype == torch.int32 else idx.to(torch.int32))
 
 
 class ScanPreprocessor:
@@ -120,7 +125,7 @@ class ScanPreprocessor:
         if getattr(c, "rand_downsample", False):
             idx = torch.randint(0, scan.shape[0], (int(scan.shape[0] * c.rand_down_r),), device=scan.device)
         else:
-            idx = voxel_down_sample_torch(scan[:, :3], train_vox)
+            idx = _voxel_down_sample_i32(scan[:, :3], train_vox)
         pc = gather(scan, idx)
         ts = None if point_ts is None else point_ts[idx]
         pc, ts = crop_frame(pc, ts, c.min_z, c.max_z, c.min_range, crop_max)
@@ -128,7 +133,7 @@ class ScanPreprocessor:
             pc = intrinsic_correct(pc, c.correction_deg)
         source = source_colors = None
         if frame_id > 0:
-            idx2 = voxel_down_sample_torch(pc[:, :3], source_vox)
+            idx2 = _voxel_down_sample_i32(pc[:, :3], source_vox)
             src = gather(pc, idx2)
             source = src[:, :3].contiguous()
             if c.color_on:

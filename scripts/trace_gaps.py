@@ -20,11 +20,16 @@ for a, b in list(zip(frames[:-1], frames[1:]))[-8:]:
     for k, v in gaps.most_common(8):
         print(f"    gap {v/1e3:8.1f} us  {k[0]} -> {k[1]}")
 
-# one mapping iteration in detail: kernels between two consecutive query builds, late in the run
-q = [i for i, e in enumerate(ev) if "make_queries" in e[2]]
-if len(q) > 4:
-    a, b = q[-3], q[-2]
-    print("one mapping iteration (start offset us, duration us, gap before us):")
+# the mapping stage of the last complete frame in detail: from the gather launch of its first group of iterations to the
+# optimiser's flush (start offset us, duration us, gap before us)
+g = [i for i, e in enumerate(ev) if "gather_batch_drawn" in e[2]]
+f = [i for i, e in enumerate(ev) if "adam_lazy_flush" in e[2]]
+if g and f:
+    b = f[-1]
+    a = max(i for i in g if i < b)
+    while a - 1 in g:
+        a -= 1
+    print("one Mapper.mapping call (start offset us, duration us, gap before us):")
     t0 = ev[a][0]
     for i in range(a, b + 1):
         print(f"    {(ev[i][0]-t0)/1e3:8.1f} {(ev[i][1]-ev[i][0])/1e3:7.1f} {(ev[i][0]-ev[i-1][1])/1e3:7.1f}  {ev[i][2][:70]}")
