@@ -33,3 +33,14 @@ if g and f:
     t0 = ev[a][0]
     for i in range(a, b + 1):
         print(f"    {(ev[i][0]-t0)/1e3:8.1f} {(ev[i][1]-ev[i][0])/1e3:7.1f} {(ev[i][0]-ev[i-1][1])/1e3:7.1f}  {ev[i][2][:70]}")
+
+# every launch of the last complete frame outside the GN loop and the training loop (start offset us, duration us, gap before us)
+if "--frame" in sys.argv and len(frames) >= 2:
+    a, b = frames[-2], frames[-1]
+    t0 = ev[a][0]
+    skip = ("knn_brick", "gn_accumulate", "gn_solve", "train_fused", "train_dw", "train_finalize", "adam_lazy_prepare")
+    print("last frame, launches outside the two hot loops:")
+    for i in range(a, b):
+        if any(k in ev[i][2] for k in skip):
+            continue
+        print(f"    {(ev[i][0]-t0)/1e3:8.1f} {(ev[i][1]-ev[i][0])/1e3:7.1f} {(ev[i][0]-ev[i-1][1])/1e3:7.1f}  {ev[i][2][:90]}")
