@@ -405,7 +405,8 @@ class Mapper(_Base):
         self._drawn = self._draw_all(iter_count)
         # the gather launch also writes the iteration's queries (the samples of this rank's shard + their Eikonal probes)
         fused_q = t.buf if t.buf.n_main == self._shard[1] - self._shard[0] else None
-        grouped = fused_q is not None and self.dp_world == 1 and self._drawn is not None
+        grouped = (fused_q is not None and self.dp_world == 1 and self._drawn is not None
+                   and getattr(self, "group_iterations", True))
         try:
             if grouped:
                 # one GPU: the batches were all drawn above and the neural points do not move while the map trains, so one

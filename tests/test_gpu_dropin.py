@@ -157,6 +157,48 @@ def test_mini_slam_loop_update_map_track():
     assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 0.01
 
 
+def test_grouped_iterations_train_like_single_ones():
+    """Mapper.mapping gathers and searches a group of iterations in one launch each (their inputs do not depend on the
+    training) and stages the decoder once per call; `group_iterations = False` keeps one gather / kNN per iteration.
+    Same seed, same state: the same batches, and the trained features / decoder agree to rounding (atomics order)."""
+    from pin_slam_amd import synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    rng = np.random.default_rng(3)
+    pts, _ = synth.disc_points(rng, 60_000, 20.0, 2)
+    base, _ = synth.disc_points(rng, 200_000, 19.0, 2)
+    nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
+    dd = 0.15 * rng.standard_normal(len(base))
+    results = []
+    for grouped in (True, False):
+        torch.manual_seed(11)
+        cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=2048, local_map_radius=40.0, local_map_travel_dist_ratio=5.0)
+        npts = NeuralPoints(cfg)
+        npts.travel_dist = torch.zeros(1, device="cuda")
+        npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+        dec = Decoder(cfg, 32, 2, 1)
+        mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
+        mp.group_iterations = grouped
+        mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
+        mp.coord_pool = mp.global_coord_pool
+        mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+        mp.weight_pool = torch.ones(len(base), device="cuda")
+        mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+        mp.pool_sample_count = len(base)
+        torch.manual_seed(5)
+        mp.mapping(20)  # more than one group of 16
+        assert mp._trainer.buf.group == 16
+        results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
+    (fa, da, ca), (fb, db, cb) = results
+    assert not torch.equal(fa, torch.zeros_like(fa))
+    # (measured: mean |difference| 1e-8 -- only the order of the float atomics differs; Adam with eps = 1e-15 can turn
+    # the rounding noise of a near-zero gradient into a step of ~lr, hence a bound on the share of such entries too)
+    assert (fa - fb).abs().mean().item() < 1e-5 and ((fa - fb).abs() > 5e-3).float().mean().item() < 1e-3
+    assert (da - db).abs().max().item() < 1e-3
+    torch.testing.assert_close(ca, cb, rtol=1e-4, atol=1e-4)
+
+
 def test_mapper_with_analytic_eikonal_term():
     """run_livox.yaml's training mode through the drop-in Mapper: per-neighbour decoding, 8 neighbours, the Eikonal term
     on the autograd gradient of every sample (numerical_grad False -> gradient_decimation 1).  Training lowers the SDF
