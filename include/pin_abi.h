@@ -499,6 +499,12 @@ int64_t pin_maint_workspace_bytes(int32_t n);
  * by ascending linearised voxel id like torch.unique.  sel_out [<= n], count_out [1]. */
 int pin_voxel_downsample(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
                          int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same selection with a third of the launches: voxel id and tie-breaking value share one 64-bit sort key (the
+ * winner of a voxel is then the first of its run).  The id has 64 - bits(1000 * 10^digits(n - 1)) bits for that: 37 for
+ * a scan of up to 10^5 points, i.e. extents of up to 5 000 voxels per axis.  A point set that needs more is REPORTED --
+ * count_out[0] = -1, sel_out undefined -- and the caller uses pin_voxel_downsample. */
+int pin_voxel_downsample_fast(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
+                              int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Spatial (Morton) order of a point set: out[i] = points[perm[i]], ascending 30-bit Morton code of floor(p / cell)
  * (10 bits per axis, wrapping).  Not a function of the reference: Tracker.tracking (utils/tracker.py:114-184) sums over

@@ -169,6 +169,7 @@ SIGNATURES = {
     "pin_maint_workspace_bytes": (i64, [i32]),
     "pin_spatial_sort": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_voxel_downsample": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
+    "pin_voxel_downsample_fast": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_map_update": (i32, [P(MapArrays), P(UpdateParams), vp, vp, vp, vp, vp, i64, vp]),
     "pin_reset_local_map": (i32, [P(MapArrays), P(LocalArrays), P(LocalParams), vp, vp, vp, i64, vp]),
     "pin_assign_local_to_global": (i32, [P(MapArrays), P(LocalArrays), i32, i32, vp]),

@@ -125,6 +125,112 @@ __global__ __launch_bounds__(MB) void vds_heads_kernel(const unsigned long long*
     flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
+// ---- the same selection in 5 launches + a keys-only sort (pin_voxel_downsample_fast) ---------------------------------
+// A voxel id needs 3 log2(extent / voxel) bits (33 for a 100 m scan at 8 cm) and the tie-breaking value
+// (quantised centre distance, index) fewer than 30: both fit ONE 64-bit word, id in the upper part.  Sorting those words
+// puts the winner of every voxel first in its run, so the segmented minimum (a clearing launch + one atomic per point)
+// and the values array go away, the merge passes of the sort move half the bytes, and the statistics the ids depend on
+// (per-axis minimum, largest voxel coordinate, largest centre distance) come from ONE pass of per-block partials that
+// the key kernel reduces itself: max_i floor(x_i / vs) = floor(max_i x_i / vs), so the largest coordinate follows from
+// the per-axis extremes.  An id that does not fit next to the value is reported (count -1): the caller falls back to
+// pin_voxel_downsample.
+struct VdsPartial { unsigned int mn[3], mx[3], dmax, pad; };
+
+__global__ __launch_bounds__(MB) void vds_fast_stats_kernel(const float* __restrict__ p, int n, float vs,
+                                                            VdsPartial* __restrict__ part, VdsStats* __restrict__ st) {
+#pragma clang fp contract(off)
+    __shared__ unsigned int red[MB / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->nseg = 0;  // (the key kernel stores -1 here if an id does not fit)
+    unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u}, dm = 0u;
+    for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) {
+        float d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = p[3 * i + a];
+            const unsigned int e = enc_f(x);
+            mn[a] = min(mn[a], e); mx[a] = max(mx[a], e);
+            const float gf = floorf(__fdiv_rn(x, vs));
+            d[a] = x - (gf + 0.5f) * vs;
+        }
+        dm = max(dm, __float_as_uint((float)sqrt((double)dist2_exact(d[0], d[1], d[2]))));  // (vds_point's arithmetic)
+    }
+    VdsPartial out;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        out.mn[a] = block_reduce_u32<true>(mn[a], red);
+        out.mx[a] = block_reduce_u32<false>(mx[a], red);
+    }
+    out.dmax = block_reduce_u32<false>(dm, red);
+    out.pad = 0u;
+    if (threadIdx.x == 0) part[blockIdx.x] = out;
+}
+
+__global__ __launch_bounds__(MB) void vds_fast_keys_kernel(const float* __restrict__ p, int n, float vs,
+                                                           const VdsPartial* __restrict__ part, int n_part, long long off10,
+                                                           int val_bits, unsigned long long* __restrict__ comp,
+                                                           VdsStats* __restrict__ st) {
+#pragma clang fp contract(off)
+    __shared__ unsigned int red[MB / 64];
+    __shared__ VdsStats sst;
+    {   // every block reduces the (<= REDUCE_BLOCKS) partials itself: no launch in between, no atomics
+        unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u}, dm = 0u;
+        for (int b = threadIdx.x; b < n_part; b += MB) {
+            const VdsPartial q = part[b];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], q.mn[a]); mx[a] = max(mx[a], q.mx[a]); }
+            dm = max(dm, q.dmax);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = block_reduce_u32<true>(mn[a], red); mx[a] = block_reduce_u32<false>(mx[a], red); }
+        dm = block_reduce_u32<false>(dm, red);
+        if (threadIdx.x == 0) {
+            long long gm = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                gm = max(gm, (long long)floorf(__fdiv_rn(dec_f(mx[a]), vs)) - (long long)floorf(__fdiv_rn(dec_f(mn[a]), vs)));
+            sst.minx = mn[0]; sst.miny = mn[1]; sst.minz = mn[2];
+            sst.gmax = (int)gm; sst.dmax = dm; sst.nseg = 0; sst.nseg_cmax = 0u;
+            if (blockIdx.x == 0) { st->minx = mn[0]; st->miny = mn[1]; st->minz = mn[2]; st->gmax = (int)gm; st->dmax = dm; }
+        }
+        __syncthreads();
+    }
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    long long g[3]; float dist;
+    vds_point(p, i, vs, &sst, g, dist);
+    const long long v = sst.gmax;
+    const unsigned long long key = (unsigned long long)(g[0] + g[1] * v + g[2] * v * v);
+    const float dm = __uint_as_float(sst.dmax);
+    const long long dq = (long long)(__fdiv_rn(dist, dm) * 999.0f);
+    const unsigned long long val = (unsigned long long)((long long)i + dq * off10);
+    if ((key >> (64 - val_bits)) != 0ull || (val >> val_bits) != 0ull) st->nseg = -1;  // does not fit (every writer stores -1)
+    comp[i] = (key << val_bits) | val;
+}
+
+// run heads of the sorted words (same voxel id = same upper part) and their per-block counts, in one launch
+__global__ __launch_bounds__(MB) void vds_fast_heads_kernel(const unsigned long long* __restrict__ comp, int n, int val_bits,
+                                                            unsigned char* __restrict__ flags, int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && (i == 0 || (comp[i] >> val_bits) != (comp[i - 1] >> val_bits));
+    if (i < n) flags[i] = f ? 1 : 0;
+    int total;
+    block_flag_scan(f, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(MB) void vds_fast_emit_kernel(const unsigned long long* __restrict__ comp, int n, int val_bits,
+                                                           const unsigned char* __restrict__ flags,
+                                                           const int* __restrict__ block_off, long long off10,
+                                                           const VdsStats* __restrict__ st, int* __restrict__ sel,
+                                                           int* __restrict__ count) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    const bool f = i < n && flags[i] != 0;
+    const int ex = block_flag_scan(f, total);
+    if (f) sel[block_off[blockIdx.x] + ex] = (int)((long long)(comp[i] & ((1ull << val_bits) - 1ull)) % off10);
+    if (i == 0 && st->nseg < 0) *count = -1;  // (the scan launch wrote the count before this one started)
+}
+
 // segment id of every sorted element = (#heads up to and including it) - 1; min of vals per segment
 __global__ __launch_bounds__(MB) void vds_segmin_kernel(const unsigned char* __restrict__ flags,
                                                         const int* __restrict__ block_off,
@@ -579,6 +685,38 @@ extern "C" int pin_voxel_downsample(const float* points, int32_t n, float voxel_
     PIN_CHECK_HIP(hipMemsetAsync(segmin, 0xff, (size_t)n * 8, s));
     hipLaunchKernelGGL(vds_segmin_kernel, dim3(nb), dim3(MB), 0, s, flags, block_off, vals2, n, segmin);
     hipLaunchKernelGGL(vds_final_kernel, dim3(nb), dim3(MB), 0, s, segmin, count_out, off10, sel_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_voxel_downsample_fast(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
+                                         int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n > 0 && points && sel_out && count_out && workspace, "bad arguments");
+    PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    VdsStats* st = c.take<VdsStats>(1);
+    unsigned long long* comp = c.take<unsigned long long>(n);
+    unsigned long long* comp2 = c.take<unsigned long long>(n);
+    VdsPartial* part = c.take<VdsPartial>(REDUCE_BLOCKS);
+    unsigned char* flags = c.take<unsigned char>(n + 1);
+    const int nb = cdiv(n, MB), rb = min(nb, REDUCE_BLOCKS);
+    int* block_off = c.take<int>(nb + 1);
+    size_t tb = sort_temp_bytes(n);
+    void* temp = c.take<char>(tb);
+    PIN_CHECK_ARG(temp != nullptr, "workspace carve failed");
+    long long off10 = 1;  // 10 ** len(str(n - 1))  (utils/tools.py:610)
+    for (long long v = n - 1; ; v /= 10) { off10 *= 10; if (v < 10) break; }
+    int val_bits = 1;  // values are below 1000 * off10
+    while ((1000ll * off10 - 1) >> val_bits) ++val_bits;
+    hipLaunchKernelGGL(vds_fast_stats_kernel, dim3(rb), dim3(MB), 0, s, points, n, voxel_size, part, st);
+    hipLaunchKernelGGL(vds_fast_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, part, rb, off10, val_bits, comp, st);
+    PIN_CHECK_LAUNCH();
+    PIN_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, comp, comp2, (size_t)n, 0, 64, s));
+    hipLaunchKernelGGL(vds_fast_heads_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, count_out);
+    hipLaunchKernelGGL(vds_fast_emit_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off, off10, st, sel_out, count_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

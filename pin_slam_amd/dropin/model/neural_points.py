@@ -240,8 +240,6 @@ class NeuralPoints(nn.Module):
         ws = self._workspace(max(n, self._n + 1))
         stream = ops._stream()
         sel = torch.empty((n,), dtype=torch.int32, device=self.device)
-        check(L.pin_voxel_downsample(_p(points), n, float(np.float32(self.resolution)), _p(sel), _p(self._cnt[0:1]),
-                                     _p(ws), ws.numel(), stream), "pin_voxel_downsample")
         if self._n + n + 1 > self._cap:  # worst case: every sample is new
             self._alloc(int(max(self._cap * 1.5, self._n + n + 1)))
         up = UpdateParams()
@@ -253,9 +251,16 @@ class NeuralPoints(nn.Module):
         up.dist2_thre = float(np.float32(3 * self.resolution ** 2))
         up.diff_travel_dist_local = float(self.diff_travel_dist_local)
         ma = self._map_arrays()
-        check(L.pin_map_update(C.byref(ma), C.byref(up), _p(points), _p(sel), _p(self._cnt[0:1]), _p(self._cnt[1:2]),
-                               _p(ws), ws.numel(), stream), "pin_map_update")
-        n_sel, n_new = (int(v) for v in self._cnt[:2].tolist())  # the one host sync of update()
+        # the down-sampler with the one-word sort key first; a sample set too wide for it reports n_sel = -1 (nothing was
+        # appended then: every kernel of pin_map_update is bounded by n_sel) and goes through the general form
+        for vds in (L.pin_voxel_downsample_fast, L.pin_voxel_downsample):
+            check(vds(_p(points), n, float(np.float32(self.resolution)), _p(sel), _p(self._cnt[0:1]), _p(ws), ws.numel(), stream),
+                  "pin_voxel_downsample")
+            check(L.pin_map_update(C.byref(ma), C.byref(up), _p(points), _p(sel), _p(self._cnt[0:1]), _p(self._cnt[1:2]),
+                                   _p(ws), ws.numel(), stream), "pin_map_update")
+            n_sel, n_new = (int(v) for v in self._cnt[:2].tolist())  # the one host sync of update()
+            if n_sel >= 0:
+                break
         old = self._n
         self._n = old + n_new
         # feature rows of the new points + the padding row (neural_points.py:395-411)

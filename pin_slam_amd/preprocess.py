@@ -46,9 +46,13 @@ def _voxel_down_sample_i32(points: torch.Tensor, voxel_size: float) -> torch.Ten
     ws = _ws(L.pin_maint_workspace_bytes(n), pts.device)
     sel = torch.empty((n,), dtype=torch.int32, device=pts.device)
     cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)
-    check(L.pin_voxel_downsample(pts.data_ptr(), n, float(np.float32(voxel_size)), sel.data_ptr(), cnt.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), ops._stream()), "pin_voxel_downsample")
-    return sel[:int(cnt.item())]
+    args = (pts.data_ptr(), n, float(np.float32(voxel_size)), sel.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream())
+    check(L.pin_voxel_downsample_fast(*args), "pin_voxel_downsample_fast")
+    c = int(cnt.item())
+    if c < 0:  # voxel ids too wide for the one-word sort key (extent > ~5 000 voxels per axis): the general form
+        check(L.pin_voxel_downsample(*args), "pin_voxel_downsample")
+        c = int(cnt.item())
+    return sel[:c]
 
 
 def crop_frame(points: torch.Tensor, ts: Optional[torch.Tensor], min_z_th=-3.0, max_z_th=100.0, min_range=2.75,

@@ -35,6 +35,40 @@ def test_voxel_downsample_matches_reference():
         assert np.array_equal(sel[:c].cpu().numpy(), d[f"sel{ts}"].astype(np.int32))
 
 
+def test_voxel_downsample_fast_form():
+    """pin_voxel_downsample_fast (voxel id and tie-breaking value in one sort key, statistics from per-block partials):
+    the reference's selection on the fixture frames and on a large random cloud (against the general form); a cloud whose
+    voxel ids do not fit the key is REPORTED (count -1) and the wrapper falls back to the general form."""
+    from pin_slam_amd import _lib, preprocess
+    d = G.load("update")
+    L = _lib.lib()
+
+    def run(fn, pts, vs):
+        n = pts.shape[0]
+        ws = torch.empty(L.pin_maint_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        sel = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(fn(pts.data_ptr(), n, float(np.float32(vs)), sel.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(), None), "vds")
+        c = int(cnt.item())
+        return c, (sel[:c].cpu().numpy() if c >= 0 else None)
+
+    for ts in range(4):
+        pts = torch.from_numpy(d[f"pts{ts}"]).cuda()
+        c, sel = run(L.pin_voxel_downsample_fast, pts, d["resolution"])
+        assert c == len(d[f"sel{ts}"]) and np.array_equal(sel, d[f"sel{ts}"].astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n, vs, spread in ((300_001, 0.08, 60.0), (1_000_000, 0.4, 150.0), (17, 0.5, 3.0), (1, 0.5, 1.0)):
+        pts = ((torch.rand((n, 3), device="cuda", generator=g) - 0.5) * spread).contiguous()
+        pts[n // 2:] = pts[n // 2:] * 0.05  # a dense core: many points per voxel, ties on the quantised distance
+        a, b = run(L.pin_voxel_downsample_fast, pts, vs), run(L.pin_voxel_downsample, pts, vs)
+        assert a[0] == b[0] > 0 and np.array_equal(a[1], b[1]), (n, vs)
+    wide = ((torch.rand((50_000, 3), device="cuda", generator=g) - 0.5) * 4000.0).contiguous()  # 2^17 voxels per axis at 3 cm
+    assert run(L.pin_voxel_downsample_fast, wide, 0.03)[0] == -1
+    ref = run(L.pin_voxel_downsample, wide, 0.03)
+    idx = preprocess._voxel_down_sample_i32(wide, 0.03)
+    assert np.array_equal(idx.cpu().numpy(), ref[1])
+
+
 def test_update_reset_local_map_bit_exact():
     """NeuralPoints.update / reset_local_map over 4 frames: point count, positions, timestamps,
     hash table, local mask and global2local equal the reference's (neural_points.py:311-513)."""
