@@ -206,6 +206,8 @@ typedef struct pin_train_params {
                               * for 2 * n_main queries.  Built for weighted_first = 0 with a one-layer decoder. */
     int32_t dec_image_current;/* pin_field.dec_image holds THIS decoder's current parameters (staged by pin_stage_decoder
                               * and kept current by pin_adam_dense.image): skip the staging launch */
+    int32_t defer_weight_grad;/* pin_train_step stops after the tile kernel (feature gradients done, operand stream in the
+                              * workspace); pin_train_weight_grad finishes the step.  Fused tile paths only. */
 } pin_train_params;
 
 /* ---- map maintenance (NeuralPoints.update / reset_local_map / assign_local_to_global,
@@ -468,6 +470,14 @@ int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* 
                    const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,
                    int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
                    float* pred_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The second half of a pin_train_step called with tp->defer_weight_grad: streamed weight gradient into dec_grad (+=) and
+ * the loss sums into loss_out, from the operand stream the first half left in `workspace` (same f / tp / workspace).  It
+ * touches neither the feature table nor the feature gradients, so a caller may run it on ANOTHER stream beside the
+ * optimiser launch that prepares the feature rows of the next iteration (pin_adam_lazy_prepare); the next
+ * pin_train_step on this workspace, and the decoder's own step, must be ordered behind it. */
+int pin_train_weight_grad(const pin_field* f, const pin_train_params* tp, float* dec_grad, double* loss_out,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Colour term of one training iteration: regress_color on the colour features of the batch
  * (first n_main queries / kNN records of pin_train_step's query set), L1 loss on the surface

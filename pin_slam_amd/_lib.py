@@ -116,7 +116,7 @@ class TrainParams(C.Structure):
         ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
         ("sigma", C.c_float), ("weight_e", C.c_float), ("eik_eps", C.c_float),
         ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float), ("eik_analytic", C.c_int32),
-        ("dec_image_current", C.c_int32),
+        ("dec_image_current", C.c_int32), ("defer_weight_grad", C.c_int32),
     ]
 
 
@@ -181,6 +181,7 @@ SIGNATURES = {
     "pin_train_make_queries": (i32, [vp, i32, i32, i32, i32, f32, vp, vp]),
     "pin_train_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "pin_train_weight_grad": (i32, [P(Field), P(TrainParams), vp, vp, vp, i64, vp]),
     "pin_train_color_step": (i32, [P(Field), P(TrainColorParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),

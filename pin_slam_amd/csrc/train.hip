@@ -869,7 +869,10 @@ template <int H, int L, int OD>
 static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const FusedColor& fcol, const float* query,
                           const float4* nb4, const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
                           const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad,
-                          double* loss_out, float* pred_out, void* workspace, int n_cu, hipStream_t s) {
+                          double* loss_out, float* pred_out, void* workspace, int n_cu, hipStream_t s, int phase = 3) {
+    // phase: bit 0 = the tile kernel (gather .. backward, operand stream out), bit 1 = weight gradient + finalize.  The two
+    // halves take the same arguments; run apart (pin_train_params.defer_weight_grad, pin_train_weight_grad) the second can
+    // share the device with the next iteration's optimiser launch on another stream.
     using G = DwGeom<H>;
     constexpr int lds_bytes = train_fused_lds_bytes<H>(L);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_fused_kernel<H, L, OD>),
@@ -896,14 +899,17 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, ws.n_tiles);
-    if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
-        image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
-    else
-        hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
-    hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
-                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
-                       n_dec, loss_partial, fcol);
-    PIN_CHECK_LAUNCH();
+    if (phase & 1) {
+        if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
+            image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+        else
+            hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
+        hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                           sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
+                           n_dec, loss_partial, fcol);
+        PIN_CHECK_LAUNCH();
+    }
+    if (!(phase & 2)) return 0;
     if (want_dec) {
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
                            dw_partial, 0);
@@ -919,9 +925,9 @@ template <int H, int OD>
 static int launch_fused(const pin_field* f, const pin_train_params* tp, const FusedColor& fcol, const float* query, const float4* nb4,
                         const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
                         float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
-                        float* pred_out, void* workspace, int n_cu, hipStream_t s) {
+                        float* pred_out, void* workspace, int n_cu, hipStream_t s, int phase = 3) {
 #define PIN_LF(LL) return launch_fused_l<H, LL, OD>(f, tp, fcol, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, \
-                                                    ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s)
+                                                    ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, n_cu, s, phase)
     switch (f->levels) {
         case 1: PIN_LF(1);
         case 2: PIN_LF(2);
@@ -937,7 +943,7 @@ template <int H, bool AN>
 static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
                             const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
                             float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
-                            float* pred_out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t s) {
+                            float* pred_out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t s, int phase = 3) {
     using G = DwGeom<H>;
     constexpr int L = 1;
     constexpr int lds_bytes = train_fused_nwf_lds_bytes<H>();
@@ -961,14 +967,17 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, cdiv(n_groups, TF_BLOCK / 64));
-    if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
-        image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
-    else
-        hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
-    hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
-                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
-                       dw_partial, n_dec, loss_partial);
-    PIN_CHECK_LAUNCH();
+    if (phase & 1) {
+        if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
+            image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+        else
+            hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
+        hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                           sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
+                           dw_partial, n_dec, loss_partial);
+        PIN_CHECK_LAUNCH();
+    }
+    if (!(phase & 2)) return 0;
     if (want_dec) {
         const dim3 dgrid(cdiv(ws.n_tiles, DW_CHUNK), L + 1);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0);
@@ -990,12 +999,12 @@ static int cu_count() {
     return n_cu;
 }
 
-extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
-                              const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
-                              const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
-                              float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
-                              void* workspace, int64_t workspace_bytes, void* stream) {
-    PIN_ENTER();
+// phase: 3 = the whole step; 1 = up to the operand stream (the weight gradient is left to pin_train_weight_grad); 2 = that
+static int train_step_impl(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
+                           const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
+                           const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
+                           float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
+                           void* workspace, int64_t workspace_bytes, void* stream, int phase) {
     PIN_CHECK_ARG(f && tp, "NULL params");
     PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K, "k must be in [1, 8]");
     PIN_CHECK_ARG(f->hidden == 32 || f->hidden == 64, "hidden must be 32 or 64");
@@ -1009,8 +1018,11 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     const int Q = tp->n_main + 6 * tp->n_eik;
     const int H = f->hidden, L = f->levels;
     PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(analytic ? 2 * Q : Q, H, L, expand) * 4, "workspace too small");
-    PIN_CHECK_ARG(query && nbr && nn_count && sdf_label && feat_grad && loss_out && f->feats && f->dec, "NULL pointer");
-    PIN_CHECK_ARG(!tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
+    PIN_CHECK_ARG(loss_out && f->dec, "NULL pointer");
+    PIN_CHECK_ARG(!(phase & 1) || (query && nbr && nn_count && sdf_label && feat_grad && f->feats), "NULL pointer");
+    PIN_CHECK_ARG(!(phase & 1) || !tp->loss_weight_on || sample_weight, "loss_weight_on needs sample_weight");
+    const bool fused = f->weighted_first != 0 || (L == 1 && use_split_decoder());
+    PIN_CHECK_ARG(phase == 3 || fused, "defer_weight_grad / pin_train_weight_grad: only the fused tile paths split in two");
     hipStream_t s = as_stream(stream);
     TrainWs ws;
     ws.Qs = ((Q + 63) / 64) * 64;
@@ -1026,19 +1038,19 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     } while (0)
     const bool quad = f->weighted_first != 0;
     const int want_dec = dec_grad != nullptr;
-    if (!quad) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the fused path sums per-block partials)
+    if (!fused) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the fused paths sum per-block partials)
     if (quad) {  // weighted_first: the fused tile kernel + the streamed weight gradient (train_fused.h)
         FusedColor none;
         memset(&none, 0, sizeof(none));
         return H == 64 ? launch_fused<64, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
-                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s)
+                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s, phase)
                        : launch_fused<32, 1>(f, tp, none, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw,
-                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s);
+                                             ts_update_rw, feat_grad, dec_grad, loss_out, pred_out, workspace, cu_count(), s, phase);
     }
     if (L == 1 && use_split_decoder()) {  // per-neighbour decoding, one-layer decoder: (query, neighbour)-column tiles
 #define PIN_NWF(HH, ANALYTIC)                                                                                                   \
     launch_fused_nwf<HH, ANALYTIC>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw, \
-                                   feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, cu_count(), s)
+                                   feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, cu_count(), s, phase)
         if (analytic) return H == 64 ? PIN_NWF(64, true) : PIN_NWF(32, true);
         return H == 64 ? PIN_NWF(64, false) : PIN_NWF(32, false);
 #undef PIN_NWF
@@ -1065,6 +1077,23 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
     }
     if (pred_out) PIN_CHECK_HIP(hipMemcpyAsync(pred_out, ws.pred, sizeof(float) * tp->n_main, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* query, const float* nbr,
+                              const int32_t* nn_count, const float* sdf_label, const float* sample_weight,
+                              const int32_t* sample_ts, float* certainty_rw, int32_t* ts_update_rw,
+                              float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    return train_step_impl(f, tp, query, nbr, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad,
+                           dec_grad, loss_out, pred_out, workspace, workspace_bytes, stream, (tp && tp->defer_weight_grad) ? 1 : 3);
+}
+
+extern "C" int pin_train_weight_grad(const pin_field* f, const pin_train_params* tp, float* dec_grad, double* loss_out,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    return train_step_impl(f, tp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dec_grad,
+                           loss_out, nullptr, workspace, workspace_bytes, stream, 2);
 }
 
 extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_params* tp, const float* query,

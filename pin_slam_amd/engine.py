@@ -150,6 +150,8 @@ class MapTrainer:
         self.comm = comm
         if world > 1 and comm is None:
             raise ValueError("MapTrainer(world > 1) needs a collective (pin_slam_amd.collective.RcclComm)")
+        self.overlap_weight_grad = None  # None = automatic, True / False force (see step_batch)
+        self._wg_stream, self._wg_ev, self._wg_pending = None, None, False
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
         self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
         self._cert0 = self._cert_scratch = None
@@ -235,13 +237,43 @@ class MapTrainer:
         # step they still owe from the iteration that last read them (+ the gradient-free steps since), and the decoder's
         # step of the previous iteration rides along in the same launch
         dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], lazy) if self.train_decoder else None
-        pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
+        # Two streams (one GPU, decoder training, fused tile paths): the weight gradient of this iteration, its finalize and the
+        # decoder's step (with the image write-through) go to a side stream -- they touch the decoder, its gradient and
+        # the workspace only -- while the caller's stream goes on with the colour branch and the lazy-Adam launch of
+        # the NEXT iteration; the next tile kernel waits for both.  Measured: with a colour branch to overlap with
+        # (C5) mapping 1.84 -> 1.73 ms per frame; without one (C3) the two cross-stream dependencies per iteration cost
+        # more than the ~15 us they can hide (1.22 -> 1.44 ms) -- hence the default (None = only with a colour branch).
+        want = self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None)
+        overlap = bool(lazy and self.train_decoder and want and self.on_grads is None
+                       and (self.fs.weighted_first or self.fs.levels == 1) and os.environ.get("PIN_MLP", "") != "f32")
+        if overlap:
+            main = torch.cuda.current_stream()
+            if self._wg_stream is None:
+                self._wg_stream = torch.cuda.Stream(device=self.fs.feats.device)
+                self._wg_ev = (torch.cuda.Event(), torch.cuda.Event())
+
+            def pre():
+                self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=None)
+                if self._wg_pending:
+                    main.wait_event(self._wg_ev[1])
+                    self._wg_pending = False
+        else:
+            pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
         ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
                        self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
                        sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                        loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
                        bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
-                       knn_ready=knn_ready)
+                       knn_ready=knn_ready, defer_weight_grad=overlap)
+        if overlap:
+            self._wg_ev[0].record(main)
+            side = self._wg_stream
+            side.wait_event(self._wg_ev[0])
+            with torch.cuda.stream(side):
+                ops.train_weight_grad(self.buf, self.gdec)
+                self.lazy.step_dense(dense, step)
+                self._wg_ev[1].record(side)
+            self._wg_pending = True
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
@@ -331,6 +363,10 @@ class MapTrainer:
             return
         nd = self.gdec.numel()
         dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], True) if self.train_decoder else None
+        if self._wg_pending:  # the side stream took the decoder through every step already (step_batch)
+            torch.cuda.current_stream().wait_event(self._wg_ev[1])
+            self._wg_pending = False
+            dense = None
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
         if self.fc is not None:
             cnd = self.fc.dec.numel()

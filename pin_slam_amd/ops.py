@@ -424,12 +424,14 @@ class TrainBuffers:
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
                global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None,
-               queries_ready=False, image_current=False, knn_ready=False):
+               queries_ready=False, image_current=False, knn_ready=False, defer_weight_grad=False):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
     `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up).
     image_current: fs.dec_image holds the decoder's current parameters (LazyAdam keeps it so when it is handed the
-    image) -- the launch sequence then has no staging kernel."""
+    image) -- the launch sequence then has no staging kernel.
+    defer_weight_grad: stop after the tile kernel; train_weight_grad(buf, dec_grad) finishes the step (the decoder's
+    weight gradient and the loss sums), possibly on another stream."""
     L = _lib.lib()
     s = _stream()
     if not queries_ready:  # (pin_gather_batch_drawn can write them in its own launch)
@@ -449,12 +451,21 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     tp.dec_image_current = int(bool(image_current) and fs.dec_image is not None)
     if buf.analytic:  # mean over every sample of the (global) batch, mapper.py:778-781
         tp.inv_n_eik = tp.inv_n_main
+    tp.defer_weight_grad = int(bool(defer_weight_grad))
     f = fs.params()
+    buf.last_call = (f, tp)
     check(L.pin_train_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
                            _ptr(sdf_label, torch.float32), _ptr(sample_weight), _ptr(sample_ts), _ptr(certainty_rw),
                            _ptr(ts_update_rw), _ptr(feat_grad, torch.float32), _ptr(dec_grad), _ptr(buf.loss),
                            _ptr(pred_out), _ptr(buf.ws), buf.ws.numel() * 4, s), "pin_train_step")
     return buf.loss
+
+
+def train_weight_grad(buf: TrainBuffers, dec_grad):
+    """Second half of a train_step(..., defer_weight_grad=True) on `buf`: pin_train_weight_grad on the current stream."""
+    f, tp = buf.last_call
+    check(_lib.lib().pin_train_weight_grad(C.byref(f), C.byref(tp), _ptr(dec_grad), _ptr(buf.loss), _ptr(buf.ws), buf.ws.numel() * 4,
+                                           _stream()), "pin_train_weight_grad")
 
 
 def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
@@ -564,6 +575,13 @@ class LazyAdam:
                                                _ptr(self.coef), self.t_max, self.b1, self.b2, self.eps,
                                                C.byref(d) if d is not None else None, _stream()), "pin_adam_lazy_prepare")
         self.t = int(step)
+
+    def step_dense(self, dense, step):
+        """The dense rider's step `step` alone (what prepare(step + 1) would apply), as its own small launch: lets a
+        caller run the decoder's step on another stream, behind that stream's weight gradient."""
+        d = self._dense(dense)
+        check(_lib.lib().pin_adam_lazy_flush(None, None, None, None, None, 0, int(step), _ptr(self.coef), self.t_max, self.b1,
+                                             self.b2, self.eps, C.byref(d), _stream()), "pin_adam_lazy_flush")
 
     def flush(self, param, grad, m, v, dense=None):
         """Settle every touched row (and the dense tensor's last step) at the step of the last prepare()."""

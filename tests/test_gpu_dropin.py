@@ -194,7 +194,9 @@ def test_mini_slam_loop_update_map_track():
 def test_grouped_iterations_train_like_single_ones():
     """Mapper.mapping gathers and searches a group of iterations in one launch each (their inputs do not depend on the
     training) and stages the decoder once per call; `group_iterations = False` keeps one gather / kNN per iteration.
-    Same seed, same state: the same batches, and the trained features / decoder agree to rounding (atomics order)."""
+    The weight gradient and the decoder's step of an iteration run on a side stream beside the next iteration's
+    optimiser launch; `overlap_weight_grad = False` keeps them in line.  Same seed, same state: the same batches, and
+    the trained features / decoder agree to rounding (atomics order) whatever the launch structure."""
     from pin_slam_amd import synth
     from pin_slam_amd.dropin.model.decoder import Decoder
     from pin_slam_amd.dropin.model.neural_points import NeuralPoints
@@ -205,7 +207,7 @@ def test_grouped_iterations_train_like_single_ones():
     nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
     dd = 0.15 * rng.standard_normal(len(base))
     results = []
-    for grouped in (True, False):
+    for grouped, overlap in ((True, True), (False, True), (True, False)):
         torch.manual_seed(11)
         cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=2048, local_map_radius=40.0, local_map_travel_dist_ratio=5.0)
         npts = NeuralPoints(cfg)
@@ -214,6 +216,7 @@ def test_grouped_iterations_train_like_single_ones():
         dec = Decoder(cfg, 32, 2, 1)
         mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
         mp.group_iterations = grouped
+        mp._get_trainer().overlap_weight_grad = overlap  # weight gradient + decoder step on a side stream, or in line
         mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
         mp.coord_pool = mp.global_coord_pool
         mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
@@ -224,13 +227,14 @@ def test_grouped_iterations_train_like_single_ones():
         mp.mapping(20)  # more than one group of 16
         assert mp._trainer.buf.group == 16
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
-    (fa, da, ca), (fb, db, cb) = results
+    fa, da, ca = results[0]
     assert not torch.equal(fa, torch.zeros_like(fa))
-    # (measured: mean |difference| 1e-8 -- only the order of the float atomics differs; Adam with eps = 1e-15 can turn
-    # the rounding noise of a near-zero gradient into a step of ~lr, hence a bound on the share of such entries too)
-    assert (fa - fb).abs().mean().item() < 1e-5 and ((fa - fb).abs() > 5e-3).float().mean().item() < 1e-3
-    assert (da - db).abs().max().item() < 1e-3
-    torch.testing.assert_close(ca, cb, rtol=1e-4, atol=1e-4)
+    for fb, db, cb in results[1:]:
+        # (measured: mean |difference| 1e-8 -- only the order of the float atomics differs; Adam with eps = 1e-15 can turn
+        # the rounding noise of a near-zero gradient into a step of ~lr, hence a bound on the share of such entries too)
+        assert (fa - fb).abs().mean().item() < 1e-5 and ((fa - fb).abs() > 5e-3).float().mean().item() < 1e-3
+        assert (da - db).abs().max().item() < 1e-3
+        torch.testing.assert_close(ca, cb, rtol=1e-4, atol=1e-4)
 
 
 def test_mapper_with_analytic_eikonal_term():
