@@ -85,3 +85,30 @@ def test_dropin_call_surface_matches_reference():
     for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
         del sys.modules[k]
     R._loaded.clear()
+
+
+@pytest.mark.reference
+def test_standalone_config_carries_the_reference_defaults():
+    """pin_slam_amd.config.PinConfig (what the benchmarks and the stand-alone tests run on) has the reference's
+    attribute names and default values (utils/config.py::Config) -- except the two listed below."""
+    import importlib
+    from oracle import ref_loader as R
+    R.load()
+    ref = importlib.import_module("utils.config").Config()
+    from pin_slam_amd.config import PinConfig
+    mine = PinConfig()
+    deliberate = {
+        "dtype": "not an attribute of the reference (it keeps torch dtypes in tran_dtype / dtype fields of its own)",
+        "track_on": "the reference switches it on from the YAML (tracker section); stand-alone runs track",
+        "infer_bs": "chunk size of inference queries: 4096 suits a CPU, the HIP kernels take 2^19 points per launch",
+    }
+    for name, value in vars(mine).items():
+        if name in deliberate:
+            continue
+        assert hasattr(ref, name), name
+        rv = getattr(ref, name)
+        assert rv == value or str(rv) == str(value), (name, value, rv)
+    import sys
+    for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
+        del sys.modules[k]
+    R._loaded.clear()
