@@ -112,3 +112,34 @@ def test_standalone_config_carries_the_reference_defaults():
     for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
         del sys.modules[k]
     R._loaded.clear()
+
+
+@pytest.mark.reference
+def test_shipped_configurations_pass_the_support_checks():
+    """Every YAML the reference ships, loaded by the reference's own Config, against the drop-in Mapper's support check
+    (what raises NotImplementedError instead of falling back): only the semantic demo is refused.  The two configurations
+    with `ba_freq_frame` train and track like the others; their bundle adjustment (pypose) is outside the hot path."""
+    import glob, importlib, os, sys, types
+    from oracle import ref_loader as R
+    R.load()
+    Config = importlib.import_module("utils.config").Config
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    refused, analytic, per_neighbour = [], [], 0
+    files = sorted(glob.glob(os.path.join(R.REF_ROOT, "config", "*", "*.yaml")))
+    assert len(files) == 20
+    for path in files:
+        c = Config()
+        c.load(path)
+        fake = types.SimpleNamespace(config=c, sdf_mlp=types.SimpleNamespace(hidden_level=c.geo_mlp_level), ba_done_flag=False)
+        try:
+            Mapper._check_supported(fake)
+        except NotImplementedError:
+            refused.append(os.path.basename(path))
+        if c.ekional_loss_on and not c.numerical_grad:
+            analytic.append(os.path.basename(path))
+        per_neighbour += int(not c.weighted_first)
+        assert c.geo_mlp_level == 1 and c.geo_mlp_hidden_dim == 64 and c.query_nn_k in (6, 8)  # the tile-kernel shapes
+    assert refused == ["run_demo_sem.yaml"] and analytic == ["run_livox.yaml"] and per_neighbour == 9
+    for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
+        del sys.modules[k]
+    R._loaded.clear()

@@ -191,7 +191,8 @@ def test_mini_slam_loop_update_map_track():
     assert np.abs(T[:3, :3] - T_true[:3, :3]).max() < 0.01
 
 
-def test_grouped_iterations_train_like_single_ones():
+@pytest.mark.parametrize("wf", [True, False])
+def test_grouped_iterations_train_like_single_ones(wf):
     """Mapper.mapping gathers and searches a group of iterations in one launch each (their inputs do not depend on the
     training) and stages the decoder once per call; `group_iterations = False` keeps one gather / kNN per iteration.
     The weight gradient and the decoder's step of an iteration run on a side stream beside the next iteration's
@@ -209,11 +210,12 @@ def test_grouped_iterations_train_like_single_ones():
     results = []
     for grouped, overlap in ((True, True), (False, True), (True, False)):
         torch.manual_seed(11)
-        cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=2048, local_map_radius=40.0, local_map_travel_dist_ratio=5.0)
+        cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=2048, local_map_radius=40.0, local_map_travel_dist_ratio=5.0,
+                   weighted_first=wf)
         npts = NeuralPoints(cfg)
         npts.travel_dist = torch.zeros(1, device="cuda")
         npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
-        dec = Decoder(cfg, 32, 2, 1)
+        dec = Decoder(cfg, 32, 2, 1) if wf else Decoder(cfg, 64, 1, 1)  # (per-neighbour decoding: the one-layer tile kernel)
         mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
         mp.group_iterations = grouped
         mp._get_trainer().overlap_weight_grad = overlap  # weight gradient + decoder step on a side stream, or in line
