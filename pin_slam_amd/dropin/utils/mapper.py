@@ -248,6 +248,14 @@ class Mapper(_Base):
                     if frame_id > c.freeze_after_frame and r > c.new_sample_ratio_restart:
                         self.adaptive_iter_offset = 10
 
+    def bundle_adjustment(self, iter_count, window_size: int = 50, use_lie_group: bool = False):
+        """mapper.py:848-937 optimises the window's poses with pypose through autograd of the SDF at re-projected pool
+        samples: outside the hot path, and the reference's own code would run it on queries that are
+        not differentiable here.  Refused rather than run wrongly (configurations with ba_freq_frame > 0:
+        run_ncd_128_s.yaml, run_replica.yaml -- set it to 0)."""
+        raise NotImplementedError("Mapper.bundle_adjustment (pypose pose optimisation) is outside libpinhip's hot path: "
+                                  "run with ba_freq_frame: 0")
+
     def transform_data_pool(self, pose_diff_torch):
         """mapper.py:527-531: re-project the global sample coordinates after a pose-graph correction."""
         p = self._pool()

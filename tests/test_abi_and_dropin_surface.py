@@ -70,7 +70,8 @@ def test_dropin_call_surface_matches_reference():
              (ref["Decoder"], mods["model.decoder"].Decoder, ["__init__", "mlp", "sdf", "regress_color", "sem_label_prob"]),
              (ref["Tracker"], mods["utils.tracker"].Tracker, ["__init__", "tracking", "query_source_points", "registration_step"]),
              (ref["Mapper"], um.Mapper, ["__init__", "mapping", "sdf", "sdf_batch", "get_batch", "process_frame",
-                                         "determine_used_pose", "init_pool", "free_pool"]),
+                                         "determine_used_pose", "init_pool", "free_pool", "bundle_adjustment",
+                                         "transform_data_pool"]),
              # the drop-in Mesher inherits the reference class: its overrides must keep the inherited signatures
              (mods["utils.mesher"].Mesher.__mro__[1], mods["utils.mesher"].Mesher, ["__init__", "query_points"])]
     for rcls, ocls, names in pairs:
