@@ -54,12 +54,13 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 10
+#define PIN_ABI_VERSION 11
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
 #define PIN_NONLOCAL (-2)          /* global2local value of a non-local point, see below */
 #define PIN_NBR_QUIRK_BIT 0x40000000
+#define PIN_ADAM_ROW_EXCLUDED (-2147483647 - 1) /* pending word of a feature row the lazy optimiser must leave alone */
 
 /* ---- voxel-hash search state: NeuralPoints fields used by
  * radius_neighborhood_search (model/neural_points.py:950-1009) ------------------- */
@@ -695,6 +696,86 @@ int pin_comm_destroy(void* comm);
  * (ncclAllReduce, ncclFloat32, ncclSum): one call per Mapper.mapping iteration, between the backward pass
  * (pin_train_step) and the optimiser step (pin_adam_step). */
 int pin_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
+
+/* Out-of-place SUM all-reduce of `count` floats on `stream` (ncclAllReduce; send == recv allowed).  Used by the
+ * spatially sharded mapper for the compact [decoder | halo rows] gradient buffer and for the owner merge. */
+int pin_allreduce_f32(void* comm, const float* send, float* recv, int64_t count, void* stream);
+
+/* ---- spatially sharded data-parallel mapper -------------------------
+ * xGMI is point-to-point, so the exchange is made small instead of fast: the voxel grid is cut into `world`
+ * axis-aligned boxes (a k-d split of the drawn batch, computed by the host and identical on every rank) and rank r
+ * trains on the samples of every drawn batch whose voxel lies in box r.  A neural point whose voxel is more than
+ * `reach` cells inside its box can only be a neighbour of that box's samples: its gradient is complete on the
+ * owner, its Adam step is the owner's (lazy, as on one GPU) and nobody else reads it during the call.  The other
+ * rows -- the HALO, a few per cent of the map -- are kept identical on every rank: per iteration ONE all-reduce of
+ * the compact buffer [decoder grads | halo-row grads] and the same dense Adam step on all of them.  At the end of
+ * Mapper.mapping every rank publishes the rows it owns (pin_dp_owner_pack + one all-reduce, once per call).
+ * The sum over ranks of the per-rank gradients equals the single-GPU gradient of the drawn batch whatever the
+ * partition is (losses are normalised by the GLOBAL counts); the Eikonal sub-sample stays the global coord[::dec]. */
+typedef struct pin_dp_regions {
+    const int32_t* boxes;   /* DEVICE [world][6]: lo x,y,z / hi x,y,z in voxel coordinates floor(p / resolution), hi
+                             * exclusive; unbounded faces are INT32_MIN / INT32_MAX.  The boxes tile the grid. */
+    int32_t world, rank;
+    int32_t reach;          /* cells a training query of a sample can lie from the sample's voxel plus the search radius:
+                             * num_nei_cells + ceil(eik_eps / resolution) (0 without Eikonal probes) */
+    float resolution;       /* voxel_size_m (the grid of the neighbour search, neural_points.py:963) */
+} pin_dp_regions;
+
+/* HOST (no device work): the boxes.  boxes_out_host [world][6] from n sample voxels cells_host [n][3]: recursive
+ * splits along the axis of largest extent at the voxel coordinate that divides the samples in proportion to the
+ * ranks on either side (std::nth_element).  Deterministic in its input: every rank calls it on the same sub-sample
+ * of the same drawn batch and gets the same boxes without an exchange. */
+int pin_dp_kd_boxes(const int32_t* cells_host, int32_t n, int32_t world, int32_t* boxes_out_host);
+
+/* Voxel coordinates of every `stride`-th sample of one drawn batch (positions s*stride < n of the batch that
+ * pin_gather_batch_drawn would gather): cells_out [n_out][3] int32 -- what the host cuts its k-d boxes from. */
+int pin_dp_sample_cells(const float* pool_coord, const int64_t* index_history, int32_t n_history,
+                        const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t stride,
+                        int32_t n_out, float resolution, int32_t* cells_out, void* stream);
+
+/* Which samples of the drawn batches are this rank's: for batch b < n_batches, sel_out[b][0 .. counts[b][0]) = the
+ * positions i < n of the batch whose sample lies in box `rank` (any order), eik_sel_out[b][0 .. counts[b][1]) those
+ * of them with i % decimation == 0 (the Eikonal sub-sample coord[::dec] of the GLOBAL batch, mapper.py:683).
+ * counts_out [n_batches][2] is cleared here; an entry larger than cap / eik_cap means the lists are truncated
+ * (grow and call again).  Index arrays as in pin_gather_batches_drawn. */
+int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coord, const int64_t* index_history, int32_t n_history,
+                     const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t decimation,
+                     int32_t n_batches, int64_t hist_stride, int64_t new_stride, int32_t* sel_out, int32_t cap,
+                     int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out, void* stream);
+
+/* Mapper.get_batch for the selected samples of n_batches drawn batches (b-th batch: sel / eik_sel / counts rows
+ * b0 + b of pin_dp_partition's outputs): *_out[b][j] = pool row of batch position sel[b][j], j < counts[b][0];
+ * query_out [n_batches][cap + 6 eik_cap][3]: the samples, then (from row counts[b][0]) the six +-eps probes of every
+ * Eikonal sample in the order x+, x-, y+, y-, z+, z-. */
+int pin_dp_gather(const float* pool_coord, const float* pool_label, const float* pool_weight, const int32_t* pool_ts,
+                  const float* pool_color, int32_t color_channels, const int64_t* index_history, int32_t n_history,
+                  const int64_t* index_new_batch, const int64_t* new_idx, int64_t hist_stride, int64_t new_stride,
+                  const int32_t* sel, int32_t cap, const int32_t* eik_sel, int32_t eik_cap, const int32_t* counts,
+                  int32_t n_batches, float* coord_out, float* label_out, float* weight_out, int32_t* ts_out,
+                  float* color_out, float* query_out, float eps, void* stream);
+
+/* Halo of the partition over the feature rows at pos [n_rows][3]: halo_rows_out = ascending indices of the rows
+ * that are NOT at least `reach` cells inside their own box (the same list on every rank), *count_out of them (at
+ * most halo_cap are written); owner_out [n_rows] = box of every row's voxel; lazy_pending (may be NULL) [n_rows]:
+ * halo rows <- PIN_ADAM_ROW_EXCLUDED so that pin_adam_lazy_* leave them to pin_dp_halo_adam.
+ * Workspace: pin_maint_workspace_bytes(n_rows). */
+int pin_dp_mark_halo(const pin_dp_regions* rg, const float* pos, int32_t n_rows, int32_t* halo_rows_out,
+                     int32_t halo_cap, int32_t* count_out, uint8_t* owner_out, int32_t* lazy_pending, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+/* After the backward pass: packed_out[h][0..8) <- feat_grad[halo_rows[h]][0..8), and the rows are cleared. */
+int pin_dp_halo_pack(const int32_t* halo_rows, int32_t n_halo, float* feat_grad, float* packed_out, void* stream);
+
+/* After the all-reduce: the dense Adam step `step` on the halo rows with the summed gradients grad_sum [n_halo][8];
+ * exp_avg / exp_avg_sq [n_halo][8] are the compact moments (zero at the start of a Mapper.mapping call); coef =
+ * the step coefficient table of pin_adam_lazy_* ([2][t_max + 1]).  Identical inputs on every rank -> identical rows. */
+int pin_dp_halo_adam(const int32_t* halo_rows, int32_t n_halo, float* feats, const float* grad_sum, float* exp_avg,
+                     float* exp_avg_sq, int32_t step, const float* coef, int32_t t_max, float beta1, float beta2,
+                     float eps, void* stream);
+
+/* End of the call: out[row] = owner[row] == rank ? feats[row] : 0 over n_rows rows of 8 floats; the SUM over ranks
+ * (pin_allreduce_f32 into the feature table) is the trained table on every rank. */
+int pin_dp_owner_pack(const uint8_t* owner, int32_t rank, const float* feats, int32_t n_rows, float* out, void* stream);
 
 /* ---- post-loop map maintenance on the device ------------------------------------ */
 

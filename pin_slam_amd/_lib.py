@@ -18,7 +18,8 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 10
+PIN_ABI_VERSION = 11
+PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
 vp = C.c_void_p
@@ -125,6 +126,10 @@ class TrainColorParams(C.Structure):
                 ("weight_i", C.c_float), ("dec_image_current", C.c_int32)]
 
 
+class DpRegions(C.Structure):
+    _fields_ = [("boxes", vp), ("world", C.c_int32), ("rank", C.c_int32), ("reach", C.c_int32), ("resolution", C.c_float)]
+
+
 class PoolArrays(C.Structure):
     _fields_ = [("coord", vp), ("global_coord", vp), ("sdf_label", vp), ("weight", vp), ("ts", vp), ("color", vp),
                 ("color_channels", C.c_int32), ("reserved", C.c_int32)]
@@ -209,6 +214,16 @@ SIGNATURES = {
     "pin_comm_init_rank": (i32, [vp, i32, i32, P(vp)]),
     "pin_comm_destroy": (i32, [vp]),
     "pin_allreduce_grads": (i32, [vp, vp, i64, vp]),
+    "pin_allreduce_f32": (i32, [vp, vp, vp, i64, vp]),
+    "pin_dp_kd_boxes": (i32, [vp, i32, i32, vp]),
+    "pin_dp_sample_cells": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, vp]),
+    "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,
+                            vp, vp, f32, vp]),
+    "pin_dp_mark_halo": (i32, [P(DpRegions), vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]),
+    "pin_dp_halo_pack": (i32, [vp, i32, vp, vp, vp]),
+    "pin_dp_halo_adam": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, f32, f32, f32, vp]),
+    "pin_dp_owner_pack": (i32, [vp, i32, vp, i32, vp, vp]),
     "pin_dp_cert_snapshot": (i32, [vp, vp, i32, vp]),
     "pin_dp_cert_delta": (i32, [vp, vp, vp, i32, vp]),
     "pin_dp_cert_apply": (i32, [vp, vp, vp, i32, vp]),

@@ -56,6 +56,10 @@ class RcclComm:
     def allreduce_grads(self, flat: torch.Tensor):
         check(_lib.lib().pin_allreduce_grads(self._h, flat.data_ptr(), flat.numel(), _stream()), "pin_allreduce_grads")
 
+    def allreduce(self, send: torch.Tensor, recv: torch.Tensor):
+        """SUM all-reduce of a flat fp32 buffer, out of place (send may be recv): pin_allreduce_f32."""
+        check(_lib.lib().pin_allreduce_f32(self._h, send.data_ptr(), recv.data_ptr(), send.numel(), _stream()), "pin_allreduce_f32")
+
     def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
         n = certainty.shape[0]
         check(_lib.lib().pin_dp_sync_side_effects(self._h, certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(),
@@ -94,6 +98,14 @@ class HostStagedComm:
         import torch.distributed as dist
         self._allreduce(flat, dist.ReduceOp.SUM)
 
+    def allreduce(self, send: torch.Tensor, recv: torch.Tensor):
+        import torch.distributed as dist
+        h = self._stage(send)
+        h.copy_(send.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        recv.reshape(-1).copy_(h, non_blocking=True)
+
     def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
         import torch.distributed as dist
         L, n = _lib.lib(), certainty.shape[0]
@@ -103,6 +115,27 @@ class HostStagedComm:
         self._allreduce(ts_update[:n], dist.ReduceOp.MAX)
         check(L.pin_dp_cert_apply(certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(), n, _stream()),
               "pin_dp_cert_apply")
+
+    def close(self):
+        pass
+
+
+class NullComm:
+    """One rank of an N-rank job measured ALONE (bench.py's per-rank emulation on a single-GPU box): every exchange is
+    the identity, so the rank does exactly its own share of the work (its samples, its rows, the whole halo) and
+    nothing arrives from the others.  Timing only -- the trained map is not the N-rank result."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world, self.kind = rank, world, "none (single rank emulated)"
+
+    def allreduce_grads(self, flat):
+        pass
+
+    def allreduce(self, send, recv):
+        pass  # (also for the owner merge: the map of the one emulated rank stays whole)
+
+    def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
+        pass
 
     def close(self):
         pass

@@ -113,6 +113,17 @@ extern "C" int pin_allreduce_grads(void* comm, float* grads, int64_t count, void
     return 0;
 }
 
+extern "C" int pin_allreduce_f32(void* comm, const float* send, float* recv, int64_t count, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(g.handle, "RCCL not loaded (pin_comm_load)");
+    PIN_CHECK_ARG(comm && count >= 0, "bad arguments");
+    if (count == 0) return 0;
+    PIN_CHECK_ARG(send && recv, "NULL pointer");
+    PIN_CHECK_NCCL(g.AllReduce(send, recv, (size_t)count, ncclFloat32, ncclSum, reinterpret_cast<ncclComm_t>(comm),
+                               as_stream(stream)));
+    return 0;
+}
+
 extern "C" int pin_dp_cert_snapshot(const float* certainty, float* certainty0_out, int32_t n, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n >= 0, "bad size");

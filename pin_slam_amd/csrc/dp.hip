@@ -1,0 +1,412 @@
+// Spatially sharded data-parallel mapper: the batch is cut by WHERE a sample
+// lies, not by its position in the batch, so that a rank's gradient stays inside its own part of the feature
+// table and only the rows along the cuts (the halo) cross xGMI every iteration.
+//
+// The reference trains on one GPU (pin_slam.py:8); the parameters of Mapper.mapping are the neural-point
+// features and the decoder (utils/mapper.py:604), and the gradient of a batch is a sum over its samples, so any
+// partition of the samples over ranks gives the reference's gradient once the per-rank sums are added.  Which rows
+// a sample can touch is bounded by the search: a query at q reads rows whose voxel is within num_nei_cells of q's
+// voxel (model/neural_points.py:950-1009) and the Eikonal probes sit eik_eps away from their sample
+// (utils/mapper.py:986-1036).
+#include <limits.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "compact.h"
+#include "pin_common.h"
+
+namespace pin {
+namespace {
+
+constexpr int DP_MAX_WORLD = 64;
+
+struct Box {
+    int lo[3], hi[3];
+};
+
+__device__ __forceinline__ int clamp_cell(long long c) {
+    return (int)(c < (long long)(INT_MIN + 1) ? (long long)(INT_MIN + 1) : (c > (long long)(INT_MAX - 1) ? (long long)(INT_MAX - 1) : c));
+}
+
+// the boxes of a launch in LDS (6 ints per rank)
+__device__ __forceinline__ void load_boxes(const pin_dp_regions& rg, int* sbox) {
+    for (int i = threadIdx.x; i < 6 * rg.world; i += blockDim.x) sbox[i] = rg.boxes[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ int region_of(const int* sbox, int world, int cx, int cy, int cz) {
+    for (int r = 0; r < world; ++r) {
+        const int* b = sbox + 6 * r;
+        if (cx >= b[0] && cy >= b[1] && cz >= b[2] && cx < b[3] && cy < b[4] && cz < b[5]) return r;
+    }
+    return world - 1;  // (the boxes tile the grid: not reached)
+}
+
+// is voxel c at least `reach` cells inside box b on every bounded face?
+__device__ __forceinline__ bool deep_inside(const int* b, int reach, int cx, int cy, int cz) {
+    const int c[3] = {cx, cy, cz};
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (b[a] != INT_MIN) in = in && ((long long)c[a] - reach >= (long long)b[a]);
+        if (b[3 + a] != INT_MAX) in = in && ((long long)c[a] + reach < (long long)b[3 + a]);
+    }
+    return in;
+}
+
+// pool row of position i of a drawn batch (Mapper.get_batch, utils/mapper.py:462-500)
+__device__ __forceinline__ size_t drawn_row(const long long* __restrict__ index_hist, int n_hist,
+                                            const long long* __restrict__ index_new_batch,
+                                            const long long* __restrict__ new_idx, int i) {
+    return (size_t)(i < n_hist ? index_hist[i] : new_idx[index_new_batch[i - n_hist]]);
+}
+
+__global__ __launch_bounds__(256) void dp_sample_cells_kernel(const float* __restrict__ pc,
+                                                              const long long* __restrict__ index_hist, int n_hist,
+                                                              const long long* __restrict__ index_new_batch,
+                                                              const long long* __restrict__ new_idx, int stride, int n_out,
+                                                              float res, int* __restrict__ cells) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_out) return;
+    const size_t row = drawn_row(index_hist, n_hist, index_new_batch, new_idx, s * stride);
+    cells[3 * s] = clamp_cell(voxel_coord(pc[3 * row], res));
+    cells[3 * s + 1] = clamp_cell(voxel_coord(pc[3 * row + 1], res));
+    cells[3 * s + 2] = clamp_cell(voxel_coord(pc[3 * row + 2], res));
+}
+
+// append the flagged lanes of a wave to a list: one counter update per wave, order inside the wave kept
+__device__ __forceinline__ void wave_append(bool flag, int value, int* __restrict__ counter, int* __restrict__ list, int cap) {
+    const unsigned long long bal = __ballot(flag);
+    if (bal == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(counter, __popcll(bal));
+    base = __shfl(base, (int)__ffsll((long long)bal) - 1, 64);
+    if (flag) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < cap) list[pos] = value;
+    }
+}
+
+__global__ __launch_bounds__(256) void dp_partition_kernel(pin_dp_regions rg, const float* __restrict__ pc,
+                                                           const long long* __restrict__ index_hist, int n_hist,
+                                                           const long long* __restrict__ index_new_batch,
+                                                           const long long* __restrict__ new_idx, int n, int dec,
+                                                           long hist_stride, long new_stride, int* __restrict__ sel, int cap,
+                                                           int* __restrict__ esel, int ecap, int* __restrict__ counts) {
+    __shared__ int sbox[6 * DP_MAX_WORLD];
+    load_boxes(rg, sbox);
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool mine = false;
+    if (i < n) {
+        const size_t row = drawn_row(index_hist + (size_t)b * hist_stride, n_hist,
+                                     index_new_batch ? index_new_batch + (size_t)b * new_stride : nullptr, new_idx, i);
+        const int cx = clamp_cell(voxel_coord(pc[3 * row], rg.resolution));
+        const int cy = clamp_cell(voxel_coord(pc[3 * row + 1], rg.resolution));
+        const int cz = clamp_cell(voxel_coord(pc[3 * row + 2], rg.resolution));
+        mine = region_of(sbox, rg.world, cx, cy, cz) == rg.rank;
+    }
+    wave_append(mine, i, counts + 2 * b, sel + (size_t)b * cap, cap);
+    if (ecap > 0) wave_append(mine && (i % dec) == 0, i, counts + 2 * b + 1, esel + (size_t)b * ecap, ecap);
+}
+
+__global__ __launch_bounds__(256) void dp_gather_kernel(const float* __restrict__ pc, const float* __restrict__ pl,
+                                                        const float* __restrict__ pw, const int* __restrict__ pt,
+                                                        const float* __restrict__ pcol, int cw,
+                                                        const long long* __restrict__ index_hist, int n_hist,
+                                                        const long long* __restrict__ index_new_batch,
+                                                        const long long* __restrict__ new_idx, long hist_stride,
+                                                        long new_stride, const int* __restrict__ sel, int cap,
+                                                        const int* __restrict__ esel, int ecap,
+                                                        const int* __restrict__ counts, float* __restrict__ coord,
+                                                        float* __restrict__ label, float* __restrict__ weight,
+                                                        int* __restrict__ ts, float* __restrict__ color,
+                                                        float* __restrict__ q, float eps) {
+    const int b = blockIdx.y;
+    const int n_main = min(counts[2 * b], cap), n_eik = ecap > 0 ? min(counts[2 * b + 1], ecap) : 0;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_main + n_eik) return;
+    index_hist += (size_t)b * hist_stride;
+    if (index_new_batch != nullptr) index_new_batch += (size_t)b * new_stride;
+    float* qb = q + 3 * (size_t)b * ((size_t)cap + 6 * (size_t)ecap);
+    if (j < n_main) {
+        const size_t s = drawn_row(index_hist, n_hist, index_new_batch, new_idx, sel[(size_t)b * cap + j]);
+        const size_t o = (size_t)b * cap + j;
+        const float x = pc[3 * s], y = pc[3 * s + 1], z = pc[3 * s + 2];
+        coord[3 * o] = x; coord[3 * o + 1] = y; coord[3 * o + 2] = z;
+        label[o] = pl[s];
+        weight[o] = pw[s];
+        ts[o] = pt[s];
+        for (int c = 0; c < cw; ++c) color[o * cw + c] = pcol[s * cw + c];
+        qb[3 * j] = x; qb[3 * j + 1] = y; qb[3 * j + 2] = z;
+        return;
+    }
+    const int e = j - n_main;
+    const size_t s = drawn_row(index_hist, n_hist, index_new_batch, new_idx, esel[(size_t)b * ecap + e]);
+    const float x = pc[3 * s], y = pc[3 * s + 1], z = pc[3 * s + 2];
+    float* p = qb + 3 * ((size_t)n_main + 6 * (size_t)e);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float d = (a & 1) ? -eps : eps;  // order x+, x-, y+, y-, z+, z- (make_queries_kernel, train.hip)
+        p[3 * a] = (a >> 1) == 0 ? x + d : x;
+        p[3 * a + 1] = (a >> 1) == 1 ? y + d : y;
+        p[3 * a + 2] = (a >> 1) == 2 ? z + d : z;
+    }
+}
+
+// flags[row] = row is a halo row; owner[row] = its box; the lazy optimiser's pending word of a halo row is parked
+__global__ __launch_bounds__(MB) void dp_halo_flags_kernel(pin_dp_regions rg, const float* __restrict__ pos, int n,
+                                                           unsigned char* __restrict__ flags,
+                                                           unsigned char* __restrict__ owner, int* __restrict__ pend,
+                                                           int* __restrict__ block_cnt) {
+    __shared__ int sbox[6 * DP_MAX_WORLD];
+    load_boxes(rg, sbox);
+    const int i = blockIdx.x * MB + threadIdx.x;
+    bool halo = false;
+    if (i < n) {
+        const int cx = clamp_cell(voxel_coord(pos[3 * (size_t)i], rg.resolution));
+        const int cy = clamp_cell(voxel_coord(pos[3 * (size_t)i + 1], rg.resolution));
+        const int cz = clamp_cell(voxel_coord(pos[3 * (size_t)i + 2], rg.resolution));
+        const int r = region_of(sbox, rg.world, cx, cy, cz);
+        halo = !deep_inside(sbox + 6 * r, rg.reach, cx, cy, cz);
+        flags[i] = halo ? 1 : 0;
+        owner[i] = (unsigned char)r;
+        if (halo && pend != nullptr) pend[i] = PIN_ADAM_ROW_EXCLUDED;
+    }
+    int total;
+    block_flag_scan(halo, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(MB) void dp_halo_scatter_kernel(const unsigned char* __restrict__ flags, int n,
+                                                             const int* __restrict__ block_off, int* __restrict__ rows,
+                                                             int cap) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    int total;
+    const int off = block_flag_scan(f, total);
+    if (f) {
+        const int pos = block_off[blockIdx.x] + off;
+        if (pos < cap) rows[pos] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void dp_halo_pack_kernel(const int* __restrict__ rows, int n_halo, float* __restrict__ g,
+                                                           float* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)n_halo * PIN_FEATURE_DIM) return;
+    const int h = (int)(t >> 3), c = (int)(t & 7);
+    const size_t i = (size_t)rows[h] * PIN_FEATURE_DIM + c;
+    out[t] = g[i];
+    g[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void dp_halo_adam_kernel(const int* __restrict__ rows, int n_halo, float* __restrict__ p,
+                                                           const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, const float* __restrict__ coef, int step,
+                                                           int t_max, float b1, float b2, float eps) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)n_halo * PIN_FEATURE_DIM) return;
+    const int h = (int)(t >> 3), c = (int)(t & 7);
+    const size_t i = (size_t)rows[h] * PIN_FEATURE_DIM + c;
+    float pi = p[i], mi = m[t], vi = v[t];
+    // the coefficients of this step from the table the lazy optimiser uses (same roundings as pin_adam_step)
+    adam_elem(pi, mi, vi, g[t], coef[step], coef[t_max + 1 + step], b1, b2, eps);
+    p[i] = pi; m[t] = mi; v[t] = vi;
+}
+
+__global__ __launch_bounds__(256) void dp_owner_pack_kernel(const unsigned char* __restrict__ owner, int rank,
+                                                            const float* __restrict__ feats, long n, float* __restrict__ out) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = owner[i >> 3] == rank ? feats[i] : 0.f;
+}
+
+int check_regions(const pin_dp_regions* rg) {
+    PIN_CHECK_ARG(rg && rg->boxes, "NULL regions");
+    PIN_CHECK_ARG(rg->world >= 1 && rg->world <= DP_MAX_WORLD && rg->rank >= 0 && rg->rank < rg->world, "bad rank / world (<= 64)");
+    PIN_CHECK_ARG(rg->reach >= 0 && rg->resolution > 0.f, "bad reach / resolution");
+    return 0;
+}
+
+}  // namespace
+}  // namespace pin
+
+using namespace pin;
+
+// ---- host: k-d boxes ----------------------------------------------------------------------------------------
+namespace {
+struct Cell { int c[3]; };
+
+void kd_split(Cell* first, Cell* last, int rank0, int count, const int* lo, const int* hi, int32_t* out) {
+    if (count == 1) {
+        for (int a = 0; a < 3; ++a) { out[6 * rank0 + a] = lo[a]; out[6 * rank0 + 3 + a] = hi[a]; }
+        return;
+    }
+    const int n_left = count / 2;
+    const long n = last - first;
+    int axis = 0, t;
+    if (n == 0) {  // nothing to balance: an empty left box is legal
+        t = lo[0] != INT_MIN ? lo[0] : (hi[0] != INT_MAX ? hi[0] : 0);
+    } else {
+        int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+        for (Cell* p = first; p != last; ++p)
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p->c[a]); mx[a] = std::max(mx[a], p->c[a]); }
+        long best = -1;
+        for (int a = 0; a < 3; ++a) {  // axis of largest extent (first of equal ones)
+            const long e = (long)mx[a] - mn[a];
+            if (e > best) { best = e; axis = a; }
+        }
+        const long want = n * n_left / count;
+        Cell* nth = first + std::min(want, n - 1);
+        std::nth_element(first, nth, last, [axis](const Cell& x, const Cell& y) { return x.c[axis] < y.c[axis]; });
+        t = nth->c[axis];  // cells < t go left
+        // ties at the cut: of the two admissible thresholds take the one closer to the wanted share
+        long below = 0, below_next = 0;
+        for (Cell* p = first; p != last; ++p) { below += p->c[axis] < t; below_next += p->c[axis] <= t; }
+        if (std::labs(below_next - want) < std::labs(below - want)) t += 1;
+        if (best > 0) t = std::min(std::max(t, mn[axis] + 1), mx[axis]);  // occupied cells on both sides when there is a choice
+    }
+    Cell* mid = std::partition(first, last, [axis, t](const Cell& x) { return x.c[axis] < t; });
+    int hi_l[3] = {hi[0], hi[1], hi[2]}, lo_r[3] = {lo[0], lo[1], lo[2]};
+    hi_l[axis] = t;
+    lo_r[axis] = t;
+    kd_split(first, mid, rank0, n_left, lo, hi_l, out);
+    kd_split(mid, last, rank0 + n_left, count - n_left, lo_r, hi, out);
+}
+}  // namespace
+
+extern "C" int pin_dp_kd_boxes(const int32_t* cells_host, int32_t n, int32_t world, int32_t* boxes_out_host) {
+    PIN_CHECK_ARG(n >= 0 && world >= 1 && world <= DP_MAX_WORLD && boxes_out_host && (n == 0 || cells_host), "bad arguments");
+    std::vector<Cell> v((size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) v[i].c[a] = cells_host[3 * i + a];
+    const int lo[3] = {INT_MIN, INT_MIN, INT_MIN}, hi[3] = {INT_MAX, INT_MAX, INT_MAX};
+    kd_split(v.data(), v.data() + n, 0, world, lo, hi, boxes_out_host);
+    return 0;
+}
+
+extern "C" int pin_dp_sample_cells(const float* pool_coord, const int64_t* index_history, int32_t n_history,
+                                   const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t stride,
+                                   int32_t n_out, float resolution, int32_t* cells_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && stride >= 1 && n_out >= 0 && resolution > 0.f, "bad sizes");
+    if (n_out == 0) return 0;
+    PIN_CHECK_ARG((long)(n_out - 1) * stride < n, "n_out * stride reaches past the batch");
+    PIN_CHECK_ARG(pool_coord && cells_out && (n_history == 0 || index_history), "NULL pointer");
+    PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
+    hipLaunchKernelGGL(dp_sample_cells_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, as_stream(stream), pool_coord,
+                       reinterpret_cast<const long long*>(index_history), n_history,
+                       reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), stride,
+                       n_out, resolution, cells_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coord, const int64_t* index_history,
+                                int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
+                                int32_t decimation, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
+                                int32_t* sel_out, int32_t cap, int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out,
+                                void* stream) {
+    PIN_ENTER();
+    if (int e = check_regions(rg)) return e;
+    PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && decimation >= 1 && n_batches >= 0 && n_batches <= 65535 &&
+                      cap >= 0 && eik_cap >= 0, "bad sizes");
+    if (n_batches == 0) return 0;
+    PIN_CHECK_ARG(counts_out, "NULL pointer");
+    PIN_CHECK_HIP(hipMemsetAsync(counts_out, 0, sizeof(int32_t) * 2 * (size_t)n_batches, as_stream(stream)));
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(pool_coord && sel_out && (eik_cap == 0 || eik_sel_out) && (n_history == 0 || index_history), "NULL pointer");
+    PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
+    PIN_CHECK_ARG(n_batches == 1 || (hist_stride >= n_history && new_stride >= n - n_history), "index strides shorter than a batch");
+    hipLaunchKernelGGL(dp_partition_kernel, dim3(cdiv(n, 256), n_batches), dim3(256), 0, as_stream(stream), *rg, pool_coord,
+                       reinterpret_cast<const long long*>(index_history), n_history,
+                       reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), n,
+                       decimation, (long)hist_stride, (long)new_stride, sel_out, cap, eik_sel_out, eik_cap, counts_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_gather(const float* pool_coord, const float* pool_label, const float* pool_weight,
+                             const int32_t* pool_ts, const float* pool_color, int32_t color_channels,
+                             const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                             const int64_t* new_idx, int64_t hist_stride, int64_t new_stride, const int32_t* sel, int32_t cap,
+                             const int32_t* eik_sel, int32_t eik_cap, const int32_t* counts, int32_t n_batches,
+                             float* coord_out, float* label_out, float* weight_out, int32_t* ts_out, float* color_out,
+                             float* query_out, float eps, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_history >= 0 && color_channels >= 0 && cap >= 0 && eik_cap >= 0 && n_batches >= 0 && n_batches <= 65535, "bad sizes");
+    if (n_batches == 0 || cap == 0) return 0;
+    PIN_CHECK_ARG(pool_coord && pool_label && pool_weight && pool_ts && sel && counts && coord_out && label_out && weight_out &&
+                      ts_out && query_out && (eik_cap == 0 || eik_sel), "NULL pointer");
+    PIN_CHECK_ARG(color_channels == 0 || (pool_color && color_out), "colour pool / output NULL");
+    hipLaunchKernelGGL(dp_gather_kernel, dim3(cdiv((long)cap + eik_cap, 256), n_batches), dim3(256), 0, as_stream(stream), pool_coord,
+                       pool_label, pool_weight, pool_ts, pool_color, color_channels, reinterpret_cast<const long long*>(index_history),
+                       n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
+                       (long)hist_stride, (long)new_stride, sel, cap, eik_sel, eik_cap, counts, coord_out, label_out, weight_out,
+                       ts_out, color_out, query_out, eps);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_mark_halo(const pin_dp_regions* rg, const float* pos, int32_t n_rows, int32_t* halo_rows_out,
+                                int32_t halo_cap, int32_t* count_out, uint8_t* owner_out, int32_t* lazy_pending,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    if (int e = check_regions(rg)) return e;
+    PIN_CHECK_ARG(n_rows >= 0 && halo_cap >= 0 && count_out, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (n_rows == 0) {
+        PIN_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t), s));
+        return 0;
+    }
+    PIN_CHECK_ARG(pos && owner_out && (halo_cap == 0 || halo_rows_out) && workspace, "NULL pointer");
+    const int nb = cdiv(n_rows, MB);
+    Carver cv{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    unsigned char* flags = cv.take<unsigned char>(n_rows);
+    int* block_cnt = cv.take<int>(nb);
+    PIN_CHECK_ARG(flags && block_cnt, "workspace too small (pin_maint_workspace_bytes(n_rows))");
+    hipLaunchKernelGGL(dp_halo_flags_kernel, dim3(nb), dim3(MB), 0, s, *rg, pos, n_rows, flags, owner_out, lazy_pending, block_cnt);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, count_out);
+    hipLaunchKernelGGL(dp_halo_scatter_kernel, dim3(nb), dim3(MB), 0, s, flags, n_rows, block_cnt, halo_rows_out, halo_cap);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_halo_pack(const int32_t* halo_rows, int32_t n_halo, float* feat_grad, float* packed_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_halo >= 0, "n_halo < 0");
+    if (n_halo == 0) return 0;
+    PIN_CHECK_ARG(halo_rows && feat_grad && packed_out, "NULL pointer");
+    hipLaunchKernelGGL(dp_halo_pack_kernel, dim3(cdiv((long)n_halo * PIN_FEATURE_DIM, 256)), dim3(256), 0, as_stream(stream),
+                       halo_rows, n_halo, feat_grad, packed_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_halo_adam(const int32_t* halo_rows, int32_t n_halo, float* feats, const float* grad_sum, float* exp_avg,
+                                float* exp_avg_sq, int32_t step, const float* coef, int32_t t_max, float beta1, float beta2,
+                                float eps, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_halo >= 0 && step >= 1 && step <= t_max, "bad n_halo / step");
+    if (n_halo == 0) return 0;
+    PIN_CHECK_ARG(halo_rows && feats && grad_sum && exp_avg && exp_avg_sq && coef, "NULL pointer");
+    hipLaunchKernelGGL(dp_halo_adam_kernel, dim3(cdiv((long)n_halo * PIN_FEATURE_DIM, 256)), dim3(256), 0, as_stream(stream),
+                       halo_rows, n_halo, feats, grad_sum, exp_avg, exp_avg_sq, coef, step, t_max, beta1, beta2, eps);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_owner_pack(const uint8_t* owner, int32_t rank, const float* feats, int32_t n_rows, float* out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_rows >= 0 && rank >= 0, "bad arguments");
+    if (n_rows == 0) return 0;
+    PIN_CHECK_ARG(owner && feats && out, "NULL pointer");
+    const long n = (long)n_rows * PIN_FEATURE_DIM;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dp_owner_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), owner, rank, feats, n, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}

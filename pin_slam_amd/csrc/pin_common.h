@@ -83,6 +83,17 @@ __device__ __forceinline__ float dist2_exact(float dx, float dy, float dz) {
     return xy + zz;
 }
 
+// One Adam element, one step (torch.optim.Adam, tools.py:198-199).  Contraction is off so that every kernel
+// that applies a step -- dense, row-flagged, lazy replay, halo rows -- performs the same roundings.
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr_over_bc1, float inv_sqrt_bc2,
+                                          float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = m + (g - m) * (1.f - b1);               // exp_avg.lerp_(grad, 1-beta1)
+    v = v * b2 + (1.f - b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p = p - lr_over_bc1 * (m / denom);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

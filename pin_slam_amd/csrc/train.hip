@@ -617,16 +617,7 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
 namespace pin {
 
 // ---- Adam --------------------------------------------------------------------------------
-// One element, one step (torch.optim.Adam, tools.py:198-199).  Contraction is off so that every kernel
-// that applies a step -- dense, row-flagged, lazy replay -- performs the same roundings.
-__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr_over_bc1, float inv_sqrt_bc2,
-                                          float b1, float b2, float eps) {
-#pragma clang fp contract(off)
-    m = m + (g - m) * (1.f - b1);               // exp_avg.lerp_(grad, 1-beta1)
-    v = v * b2 + (1.f - b2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-    p = p - lr_over_bc1 * (m / denom);
-}
+// (adam_elem: one element, one step -- pin_common.h, shared with the data-parallel halo step in dp.hip)
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
@@ -730,7 +721,8 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     // 210k more random line updates per iteration, which the tile kernel that follows could feel).
     if (row >= 0 && j == 0) {
         const int cur = pend[row];  // (a stale value only makes the compare-and-swap fail)
-        if (cur != step && cur != -step) {
+        // (PIN_ADAM_ROW_EXCLUDED: a row some other step owns -- the halo rows of the spatially sharded mapper, dp.hip)
+        if (cur != step && cur != -step && cur != PIN_ADAM_ROW_EXCLUDED) {
             const int want = cur == 0 ? -step : step;
             if (atomicCAS(pend + row, cur, want) == cur) { own = 1; n = cur; }
         }
@@ -769,7 +761,7 @@ __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict_
     const long stride = (long)row_blocks * 256;
     for (; i < n; i += stride) {
         const int nn = pend[i / PIN_FEATURE_DIM];
-        if (nn == 0) continue;
+        if (nn == 0 || nn == PIN_ADAM_ROW_EXCLUDED) continue;
         float pi = p[i], mi = 0.f, vi = 0.f;
         if (nn > 0) { mi = m[i]; vi = v[i]; }
         lazy_settle(pi, mi, vi, g[i], nn, t_final, lazy_coef, t_max, b1, b2, eps);

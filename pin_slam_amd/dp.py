@@ -1,0 +1,258 @@
+"""Spatially sharded data-parallel mapper (kernels in csrc/dp.hip).
+
+MI355X's xGMI is point-to-point (7 links x ~153 GB/s per GPU): a dense all-reduce of the 71 MB feature-gradient
+table every iteration costs as much as a rank's share of the training step.  So the batch is cut by WHERE a sample
+lies: the voxel grid is split into `world` boxes (a k-d split of the drawn batch) and rank r trains on the samples of
+every drawn batch that fall in box r.  The gradient of a feature row well inside a box is then complete on its
+owner, whose (lazy, exact) Adam step is the only one that row needs, and nobody else reads the row while the call
+runs.  Only the rows within reach of a cut -- the halo, a few per cent of the map -- are shared: per iteration ONE
+all-reduce of the compact buffer [decoder grads | halo-row grads] followed by the same dense Adam step on every
+rank; at the end of Mapper.mapping every rank publishes the rows it owns with one more all-reduce.
+
+The sum of the per-rank gradients is the reference's whole-batch gradient for ANY partition of the samples (the
+losses are normalised by the global counts, utils/mapper.py:732-780), so the result does not depend on the boxes;
+they only decide load balance and the size of the halo.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import DpRegions, check
+
+INT_MIN, INT_MAX = -(1 << 31), (1 << 31) - 1
+
+
+def kd_boxes(cells: np.ndarray, world: int) -> np.ndarray:
+    """pin_dp_kd_boxes: [world][6] int32 boxes that tile the voxel grid (host code of libpinhip, no device work)."""
+    cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+    out = np.empty((world, 6), dtype=np.int32)
+    check(_lib.lib().pin_dp_kd_boxes(cells.ctypes.data, cells.shape[0], int(world), out.ctypes.data), "pin_dp_kd_boxes")
+    return out
+
+
+def kd_boxes_numpy(cells: np.ndarray, world: int) -> np.ndarray:
+    """The same split in numpy (tests compare the two).  [world][6] int32 boxes (lo xyz, hi xyz exclusive; unbounded faces INT_MIN / INT_MAX) that tile the voxel grid:
+    recursive splits of the sample cells `cells` [n,3] along the axis of largest extent, at the voxel coordinate
+    that divides the samples in proportion to the ranks on either side.  Deterministic in its input (every rank
+    calls it on the same sub-sample of the same drawn batch)."""
+    cells = np.asarray(cells, dtype=np.int64).reshape(-1, 3)
+    out = np.empty((world, 6), dtype=np.int64)
+
+    def split(idx, first, count, lo, hi):
+        if count == 1:
+            out[first, :3], out[first, 3:] = lo, hi
+            return
+        c = cells[idx]
+        n_left = count // 2
+        if len(c) == 0:  # nothing to balance: an empty left box is legal
+            axis = 0
+            t = lo[0] if lo[0] != INT_MIN else (hi[0] if hi[0] != INT_MAX else 0)
+        else:
+            ext = c.max(0) - c.min(0)
+            axis = int(np.argmax(ext))  # (first of equal extents)
+            v = np.sort(c[:, axis], kind="stable")
+            want = (len(v) * n_left) // count
+            t = int(v[min(want, len(v) - 1)])  # cells < t go left
+            # ties at the cut: of the two admissible thresholds take the one closer to the wanted share
+            below, below_next = int(np.searchsorted(v, t, side="left")), int(np.searchsorted(v, t, side="right"))
+            if abs(below_next - want) < abs(below - want):
+                t += 1
+            if ext[axis] > 0:  # keep occupied cells on both sides when there is a choice
+                t = min(max(t, int(v[0]) + 1), int(v[-1]))
+        hi_l, lo_r = list(hi), list(lo)
+        hi_l[axis], lo_r[axis] = t, t
+        left = idx[cells[idx, axis] < t] if len(idx) else idx
+        right = idx[cells[idx, axis] >= t] if len(idx) else idx
+        split(left, first, n_left, list(lo), hi_l)
+        split(right, first + n_left, count - n_left, lo_r, list(hi))
+
+    split(np.arange(len(cells)), 0, world, [INT_MIN] * 3, [INT_MAX] * 3)
+    return out.astype(np.int32)
+
+
+def region_of_cells(boxes: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """Host mirror of the device lookup (tests)."""
+    cells = np.asarray(cells, np.int64)
+    r = np.full(len(cells), -1, np.int64)
+    for i, b in enumerate(np.asarray(boxes, np.int64)):
+        inside = np.all(cells >= b[:3], 1) & np.all(cells < b[3:], 1)
+        r[inside & (r < 0)] = i
+    return r
+
+
+class SpatialShards:
+    """Per-trainer state of the spatially sharded mapper: the boxes, the halo, the compact exchange buffer and the
+    per-call partition of the drawn batches."""
+
+    KD_SAMPLES = 8192
+
+    def __init__(self, rank: int, world: int, comm, device):
+        if not (1 <= world <= 64):
+            raise ValueError("world size 1..64")
+        self.rank, self.world, self.comm, self.device = rank, world, comm, device
+        self.boxes_dev = torch.zeros((world, 6), dtype=torch.int32, device=device)
+        self._boxes_host = torch.zeros((world, 6), dtype=torch.int32).pin_memory()
+        self._cells = self._cells_host = None
+        self.halo_rows = self.owner = self.xbuf = self.hm = self.hv = None
+        self.n_halo = 0
+        self._cnt = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.sel = self.esel = self.counts = None
+        self.cap = self.ecap = 0
+        self.counts_host = None
+        self._ws = None
+        self.fixed_boxes: Optional[np.ndarray] = None  # tests may pin the partition
+        self.stats = {}
+
+    # ------------------------------------------------------------------ regions
+    def regions(self, resolution: float, reach: int) -> DpRegions:
+        rg = DpRegions()
+        rg.boxes, rg.world, rg.rank, rg.reach = self.boxes_dev.data_ptr(), self.world, self.rank, int(reach)
+        rg.resolution = float(np.float32(resolution))
+        return rg
+
+    def _draw_args(self, hist, new, new_idx):
+        n_hist = hist.shape[1]
+        n_new = 0 if new is None else new.shape[1]
+        return (hist.data_ptr(), n_hist, None if new is None else new.data_ptr(), None if new is None else new_idx.data_ptr(),
+                n_hist + n_new, n_hist, n_new)
+
+    def plan(self, pool_coord: torch.Tensor, hist: torch.Tensor, new: Optional[torch.Tensor], new_idx, *, decimation: int,
+             eikonal: bool, resolution: float, reach: int, pos: torch.Tensor, lazy_pending: Optional[torch.Tensor],
+             nd: int):
+        """Everything a Mapper.mapping call needs before its first iteration: boxes from a sub-sample of the first drawn
+        batch (host, one small read-back), the halo of the feature rows at `pos`, the partition of ALL drawn batches
+        (hist [iters][n_hist] / new [iters][n_new] int64, as Mapper._draw_all makes them) and its counts (second
+        read-back).  nd = decoder parameters in front of the halo gradients in the exchange buffer."""
+        L = _lib.lib()
+        s = ops._stream()
+        hp, n_hist, npn, nip, n, hs, ns = self._draw_args(hist, new, new_idx)
+        iters = hist.shape[0]
+        # ---- boxes
+        if self.fixed_boxes is not None:
+            boxes = np.asarray(self.fixed_boxes, np.int32).reshape(self.world, 6)
+        else:
+            n_out = min(self.KD_SAMPLES, n)
+            stride = max(1, n // max(n_out, 1))
+            n_out = min(n_out, (n + stride - 1) // stride)
+            if self._cells is None or self._cells.shape[0] < n_out:
+                self._cells = torch.empty((self.KD_SAMPLES, 3), dtype=torch.int32, device=self.device)
+                self._cells_host = torch.empty((self.KD_SAMPLES, 3), dtype=torch.int32).pin_memory()
+            check(L.pin_dp_sample_cells(pool_coord.data_ptr(), hp, n_hist, npn, nip, n, stride, n_out,
+                                        float(np.float32(resolution)), self._cells.data_ptr(), s), "pin_dp_sample_cells")
+            self._cells_host[:n_out].copy_(self._cells[:n_out], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            boxes = kd_boxes(self._cells_host[:n_out].numpy(), self.world)
+        self.boxes = boxes
+        self._boxes_host.copy_(torch.from_numpy(boxes))
+        self.boxes_dev.copy_(self._boxes_host, non_blocking=True)
+        rg = self.regions(resolution, reach)
+        # ---- halo of the feature rows
+        rows = pos.shape[0]
+        if self.halo_rows is None or self.halo_rows.shape[0] < rows:
+            cap_rows = int(rows * 1.25) + 1024
+            self.halo_rows = torch.empty((cap_rows,), dtype=torch.int32, device=self.device)
+            self.owner = torch.empty((cap_rows,), dtype=torch.uint8, device=self.device)
+        need = int(L.pin_maint_workspace_bytes(rows))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
+        check(L.pin_dp_mark_halo(C.byref(rg), pos.data_ptr(), rows, self.halo_rows.data_ptr(), self.halo_rows.shape[0],
+                                 self._cnt.data_ptr(), self.owner.data_ptr(), None if lazy_pending is None else lazy_pending.data_ptr(),
+                                 self._ws.data_ptr(), self._ws.numel(), s), "pin_dp_mark_halo")
+        # ---- partition of every drawn batch
+        if self.counts is None or self.counts.shape[0] < iters:
+            self.counts = torch.zeros((max(iters, 16), 2), dtype=torch.int32, device=self.device)
+            self.counts_host = torch.zeros((max(iters, 16) * 2 + 1,), dtype=torch.int32).pin_memory()
+        want_cap = int(n / self.world * 1.15) + 1024
+        want_ecap = (int((n + decimation - 1) // decimation / self.world * 1.25) + 256) if eikonal else 0
+        while True:
+            if self.sel is None or self.cap < want_cap or self.ecap < want_ecap or self.sel.shape[0] < iters * self.cap:
+                self.cap, self.ecap = max(self.cap, want_cap), max(self.ecap, want_ecap)
+                self.sel = torch.empty((max(iters, 1) * self.cap,), dtype=torch.int32, device=self.device)
+                self.esel = torch.empty((max(iters, 1) * max(self.ecap, 1),), dtype=torch.int32, device=self.device)
+            ecap = self.ecap if eikonal else 0
+            check(L.pin_dp_partition(C.byref(rg), pool_coord.data_ptr(), hp, n_hist, npn, nip, n, int(decimation), iters, hs, ns,
+                                     self.sel.data_ptr(), self.cap, self.esel.data_ptr(), ecap, self.counts.data_ptr(), s),
+                  "pin_dp_partition")
+            ch = self.counts_host
+            ch[:2 * iters].copy_(self.counts[:iters].reshape(-1), non_blocking=True)
+            ch[2 * iters:2 * iters + 1].copy_(self._cnt, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            cnt = ch[:2 * iters].numpy().reshape(iters, 2).copy()
+            if cnt[:, 0].max(initial=0) <= self.cap and (not eikonal or cnt[:, 1].max(initial=0) <= self.ecap):
+                break
+            # an unbalanced cut (a clustered pool): grow the lists and partition again
+            want_cap = max(want_cap, int(cnt[:, 0].max() * 1.1) + 1024)
+            want_ecap = max(want_ecap, int(cnt[:, 1].max() * 1.1) + 256) if eikonal else 0
+        self.n_main, self.n_eik = cnt[:, 0].astype(int), (cnt[:, 1].astype(int) if eikonal else np.zeros(iters, int))
+        self.eik_cap = ecap
+        self.n_halo = int(ch[2 * iters])
+        if self.n_halo > self.halo_rows.shape[0]:
+            raise RuntimeError("halo list overflow")  # (cannot happen: the list is sized for every row)
+        # ---- exchange buffer [decoder grads | halo-row grads] and the halo's compact Adam moments
+        nx = nd + 8 * self.n_halo
+        if self.xbuf is None or self.xbuf.numel() < nx or self._nd != nd:
+            capx = nd + int(8 * self.n_halo * 1.25) + 1024
+            self.xbuf = torch.zeros((capx,), dtype=torch.float32, device=self.device)
+            self.hm = torch.zeros((capx,), dtype=torch.float32, device=self.device)
+            self.hv = torch.zeros((capx,), dtype=torch.float32, device=self.device)
+            self._nd = nd
+        else:
+            self.hm[:8 * self.n_halo].zero_()
+            self.hv[:8 * self.n_halo].zero_()
+        self.nd = nd
+        self.stats = dict(rows=rows, halo_rows=self.n_halo, halo_fraction=self.n_halo / max(rows, 1),
+                          exchange_bytes=4 * nx, samples_min=int(self.n_main.min(initial=0)), samples_max=int(self.n_main.max(initial=0)),
+                          samples_ideal=n / self.world)
+        self._hist, self._new, self._new_idx, self._pool_coord = hist, new, new_idx, pool_coord
+        return self
+
+    # ------------------------------------------------------------------ per group of iterations
+    def gather(self, pool: dict, global_coord: bool, C_color: int, it0: int, gn: int, out: dict, query_all: torch.Tensor, eps: float):
+        """Mapper.get_batch of iterations it0 .. it0 + gn - 1 for this rank's samples (pin_dp_gather): out = dict of
+        [gn][cap] buffers (coord, label, weight, ts, color), query_all [gn][cap + 6 ecap][3]."""
+        hist, new = self._hist, self._new
+        n_hist = hist.shape[1]
+        n_new = 0 if new is None else new.shape[1]
+        check(_lib.lib().pin_dp_gather(
+            (pool["global_coord"] if global_coord else pool["coord"]).data_ptr(), pool["sdf_label"].data_ptr(), pool["weight"].data_ptr(),
+            pool["ts"].data_ptr(), pool["color"].data_ptr() if C_color else None, C_color,
+            hist.data_ptr() + 8 * it0 * n_hist, n_hist, None if new is None else new.data_ptr() + 8 * it0 * n_new,
+            None if new is None else self._new_idx.data_ptr(), n_hist, n_new,
+            self.sel.data_ptr() + 4 * it0 * self.cap, self.cap, self.esel.data_ptr() + 4 * it0 * max(self.eik_cap, 0), self.eik_cap,
+            self.counts.data_ptr() + 8 * it0, gn, out["coord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
+            out["ts"].data_ptr(), None if out.get("color") is None else out["color"].data_ptr(), query_all.data_ptr(),
+            float(np.float32(eps)), ops._stream()), "pin_dp_gather")
+
+    # ------------------------------------------------------------------ per iteration
+    def exchange(self, feats: torch.Tensor, gfeat: torch.Tensor, step: int, coef: torch.Tensor, t_max: int, b1, b2, eps,
+                 on_allreduce=None):
+        """After the backward pass of iteration `step`: halo gradients into the exchange buffer (its head already holds
+        the decoder gradient), ONE all-reduce, the dense Adam step on the halo rows."""
+        L, s = _lib.lib(), ops._stream()
+        nx = self.nd + 8 * self.n_halo
+        check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), self.n_halo, gfeat.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd, s),
+              "pin_dp_halo_pack")
+        if on_allreduce is not None:
+            on_allreduce(True)
+        self.comm.allreduce(self.xbuf[:nx], self.xbuf[:nx])
+        if on_allreduce is not None:
+            on_allreduce(False)
+        check(L.pin_dp_halo_adam(self.halo_rows.data_ptr(), self.n_halo, feats.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd,
+                                 self.hm.data_ptr(), self.hv.data_ptr(), int(step), coef.data_ptr(), int(t_max), float(b1), float(b2),
+                                 float(eps), s), "pin_dp_halo_adam")
+
+    # ------------------------------------------------------------------ end of the call
+    def publish(self, feats: torch.Tensor, scratch: torch.Tensor):
+        """Every rank's owned rows -> the whole trained table on every rank (rows [0, n_rows) of `feats`; the padding row
+        behind them never trains).  scratch: n_rows * 8 floats that may be overwritten (the lazy optimiser's moment
+        array: it is rebuilt from scratch by the next call)."""
+        rows = self.stats["rows"]
+        check(_lib.lib().pin_dp_owner_pack(self.owner.data_ptr(), self.rank, feats.data_ptr(), rows, scratch.data_ptr(), ops._stream()),
+              "pin_dp_owner_pack")
+        self.comm.allreduce(scratch[:8 * rows], feats.reshape(-1)[:8 * rows])

@@ -95,6 +95,10 @@ class Mapper(_Base):
         # batch (same seed) and trains on its contiguous shard; set by the launcher, 1 rank by default
         self.dp_rank, self.dp_world = 0, 1
         self.dp_comm = None  # pin_slam_amd.collective.RcclComm when dp_world > 1
+        # how the batch is cut over the ranks (engine.MapTrainer): "spatial" = k-d boxes of the voxel grid, only the
+        # halo rows cross xGMI per iteration (pin_slam_amd.dp); "dense" = contiguous index shards + an all-reduce of the
+        # whole gradient table per iteration
+        self.dp_mode = "spatial"
         self.static_mask = None
         self.cur_sample_count = 0
         self.cur_new_point_ratio = 0.0
@@ -379,14 +383,15 @@ class Mapper(_Base):
         if eik and not c.numerical_grad:  # run_livox.yaml: the autograd gradient of every sample (mapper.py:677-678)
             eik = "analytic"
         t = self._trainer
-        if (t is None or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel() or t.eikonal != eik
+        mode = None if self.dp_comm is None else ("dense" if eik == "analytic" else self.dp_mode)
+        if (t is None or t.bs != c.bs or t.fs.dec.numel() != fs.dec.numel() or t.eikonal != eik or t.dp_mode != mode
                 or t.fs.weighted_first != fs.weighted_first or (t.rank, t.world) != (self.dp_rank, self.dp_world)):
             t = engine.MapTrainer(st, fs, None, None, None, None, npts.local_point_ts_update, bs=c.bs,
                                   decimation=c.gradient_decimation, sigma=self.sdf_scale,
                                   weight_e=c.weight_e if eik else 0.0,
                                   eik_eps=c.voxel_size_m * c.num_grad_step_ratio, lr=c.lr, adam_eps=c.adam_eps,
                                   loss_weight_on=c.loss_weight_on, eikonal=eik, rank=self.dp_rank, world=self.dp_world,
-                                  comm=self.dp_comm)
+                                  comm=self.dp_comm, dp_mode=mode or "spatial")
             self._trainer = t
         t.resize(fs)  # the local map changes size every frame: same buffers, new views
         t.st, t.ts_update, t.train_decoder = st, npts.local_point_ts_update, train_dec
@@ -407,6 +412,9 @@ class Mapper(_Base):
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         t = self._get_trainer()
         t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
+        if t.dp is not None:  # spatially sharded over the ranks (pin_slam_amd.dp)
+            self._mapping_spatial(t, iter_count)
+            return
         from ...sharding import shard_range
         self._shard = shard_range(self.config.bs, self.dp_rank, self.dp_world)
         t.begin_side_effects()
@@ -450,6 +458,23 @@ class Mapper(_Base):
             self._queries_for = self._drawn = self._shard = None
         t.finish_optimizer()
         t.merge_side_effects()  # dp: certainty / ts side effects of the other ranks' shards, one exchange per call
+        self.neural_points.assign_local_to_global()
+
+    def _mapping_spatial(self, t, iter_count):
+        """Mapper.mapping on a rank of the spatially sharded mapper: the batches are drawn as on one GPU (identically on every
+        rank: same generator state), each rank trains on the samples of every batch that lie in its box."""
+        c, p = self.config, self._pool()
+        t.begin_side_effects()
+        drawn = self._draw_all(iter_count)
+        if drawn is not None:
+            b = p.bufs[0]
+            gc = not self.ba_done_flag
+            self.dp_stats = t.plan_shards(b["global_coord"] if gc else b["coord"], drawn["hist"], drawn["new"], self.new_idx,
+                                          num_nei_cells=c.num_nei_cells)
+            t.run_shards(b, gc, iter_count)
+            self.total_iter += iter_count
+        t.finish_optimizer()
+        t.merge_side_effects()
         self.neural_points.assign_local_to_global()
 
     def sdf(self, x, get_std=False, min_nn_count=1, accumulate_stability=False):

@@ -136,7 +136,7 @@ class MapTrainer:
     def __init__(self, st: ops.SearchState, fs: ops.FieldState, pool_coord, pool_label, pool_weight, pool_ts,
                  ts_update, *, bs: int, decimation: int, sigma: float, weight_e: float, eik_eps: float,
                  lr: float = 0.01, adam_eps: float = 1e-15, loss_weight_on: bool = False, train_decoder: bool = True,
-                 eikonal: bool = True, rank: int = 0, world: int = 1, comm=None):
+                 eikonal: bool = True, rank: int = 0, world: int = 1, comm=None, dp_mode: str = "spatial"):
         self.st, self.fs = st, fs
         self.pool = (pool_coord, pool_label, pool_weight, pool_ts)
         self.ts_update = ts_update
@@ -150,23 +150,38 @@ class MapTrainer:
         self.comm = comm
         if world > 1 and comm is None:
             raise ValueError("MapTrainer(world > 1) needs a collective (pin_slam_amd.collective.RcclComm)")
+        # how the batch is cut over the ranks: "spatial" (pin_slam_amd.dp: k-d boxes of the voxel grid, lazy Adam on the
+        # owned rows, one all-reduce of [decoder | halo rows] per iteration) or "dense" (contiguous index shards, one
+        # all-reduce of the whole [decoder | feature] gradient per iteration, replicated dense Adam)
+        if dp_mode not in ("spatial", "dense"):
+            raise ValueError("dp_mode: spatial | dense")
+        self.dp_mode = dp_mode if comm is not None else None
+        self.dp = None
         self.overlap_weight_grad = None  # None = automatic, True / False force (see step_batch)
         self._wg_stream, self._wg_ev, self._wg_pending = None, None, False
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
         self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
         self._cert0 = self._cert_scratch = None
-        assert self.bs % world == 0, "global batch must divide over the ranks"
-        self.bs_local = self.bs // world
         dev = fs.feats.device
         self._store = None
         self.resize(fs)
         from .sharding import n_eik_global, shard_range
-        start, _ = shard_range(self.bs, rank, world)
-        # one gather + one kNN launch per GROUP of iterations on one GPU (their inputs do not depend on the training)
-        q_iter = self.bs_local + 6 * (0 if eikonal in (False, "analytic") else (self.bs_local + self.dec - 1) // self.dec)
-        group = max(1, min(16, (1 << 22) // max(q_iter, 1))) if world == 1 else 1
-        self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
-                                    shard_start=start, weighted_first=fs.weighted_first, group=group)
+        if self.dp_mode == "spatial":
+            if eikonal == "analytic":
+                raise NotImplementedError("spatially sharded mapper with the analytic Eikonal term (use dp_mode='dense')")
+            from .dp import SpatialShards
+            self.dp = SpatialShards(rank, world, comm, dev)
+            self.bs_local = self.bs  # (capacity of the per-rank gather buffers is set per call, _shard_buffers)
+            self.buf = None
+        else:
+            assert self.bs % world == 0, "global batch must divide over the ranks"
+            self.bs_local = self.bs // world
+            start, _ = shard_range(self.bs, rank, world)
+            # one gather + one kNN launch per GROUP of iterations on one GPU (their inputs do not depend on the training)
+            q_iter = self.bs_local + 6 * (0 if eikonal in (False, "analytic") else (self.bs_local + self.dec - 1) // self.dec)
+            group = max(1, min(16, (1 << 22) // max(q_iter, 1))) if world == 1 else 1
+            self.buf = ops.TrainBuffers(self.bs_local, self.dec, fs.k, fs.hidden, fs.levels, eikonal=eikonal,
+                                        shard_start=start, weighted_first=fs.weighted_first, group=group)
         self.coord = torch.empty((self.bs_local, 3), dtype=torch.float32, device=dev)
         self.label = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
         self.weight = torch.empty((self.bs_local,), dtype=torch.float32, device=dev)
@@ -210,12 +225,58 @@ class MapTrainer:
             self.fc = None
             return
         if self.comm is not None:
-            raise NotImplementedError("colour training is single-GPU for now (the geometry all-reduce buffer excludes it)")
+            raise NotImplementedError("colour training is single-GPU for now (the geometry exchange buffer excludes it)")
         nf, nd = fc.feats.numel(), fc.dec.numel()
         if self.fc is None or self.cgrad.numel() != nf + nd:
             self.cgrad = torch.zeros((nd + nf,), dtype=torch.float32, device=fc.feats.device)
             self.cm, self.cv = torch.zeros_like(self.cgrad), torch.zeros_like(self.cgrad)
         self.fc, self.c_range, self.c_weight, self.c_train_dec = fc, float(surface_range), float(weight_i), train_decoder
+
+    # ------------------------------------------------------------------ spatially sharded data-parallel mapping (dp.py)
+    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int):
+        """Start of a spatially sharded Mapper.mapping call, after reset_optimizer(): boxes, halo, this rank's samples of
+        every drawn batch (SpatialShards.plan) and buffers of the size that came out."""
+        dp, fs = self.dp, self.fs
+        eik = bool(self.eikonal)
+        res = float(self.st.resolution)
+        reach = int(num_nei_cells) + (int(np.ceil(float(self.eik_eps) / res - 1e-9)) if eik else 0)
+        nd = self.m.numel() - fs.feats.numel()
+        dp.plan(pool_coord, hist, new, new_idx, decimation=self.dec, eikonal=eik, resolution=res, reach=reach, pos=fs.pos,
+                lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd)
+        self.gdec = dp.xbuf[:nd]  # the decoder gradient lives at the head of the exchange buffer
+        b = self.buf
+        if b is None or b.cap_main < dp.cap or b.cap_eik < dp.eik_cap or (dp.eik_cap == 0) != (b.cap_eik == 0):
+            q_iter = dp.cap + 6 * dp.eik_cap
+            group = max(1, min(16, (1 << 22) // max(q_iter, 1)))
+            self.buf = ops.TrainBuffers(dp.cap, 1, fs.k, fs.hidden, fs.levels, eikonal=eik, weighted_first=fs.weighted_first,
+                                        group=group, n_eik=dp.eik_cap)
+            dev, G, cap = fs.feats.device, group, dp.cap
+            self._shard_out = dict(coord=torch.empty((G, cap, 3), dtype=torch.float32, device=dev),
+                                   label=torch.empty((G, cap), dtype=torch.float32, device=dev),
+                                   weight=torch.empty((G, cap), dtype=torch.float32, device=dev),
+                                   ts=torch.empty((G, cap), dtype=torch.int32, device=dev), color=None)
+        # (the partition lists use dp.cap / dp.eik_cap as strides; the buffers above may be larger: gather with the lists' strides)
+        if self.buf.cap_main != dp.cap or self.buf.cap_eik != dp.eik_cap:
+            raise RuntimeError("shard buffer strides out of step with the partition")  # (grown together above)
+        return dp.stats
+
+    def run_shards(self, pool: dict, global_coord: bool, iters: int, on_iteration=None):
+        """The iterations of a spatially sharded call: per group one gather launch, per iteration kNN + step_batch."""
+        dp, buf = self.dp, self.buf
+        out = self._shard_out
+        for it0 in range(0, iters, buf.group):
+            gn = min(buf.group, iters - it0)
+            dp.gather(pool, global_coord, 0, it0, gn, out, buf.query_all, self.eik_eps)
+            for j in range(gn):
+                it = it0 + j
+                buf.set_counts(j, int(dp.n_main[it]), int(dp.n_eik[it]))
+                nm = buf.n_main
+                if nm:
+                    ops.knn_query(self.st, buf.query, self.fs.k, out=(buf.nbr, buf.nn, None), bricks=self.bricks)
+                self.step_batch(out["coord"][j, :nm], out["label"][j, :nm], out["weight"][j, :nm], out["ts"][j, :nm], it + 1,
+                                queries_ready=True, knn_ready=True)
+                if on_iteration is not None:
+                    on_iteration(it)
 
     def iteration(self, index_local: torch.Tensor, step: int):
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
@@ -259,12 +320,18 @@ class MapTrainer:
                     self._wg_pending = False
         else:
             pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
-        ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
-                       self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
-                       sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
-                       loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
-                       bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
-                       knn_ready=knn_ready, defer_weight_grad=overlap)
+        if self.dp is not None and coord.shape[0] == 0:
+            # none of this batch's samples fell into this rank's box: its rows settle nothing, the decoder still takes its
+            # step (the dense rider of the lazy launch) and the exchange below still runs -- the other ranks wait in it
+            if pre is not None:
+                pre()
+        else:
+            ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
+                           self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
+                           sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
+                           loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
+                           bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
+                           knn_ready=knn_ready, defer_weight_grad=overlap)
         if overlap:
             self._wg_ev[0].record(main)
             side = self._wg_stream
@@ -288,6 +355,13 @@ class MapTrainer:
                                    eps=self.adam_eps)
                 if self.c_train_dec:
                     ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
+        if self.dp is not None:  # spatial shards: [decoder | halo rows] all-reduced, the halo rows' Adam step right behind
+            self.dp.exchange(self.fs.feats, self.gfeat, step, self.lazy.coef, self.lazy.t_max, self.lazy.b1, self.lazy.b2,
+                             self.lazy.eps, on_allreduce=self.on_allreduce)
+            if self.on_grads is not None:
+                self.on_grads(self.dp.xbuf[:self.dp.nd + 8 * self.dp.n_halo])
+            self.total_iter += 1
+            return
         if self.comm is not None:  # SUM of the per-rank gradients of [decoder | features] (pin_allreduce_grads)
             if self.on_allreduce is not None:
                 self.on_allreduce(True)
@@ -329,7 +403,9 @@ class MapTrainer:
         """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615).  With the iteration count
         known (and one GPU) the feature tables use the lazy exact Adam: call finish_optimizer() after the last
         iteration; without it, the row-flagged / dense step."""
-        self.lazy_on = bool(iters) and self.comm is None
+        self.lazy_on = bool(iters) and (self.comm is None or self.dp is not None)
+        if self.dp is not None and not self.lazy_on:
+            raise ValueError("the spatially sharded mapper needs the iteration count (lazy Adam on the owned rows)")
         nd = self.gdec.numel()
         if self.lazy_on:
             dev = self.fs.feats.device
@@ -367,7 +443,10 @@ class MapTrainer:
             torch.cuda.current_stream().wait_event(self._wg_ev[1])
             self._wg_pending = False
             dense = None
+        stepped = self.lazy.t > 0
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
+        if self.dp is not None and stepped:  # every rank's owned rows -> the whole table everywhere (the moment array is free now)
+            self.dp.publish(self.fs.feats, self.m[nd:])
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], True) if self.c_train_dec else None

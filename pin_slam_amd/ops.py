@@ -391,7 +391,7 @@ class TrainBuffers:
     (numerical_grad_on False, run_livox.yaml:27: no probes), False = off."""
 
     def __init__(self, n_main: int, decimation: int, k: int, hidden: int, levels: int, eikonal=True, device="cuda",
-                 shard_start: int = 0, weighted_first: bool = True, group: int = 1):
+                 shard_start: int = 0, weighted_first: bool = True, group: int = 1, n_eik: Optional[int] = None):
         from .sharding import eikonal_shard
         self.n_main = int(n_main)
         self.dec = int(decimation)
@@ -400,6 +400,9 @@ class TrainBuffers:
             raise NotImplementedError("analytic Eikonal term (numerical_grad_on False) is built for weighted_first False "
                                       "with a one-layer decoder (config/lidar_slam/run_livox.yaml)")
         self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if (eikonal and not self.analytic) else (0, 0)
+        if n_eik is not None:  # capacities: the spatial shards (pin_slam_amd.dp) set the counts per iteration, set_counts()
+            self.eik_first, self.n_eik, self.dec = 0, (int(n_eik) if (eikonal and not self.analytic) else 0), 1
+        self.cap_main, self.cap_eik = self.n_main, self.n_eik
         self.Q = self.n_main + 6 * self.n_eik
         # `group` iterations' worth of queries / kNN records: the batches of a Mapper.mapping call are drawn up front and
         # the neural point positions do not move while the map trains, so ONE gather launch and ONE kNN launch serve
@@ -419,6 +422,15 @@ class TrainBuffers:
 
     def select(self, j: int):
         self.query, self.nbr, self.nn = self._views[j]
+
+    def set_counts(self, j: int, n_main: int, n_eik: int):
+        """Shards of varying size: slot j of the (capacity-strided) group buffers holds n_main samples followed by the
+        6 * n_eik probes of its Eikonal samples."""
+        if n_main > self.cap_main or n_eik > self.cap_eik:
+            raise ValueError("shard larger than the buffers")
+        self.n_main, self.n_eik = int(n_main), int(n_eik)
+        a, b = j * self.Q, j * self.Q + self.n_main + 6 * self.n_eik
+        self.query, self.nbr, self.nn = self.query_all[a:b], self.nbr_all[a:b], self.nn_all[a:b]
 
 
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,

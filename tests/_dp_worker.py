@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_dp.py: one rank of engine.MapTrainer on cuda:0, two mapping iterations on a golden
-fixture's fixed batches (its shard of them).  transport: none | host (gloo over pinned host buffers, for ranks that
-share the device) | rccl (RCCL through the C ABI; one rank per GPU, so world must be 1 on a single-GPU box)."""
+fixture's fixed batches.  transport: none | host (gloo over pinned host buffers, for ranks that share the device) |
+rccl (RCCL through the C ABI; one rank per GPU, so world must be 1 on a single-GPU box) | null (collective.NullComm).
+mode: dense (contiguous index shards, whole-table all-reduce) | spatial (pin_slam_amd.dp: k-d boxes, halo exchange)."""
 import os
 import sys
 
@@ -13,10 +14,12 @@ from tests import golden_util as G  # noqa: E402
 from tests import gpu_util as U  # noqa: E402
 
 
-def main(rank, world, port, case, transport, out):
+def main(rank, world, port, case, transport, out, mode="dense"):
     torch.cuda.set_device(0)
     comm = None
-    if transport != "none":
+    if transport == "null":
+        comm = collective.NullComm(rank, world)
+    elif transport != "none":
         import torch.distributed as dist
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,27 +30,47 @@ def main(rank, world, port, case, transport, out):
     bs = d["map_coord0"].shape[0]
     t = engine.MapTrainer(st, fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
                           weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
-                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm)
+                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm, dp_mode=mode)
     grads = []
     t.on_grads = lambda g: grads.append(g.cpu().numpy().copy())
-    t.reset_optimizer(2 if transport == "none" else None)  # one GPU: the lazy exact Adam, as Mapper.mapping runs it
-    t.begin_side_effects()
-    a, b = sharding.shard_range(bs, rank, world)
-    for it in range(2):
-        t.step_batch(U.dev(d[f"map_coord{it}"][a:b]), U.dev(d[f"map_label{it}"][a:b]), U.dev(d[f"map_w{it}"][a:b]),
-                     U.dev(d[f"map_ts{it}"][a:b], torch.int32), it + 1)
-    t.finish_optimizer()
-    t.merge_side_effects()
-    torch.cuda.synchronize()
     nd = fs.dec.numel()
+    extra = {}
+    if comm is not None and mode == "spatial":
+        t.reset_optimizer(2)
+        t.begin_side_effects()
+        cat = lambda key, dt=None: U.dev(np.concatenate([d[f"{key}0"], d[f"{key}1"]]), dt)
+        pool = dict(coord=cat("map_coord"), sdf_label=cat("map_label"), weight=cat("map_w"), ts=cat("map_ts", torch.int32))
+        pool["global_coord"] = pool["coord"]
+        hist = torch.arange(2 * bs, dtype=torch.int64, device="cuda").reshape(2, bs)  # batch it = pool rows [it*bs, (it+1)*bs)
+        stats = t.plan_shards(pool["coord"], hist, None, None, num_nei_cells=int(np.abs(d["neighbor_dx"]).max()))
+        t.run_shards(pool, False, 2)
+        t.finish_optimizer()
+        t.merge_side_effects()
+        torch.cuda.synchronize()
+        extra = dict(n_main=t.dp.n_main, n_eik=t.dp.n_eik, n_halo=np.array(t.dp.n_halo), rows=np.array(stats["rows"]),
+                     boxes=t.dp.boxes, halo_rows=t.dp.halo_rows[:t.dp.n_halo].cpu().numpy(),
+                     owner=t.dp.owner[:stats["rows"]].cpu().numpy())
+        gsave = dict(gdec0=grads[0][:nd], gdec1=grads[1][:nd], ghalo0=grads[0][nd:], ghalo1=grads[1][nd:])
+    else:
+        t.reset_optimizer(2 if transport == "none" else None)  # one GPU: the lazy exact Adam, as Mapper.mapping runs it
+        t.begin_side_effects()
+        a, b = sharding.shard_range(bs, rank, world)
+        for it in range(2):
+            t.step_batch(U.dev(d[f"map_coord{it}"][a:b]), U.dev(d[f"map_label{it}"][a:b]), U.dev(d[f"map_w{it}"][a:b]),
+                         U.dev(d[f"map_ts{it}"][a:b], torch.int32), it + 1)
+        t.finish_optimizer()
+        t.merge_side_effects()
+        torch.cuda.synchronize()
+        gsave = dict(gdec0=grads[0][:nd], gfeat0=grads[0][nd:], gdec1=grads[1][:nd], gfeat1=grads[1][nd:])
     np.savez(out, feats=fs.feats.cpu().numpy(), dec=fs.dec.cpu().numpy(), cert=fs.certainty.cpu().numpy(),
-             tsu=tsu.cpu().numpy(), gdec0=grads[0][:nd], gfeat0=grads[0][nd:], gdec1=grads[1][:nd], gfeat1=grads[1][nd:],
-             kind=np.array(getattr(comm, "kind", "none")))
+             tsu=tsu.cpu().numpy(), kind=np.array(getattr(comm, "kind", "none")), **gsave, **extra)
     if comm is not None:
         comm.close()
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        if transport != "null":
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6],
+         *(sys.argv[7:8]))

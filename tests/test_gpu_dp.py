@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(tmp_path, world, transport, case):
+def _launch(tmp_path, world, transport, case, mode="dense"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    outs = [str(tmp_path / f"{transport}_{r}.npz") for r in range(world)]
+    outs = [str(tmp_path / f"{transport}_{mode}_{world}_{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_worker.py"), str(r), str(world), str(port), case,
-                               transport, outs[r]]) for r in range(world)]
+                               transport, outs[r], mode]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     return [np.load(o) for o in outs]
@@ -61,6 +61,51 @@ def test_two_ranks_reproduce_the_reference(tmp_path, case):
     clean = (np.abs(d["map_gfeat0"]) > 1e-4 * np.abs(d["map_gfeat0"]).max()) & \
             (np.abs(d["map_gfeat1"]) > 1e-4 * np.abs(d["map_gfeat1"]).max())
     assert np.abs(one["feats"] - r0["feats"])[clean].max() < 1e-4
+
+
+@pytest.mark.parametrize("case,world", [("c2_wf", 2), ("c3_bigtable", 2), ("c2_wf", 3)])
+def test_spatial_shards_reproduce_the_reference(tmp_path, case, world):
+    """The spatially sharded mapper (pin_slam_amd.dp): ranks that share cuda:0 cut the fixture's two batches by k-d boxes,
+    train their samples (lazy Adam on the rows they own), all-reduce [decoder | halo rows] per iteration (host-staged gloo,
+    the kernels around it are the product's) and publish their rows at the end.  Every rank must end with the SAME
+    model, bit for bit, and that model must be the reference's whole-batch result within the training bars."""
+    d = G.load(case)
+    rs = _launch(tmp_path, world, "host", case, "spatial")
+    bs = d["map_coord0"].shape[0]
+    dec = int(d["map_dec"])
+    for it in range(2):  # the boxes cut every batch into `world` parts: nothing lost, nothing doubled
+        assert sum(int(r["n_main"][it]) for r in rs) == bs
+        assert sum(int(r["n_eik"][it]) for r in rs) == (bs + dec - 1) // dec
+    for r in rs[1:]:
+        for key in ("feats", "dec", "cert", "tsu", "gdec0", "gdec1", "ghalo0", "ghalo1", "boxes", "halo_rows", "owner"):
+            assert np.array_equal(rs[0][key].view(np.uint8), r[key].view(np.uint8)), key
+    r0 = rs[0]
+    assert 0 < int(r0["n_halo"]) <= int(r0["rows"])
+    # the exchanged gradients are the reference's: decoder whole, feature rows on the halo
+    for it in range(2):
+        gd, gf = d[f"map_gdec{it}"], d[f"map_gfeat{it}"]
+        assert np.max(np.abs(r0[f"gdec{it}"] - gd)) < 1e-4 * np.abs(gd).max()
+        assert np.max(np.abs(r0[f"ghalo{it}"].reshape(-1, 8) - gf[r0["halo_rows"]])) < 1e-4 * np.abs(gf).max()
+    # the trained model against the reference's Mapper.mapping(2); the gradient noise estimate comes from the dense run
+    dense = _launch(tmp_path, 2, "host", case)[0]
+    _against_reference(d, r0, grads=dense)
+    clean = (np.abs(d["map_gfeat0"]) > 1e-4 * np.abs(d["map_gfeat0"]).max()) & \
+            (np.abs(d["map_gfeat1"]) > 1e-4 * np.abs(d["map_gfeat1"]).max())
+    assert np.abs(dense["feats"] - r0["feats"])[clean].max() < 1e-4
+
+
+def test_spatial_shards_over_rccl_single_rank(tmp_path):
+    """The spatial path through RCCL itself (pin_allreduce_f32 for the halo exchange and the owner merge): with one rank
+    every row is owned and private, the reductions are identities and the run must equal the reference."""
+    d = G.load("c2_wf")
+    (r,) = _launch(tmp_path, 1, "rccl", "c2_wf", "spatial")
+    assert str(r["kind"]) == "rccl" and int(r["n_halo"]) == 0
+    dense = _launch(tmp_path, 1, "none", "c2_wf")[0]
+    _against_reference(d, r, grads=_launch(tmp_path, 2, "host", "c2_wf")[0])
+    # = the single-GPU lazy Adam up to the order of the gradient atomics (the shard lists are unordered)
+    clean = (np.abs(d["map_gfeat0"]) > 1e-4 * np.abs(d["map_gfeat0"]).max()) & \
+            (np.abs(d["map_gfeat1"]) > 1e-4 * np.abs(d["map_gfeat1"]).max())
+    assert np.abs(dense["feats"] - r["feats"])[clean].max() < 1e-4
 
 
 def test_rccl_transport_single_rank(tmp_path):

@@ -28,6 +28,27 @@ def test_eikonal_shard_partition():
         assert len(picked) == sharding.n_eik_global(bs, dec)
 
 
+def test_kd_boxes_tile_the_grid_and_balance():
+    """pin_dp_kd_boxes (host code of libpinhip, pin_slam_amd.dp): the boxes of the spatially sharded mapper tile the voxel
+    grid -- every cell lies in exactly one -- split the samples they were cut from evenly, and equal the numpy statement of
+    the same split."""
+    from pin_slam_amd import dp
+    rng = np.random.default_rng(3)
+    r, th = 80 * np.sqrt(rng.random(6000)), 2 * np.pi * rng.random(6000)
+    cells = np.floor(np.stack([r * np.cos(th), r * np.sin(th), -2 + 12.8 * rng.random(6000)], 1) / 0.4).astype(np.int32)
+    far = np.array([[2 ** 30, -2 ** 30, 0], [-5000, 7, 123456], [0, 0, 0]], np.int32)
+    for world in (1, 2, 3, 5, 8, 16):
+        boxes = dp.kd_boxes(cells, world)
+        assert np.array_equal(boxes, dp.kd_boxes_numpy(cells, world))
+        inside = np.stack([np.all(cells >= b[:3], 1) & np.all(cells < b[3:], 1) for b in boxes.astype(np.int64)])
+        assert np.array_equal(inside.sum(0), np.ones(len(cells), int))  # exactly one box per sample
+        counts = inside.sum(1)
+        assert counts.max() - counts.min() <= 0.03 * len(cells) / world + 40, counts
+        assert np.all(dp.region_of_cells(boxes, far) >= 0)  # cells far outside the samples belong to some box too
+    for degenerate in (np.zeros((0, 3), np.int32), np.zeros((10, 3), np.int32)):
+        assert np.array_equal(dp.kd_boxes(degenerate, 4), dp.kd_boxes_numpy(degenerate, 4))
+
+
 def _shard_grad(d, rank, world):
     k = int(d["query_nn_k"])
     table = G.dense_table(d)
@@ -80,3 +101,20 @@ def test_two_rank_allreduce_equals_single_rank_gradient():
     one, loss1 = _shard_grad(d, 0, 1)
     assert np.max(np.abs(flat - one)) < 1e-9 * max(1.0, np.abs(one).max())
     assert abs(loss - loss1) < 1e-9
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's plain command form) must start two ranks itself and have them meet;
+    --dry-launch stops after the rendez-vous (gloo, CPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"dry_launch": True, "ranks": 2, "rank_sum": 3.0, "expected": 3.0}
