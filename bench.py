@@ -100,6 +100,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=2_000_000, help="samples in the pool (= pool_capacity)")
     ap.add_argument("--pretrain-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed kernels on the timed workload")
     ap.add_argument("--parallel", default="dp", choices=["dp", "replicas"],
                     help="N > 1: 'dp' (default) = the data-parallel mapper of config C4: a global batch of --global-bs "
                          "samples sharded over the ranks, one RCCL all-reduce of [decoder | feature] gradients per "
@@ -110,6 +111,9 @@ def parse():
                          "(pin_slam_amd.dp); dense = contiguous index shards, all-reduce of the whole gradient table")
     ap.add_argument("--dp-emulate", default="2,4,8", help="N = 1: world sizes whose single ranks are run alone on this GPU "
                                                           "(c4_per_rank_emulated; empty = skip)")
+    ap.add_argument("--emulate-rank", default="", help="W:r -- profiling aid: ONLY rank r of a W-rank data-parallel mapper, alone on "
+                                                        "this GPU with the identity exchange (1:0 = the single-GPU mapper); --steps "
+                                                        "calls of --map-iters iterations at --global-bs, one JSON line, exit")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendez-vous over gloo on the CPU, print one JSON line and exit (no GPU needed): "
                          "checks the launcher of `--gpus N`")
@@ -255,6 +259,25 @@ def main():
             return float(t.item())
         return x
 
+    if args.emulate_rank:
+        from pin_slam_amd import collective
+        W, r = (int(v) for v in args.emulate_rank.split(":"))
+        cfg.bs = args.global_bs
+        if W > 1:
+            mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = r, W, collective.NullComm(r, W), args.dp_mode
+        for _ in range(max(1, args.warmup)):
+            mp.mapping(args.map_iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mp.mapping(args.map_iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"emulated_rank": r, "world": W, "dp_mode": args.dp_mode if W > 1 else None, "global_batch": args.global_bs,
+                          "iterations_per_call": args.map_iters, "ms_per_call": round(1e3 * dt / args.steps, 4),
+                          "ms_per_iteration": round(1e3 * dt / (args.steps * args.map_iters), 4),
+                          "shards": getattr(mp, "dp_stats", None)}), flush=True)
+        return
     if mapper_dp:
         # the same workload on ONE GPU first, on this box in this run: the N = 1 point the N-rank value is set against
         for _ in range(max(1, args.pretrain_iters // 50)):
@@ -393,8 +416,8 @@ def main():
     # the benchmarked kernels -- brick kNN + the GN tile kernel -- on a sub-sample of the timed scan, against the
     # map as it stands after the timed frames
     parity_in = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k, rgb=state["rgb"])
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k, rgb=state["rgb"], mp=mp, cdec=cdec)
 
     # achievable HBM ceiling on this box: a 1 GiB device-to-device copy (read + write), outside the timed regions
     ca = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
@@ -522,9 +545,13 @@ def main():
         except Exception:
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(
+        out["cpu_baseline"] = cpu_baseline(
             m, cfg, scan_np, raw.cpu().numpy(), raw_ts.cpu().numpy(), pool_c, pool_l, m.features,
-            dec.flat_params().cpu().numpy(), H, L, k, dec.sdf_scale, args, parity_in)
+            dec.flat_params().cpu().numpy(), H, L, k, dec.sdf_scale, args)
+    out["parity"] = None
+    if parity_in is not None:
+        from oracle import pin_oracle as O  # the checker; never inside a timed region
+        out["parity"] = parity_vs_oracle(O, parity_in, H, L, k, dec.sdf_scale)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -532,11 +559,15 @@ def main():
         dist.destroy_process_group()
 
 
-def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None):
-    """Device side of bench.py's parity line: the timed kernels (brick kNN as the tracker launches it, then the
-    GN tile kernel with per-point outputs) on `n` points of the timed scan, plus a host copy of the map state
-    the oracle needs to answer the same queries."""
+def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None, mp=None, cdec=None, n_train=2048):
+    """Device side of bench.py's parity line, on the map as it stands after the timed frames: (i) the timed tracker kernels
+    -- brick kNN as the tracker launches it, then the GN tile kernel with per-point outputs (+ the colour query of the
+    photometric term) -- on `n` points of the timed scan; (ii) one training step of the timed shape -- pin_train_step
+    (+ the colour step) as Mapper.mapping launches it -- on the first `n_train` samples of the pool, into scratch
+    gradient / side-effect buffers.  Returns host copies of the outputs and of the map state the oracle needs."""
+    import dataclasses
     from pin_slam_amd import ops
+    cfg = npts.config
     q = xyz[:n].contiguous()
     nbr, nn, _ = npts.knn(q, True)
     fs = npts.field_state(dec, query_locally=True)
@@ -546,13 +577,48 @@ def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None):
     raw = nbr.cpu().numpy()[..., 3].view(np.int32)
     idx = np.where(raw >= 0, raw & ~0x40000000, raw)
     td = npts._travel()
-    return dict(q=q.cpu().numpy(), idx=idx, nn=nn.cpu().numpy(), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy(),
-                table=npts.buffer_pt_index.cpu().numpy().astype(np.int64), pos=npts.neural_points.cpu().numpy(),
-                ts_create=npts.point_ts_create.cpu().numpy(), travel=None if td is None else td.cpu().numpy(),
-                cur_ts=int(npts.cur_ts), diff=float(npts.diff_travel_dist_local), g2l=npts.global2local.cpu().numpy(),
-                lfeat=npts.local_geo_features.data.cpu().numpy(), lpos=npts.local_neural_points.cpu().numpy(),
-                dec=dec.flat_params().cpu().numpy(), dx=npts.neighbor_dx.cpu().numpy(), mv=float(npts.max_valid_dist2),
-                res=float(npts.resolution), valid_nn_k=int(gp.valid_nn_k))
+    g = dict(q=q.cpu().numpy(), idx=idx, nn=nn.cpu().numpy(), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy(),
+             table=npts.buffer_pt_index.cpu().numpy().astype(np.int64), pos=npts.neural_points.cpu().numpy(),
+             ts_create=npts.point_ts_create.cpu().numpy(), travel=None if td is None else td.cpu().numpy(),
+             cur_ts=int(npts.cur_ts), diff=float(npts.diff_travel_dist_local), g2l=npts.global2local.cpu().numpy(),
+             lfeat=npts.local_geo_features.data.cpu().numpy(), lpos=npts.local_neural_points.cpu().numpy(),
+             dec=dec.flat_params().cpu().numpy(), dx=npts.neighbor_dx.cpu().numpy(), mv=float(npts.max_valid_dist2),
+             res=float(npts.resolution), valid_nn_k=int(gp.valid_nn_k), weighted_first=bool(cfg.weighted_first))
+    fc = None
+    if cdec is not None:
+        fc = npts.field_state(cdec, query_locally=True, color=True)
+        col, _, _ = ops.color_query(fc, q, nbr, nn, want_grad=False)
+        g.update(color=col.cpu().numpy(), lcfeat=npts.local_color_features.data.cpu().numpy(), cdec=cdec.flat_params().cpu().numpy())
+    if mp is not None and mp.pool_sample_count >= n_train:
+        b = mp._pool().bufs[0]
+        coord, label = b["global_coord"][:n_train].contiguous(), b["sdf_label"][:n_train].contiguous()
+        wt, ts = b["weight"][:n_train].contiguous(), b["ts"][:n_train].contiguous()
+        st = npts.search_state()
+        cert, tsu = fs.certainty.clone(), npts.local_point_ts_update.clone()
+        fst = dataclasses.replace(fs, certainty=cert, dec_image=None)
+        gfeat, gdec = torch.zeros_like(fs.feats), torch.zeros_like(fs.dec)
+        dec_n = int(cfg.gradient_decimation)
+        eps = np.float32(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+        buf = ops.TrainBuffers(n_train, dec_n, k, fs.hidden, fs.levels, weighted_first=fs.weighted_first)
+        bricks = npts._use_bricks()
+        tf = bool(npts.temporal_local_map_on and npts.travel_dist is not None)
+        if bricks is not None and (bricks.mode[:2] != (tf, True) or npts.neighbor_K != bricks.cand_dx.shape[0]):
+            bricks = None
+        loss = ops.train_step(st, fst, buf, coord, label, wt, ts, cert, tsu, gfeat, gdec, sigma=mp.sdf_scale, weight_e=cfg.weight_e,
+                              eik_eps=eps, loss_weight_on=cfg.loss_weight_on, bricks=bricks)
+        g["train"] = dict(coord=coord.cpu().numpy(), label=label.cpu().numpy(), weight=wt.cpu().numpy(), gfeat=gfeat.cpu().numpy(),
+                          gdec=gdec.cpu().numpy(), loss=loss.cpu().numpy().copy(), n_eik=buf.n_eik, dec_n=dec_n, eps=float(eps),
+                          weight_e=float(cfg.weight_e), loss_weight_on=bool(cfg.loss_weight_on), sigma=float(mp.sdf_scale))
+        if fc is not None and cfg.weight_i > 0:
+            clab = b["color"][:n_train, :3].contiguous()
+            fct = dataclasses.replace(fc, certainty=cert, dec_image=None)
+            gc, gcd = torch.zeros_like(fc.feats), torch.zeros_like(fc.dec)
+            ops.train_color_step(fct, buf, label, clab, wt, gc, gcd, surface_range=cfg.surface_sample_range_m, weight_i=cfg.weight_i,
+                                 loss_weight_on=cfg.loss_weight_on)
+            g["train"].update(color_label=clab.cpu().numpy(), gcfeat=gc.cpu().numpy(), gcdec=gcd.cpu().numpy(),
+                              surface_range=float(cfg.surface_sample_range_m), weight_i=float(cfg.weight_i))
+        torch.cuda.synchronize()
+    return g
 
 
 def c4_single_gpu(args, cfg, mp):
@@ -725,7 +791,7 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
     }
 
 
-def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k, sdf_scale, args, parity_in=None):
+def cpu_baseline(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k, sdf_scale, args):
     """The numpy oracle (a port of the reference's torch-CPU chain) timed on a bounded sample of
     the same workload on this host; odometry and mapping are extrapolated linearly in the query
     count, the preprocess / map-prep stages are timed at full size (they are cheap)."""
@@ -798,28 +864,61 @@ def cpu_baseline_and_parity(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, de
                       f"{args.reg_iters}x{args.scan} + {args.map_iters}x{args.bs}; preprocess + map-prep stages once at "
                       f"full size ({t_prep:.1f} s); one host thread (host has {os.cpu_count()} cores)",
             "registration_queries_per_sec": round(n_s / t_reg, 1), "mapper_samples_per_sec": round(bs_s / t_tr, 1)}
-    return base, (None if parity_in is None else parity_vs_oracle(O, parity_in, H, L, k, sdf_scale))
+    return base
 
 
 def parity_vs_oracle(O, g, H, L, k, sdf_scale):
     """The oracle's answer to the queries of gpu_parity_sample() on the same map state (the checker; never timed)."""
-    s = O.radius_search(g["q"], g["table"], g["pos"], g["res"], g["dx"], g["mv"], ts_create=g["ts_create"],
-                        travel_dist=g["travel"], cur_ts=g["cur_ts"], diff_travel_dist_local=g["diff"])
+    wf = g["weighted_first"]
+
+    def search(p):
+        return O.radius_search(p, g["table"], g["pos"], g["res"], g["dx"], g["mv"], ts_create=g["ts_create"],
+                               travel_dist=g["travel"], cur_ts=g["cur_ts"], diff_travel_dist_local=g["diff"])
+
+    s = search(g["q"])
     qf = O.query_feature(g["q"], s, g["lfeat"], g["lpos"], None, k, global2local=g["g2l"])
     params = O.unpack_decoder(g["dec"], 11, H, L)
-    rs, rg, _, rnn, _ = O.query_sdf(g["q"], s, g["lfeat"], g["lpos"], params, sdf_scale, k, global2local=g["g2l"])
+    rs, rg, _, rnn, _ = O.query_sdf(g["q"], s, g["lfeat"], g["lpos"], params, sdf_scale, k, weighted_first=wf, global2local=g["g2l"])
     has = rnn >= g["valid_nn_k"]
     scale = float(np.abs(rs[has]).max()) if has.any() else 1.0
     gscale = np.abs(rg).max(1, keepdims=True) + 1e-6
-    return {"n_checked": int(len(g["q"])), "n_with_neighbours": int(has.sum()),
-            "idx_mismatch": int((g["idx"] != qf["knn_idx"].astype(np.int32)).sum()),
-            "nn_count_mismatch": int((g["nn"] != rnn).sum()),
-            "sdf_max_abs": float(np.abs(g["sdf"] - rs)[has].max()) if has.any() else None,
-            "sdf_max_rel": float(np.abs(g["sdf"] - rs)[has].max() / scale) if has.any() else None,
-            "grad_max_rel": float((np.abs(g["grad"] - rg) / gscale)[has].max()) if has.any() else None,
-            "definition": "brick kNN + GN tile kernel (the timed kernels) vs the numpy oracle (float64 decoder) on the first "
-                          "n_checked points of the timed scan and the map after the timed frames; sdf_max_rel = max |sdf - ref| "
-                          "/ max |ref|, grad_max_rel = max over points of |grad - ref| / max-component of ref; target 1e-4"}
+    out = {"n_checked": int(len(g["q"])), "n_with_neighbours": int(has.sum()),
+           "idx_mismatch": int((g["idx"] != qf["knn_idx"].astype(np.int32)).sum()),
+           "nn_count_mismatch": int((g["nn"] != rnn).sum()),
+           "sdf_max_abs": float(np.abs(g["sdf"] - rs)[has].max()) if has.any() else None,
+           "sdf_max_rel": float(np.abs(g["sdf"] - rs)[has].max() / scale) if has.any() else None,
+           "grad_max_rel": float((np.abs(g["grad"] - rg) / gscale)[has].max()) if has.any() else None,
+           "definition": "brick kNN + GN tile kernel (the timed kernels) vs the numpy oracle (float64 decoder) on the first "
+                         "n_checked points of the timed scan and the map after the timed frames; sdf_max_rel = max |sdf - ref| "
+                         "/ max |ref|, grad_max_rel = max over points of |grad - ref| / max-component of ref; train_*: one "
+                         "pin_train_step (+ colour step) of the timed shape on the first n_train pool samples, max |g - ref| / "
+                         "max |ref| over the feature rows / decoder parameters, relative error of the two loss terms; target 1e-4"}
+    if "color" in g:  # Decoder.regress_color of the photometric term (tracker.py:342-350)
+        cpar = O.unpack_decoder(g["cdec"], 11, H, L, 3)
+        rc, _, _ = O.query_color(g["q"], s, g["lcfeat"], g["lpos"], cpar, k, weighted_first=wf, global2local=g["g2l"])
+        out["color_max_abs"] = float(np.abs(g["color"] - rc)[rnn > 0].max())
+    t = g.get("train")
+    if t is not None:
+        def searcher(table_feats):
+            return lambda p: O.query_feature(p, search(p), table_feats, g["lpos"], None, k, global2local=g["g2l"], weighted_first=False)
+        r = O.train_step(t["coord"], t["label"], t["weight"], searcher(g["lfeat"]), g["lfeat"], g["lpos"], g["dec"], (11, H, L),
+                         t["sigma"], k, weighted_first=wf, dec=t["dec_n"], eps=t["eps"], weight_e=t["weight_e"],
+                         loss_weight_on=t["loss_weight_on"])
+        n_tr = len(t["label"])
+        out.update({"n_train": n_tr,
+                    "train_feat_grad_max_rel": float(np.abs(t["gfeat"] - r["feat_grad"]).max() / np.abs(r["feat_grad"]).max()),
+                    "train_dec_grad_max_rel": float(np.abs(t["gdec"] - r["dec_grad"]).max() / np.abs(r["dec_grad"]).max()),
+                    "train_rows_touched_mismatch": int(((np.abs(t["gfeat"]).max(1) > 0) != (np.abs(r["feat_grad"]).max(1) > 0)).sum()),
+                    "train_bce_loss_rel": float(abs(t["loss"][0] / n_tr - r["sdf_loss"]) / abs(r["sdf_loss"])),
+                    "train_eik_loss_rel": float(abs(t["loss"][1] / max(t["n_eik"], 1) - r["eik_loss"]) / abs(r["eik_loss"]))
+                                          if t["n_eik"] and r["eik_loss"] else None})
+        if "gcfeat" in t:
+            rc = O.train_color_step(t["coord"], t["label"], t["color_label"], t["weight"], searcher(g["lcfeat"]), g["lcfeat"], g["cdec"],
+                                    (11, H, L, 3), k, weighted_first=wf, surface_range=t["surface_range"], weight_i=t["weight_i"],
+                                    loss_weight_on=t["loss_weight_on"])
+            out.update({"train_color_feat_grad_max_rel": float(np.abs(t["gcfeat"] - rc["feat_grad"]).max() / np.abs(rc["feat_grad"]).max()),
+                        "train_color_dec_grad_max_rel": float(np.abs(t["gcdec"] - rc["dec_grad"]).max() / np.abs(rc["dec_grad"]).max())})
+    return out
 
 
 if __name__ == "__main__":

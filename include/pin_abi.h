@@ -737,11 +737,13 @@ int pin_dp_sample_cells(const float* pool_coord, const int64_t* index_history, i
  * positions i < n of the batch whose sample lies in box `rank` (any order), eik_sel_out[b][0 .. counts[b][1]) those
  * of them with i % decimation == 0 (the Eikonal sub-sample coord[::dec] of the GLOBAL batch, mapper.py:683).
  * counts_out [n_batches][2] is cleared here; an entry larger than cap / eik_cap means the lists are truncated
- * (grow and call again).  Index arrays as in pin_gather_batches_drawn. */
+ * (grow and call again).  Index arrays as in pin_gather_batches_drawn.  pool_region [pool_rows] (scratch, one byte per
+ * pool row): the box of every row of pool_coord is computed once, the draws then look it up. */
 int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coord, const int64_t* index_history, int32_t n_history,
                      const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t decimation,
                      int32_t n_batches, int64_t hist_stride, int64_t new_stride, int32_t* sel_out, int32_t cap,
-                     int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out, void* stream);
+                     int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out, int64_t pool_rows, uint8_t* pool_region,
+                     void* stream);
 
 /* Mapper.get_batch for the selected samples of n_batches drawn batches (b-th batch: sel / eik_sel / counts rows
  * b0 + b of pin_dp_partition's outputs): *_out[b][j] = pool row of batch position sel[b][j], j < counts[b][0];

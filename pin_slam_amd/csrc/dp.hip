@@ -75,41 +75,63 @@ __global__ __launch_bounds__(256) void dp_sample_cells_kernel(const float* __res
     cells[3 * s + 2] = clamp_cell(voxel_coord(pc[3 * row + 2], res));
 }
 
-// append the flagged lanes of a wave to a list: one counter update per wave, order inside the wave kept
-__device__ __forceinline__ void wave_append(bool flag, int value, int* __restrict__ counter, int* __restrict__ list, int cap) {
-    const unsigned long long bal = __ballot(flag);
-    if (bal == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(counter, __popcll(bal));
-    base = __shfl(base, (int)__ffsll((long long)bal) - 1, 64);
-    if (flag) {
-        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (pos < cap) list[pos] = value;
-    }
+// box of every POOL row, once per call: the partition below then reads one byte per drawn index (the 2 MB array
+// stays in L2) instead of gathering 12-byte coordinates and searching the boxes for each of iters x bs draws
+__global__ __launch_bounds__(256) void dp_pool_regions_kernel(pin_dp_regions rg, const float* __restrict__ pc, long n,
+                                                              unsigned char* __restrict__ region) {
+    __shared__ int sbox[6 * DP_MAX_WORLD];
+    load_boxes(rg, sbox);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cx = clamp_cell(voxel_coord(pc[3 * i], rg.resolution));
+    const int cy = clamp_cell(voxel_coord(pc[3 * i + 1], rg.resolution));
+    const int cz = clamp_cell(voxel_coord(pc[3 * i + 2], rg.resolution));
+    region[i] = (unsigned char)region_of(sbox, rg.world, cx, cy, cz);
 }
 
-__global__ __launch_bounds__(256) void dp_partition_kernel(pin_dp_regions rg, const float* __restrict__ pc,
+// A block walks PART_PER_THREAD x 256 consecutive batch positions, keeps its picks in LDS and appends them to the list with ONE
+// counter update (a counter update per wave -- 200k same-address atomics per call at 12 x 2^20 draws -- took 3.4 ms).
+constexpr int PART_PER_THREAD = 8;
+constexpr int PART_CHUNK = 256 * PART_PER_THREAD;
+
+__global__ __launch_bounds__(256) void dp_partition_kernel(int rank, const unsigned char* __restrict__ region,
                                                            const long long* __restrict__ index_hist, int n_hist,
                                                            const long long* __restrict__ index_new_batch,
                                                            const long long* __restrict__ new_idx, int n, int dec,
                                                            long hist_stride, long new_stride, int* __restrict__ sel, int cap,
                                                            int* __restrict__ esel, int ecap, int* __restrict__ counts) {
-    __shared__ int sbox[6 * DP_MAX_WORLD];
-    load_boxes(rg, sbox);
+    __shared__ int picks[PART_CHUNK], epicks[PART_CHUNK];
+    __shared__ int n_pick, n_epick, base, ebase;
+    if (threadIdx.x == 0) { n_pick = 0; n_epick = 0; }
+    __syncthreads();
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool mine = false;
-    if (i < n) {
-        const size_t row = drawn_row(index_hist + (size_t)b * hist_stride, n_hist,
-                                     index_new_batch ? index_new_batch + (size_t)b * new_stride : nullptr, new_idx, i);
-        const int cx = clamp_cell(voxel_coord(pc[3 * row], rg.resolution));
-        const int cy = clamp_cell(voxel_coord(pc[3 * row + 1], rg.resolution));
-        const int cz = clamp_cell(voxel_coord(pc[3 * row + 2], rg.resolution));
-        mine = region_of(sbox, rg.world, cx, cy, cz) == rg.rank;
+    index_hist += (size_t)b * hist_stride;
+    if (index_new_batch != nullptr) index_new_batch += (size_t)b * new_stride;
+    const int lane = threadIdx.x & 63;
+    for (int r = 0; r < PART_PER_THREAD; ++r) {
+        const int i = blockIdx.x * PART_CHUNK + r * 256 + threadIdx.x;
+        bool mine = false;
+        if (i < n) mine = region[drawn_row(index_hist, n_hist, index_new_batch, new_idx, i)] == rank;
+        const bool eik = mine && ecap > 0 && (i % dec) == 0;
+        const unsigned long long bal = __ballot(mine), ebal = __ballot(eik);
+        int wbase = 0, webase = 0;
+        if (lane == 0 && bal) wbase = atomicAdd(&n_pick, __popcll(bal));     // (LDS atomics: cheap)
+        if (lane == 0 && ebal) webase = atomicAdd(&n_epick, __popcll(ebal));
+        wbase = __shfl(wbase, 0, 64);
+        webase = __shfl(webase, 0, 64);
+        if (mine) picks[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        if (eik) epicks[webase + __popcll(ebal & ((1ull << lane) - 1ull))] = i;
     }
-    wave_append(mine, i, counts + 2 * b, sel + (size_t)b * cap, cap);
-    if (ecap > 0) wave_append(mine && (i % dec) == 0, i, counts + 2 * b + 1, esel + (size_t)b * ecap, ecap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base = n_pick ? atomicAdd(counts + 2 * b, n_pick) : 0;
+        ebase = n_epick ? atomicAdd(counts + 2 * b + 1, n_epick) : 0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_pick; j += 256)
+        if (base + j < cap) sel[(size_t)b * cap + base + j] = picks[j];
+    for (int j = threadIdx.x; j < n_epick; j += 256)
+        if (ebase + j < ecap) esel[(size_t)b * ecap + ebase + j] = epicks[j];
 }
 
 __global__ __launch_bounds__(256) void dp_gather_kernel(const float* __restrict__ pc, const float* __restrict__ pl,
@@ -309,9 +331,10 @@ extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coor
                                 int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
                                 int32_t decimation, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
                                 int32_t* sel_out, int32_t cap, int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out,
-                                void* stream) {
+                                int64_t pool_rows, uint8_t* pool_region, void* stream) {
     PIN_ENTER();
     if (int e = check_regions(rg)) return e;
+    PIN_CHECK_ARG(pool_rows >= 0 && (pool_rows == 0 || pool_region), "pool_region NULL");
     PIN_CHECK_ARG(n >= 0 && n_history >= 0 && n_history <= n && decimation >= 1 && n_batches >= 0 && n_batches <= 65535 &&
                       cap >= 0 && eik_cap >= 0, "bad sizes");
     if (n_batches == 0) return 0;
@@ -321,7 +344,10 @@ extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coor
     PIN_CHECK_ARG(pool_coord && sel_out && (eik_cap == 0 || eik_sel_out) && (n_history == 0 || index_history), "NULL pointer");
     PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
     PIN_CHECK_ARG(n_batches == 1 || (hist_stride >= n_history && new_stride >= n - n_history), "index strides shorter than a batch");
-    hipLaunchKernelGGL(dp_partition_kernel, dim3(cdiv(n, 256), n_batches), dim3(256), 0, as_stream(stream), *rg, pool_coord,
+    hipLaunchKernelGGL(dp_pool_regions_kernel, dim3(cdiv(pool_rows, 256)), dim3(256), 0, as_stream(stream), *rg, pool_coord,
+                       (long)pool_rows, pool_region);
+    PIN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dp_partition_kernel, dim3(cdiv(n, PART_CHUNK), n_batches), dim3(256), 0, as_stream(stream), rg->rank, pool_region,
                        reinterpret_cast<const long long*>(index_history), n_history,
                        reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), n,
                        decimation, (long)hist_stride, (long)new_stride, sel_out, cap, eik_sel_out, eik_cap, counts_out);

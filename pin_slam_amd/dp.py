@@ -105,7 +105,7 @@ class SpatialShards:
         self.sel = self.esel = self.counts = None
         self.cap = self.ecap = 0
         self.counts_host = None
-        self._ws = None
+        self._ws = self._pool_region = None
         self.fixed_boxes: Optional[np.ndarray] = None  # tests may pin the partition
         self.stats = {}
 
@@ -124,7 +124,7 @@ class SpatialShards:
 
     def plan(self, pool_coord: torch.Tensor, hist: torch.Tensor, new: Optional[torch.Tensor], new_idx, *, decimation: int,
              eikonal: bool, resolution: float, reach: int, pos: torch.Tensor, lazy_pending: Optional[torch.Tensor],
-             nd: int):
+             nd: int, pool_rows: Optional[int] = None):
         """Everything a Mapper.mapping call needs before its first iteration: boxes from a sub-sample of the first drawn
         batch (host, one small read-back), the halo of the feature rows at `pos`, the partition of ALL drawn batches
         (hist [iters][n_hist] / new [iters][n_new] int64, as Mapper._draw_all makes them) and its counts (second
@@ -176,9 +176,12 @@ class SpatialShards:
                 self.sel = torch.empty((max(iters, 1) * self.cap,), dtype=torch.int32, device=self.device)
                 self.esel = torch.empty((max(iters, 1) * max(self.ecap, 1),), dtype=torch.int32, device=self.device)
             ecap = self.ecap if eikonal else 0
+            pool_rows = pool_coord.shape[0] if pool_rows is None else int(pool_rows)
+            if self._pool_region is None or self._pool_region.shape[0] < pool_rows:
+                self._pool_region = torch.empty((int(pool_rows * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
             check(L.pin_dp_partition(C.byref(rg), pool_coord.data_ptr(), hp, n_hist, npn, nip, n, int(decimation), iters, hs, ns,
-                                     self.sel.data_ptr(), self.cap, self.esel.data_ptr(), ecap, self.counts.data_ptr(), s),
-                  "pin_dp_partition")
+                                     self.sel.data_ptr(), self.cap, self.esel.data_ptr(), ecap, self.counts.data_ptr(), pool_rows,
+                                     self._pool_region.data_ptr(), s), "pin_dp_partition")
             ch = self.counts_host
             ch[:2 * iters].copy_(self.counts[:iters].reshape(-1), non_blocking=True)
             ch[2 * iters:2 * iters + 1].copy_(self._cnt, non_blocking=True)
@@ -207,7 +210,7 @@ class SpatialShards:
             self.hv[:8 * self.n_halo].zero_()
         self.nd = nd
         self.stats = dict(rows=rows, halo_rows=self.n_halo, halo_fraction=self.n_halo / max(rows, 1),
-                          exchange_bytes=4 * nx, samples_min=int(self.n_main.min(initial=0)), samples_max=int(self.n_main.max(initial=0)),
+                          exchange_bytes=4 * nx, samples_min=int(self.n_main.min()) if iters else 0, samples_max=int(self.n_main.max()) if iters else 0,
                           samples_ideal=n / self.world)
         self._hist, self._new, self._new_idx, self._pool_coord = hist, new, new_idx, pool_coord
         return self

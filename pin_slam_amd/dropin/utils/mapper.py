@@ -470,7 +470,7 @@ class Mapper(_Base):
             b = p.bufs[0]
             gc = not self.ba_done_flag
             self.dp_stats = t.plan_shards(b["global_coord"] if gc else b["coord"], drawn["hist"], drawn["new"], self.new_idx,
-                                          num_nei_cells=c.num_nei_cells)
+                                          num_nei_cells=c.num_nei_cells, pool_rows=p.n)
             t.run_shards(b, gc, iter_count)
             self.total_iter += iter_count
         t.finish_optimizer()

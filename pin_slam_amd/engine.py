@@ -233,7 +233,7 @@ class MapTrainer:
         self.fc, self.c_range, self.c_weight, self.c_train_dec = fc, float(surface_range), float(weight_i), train_decoder
 
     # ------------------------------------------------------------------ spatially sharded data-parallel mapping (dp.py)
-    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int):
+    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None):
         """Start of a spatially sharded Mapper.mapping call, after reset_optimizer(): boxes, halo, this rank's samples of
         every drawn batch (SpatialShards.plan) and buffers of the size that came out."""
         dp, fs = self.dp, self.fs
@@ -242,7 +242,7 @@ class MapTrainer:
         reach = int(num_nei_cells) + (int(np.ceil(float(self.eik_eps) / res - 1e-9)) if eik else 0)
         nd = self.m.numel() - fs.feats.numel()
         dp.plan(pool_coord, hist, new, new_idx, decimation=self.dec, eikonal=eik, resolution=res, reach=reach, pos=fs.pos,
-                lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd)
+                lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd, pool_rows=pool_rows)
         self.gdec = dp.xbuf[:nd]  # the decoder gradient lives at the head of the exchange buffer
         b = self.buf
         if b is None or b.cap_main < dp.cap or b.cap_eik < dp.eik_cap or (dp.eik_cap == 0) != (b.cap_eik == 0):

@@ -31,16 +31,12 @@ def _ptr(t: Optional[torch.Tensor], dtype=None):
     return t.data_ptr()
 
 
-_device_index = None
-
-
 def _stream():
-    """Raw handle of torch's current stream.  (torch.cuda.current_stream() builds a Stream object through several
-    Python layers, ~5 us a call -- four calls per training iteration; the raw getter is what it ends in.)"""
-    global _device_index
-    if _device_index is None:
-        _device_index = torch.cuda.current_device()  # one device per process (bench.py / torchrun: LOCAL_RANK)
-    return torch._C._cuda_getCurrentRawStream(_device_index)
+    """Raw handle of torch's current stream ON THE CURRENT DEVICE.  (torch.cuda.current_stream() builds a Stream object
+    through several Python layers, ~5 us a call -- four calls per training iteration; the two raw getters are what it ends
+    in.  The device is looked up on every call: a rank that calls torch.cuda.set_device after its first op must not keep
+    launching on the stream of the device it started on.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def spatial_sort(points: torch.Tensor, cell: float, return_perm: bool = False):

@@ -100,7 +100,7 @@ def make_pool(m: SynthMap, n=2_000_000, sigma=0.25, seed=2, radius=None):
     return coord, label
 
 
-def init_decoder(hidden, levels, in_dim=11, seed=42):
+def init_decoder(hidden, levels, in_dim=11, seed=42, out_dim=1):
     """nn.Linear default init (uniform +-1/sqrt(fan_in)) in state_dict order, flat."""
     rng = np.random.default_rng(seed)
     out, d = [], in_dim
@@ -109,5 +109,5 @@ def init_decoder(hidden, levels, in_dim=11, seed=42):
         out += [rng.uniform(-b, b, hidden * d), rng.uniform(-b, b, hidden)]
         d = hidden
     b = 1.0 / np.sqrt(d)
-    out += [rng.uniform(-b, b, d), rng.uniform(-b, b, 1)]
+    out += [rng.uniform(-b, b, out_dim * d), rng.uniform(-b, b, out_dim)]
     return np.concatenate(out).astype(np.float32)
