@@ -727,6 +727,12 @@ typedef struct pin_dp_regions {
  * of the same drawn batch and gets the same boxes without an exchange. */
 int pin_dp_kd_boxes(const int32_t* cells_host, int32_t n, int32_t world, int32_t* boxes_out_host);
 
+/* Rank 0's boxes become everybody's (a rank whose host computed something else -- a pool that differs in one bit -- must
+ * not run with a different halo: the all-reduce sizes would disagree): every int32 coordinate travels as two fp32 halves
+ * (v >> 16 and v & 0xffff, both exact in fp32), rank 0 sends them and the others send zeros through pin_allreduce_f32;
+ * this decodes halves [world][6][2] into boxes_out [world][6] on the device. */
+int pin_dp_boxes_decode(const float* halves, int32_t world, int32_t* boxes_out, void* stream);
+
 /* Voxel coordinates of every `stride`-th sample of one drawn batch (positions s*stride < n of the batch that
  * pin_gather_batch_drawn would gather): cells_out [n_out][3] int32 -- what the host cuts its k-d boxes from. */
 int pin_dp_sample_cells(const float* pool_coord, const int64_t* index_history, int32_t n_history,

@@ -216,6 +216,7 @@ SIGNATURES = {
     "pin_allreduce_grads": (i32, [vp, vp, i64, vp]),
     "pin_allreduce_f32": (i32, [vp, vp, vp, i64, vp]),
     "pin_dp_kd_boxes": (i32, [vp, i32, i32, vp]),
+    "pin_dp_boxes_decode": (i32, [vp, i32, vp, vp]),
     "pin_dp_sample_cells": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
     "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp]),
     "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,

@@ -246,6 +246,12 @@ __global__ __launch_bounds__(256) void dp_owner_pack_kernel(const unsigned char*
     for (; i < n; i += stride) out[i] = owner[i >> 3] == rank ? feats[i] : 0.f;
 }
 
+// int32 box coordinates back from the two exactly representable fp32 halves they travelled in (pin_dp_boxes_decode)
+__global__ void dp_boxes_decode_kernel(const float* __restrict__ halves, int n, int* __restrict__ boxes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) boxes[i] = (int)(((unsigned)(int)halves[2 * i] << 16) | ((unsigned)(int)halves[2 * i + 1] & 0xffffu));
+}
+
 int check_regions(const pin_dp_regions* rg) {
     PIN_CHECK_ARG(rg && rg->boxes, "NULL regions");
     PIN_CHECK_ARG(rg->world >= 1 && rg->world <= DP_MAX_WORLD && rg->rank >= 0 && rg->rank < rg->world, "bad rank / world (<= 64)");
@@ -307,6 +313,14 @@ extern "C" int pin_dp_kd_boxes(const int32_t* cells_host, int32_t n, int32_t wor
         for (int a = 0; a < 3; ++a) v[i].c[a] = cells_host[3 * i + a];
     const int lo[3] = {INT_MIN, INT_MIN, INT_MIN}, hi[3] = {INT_MAX, INT_MAX, INT_MAX};
     kd_split(v.data(), v.data() + n, 0, world, lo, hi, boxes_out_host);
+    return 0;
+}
+
+extern "C" int pin_dp_boxes_decode(const float* halves, int32_t world, int32_t* boxes_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(halves && boxes_out && world >= 1 && world <= DP_MAX_WORLD, "bad arguments");
+    hipLaunchKernelGGL(dp_boxes_decode_kernel, dim3(cdiv(6 * world, 64)), dim3(64), 0, as_stream(stream), halves, 6 * world, boxes_out);
+    PIN_CHECK_LAUNCH();
     return 0;
 }
 

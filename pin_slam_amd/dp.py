@@ -105,7 +105,7 @@ class SpatialShards:
         self.sel = self.esel = self.counts = None
         self.cap = self.ecap = 0
         self.counts_host = None
-        self._ws = self._pool_region = None
+        self._ws = self._pool_region = self._halves = self._halves_host = None
         self.fixed_boxes: Optional[np.ndarray] = None  # tests may pin the partition
         self.stats = {}
 
@@ -149,8 +149,24 @@ class SpatialShards:
             torch.cuda.current_stream().synchronize()
             boxes = kd_boxes(self._cells_host[:n_out].numpy(), self.world)
         self.boxes = boxes
-        self._boxes_host.copy_(torch.from_numpy(boxes))
-        self.boxes_dev.copy_(self._boxes_host, non_blocking=True)
+        if self.world > 1 and getattr(self.comm, "kind", "").startswith("none"):
+            self._boxes_host.copy_(torch.from_numpy(boxes))  # (a rank emulated alone: nobody to agree with)
+            self.boxes_dev.copy_(self._boxes_host, non_blocking=True)
+        else:
+            # rank 0's boxes are everybody's: exact fp32 halves through the all-reduce (pin_dp_boxes_decode)
+            if self._halves is None:
+                self._halves = torch.zeros((self.world * 12,), dtype=torch.float32, device=self.device)
+                self._halves_host = torch.zeros((self.world * 12,), dtype=torch.float32).pin_memory()
+            hh = self._halves_host.numpy().reshape(-1, 2)
+            if self.rank == 0:
+                v = boxes.astype(np.int64).reshape(-1)
+                hh[:, 0], hh[:, 1] = (v >> 16).astype(np.float32), (v & 0xFFFF).astype(np.float32)
+            else:
+                hh[:] = 0.0
+            self._halves.copy_(self._halves_host, non_blocking=True)
+            if self.world > 1:
+                self.comm.allreduce(self._halves, self._halves)
+            check(L.pin_dp_boxes_decode(self._halves.data_ptr(), self.world, self.boxes_dev.data_ptr(), s), "pin_dp_boxes_decode")
         rg = self.regions(resolution, reach)
         # ---- halo of the feature rows
         rows = pos.shape[0]

@@ -30,7 +30,13 @@ def main(rank, world, port, case, transport, out, mode="dense"):
     bs = d["map_coord0"].shape[0]
     t = engine.MapTrainer(st, fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
                           weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
-                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm, dp_mode=mode)
+                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm,
+                          dp_mode=mode.split("-")[0])
+    if mode == "spatial-skew" and rank != 0:
+        # this rank's HOST comes up with other boxes than rank 0's: it must still run with rank 0's (pin_dp_boxes_decode)
+        from pin_slam_amd import dp as dpm
+        t.dp.fixed_boxes = dpm.kd_boxes(np.floor(d["map_coord1"][::3] / d["resolution"]).astype(np.int32) + 2, world)
+    mode = mode.split("-")[0]
     grads = []
     t.on_grads = lambda g: grads.append(g.cpu().numpy().copy())
     nd = fs.dec.numel()
