@@ -114,6 +114,9 @@ def parse():
     ap.add_argument("--emulate-rank", default="", help="W:r -- profiling aid: ONLY rank r of a W-rank data-parallel mapper, alone on "
                                                         "this GPU with the identity exchange (1:0 = the single-GPU mapper); --steps "
                                                         "calls of --map-iters iterations at --global-bs, one JSON line, exit")
+    ap.add_argument("--coherent-probe", action="store_true",
+                    help="one extra registration, synchronised per iteration: pose step and share of the queries on the coherent "
+                         "search path per Gauss-Newton iteration (knn_coherent_probe in the line)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendez-vous over gloo on the CPU, print one JSON line and exit (no GPU needed): "
                          "checks the launcher of `--gpus N`")
@@ -401,6 +404,13 @@ def main():
     host_ms = {n: round(1e3 * float(np.mean([h[i + 1] - h[i] for h in host_marks])), 3) for i, n in enumerate(names)}
     pool_now, new_now, n_src = mp.pool_sample_count, (0 if mp.new_idx is None else int(mp.new_idx.shape[0])), int(state["src"].shape[0])
 
+    probe = None
+    if args.coherent_probe:
+        probe = []
+        gnp = trk._engine(state["xyz"].shape[0], gp, cfg.reg_lm_lambda)
+        gnp.track(state["xyz"], T_init, args.reg_iters, early_exit=False, probe=probe)
+        for r in probe:
+            r.pop("_T")
     # the reference's own odometry workload: register the source-down-sampled subset (reported, not `value`)
     elapsed_ds = None
     if not args.skip_downsampled:
@@ -499,6 +509,7 @@ def main():
         "frames_per_sec_source_downsampled": None if elapsed_ds is None else round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
+        "knn_coherent_probe": probe,
         "c4_single_gpu": c4,
         "c4_per_rank_emulated": c4_emul,
         "roofline": {"kernel": ("gn_accumulate_quad_kernel<COLOR> (SDF + colour decoders on two split-fp16 images, photometric rows)"

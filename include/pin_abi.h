@@ -336,6 +336,17 @@ int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, v
 int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n,
                int32_t k, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
                void* stream);
+/* pin_gn_knn through the brick cache, COHERENT across the iterations of one registration: the source points are searched
+ * ~50 times under a pose that moves less and less.  iteration 0: the full search, which also leaves, per query, where it
+ * stood, its k winners (entry offset | candidate number << 24; coh_win [n][8] uint32) and a margin -- how far it may move
+ * before its voxel, the set of accepted candidates or the set of winners can change (coh_state [n][4] f32 = position,
+ * margin squared).  iteration > 0: a query that stands within its margin re-measures only its winners and re-ranks them --
+ * the same record, bit for bit, as the full search (its nn_count_out entry is left as it stands); the others take the full
+ * search, which renews their state.  The state is valid for one (src, map, brick cache) and as long as nbr_out /
+ * nn_count_out are the buffers of the previous iteration. */
+int pin_gn_knn_coherent(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
+                        const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, float* coh_state,
+                        uint32_t* coh_win, int32_t iteration, void* stream);
 /* the two halves of pin_gn_accumulate_solve, separately launchable (bench.py brackets the
  * accumulate kernel with HIP events) */
 int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,

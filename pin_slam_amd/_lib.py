@@ -160,6 +160,7 @@ SIGNATURES = {
     "pin_decoder_image_bytes": (i64, [i32, i32]),
     "pin_stage_decoder": (i32, [P(Field), vp, i64, vp]),
     "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_gn_knn_coherent": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_gn_solve": (i32, [vp, vp, P(GnLoopParams), vp]),
     "pin_gn_accumulate_solve": (i32, [P(Field), P(GnParams), P(ColorTerm), P(GnLoopParams), vp, vp, vp, vp, i32, vp, vp, vp]),

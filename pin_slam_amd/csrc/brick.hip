@@ -222,15 +222,33 @@ __device__ __forceinline__ unsigned int knn_cell_offset(const unsigned short* __
 // compares heads -- 26.2 vs 26.8 us, not worth the refill logic; FOUR lanes per query with 21 candidates each -- 35 %
 // fewer instructions per query on paper, 30.6 vs 26.3 us measured: at 104 registers the kernel keeps too few waves
 // in flight for its entry gathers.)
-template <int R>
+// COHERENT SEARCH ACROSS GAUSS-NEWTON ITERATIONS (pin_gn_knn_coherent; knn_brick_kernel<R, true>).  Tracker.tracking searches the same source
+// points 50 times under a pose that soon moves by micrometres (utils/tracker.py:114-184).  A full search leaves per query
+// (i) where it stood, (ii) the entry offsets + candidate numbers of its k winners and (iii) a MARGIN: how far the query may
+// move before anything about its result can change -- its voxel (distance to the nearest cell face), the set of accepted
+// candidates (every candidate's distance to the acceptance radius) and the set of winners (gap between the k-th and the
+// (k+1)-th accepted distance); a query's move of delta changes every distance by at most delta.  In a later iteration a
+// query (8 lanes) that stands within its margin re-measures ONLY its k winners and re-ranks them on (distance bits, candidate
+// number) -- the same record, bit for bit, as the full search would write (same entries, same distance arithmetic, same tie
+// rule); a wave whose eight queries all do so is done after that, any other wave takes its remaining queries through the
+// full search, which renews their state.
+// (Measured and not kept: a pre-pass kernel that sends the queries outside their margins to a worklist for a compacted
+// full search -- with ~1 % of the queries on the list the second launch still costs the ~12 us latency chain of one wave,
+// and the pre-pass ~10 us of its own: no gain over the plain search.)
+constexpr unsigned int COH_NONE = 0xffffffffu;
+template <int R, bool COH>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,
                                                                 float* __restrict__ query_out, float4* __restrict__ nbr,
-                                                                int* __restrict__ nn_count, const double* __restrict__ state) {
+                                                                int* __restrict__ nn_count, const double* __restrict__ state,
+                                                                float4* __restrict__ coh_state, unsigned int* __restrict__ coh_win,
+                                                                int coh_mode) {
     constexpr int G = 8;
-    __shared__ unsigned short lut[512];
-    __shared__ unsigned int cpack[128];                 // candidate -> (dx + nd) | (dy + nd) << 3 | (dz + nd) << 6
-    __shared__ uint4 hdr[BRICK_BLOCK / G][8];           // per query: its 2x2x2 window bricks
+    // the tables are per WAVE: nothing in this kernel crosses a wave, so there is no block barrier (and a wave on the
+    // coherent path leaves without keeping anybody waiting)
+    __shared__ unsigned short lut_all[BRICK_BLOCK / 64][512];
+    __shared__ unsigned int cpack_all[BRICK_BLOCK / 64][128];  // candidate -> (dx + nd) | (dy + nd) << 3 | (dz + nd) << 6
+    __shared__ uint4 hdr[BRICK_BLOCK / G][8];                  // per query: its 2x2x2 window bricks
     if (state != nullptr) {
         if (state[PIN_GN_STATE_DONE] != 0.0) return;  // (block-uniform)
 #pragma unroll
@@ -238,14 +256,12 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         pose.on = 1;
     }
     const int nd = bc.n_dilate;
-    reinterpret_cast<unsigned int*>(lut)[threadIdx.x] = reinterpret_cast<const unsigned int*>(KNN_LUT.v)[threadIdx.x];
-    if (threadIdx.x < 128) {
-        const int c = threadIdx.x < sp.n_cand ? threadIdx.x : 0;
-        cpack[threadIdx.x] = (unsigned int)((bc.cand_dx[3 * c] + nd) | ((bc.cand_dx[3 * c + 1] + nd) << 3) | ((bc.cand_dx[3 * c + 2] + nd) << 6));
-    }
     const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const int wlane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned short* const lut = lut_all[wv];
+    unsigned int* const cpack = cpack_all[wv];
     const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
-    const bool active = qi < n;
+    bool active = qi < n;
     const int qq = active ? qi : n - 1;
     float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
     if (pose.on) {
@@ -256,6 +272,38 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         qx = tx; qy = ty; qz = tz;
         if (query_out != nullptr && active && sub == 0) {
             query_out[3 * qi + 0] = qx; query_out[3 * qi + 1] = qy; query_out[3 * qi + 2] = qz;
+        }
+    }
+    const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+    if (COH && coh_mode == 2) {
+        const float4 st = coh_state[qq];  // (where the last full search of this query stood, its margin squared)
+        const float ex = qx - st.x, ey = qy - st.y, ez = qz - st.z;
+        const bool near = active && (ex * ex + ey * ey + ez * ez) < st.w;
+        if (near) {  // lane t re-measures winner t and finds its rank among the eight
+            const unsigned int w = coh_win[(size_t)qq * G + sub];
+            const bool has = w != COH_NONE;
+            const float4 Ew = entries[has ? (w & 0xffffffu) : (unsigned int)bc.max_entries];
+            const float dx = Ew.x - qx, dy = Ew.y - qy, dz = Ew.z - qz;
+            const unsigned int db = has ? __float_as_uint(dist2_exact(dx, dy, dz)) : 0xffffffffu;
+            const unsigned int cb = has ? (w >> 24) : (0x100u + (unsigned int)sub);  // (empty slots rank behind, in lane order)
+            int rank = 0;
+#pragma unroll
+            for (int j = 1; j < G; ++j) {  // (xor patterns below 8 stay inside the query's eight lanes, all of them here)
+                const unsigned int od = (unsigned int)__shfl_xor((int)db, j, 64), oc = (unsigned int)__shfl_xor((int)cb, j, 64);
+                rank += (od < db || (od == db && oc < cb)) ? 1 : 0;
+            }
+            if (rank < k) nbr[(size_t)qq * k + rank] = has ? make_float4(-dx, -dy, -dz, Ew.w) : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            // (nn_count stands: the set of accepted candidates has not changed)
+        }
+        active = active && !near;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;  // nobody left for the full search
+    }
+    {   // this wave's copies of the two tables
+        reinterpret_cast<uint4*>(lut)[wlane] = reinterpret_cast<const uint4*>(KNN_LUT.v)[wlane];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ci = wlane + 64 * h, c = ci < sp.n_cand ? ci : 0;
+            cpack[ci] = (unsigned int)((bc.cand_dx[3 * c] + nd) | ((bc.cand_dx[3 * c + 1] + nd) << 3) | ((bc.cand_dx[3 * c + 2] + nd) << 6));
         }
     }
     // floor(q / res) as in voxel_coord (IEEE division); the cached path works on 32-bit cell coordinates, anything
@@ -280,8 +328,9 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         hdr[grp][sub] = make_uint4((unsigned int)bi.base, bi.lo, bi.hi, (unsigned int)bi.base + (unsigned int)__popc(bi.lo));
     }
     const bool general = __builtin_amdgcn_ballot_w64(uncached) != 0ull;  // some window brick of the wave is not cached
-    __syncthreads();
-    const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tables and header rows were written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const char* const hrow = reinterpret_cast<const char*>(&hdr[grp][0]);
     const unsigned int sentinel = (unsigned int)bc.max_entries;
 
@@ -298,6 +347,7 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         E[r] = entries[off];
     }
     int cnt = 0;
+    float m_acc = __builtin_inff();  // COH: min over the candidates of |d2 - R^2| (how close anything is to being accepted / rejected)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
@@ -305,6 +355,7 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         const bool acc = !(d2 > sp.max_valid_dist2);  // (the sentinel gives +inf)
         d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;  // d2 >= 0: the bit pattern orders like the value
         cnt += acc ? 1 : 0;
+        if (COH) m_acc = fminf(m_acc, fabsf(d2 - sp.max_valid_dist2));
     }
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
     const long long gx = (long long)fx, gy = (long long)fy, gz = (long long)fz;  // (used by the exact probe only)
@@ -332,6 +383,8 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     // k rounds of an 8-lane tournament on (d2 bits, candidate order): two 32-bit group reductions
     // on the DPP path per round (no LDS crossbar, no 64-bit keys); lane t remembers winner t
     int mine = -1;
+    unsigned int d_last = 0u;  // COH: distance bits of the last winner found
+    int n_win = 0;
     for (int t = 0; t < k; ++t) {
         unsigned int bd = d2b[0];
         int br = 0;
@@ -340,6 +393,8 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
             if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
         const unsigned int wd = group_min_u32<G>(bd);
         if (wd == 0xffffffffu) break;
+        d_last = wd;
+        ++n_win;
         const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
         const unsigned int wc = group_min_u32<G>(myc);
         if (myc == wc) {  // exactly one lane of the group
@@ -367,6 +422,39 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
             rec = make_float4(-dx, -dy, -dz, __int_as_float(l));
         }
         if (active && sub < k) nbr[(size_t)qq * k + sub] = rec;
+        if (COH && coh_mode != 0) {
+            // what the coherent path of a later iteration needs: lane t's winner (entry offset | candidate << 24) ...
+            const bool cached = mine >= 0 && !far && (int)hdr[grp][lut[T] >> 10].x >= 0;
+            const unsigned int off = cached ? knn_cell_offset(lut, hrow, T, sentinel) : 0u;
+            const bool bad = (mine >= 0 && !cached) || off >= 0x1000000u;  // a winner from the exact probe: no entry to come back to
+            // ... and the margin.  The winners stay the winners while the query moves less than half the gap between the k-th
+            // and the (k+1)-th accepted distance; a candidate at distance s crosses the acceptance radius Rv after
+            // |s - Rv| = |d - Rv^2| / (s + Rv) >= |d - Rv^2| / (3 Rv) while s <= 2 Rv, and is more than Rv away otherwise.
+            const float Rv = sqrtf(sp.max_valid_dist2);
+            unsigned int d_next = 0xffffffffu;  // the (k+1)-th accepted distance, if the list was full
+            if (n_win == k) {
+                unsigned int bd = d2b[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) bd = min(bd, d2b[r]);
+                d_next = group_min_u32<G>(bd);
+            }
+            float m_sel = __builtin_inff();
+            if (d_next != 0xffffffffu) m_sel = 0.5f * (sqrtf(__uint_as_float(d_next)) - sqrtf(__uint_as_float(d_last)));  // half the gap
+            float m_a = __uint_as_float(group_min_u32<G>(__float_as_uint(m_acc)));  // (non-negative floats order like their bits)
+            m_a = fminf(m_a / (3.f * Rv), Rv);
+            const float r = sp.resolution;
+            const float ux = fmaf(-fx, r, qx), uy = fmaf(-fy, r, qy), uz = fmaf(-fz, r, qz);  // position inside the voxel
+            const float m_cell = fminf(fminf(fminf(ux, r - ux), fminf(uy, r - uy)), fminf(uz, r - uz));
+            // rounding of floor(q / res) and of the position inside the voxel: a few ulp of the coordinate
+            const float safety = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fmaxf(fabsf(qz), 1.f)) * 4.8e-7f + 1e-6f;
+            float m = fminf(fminf(m_sel, m_a), m_cell) - safety;
+            const bool any_bad = group_sum_u32<G>((bad || uncached) ? 1u : 0u) != 0u;
+            if (any_bad || far || !(m > 0.f)) m = 0.f;
+            if (active) {
+                coh_win[(size_t)qq * G + sub] = mine >= 0 && !bad ? (off | ((unsigned int)cc << 24)) : COH_NONE;
+                if (sub == 0) coh_state[qq] = make_float4(qx, qy, qz, m * m);
+            }
+        }
     }
 }
 }  // namespace pin
@@ -402,7 +490,8 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
 
 static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
                       const float* pose_host, const double* state, float* query_out, float* nbr_out,
-                      int32_t* nn_count_out, void* stream);
+                      int32_t* nn_count_out, void* stream, float* coh_state = nullptr, uint32_t* coh_win = nullptr,
+                      int coh_mode = 0);
 
 extern "C" int pin_knn_query_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query,
                                     int32_t n, int32_t k, const float* pose_host, float* query_out, float* nbr_out,
@@ -418,9 +507,20 @@ int knn_bricks_dev(const pin_search_params* sp, const pin_brick_cache* bc, const
 }
 }  // namespace pin
 
+extern "C" int pin_gn_knn_coherent(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
+                                   const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
+                                   float* coh_state, uint32_t* coh_win, int32_t iteration, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(state && cur_out && bc, "state / cur_out / brick cache NULL");
+    PIN_CHECK_ARG(iteration >= 0, "iteration < 0");
+    PIN_CHECK_ARG(coh_state && coh_win, "coherent state NULL");
+    return knn_bricks(sp, bc, src, n, k, nullptr, state, cur_out, nbr_out, nn_count_out, stream, coh_state, coh_win,
+                      iteration == 0 ? 1 : 2);
+}
+
 static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
                       const float* pose_host, const double* state, float* query_out, float* nbr_out,
-                      int32_t* nn_count_out, void* stream) {
+                      int32_t* nn_count_out, void* stream, float* coh_state, uint32_t* coh_win, int coh_mode) {
     PIN_CHECK_ARG(sp && bc, "NULL params");
     PIN_CHECK_ARG(n >= 0, "n < 0");
     PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K, "k must be in [1, 8]");
@@ -436,8 +536,16 @@ static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, co
     PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 2 && sp->n_cand <= 125, "the brick cache covers num_nei_cells <= 2");
     const dim3 grid(cdiv((long)n * 8, BRICK_BLOCK)), block(BRICK_BLOCK);
     const int rounds = cdiv(sp->n_cand, 8);
-#define PIN_LAUNCH_KB(R) \
-    hipLaunchKernelGGL((knn_brick_kernel<R>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr, nn_count_out, state)
+    float4* cst = reinterpret_cast<float4*>(coh_state);
+#define PIN_LAUNCH_KB(R)                                                                                                         \
+    do {                                                                                                                         \
+        if (coh_mode != 0)                                                                                                       \
+            hipLaunchKernelGGL((knn_brick_kernel<R, true>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr,      \
+                               nn_count_out, state, cst, coh_win, coh_mode);                                                     \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((knn_brick_kernel<R, false>), grid, block, 0, s, *sp, *bc, query, n, k, pose, query_out, nbr,     \
+                               nn_count_out, state, cst, coh_win, 0);                                                            \
+    } while (0)
     if (rounds <= 4) PIN_LAUNCH_KB(4);
     else if (rounds <= 5) PIN_LAUNCH_KB(5);
     else if (rounds <= 8) PIN_LAUNCH_KB(8);

@@ -38,6 +38,12 @@ class GNTracker:
         # device loop: Morton-order the source points once per registration (pin_spatial_sort); cell ~ voxel / 4
         self.sort_points, self.sort_cell, self.sort_min_points = True, max(float(st.resolution) / 4.0, 1e-3), 4096
         self._sorted = self._sort_ws = None
+        # device loop, brick cache: searches coherent across the iterations (pin_gn_knn_coherent) -- a query that has not
+        # left the margin of its last full search only re-ranks its k winners; bit-identical records.  OFF by default:
+        # measured neutral on the C3 frame -- the pose keeps moving by more than the median margin
+        # (1 cm) for most of the 50 iterations, and a wave only skips the full search when all its 8 queries stand still
+        self.coherent = os.environ.get("PIN_KNN_COHERENT", "0") == "1"
+        self._coh = None
 
     def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None,
              color=None):
@@ -59,7 +65,7 @@ class GNTracker:
 
     def track(self, src: torch.Tensor, T_init: np.ndarray, iters: int, term_deg: float = 0.01,
               term_m: float = 0.001, early_exit: bool = True, min_valid_ratio: float = 0.2,
-              time_filtering=True, local=True, labels=None, color=None):
+              time_filtering=True, local=True, labels=None, color=None, probe: Optional[list] = None):
         """Device-resident GN loop (Tracker.tracking, tracker.py:114-184): `iters` x (kNN with the
         pose read from device state, fused SDF+Jacobian+sums, one-wave 6x6 solve + loop control)
         enqueued back to back; kernels turn into no-ops once the loop has ended on the device.
@@ -109,10 +115,20 @@ class GNTracker:
         sums_p, st_p = self.sums.data_ptr(), self.state.data_ptr()
         lab_p = None if labels is None else labels.data_ptr()
         k = self.fs.k
-        for _ in range(iters):
+        coh = self.coherent and bc is not None
+        if coh:
+            if self._coh is None or self._coh[0].shape[0] < n:
+                rows = self.nbr.shape[0]
+                self._coh = (torch.empty((rows, 4), dtype=torch.float32, device=src.device),
+                             torch.empty((rows, 8), dtype=torch.int32, device=src.device))
+            cs_p, cw_p = (t.data_ptr() for t in self._coh)
+        for it in range(iters):
             if self.on_knn:
                 self.on_knn(True)
-            rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)
+            if coh:  # iteration 0: the full search that leaves the coherent state; later ones use it
+                rc = L.pin_gn_knn_coherent(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, cs_p, cw_p, it, stream)
+            else:
+                rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)
             if self.on_knn:
                 self.on_knn(False)
             if self.on_gn:
@@ -124,6 +140,17 @@ class GNTracker:
                 rc |= L.pin_gn_accumulate_solve(f_r, gp_r, ct_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
             if rc:
                 check(rc, "pin_gn_knn / pin_gn_accumulate_solve")
+            if probe is not None:  # diagnostics (bench.py --coherent-probe): synchronises every iteration
+                torch.cuda.synchronize()
+                T_now = self.state[:16].cpu().numpy().reshape(4, 4).copy()
+                rec = dict(iteration=it, translation_step_m=None if not probe else float(np.linalg.norm(T_now[:3, 3] - probe[-1]["_T"][:3, 3])),
+                           rotation_step_rad=None if not probe else float(np.linalg.norm(T_now[:3, :3] - probe[-1]["_T"][:3, :3])), _T=T_now)
+                if coh:
+                    stale = (self._coh[0][:n, :3] != self.cur[:n]).any(1)
+                    rec["coherent_query_share"] = float(stale.float().mean().item())
+                    rec["margin_m_median"] = float(self._coh[0][:n, 3].sqrt().median().item())
+                    rec["margin_zero_share"] = float((self._coh[0][:n, 3] == 0).float().mean().item())
+                probe.append(rec)
         self.state_host.copy_(self.state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         s = self.state_host.numpy()

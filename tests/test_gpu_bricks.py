@@ -88,3 +88,54 @@ def test_bricks_large_synthetic_map():
     for pts in (scan, pool):
         nbr, nn, _ = _same(st, U.dev(pts), 8, bricks)
     assert float(nn.float().mean()) > 20
+
+
+@pytest.mark.parametrize("case,scale", [("c2_wf", 1.0), ("kitti_nwf", 1.0), ("c3_bigtable", 1.0), ("c2_wf", 30.0)])
+def test_coherent_search_equals_full_search(case, scale):
+    """pin_gn_knn_coherent over a Gauss-Newton-like sequence of poses (steps that shrink from centimetres to micrometres,
+    `scale` x larger in the last case so that queries keep leaving their margins): every iteration's records and counts
+    are the bits of a full search under the same pose, and once the steps are small most queries take the coherent path
+    (their stored position stops following the pose)."""
+    import ctypes as C
+    from pin_slam_amd import _lib, ops
+    from tests import gpu_util as U
+    d = G.load(case)
+    st = U.search_state(d)
+    k = int(d["query_nn_k"])
+    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st, wait=True)
+    rng = np.random.default_rng(4)
+    src_np = np.concatenate([d["reg_src"], d["query"],
+                             (d["local_neural_points"][::2] + rng.normal(0, 0.2, d["local_neural_points"][::2].shape))]).astype(np.float32)
+    src = U.dev(src_np)
+    n = src.shape[0]
+    L = _lib.lib()
+    sp, bc = st.params(time_filtering=True, local=True), bricks.params()
+    nbr = torch.empty((n, k, 4), dtype=torch.float32, device="cuda")
+    nn = torch.empty((n,), dtype=torch.int32, device="cuda")
+    cur = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    cst = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cwin = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    state = torch.zeros(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device="cuda")
+    T = np.eye(4)
+    coherent_share = []
+    for it in range(14):
+        step = scale * 0.05 * 0.35 ** it  # 5 cm, 1.7 cm, 6 mm, ... , ~1e-7 m
+        ang = step * 0.02
+        dT = np.eye(4)
+        dT[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+        dT[:3, 3] = step * np.array([0.6, -0.5, 0.3])
+        T = dT @ T
+        state[:16] = torch.from_numpy(T.reshape(-1)).cuda()
+        _lib.check(L.pin_gn_knn_coherent(C.byref(sp), C.byref(bc), src.data_ptr(), n, k, state.data_ptr(), cur.data_ptr(),
+                                         nbr.data_ptr(), nn.data_ptr(), cst.data_ptr(), cwin.data_ptr(), it,
+                                         ops._stream()), "pin_gn_knn_coherent")
+        ref_nbr, ref_nn, ref_cur = ops.knn_query(st, src, k, pose=T, bricks=bricks)
+        assert torch.equal(cur, ref_cur)
+        assert torch.equal(nn, ref_nn), f"nn_count differs at iteration {it}"
+        assert torch.equal(nbr.view(torch.int32), ref_nbr.view(torch.int32)), f"kNN record differs at iteration {it}"
+        coherent_share.append(float((cst[:, :3] != cur).any(1).float().mean().item()))
+    assert coherent_share[0] == 0.0
+    if scale == 1.0:
+        assert coherent_share[-1] > 0.8, coherent_share
+    else:
+        assert 0.0 < max(coherent_share) and min(coherent_share[1:]) < 0.9, coherent_share
