@@ -109,6 +109,10 @@ def parse():
     ap.add_argument("--dp-mode", default="spatial", choices=["spatial", "dense"],
                     help="how the mapper batch is cut over the ranks: spatial = k-d boxes of the voxel grid, halo-row exchange "
                          "(pin_slam_amd.dp); dense = contiguous index shards, all-reduce of the whole gradient table")
+    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "host"],
+                    help="rccl = the product transport (one rank per GPU).  host = TEST mode for a single-GPU box: the ranks share "
+                         "cuda:0 and exchange through pinned host buffers over gloo (collective.HostStagedComm) -- the N > 1 code "
+                         "path end to end, not a measurement")
     ap.add_argument("--dp-emulate", default="2,4,8", help="N = 1: world sizes whose single ranks are run alone on this GPU "
                                                           "(c4_per_rank_emulated; empty = skip)")
     ap.add_argument("--emulate-rank", default="", help="W:r -- profiling aid: ONLY rank r of a W-rank data-parallel mapper, alone on "
@@ -153,7 +157,7 @@ def launch_ranks(args) -> int:
     127.0.0.1) and hand their exit code back.  Rank 0 prints the JSON line on the inherited stdout."""
     import socket
     import subprocess
-    if not args.dry_launch:
+    if not args.dry_launch and args.dp_transport == "rccl":
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {have} GPU(s); one rank per GPU is required "
@@ -195,11 +199,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if args.dry_launch:
         return dry_launch(rank, world)
+    shared_gpu = args.dp_transport == "host"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from pin_slam_amd import preprocess, synth
     from pin_slam_amd.config import PinConfig
@@ -257,7 +267,7 @@ def main():
     def max_over_ranks(x):
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x
@@ -289,7 +299,8 @@ def main():
             single_gpu_c4 = c4_single_gpu(args, cfg, mp)
         # RCCL through the C ABI; torch.distributed only carries the ncclUniqueId (and this script's barriers)
         from pin_slam_amd import collective
-        mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, collective.RcclComm(rank, world), args.dp_mode
+        comm = collective.HostStagedComm(rank, world) if shared_gpu else collective.RcclComm(rank, world)
+        mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, comm, args.dp_mode
         out = bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P, single_gpu_c4)
         mp.dp_comm.close()
         if world > 1:
@@ -471,15 +482,15 @@ def main():
     # one 4-byte slot per candidate cell, one 16-byte position per occupied cell, kNN record out
     bytes_q = 12 + 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4
     achieved = bytes_q * n_reg / (knn_ms * 1e-3) / 1e9
+    # counters of THIS command on this workload (scripts/pmc_bench.sh -> profiles/r03_pmc_<workload>.json): HBM-side bytes per
+    # launch, matrix-pipe and vector-ALU utilisation of the two tracker kernels
     pmc_data, pmc_src = {}, None
-    for name in ("r02_pmc.json", "r01_pmc.json"):  # PMC passes of THIS command (scripts/pmc_bench.sh) when present
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            try:
-                pmc_data, pmc_src = json.load(open(path)), "profiles/" + name
-                break
-            except Exception:
-                pass
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload}.json")
+    if os.path.exists(path):
+        try:
+            pmc_data, pmc_src = json.load(open(path)), f"profiles/r03_pmc_{args.workload}.json"
+        except Exception:
+            pass
     gnk = pmc_data.get("kernels", {}).get("gn", {})
     knk = pmc_data.get("kernels", {}).get("knn_brick", {})
 
@@ -519,9 +530,14 @@ def main():
                                                "gn_accumulate_quad_nwf_kernel (per-neighbour decoding: a column per (query, neighbour) pair)"
                                                if L == 1 else
                                                "gn_accumulate_mfma_kernel (per-neighbour decoding; 64 queries per wave)"),
-                     "bound": "mfma", "achieved": round(gn_tflops, 2),
+                     "bound": "valu+latency",
+                     "bound_note": "vector-ALU issue and gather latency (PMC: matrix pipes busy mfma_util of the SIMD-cycles, vector "
+                                   "ALU valu_active); `achieved` / `peak` state the decoder's algorithmic fp32 flops against the fp32 "
+                                   "peak for scale -- the kernel does not sit on the matrix-core roofline",
+                     "achieved": round(gn_tflops, 2),
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gn_tflops / FP32_PEAK_TFLOPS, 4),
-                     "traffic": pmc_data.get("gn_hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                     "traffic": gnk.get("hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                     "mfma_util": gnk.get("mfma_util"), "valu_active": gnk.get("valu_active"),
                      "avg_launch_ms": round(gn_ms, 4),
                      "launches": len(gn_pairs), "algorithmic_flops_per_query": flops_q,
                      "share_of_frame": round(gn_ms * args.reg_iters / ms_step, 3),
@@ -529,7 +545,6 @@ def main():
                                     "products per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulate; "
                                     "`achieved`/`peak` are fp32-equivalent")
                                    if split_f16 else "v_mfma_f32_16x16x4_f32",
-                     "limiter": "vector-ALU + MFMA issue, additive on gfx950 (scripts/mfma_valu_overlap.hip)",
                      "valu_insts_per_launch": gnk.get("SQ_INSTS_VALU"),
                      "mfma_busy_cycles_per_launch": gnk.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                      "executed": {"flops_per_query": exec_flops_q, "tflops": round(exec_tflops, 1),
@@ -540,8 +555,8 @@ def main():
                                                         "is below the algorithmic bytes; the GB/s figure is the "
                                                         "algorithmic rate, stated against HBM for scale only",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_data.get("knn_brick_hbm_bytes_per_launch"),
-                         "traffic_source": pmc_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": knk.get("hbm_bytes_per_launch"),
+                         "traffic_source": pmc_src, "valu_active": knk.get("valu_active"),
                          "avg_launch_ms": round(knn_ms, 4), "launches": len(ev_pairs),
                          "algorithmic_bytes_per_query": round(bytes_q, 1),
                          "valu_insts_per_query": None if not knk.get("SQ_INSTS_VALU") else
@@ -549,7 +564,7 @@ def main():
                          "measured_copy_gbs": round(copy_gbs, 1),
                          "share_of_frame": round(knn_ms * args.reg_iters / ms_step, 3)},
     }
-    ref_cpu = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
+    ref_cpu = os.path.join(ROOT, "profiles", "r03_ref_cpu_baseline.json")
     if os.path.exists(ref_cpu):  # the real reference (torch CPU) timed by scripts/ref_cpu_baseline.py, see the file
         try:
             out["cpu_baseline_reference"] = json.load(open(ref_cpu))
@@ -660,9 +675,15 @@ def sync_replicas(npts, dec, world):
     if world <= 1:
         return
     import torch.distributed as dist
+    host = dist.get_backend() == "gloo"  # (--dp-transport host: the ranks share one GPU)
     for t in (npts._g["geo"], npts._l["geo"], npts._g["cert"], npts._l["cert"], npts._g["ts_update"], npts._l["ts_update"],
               dec.flat_params()):
-        dist.broadcast(t, src=0)
+        if host:
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=0)
     torch.cuda.synchronize()
 
 

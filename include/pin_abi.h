@@ -813,8 +813,9 @@ int pin_hash_rebuild(const pin_map_arrays* src, const pin_map_arrays* dst, const
 /* NeuralPoints.prune_map (model/neural_points.py:748-789): rows with certainty < certainty_thre (and, unless
  * global_prune, |travel[cur_ts] - travel[ts_update]| > diff_travel_dist_local) are dropped; the kept rows of `src`
  * are written to `dst` in order (ordered compaction, feature padding row appended, pos4 mirror written);
- * *n_keep_out = rows kept.  The caller adopts `dst` when n_points - n_keep exceeds min_prune_count, as the
- * reference does.  Workspace: pin_maint_workspace_bytes(n_points). */
+ * *n_keep_out = rows kept.  dst == NULL: count only (the caller decides from n_points - n_keep > min_prune_count, as the
+ * reference does, before it spends a second set of map arrays on the compaction).
+ * Workspace: pin_maint_workspace_bytes(n_points). */
 int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_prune_params* pp,
                   int32_t* n_keep_out, void* workspace, int64_t workspace_bytes, void* stream);
 

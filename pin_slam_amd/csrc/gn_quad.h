@@ -256,15 +256,17 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
 }
 
 __host__ __device__ constexpr int gq_red_offset(int image_bytes) { return (image_bytes + 15) & ~15; }
-__host__ __device__ constexpr int gq_lds_bytes(int image_bytes) {
-    return gq_red_offset(image_bytes) + (GQ_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+__host__ __device__ constexpr int gq_lds_bytes(int image_bytes, int block = GQ_BLOCK) {
+    return gq_red_offset(image_bytes) + (block / 64) * PIN_GN_NSUMS * (int)sizeof(float);
 }
 
 // LC: the number of H-wide layers when the split-fp16 decoder is used (compile time: both sweeps unrolled);
 // 0 with the fp32 image, which reads it from the field
 // COLOR: + the colour term (a second image of LC layers and 3 heads behind the first, staged per block from ct.fc.dec)
-template <int H, bool ORIENT, bool SPLIT, int LC, bool COLOR = false>
-__global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_field f, pin_gn_params gp,
+// BLK: threads per (persistent, one-per-CU) block = 4 SIMDs x BLK / 256 waves; 768 = three waves per SIMD, which caps
+// the kernel at 168 registers
+template <int H, bool ORIENT, bool SPLIT, int LC, bool COLOR = false, int BLK = GQ_BLOCK>
+__global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f, pin_gn_params gp,
                                                                          const float* __restrict__ query,
                                                                          const float4* __restrict__ nbr,
                                                                          const int* __restrict__ nn_count,
@@ -288,26 +290,26 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         uint4* __restrict__ dst_c = reinterpret_cast<uint4*>(lds_c);
         constexpr int n16 = Q::bytes(LC) >> 4;
-        for (int i = threadIdx.x; i < n16; i += GQ_BLOCK) { dst[i] = src[i]; dst_c[i] = src_c[i]; }
+        for (int i = threadIdx.x; i < n16; i += BLK) { dst[i] = src[i]; dst_c[i] = src_c[i]; }
     } else if (SPLIT && f.dec_image != nullptr && f.dec_image_bytes == Q::bytes(f.levels)) {
         // all loads of the copy in flight at once (the image size is a compile-time constant with the split decoder):
         // one memory round trip instead of one per unrolled chunk
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
-        constexpr int N16 = Q::bytes(LC > 0 ? LC : 1) >> 4, TRIPS = (N16 + GQ_BLOCK - 1) / GQ_BLOCK;
+        constexpr int N16 = Q::bytes(LC > 0 ? LC : 1) >> 4, TRIPS = (N16 + BLK - 1) / BLK;
         uint4 v[TRIPS];
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = it * GQ_BLOCK + threadIdx.x;
+            const int i = it * BLK + threadIdx.x;
             v[it] = src[i < N16 ? i : 0];
         }
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = it * GQ_BLOCK + threadIdx.x;
+            const int i = it * BLK + threadIdx.x;
             if (i < N16) dst[i] = v[it];
         }
     } else {
-        Q::stage(f.dec, f.levels, lds, threadIdx.x, GQ_BLOCK);
+        Q::stage(f.dec, f.levels, lds, threadIdx.x, BLK);
     }
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_tiles = (n_q + 15) >> 4;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
     // running sums: lane (n, g) keeps sums i = 4j + g (j = 0..7) of ITS queries; one row reduction at the end
     float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool staged = false;
-    for (int tile = simd + n_simd * (wave >> 2);; tile += n_simd * (GQ_BLOCK / 256)) {
+    for (int tile = simd + n_simd * (wave >> 2);; tile += n_simd * (BLK / 256)) {
         const bool work = tile < n_tiles;
         if (!work && staged) break;
         const int qi = (work ? tile : 0) * 16 + nq;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(GQ_BLOCK, 1) void gn_accumulate_quad_kernel(pin_fie
     if (threadIdx.x < PIN_GN_NSUMS) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < GQ_BLOCK / 64; ++w) t += (double)red[w][threadIdx.x];
+        for (int w = 0; w < BLK / 64; ++w) t += (double)red[w][threadIdx.x];
         if (t != 0.0) atomicAdd(sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS + threadIdx.x, t);
     }
 }

@@ -846,13 +846,14 @@ extern "C" int pin_hash_rebuild(const pin_map_arrays* src, const pin_map_arrays*
 extern "C" int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* dst, const pin_prune_params* pp,
                              int32_t* n_keep_out, void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();
-    PIN_CHECK_ARG(src && dst && pp && n_keep_out && workspace, "NULL pointer");
+    PIN_CHECK_ARG(src && pp && n_keep_out && workspace, "NULL pointer");
     const int n = pp->n_points;
     PIN_CHECK_ARG(n > 0, "empty map");
     PIN_CHECK_ARG(pp->global_prune || pp->travel_dist, "travel_dist NULL");
     PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
-    PIN_CHECK_ARG(src->pos && src->orient && src->geo && src->ts_create && src->ts_update && src->certainty && dst->pos &&
-                  dst->pos4 && dst->orient && dst->geo && dst->ts_create && dst->ts_update && dst->certainty, "NULL map array");
+    PIN_CHECK_ARG(src->pos && src->orient && src->geo && src->ts_create && src->ts_update && src->certainty, "NULL map array");
+    PIN_CHECK_ARG(dst == nullptr || (dst->pos && dst->pos4 && dst->orient && dst->geo && dst->ts_create && dst->ts_update && dst->certainty),
+                  "NULL map array");
     hipStream_t s = as_stream(stream);
     Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
     const int n1 = n + 1, nb = cdiv(n1, MB);
@@ -862,7 +863,7 @@ extern "C" int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* ds
     hipLaunchKernelGGL(prune_flags_kernel, dim3(nb), dim3(MB), 0, s, *src, *pp, flags);
     hipLaunchKernelGGL(block_counts_kernel, dim3(nb), dim3(MB), 0, s, flags, n1, block_off);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, n_keep_out);
-    hipLaunchKernelGGL(prune_compact_kernel, dim3(nb), dim3(MB), 0, s, *src, *dst, n, flags, block_off);
+    if (dst != nullptr) hipLaunchKernelGGL(prune_compact_kernel, dim3(nb), dim3(MB), 0, s, *src, *dst, n, flags, block_off);
     hipLaunchKernelGGL(dec_count_kernel, dim3(1), dim3(1), 0, s, n_keep_out);  // the padding entry was counted
     PIN_CHECK_LAUNCH();
     return 0;

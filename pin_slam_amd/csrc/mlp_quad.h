@@ -6,7 +6,10 @@
 
 namespace pin {
 
-constexpr int GQ_BLOCK = 512;  // 2 waves per SIMD: up to 256 VGPRs each (the tile kernels are bound by instruction issue, not occupancy)
+#ifndef PIN_GQ_BLOCK
+#define PIN_GQ_BLOCK 512
+#endif
+constexpr int GQ_BLOCK = PIN_GQ_BLOCK;  // 2 waves per SIMD: up to 256 VGPRs each (the tile kernels are bound by instruction issue, not occupancy)
 
 template <int H>
 struct QuadDecoder {

@@ -649,21 +649,39 @@ static int gq_cu_count() {
     return n_cu;
 }
 
+template <int H, bool ORIENT, bool SPLIT, int LC, int BLK>
+static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
+                           const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
+                           float* grad_out, const double* state, hipStream_t s) {
+    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, SPLIT>::bytes(LC > 0 ? LC : MLP_MAX_LEVELS), BLK);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC, false, BLK>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+    if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
+    const int tiles = cdiv(n, 16);
+    const dim3 grid(min(gq_cu_count(), tiles)), block(BLK);  // all CUs, even when there are fewer tiles than waves
+    ColorTerm none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC, false, BLK>), grid, block,
+                       gq_lds_bytes(QuadDec<H, SPLIT>::bytes(f->levels), BLK), s, *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out,
+                       grad_out, state, none);
+    return 0;
+}
+
+// waves per SIMD of the tile kernel: 2 (up to 256 registers) or 3 (168 registers; PIN_GQ_WAVES=3)
+static int gq_waves() {
+    static const int w = [] { const char* e = getenv("PIN_GQ_WAVES"); return (e && e[0] == '3') ? 3 : 2; }();
+    return w;
+}
+
 template <int H, bool ORIENT, bool SPLIT, int LC>
 static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                             const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                             float* grad_out, const double* state, hipStream_t s) {
-    constexpr int max_bytes = gq_lds_bytes(QuadDec<H, SPLIT>::bytes(LC > 0 ? LC : MLP_MAX_LEVELS));
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
-    if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
-    const int tiles = cdiv(n, 16);
-    const dim3 grid(min(gq_cu_count(), tiles)), block(GQ_BLOCK);  // all CUs, even when there are fewer tiles than waves
-    ColorTerm none;
-    memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC>), grid, block, gq_lds_bytes(QuadDec<H, SPLIT>::bytes(f->levels)), s,
-                       *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, none);
-    return 0;
+    if constexpr (SPLIT && !ORIENT) {
+        if (gq_waves() == 3)
+            return launch_quad_blk<H, ORIENT, SPLIT, LC, 768>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
+    }
+    return launch_quad_blk<H, ORIENT, SPLIT, LC, GQ_BLOCK>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
 }
 
 // the same kernel with the colour term of the registration: two split-fp16 images (sdf, colour) of LC layers each

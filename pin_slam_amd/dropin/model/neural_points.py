@@ -219,6 +219,8 @@ class NeuralPoints(nn.Module):
 
     def field_state(self, decoder, query_locally=True, color=False) -> ops.FieldState:
         """FieldState over the local (or global) tables for `decoder` (a dropin Decoder)."""
+        if query_locally and getattr(self, "_local_count_pending", False):
+            raise RuntimeError("the local map was reset but its size has not been read back yet (Mapper.process_frame defers it)")
         l = self._l if query_locally else self._g
         if query_locally:
             feats = (self.local_color_features if color else self.local_geo_features).data
@@ -395,6 +397,8 @@ class NeuralPoints(nn.Module):
             raise SystemExit("you need to at least query one kind of feature")
         if self.config.layer_norm_on or self.config.pos_encoding_band > 0:
             raise NotImplementedError("layer_norm_on / positional encoding are off in every shipped config")
+        if query_locally and getattr(self, "_local_count_pending", False):
+            raise RuntimeError("the local map was reset but its size has not been read back yet (Mapper.process_frame defers it)")
         q = query_points.detach().to(torch.float32).contiguous()
         nbr, nn_i32, _ = self.knn(q, query_locally)
         cert = self._l["cert"][:self._m] if query_locally else self._g["cert"][:self._n]
@@ -450,17 +454,21 @@ class NeuralPoints(nn.Module):
         pp.travel_dist = None if global_prune else _p(self._travel())
         pp.n_points, pp.cur_ts, pp.global_prune = n, int(self.cur_ts), int(bool(global_prune))
         pp.certainty_thre, pp.diff_travel_dist_local = float(prune_certainty_thre), float(self.diff_travel_dist_local)
-        dst = self._spare_arrays()
         ws = self._workspace(n + 1)
-        src_a, dst_a = self._map_arrays(), self._map_arrays(dst)
-        check(_lib.lib().pin_prune_map(C.byref(src_a), C.byref(dst_a), C.byref(pp), _p(self._cnt[3:4]), _p(ws), ws.numel(),
+        src_a = self._map_arrays()
+        # count first (dst = NULL): the second set of map arrays is only spent when the result is adopted
+        check(_lib.lib().pin_prune_map(C.byref(src_a), None, C.byref(pp), _p(self._cnt[3:4]), _p(ws), ws.numel(),
                                        ops._stream()), "pin_prune_map")
         n_keep = int(self._cnt[3].item())
         if n - n_keep <= min_prune_count:
             return False
         if not self.silence:
             print("# Prune neural points: ", n - n_keep)
-        self._g, self._spare = dst, self._g  # the compacted set becomes the map (recreate the hash next, as the reference says)
+        dst = self._spare_arrays()
+        dst_a = self._map_arrays(dst)
+        check(_lib.lib().pin_prune_map(C.byref(src_a), C.byref(dst_a), C.byref(pp), _p(self._cnt[3:4]), _p(ws), ws.numel(),
+                                       ops._stream()), "pin_prune_map")
+        self._g, self._spare = dst, None  # the compacted set becomes the map (recreate the hash next, as the reference says); the old set is released
         self._n = n_keep
         return True
 
@@ -505,7 +513,7 @@ class NeuralPoints(nn.Module):
                                               ops._stream()), "pin_hash_rebuild")
             if not kept_points:
                 self._n = int(self._cnt[3].item())
-                self._g, self._spare = dst, self._g
+                self._g, self._spare = dst, None  # (the old set is released: map memory does not stay doubled)
             self._bricks = None  # the cache mirrors the table that was just rewritten
         else:
             self._table.fill_(-1)

@@ -102,6 +102,11 @@ class Mapper(_Base):
         self.static_mask = None
         self.cur_sample_count = 0
         self.cur_new_point_ratio = 0.0
+        if getattr(config, "ba_freq_frame", 0) and config.ba_freq_frame > 0:
+            # say it before the run starts, not at the first bundle-adjustment frame (run_replica.yaml, run_ncd_128_s.yaml)
+            print(f"[pin_slam_amd] WARNING: ba_freq_frame = {config.ba_freq_frame}: Mapper.bundle_adjustment (pypose pose optimisation) is "
+                  f"not part of libpinhip's hot path and will raise NotImplementedError at frame {config.ba_freq_frame}; run with "
+                  f"ba_freq_frame: 0", flush=True)
 
     # ------------------------------------------------------------------ data pool
     _POOL_ATTRS = (("coord_pool", "coord"), ("global_coord_pool", "global_coord"), ("sdf_label_pool", "sdf_label"),
@@ -217,6 +222,14 @@ class Mapper(_Base):
             self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
         finally:
             npts._defer_local_count = False
+        try:
+            self._process_frame_tail(c, npts, p, frame_id, filtering, kept, n_new, defer)
+        finally:
+            # an exception between update() and the read-back below must not leave the local tables at last frame's size
+            if getattr(npts, "_local_count_pending", False):
+                npts._finish_local_map(int(npts._cnt[2].item()))
+
+    def _process_frame_tail(self, c, npts, p, frame_id, filtering, kept, n_new, defer):
         if not defer:
             npts.record_memory(verbose=(not self.silence))
         self.determine_used_pose()

@@ -6,7 +6,11 @@ itself a moment ago.
 `remember(t, a)` records that device tensor `t` currently holds the host array `a`; `lookup(t)` returns a copy of `a`
 if `t` is that tensor or a view / detach() of it with the same layout and nothing has written to the storage since
 (torch's version counter, shared by all views of a storage).  The cache keeps a reference to the tensor, so its memory
-cannot be recycled for another tensor while the entry lives: (data_ptr, version) cannot collide."""
+cannot be recycled for another tensor while the entry lives: (data_ptr, version) cannot collide.
+
+Freshness rests on torch's version counter, which only torch ops bump: libpinhip kernels and RCCL write through raw
+pointers.  Only remember() tensors that torch wrote from host numbers (the pose: torch.tensor(host_array)), and call
+invalidate(t) from any code that lets a C-ABI call write into a tensor that may be cached."""
 from __future__ import annotations
 
 import numpy as np
@@ -21,6 +25,17 @@ def remember(t: torch.Tensor, a) -> None:
         return
     _entries.append((t, t._version, np.array(a, copy=True)))
     del _entries[:-_CAP]
+
+
+def invalidate(t: torch.Tensor) -> None:
+    """Forget every entry that shares storage with `t` (for writers the version counter does not see)."""
+    if not isinstance(t, torch.Tensor):
+        return
+    try:
+        base = t.untyped_storage().data_ptr()
+    except Exception:
+        base = t.data_ptr()
+    _entries[:] = [e for e in _entries if e[0].untyped_storage().data_ptr() != base]
 
 
 def lookup(t: torch.Tensor):

@@ -224,10 +224,10 @@ def run(args):
     import torch
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
-    log = {"impl": args.impl, "frames": args.frames}
+    log = {"impl": args.impl, "frames": args.frames, "scan_points": args.scan_points}
     ref = reference_tree(args.reference)
     work = tempfile.mkdtemp(prefix="pin_e2e_")
-    pc_dir, gt = write_sequence(work, args.frames)
+    pc_dir, gt = write_sequence(work, args.frames, n_scan=args.scan_points)
     cfg_path = os.path.join(work, "e2e.yaml")
     with open(cfg_path, "w") as f:
         # --per-neighbour: decode every neighbour and weight the predictions (run_kitti.yaml: weighted_first False, 6 neighbours)
@@ -324,6 +324,7 @@ def main():
     r.add_argument("--impl", choices=["dropin", "reference"], default="dropin")
     r.add_argument("--frames", type=int, default=10)
     r.add_argument("--iters", type=int, default=15)
+    r.add_argument("--scan-points", type=int, default=60_000, help="points per simulated scan")
     r.add_argument("--per-neighbour", action="store_true", help="weighted_first: False, query_nn_k: 6 (run_kitti.yaml style)")
     r.add_argument("--livox-style", action="store_true", help="run_livox.yaml style: weighted_first False, query_nn_k 8, "
                                                               "numerical_grad_on False (analytic Eikonal term)")

@@ -11,7 +11,7 @@ own classes and times
   * Mapper.mapping(12)         (batch 16384 + Eikonal, backward, Adam over every local feature),
 
 with time.perf_counter, 1 warm-up + the median of `--reps` repeats, torch.get_num_threads() threads.  Writes
-profiles/r02_ref_cpu_baseline.json, which bench.py attaches to its JSON line as `cpu_baseline_reference`
+profiles/r03_ref_cpu_baseline.json, which bench.py attaches to its JSON line as `cpu_baseline_reference`
 (baseline only: a GPU/CPU ratio says nothing about kernel quality)."""
 from __future__ import annotations
 
@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--bs", type=int, default=16384)
     ap.add_argument("--map-iters", type=int, default=12)
     ap.add_argument("--reg-iters", type=int, default=50)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_ref_cpu_baseline.json"))
     a = ap.parse_args()
     m = R.load()
     H, L, k = 64, 4, 8
@@ -113,7 +113,7 @@ def main():
     out["mapping_iterations"] = a.map_iters
     out["mapper_samples_per_sec"] = round(a.bs * a.map_iters / t, 1)
     print("mapping", out["mapping_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
-    t, all_ = timed(tracking, max(1, a.reps // 2))
+    t, all_ = timed(tracking, a.reps)
     out["tracking_ms"] = round(t * 1e3, 1)
     out["tracking_note"] = "Tracker.tracking with its own convergence test (it may stop before reg_iter_n iterations)"
     print("tracking", out["tracking_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
