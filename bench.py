@@ -124,8 +124,8 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendez-vous over gloo on the CPU, print one JSON line and exit (no GPU needed): "
                          "checks the launcher of `--gpus N`")
-    ap.add_argument("--c4-iters", type=int, default=4, help="N = 1: iterations per timed Mapper.mapping call of the "
-                                                             "single-GPU C4 leg (0 = skip it)")
+    ap.add_argument("--c4-iters", type=int, default=12, help="N = 1: iterations per timed Mapper.mapping call of the "
+                                                              "single-GPU C4 leg and of the emulated ranks (0 = skip them)")
     ap.add_argument("--skip-downsampled", action="store_true",
                     help="skip the second timed leg (registering the source-down-sampled subset): profiles of this "
                          "command then hold one launch shape per tracker kernel")
@@ -696,6 +696,10 @@ def allreduce_model_us(nbytes, world):
     return AR_LATENCY_US + 2.0 * (world - 1) / world * nbytes / (AR_BUSBW_GBS * 1e3)
 
 
+def allgather_model_us(total_bytes, world):
+    return AR_LATENCY_US + (world - 1) / world * total_bytes / (AR_BUSBW_GBS * 1e3)
+
+
 def c4_per_rank_emulated(args, cfg, mp, worlds, single):
     """N = 1 box: single ranks of W-rank jobs, ALONE on this GPU (collective.NullComm: the identity exchange).  A rank of
     the spatially sharded mapper does its own share only -- its samples, the rows it owns, the whole halo -- so its time
@@ -721,12 +725,19 @@ def c4_per_rank_emulated(args, cfg, mp, worlds, single):
                 dt = time.perf_counter() - t0
                 st = dict(getattr(mp, "dp_stats", None) or {})
                 per.append(dict(rank=r, ms_per_iteration=round(1e3 * dt / (2 * args.c4_iters), 4), samples_max=st.get("samples_max"),
-                                halo_fraction=round(st.get("halo_fraction", 0.0), 4), exchange_bytes=st.get("exchange_bytes")))
+                                halo_fraction=round(st.get("halo_fraction", 0.0), 4), exchange_bytes=st.get("exchange_bytes"),
+                                halo_rows=st.get("halo_rows"), merge=st.get("merge"), merge_bytes_per_call=st.get("merge_bytes_per_call")))
             slow = max(p["ms_per_iteration"] for p in per)
             xb = per[0]["exchange_bytes"] or (4 * int(mp._get_trainer().grad.numel()))
             rows = int(mp.neural_points.local_count())
-            # per call: certainty (fp32) + ts (int32) all-reduces over the rows, and (spatial) the owner merge of the table
-            per_call_us = 2 * allreduce_model_us(4 * rows, W) + (allreduce_model_us(32 * rows, W) if args.dp_mode == "spatial" else 0.0)
+            # per call.  spatial, merge "gather": one all-gather of the owned rows (features + certainty + ts), the halo's side
+            # effects as two small all-reduces; merge "reduce" / dense: certainty (fp32) + ts (int32) all-reduces over every
+            # row, and (spatial) the all-reduce of the table
+            if per[0].get("merge") == "gather":
+                per_call_us = allgather_model_us(40 * W * max(1, (per[0]["merge_bytes_per_call"] - 12 * per[0]["halo_rows"]) // (40 * W)), W) \
+                    + 2 * allreduce_model_us(4 * per[0]["halo_rows"], W)
+            else:
+                per_call_us = 2 * allreduce_model_us(4 * rows, W) + (allreduce_model_us(32 * rows, W) if args.dp_mode == "spatial" else 0.0)
             comm_ms = (allreduce_model_us(xb, W) + per_call_us / args.c4_iters) * 1e-3
             proj = args.global_bs / ((slow + comm_ms) * 1e-3)
             out[str(W)] = dict(ranks_measured=per, slowest_rank_ms_per_iteration=slow, exchange_bytes_per_iteration=xb,
@@ -738,8 +749,9 @@ def c4_per_rank_emulated(args, cfg, mp, worlds, single):
         mp.dp_rank, mp.dp_world, mp.dp_comm = 0, 1, None
         mp._trainer = None
     out["model"] = (f"PROJECTED, not measured: slowest measured rank + all-reduce model {AR_LATENCY_US:.0f} us + 2(W-1)/W * bytes / "
-                    f"{AR_BUSBW_GBS:.0f} GB/s (per iteration: the [decoder | halo] buffer; per call of {args.c4_iters} iterations: certainty, "
-                    f"ts and the owner merge); ranks run alone on one GPU with the identity exchange (dp_mode {args.dp_mode})")
+                    f"{AR_BUSBW_GBS:.0f} GB/s, all-gather {AR_LATENCY_US:.0f} us + (W-1)/W * bytes / {AR_BUSBW_GBS:.0f} GB/s (per iteration: the "
+                    f"[decoder | halo] buffer; per call of {args.c4_iters} iterations: the owner merge and the halo's side effects); ranks run "
+                    f"alone on one GPU with the identity exchange (dp_mode {args.dp_mode})")
     return out
 
 

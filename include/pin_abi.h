@@ -775,7 +775,7 @@ int pin_dp_gather(const float* pool_coord, const float* pool_label, const float*
 
 /* Halo of the partition over the feature rows at pos [n_rows][3]: halo_rows_out = ascending indices of the rows
  * that are NOT at least `reach` cells inside their own box (the same list on every rank), *count_out of them (at
- * most halo_cap are written); owner_out [n_rows] = box of every row's voxel; lazy_pending (may be NULL) [n_rows]:
+ * most halo_cap are written); owner_out [n_rows] = box of every row's voxel, | 0x80 for the halo rows; lazy_pending (may be NULL) [n_rows]:
  * halo rows <- PIN_ADAM_ROW_EXCLUDED so that pin_adam_lazy_* leave them to pin_dp_halo_adam.
  * Workspace: pin_maint_workspace_bytes(n_rows). */
 int pin_dp_mark_halo(const pin_dp_regions* rg, const float* pos, int32_t n_rows, int32_t* halo_rows_out,
@@ -792,9 +792,33 @@ int pin_dp_halo_adam(const int32_t* halo_rows, int32_t n_halo, float* feats, con
                      float* exp_avg_sq, int32_t step, const float* coef, int32_t t_max, float beta1, float beta2,
                      float eps, void* stream);
 
-/* End of the call: out[row] = owner[row] == rank ? feats[row] : 0 over n_rows rows of 8 floats; the SUM over ranks
- * (pin_allreduce_f32 into the feature table) is the trained table on every rank. */
+/* End of the call, form 1 (any transport with an all-reduce): out[row] = (owner[row] & 0x7f) == rank ? feats[row] : 0 over
+ * n_rows rows of 8 floats; the SUM over ranks (pin_allreduce_f32 into the feature table) is the trained table on every
+ * rank.  owner[] as pin_dp_mark_halo writes it: box | 0x80 for halo rows. */
 int pin_dp_owner_pack(const uint8_t* owner, int32_t rank, const float* feats, int32_t n_rows, float* out, void* stream);
+
+/* End of the call, form 2 (half the bytes: an all-GATHER of what each rank owns instead of an all-reduce of the table).
+ * pin_dp_owner_lists: lists_out = the PRIVATE rows (no halo bit) of box 0, then of box 1, ... (a deterministic counting
+ * sort of owner[]: the same lists on every rank), offsets_out [world + 1] (device) where each list starts.
+ * pin_dp_rows_pack: out[j] = (8 features, certainty, ts_update bits) of row rows[j] -- a rank packs ITS list, padded by the
+ * caller to the longest list (segment_rows); pin_allgather_f32 (ncclAllGather, count_per_rank = 10 * segment_rows floats);
+ * pin_dp_rows_unpack: the other ranks' records back into the tables.  A private row is only ever touched by its owner's
+ * samples -- features, certainty and ts_update alike -- so the owner's values ARE the merged values; the halo rows'
+ * certainty (sum of deltas) and ts_update (max) go through pin_dp_sync_side_effects in compact form
+ * (pin_dp_halo_side_gather / _scatter), their features are identical everywhere already. */
+int64_t pin_dp_owner_lists_workspace_bytes(int32_t n_rows, int32_t world);
+int pin_dp_owner_lists(const uint8_t* owner, int32_t n_rows, int32_t world, int32_t* lists_out, int32_t* offsets_out,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+int pin_dp_rows_pack(const int32_t* rows, int32_t count, const float* feats, const float* certainty, const int32_t* ts_update,
+                     float* out, void* stream);
+int pin_dp_rows_unpack(const float* gathered, int32_t segment_rows, const int32_t* lists, const int32_t* offsets, int32_t world,
+                       int32_t rank, float* feats, float* certainty, int32_t* ts_update, void* stream);
+int pin_dp_halo_side_gather(const int32_t* halo_rows, int32_t n_halo, const float* certainty, const float* certainty0,
+                            const int32_t* ts_update, float* cert_out, float* cert0_out, int32_t* ts_out, void* stream);
+int pin_dp_halo_side_scatter(const int32_t* halo_rows, int32_t n_halo, const float* cert_in, const int32_t* ts_in,
+                             float* certainty, int32_t* ts_update, void* stream);
+/* ncclAllGather of count_per_rank floats per rank on `stream` (recv [world][count_per_rank]). */
+int pin_allgather_f32(void* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);
 
 /* ---- post-loop map maintenance on the device ------------------------------------ */
 

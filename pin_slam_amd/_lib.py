@@ -226,6 +226,13 @@ SIGNATURES = {
     "pin_dp_halo_pack": (i32, [vp, i32, vp, vp, vp]),
     "pin_dp_halo_adam": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, f32, f32, f32, vp]),
     "pin_dp_owner_pack": (i32, [vp, i32, vp, i32, vp, vp]),
+    "pin_dp_owner_lists_workspace_bytes": (i64, [i32, i32]),
+    "pin_dp_owner_lists": (i32, [vp, i32, i32, vp, vp, vp, i64, vp]),
+    "pin_dp_rows_pack": (i32, [vp, i32, vp, vp, vp, vp, vp]),
+    "pin_dp_rows_unpack": (i32, [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "pin_dp_halo_side_gather": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "pin_dp_halo_side_scatter": (i32, [vp, i32, vp, vp, vp, vp, vp]),
+    "pin_allgather_f32": (i32, [vp, vp, vp, i64, vp]),
     "pin_dp_cert_snapshot": (i32, [vp, vp, i32, vp]),
     "pin_dp_cert_delta": (i32, [vp, vp, vp, i32, vp]),
     "pin_dp_cert_apply": (i32, [vp, vp, vp, i32, vp]),

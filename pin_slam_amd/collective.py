@@ -60,6 +60,10 @@ class RcclComm:
         """SUM all-reduce of a flat fp32 buffer, out of place (send may be recv): pin_allreduce_f32."""
         check(_lib.lib().pin_allreduce_f32(self._h, send.data_ptr(), recv.data_ptr(), send.numel(), _stream()), "pin_allreduce_f32")
 
+    def allgather(self, send: torch.Tensor, recv: torch.Tensor):
+        """recv [world][send.numel()] <- every rank's send (pin_allgather_f32)."""
+        check(_lib.lib().pin_allgather_f32(self._h, send.data_ptr(), recv.data_ptr(), send.numel(), _stream()), "pin_allgather_f32")
+
     def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
         n = certainty.shape[0]
         check(_lib.lib().pin_dp_sync_side_effects(self._h, certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(),
@@ -106,6 +110,13 @@ class HostStagedComm:
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
         recv.reshape(-1).copy_(h, non_blocking=True)
 
+    def allgather(self, send: torch.Tensor, recv: torch.Tensor):
+        import torch.distributed as dist
+        h = send.reshape(-1).cpu()
+        parts = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(parts, h, group=self.group)
+        recv.reshape(-1)[:self.world * h.numel()].copy_(torch.cat(parts))
+
     def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
         import torch.distributed as dist
         L, n = _lib.lib(), certainty.shape[0]
@@ -133,6 +144,9 @@ class NullComm:
 
     def allreduce(self, send, recv):
         pass  # (also for the owner merge: the map of the one emulated rank stays whole)
+
+    def allgather(self, send, recv):
+        pass
 
     def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
         pass

@@ -18,6 +18,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -68,6 +69,7 @@ extern "C" int pin_comm_load(const char* rccl_path) {
     PIN_SYM(CommInitRank, "ncclCommInitRank");
     PIN_SYM(CommDestroy, "ncclCommDestroy");
     PIN_SYM(AllReduce, "ncclAllReduce");
+    PIN_SYM(AllGather, "ncclAllGather");
     PIN_SYM(GroupStart, "ncclGroupStart");
     PIN_SYM(GroupEnd, "ncclGroupEnd");
     PIN_SYM(GetErrorString, "ncclGetErrorString");
@@ -121,6 +123,16 @@ extern "C" int pin_allreduce_f32(void* comm, const float* send, float* recv, int
     PIN_CHECK_ARG(send && recv, "NULL pointer");
     PIN_CHECK_NCCL(g.AllReduce(send, recv, (size_t)count, ncclFloat32, ncclSum, reinterpret_cast<ncclComm_t>(comm),
                                as_stream(stream)));
+    return 0;
+}
+
+extern "C" int pin_allgather_f32(void* comm, const float* send, float* recv, int64_t count_per_rank, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(g.handle, "RCCL not loaded (pin_comm_load)");
+    PIN_CHECK_ARG(comm && count_per_rank >= 0, "bad arguments");
+    if (count_per_rank == 0) return 0;
+    PIN_CHECK_ARG(send && recv, "NULL pointer");
+    PIN_CHECK_NCCL(g.AllGather(send, recv, (size_t)count_per_rank, ncclFloat32, reinterpret_cast<ncclComm_t>(comm), as_stream(stream)));
     return 0;
 }
 

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(MB) void dp_halo_flags_kernel(pin_dp_regions rg, co
         const int r = region_of(sbox, rg.world, cx, cy, cz);
         halo = !deep_inside(sbox + 6 * r, rg.reach, cx, cy, cz);
         flags[i] = halo ? 1 : 0;
-        owner[i] = (unsigned char)r;
+        owner[i] = (unsigned char)(r | (halo ? 0x80 : 0));  // bit 7: halo row (kept identical everywhere, nobody's to publish)
         if (halo && pend != nullptr) pend[i] = PIN_ADAM_ROW_EXCLUDED;
     }
     int total;
@@ -243,13 +243,126 @@ __global__ __launch_bounds__(256) void dp_owner_pack_kernel(const unsigned char*
                                                             const float* __restrict__ feats, long n, float* __restrict__ out) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
-    for (; i < n; i += stride) out[i] = owner[i >> 3] == rank ? feats[i] : 0.f;
+    for (; i < n; i += stride) out[i] = (owner[i >> 3] & 0x7f) == rank ? feats[i] : 0.f;
 }
 
 // int32 box coordinates back from the two exactly representable fp32 halves they travelled in (pin_dp_boxes_decode)
 __global__ void dp_boxes_decode_kernel(const float* __restrict__ halves, int n, int* __restrict__ boxes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) boxes[i] = (int)(((unsigned)(int)halves[2 * i] << 16) | ((unsigned)(int)halves[2 * i + 1] & 0xffffu));
+}
+
+// ---- owner lists: the PRIVATE rows of every box, box after box (a deterministic counting sort of the owner bytes: every
+// rank computes the same lists).  Per block and owner the number of its rows (ballots, wave by wave) ...
+__global__ __launch_bounds__(MB) void dp_owner_count_kernel(const unsigned char* __restrict__ owner, int n, int world,
+                                                            int* __restrict__ block_cnt /*[world][nb]*/, int nb) {
+    __shared__ int cnt[DP_MAX_WORLD];
+    if (threadIdx.x < world) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const int o = i < n ? owner[i] : 0xff;  // (halo rows carry bit 7: no owner list takes them)
+    const int lane = threadIdx.x & 63;
+    for (int w = 0; w < world; ++w) {
+        const unsigned long long bal = __ballot(o == w);
+        if (lane == 0 && bal) atomicAdd(&cnt[w], __popcll(bal));
+    }
+    __syncthreads();
+    if (threadIdx.x < world) block_cnt[(size_t)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// ... one exclusive scan over the [world][nb] counts in owner-major order (so list w starts at offsets[w]) ...
+__global__ __launch_bounds__(1024) void dp_owner_scan_kernel(int* __restrict__ block_cnt, int total, int nb, int world,
+                                                             int* __restrict__ offsets /*[world + 1]*/) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, total);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += block_cnt[b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) {
+        const int c = block_cnt[b];
+        if (b % nb == 0) offsets[b / nb] = run;
+        block_cnt[b] = run;
+        run += c;
+    }
+    if (t == 1023) offsets[world] = part[1023];
+}
+
+// ... and the scatter: row i goes to block_cnt[owner][block] + its rank among the block's rows of that owner.
+__global__ __launch_bounds__(MB) void dp_owner_scatter_kernel(const unsigned char* __restrict__ owner, int n, int world,
+                                                              const int* __restrict__ block_off, int nb, int* __restrict__ lists) {
+    __shared__ int wave_cnt[MB / 64][DP_MAX_WORLD];
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const int o = i < n ? owner[i] : 0xff;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int before = 0;
+    for (int w = 0; w < world; ++w) {
+        const unsigned long long bal = __ballot(o == w);
+        if (lane == 0) wave_cnt[wave][w] = __popcll(bal);
+        if (o == w) before = __popcll(bal & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (o < world) {
+        int off = block_off[(size_t)o * nb + blockIdx.x] + before;
+        for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2][o];
+        lists[off] = i;
+    }
+}
+
+// the record of a published row: 8 features, its certainty, its ts_update bits
+constexpr int DP_REC = 10;
+__global__ __launch_bounds__(256) void dp_rows_pack_kernel(const int* __restrict__ rows, int count, const float* __restrict__ feats,
+                                                           const float* __restrict__ cert, const int* __restrict__ ts,
+                                                           float* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)count * DP_REC) return;
+    const int j = (int)(t / DP_REC), c = (int)(t - (long)j * DP_REC);
+    const size_t r = (size_t)rows[j];
+    out[t] = c < 8 ? feats[r * PIN_FEATURE_DIM + c] : (c == 8 ? cert[r] : __int_as_float(ts[r]));
+}
+
+__global__ __launch_bounds__(256) void dp_rows_unpack_kernel(const float* __restrict__ all, int seg, const int* __restrict__ lists,
+                                                             const int* __restrict__ offsets, int world, int rank,
+                                                             float* __restrict__ feats, float* __restrict__ cert, int* __restrict__ ts) {
+    const int o = blockIdx.y;
+    if (o == rank) return;
+    const int count = offsets[o + 1] - offsets[o];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)count * DP_REC) return;
+    const int j = (int)(t / DP_REC), c = (int)(t - (long)j * DP_REC);
+    const size_t r = (size_t)lists[offsets[o] + j];
+    const float v = all[((size_t)o * seg + j) * DP_REC + c];
+    if (c < 8) feats[r * PIN_FEATURE_DIM + c] = v;
+    else if (c == 8) cert[r] = v;
+    else ts[r] = __float_as_int(v);
+}
+
+// side effects of the halo rows in compact form (the certainty sum / ts max of pin_dp_sync_side_effects run over these)
+__global__ __launch_bounds__(256) void dp_halo_side_gather_kernel(const int* __restrict__ rows, int n, const float* __restrict__ cert,
+                                                                  const float* __restrict__ cert0, const int* __restrict__ ts,
+                                                                  float* __restrict__ ccert, float* __restrict__ ccert0,
+                                                                  int* __restrict__ cts) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n) return;
+    const size_t r = (size_t)rows[h];
+    ccert[h] = cert[r]; ccert0[h] = cert0[r]; cts[h] = ts[r];
+}
+__global__ __launch_bounds__(256) void dp_halo_side_scatter_kernel(const int* __restrict__ rows, int n, const float* __restrict__ ccert,
+                                                                   const int* __restrict__ cts, float* __restrict__ cert,
+                                                                   int* __restrict__ ts) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n) return;
+    const size_t r = (size_t)rows[h];
+    cert[r] = ccert[h]; ts[r] = cts[h];
 }
 
 int check_regions(const pin_dp_regions* rg) {
@@ -435,6 +548,79 @@ extern "C" int pin_dp_halo_adam(const int32_t* halo_rows, int32_t n_halo, float*
     PIN_CHECK_ARG(halo_rows && feats && grad_sum && exp_avg && exp_avg_sq && coef, "NULL pointer");
     hipLaunchKernelGGL(dp_halo_adam_kernel, dim3(cdiv((long)n_halo * PIN_FEATURE_DIM, 256)), dim3(256), 0, as_stream(stream),
                        halo_rows, n_halo, feats, grad_sum, exp_avg, exp_avg_sq, coef, step, t_max, beta1, beta2, eps);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_owner_lists(const uint8_t* owner, int32_t n_rows, int32_t world, int32_t* lists_out, int32_t* offsets_out,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_rows >= 0 && world >= 1 && world <= DP_MAX_WORLD && offsets_out, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (n_rows == 0) {
+        PIN_CHECK_HIP(hipMemsetAsync(offsets_out, 0, sizeof(int32_t) * (world + 1), s));
+        return 0;
+    }
+    PIN_CHECK_ARG(owner && lists_out && workspace, "NULL pointer");
+    const int nb = cdiv(n_rows, MB);
+    Carver cv{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    int* block_cnt = cv.take<int>((size_t)world * nb);
+    PIN_CHECK_ARG(block_cnt, "workspace too small (pin_dp_owner_lists_workspace_bytes)");
+    hipLaunchKernelGGL(dp_owner_count_kernel, dim3(nb), dim3(MB), 0, s, owner, n_rows, world, block_cnt, nb);
+    hipLaunchKernelGGL(dp_owner_scan_kernel, dim3(1), dim3(1024), 0, s, block_cnt, world * nb, nb, world, offsets_out);
+    hipLaunchKernelGGL(dp_owner_scatter_kernel, dim3(nb), dim3(MB), 0, s, owner, n_rows, world, block_cnt, nb, lists_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t pin_dp_owner_lists_workspace_bytes(int32_t n_rows, int32_t world) {
+    return 512 + (int64_t)sizeof(int) * (world < 1 ? 1 : world) * (int64_t)cdiv(n_rows < 0 ? 0 : n_rows, MB);
+}
+
+extern "C" int pin_dp_rows_pack(const int32_t* rows, int32_t count, const float* feats, const float* certainty,
+                                const int32_t* ts_update, float* out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(count >= 0, "count < 0");
+    if (count == 0) return 0;
+    PIN_CHECK_ARG(rows && feats && certainty && ts_update && out, "NULL pointer");
+    hipLaunchKernelGGL(dp_rows_pack_kernel, dim3(cdiv((long)count * DP_REC, 256)), dim3(256), 0, as_stream(stream), rows, count, feats,
+                       certainty, ts_update, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_rows_unpack(const float* gathered, int32_t segment_rows, const int32_t* lists, const int32_t* offsets,
+                                  int32_t world, int32_t rank, float* feats, float* certainty, int32_t* ts_update, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(segment_rows >= 0 && world >= 1 && world <= DP_MAX_WORLD && rank >= 0 && rank < world, "bad arguments");
+    if (segment_rows == 0 || world == 1) return 0;
+    PIN_CHECK_ARG(gathered && lists && offsets && feats && certainty && ts_update, "NULL pointer");
+    hipLaunchKernelGGL(dp_rows_unpack_kernel, dim3(cdiv((long)segment_rows * DP_REC, 256), world), dim3(256), 0, as_stream(stream),
+                       gathered, segment_rows, lists, offsets, world, rank, feats, certainty, ts_update);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_halo_side_gather(const int32_t* halo_rows, int32_t n_halo, const float* certainty, const float* certainty0,
+                                       const int32_t* ts_update, float* cert_out, float* cert0_out, int32_t* ts_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_halo >= 0, "n_halo < 0");
+    if (n_halo == 0) return 0;
+    PIN_CHECK_ARG(halo_rows && certainty && certainty0 && ts_update && cert_out && cert0_out && ts_out, "NULL pointer");
+    hipLaunchKernelGGL(dp_halo_side_gather_kernel, dim3(cdiv(n_halo, 256)), dim3(256), 0, as_stream(stream), halo_rows, n_halo, certainty,
+                       certainty0, ts_update, cert_out, cert0_out, ts_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_halo_side_scatter(const int32_t* halo_rows, int32_t n_halo, const float* cert_in, const int32_t* ts_in,
+                                        float* certainty, int32_t* ts_update, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_halo >= 0, "n_halo < 0");
+    if (n_halo == 0) return 0;
+    PIN_CHECK_ARG(halo_rows && cert_in && ts_in && certainty && ts_update, "NULL pointer");
+    hipLaunchKernelGGL(dp_halo_side_scatter_kernel, dim3(cdiv(n_halo, 256)), dim3(256), 0, as_stream(stream), halo_rows, n_halo, cert_in,
+                       ts_in, certainty, ts_update);
     PIN_CHECK_LAUNCH();
     return 0;
 }

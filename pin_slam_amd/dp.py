@@ -106,6 +106,10 @@ class SpatialShards:
         self.cap = self.ecap = 0
         self.counts_host = None
         self._ws = self._pool_region = self._halves = self._halves_host = None
+        self.lists = self.offsets = self._send = self._recv = self._side = None
+        # end-of-call merge: "gather" = every rank publishes the rows it owns (all-gather, certainty / ts ride along, the halo's
+        # side effects in compact form); "reduce" = all-reduce of the whole table + the side-effect all-reduces over every row
+        self.merge = "gather"
         self.fixed_boxes: Optional[np.ndarray] = None  # tests may pin the partition
         self.stats = {}
 
@@ -180,10 +184,20 @@ class SpatialShards:
         check(L.pin_dp_mark_halo(C.byref(rg), pos.data_ptr(), rows, self.halo_rows.data_ptr(), self.halo_rows.shape[0],
                                  self._cnt.data_ptr(), self.owner.data_ptr(), None if lazy_pending is None else lazy_pending.data_ptr(),
                                  self._ws.data_ptr(), self._ws.numel(), s), "pin_dp_mark_halo")
+        # ---- the private rows of every box, box after box (what each rank publishes at the end of the call)
+        if self.lists is None or self.lists.shape[0] < rows:
+            self.lists = torch.empty((int(rows * 1.25) + 1024,), dtype=torch.int32, device=self.device)
+            self.offsets = torch.zeros((self.world + 1,), dtype=torch.int32, device=self.device)
+        need = int(L.pin_dp_owner_lists_workspace_bytes(rows, self.world))
+        if self._ws.numel() < need:
+            self._ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
+        check(L.pin_dp_owner_lists(self.owner.data_ptr(), rows, self.world, self.lists.data_ptr(), self.offsets.data_ptr(),
+                                   self._ws.data_ptr(), self._ws.numel(), s), "pin_dp_owner_lists")
         # ---- partition of every drawn batch
+        W1 = self.world + 1
         if self.counts is None or self.counts.shape[0] < iters:
             self.counts = torch.zeros((max(iters, 16), 2), dtype=torch.int32, device=self.device)
-            self.counts_host = torch.zeros((max(iters, 16) * 2 + 1,), dtype=torch.int32).pin_memory()
+            self.counts_host = torch.zeros((max(iters, 16) * 2 + 1 + W1,), dtype=torch.int32).pin_memory()
         want_cap = int(n / self.world * 1.15) + 1024
         want_ecap = (int((n + decimation - 1) // decimation / self.world * 1.25) + 256) if eikonal else 0
         while True:
@@ -201,6 +215,7 @@ class SpatialShards:
             ch = self.counts_host
             ch[:2 * iters].copy_(self.counts[:iters].reshape(-1), non_blocking=True)
             ch[2 * iters:2 * iters + 1].copy_(self._cnt, non_blocking=True)
+            ch[2 * iters + 1:2 * iters + 1 + W1].copy_(self.offsets, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             cnt = ch[:2 * iters].numpy().reshape(iters, 2).copy()
             if cnt[:, 0].max(initial=0) <= self.cap and (not eikonal or cnt[:, 1].max(initial=0) <= self.ecap):
@@ -211,6 +226,8 @@ class SpatialShards:
         self.n_main, self.n_eik = cnt[:, 0].astype(int), (cnt[:, 1].astype(int) if eikonal else np.zeros(iters, int))
         self.eik_cap = ecap
         self.n_halo = int(ch[2 * iters])
+        self.offsets_host = ch[2 * iters + 1:2 * iters + 1 + W1].numpy().astype(np.int64).copy()
+        self.seg_rows = int(np.diff(self.offsets_host).max(initial=0))
         if self.n_halo > self.halo_rows.shape[0]:
             raise RuntimeError("halo list overflow")  # (cannot happen: the list is sized for every row)
         # ---- exchange buffer [decoder grads | halo-row grads] and the halo's compact Adam moments
@@ -226,7 +243,8 @@ class SpatialShards:
             self.hv[:8 * self.n_halo].zero_()
         self.nd = nd
         self.stats = dict(rows=rows, halo_rows=self.n_halo, halo_fraction=self.n_halo / max(rows, 1),
-                          exchange_bytes=4 * nx, samples_min=int(self.n_main.min()) if iters else 0, samples_max=int(self.n_main.max()) if iters else 0,
+                          exchange_bytes=4 * nx, merge=self.merge,
+                          merge_bytes_per_call=(40 * self.seg_rows * self.world + 12 * self.n_halo) if self.merge == "gather" else (32 + 8) * rows, samples_min=int(self.n_main.min()) if iters else 0, samples_max=int(self.n_main.max()) if iters else 0,
                           samples_ideal=n / self.world)
         self._hist, self._new, self._new_idx, self._pool_coord = hist, new, new_idx, pool_coord
         return self
@@ -267,11 +285,41 @@ class SpatialShards:
                                  float(eps), s), "pin_dp_halo_adam")
 
     # ------------------------------------------------------------------ end of the call
-    def publish(self, feats: torch.Tensor, scratch: torch.Tensor):
-        """Every rank's owned rows -> the whole trained table on every rank (rows [0, n_rows) of `feats`; the padding row
-        behind them never trains).  scratch: n_rows * 8 floats that may be overwritten (the lazy optimiser's moment
-        array: it is rebuilt from scratch by the next call)."""
-        rows = self.stats["rows"]
-        check(_lib.lib().pin_dp_owner_pack(self.owner.data_ptr(), self.rank, feats.data_ptr(), rows, scratch.data_ptr(), ops._stream()),
-              "pin_dp_owner_pack")
-        self.comm.allreduce(scratch[:8 * rows], feats.reshape(-1)[:8 * rows])
+    def publish(self, feats: torch.Tensor, scratch: torch.Tensor, certainty: torch.Tensor, certainty0: torch.Tensor,
+                cert_scratch: torch.Tensor, ts_update: torch.Tensor):
+        """The trained table, the certainties and the timestamps on every rank (rows [0, n_rows); the padding row behind
+        them never trains).  merge "gather": every rank packs the (features, certainty, ts_update) of the rows it OWNS
+        (a private row is only ever touched by its owner's samples, so the owner's values are the merged values), one
+        all-gather, everybody unpacks the others' rows; the halo rows' features are identical everywhere already, their
+        certainty (sum of the ranks' deltas) and ts_update (max) go through the side-effect exchange in compact form.
+        merge "reduce": owner ? row : 0 all-reduced into the table + the side-effect exchange over every row.
+        scratch: n_rows * 8 floats that may be overwritten (the lazy optimiser's moment array: rebuilt by the next call)."""
+        L, s = _lib.lib(), ops._stream()
+        rows, W = self.stats["rows"], self.world
+        if self.merge != "gather":
+            check(L.pin_dp_owner_pack(self.owner.data_ptr(), self.rank, feats.data_ptr(), rows, scratch.data_ptr(), s), "pin_dp_owner_pack")
+            self.comm.allreduce(scratch[:8 * rows], feats.reshape(-1)[:8 * rows])
+            self.comm.sync_side_effects(certainty, certainty0, cert_scratch, ts_update)
+            return
+        seg, nh = self.seg_rows, self.n_halo
+        if self._send is None or self._send.numel() < 10 * seg or self._recv.numel() < 10 * seg * W:
+            cap = int(10 * seg * 1.1) + 1024
+            self._send = torch.empty((cap,), dtype=torch.float32, device=self.device)
+            self._recv = torch.empty((cap * W,), dtype=torch.float32, device=self.device)
+        if self._side is None or self._side[0].numel() < nh:
+            cap = int(nh * 1.25) + 1024
+            self._side = (torch.empty((cap,), dtype=torch.float32, device=self.device), torch.empty((cap,), dtype=torch.float32, device=self.device),
+                          torch.empty((cap,), dtype=torch.float32, device=self.device), torch.empty((cap,), dtype=torch.int32, device=self.device))
+        mine = int(self.offsets_host[self.rank + 1] - self.offsets_host[self.rank])
+        check(L.pin_dp_rows_pack(self.lists.data_ptr() + 4 * int(self.offsets_host[self.rank]), mine, feats.data_ptr(), certainty.data_ptr(),
+                                 ts_update.data_ptr(), self._send.data_ptr(), s), "pin_dp_rows_pack")
+        self.comm.allgather(self._send[:10 * seg], self._recv[:10 * seg * W])
+        check(L.pin_dp_rows_unpack(self._recv.data_ptr(), seg, self.lists.data_ptr(), self.offsets.data_ptr(), W, self.rank,
+                                   feats.data_ptr(), certainty.data_ptr(), ts_update.data_ptr(), s), "pin_dp_rows_unpack")
+        if nh:
+            cc, cc0, csc, cts = (t[:nh] for t in self._side)
+            check(L.pin_dp_halo_side_gather(self.halo_rows.data_ptr(), nh, certainty.data_ptr(), certainty0.data_ptr(), ts_update.data_ptr(),
+                                            cc.data_ptr(), cc0.data_ptr(), cts.data_ptr(), s), "pin_dp_halo_side_gather")
+            self.comm.sync_side_effects(cc, cc0, csc, cts)
+            check(L.pin_dp_halo_side_scatter(self.halo_rows.data_ptr(), nh, cc.data_ptr(), cts.data_ptr(), certainty.data_ptr(),
+                                             ts_update.data_ptr(), s), "pin_dp_halo_side_scatter")

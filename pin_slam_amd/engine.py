@@ -472,8 +472,8 @@ class MapTrainer:
             dense = None
         stepped = self.lazy.t > 0
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
-        if self.dp is not None and stepped:  # every rank's owned rows -> the whole table everywhere (the moment array is free now)
-            self.dp.publish(self.fs.feats, self.m[nd:])
+        if self.dp is not None and stepped:  # every rank's owned rows (and all side effects) everywhere; the moment array is free now
+            self.dp.publish(self.fs.feats, self.m[nd:], self.fs.certainty, self._cert0, self._cert_scratch, self.ts_update)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], True) if self.c_train_dec else None
@@ -506,6 +506,6 @@ class MapTrainer:
     def merge_side_effects(self):
         """world > 1: certainty / ts_update side effects of the other ranks' shards, once per mapping call
         (pin_dp_sync_side_effects)."""
-        if self.comm is None:
+        if self.comm is None or self.dp is not None:  # (spatial shards: the side effects are merged with the rows, SpatialShards.publish)
             return
         self.comm.sync_side_effects(self.fs.certainty, self._cert0, self._cert_scratch, self.ts_update)

@@ -224,7 +224,7 @@ def run(args):
     import torch
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
-    log = {"impl": args.impl, "frames": args.frames, "scan_points": args.scan_points}
+    log = {"impl": args.impl, "frames": args.frames, "scan_points": args.scan_points, "seed": args.seed}
     ref = reference_tree(args.reference)
     work = tempfile.mkdtemp(prefix="pin_e2e_")
     pc_dir, gt = write_sequence(work, args.frames, n_scan=args.scan_points)
@@ -269,7 +269,7 @@ def run(args):
         keep["dataset"] = self
     sd.SLAMDataset.__init__ = spy_init
     t0 = time.perf_counter()
-    pin_slam.run_pin_slam(cfg_path, None, None, None, None, None, 42, False, False, args.impl == "reference", False, False,
+    pin_slam.run_pin_slam(cfg_path, None, None, None, None, None, args.seed, False, False, args.impl == "reference", False, False,
                           True, False, False, False)
     log["wall_s"] = round(time.perf_counter() - t0, 2)
     ds = keep["dataset"]
@@ -325,6 +325,7 @@ def main():
     r.add_argument("--frames", type=int, default=10)
     r.add_argument("--iters", type=int, default=15)
     r.add_argument("--scan-points", type=int, default=60_000, help="points per simulated scan")
+    r.add_argument("--seed", type=int, default=42, help="seed handed to run_pin_slam (feature initialisation, batch draws)")
     r.add_argument("--per-neighbour", action="store_true", help="weighted_first: False, query_nn_k: 6 (run_kitti.yaml style)")
     r.add_argument("--livox-style", action="store_true", help="run_livox.yaml style: weighted_first False, query_nn_k 8, "
                                                               "numerical_grad_on False (analytic Eikonal term)")

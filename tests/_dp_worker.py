@@ -36,6 +36,8 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         # this rank's HOST comes up with other boxes than rank 0's: it must still run with rank 0's (pin_dp_boxes_decode)
         from pin_slam_amd import dp as dpm
         t.dp.fixed_boxes = dpm.kd_boxes(np.floor(d["map_coord1"][::3] / d["resolution"]).astype(np.int32) + 2, world)
+    if mode == "spatial-reduce":  # the end-of-call merge as an all-reduce of the table instead of the all-gather of owned rows
+        t.dp.merge = "reduce"
     mode = mode.split("-")[0]
     grads = []
     t.on_grads = lambda g: grads.append(g.cpu().numpy().copy())
