@@ -290,6 +290,9 @@ typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapp
     float surface_range;     /* surface_sample_range_m: samples with |sdf_label| below it carry colour */
     float weight_i;          /* config.weight_i */
     int32_t dec_image_current;/* as in pin_train_params, for the colour field's dec_image */
+    const int32_t* surface_count; /* DEVICE, may be NULL: the number of surface samples of the GLOBAL batch when this call
+                              * evaluates a shard of it (the colour loss is a mean over them, utils/loss.py:31-42);
+                              * NULL = count the samples of this call */
 } pin_train_color_params;
 
 /* ---- library ------------------------------------------------------------------- */
@@ -755,12 +758,14 @@ int pin_dp_sample_cells(const float* pool_coord, const int64_t* index_history, i
  * of them with i % decimation == 0 (the Eikonal sub-sample coord[::dec] of the GLOBAL batch, mapper.py:683).
  * counts_out [n_batches][2] is cleared here; an entry larger than cap / eik_cap means the lists are truncated
  * (grow and call again).  Index arrays as in pin_gather_batches_drawn.  pool_region [pool_rows] (scratch, one byte per
- * pool row): the box of every row of pool_coord is computed once, the draws then look it up. */
+ * pool row): the box of every row of pool_coord is computed once, the draws then look it up.  pool_label /
+ * surface_counts_out (may be NULL): surface_counts_out[b] = samples of the WHOLE batch b with |label| < surface_range --
+ * the normalisation of the colour loss, which a rank cannot count from its own samples. */
 int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coord, const int64_t* index_history, int32_t n_history,
                      const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t decimation,
                      int32_t n_batches, int64_t hist_stride, int64_t new_stride, int32_t* sel_out, int32_t cap,
                      int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out, int64_t pool_rows, uint8_t* pool_region,
-                     void* stream);
+                     const float* pool_label, float surface_range, int32_t* surface_counts_out, void* stream);
 
 /* Mapper.get_batch for the selected samples of n_batches drawn batches (b-th batch: sel / eik_sel / counts rows
  * b0 + b of pin_dp_partition's outputs): *_out[b][j] = pool row of batch position sel[b][j], j < counts[b][0];
@@ -800,8 +805,9 @@ int pin_dp_owner_pack(const uint8_t* owner, int32_t rank, const float* feats, in
 /* End of the call, form 2 (half the bytes: an all-GATHER of what each rank owns instead of an all-reduce of the table).
  * pin_dp_owner_lists: lists_out = the PRIVATE rows (no halo bit) of box 0, then of box 1, ... (a deterministic counting
  * sort of owner[]: the same lists on every rank), offsets_out [world + 1] (device) where each list starts.
- * pin_dp_rows_pack: out[j] = (8 features, certainty, ts_update bits) of row rows[j] -- a rank packs ITS list, padded by the
- * caller to the longest list (segment_rows); pin_allgather_f32 (ncclAllGather, count_per_rank = 10 * segment_rows floats);
+ * pin_dp_rows_pack: out[j] = (8 features, certainty, ts_update bits[, 8 colour features when color_feats != NULL]) of row
+ * rows[j] -- a rank packs ITS list, padded by the caller to the longest list (segment_rows); pin_allgather_f32
+ * (ncclAllGather, count_per_rank = 10 (18 with colour) * segment_rows floats);
  * pin_dp_rows_unpack: the other ranks' records back into the tables.  A private row is only ever touched by its owner's
  * samples -- features, certainty and ts_update alike -- so the owner's values ARE the merged values; the halo rows'
  * certainty (sum of deltas) and ts_update (max) go through pin_dp_sync_side_effects in compact form
@@ -810,9 +816,11 @@ int64_t pin_dp_owner_lists_workspace_bytes(int32_t n_rows, int32_t world);
 int pin_dp_owner_lists(const uint8_t* owner, int32_t n_rows, int32_t world, int32_t* lists_out, int32_t* offsets_out,
                        void* workspace, int64_t workspace_bytes, void* stream);
 int pin_dp_rows_pack(const int32_t* rows, int32_t count, const float* feats, const float* certainty, const int32_t* ts_update,
-                     float* out, void* stream);
+                     const float* color_feats, float* out, void* stream);
 int pin_dp_rows_unpack(const float* gathered, int32_t segment_rows, const int32_t* lists, const int32_t* offsets, int32_t world,
-                       int32_t rank, float* feats, float* certainty, int32_t* ts_update, void* stream);
+                       int32_t rank, float* feats, float* certainty, int32_t* ts_update, float* color_feats, void* stream);
+/* lazy_pending[rows[h]] <- PIN_ADAM_ROW_EXCLUDED: the halo rows of a second lazily stepped table (the colour features). */
+int pin_dp_exclude_rows(const int32_t* rows, int32_t n, int32_t* lazy_pending, void* stream);
 int pin_dp_halo_side_gather(const int32_t* halo_rows, int32_t n_halo, const float* certainty, const float* certainty0,
                             const int32_t* ts_update, float* cert_out, float* cert0_out, int32_t* ts_out, void* stream);
 int pin_dp_halo_side_scatter(const int32_t* halo_rows, int32_t n_halo, const float* cert_in, const int32_t* ts_in,

@@ -123,7 +123,7 @@ class TrainParams(C.Structure):
 
 class TrainColorParams(C.Structure):
     _fields_ = [("n_main", C.c_int32), ("loss_weight_on", C.c_int32), ("surface_range", C.c_float),
-                ("weight_i", C.c_float), ("dec_image_current", C.c_int32)]
+                ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("surface_count", vp)]
 
 
 class DpRegions(C.Structure):
@@ -219,7 +219,7 @@ SIGNATURES = {
     "pin_dp_kd_boxes": (i32, [vp, i32, i32, vp]),
     "pin_dp_boxes_decode": (i32, [vp, i32, vp, vp]),
     "pin_dp_sample_cells": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
-    "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp]),
+    "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, f32, vp, vp]),
     "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,
                             vp, vp, f32, vp]),
     "pin_dp_mark_halo": (i32, [P(DpRegions), vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]),
@@ -228,8 +228,9 @@ SIGNATURES = {
     "pin_dp_owner_pack": (i32, [vp, i32, vp, i32, vp, vp]),
     "pin_dp_owner_lists_workspace_bytes": (i64, [i32, i32]),
     "pin_dp_owner_lists": (i32, [vp, i32, i32, vp, vp, vp, i64, vp]),
-    "pin_dp_rows_pack": (i32, [vp, i32, vp, vp, vp, vp, vp]),
-    "pin_dp_rows_unpack": (i32, [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "pin_dp_rows_pack": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+    "pin_dp_rows_unpack": (i32, [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_dp_exclude_rows": (i32, [vp, i32, vp, vp]),
     "pin_dp_halo_side_gather": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     "pin_dp_halo_side_scatter": (i32, [vp, i32, vp, vp, vp, vp, vp]),
     "pin_allgather_f32": (i32, [vp, vp, vp, i64, vp]),

@@ -99,10 +99,12 @@ __global__ __launch_bounds__(256) void dp_partition_kernel(int rank, const unsig
                                                            const long long* __restrict__ index_new_batch,
                                                            const long long* __restrict__ new_idx, int n, int dec,
                                                            long hist_stride, long new_stride, int* __restrict__ sel, int cap,
-                                                           int* __restrict__ esel, int ecap, int* __restrict__ counts) {
+                                                           int* __restrict__ esel, int ecap, int* __restrict__ counts,
+                                                           const float* __restrict__ pool_label, float surface_range,
+                                                           int* __restrict__ surf_counts) {
     __shared__ int picks[PART_CHUNK], epicks[PART_CHUNK];
-    __shared__ int n_pick, n_epick, base, ebase;
-    if (threadIdx.x == 0) { n_pick = 0; n_epick = 0; }
+    __shared__ int n_pick, n_epick, base, ebase, n_surf;
+    if (threadIdx.x == 0) { n_pick = 0; n_epick = 0; n_surf = 0; }
     __syncthreads();
     const int b = blockIdx.y;
     index_hist += (size_t)b * hist_stride;
@@ -110,8 +112,16 @@ __global__ __launch_bounds__(256) void dp_partition_kernel(int rank, const unsig
     const int lane = threadIdx.x & 63;
     for (int r = 0; r < PART_PER_THREAD; ++r) {
         const int i = blockIdx.x * PART_CHUNK + r * 256 + threadIdx.x;
-        bool mine = false;
-        if (i < n) mine = region[drawn_row(index_hist, n_hist, index_new_batch, new_idx, i)] == rank;
+        bool mine = false, surf = false;
+        if (i < n) {
+            const size_t row = drawn_row(index_hist, n_hist, index_new_batch, new_idx, i);
+            mine = region[row] == rank;
+            if (surf_counts != nullptr) surf = fabsf(pool_label[row]) < surface_range;  // (of the WHOLE batch, whoever trains it)
+        }
+        if (surf_counts != nullptr) {
+            const unsigned long long sb = __ballot(surf);
+            if (lane == 0 && sb) atomicAdd(&n_surf, __popcll(sb));
+        }
         const bool eik = mine && ecap > 0 && (i % dec) == 0;
         const unsigned long long bal = __ballot(mine), ebal = __ballot(eik);
         int wbase = 0, webase = 0;
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(256) void dp_partition_kernel(int rank, const unsig
     if (threadIdx.x == 0) {
         base = n_pick ? atomicAdd(counts + 2 * b, n_pick) : 0;
         ebase = n_epick ? atomicAdd(counts + 2 * b + 1, n_epick) : 0;
+        if (surf_counts != nullptr && n_surf) atomicAdd(surf_counts + b, n_surf);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < n_pick; j += 256)
@@ -318,32 +329,40 @@ __global__ __launch_bounds__(MB) void dp_owner_scatter_kernel(const unsigned cha
     }
 }
 
-// the record of a published row: 8 features, its certainty, its ts_update bits
-constexpr int DP_REC = 10;
+// the record of a published row: 8 features, its certainty, its ts_update bits (+ the 8 colour features of a colour map)
+constexpr int DP_REC = 10, DP_REC_COLOR = 18;
 __global__ __launch_bounds__(256) void dp_rows_pack_kernel(const int* __restrict__ rows, int count, const float* __restrict__ feats,
                                                            const float* __restrict__ cert, const int* __restrict__ ts,
-                                                           float* __restrict__ out) {
+                                                           const float* __restrict__ cfeats, int rec, float* __restrict__ out) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)count * DP_REC) return;
-    const int j = (int)(t / DP_REC), c = (int)(t - (long)j * DP_REC);
+    if (t >= (long)count * rec) return;
+    const int j = (int)(t / rec), c = (int)(t - (long)j * rec);
     const size_t r = (size_t)rows[j];
-    out[t] = c < 8 ? feats[r * PIN_FEATURE_DIM + c] : (c == 8 ? cert[r] : __int_as_float(ts[r]));
+    out[t] = c < 8 ? feats[r * PIN_FEATURE_DIM + c] : (c == 8 ? cert[r] : (c == 9 ? __int_as_float(ts[r]) : cfeats[r * PIN_FEATURE_DIM + (c - 10)]));
 }
 
 __global__ __launch_bounds__(256) void dp_rows_unpack_kernel(const float* __restrict__ all, int seg, const int* __restrict__ lists,
                                                              const int* __restrict__ offsets, int world, int rank,
-                                                             float* __restrict__ feats, float* __restrict__ cert, int* __restrict__ ts) {
+                                                             float* __restrict__ feats, float* __restrict__ cert, int* __restrict__ ts,
+                                                             float* __restrict__ cfeats, int rec) {
     const int o = blockIdx.y;
     if (o == rank) return;
     const int count = offsets[o + 1] - offsets[o];
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)count * DP_REC) return;
-    const int j = (int)(t / DP_REC), c = (int)(t - (long)j * DP_REC);
+    if (t >= (long)count * rec) return;
+    const int j = (int)(t / rec), c = (int)(t - (long)j * rec);
     const size_t r = (size_t)lists[offsets[o] + j];
-    const float v = all[((size_t)o * seg + j) * DP_REC + c];
+    const float v = all[((size_t)o * seg + j) * rec + c];
     if (c < 8) feats[r * PIN_FEATURE_DIM + c] = v;
     else if (c == 8) cert[r] = v;
-    else ts[r] = __float_as_int(v);
+    else if (c == 9) ts[r] = __float_as_int(v);
+    else cfeats[r * PIN_FEATURE_DIM + (c - 10)] = v;
+}
+
+// pending words of the halo rows of another lazily stepped table (the colour features) parked like the first one's
+__global__ __launch_bounds__(256) void dp_exclude_rows_kernel(const int* __restrict__ rows, int n, int* __restrict__ pend) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h < n) pend[rows[h]] = PIN_ADAM_ROW_EXCLUDED;
 }
 
 // side effects of the halo rows in compact form (the certainty sum / ts max of pin_dp_sync_side_effects run over these)
@@ -458,7 +477,8 @@ extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coor
                                 int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
                                 int32_t decimation, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
                                 int32_t* sel_out, int32_t cap, int32_t* eik_sel_out, int32_t eik_cap, int32_t* counts_out,
-                                int64_t pool_rows, uint8_t* pool_region, void* stream) {
+                                int64_t pool_rows, uint8_t* pool_region, const float* pool_label, float surface_range,
+                                int32_t* surface_counts_out, void* stream) {
     PIN_ENTER();
     if (int e = check_regions(rg)) return e;
     PIN_CHECK_ARG(pool_rows >= 0 && (pool_rows == 0 || pool_region), "pool_region NULL");
@@ -467,6 +487,8 @@ extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coor
     if (n_batches == 0) return 0;
     PIN_CHECK_ARG(counts_out, "NULL pointer");
     PIN_CHECK_HIP(hipMemsetAsync(counts_out, 0, sizeof(int32_t) * 2 * (size_t)n_batches, as_stream(stream)));
+    PIN_CHECK_ARG(surface_counts_out == nullptr || pool_label, "surface counts need pool_label");
+    if (surface_counts_out) PIN_CHECK_HIP(hipMemsetAsync(surface_counts_out, 0, sizeof(int32_t) * (size_t)n_batches, as_stream(stream)));
     if (n == 0) return 0;
     PIN_CHECK_ARG(pool_coord && sel_out && (eik_cap == 0 || eik_sel_out) && (n_history == 0 || index_history), "NULL pointer");
     PIN_CHECK_ARG(n_history == n || (index_new_batch && new_idx), "index_new_batch / new_idx NULL");
@@ -477,7 +499,8 @@ extern "C" int pin_dp_partition(const pin_dp_regions* rg, const float* pool_coor
     hipLaunchKernelGGL(dp_partition_kernel, dim3(cdiv(n, PART_CHUNK), n_batches), dim3(256), 0, as_stream(stream), rg->rank, pool_region,
                        reinterpret_cast<const long long*>(index_history), n_history,
                        reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), n,
-                       decimation, (long)hist_stride, (long)new_stride, sel_out, cap, eik_sel_out, eik_cap, counts_out);
+                       decimation, (long)hist_stride, (long)new_stride, sel_out, cap, eik_sel_out, eik_cap, counts_out, pool_label,
+                       surface_range, surface_counts_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -577,26 +600,39 @@ extern "C" int64_t pin_dp_owner_lists_workspace_bytes(int32_t n_rows, int32_t wo
     return 512 + (int64_t)sizeof(int) * (world < 1 ? 1 : world) * (int64_t)cdiv(n_rows < 0 ? 0 : n_rows, MB);
 }
 
+extern "C" int pin_dp_exclude_rows(const int32_t* rows, int32_t n, int32_t* lazy_pending, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(rows && lazy_pending, "NULL pointer");
+    hipLaunchKernelGGL(dp_exclude_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), rows, n, lazy_pending);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_dp_rows_pack(const int32_t* rows, int32_t count, const float* feats, const float* certainty,
-                                const int32_t* ts_update, float* out, void* stream) {
+                                const int32_t* ts_update, const float* color_feats, float* out, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(count >= 0, "count < 0");
     if (count == 0) return 0;
     PIN_CHECK_ARG(rows && feats && certainty && ts_update && out, "NULL pointer");
-    hipLaunchKernelGGL(dp_rows_pack_kernel, dim3(cdiv((long)count * DP_REC, 256)), dim3(256), 0, as_stream(stream), rows, count, feats,
-                       certainty, ts_update, out);
+    const int rec = color_feats ? DP_REC_COLOR : DP_REC;
+    hipLaunchKernelGGL(dp_rows_pack_kernel, dim3(cdiv((long)count * rec, 256)), dim3(256), 0, as_stream(stream), rows, count, feats,
+                       certainty, ts_update, color_feats, rec, out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int pin_dp_rows_unpack(const float* gathered, int32_t segment_rows, const int32_t* lists, const int32_t* offsets,
-                                  int32_t world, int32_t rank, float* feats, float* certainty, int32_t* ts_update, void* stream) {
+                                  int32_t world, int32_t rank, float* feats, float* certainty, int32_t* ts_update,
+                                  float* color_feats, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(segment_rows >= 0 && world >= 1 && world <= DP_MAX_WORLD && rank >= 0 && rank < world, "bad arguments");
     if (segment_rows == 0 || world == 1) return 0;
     PIN_CHECK_ARG(gathered && lists && offsets && feats && certainty && ts_update, "NULL pointer");
-    hipLaunchKernelGGL(dp_rows_unpack_kernel, dim3(cdiv((long)segment_rows * DP_REC, 256), world), dim3(256), 0, as_stream(stream),
-                       gathered, segment_rows, lists, offsets, world, rank, feats, certainty, ts_update);
+    const int rec = color_feats ? DP_REC_COLOR : DP_REC;
+    hipLaunchKernelGGL(dp_rows_unpack_kernel, dim3(cdiv((long)segment_rows * rec, 256), world), dim3(256), 0, as_stream(stream),
+                       gathered, segment_rows, lists, offsets, world, rank, feats, certainty, ts_update, color_feats, rec);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -1113,9 +1113,11 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
     int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)train_ws_floats(Q, H, L, expand) * 4);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     const dim3 mgrid(cdiv(ws.Qs, MF_BLOCK)), mblock(MF_BLOCK);
-    PIN_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    const bool given = tp->surface_count != nullptr;  // (a shard of a larger batch: the caller knows the batch's count)
+    if (given) count = const_cast<int*>(tp->surface_count);
+    else PIN_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     if (fc->weighted_first) {  // the fused tile kernel with three heads + the streamed weight gradient (train_fused.h)
-        hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
+        if (!given) hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
         pin_train_params sp;
         memset(&sp, 0, sizeof(sp));
         sp.n_main = Q;  // plain tiles of 16 samples, no probes
@@ -1135,7 +1137,7 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
         else hipLaunchKernelGGL((KERNEL<32, false, 3>), mgrid, mblock, 0, s, __VA_ARGS__);          \
     } while (0)
     PIN_TRAIN_C(train_fwd_mfma_kernel, *fc, query, nb4, nn_count, Q, Q, ws, (float*)nullptr, (int*)nullptr, (const int*)nullptr);
-    hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
+    if (!given) hipLaunchKernelGGL(color_count_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, sdf_label, Q, tp->surface_range, count);
     hipLaunchKernelGGL(train_color_loss_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, s, *tp, sdf_label, color_label,
                        sample_weight, ws, count, loss_out);
     const int want_dec = dec_grad != nullptr;

@@ -106,7 +106,7 @@ class SpatialShards:
         self.cap = self.ecap = 0
         self.counts_host = None
         self._ws = self._pool_region = self._halves = self._halves_host = None
-        self.lists = self.offsets = self._send = self._recv = self._side = None
+        self.lists = self.offsets = self._send = self._recv = self._side = self.surf_counts = None
         # end-of-call merge: "gather" = every rank publishes the rows it owns (all-gather, certainty / ts ride along, the halo's
         # side effects in compact form); "reduce" = all-reduce of the whole table + the side-effect all-reduces over every row
         self.merge = "gather"
@@ -128,7 +128,8 @@ class SpatialShards:
 
     def plan(self, pool_coord: torch.Tensor, hist: torch.Tensor, new: Optional[torch.Tensor], new_idx, *, decimation: int,
              eikonal: bool, resolution: float, reach: int, pos: torch.Tensor, lazy_pending: Optional[torch.Tensor],
-             nd: int, pool_rows: Optional[int] = None):
+             nd: int, pool_rows: Optional[int] = None, color_pending: Optional[torch.Tensor] = None,
+             pool_label: Optional[torch.Tensor] = None, surface_range: float = 0.0):
         """Everything a Mapper.mapping call needs before its first iteration: boxes from a sub-sample of the first drawn
         batch (host, one small read-back), the halo of the feature rows at `pos`, the partition of ALL drawn batches
         (hist [iters][n_hist] / new [iters][n_new] int64, as Mapper._draw_all makes them) and its counts (second
@@ -209,9 +210,13 @@ class SpatialShards:
             pool_rows = pool_coord.shape[0] if pool_rows is None else int(pool_rows)
             if self._pool_region is None or self._pool_region.shape[0] < pool_rows:
                 self._pool_region = torch.empty((int(pool_rows * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
+            want_surf = color_pending is not None and pool_label is not None
+            if want_surf and (self.surf_counts is None or self.surf_counts.shape[0] < iters):
+                self.surf_counts = torch.zeros((max(iters, 16),), dtype=torch.int32, device=self.device)
             check(L.pin_dp_partition(C.byref(rg), pool_coord.data_ptr(), hp, n_hist, npn, nip, n, int(decimation), iters, hs, ns,
                                      self.sel.data_ptr(), self.cap, self.esel.data_ptr(), ecap, self.counts.data_ptr(), pool_rows,
-                                     self._pool_region.data_ptr(), s), "pin_dp_partition")
+                                     self._pool_region.data_ptr(), pool_label.data_ptr() if want_surf else None, float(surface_range),
+                                     self.surf_counts.data_ptr() if want_surf else None, s), "pin_dp_partition")
             ch = self.counts_host
             ch[:2 * iters].copy_(self.counts[:iters].reshape(-1), non_blocking=True)
             ch[2 * iters:2 * iters + 1].copy_(self._cnt, non_blocking=True)
@@ -230,21 +235,26 @@ class SpatialShards:
         self.seg_rows = int(np.diff(self.offsets_host).max(initial=0))
         if self.n_halo > self.halo_rows.shape[0]:
             raise RuntimeError("halo list overflow")  # (cannot happen: the list is sized for every row)
-        # ---- exchange buffer [decoder grads | halo-row grads] and the halo's compact Adam moments
-        nx = nd + 8 * self.n_halo
+        # ---- exchange buffer [decoder grads | halo-row grads (| the colour table's halo-row grads)] and the halo's compact
+        # Adam moments (geometry first, colour behind)
+        self.tables = 2 if color_pending is not None else 1
+        if color_pending is not None:
+            check(L.pin_dp_exclude_rows(self.halo_rows.data_ptr(), self.n_halo, color_pending.data_ptr(), s), "pin_dp_exclude_rows")
+        nx = nd + 8 * self.n_halo * self.tables
         if self.xbuf is None or self.xbuf.numel() < nx or self._nd != nd:
-            capx = nd + int(8 * self.n_halo * 1.25) + 1024
+            capx = nd + int(8 * self.n_halo * self.tables * 1.25) + 1024
             self.xbuf = torch.zeros((capx,), dtype=torch.float32, device=self.device)
             self.hm = torch.zeros((capx,), dtype=torch.float32, device=self.device)
             self.hv = torch.zeros((capx,), dtype=torch.float32, device=self.device)
             self._nd = nd
         else:
-            self.hm[:8 * self.n_halo].zero_()
-            self.hv[:8 * self.n_halo].zero_()
+            self.hm[:8 * self.n_halo * self.tables].zero_()
+            self.hv[:8 * self.n_halo * self.tables].zero_()
         self.nd = nd
         self.stats = dict(rows=rows, halo_rows=self.n_halo, halo_fraction=self.n_halo / max(rows, 1),
                           exchange_bytes=4 * nx, merge=self.merge,
-                          merge_bytes_per_call=(40 * self.seg_rows * self.world + 12 * self.n_halo) if self.merge == "gather" else (32 + 8) * rows, samples_min=int(self.n_main.min()) if iters else 0, samples_max=int(self.n_main.max()) if iters else 0,
+                          merge_bytes_per_call=((40 + 32 * (self.tables - 1)) * self.seg_rows * self.world + 12 * self.n_halo)
+                          if self.merge == "gather" else (32 * self.tables + 8) * rows, samples_min=int(self.n_main.min()) if iters else 0, samples_max=int(self.n_main.max()) if iters else 0,
                           samples_ideal=n / self.world)
         self._hist, self._new, self._new_idx, self._pool_coord = hist, new, new_idx, pool_coord
         return self
@@ -268,25 +278,34 @@ class SpatialShards:
 
     # ------------------------------------------------------------------ per iteration
     def exchange(self, feats: torch.Tensor, gfeat: torch.Tensor, step: int, coef: torch.Tensor, t_max: int, b1, b2, eps,
-                 on_allreduce=None):
+                 on_allreduce=None, color=None):
         """After the backward pass of iteration `step`: halo gradients into the exchange buffer (its head already holds
-        the decoder gradient), ONE all-reduce, the dense Adam step on the halo rows."""
+        the decoder gradients), ONE all-reduce, the dense Adam step on the halo rows.  color = (colour features, their
+        gradient table) of a colour map: the same rows of the second table ride in the same message."""
         L, s = _lib.lib(), ops._stream()
-        nx = self.nd + 8 * self.n_halo
-        check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), self.n_halo, gfeat.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd, s),
+        nh = self.n_halo
+        nx = self.nd + 8 * nh * self.tables
+        check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), nh, gfeat.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd, s),
               "pin_dp_halo_pack")
+        if color is not None:
+            check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), nh, color[1].data_ptr(), self.xbuf.data_ptr() + 4 * (self.nd + 8 * nh), s),
+                  "pin_dp_halo_pack")
         if on_allreduce is not None:
             on_allreduce(True)
         self.comm.allreduce(self.xbuf[:nx], self.xbuf[:nx])
         if on_allreduce is not None:
             on_allreduce(False)
-        check(L.pin_dp_halo_adam(self.halo_rows.data_ptr(), self.n_halo, feats.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd,
+        check(L.pin_dp_halo_adam(self.halo_rows.data_ptr(), nh, feats.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd,
                                  self.hm.data_ptr(), self.hv.data_ptr(), int(step), coef.data_ptr(), int(t_max), float(b1), float(b2),
                                  float(eps), s), "pin_dp_halo_adam")
+        if color is not None:
+            check(L.pin_dp_halo_adam(self.halo_rows.data_ptr(), nh, color[0].data_ptr(), self.xbuf.data_ptr() + 4 * (self.nd + 8 * nh),
+                                     self.hm.data_ptr() + 32 * nh, self.hv.data_ptr() + 32 * nh, int(step), coef.data_ptr(), int(t_max),
+                                     float(b1), float(b2), float(eps), s), "pin_dp_halo_adam")
 
     # ------------------------------------------------------------------ end of the call
     def publish(self, feats: torch.Tensor, scratch: torch.Tensor, certainty: torch.Tensor, certainty0: torch.Tensor,
-                cert_scratch: torch.Tensor, ts_update: torch.Tensor):
+                cert_scratch: torch.Tensor, ts_update: torch.Tensor, color=None):
         """The trained table, the certainties and the timestamps on every rank (rows [0, n_rows); the padding row behind
         them never trains).  merge "gather": every rank packs the (features, certainty, ts_update) of the rows it OWNS
         (a private row is only ever touched by its owner's samples, so the owner's values are the merged values), one
@@ -299,11 +318,16 @@ class SpatialShards:
         if self.merge != "gather":
             check(L.pin_dp_owner_pack(self.owner.data_ptr(), self.rank, feats.data_ptr(), rows, scratch.data_ptr(), s), "pin_dp_owner_pack")
             self.comm.allreduce(scratch[:8 * rows], feats.reshape(-1)[:8 * rows])
+            if color is not None:  # color = (colour features, a scratch table of their size)
+                check(L.pin_dp_owner_pack(self.owner.data_ptr(), self.rank, color[0].data_ptr(), rows, color[1].data_ptr(), s), "pin_dp_owner_pack")
+                self.comm.allreduce(color[1][:8 * rows], color[0].reshape(-1)[:8 * rows])
             self.comm.sync_side_effects(certainty, certainty0, cert_scratch, ts_update)
             return
         seg, nh = self.seg_rows, self.n_halo
-        if self._send is None or self._send.numel() < 10 * seg or self._recv.numel() < 10 * seg * W:
-            cap = int(10 * seg * 1.1) + 1024
+        rec = 18 if color is not None else 10
+        cf = None if color is None else color[0].data_ptr()
+        if self._send is None or self._send.numel() < rec * seg or self._recv.numel() < rec * seg * W:
+            cap = int(rec * seg * 1.1) + 1024
             self._send = torch.empty((cap,), dtype=torch.float32, device=self.device)
             self._recv = torch.empty((cap * W,), dtype=torch.float32, device=self.device)
         if self._side is None or self._side[0].numel() < nh:
@@ -312,10 +336,10 @@ class SpatialShards:
                           torch.empty((cap,), dtype=torch.float32, device=self.device), torch.empty((cap,), dtype=torch.int32, device=self.device))
         mine = int(self.offsets_host[self.rank + 1] - self.offsets_host[self.rank])
         check(L.pin_dp_rows_pack(self.lists.data_ptr() + 4 * int(self.offsets_host[self.rank]), mine, feats.data_ptr(), certainty.data_ptr(),
-                                 ts_update.data_ptr(), self._send.data_ptr(), s), "pin_dp_rows_pack")
-        self.comm.allgather(self._send[:10 * seg], self._recv[:10 * seg * W])
+                                 ts_update.data_ptr(), cf, self._send.data_ptr(), s), "pin_dp_rows_pack")
+        self.comm.allgather(self._send[:rec * seg], self._recv[:rec * seg * W])
         check(L.pin_dp_rows_unpack(self._recv.data_ptr(), seg, self.lists.data_ptr(), self.offsets.data_ptr(), W, self.rank,
-                                   feats.data_ptr(), certainty.data_ptr(), ts_update.data_ptr(), s), "pin_dp_rows_unpack")
+                                   feats.data_ptr(), certainty.data_ptr(), ts_update.data_ptr(), cf, s), "pin_dp_rows_unpack")
         if nh:
             cc, cc0, csc, cts = (t[:nh] for t in self._side)
             check(L.pin_dp_halo_side_gather(self.halo_rows.data_ptr(), nh, certainty.data_ptr(), certainty0.data_ptr(), ts_update.data_ptr(),

@@ -483,7 +483,7 @@ class Mapper(_Base):
             b = p.bufs[0]
             gc = not self.ba_done_flag
             self.dp_stats = t.plan_shards(b["global_coord"] if gc else b["coord"], drawn["hist"], drawn["new"], self.new_idx,
-                                          num_nei_cells=c.num_nei_cells, pool_rows=p.n)
+                                          num_nei_cells=c.num_nei_cells, pool_rows=p.n, pool_label=b["sdf_label"])
             t.run_shards(b, gc, iter_count)
             self.total_iter += iter_count
         t.finish_optimizer()

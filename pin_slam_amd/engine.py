@@ -251,16 +251,18 @@ class MapTrainer:
         if fc is None:
             self.fc = None
             return
-        if self.comm is not None:
-            raise NotImplementedError("colour training is single-GPU for now (the geometry exchange buffer excludes it)")
+        if self.comm is not None and self.dp is None:
+            raise NotImplementedError("colour training with dp_mode = 'dense' (the flat all-reduce buffer holds the geometry only): use the "
+                                      "spatial shards")
         nf, nd = fc.feats.numel(), fc.dec.numel()
         if self.fc is None or self.cgrad.numel() != nf + nd:
             self.cgrad = torch.zeros((nd + nf,), dtype=torch.float32, device=fc.feats.device)
             self.cm, self.cv = torch.zeros_like(self.cgrad), torch.zeros_like(self.cgrad)
         self.fc, self.c_range, self.c_weight, self.c_train_dec = fc, float(surface_range), float(weight_i), train_decoder
+        self.cgdec = self.cgrad[:nd]  # (spatial shards: re-pointed at the exchange buffer by plan_shards)
 
     # ------------------------------------------------------------------ spatially sharded data-parallel mapping (dp.py)
-    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None):
+    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None, pool_label=None):
         """Start of a spatially sharded Mapper.mapping call, after reset_optimizer(): boxes, halo, this rank's samples of
         every drawn batch (SpatialShards.plan) and buffers of the size that came out."""
         dp, fs = self.dp, self.fs
@@ -268,9 +270,14 @@ class MapTrainer:
         res = float(self.st.resolution)
         reach = int(num_nei_cells) + (int(np.ceil(float(self.eik_eps) / res - 1e-9)) if eik else 0)
         nd = self.m.numel() - fs.feats.numel()
+        cnd = self.fc.dec.numel() if self.fc is not None else 0
         dp.plan(pool_coord, hist, new, new_idx, decimation=self.dec, eikonal=eik, resolution=res, reach=reach, pos=fs.pos,
-                lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd, pool_rows=pool_rows)
-        self.gdec = dp.xbuf[:nd]  # the decoder gradient lives at the head of the exchange buffer
+                lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd + cnd, pool_rows=pool_rows,
+                color_pending=self.lazy_c.state if (self.fc is not None and self.lazy_on) else None,
+                pool_label=pool_label, surface_range=getattr(self, "c_range", 0.0))
+        self.gdec = dp.xbuf[:nd]  # the decoder gradients live at the head of the exchange buffer
+        if self.fc is not None:
+            self.cgdec = dp.xbuf[nd:nd + cnd]
         b = self.buf
         if b is None or b.cap_main < dp.cap or b.cap_eik < dp.eik_cap or (dp.eik_cap == 0) != (b.cap_eik == 0):
             q_iter = dp.cap + 6 * dp.eik_cap
@@ -282,6 +289,8 @@ class MapTrainer:
                                    label=torch.empty((G, cap), dtype=torch.float32, device=dev),
                                    weight=torch.empty((G, cap), dtype=torch.float32, device=dev),
                                    ts=torch.empty((G, cap), dtype=torch.int32, device=dev), color=None)
+        if self.fc is not None and (self._shard_out.get("color") is None or self._shard_out["color"].shape[:2] != self._shard_out["label"].shape):
+            self._shard_out["color"] = torch.empty(tuple(self._shard_out["label"].shape) + (3,), dtype=torch.float32, device=fs.feats.device)
         # (the partition lists use dp.cap / dp.eik_cap as strides; the buffers above may be larger: gather with the lists' strides)
         if self.buf.cap_main != dp.cap or self.buf.cap_eik != dp.eik_cap:
             raise RuntimeError("shard buffer strides out of step with the partition")  # (grown together above)
@@ -293,7 +302,10 @@ class MapTrainer:
         out = self._shard_out
         for it0 in range(0, iters, buf.group):
             gn = min(buf.group, iters - it0)
-            dp.gather(pool, global_coord, 0, it0, gn, out, buf.query_all, self.eik_eps)
+            C_color = 3 if self.fc is not None else 0
+            if C_color and (pool.get("color") is None or pool["color"].shape[1] != 3):
+                raise RuntimeError("colour training needs a 3-channel colour pool")
+            dp.gather(pool, global_coord, C_color, it0, gn, out if C_color else dict(out, color=None), buf.query_all, self.eik_eps)
             for j in range(gn):
                 it = it0 + j
                 buf.set_counts(j, int(dp.n_main[it]), int(dp.n_eik[it]))
@@ -301,7 +313,8 @@ class MapTrainer:
                 if nm:
                     ops.knn_query(self.st, buf.query, self.fs.k, out=(buf.nbr, buf.nn, None), bricks=self.bricks)
                 self.step_batch(out["coord"][j, :nm], out["label"][j, :nm], out["weight"][j, :nm], out["ts"][j, :nm], it + 1,
-                                queries_ready=True, knn_ready=True)
+                                color_label=out["color"][j, :nm] if C_color else None, queries_ready=True, knn_ready=True,
+                                surface_count=dp.surf_counts[it:it + 1] if C_color else None)
                 if on_iteration is not None:
                     on_iteration(it)
 
@@ -316,7 +329,7 @@ class MapTrainer:
                       bricks=self.bricks)
 
     def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False,
-                   knn_ready: bool = False):
+                   knn_ready: bool = False, surface_count=None):
         """One iteration on an explicit (already gathered) batch shard.  queries_ready: buf.query already holds this
         batch's queries (written by the gather launch); knn_ready: buf.nbr / buf.nn hold their neighbours (knn_group)."""
         nd = self.gdec.numel()
@@ -332,7 +345,7 @@ class MapTrainer:
         # (C5) mapping 1.84 -> 1.73 ms per frame; without one (C3) the two cross-stream dependencies per iteration cost
         # more than the ~15 us they can hide (1.22 -> 1.44 ms) -- hence the default (None = only with a colour branch).
         want = self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None)
-        overlap = bool(lazy and self.train_decoder and want and self.on_grads is None
+        overlap = bool(lazy and self.train_decoder and want and self.on_grads is None and self.dp is None
                        and (self.fs.weighted_first or self.fs.levels == 1) and os.environ.get("PIN_MLP", "") != "f32")
         if overlap:
             main = torch.cuda.current_stream()
@@ -370,23 +383,26 @@ class MapTrainer:
             self._wg_pending = True
         if self.fc is not None:
             cnd = self.fc.dec.numel()
-            cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
+            cdense = self._dense(self.fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
             if lazy:
                 self.lazy_c.prepare(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
-            ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
-                                 self.cgrad[:cnd] if self.c_train_dec else None, surface_range=self.c_range,
-                                 weight_i=self.c_weight, loss_weight_on=self.loss_weight_on, image_current=lazy)
+            if coord.shape[0] > 0:  # (a rank whose box holds none of this batch's samples only takes the decoder's step above)
+                ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
+                                     self.cgdec if self.c_train_dec else None, surface_range=self.c_range,
+                                     weight_i=self.c_weight, loss_weight_on=self.loss_weight_on, image_current=lazy,
+                                     surface_count=surface_count)
             if not lazy:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
                                    eps=self.adam_eps)
                 if self.c_train_dec:
-                    ops.adam_step(self.fc.dec, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
+                    ops.adam_step(self.fc.dec, self.cgdec, self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
         if self.dp is not None:  # spatial shards: [decoder | halo rows] all-reduced, the halo rows' Adam step right behind
             self.dp.exchange(self.fs.feats, self.gfeat, step, self.lazy.coef, self.lazy.t_max, self.lazy.b1, self.lazy.b2,
-                             self.lazy.eps, on_allreduce=self.on_allreduce)
+                             self.lazy.eps, on_allreduce=self.on_allreduce,
+                             color=None if self.fc is None else (self.fc.feats, self.cgrad[self.fc.dec.numel():]))
             if self.on_grads is not None:
-                self.on_grads(self.dp.xbuf[:self.dp.nd + 8 * self.dp.n_halo])
+                self.on_grads(self.dp.xbuf[:self.dp.nd + 8 * self.dp.n_halo * self.dp.tables])
             self.total_iter += 1
             return
         if self.comm is not None:  # SUM of the per-rank gradients of [decoder | features] (pin_allreduce_grads)
@@ -472,12 +488,13 @@ class MapTrainer:
             dense = None
         stepped = self.lazy.t > 0
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)
-        if self.dp is not None and stepped:  # every rank's owned rows (and all side effects) everywhere; the moment array is free now
-            self.dp.publish(self.fs.feats, self.m[nd:], self.fs.certainty, self._cert0, self._cert_scratch, self.ts_update)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
-            cdense = self._dense(self.fc, self.cgrad[:cnd], self.cm[:cnd], self.cv[:cnd], True) if self.c_train_dec else None
+            cdense = self._dense(self.fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], True) if self.c_train_dec else None
             self.lazy_c.flush(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], dense=cdense)
+        if self.dp is not None and stepped:  # every rank's owned rows (and all side effects) everywhere; the moment arrays are free now
+            self.dp.publish(self.fs.feats, self.m[nd:], self.fs.certainty, self._cert0, self._cert_scratch, self.ts_update,
+                            color=None if self.fc is None else (self.fc.feats, self.cm[self.fc.dec.numel():]))
         self._grad_clean = self.train_decoder  # (a frozen decoder's gradient slot is never written either, but keep it simple)
         self.lazy_on = False
 

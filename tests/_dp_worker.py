@@ -30,7 +30,7 @@ def main(rank, world, port, case, transport, out, mode="dense"):
     bs = d["map_coord0"].shape[0]
     t = engine.MapTrainer(st, fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
                           weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
-                          loss_weight_on=bool(d["map_loss_weight_on"]), rank=rank, world=world, comm=comm,
+                          loss_weight_on=bool(d.get("map_loss_weight_on", False)), rank=rank, world=world, comm=comm,
                           dp_mode=mode.split("-")[0])
     if mode == "spatial-skew" and rank != 0:
         # this rank's HOST comes up with other boxes than rank 0's: it must still run with rank 0's (pin_dp_boxes_decode)
@@ -39,8 +39,19 @@ def main(rank, world, port, case, transport, out, mode="dense"):
     if mode == "spatial-reduce":  # the end-of-call merge as an all-reduce of the table instead of the all-gather of owned rows
         t.dp.merge = "reduce"
     mode = mode.split("-")[0]
-    grads = []
-    t.on_grads = lambda g: grads.append(g.cpu().numpy().copy())
+    fc = None
+    if "cdec_flat" in d:  # a colour map (replica_color): the colour branch rides along (mapper.py:668-671, 802-812)
+        import dataclasses
+        fc = dataclasses.replace(fs, feats=U.dev(d["local_color_features"]), dec=U.dev(d["cdec_flat"]), hidden=int(d["cdec_hidden"]),
+                                 levels=int(d["cdec_levels"]), out_dim=3)
+        t.set_color(fc, surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"])
+    grads, cgrads = [], []
+
+    def on_grads(g):
+        grads.append(g.cpu().numpy().copy())
+        if fc is not None:  # this rank's colour-feature gradient after the exchange: private rows (the halo rows were moved out)
+            cgrads.append(t.cgrad[fc.dec.numel():].cpu().numpy().copy())
+    t.on_grads = on_grads
     nd = fs.dec.numel()
     extra = {}
     if comm is not None and mode == "spatial":
@@ -49,8 +60,11 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         cat = lambda key, dt=None: U.dev(np.concatenate([d[f"{key}0"], d[f"{key}1"]]), dt)
         pool = dict(coord=cat("map_coord"), sdf_label=cat("map_label"), weight=cat("map_w"), ts=cat("map_ts", torch.int32))
         pool["global_coord"] = pool["coord"]
+        if fc is not None:
+            pool["color"] = cat("map_color")
         hist = torch.arange(2 * bs, dtype=torch.int64, device="cuda").reshape(2, bs)  # batch it = pool rows [it*bs, (it+1)*bs)
-        stats = t.plan_shards(pool["coord"], hist, None, None, num_nei_cells=int(np.abs(d["neighbor_dx"]).max()))
+        stats = t.plan_shards(pool["coord"], hist, None, None, num_nei_cells=int(np.abs(d["neighbor_dx"]).max()),
+                              pool_label=pool["sdf_label"])
         t.run_shards(pool, False, 2)
         t.finish_optimizer()
         t.merge_side_effects()
@@ -58,7 +72,10 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         extra = dict(n_main=t.dp.n_main, n_eik=t.dp.n_eik, n_halo=np.array(t.dp.n_halo), rows=np.array(stats["rows"]),
                      boxes=t.dp.boxes, halo_rows=t.dp.halo_rows[:t.dp.n_halo].cpu().numpy(),
                      owner=t.dp.owner[:stats["rows"]].cpu().numpy())
-        gsave = dict(gdec0=grads[0][:nd], gdec1=grads[1][:nd], ghalo0=grads[0][nd:], ghalo1=grads[1][nd:])
+        ndx, nh8 = t.dp.nd, 8 * t.dp.n_halo  # exchange buffer: [decoders | geometry halo | colour halo]
+        gsave = dict(gdec0=grads[0][:nd], gdec1=grads[1][:nd], ghalo0=grads[0][ndx:ndx + nh8], ghalo1=grads[1][ndx:ndx + nh8])
+        if fc is not None:
+            gsave.update(cgdec0=grads[0][nd:ndx], chalo0=grads[0][ndx + nh8:ndx + 2 * nh8], cprivate0=cgrads[0])
     else:
         t.reset_optimizer(2 if transport == "none" else None)  # one GPU: the lazy exact Adam, as Mapper.mapping runs it
         t.begin_side_effects()
@@ -70,6 +87,8 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         t.merge_side_effects()
         torch.cuda.synchronize()
         gsave = dict(gdec0=grads[0][:nd], gfeat0=grads[0][nd:], gdec1=grads[1][:nd], gfeat1=grads[1][nd:])
+    if fc is not None:
+        extra = dict(extra, cfeats=fc.feats.cpu().numpy(), cdec=fc.dec.cpu().numpy())
     np.savez(out, feats=fs.feats.cpu().numpy(), dec=fs.dec.cpu().numpy(), cert=fs.certainty.cpu().numpy(),
              tsu=tsu.cpu().numpy(), kind=np.array(getattr(comm, "kind", "none")), **gsave, **extra)
     if comm is not None:

@@ -96,6 +96,36 @@ def test_spatial_shards_reproduce_the_reference(tmp_path, case, world, mode):
     assert np.abs(dense["feats"] - r0["feats"])[clean].max() < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["spatial", "spatial-reduce"])
+def test_spatial_shards_with_the_colour_branch(tmp_path, mode):
+    """Colour maps (replica_color: SDF + colour decoders, colour L1 on the surface samples) through the spatial shards: the
+    colour table's halo rows ride in the same all-reduce, its owned rows in the same end-of-call merge.  Both ranks end
+    bit-identical and on the reference's parameters (the bars of test_gpu_color.test_color_mapping_two_iterations)."""
+    d = G.load("replica_color")
+    r0, r1 = _launch(tmp_path, 2, "host", "replica_color", mode)
+    for key in ("feats", "dec", "cfeats", "cdec", "cert", "tsu"):
+        assert np.array_equal(r0[key].view(np.uint8), r1[key].view(np.uint8)), key
+    assert 0 < int(r0["n_halo"]) < int(r0["rows"])
+    # the colour gradients of the first iteration, put together from what the ranks hold after the exchange: the summed halo
+    # rows (identical on both) + every rank's private rows -- the reference's whole-batch gradient (test_gpu_color's bar)
+    ref = d["map_cfeat0"]
+    total = (r0["cprivate0"] + r1["cprivate0"]).reshape(ref.shape)
+    assert np.abs(total[r0["halo_rows"]]).max() == 0.0  # (moved into the exchange buffer)
+    total[r0["halo_rows"]] = r0["chalo0"].reshape(-1, 8)
+    assert np.max(np.abs(total - ref)) < 4e-4 * np.abs(ref).max()
+    assert np.max(np.abs(r0["cgdec0"] - d["map_cdec0"])) < 4e-4 * np.abs(d["map_cdec0"]).max()
+    # the trained tables: eps = 1e-15 makes Adam step by ~lr on gradients at the rounding noise (golden_util.adam_outliers);
+    # entries whose reference gradient is well above it in both iterations must agree, the others are bounded by Adam's reach
+    for got, key, gk in ((r0["feats"], "map_geo_after", "map_gfeat"), (r0["cfeats"], "map_color_after", "map_cfeat"),
+                         (r0["dec"], "map_gdec_after", "map_gdec"), (r0["cdec"], "map_cdec_after", "map_cdec")):
+        g0, g1 = d[gk + "0"].reshape(got.shape), d[gk + "1"].reshape(got.shape)
+        clean = (np.abs(g0) > 4e-2 * np.abs(g0).max()) & (np.abs(g1) > 4e-2 * np.abs(g1).max())
+        diff = np.abs(got - d[key].reshape(got.shape))
+        assert clean.any() and diff[clean].max() < 1e-4, key
+        assert diff.max() <= 2.0 * d["map_lr"] * 2 * 1.05, key
+        assert np.mean(diff < 1e-4) > 0.95, key
+
+
 def test_spatial_shards_over_rccl_single_rank(tmp_path):
     """The spatial path through RCCL itself (pin_allreduce_f32 for the halo exchange and the owner merge): with one rank
     every row is owned and private, the reductions are identities and the run must equal the reference."""
