@@ -593,6 +593,13 @@ typedef struct pin_adam_dense {
 int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
                           float* exp_avg_sq, int32_t* pending, int32_t step, const float* coef, int32_t t_max,
                           float beta1, float beta2, float eps, const pin_adam_dense* dense, void* stream);
+/* pin_adam_lazy_prepare for LARGE batches (many more records than rows; a 2^20 batch: 13 M records over 2.2 M rows): the
+ * records only flag their rows (row_flags [n_rows] uint8, all zero on entry and again on return), one pass over the rows
+ * settles the flagged ones -- no election, the same arithmetic, the same bits. */
+int pin_adam_lazy_prepare_rows(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
+                               float* exp_avg_sq, int32_t* pending, uint8_t* row_flags, int64_t n_rows, int32_t step,
+                               const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                               const pin_adam_dense* dense, void* stream);
 int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* pending,
                         int64_t n_rows, int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2,
                         float eps, const pin_adam_dense* dense, void* stream);

@@ -193,6 +193,7 @@ SIGNATURES = {
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),
     "pin_adam_step_rows": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, f32, i32, vp]),
     "pin_adam_lazy_prepare": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
+    "pin_adam_lazy_prepare_rows": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
     "pin_adam_lazy_flush": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i32, f32, f32, f32, P(AdamDense), vp]),
     "pin_pool_workspace_bytes": (i64, [i64]),
     "pin_sample_rays": (i32, [P(SampleParams), vp, vp, i32, i32, vp, vp, vp, P(PoolArrays), vp]),

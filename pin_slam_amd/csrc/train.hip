@@ -738,6 +738,48 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     g[i] = 0.f;
 }
 
+// The same step for LARGE batches (many more records than rows: a 2^20 batch holds 13 M records over 2.2 M rows, six
+// visits per row of which five lose the election): the records only FLAG their rows (mark_rows_kernel), then one pass
+// over the rows settles the flagged ones -- eight lanes per row, no compare-and-swap, the same lazy_settle arithmetic, so
+// the tables are the bits of the record-parallel form.  Clears the flags it consumes.
+__global__ __launch_bounds__(256) void adam_lazy_prepare_rows_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                                     float* __restrict__ m, float* __restrict__ v,
+                                                                     int* __restrict__ pend, unsigned char* __restrict__ flags,
+                                                                     long n_rows, int step, const float* __restrict__ coef, int t_max,
+                                                                     float b1, float b2, float eps, int row_blocks,
+                                                                     pin_adam_dense dense, int dense_step) {
+    if ((int)blockIdx.x >= row_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
+        const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (e < dense.n) {
+            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
+            adam_elem(pi, mi, vi, dense.grad[e], coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
+            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
+            dense.grad[e] = 0.f;
+            dense_image_entry(dense, (int)e, pi);
+        }
+        return;
+    }
+    extern __shared__ float lazy_coef[];  // (see adam_lazy_prepare_kernel)
+    for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
+    __syncthreads();
+    const long stride = (long)row_blocks * 32;
+    for (long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3); row < n_rows; row += stride) {
+        if (!flags[row]) continue;
+        const int j = threadIdx.x & 7;
+        const int n = pend[row];
+        // (all eight lanes of the row have read `n` before lane 0 rewrites it: the eight are in one wave, the store below is
+        // program-ordered behind the load above)
+        if (j == 0) { flags[row] = 0; if (n != PIN_ADAM_ROW_EXCLUDED) pend[row] = n == 0 ? -step : step; }
+        if (n == 0 || n == PIN_ADAM_ROW_EXCLUDED || n == step || n == -step) continue;  // first touch: nothing to settle yet
+        const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
+        float pi = p[i], mi = 0.f, vi = 0.f;
+        if (n > 0) { mi = m[i]; vi = v[i]; }
+        lazy_settle(pi, mi, vi, g[i], n, step - 1, lazy_coef, t_max, b1, b2, eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        g[i] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v,
                                                               const int* __restrict__ pend, long n, int t_final,
@@ -1227,6 +1269,27 @@ extern "C" int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float*
     hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(rec_blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), as_stream(stream),
                        reinterpret_cast<const float4*>(nbr), (long)n_records, param, grad, exp_avg, exp_avg_sq, pending, step, coef,
                        t_max, beta1, beta2, eps, rec_blocks, d, step - 1);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_adam_lazy_prepare_rows(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
+                                          float* exp_avg_sq, int32_t* pending, uint8_t* row_flags, int64_t n_rows, int32_t step,
+                                          const float* coef, int32_t t_max, float beta1, float beta2, float eps,
+                                          const pin_adam_dense* dense, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_records >= 0 && n_rows >= 0 && step >= 1 && step <= t_max && t_max < 4096, "bad sizes / step (t_max < 4096)");
+    pin_adam_dense d;
+    if (int e = lazy_dense(step > 1 ? dense : nullptr, coef, d)) return e;  // (nothing to step before the first iteration)
+    if (n_records == 0 && d.n == 0) return 0;
+    PIN_CHECK_ARG(n_records == 0 || (nbr && param && grad && exp_avg && exp_avg_sq && pending && row_flags && coef), "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    if (n_records > 0)
+        hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n_records, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(nbr), (long)n_records,
+                           row_flags);
+    const int row_blocks = n_records > 0 ? (int)min((long)cdiv(n_rows, 32), 8192L) : 0, dense_blocks = (int)cdiv(d.n, 256);
+    hipLaunchKernelGGL(adam_lazy_prepare_rows_kernel, dim3(row_blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), s, param,
+                       grad, exp_avg, exp_avg_sq, pending, row_flags, (long)n_rows, step, coef, t_max, beta1, beta2, eps, row_blocks, d, step - 1);
     PIN_CHECK_LAUNCH();
     return 0;
 }

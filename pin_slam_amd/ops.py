@@ -8,6 +8,7 @@ from dataclasses import dataclass
 from typing import Optional
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -547,12 +548,17 @@ class LazyAdam:
 
     def __init__(self, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15):
         self.lr, self.b1, self.b2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
-        self.state = None
+        self.state = self.flags = None
         self.t = 0
+        # batches with at least this many records per table row go through the row-parallel form (pin_adam_lazy_prepare_rows).
+        # Measured: 0.09 records per row (C3: 210 k records, 2.2 M rows) 1.26 vs 1.40 ms of mapping in favour of the records;
+        # 0.76 (a rank of 8 at C4) 0.610 vs 0.577 ms per iteration and 6 (C4 on one GPU) 4.29 vs 3.89 ms in favour of the rows
+        self.rows_form_ratio = float(os.environ.get("PIN_LAZY_ROWS_RATIO", "0.5"))
 
     def reset(self, rows, t_max, device):
         if self.state is None or self.state.shape[0] < rows:
             self.state = torch.zeros((int(rows * 1.25) + 1024,), dtype=torch.int32, device=device)  # pending step per row
+            self.flags = torch.zeros((int(rows * 1.25) + 1024,), dtype=torch.uint8, device=device)  # (kept clear by the kernel)
         else:
             self.state.zero_()
         self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
@@ -579,6 +585,15 @@ class LazyAdam:
         if step <= self.t:
             raise ValueError("steps must grow within one optimiser lifetime (the step elects one owner per row and call)")
         d = self._dense(dense)
+        n_rec = nbr.numel() // 4
+        if n_rec >= self.rows_form_ratio * param.shape[0]:  # many visits per row: flag the rows, settle them in one pass over the table
+            check(_lib.lib().pin_adam_lazy_prepare_rows(_ptr(nbr, torch.float32), n_rec, _ptr(param, torch.float32), _ptr(grad, torch.float32),
+                                                        _ptr(m, torch.float32), _ptr(v, torch.float32), self.state.data_ptr(),
+                                                        self.flags.data_ptr(), param.shape[0], int(step), _ptr(self.coef), self.t_max,
+                                                        self.b1, self.b2, self.eps, C.byref(d) if d is not None else None, _stream()),
+                  "pin_adam_lazy_prepare_rows")
+            self.t = int(step)
+            return
         check(_lib.lib().pin_adam_lazy_prepare(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
                                                _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),
                                                self.state.data_ptr(), int(step),

@@ -434,14 +434,16 @@ def test_sparse_adam_is_bit_identical_to_dense():
     assert not torch.equal(pd, p0)
 
 
-@pytest.mark.parametrize("steps", [1, 12, 70])
-def test_lazy_adam_is_bit_identical_to_dense(steps):
+@pytest.mark.parametrize("steps,rows_form", [(1, False), (12, False), (70, False), (12, True), (5, "mixed")])
+def test_lazy_adam_is_bit_identical_to_dense(steps, rows_form):
     """ops.LazyAdam (ONE launch per iteration, before the forward pass: the rows about to be read settle the step they
     still owe and the gradient-free steps since; flush at the end) against the dense pin_adam_step every iteration:
     at every iteration the rows about to be read hold their dense values, and after the flush the parameter table and
     the moments of every touched row are equal bit for bit.  The m / v arrays start as garbage on the lazy side (it
     never clears them); 70 steps goes beyond the default table size.  A dense tensor (the decoder) rides along: after
-    prepare(t) it holds its value of step t - 1, after the flush that of the last step."""
+    prepare(t) it holds its value of step t - 1, after the flush that of the last step.
+    rows_form: the large-batch form (pin_adam_lazy_prepare_rows: the records flag their rows, one pass over the table
+    settles them) for every iteration, or alternating with the record-parallel form ("mixed") -- the same bits."""
     from pin_slam_amd import ops
     torch.manual_seed(steps)
     rows, k, Q = 30_000, 8, 1500
@@ -452,6 +454,7 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
     gl = torch.zeros_like(p0)
     lazy = ops.LazyAdam(0.01, eps=1e-15)
     lazy.reset(rows + 1, steps, "cuda")
+    lazy.rows_form_ratio = 0.0 if rows_form is True else 1e9
     touched = torch.zeros(rows + 1, dtype=torch.bool, device="cuda")
     d0 = torch.randn(1337, device="cuda")
     dec_a = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
@@ -465,7 +468,10 @@ def test_lazy_adam_is_bit_identical_to_dense(steps):
         nbr = torch.zeros((Q, k, 4), dtype=torch.float32, device="cuda")
         nbr.view(torch.int32)[..., 3] = idx.to(torch.int32)
         valid = torch.unique(idx[idx >= 0])
+        if rows_form == "mixed":
+            lazy.rows_form_ratio = 0.0 if step % 2 else 1e9
         lazy.prepare(nbr, pl, gl, ml, vl, step, dense=(dec_b[0], gb, dec_b[1], dec_b[2]))
+        assert not lazy.flags.any()  # (the row form clears the flags it consumed)
         assert torch.equal(pl[valid].view(torch.int32), pd[valid].view(torch.int32)), step  # what the forward pass reads
         assert not gl[valid].any()  # the settled gradients were cleared
         for x, y in zip(dec_a, dec_b):  # the dense tensor: its step of the previous iteration was taken
