@@ -140,7 +140,7 @@ struct NbrW {
 // weights only (no gradient terms), same arithmetic as sdf.hip load_neighbors
 __device__ __forceinline__ void neighbor_weights(const float4* __restrict__ nbr, int nn, int qi, int k, NbrW& nb,
                                                  float (&vx)[PIN_MAX_K], float (&vy)[PIN_MAX_K],
-                                                 float (&vz)[PIN_MAX_K], bool (&quirk)[PIN_MAX_K]) {
+                                                 float (&vz)[PIN_MAX_K], bool (&quirk)[PIN_MAX_K], float* u_out = nullptr) {
     // straight-line: the k record loads are issued together (one memory round trip, not k)
     float4 e[PIN_MAX_K];
 #pragma unroll
@@ -163,6 +163,11 @@ __device__ __forceinline__ void neighbor_weights(const float4* __restrict__ nbr,
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t)
         if (nb.idx[t] >= 0) nb.w[t] = u[t] / S;
+    if (u_out != nullptr) {  // (the analytic Eikonal term differentiates the weights: u_t of the valid neighbours, then S)
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) u_out[t] = nb.idx[t] >= 0 ? u[t] : 0.f;
+        u_out[PIN_MAX_K] = S;
+    }
 }
 
 // ---- forward / backward with the decoder on the matrix cores (mlp_mfma.h) -------------------
@@ -971,6 +976,71 @@ static int launch_fused(const pin_field* f, const pin_train_params* tp, const Fu
 #undef PIN_LF
 }
 
+// weighted_first with the analytic Eikonal term (train_fused_an_kernel): two operand streams, any decoder depth
+template <int H, int L>
+static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4,
+                             const int32_t* nn_count, const float* sdf_label, const float* sample_weight, const int32_t* sample_ts,
+                             float* certainty_rw, int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
+                             float* pred_out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t s) {
+    using G = DwGeom<H>;
+    constexpr int lds_bytes = train_fused_an_lds_bytes<H>(L);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_fused_an_kernel<H, L>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "training tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    DwStream ws, ws2;
+    ws.n_tiles = ws2.n_tiles = cdiv(tp->n_main, 16);
+    const size_t per_stream = 2 * G::total((size_t)ws.n_tiles, L);
+    const size_t need = 2 * per_stream * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
+    PIN_CHECK_ARG((size_t)workspace_bytes >= need, "workspace too small");
+    ws.d = reinterpret_cast<uint2*>(workspace);
+    ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
+    ws2.d = ws.d + per_stream;
+    ws2.a = ws.a + per_stream;
+    const float unit_main = tp->inv_n_main * f->sdf_scale / tp->sigma;
+    const float unit_eik = 2.f * tp->weight_e * tp->inv_n_eik * f->sdf_scale;
+    const float dscale = exp2f(-ceilf(log2f(fmaxf(fmaxf(unit_main, unit_eik), 1e-30f))));
+    const int want_dec = dec_grad != nullptr;
+    const int n_dec = H * MLP_IN + H + (L - 1) * (H * H + H) + H + 1;
+    float* dw_partial = reinterpret_cast<float*>(ws.d + 2 * per_stream);
+    double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
+    const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
+    const int grid = min(n_cu, ws.n_tiles);
+    if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
+        image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+    else
+        hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
+    hipLaunchKernelGGL((train_fused_an_kernel<H, L>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+                       sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
+                       dw_partial, n_dec, loss_partial);
+    PIN_CHECK_LAUNCH();
+    if (want_dec) {
+        const dim3 dgrid(cdiv(ws.n_tiles, DW_CHUNK), L + 1);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1);
+        PIN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
+                       dec_grad, loss_partial, grid, loss_out, 2);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int H>
+static int launch_fused_an(const pin_field* f, const pin_train_params* tp, const float* query, const float4* nb4, const int32_t* nn_count,
+                           const float* sdf_label, const float* sample_weight, const int32_t* sample_ts, float* certainty_rw,
+                           int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out, float* pred_out, void* workspace,
+                           int64_t workspace_bytes, int n_cu, hipStream_t s) {
+#define PIN_LA(LL) return launch_fused_an_l<H, LL>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw, \
+                                                   feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, n_cu, s)
+    switch (f->levels) {
+        case 1: PIN_LA(1);
+        case 2: PIN_LA(2);
+        case 3: PIN_LA(3);
+        default: PIN_LA(4);
+    }
+#undef PIN_LA
+}
+
 // weighted_first = False with a one-layer decoder: groups of three (query, neighbour)-column tiles (train_fused.h);
 // AN = the Eikonal term on the analytic gradient of every sample (a second operand stream for the derivative network)
 template <int H, bool AN>
@@ -1047,8 +1117,9 @@ static int train_step_impl(const pin_field* f, const pin_train_params* tp, const
     PIN_CHECK_ARG(tp->n_main > 0 && tp->n_eik >= 0, "bad batch sizes");
     const bool analytic = tp->eik_analytic != 0;
     PIN_CHECK_ARG(!analytic || tp->n_eik == 0, "analytic Eikonal term: no probe samples (n_eik = 0)");
-    PIN_CHECK_ARG(!analytic || f->weighted_first == 0,
-                  "analytic Eikonal term: built for per-neighbour decoding with a one-layer decoder (run_livox.yaml)");
+    PIN_CHECK_ARG(!analytic || f->weighted_first != 0 || f->levels == 1,
+                  "analytic Eikonal term with per-neighbour decoding: one-layer decoders (run_livox.yaml)");
+    PIN_CHECK_ARG(!analytic || use_split_decoder(), "analytic Eikonal term: split-fp16 decoder only (unset PIN_MLP)");
     const int Q = tp->n_main + 6 * tp->n_eik;
     const int H = f->hidden, L = f->levels;
     PIN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)train_ws_floats(analytic ? 2 * Q : Q, H, L, expand) * 4, "workspace too small");
@@ -1073,6 +1144,13 @@ static int train_step_impl(const pin_field* f, const pin_train_params* tp, const
     const bool quad = f->weighted_first != 0;
     const int want_dec = dec_grad != nullptr;
     if (!fused) PIN_CHECK_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(double), s));  // (the fused paths sum per-block partials)
+    if (quad && analytic) {  // weighted_first, Eikonal term on the autograd gradient of every sample: train_fused_an_kernel
+        PIN_CHECK_ARG(phase == 3, "analytic Eikonal term: the step is not split in two");
+        return H == 64 ? launch_fused_an<64>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
+                                             feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, cu_count(), s)
+                       : launch_fused_an<32>(f, tp, query, nb4, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw,
+                                             feat_grad, dec_grad, loss_out, pred_out, workspace, workspace_bytes, cu_count(), s);
+    }
     if (quad) {  // weighted_first: the fused tile kernel + the streamed weight gradient (train_fused.h)
         FusedColor none;
         memset(&none, 0, sizeof(none));

@@ -770,6 +770,357 @@ constexpr int train_fused_nwf_lds_bytes() {
     return ((QuadDecoderH<H>::bytes(1) + 15) & ~15) + (TF_BLOCK / 64) * (16 * 8 + 16) * 4 + (TF_BLOCK / 64) * 2 * 8;
 }
 
+// ---- weighted_first with the analytic Eikonal term (numerical_grad_on False with weighted_first True; any depth) ----
+// mapper.py:642-643, 677-678, 760-782 with the decoder applied to the interpolated input z = sum_t w_t [f_t; v_t].
+// Per sample, with a = d head / d z (the UNIT backward sweep through the decoder):
+//     g = d pred / d q = s (M^T a_pos + (sum_t (a . y_t) d u_t/dq  -  (a . z) G) / S),   d u_t / d q = -2 u_t^2 (q - P_t),
+// G = sum_t d u_t / d q, M = sum_t w_t R_t (gn_quad.h's Jacobian).  With c = d loss / d g the scalar c . g equals
+// s a . zdot, zdot = (d z / d q) c -- linear in the derivative network along zdot (same weights, no biases, the forward
+// ReLU patterns as fixed masks):  c . g = s wo . t_L,  t_1 = D_1 W_0 zdot,  t_{l+1} = D_{l+1} W_l t_l.  So
+//     d (c . g) / d W_l = s deltau_{l+1} (x) t_l   (deltau = the unit sweep's deltas, which the BCE sweep also is,
+//                                                   times d loss / d head: ONE backward sweep serves both terms),
+//     d (c . g) / d f_t = s a_feat (c . d w_t / d q),
+// a second operand stream (ws2: D = deltau pieces, A = t_l pieces, no bias gradient) next to the BCE term's.
+template <int H, int L>
+__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f, pin_train_params tp,
+                                                                     const float* __restrict__ query,
+                                                                     const float4* __restrict__ nbr,
+                                                                     const int* __restrict__ nn_count,
+                                                                     const float* __restrict__ label,
+                                                                     const float* __restrict__ weight,
+                                                                     const int* __restrict__ sample_ts,
+                                                                     float* __restrict__ cert_rw, int* __restrict__ ts_rw,
+                                                                     float* __restrict__ feat_grad, float* __restrict__ pred_out,
+                                                                     DwStream ws, DwStream ws2, int want_dec, float dscale,
+                                                                     const unsigned char* __restrict__ dec_image,
+                                                                     float* __restrict__ dw_partial, int n_dec,
+                                                                     double* __restrict__ loss_partial) {
+    using Q = QuadDecoderH<H>;
+    using G = DwGeom<H>;
+    constexpr int MT = Q::MT, NJ = Q::NJ;
+    constexpr int PATCH = 6 * 16 * 8;  // per wave: dz, w, idx [16][8], d u_t / d q [16][8][3]
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
+    unsigned char* const lds = tf_smem;
+    constexpr int IMG = (Q::bytes(L) + 15) & ~15;
+    float* const sdz = reinterpret_cast<float*>(lds + IMG) + (threadIdx.x >> 6) * PATCH;
+    float* const sw = sdz + 16 * 8;
+    int* const sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
+    float* const sgu = sdz + 3 * 16 * 8;
+    double (*lred)[2] = reinterpret_cast<double (*)[2]>(lds + IMG + (TF_BLOCK / 64) * PATCH * 4);
+    const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int n_main = tp.n_main;
+    const int n_tiles = ws.n_tiles;
+    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const float inv_dscale = 1.0f / dscale, s = f.sdf_scale;
+    const bool orient = f.orient != nullptr;
+    v4h_t ident;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ident[r] = (nq == 4 * g + r) ? (_Float16)1.0f : (_Float16)0.0f;
+    double acc_bce = 0.0, acc_eik = 0.0;
+    if (want_dec) {
+        const int n = DW_SLOTS * n_dec;
+        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+    }
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+        constexpr int n16 = Q::bytes(L) >> 4;
+        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
+    // ReLU pattern of a layer out of the pieces of its activations (train_fused_kernel's backward sweep)
+    auto piece_on = [](const v4u_t (&ph)[NJ], const v4u_t (&pl)[NJ], int mj, int r) {
+        const unsigned int word = ph[mj >> 1][2 * (mj & 1) + (r >> 1)] | pl[mj >> 1][2 * (mj & 1) + (r >> 1)];
+        return (r & 1) ? ((word & 0x7fff0000u) != 0u) : ((word & 0x7fffu) != 0u);
+    };
+    for (int tile = blockIdx.x + gridDim.x * wave; tile < n_tiles; tile += n_waves) {
+        const int qi = 16 * tile + nq;
+        const bool active = qi < n_main;
+        const int qq = active ? qi : 0;
+        const float qx = query[3 * qq], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+        NbrW nb;
+        float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K], u[PIN_MAX_K + 1];
+        bool quirk[PIN_MAX_K];
+        neighbor_weights(nbr, nn_count[qq], qq, f.k, nb, vx, vy, vz, quirk, u);
+        const float invS = 1.0f / u[PIN_MAX_K];
+        float4 row[PIN_MAX_K];
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            const size_t id = nb.idx[t] >= 0 ? (size_t)nb.idx[t] : 0;
+            row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
+        }
+        if (g == 3 && active && cert_rw != nullptr) {  // training-mode side effects (neural_points.py:685-710)
+            const int my_ts = sample_ts != nullptr ? sample_ts[qi] : 0;
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t)
+                if (nb.idx[t] >= 0) {
+                    atomicAdd(cert_rw + nb.idx[t], nb.w[t]);
+                    if (ts_rw != nullptr && sample_ts != nullptr && ts_rw[nb.idx[t]] < my_ts) atomicMax(ts_rw + nb.idx[t], my_ts);
+                }
+        }
+        // ---- gather: z, and what the derivative of z with respect to q needs (gn_quad.h's QuadIn)
+        float z[4] = {0.f, 0.f, 0.f, 0.f}, Y[3][4], M[9];
+        float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[c][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < PIN_MAX_K; ++t) {
+            const bool val = nb.idx[t] >= 0;
+            const float cg = -2.f * u[t] * u[t];
+            const float g0 = cg * vx[t], g1 = cg * vy[t], g2 = cg * vz[t];  // d u_t / d q (0 for an invalid neighbour)
+            Gx += g0; Gy += g1; Gz += g2; wsum += nb.w[t];
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g < 2) {
+                if (val) { y[0] = row[t].x; y[1] = row[t].y; y[2] = row[t].z; y[3] = row[t].w; }
+            } else if (g == 2 && val) {
+                float v[3] = {vx[t], vy[t], vz[t]};
+                if (orient || quirk[t]) {
+                    float Rm[9];
+                    neighbor_vector_rot(f, nb.idx[t], quirk[t], vx[t], vy[t], vz[t], qx, qy, qz, v, Rm);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) M[i] = fmaf(nb.w[t], Rm[i], M[i]);
+                } else {
+                    M[0] += nb.w[t]; M[4] += nb.w[t]; M[8] += nb.w[t];
+                }
+                y[0] = v[0]; y[1] = v[1]; y[2] = v[2];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z[r] = fmaf(nb.w[t], y[r], z[r]);
+                Y[0][r] = fmaf(g0, y[r], Y[0][r]);
+                Y[1][r] = fmaf(g1, y[r], Y[1][r]);
+                Y[2][r] = fmaf(g2, y[r], Y[2][r]);
+            }
+            if (g == 2) {
+                sw[nq * 8 + t] = nb.w[t]; sidx[nq * 8 + t] = active ? nb.idx[t] : -1;
+                sgu[(nq * 8 + t) * 3] = g0; sgu[(nq * 8 + t) * 3 + 1] = g1; sgu[(nq * 8 + t) * 3 + 2] = g2;
+            }
+        }
+        (void)wsum;
+        // ---- forward
+        v2u_t zh, zl;
+        Q::split_input(z, zh, zl);
+        v4f_t h[MT], acc[MT];
+        v4u_t ph[L][NJ], pl[L][NJ];
+        Q::layer0(lds, L, zh, zl, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            Q::split_acts(h, ph[l - 1], pl[l - 1]);
+            Q::load_bias(lds, L, l, acc);
+            Q::matmul(lds + Q::off_hidf(L, l), ph[l - 1], pl[l - 1], acc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+        }
+        Q::split_acts(h, ph[L - 1], pl[L - 1]);
+        float x = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
+        }
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        x += O[MF_OD_MAX * H];
+        const float pred = s * x;
+        if (active && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
+        float dxm;  // d BCE / d head, times dscale (train_loss_kernel's arithmetic)
+        {
+            const float xl = pred / tp.sigma;
+            const float yl = 1.f / (1.f + expf(-label[qq] / tp.sigma));
+            float l = fmaxf(xl, 0.f) - xl * yl + log1pf(expf(-fabsf(xl)));
+            float gg = 1.f / (1.f + expf(-xl)) - yl;
+            if (tp.loss_weight_on) { const float w = fabsf(weight[qq]); l *= w; gg *= w; }
+            if (active && g == 0) acc_bce += (double)l;
+            dxm = active ? gg * tp.inv_n_main / tp.sigma * s * dscale : 0.f;
+        }
+        // ---- the unit backward sweep: deltau_l; the BCE term's deltas are dxm * deltau_l
+        const size_t tbase = (size_t)tile * 128 + lane;
+        const size_t tbig = (size_t)tile * 128 * (MT - 1) + tbase;
+        if (want_dec) {
+            unsigned int dh0, dl0, eh0, el0;
+            h2_split2((g == 0) ? dxm : 0.f, 0.f, dh0, dl0);
+            h2_split2((g == 0 && active) ? 1.f : 0.f, 0.f, eh0, el0);
+            uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
+            D[0] = transpose_block(dh0, 0u, ident);
+            D[64] = transpose_block(dl0, 0u, ident);
+            uint2* __restrict__ E = ws2.d + G::d_off(n_tiles, L) + tbase;
+            E[0] = transpose_block(eh0, 0u, ident);
+            E[64] = transpose_block(el0, 0u, ident);
+            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, L) + tbig;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                A[mt * 128] = transpose_block(ph[L - 1][mt >> 1][2 * (mt & 1)], ph[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                A[mt * 128 + 64] = transpose_block(pl[L - 1][mt >> 1][2 * (mt & 1)], pl[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + 16 * kt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[kt][r] = (active && h[kt][r] > 0.f) ? wo[r] : 0.f;
+        }
+        float a[4];
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            v4u_t uh[NJ], ul[NJ];
+            Q::split_acts(h, uh, ul);
+            if (want_dec) {
+                v4f_t hm[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hm[mt][r] = dxm * h[mt][r];
+                v4u_t bh[NJ], bl[NJ];
+                Q::split_acts(hm, bh, bl);
+                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + tbig;
+                uint2* __restrict__ E = ws2.d + G::d_off(n_tiles, l) + tbig;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
+                    D[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
+                    E[mt * 128] = transpose_block(uh[mt >> 1][2 * (mt & 1)], uh[mt >> 1][2 * (mt & 1) + 1], ident);
+                    E[mt * 128 + 64] = transpose_block(ul[mt >> 1][2 * (mt & 1)], ul[mt >> 1][2 * (mt & 1) + 1], ident);
+                }
+                if (l > 0) {
+                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + tbig;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        A[mt * 128] = transpose_block(ph[l - 1][mt >> 1][2 * (mt & 1)], ph[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                        A[mt * 128 + 64] = transpose_block(pl[l - 1][mt >> 1][2 * (mt & 1)], pl[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
+                    }
+                } else {
+                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
+                    A[0] = transpose_block(zh[0], zh[1], ident);
+                    A[64] = transpose_block(zl[0], zl[1], ident);
+                }
+            }
+            if (l > 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                Q::matmul(lds + Q::off_hidb(L, l), uh, ul, acc);
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[mj][r] = piece_on(ph[l - 1], pl[l - 1], mj, r) ? acc[mj][r] : 0.f;
+            } else {
+                Q::input_backward(lds, L, uh, ul, a);
+            }
+        }
+        // ---- d pred / d q, the Eikonal term and c = d loss / d g (times s dscale: what multiplies the derivative network)
+        float c0, c1, c2, cG;
+        {
+            float ax = 0.f, ay = 0.f, az = 0.f, cbar = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ax = fmaf(a[r], Y[0][r], ax); ay = fmaf(a[r], Y[1][r], ay); az = fmaf(a[r], Y[2][r], az);
+                cbar = fmaf(a[r], z[r], cbar);
+            }
+            if (g == 2) {  // M^T a_pos
+                d0 = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
+                d1 = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
+                d2 = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
+            }
+            ax = quad_lanes_sum(ax); ay = quad_lanes_sum(ay); az = quad_lanes_sum(az); cbar = quad_lanes_sum(cbar);
+            d0 = quad_lanes_sum(d0); d1 = quad_lanes_sum(d1); d2 = quad_lanes_sum(d2);
+            const float gx = s * (d0 + (ax - cbar * Gx) * invS);
+            const float gy = s * (d1 + (ay - cbar * Gy) * invS);
+            const float gz = s * (d2 + (az - cbar * Gz) * invS);
+            const float n = sqrtf(gx * gx + gy * gy + gz * gz);
+            const float r = n - 1.f;  // mapper.py:778-781, every sample (gradient_decimation = 1, config.py:438-439)
+            if (active && g == 0) acc_eik += (double)(r * r);
+            const float cf = (active && n > 0.f) ? tp.weight_e * 2.f * r * tp.inv_n_eik / n * s * dscale : 0.f;
+            c0 = cf * gx; c1 = cf * gy; c2 = cf * gz;
+            cG = c0 * Gx + c1 * Gy + c2 * Gz;
+        }
+        if (want_dec) {  // ---- the derivative network along zdot = (d z / d q) c: its activations are stream 2's A operands
+            float zd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zd[r] = (c0 * Y[0][r] + c1 * Y[1][r] + c2 * Y[2][r] - cG * z[r]) * invS;
+            if (g == 2) {
+                zd[0] += M[0] * c0 + M[1] * c1 + M[2] * c2;
+                zd[1] += M[3] * c0 + M[4] * c1 + M[5] * c2;
+                zd[2] += M[6] * c0 + M[7] * c1 + M[8] * c2;
+            }
+            v2u_t th, tl;
+            Q::split_input(zd, th, tl);
+            uint2* __restrict__ B0 = ws2.a + G::a_off(n_tiles, 0) + tbase;
+            B0[0] = transpose_block(th[0], th[1], ident);
+            B0[64] = transpose_block(tl[0], tl[1], ident);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+            Q::layer0_add(lds, L, th, tl, acc);
+#pragma unroll
+            for (int l = 1; l <= L; ++l) {
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[mj][r] = piece_on(ph[l - 1], pl[l - 1], mj, r) ? acc[mj][r] : 0.f;
+                v4u_t mh[NJ], ml[NJ];
+                Q::split_acts(h, mh, ml);
+                uint2* __restrict__ B = ws2.a + G::a_off(n_tiles, l) + tbig;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    B[mt * 128] = transpose_block(mh[mt >> 1][2 * (mt & 1)], mh[mt >> 1][2 * (mt & 1) + 1], ident);
+                    B[mt * 128 + 64] = transpose_block(ml[mt >> 1][2 * (mt & 1)], ml[mt >> 1][2 * (mt & 1) + 1], ident);
+                }
+                if (l < L) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                    Q::matmul(lds + Q::off_hidf(L, l), mh, ml, acc);
+                }
+            }
+        }
+        // ---- feature-gradient scatter: row t gets a_feat (w_t d loss / d head + c . d w_t / d q)
+        if (g < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = a[r] * inv_dscale;
+        } else if (g == 2) {
+            const float base = dxm - cG * invS;
+#pragma unroll
+            for (int t = 0; t < PIN_MAX_K; ++t) {
+                const float* gu = sgu + (nq * 8 + t) * 3;
+                sw[nq * 8 + t] = fmaf(sw[nq * 8 + t], base, (c0 * gu[0] + c1 * gu[1] + c2 * gu[2]) * invS);
+            }
+        }
+        wave_lds_sync();
+        {
+            const int t = lane >> 3, j = lane & 7;
+            for (int i = 0; i < 16; ++i) {
+                const int idx = sidx[i * 8 + t];
+                if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
+            }
+        }
+        wave_lds_sync();
+    }
+    acc_bce = wave_sum(acc_bce);
+    acc_eik = wave_sum(acc_eik);
+    if (lane == 0) { lred[wave][0] = acc_bce; lred[wave][1] = acc_eik; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double tt = 0.0;
+#pragma unroll
+        for (int w = 0; w < TF_BLOCK / 64; ++w) tt += lred[w][threadIdx.x];
+        loss_partial[2 * blockIdx.x + threadIdx.x] = tt;
+    }
+}
+
+template <int H>
+constexpr int train_fused_an_lds_bytes(int L) {
+    return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (TF_BLOCK / 64) * 6 * 16 * 8 * 4 + (TF_BLOCK / 64) * 2 * 8;
+}
+
 // the decoder image of train_fused_kernel, once per call: the hidden layers over blocks 0 .. STAGE_BLOCKS - 4 (the split
 // is a chain of memory round trips, one trip per thread here), the three small parts on a block each
 constexpr int STAGE_BLOCKS = 15;

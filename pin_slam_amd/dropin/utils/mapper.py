@@ -378,8 +378,8 @@ class Mapper(_Base):
         if getattr(c, "color_on", False) and c.weight_i > 0 and c.color_channel != 3: bad.append("color_channel != 3")
         if c.main_loss_type != "bce": bad.append("main_loss_type != bce")
         if c.proj_correction_on or c.consistency_loss_on: bad.append("proj_correction / consistency loss")
-        if c.ekional_loss_on and c.weight_e > 0 and not c.numerical_grad and (c.weighted_first or self.sdf_mlp.hidden_level != 1):
-            bad.append("analytic Eikonal (numerical_grad_on False) outside per-neighbour decoding with a one-layer decoder")
+        if c.ekional_loss_on and c.weight_e > 0 and not c.numerical_grad and not c.weighted_first and self.sdf_mlp.hidden_level != 1:
+            bad.append("analytic Eikonal (numerical_grad_on False) with per-neighbour decoding and more than one decoder layer")
         if c.ekional_loss_on and c.ekional_add_to != "all": bad.append("ekional_add_to != all")
         if not c.opt_adam: bad.append("SGD")
         if c.weight_decay != 0.0: bad.append("weight_decay")

@@ -393,9 +393,9 @@ class TrainBuffers:
         self.n_main = int(n_main)
         self.dec = int(decimation)
         self.analytic = eikonal == "analytic"
-        if self.analytic and (weighted_first or levels != 1):
-            raise NotImplementedError("analytic Eikonal term (numerical_grad_on False) is built for weighted_first False "
-                                      "with a one-layer decoder (config/lidar_slam/run_livox.yaml)")
+        if self.analytic and not weighted_first and levels != 1:
+            raise NotImplementedError("analytic Eikonal term (numerical_grad_on False) with per-neighbour decoding "
+                                      "(weighted_first False): one-layer decoders (config/lidar_slam/run_livox.yaml)")
         self.eik_first, self.n_eik = eikonal_shard(shard_start, self.n_main, self.dec) if (eikonal and not self.analytic) else (0, 0)
         if n_eik is not None:  # capacities: the spatial shards (pin_slam_amd.dp) set the counts per iteration, set_counts()
             self.eik_first, self.n_eik, self.dec = 0, (int(n_eik) if (eikonal and not self.analytic) else 0), 1

@@ -242,7 +242,7 @@ def test_grouped_iterations_train_like_single_ones(wf):
 def test_mapper_with_analytic_eikonal_term():
     """run_livox.yaml's training mode through the drop-in Mapper: per-neighbour decoding, 8 neighbours, the Eikonal term
     on the autograd gradient of every sample (numerical_grad False -> gradient_decimation 1).  Training lowers the SDF
-    error and pulls the gradient norm of the field to 1; configurations the analytic term is not built for raise."""
+    error and pulls the gradient norm of the field to 1; the same with weighted-first decoding."""
     from pin_slam_amd import ops, synth
     from pin_slam_amd.dropin.model.decoder import Decoder
     from pin_slam_amd.dropin.model.neural_points import NeuralPoints
@@ -280,10 +280,17 @@ def test_mapper_with_analytic_eikonal_term():
     err1, n1 = (mp.sdf(probe)[0] - lab).abs().mean().item(), grad_norm()
     assert err1 < 0.35 * err0 and err1 < 0.05, (err0, err1)
     assert (n1 - 1).abs().mean().item() < 0.2 and (n1 - 1).abs().mean().item() < 0.5 * (n0 - 1).abs().mean().item()
+    # weighted-first decoding with the same term (train_fused_an_kernel): the field keeps training
     cfg.weighted_first = True
     mp2 = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
-    with pytest.raises(NotImplementedError):
-        mp2.mapping(1)
+    mp2.coord_pool, mp2.global_coord_pool, mp2.sdf_label_pool = mp.coord_pool, mp.global_coord_pool, mp.sdf_label_pool
+    mp2.weight_pool, mp2.time_pool, mp2.pool_sample_count = mp.weight_pool, mp.time_pool, mp.pool_sample_count
+    mp2.mapping(1)
+    e0 = (mp2.sdf(probe)[0] - lab).abs().mean().item()
+    mp2.mapping(200)
+    assert mp2._trainer.eikonal == "analytic" and mp2._trainer.fs.weighted_first
+    e1 = (mp2.sdf(probe)[0] - lab).abs().mean().item()
+    assert e1 < 0.05 and e1 < 1.05 * e0, (e0, e1)
     cfg.weighted_first = False
 
 

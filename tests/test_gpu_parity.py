@@ -259,26 +259,27 @@ def test_mapping_two_iterations(gold):
     assert np.array_equal(tsu.cpu().numpy(), d["map_ts_after"])
 
 
-@pytest.mark.parametrize("tag", ["nwf", "pgo"])
+@pytest.mark.parametrize("tag", ["nwf", "pgo", "wf"])
 def test_analytic_eikonal_mapping(tag):
     """numerical_grad_on False (config/lidar_slam/run_livox.yaml:27): the Eikonal term on the autograd gradient of every
     sample, differentiated a second time (mapper.py:642-643, 677-678, 760-782) -- per-iteration gradients, scalar losses
     and side effects against the reference's run (fixture analytic_eik: per-neighbour decoding, k = 8, decoder 1x64;
-    `pgo` = neighbour vectors rotated by the point orientations)."""
+    `pgo` = neighbour vectors rotated by the point orientations; `wf` = weighted-first decoding, train_fused_an_kernel)."""
     from pin_slam_amd import ops
     from tests import gpu_util as U
     d = G.load("analytic_eik")
+    wf = tag == "wf"
     st = U.search_state(d)
     k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
     feats, dec = U.dev(d[f"{tag}_feat_before"]), U.dev(d[f"{tag}_dec_before"])
     cert, tsu = U.dev(d[f"{tag}_cert_before"]), U.dev(d[f"{tag}_tsu_before"], torch.int32)
-    fs = ops.FieldState(feats=feats, dec=dec, k=k, hidden=H, levels=L, weighted_first=False, sdf_scale=d["sdf_scale"],
+    fs = ops.FieldState(feats=feats, dec=dec, k=k, hidden=H, levels=L, weighted_first=wf, sdf_scale=d["sdf_scale"],
                         certainty=cert, orient=U.dev(d["pgo_quat"]) if tag == "pgo" else None,
                         pos=U.dev(d["local_neural_points"]))
     gfeat, gdec = torch.zeros_like(feats), torch.zeros_like(dec)
     mf, vf, md, vd = torch.zeros_like(feats), torch.zeros_like(feats), torch.zeros_like(dec), torch.zeros_like(dec)
     bs = d[f"{tag}_coord0"].shape[0]
-    buf = ops.TrainBuffers(bs, 1, k, H, L, eikonal="analytic", weighted_first=False)
+    buf = ops.TrainBuffers(bs, 1, k, H, L, eikonal="analytic", weighted_first=wf)
     assert buf.n_eik == 0 and buf.Q == bs
     for it in range(len(d[f"{tag}_loss_total"])):
         loss = ops.train_step(st, fs, buf, U.dev(d[f"{tag}_coord{it}"]), U.dev(d[f"{tag}_label{it}"]),
@@ -308,12 +309,57 @@ def test_analytic_eikonal_mapping(tag):
     torch.testing.assert_close(gfeat, g_both, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("shape,pgo", [((64, 3), False), ((64, 4), True), ((32, 2), False), ((32, 1), True)])
+def test_analytic_eikonal_weighted_first_any_depth(shape, pgo):
+    """numerical_grad_on False with weighted_first True and decoders of 1..4 layers (mapper.py:677-678 through
+    Decoder.sdf on the interpolated input): one iteration's gradients and both losses of train_fused_an_kernel against
+    the oracle's double backward (pinned on the reference's `wf` run of the fixture at 1x64), with and without rotated
+    neighbour vectors."""
+    from pin_slam_amd import ops, synth
+    from tests import gpu_util as U
+    from tests.test_oracle_vs_golden import _search
+    d = G.load("analytic_eik")
+    d["table"] = G.dense_table(d)
+    H, L = shape
+    k = int(d["query_nn_k"])
+    st = U.search_state(d)
+    flat = synth.init_decoder(H, L, seed=5)
+    feats_np = d["wf_feat_before"]
+    orient = d["pgo_quat"] if pgo else None
+    feats, dec = U.dev(feats_np), U.dev(flat)
+    fs = ops.FieldState(feats=feats, dec=dec, k=k, hidden=H, levels=L, weighted_first=True, sdf_scale=d["sdf_scale"],
+                        certainty=None, orient=U.dev(orient) if pgo else None, pos=U.dev(d["local_neural_points"]))
+    coord, label, w = d["wf_coord0"], d["wf_label0"], d["wf_w0"]
+    bs = coord.shape[0]
+    buf = ops.TrainBuffers(bs, 1, k, H, L, eikonal="analytic", weighted_first=True)
+    gfeat, gdec = torch.zeros_like(feats), torch.zeros_like(dec)
+    loss = ops.train_step(st, fs, buf, U.dev(coord), U.dev(label), U.dev(w), U.dev(d["wf_ts0"], torch.int32), None, None,
+                          gfeat, gdec, sigma=d["sdf_scale"], weight_e=0.5, eik_eps=d["wf_eps"], loss_weight_on=True)
+
+    def searcher(points):
+        s = _search(d, points, tf=True)
+        return O.query_feature(points, s, feats_np, d["local_neural_points"], None, k, global2local=d["global2local"],
+                               orientations=orient, weighted_first=False)
+
+    r = O.train_step(coord, label, w, searcher, feats_np.astype(np.float64), d["local_neural_points"], flat.astype(np.float64),
+                     (11, H, L), d["sdf_scale"], k, weighted_first=True, dec=1, weight_e=0.5, loss_weight_on=True,
+                     analytic=True, orientations=orient)
+    assert np.max(np.abs(gfeat.cpu().numpy() - r["feat_grad"])) < 1e-4 * np.abs(r["feat_grad"]).max()
+    assert np.max(np.abs(gdec.cpu().numpy() - r["dec_grad"])) < 1e-4 * np.abs(r["dec_grad"]).max()
+    l_bce, l_eik = (loss.cpu().numpy() / bs).tolist()
+    assert r["eik_loss"] > 0.01 and abs(l_eik - r["eik_loss"]) < 1e-4 * r["eik_loss"]
+    assert abs(l_bce - r["sdf_loss"]) < 1e-4 * abs(r["sdf_loss"])
+    # a frozen decoder: same feature gradients without the operand streams
+    g_both = gfeat.clone(); gfeat.zero_()
+    ops.train_step(st, fs, buf, U.dev(coord), U.dev(label), U.dev(w), U.dev(d["wf_ts0"], torch.int32), None, None, gfeat, None,
+                   sigma=d["sdf_scale"], weight_e=0.5, eik_eps=d["wf_eps"], loss_weight_on=True)
+    torch.testing.assert_close(gfeat, g_both, rtol=1e-5, atol=1e-9)
+
+
 def test_analytic_eikonal_unsupported_shapes_raise():
-    """The analytic term is built for the shipped use (run_livox.yaml: per-neighbour decoding, decoder 1x64); the other
-    shapes fail loudly, in Python and at the C ABI."""
+    """Per-neighbour decoding has the analytic term for the shipped use (run_livox.yaml: decoder 1x64); deeper decoders
+    there fail loudly, in Python and at the C ABI."""
     from pin_slam_amd import ops
-    with pytest.raises(NotImplementedError):
-        ops.TrainBuffers(512, 1, 8, 64, 1, eikonal="analytic", weighted_first=True)
     with pytest.raises(NotImplementedError):
         ops.TrainBuffers(512, 1, 8, 64, 2, eikonal="analytic", weighted_first=False)
 
