@@ -109,8 +109,10 @@ def parse():
     ap.add_argument("--dp-mode", default="spatial", choices=["spatial", "dense"],
                     help="how the mapper batch is cut over the ranks: spatial = k-d boxes of the voxel grid, halo-row exchange "
                          "(pin_slam_amd.dp); dense = contiguous index shards, all-reduce of the whole gradient table")
-    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "host"],
-                    help="rccl = the product transport (one rank per GPU).  host = TEST mode for a single-GPU box: the ranks share "
+    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "torch", "host"],
+                    help="rccl = the product transport (one rank per GPU; RCCL through the C ABI, self-tested at start-up -- if any "
+                         "rank fails the test all ranks use torch.distributed's communicator instead and the line says so).  "
+                         "torch = torch.distributed's RCCL communicator.  host = TEST mode for a single-GPU box: the ranks share "
                          "cuda:0 and exchange through pinned host buffers over gloo (collective.HostStagedComm) -- the N > 1 code "
                          "path end to end, not a measurement")
     ap.add_argument("--dp-emulate", default="2,4,8", help="N = 1: world sizes whose single ranks are run alone on this GPU "
@@ -157,7 +159,7 @@ def launch_ranks(args) -> int:
     127.0.0.1) and hand their exit code back.  Rank 0 prints the JSON line on the inherited stdout."""
     import socket
     import subprocess
-    if not args.dry_launch and args.dp_transport == "rccl":
+    if not args.dry_launch and args.dp_transport != "host":
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {have} GPU(s); one rank per GPU is required "
@@ -299,7 +301,7 @@ def main():
             single_gpu_c4 = c4_single_gpu(args, cfg, mp)
         # RCCL through the C ABI; torch.distributed only carries the ncclUniqueId (and this script's barriers)
         from pin_slam_amd import collective
-        comm = collective.HostStagedComm(rank, world) if shared_gpu else collective.RcclComm(rank, world)
+        comm = collective.make_comm(rank, world, args.dp_transport)
         mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, comm, args.dp_mode
         out = bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P, single_gpu_c4)
         mp.dp_comm.close()

@@ -131,6 +131,92 @@ class HostStagedComm:
         pass
 
 
+class TorchComm:
+    """The same exchanges through ``torch.distributed``'s own communicator (backend "nccl" = the RCCL inside torch, or gloo
+    with device tensors in tests).  Selected explicitly (`bench.py --dp-transport torch`) or by :func:`make_comm` when
+    :class:`RcclComm` does not pass its self-test on some rank; the element-wise kernels stay the C ABI's."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        import torch.distributed as dist
+        self.rank, self.world, self.group = rank, world, group
+        self.kind = f"torch.distributed {dist.get_backend(group)}"
+
+    def allreduce_grads(self, flat: torch.Tensor):
+        import torch.distributed as dist
+        dist.all_reduce(flat, group=self.group)
+
+    def allreduce(self, send: torch.Tensor, recv: torch.Tensor):
+        import torch.distributed as dist
+        if recv.data_ptr() != send.data_ptr():
+            recv.reshape(-1)[:send.numel()].copy_(send.reshape(-1))
+        dist.all_reduce(recv.reshape(-1)[:send.numel()], group=self.group)
+
+    def allgather(self, send: torch.Tensor, recv: torch.Tensor):
+        import torch.distributed as dist
+        n = send.numel()
+        parts = list(recv.reshape(-1)[:self.world * n].split(n))
+        dist.all_gather(parts, send.reshape(-1).contiguous(), group=self.group)
+
+    def sync_side_effects(self, certainty, certainty0, scratch, ts_update):
+        import torch.distributed as dist
+        L, n = _lib.lib(), certainty.shape[0]
+        check(L.pin_dp_cert_delta(certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(), n, _stream()),
+              "pin_dp_cert_delta")
+        dist.all_reduce(scratch[:n], group=self.group)
+        dist.all_reduce(ts_update[:n], op=dist.ReduceOp.MAX, group=self.group)
+        check(L.pin_dp_cert_apply(certainty.data_ptr(), certainty0.data_ptr(), scratch.data_ptr(), n, _stream()),
+              "pin_dp_cert_apply")
+
+    def close(self):
+        pass
+
+
+def self_test(comm, device="cuda") -> bool:
+    """Both collectives of a transport on known values: SUM of (rank + 1) and the gathered ranks."""
+    w, r = comm.world, comm.rank
+    send = torch.full((257,), float(r + 1), dtype=torch.float32, device=device)
+    recv = torch.zeros_like(send)
+    comm.allreduce(send, recv)
+    gat = torch.zeros((w, 5), dtype=torch.float32, device=device)
+    comm.allgather(torch.full((5,), float(r), dtype=torch.float32, device=device), gat)
+    want = torch.arange(w, dtype=torch.float32, device=device)[:, None].expand(w, 5)
+    return bool((recv == w * (w + 1) / 2).all().item()) and bool((gat == want).all().item())
+
+
+def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device="cuda"):
+    """The mapper's transport for this job.  "rccl": RCCL through the C ABI, checked with :func:`self_test` on every rank;
+    when ANY rank fails to create the communicator or fails the test, all ranks switch to :class:`TorchComm` together and
+    say so (`kind` carries the reason) -- a job never runs with mixed transports."""
+    import torch.distributed as dist
+    if transport == "host":
+        return HostStagedComm(rank, world, group)
+    if transport == "torch":
+        return TorchComm(rank, world, group)
+    comm, why = None, ""
+    try:
+        comm = RcclComm(rank, world, group)
+        if not self_test(comm, device):
+            why = "self-test mismatch"
+    except Exception as e:  # noqa: BLE001 -- any failure of the optional path selects the other one, on every rank
+        why = f"{type(e).__name__}: {e}"
+    if world > 1:
+        flags = [None] * world
+        dist.all_gather_object(flags, why, group=group)
+        why = next((f"rank {i}: {f}" for i, f in enumerate(flags) if f), "")
+    if not why:
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+    alt = TorchComm(rank, world, group)
+    if not self_test(alt, device):
+        raise RuntimeError(f"no working transport: RcclComm failed ({why}) and torch.distributed fails its self-test")
+    alt.kind += f" (RcclComm not used: {why[:200]})"
+    return alt
+
+
 class NullComm:
     """One rank of an N-rank job measured ALONE (bench.py's per-rank emulation on a single-GPU box): every exchange is
     the identity, so the rank does exactly its own share of the work (its samples, its rows, the whole halo) and

@@ -23,7 +23,7 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         import torch.distributed as dist
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = collective.RcclComm(rank, world) if transport == "rccl" else collective.HostStagedComm(rank, world)
+        comm = collective.make_comm(rank, world, transport)  # rccl | torch (here: gloo on device tensors) | host
     d = G.load(case)
     st, fs = U.search_state(d), U.field_state(d)
     tsu = U.dev(d["local_point_ts_update"], torch.int32)

@@ -96,6 +96,21 @@ def test_spatial_shards_reproduce_the_reference(tmp_path, case, world, mode):
     assert np.abs(dense["feats"] - r0["feats"])[clean].max() < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["dense", "spatial", "spatial-reduce"])
+def test_torch_distributed_transport(tmp_path, mode):
+    """collective.TorchComm (what make_comm falls back to when RcclComm fails its self-test, and `--dp-transport torch`):
+    the same exchanges through torch.distributed on DEVICE tensors (here gloo, two ranks on cuda:0) -- all-reduce,
+    all-gather / reduce merge and the side-effect sync; the result is held against the reference's run like the host-staged one."""
+    d = G.load("c2_wf")
+    a = _launch(tmp_path, 2, "torch", "c2_wf", mode)
+    assert str(a[0]["kind"]).startswith("torch.distributed")
+    for key in ("feats", "dec", "cert", "tsu", "gdec0", "gdec1"):  # both ranks end with the same model
+        assert np.array_equal(a[0][key].view(np.uint8), a[1][key].view(np.uint8)), key
+    # (two runs differ in the order of the feature-gradient atomics: compared through the reference, not bit for bit)
+    dense = a[0] if mode == "dense" else _launch(tmp_path, 2, "host", "c2_wf")[0]
+    _against_reference(d, a[0], grads=None if mode == "dense" else dense)
+
+
 @pytest.mark.parametrize("mode", ["spatial", "spatial-reduce"])
 def test_spatial_shards_with_the_colour_branch(tmp_path, mode):
     """Colour maps (replica_color: SDF + colour decoders, colour L1 on the surface samples) through the spatial shards: the

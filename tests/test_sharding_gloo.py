@@ -103,6 +103,44 @@ def test_two_rank_allreduce_equals_single_rank_gradient():
     assert abs(loss - loss1) < 1e-9
 
 
+def _fallback_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pin_slam_amd import collective
+    if rank == 1:  # only ONE rank cannot bring RCCL up: every rank must still end on the same transport
+        collective.RcclComm.__init__ = lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("no RCCL on this rank"))
+    else:
+        def fake(self, r, w, group=None):
+            self.rank, self.world, self.kind, self._h = r, w, "rccl", None
+        collective.RcclComm.__init__ = fake
+        collective.RcclComm.allreduce = lambda self, s, r: r.copy_(s * 3.0)   # (3 = 1 + 2: passes the self-test alone)
+        collective.RcclComm.allgather = lambda self, s, r: r.copy_(torch.arange(2.0)[:, None].expand(2, 5))
+        collective.RcclComm.close = lambda self: None
+    comm = collective.make_comm(rank, world, "rccl", device="cpu")
+    t = torch.full((4,), float(rank + 1))
+    comm.allreduce_grads(t)
+    q.put((rank, comm.kind, t.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_transport_fallback_is_agreed_by_all_ranks():
+    """collective.make_comm: RcclComm failing on ONE rank moves every rank to torch.distributed's communicator (never a
+    mixed job), the reason is carried in `kind`, and the fallback transport works."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for _, kind, vals in got:
+        assert kind.startswith("torch.distributed gloo") and "rank 1: RuntimeError: no RCCL on this rank" in kind
+        assert vals == [3.0] * 4
+
+
 @pytest.mark.timeout(300)
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` (the driver's plain command form) must start two ranks itself and have them meet;
