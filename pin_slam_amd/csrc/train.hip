@@ -619,6 +619,20 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
 
 }  // namespace pin
 #include "train_fused.h"
+
+namespace pin {
+// tiles per block of the weight-gradient launch.  DW_CHUNK (32) at the reference's batch, where the launch is one round
+// of blocks; large batches take longer chunks -- fewer block tails (the reduction over the phases and the slot atomics):
+// 1.12 -> 0.93 ms per launch at 2^20 samples with 256 -- as long as ~4 rounds of blocks are left to balance the CUs.
+// PIN_DW_CHUNK overrides it for A/B runs.
+static int dw_chunk(int n_tiles, int layers_plus_one) {
+    static const int forced = [] { const char* e = getenv("PIN_DW_CHUNK"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    const long want = (long)n_tiles * layers_plus_one / 1024;
+    const int c = (int)(want / DW_CHUNK) * DW_CHUNK;
+    return c < DW_CHUNK ? DW_CHUNK : (c > 256 ? 256 : c);
+}
+}  // namespace pin
 namespace pin {
 
 // ---- Adam --------------------------------------------------------------------------------
@@ -943,15 +957,16 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
             image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
         else
             hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
-        hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+        hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TFW_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                            sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
                            n_dec, loss_partial, fcol);
         PIN_CHECK_LAUNCH();
     }
     if (!(phase & 2)) return 0;
     if (want_dec) {
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, DW_CHUNK), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
-                           dw_partial, 0);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
+                           dw_partial, 0, chunk);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
@@ -1014,9 +1029,10 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
                        dw_partial, n_dec, loss_partial);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        const dim3 dgrid(cdiv(ws.n_tiles, DW_CHUNK), L + 1);
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0);
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        const dim3 dgrid(cdiv(ws.n_tiles, chunk), L + 1);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
@@ -1083,9 +1099,10 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     }
     if (!(phase & 2)) return 0;
     if (want_dec) {
-        const dim3 dgrid(cdiv(ws.n_tiles, DW_CHUNK), L + 1);
-        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0);
-        if (AN) hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        const dim3 dgrid(cdiv(ws.n_tiles, chunk), L + 1);
+        hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
+        if (AN) hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
         PIN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,

@@ -47,7 +47,9 @@ struct FusedColor {          // OD = 3 only
     int loss_weight_on;
 };
 
-constexpr int TF_BLOCK = 512;  // 8 waves per CU, 2 per SIMD (<= 256 VGPRs)
+constexpr int TF_BLOCK = 512;  // 8 waves per CU, 2 per SIMD (<= 256 VGPRs): the per-neighbour and analytic-Eikonal kernels
+constexpr int TFW_BLOCK = 768; // train_fused_kernel: 12 waves per CU, 3 per SIMD (<= 168 VGPRs) -- a tile is a latency chain
+                               // (~80 k cycles for ~11 k cycles of vector issue): throughput at large batches is waves in flight
 // (DW_SLOTS partial weight gradients, train.hip: chunk c of the streamed product adds into slot c % DW_SLOTS)
 
 // operand stream of the weight-gradient launch.  Layer index lam = 0..L: delta_{lam+1} (x) a_lam, with a_0 = z (one
@@ -87,7 +89,7 @@ __device__ __forceinline__ uint2 transpose_block(unsigned int w0, unsigned int w
 }
 
 template <int H, int L, int OD = 1>
-__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, pin_train_params tp,
+__global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, pin_train_params tp,
                                                                   const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count,
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
     unsigned char* const lds = tf_smem;
     constexpr int IMG = (Q::bytes(L) + 15) & ~15;
     float* const xch = reinterpret_cast<float*>(lds + IMG) + (threadIdx.x >> 6) * (3 * 16 * 8);  // per wave: dz, w, idx [16][8]
-    double (*lred)[2] = reinterpret_cast<double (*)[2]>(lds + IMG + (TF_BLOCK / 64) * 3 * 16 * 8 * 4);
+    double (*lred)[2] = reinterpret_cast<double (*)[2]>(lds + IMG + (TFW_BLOCK / 64) * 3 * 16 * 8 * 4);
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_main = tp.n_main, n_eik = tp.n_eik;
     const int n_mixed = fused_mixed_tiles(n_eik);
     const int n_tiles = ws.n_tiles;
-    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const int n_waves = gridDim.x * (TFW_BLOCK / 64);
     const float inv_dscale = 1.0f / dscale;
     // identity operand of the transposing MFMA: B[k = 4 (lane >> 4) + r][n = lane & 15]
     v4h_t ident;
@@ -124,22 +126,22 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
     double acc_bce = 0.0, acc_eik = 0.0;
     if (want_dec) {  // the slot partials of the weight-gradient launch start from zero (it runs after this kernel)
         const int n = DW_SLOTS * n_dec;
-        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+        for (int i = blockIdx.x * TFW_BLOCK + threadIdx.x; i < n; i += gridDim.x * TFW_BLOCK) dw_partial[i] = 0.f;
     }
     {   // the decoder image, split and permuted once per call by train_stage_kernel: a linear copy per block, in
         // flight behind the first tile's gather loads
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
-        constexpr int N16 = Q::bytes(L) >> 4, TRIPS = (N16 + TF_BLOCK - 1) / TF_BLOCK;
+        constexpr int N16 = Q::bytes(L) >> 4, TRIPS = (N16 + TFW_BLOCK - 1) / TFW_BLOCK;
         uint4 v[TRIPS];  // (all loads of the copy in flight at once)
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = it * TF_BLOCK + threadIdx.x;
+            const int i = it * TFW_BLOCK + threadIdx.x;
             v[it] = src[i < N16 ? i : 0];
         }
 #pragma unroll
         for (int it = 0; it < TRIPS; ++it) {
-            const int i = it * TF_BLOCK + threadIdx.x;
+            const int i = it * TFW_BLOCK + threadIdx.x;
             if (i < N16) dst[i] = v[it];
         }
     }
@@ -218,25 +220,55 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
 #pragma unroll
             for (int t = 0; t < PIN_MAX_K; ++t) { sw[nq * 8 + t] = nb.w[t]; sidx[nq * 8 + t] = nb.idx[t]; }
         }
-        // ---- forward; the pieces of every layer's input stay in registers for the weight gradient
+        // ---- forward.  The pieces of a layer's input are the B operand of its product AND the A operand of its weight
+        // gradient: they go out to the operand stream right here and only the layer's ReLU pattern (16 bits per lane)
+        // stays for the backward sweep -- r03a kept all pieces in registers (64 at 4 x 64) and ran 2 waves per SIMD
+        const size_t tbase = (size_t)tile * 128 + lane;
+        const size_t tbig = (size_t)tile * 128 * (MT - 1) + tbase;
+        auto stream_acts = [&](const v4u_t (&ph)[NJ], const v4u_t (&pl)[NJ], int l) {  // a_l, l = 1 .. L
+            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + tbig;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                A[mt * 128] = transpose_block(ph[mt >> 1][2 * (mt & 1)], ph[mt >> 1][2 * (mt & 1) + 1], ident);
+                A[mt * 128 + 64] = transpose_block(pl[mt >> 1][2 * (mt & 1)], pl[mt >> 1][2 * (mt & 1) + 1], ident);
+            }
+        };
+        auto pattern16 = [](const v4f_t (&h)[MT]) {  // bit 4 mt + r: unit (mt, r) of this lane is active (h = relu(.) >= +0)
+            unsigned int m = 0u;
+#pragma unroll
+            for (int mt = MT - 1; mt >= 0; --mt)
+#pragma unroll
+                for (int r = 3; r >= 0; --r) m = (m << 1) | ((__float_as_uint(h[mt][r]) + 0x7fffffffu) >> 31);
+            return m;
+        };
         v2u_t zh, zl;
         Q::split_input(z, zh, zl);
+        if (want_dec && work) {
+            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
+            A[0] = transpose_block(zh[0], zh[1], ident);
+            A[64] = transpose_block(zl[0], zl[1], ident);
+        }
         v4f_t h[MT], acc[MT];
-        v4u_t ph[L][NJ], pl[L][NJ];  // pieces of a_1 .. a_L
+        unsigned int pat[L];  // ReLU patterns of a_1 .. a_L
         Q::layer0(lds, L, zh, zl, acc);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
 #pragma unroll
-        for (int l = 1; l < L; ++l) {
-            Q::split_acts(h, ph[l - 1], pl[l - 1]);
-            Q::load_bias(lds, L, l, acc);
-            Q::matmul(lds + Q::off_hidf(L, l), ph[l - 1], pl[l - 1], acc);
+        for (int l = 1; l <= L; ++l) {
+            v4u_t ph[NJ], pl[NJ];
+            pat[l - 1] = pattern16(h);
+            if (l < L || want_dec) Q::split_acts(h, ph, pl);
+            if (want_dec) stream_acts(ph, pl, l);
+            if (l < L) {
+                Q::load_bias(lds, L, l, acc);
+                Q::matmul(lds + Q::off_hidf(L, l), ph, pl, acc);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+                    for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+            }
         }
         const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
         float dxc[OD];  // d loss / d head c of this column, times dscale
@@ -304,21 +336,13 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
             }
         }
         // ---- backward
-        size_t tbase = (size_t)tile * 128 + lane;
-        if (want_dec) {  // out layer: delta = d loss / d heads in units 0 .. OD - 1 of a 16-unit block, input a_L
-            Q::split_acts(h, ph[L - 1], pl[L - 1]);
+        if (want_dec) {  // out layer: delta = d loss / d heads in units 0 .. OD - 1 of a 16-unit block (its input a_L is out already)
             unsigned int dh0, dl0, dh1 = 0u, dl1 = 0u;
             h2_split2((g == 0) ? dxc[0] : 0.f, (g == 0 && OD > 1) ? dxc[OD > 1 ? 1 : 0] : 0.f, dh0, dl0);
             if constexpr (OD > 2) h2_split2((g == 0) ? dxc[2] : 0.f, 0.f, dh1, dl1);
             uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
             D[0] = transpose_block(dh0, dh1, ident);
             D[64] = transpose_block(dl0, dl1, ident);
-            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, L) + (size_t)tile * 128 * (MT - 1) + tbase;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                A[mt * 128] = transpose_block(ph[L - 1][mt >> 1][2 * (mt & 1)], ph[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
-                A[mt * 128 + 64] = transpose_block(pl[L - 1][mt >> 1][2 * (mt & 1)], pl[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
-            }
         }
         bool any_dx = false;
 #pragma unroll
@@ -333,7 +357,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
                 for (int r = 0; r < 4; ++r) sd[r] = fmaf(dxc[c], wo[r], sd[r]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[kt][r] = h[kt][r] > 0.f ? sd[r] : 0.f;
+            for (int r = 0; r < 4; ++r) h[kt][r] = ((pat[L - 1] >> (4 * kt + r)) & 1u) ? sd[r] : 0.f;
         }
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
@@ -341,39 +365,22 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
             v4u_t bh[NJ], bl[NJ];
             Q::split_acts(h, bh, bl);
             if (want_dec) {
-                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + (size_t)tile * 128 * (MT - 1) + tbase;
+                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + tbig;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
                     D[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
-                }
-                if (l > 0) {
-                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + (size_t)tile * 128 * (MT - 1) + tbase;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        A[mt * 128] = transpose_block(ph[l - 1][mt >> 1][2 * (mt & 1)], ph[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
-                        A[mt * 128 + 64] = transpose_block(pl[l - 1][mt >> 1][2 * (mt & 1)], pl[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
-                    }
-                } else {
-                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
-                    A[0] = transpose_block(zh[0], zh[1], ident);
-                    A[64] = transpose_block(zl[0], zl[1], ident);
                 }
             }
             if (l > 0) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f_t){0.f, 0.f, 0.f, 0.f};
                 Q::matmul(lds + Q::off_hidb(L, l), bh, bl, acc);
-                // ReLU pattern of a_l out of its pieces: a positive activation has a non-zero piece (down to 2^-36:
-                // far inside the rounding noise of the pre-activation; the Gauss-Newton kernel keeps exact patterns)
+                // ReLU pattern of a_l (exact: taken from the fp32 activations of the forward pass)
 #pragma unroll
                 for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned int word = ph[l - 1][mj >> 1][2 * (mj & 1) + (r >> 1)] | pl[l - 1][mj >> 1][2 * (mj & 1) + (r >> 1)];
-                        const bool on = (r & 1) ? ((word & 0x7fff0000u) != 0u) : ((word & 0x7fffu) != 0u);
-                        h[mj][r] = on ? acc[mj][r] : 0.f;
-                    }
+                    for (int r = 0; r < 4; ++r) h[mj][r] = ((pat[l - 1] >> (4 * mj + r)) & 1u) ? acc[mj][r] : 0.f;
             } else {
                 float dz[4];
                 Q::input_backward(lds, L, bh, bl, dz);
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_kernel(pin_field f, p
     if (threadIdx.x < 2) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < TF_BLOCK / 64; ++w) t += lred[w][threadIdx.x];
+        for (int w = 0; w < TFW_BLOCK / 64; ++w) t += lred[w][threadIdx.x];
         loss_partial[2 * blockIdx.x + threadIdx.x] = t;
     }
 }
@@ -1134,7 +1141,7 @@ __global__ __launch_bounds__(512) void train_stage_kernel(pin_field f, unsigned 
 
 template <int H>
 constexpr int train_fused_lds_bytes(int L) {
-    return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (TF_BLOCK / 64) * 3 * 16 * 8 * 4 + (TF_BLOCK / 64) * 2 * 8;
+    return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (TFW_BLOCK / 64) * 3 * 16 * 8 * 4 + (TFW_BLOCK / 64) * 2 * 8;
 }
 
 // ---- weight gradient over the operand stream ----------------------------------------------------------------------
@@ -1152,7 +1159,7 @@ constexpr int DW_VALS = 20;    // per lane: 4 input blocks x 4 + 4 bias sums
 
 template <int H>
 __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream ws, int L, int OD, int n_dec,
-                                                                        float* __restrict__ partial, int no_bias) {
+                                                                        float* __restrict__ partial, int no_bias, int chunk) {
     using G = DwGeom<H>;
     constexpr int MT = G::MT;
     __shared__ float red[DW_WAVES / 2][DW_VALS][64];
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
     const size_t n_tiles = (size_t)ws.n_tiles;
     const uint2* __restrict__ D = ws.d + G::d_off(n_tiles, lam) + (size_t)ob * 128 + lane;
     const uint2* __restrict__ A = ws.a + G::a_off(n_tiles, lam) + lane;
-    const int t0 = blockIdx.x * DW_CHUNK, t1 = min(t0 + DW_CHUNK, ws.n_tiles);
+    const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, ws.n_tiles);
     v4f_t mainv[MT], cross[MT], bmain = (v4f_t){0.f, 0.f, 0.f, 0.f}, bcross = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ib = 0; ib < MT; ++ib) { mainv[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; cross[ib] = (v4f_t){0.f, 0.f, 0.f, 0.f}; }
