@@ -621,16 +621,20 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
 #include "train_fused.h"
 
 namespace pin {
-// tiles per block of the weight-gradient launch.  DW_CHUNK (32) at the reference's batch, where the launch is one round
-// of blocks; large batches take longer chunks -- fewer block tails (the reduction over the phases and the slot atomics):
-// 1.12 -> 0.93 ms per launch at 2^20 samples with 256 -- as long as ~4 rounds of blocks are left to balance the CUs.
-// PIN_DW_CHUNK overrides it for A/B runs.
-static int dw_chunk(int n_tiles, int layers_plus_one) {
+// tiles per block of the weight-gradient launch: whole rounds of blocks.  The grid is (chunks, L + 1 layers) and a block
+// fills a CU (16 waves, 128 registers), so `rounds * n_cu / (L + 1)` chunks make exactly `rounds` rounds -- r03a's fixed 32
+// tiles gave 52 x 5 = 260 blocks on 256 CUs at the reference's batch: a second round for four blocks.  Large batches take
+// chunks of up to ~DW_MAX_CHUNK tiles (fewer block tails: the reduction over the phases and the slot atomics).
+// PIN_DW_CHUNK / PIN_DW_MAXCHUNK override for A/B runs.
+constexpr int DW_MAX_CHUNK = 256;
+static int dw_chunk(int n_tiles, int layers_plus_one, int n_cu) {
     static const int forced = [] { const char* e = getenv("PIN_DW_CHUNK"); return e ? atoi(e) : 0; }();
+    static const int max_chunk = [] { const char* e = getenv("PIN_DW_MAXCHUNK"); return e ? atoi(e) : DW_MAX_CHUNK; }();
     if (forced > 0) return forced;
-    const long want = (long)n_tiles * layers_plus_one / 1024;
-    const int c = (int)(want / DW_CHUNK) * DW_CHUNK;
-    return c < DW_CHUNK ? DW_CHUNK : (c > 256 ? 256 : c);
+    const long work = (long)n_tiles * layers_plus_one;
+    const int rounds = (int)((work + (long)n_cu * max_chunk - 1) / ((long)n_cu * max_chunk));
+    const int chunks = max(1, rounds * n_cu / layers_plus_one);
+    return max(1, cdiv(n_tiles, chunks));
 }
 }  // namespace pin
 namespace pin {
@@ -964,7 +968,7 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     }
     if (!(phase & 2)) return 0;
     if (want_dec) {
-        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
                            dw_partial, 0, chunk);
         PIN_CHECK_LAUNCH();
@@ -1029,7 +1033,7 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
                        dw_partial, n_dec, loss_partial);
     PIN_CHECK_LAUNCH();
     if (want_dec) {
-        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
         const dim3 dgrid(cdiv(ws.n_tiles, chunk), L + 1);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
@@ -1099,7 +1103,7 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     }
     if (!(phase & 2)) return 0;
     if (want_dec) {
-        const int chunk = dw_chunk(ws.n_tiles, L + 1);
+        const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
         const dim3 dgrid(cdiv(ws.n_tiles, chunk), L + 1);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
         if (AN) hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
