@@ -313,6 +313,8 @@ def main():
         ctypes.CDLL(None).fflush(None)
         if rank == 0:
             print(json.dumps(out), flush=True)
+        if getattr(comm, "abandoned_thread", False):
+            os._exit(0)  # (a bootstrap thread of the transport that was not used is still blocked in the library)
         return
 
     scan_np = synth.make_scan(m, n=args.scan, seed=1, noise=wl.get("scan_noise", 0.02))

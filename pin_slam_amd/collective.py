@@ -193,19 +193,48 @@ def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device
     if transport == "torch":
         return TorchComm(rank, world, group)
     comm, why = None, ""
-    try:
-        comm = RcclComm(rank, world, group)
-        if not self_test(comm, device):
-            why = "self-test mismatch"
-    except Exception as e:  # noqa: BLE001 -- any failure of the optional path selects the other one, on every rank
-        why = f"{type(e).__name__}: {e}"
+    # communicator set-up and the self-test run under a watchdog: a bootstrap that never returns (it blocks inside
+    # ncclCommInitRank on every rank alike) must end in the other transport, not in a job that hangs
+    box = {}
+
+    def bring_up():
+        try:
+            c = RcclComm(rank, world, group)
+            box["comm"] = c
+            box["ok"] = self_test(c, device)
+        except Exception as e:  # noqa: BLE001 -- any failure of the optional path selects the other one, on every rank
+            box["err"] = f"{type(e).__name__}: {e}"
+
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("PIN_COMM_INIT_TIMEOUT", "120"))
+        dev_index = torch.cuda.current_device() if device != "cpu" else None
+
+        def in_thread():  # (a new thread starts on device 0: the kernels of the self-test must run on this rank's device)
+            if dev_index is not None:
+                torch.cuda.set_device(dev_index)
+            bring_up()
+
+        th = threading.Thread(target=in_thread, daemon=True)
+        th.start()
+        th.join(limit)
+        if th.is_alive():
+            box.setdefault("err", f"set-up or self-test did not finish within {limit:.0f} s")
+            box["stuck"] = True
+    else:
+        bring_up()
+    comm = box.get("comm")
+    if "err" in box:
+        why = box["err"]
+    elif not box.get("ok", False):
+        why = "self-test mismatch"
     if world > 1:
         flags = [None] * world
         dist.all_gather_object(flags, why, group=group)
         why = next((f"rank {i}: {f}" for i, f in enumerate(flags) if f), "")
     if not why:
         return comm
-    if comm is not None:
+    if comm is not None and not box.get("stuck"):
         try:
             comm.close()
         except Exception:  # noqa: BLE001
@@ -214,6 +243,7 @@ def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device
     if not self_test(alt, device):
         raise RuntimeError(f"no working transport: RcclComm failed ({why}) and torch.distributed fails its self-test")
     alt.kind += f" (RcclComm not used: {why[:200]})"
+    alt.abandoned_thread = bool(box.get("stuck"))  # the caller should leave with os._exit: a thread still sits in the bootstrap
     return alt
 
 

@@ -96,6 +96,8 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         if transport != "null":
             import torch.distributed as dist
             dist.destroy_process_group()
+        if getattr(comm, "abandoned_thread", False):
+            os._exit(0)  # (collective.make_comm: a bootstrap thread of the unused transport is still blocked)
 
 
 if __name__ == "__main__":

@@ -155,6 +155,20 @@ def test_spatial_shards_over_rccl_single_rank(tmp_path):
     assert np.abs(dense["feats"] - r["feats"])[clean].max() < 1e-4
 
 
+def test_rccl_failing_on_a_shared_gpu_falls_back_on_every_rank(tmp_path, monkeypatch):
+    """Two ranks on ONE device ask for the RCCL transport: RCCL refuses (or never finishes its bootstrap -- the watchdog of
+    collective.make_comm ends that), every rank moves to torch.distributed's communicator together, the reason is in
+    `kind`, and the run still reproduces the reference."""
+    monkeypatch.setenv("PIN_COMM_INIT_TIMEOUT", "30")
+    d = G.load("c2_wf")
+    a = _launch(tmp_path, 2, "rccl", "c2_wf", "spatial")
+    for r in a:
+        assert str(r["kind"]).startswith("torch.distributed") and "RcclComm not used" in str(r["kind"]), str(r["kind"])
+    for key in ("feats", "dec", "cert", "tsu"):
+        assert np.array_equal(a[0][key].view(np.uint8), a[1][key].view(np.uint8)), key
+    _against_reference(d, a[0], grads=_launch(tmp_path, 2, "host", "c2_wf")[0])
+
+
 def test_rccl_transport_single_rank(tmp_path):
     """RCCL through the C ABI (dlopen, ncclGetUniqueId, ncclCommInitRank, in-place ncclAllReduce on the stream, the grouped
     certainty / ts exchange): with one rank the reductions are identities and the run must equal the reference."""

@@ -103,12 +103,16 @@ def test_two_rank_allreduce_equals_single_rank_gradient():
     assert abs(loss - loss1) < 1e-9
 
 
-def _fallback_worker(rank, world, port, q):
+def _fallback_worker(rank, world, port, q, hang=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pin_slam_amd import collective
-    if rank == 1:  # only ONE rank cannot bring RCCL up: every rank must still end on the same transport
+    if hang:  # the bootstrap never returns (on any rank): the watchdog ends it
+        import time
+        os.environ["PIN_COMM_INIT_TIMEOUT"] = "3"
+        collective.RcclComm.__init__ = lambda self, *a, **k: time.sleep(3600)
+    elif rank == 1:  # only ONE rank cannot bring RCCL up: every rank must still end on the same transport
         collective.RcclComm.__init__ = lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("no RCCL on this rank"))
     else:
         def fake(self, r, w, group=None):
@@ -122,6 +126,26 @@ def _fallback_worker(rank, world, port, q):
     comm.allreduce_grads(t)
     q.put((rank, comm.kind, t.tolist()))
     dist.destroy_process_group()
+    if getattr(comm, "abandoned_thread", False):
+        q.close(); q.join_thread()
+        os._exit(0)
+
+
+@pytest.mark.timeout(300)
+def test_transport_bring_up_that_never_returns_falls_back():
+    """collective.make_comm's watchdog: an RCCL bootstrap that blocks for ever ends in torch.distributed's communicator on
+    every rank after PIN_COMM_INIT_TIMEOUT seconds, and the ranks are told to leave with os._exit."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for _, kind, vals in got:
+        assert kind.startswith("torch.distributed gloo") and "did not finish within 3 s" in kind
+        assert vals == [3.0] * 4
 
 
 @pytest.mark.timeout(300)
