@@ -463,7 +463,7 @@ def main():
     c4 = None
     c4_emul = None
     if world == 1 and args.c4_iters > 0 and not colour:
-        c4 = c4_single_gpu(args, cfg, mp)
+        c4 = c4_single_gpu(args, cfg, mp, nn_mean, int(npts.neighbor_K), k)
         worlds = [int(w) for w in args.dp_emulate.split(",") if w.strip()]
         if worlds and cfg.weighted_first:
             c4_emul = c4_per_rank_emulated(args, cfg, mp, worlds, c4)
@@ -651,7 +651,7 @@ def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None, mp=None, cde
     return g
 
 
-def c4_single_gpu(args, cfg, mp):
+def c4_single_gpu(args, cfg, mp, nn_mean=None, Kc=81, k=8):
     """Config C4 on one GPU: Mapper.mapping on a global batch of --global-bs samples (the quantity
     `bench.py --gpus N` reports for N > 1), timed with the host clock around synchronised calls."""
     bs0 = cfg.bs
@@ -665,12 +665,51 @@ def c4_single_gpu(args, cfg, mp):
             mp.mapping(args.c4_iters)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        group = int(getattr(getattr(mp._trainer, "buf", None), "group", 1) or 1)
     finally:
         cfg.bs = bs0
         mp._trainer = None  # drop the 2^20-sample workspace
     it = reps * args.c4_iters
-    return {"global_batch": args.global_bs, "iterations_timed": it, "ms_per_iteration": round(1e3 * dt / it, 4),
-            "mapper_samples_per_sec": round(args.global_bs * it / dt, 1), "optimizer": "lazy exact Adam (single GPU)"}
+    out = {"global_batch": args.global_bs, "iterations_timed": it, "ms_per_iteration": round(1e3 * dt / it, 4),
+           "mapper_samples_per_sec": round(args.global_bs * it / dt, 1), "optimizer": "lazy exact Adam (single GPU)"}
+    out["roofline_train"] = roofline_train(args, cfg, out["ms_per_iteration"], nn_mean, Kc, k, group)
+    return out
+
+
+def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
+    """The mapper iteration at the C4 batch against the HBM roofline: SURVEY 8(d)'s algorithmic bytes per sample (without the
+    Adam term: the lazy optimiser's traffic is in the counters, not in the formula) x the batch, over the measured iteration;
+    `traffic` = HBM-side bytes of the iteration's kernels from the PMC passes of this command (scripts/pmc_bench.sh c4 ->
+    profiles/r03_pmc_c4.json; FETCH_SIZE of the wide streaming reads of the weight-gradient kernel corrected x2 as
+    MI355X_MICROARCH.md prescribes for gfx950, the random-row kernels at face value)."""
+    rho = nn_mean / Kc if nn_mean else 0.56  # (the C3 map's measured share of occupied candidate cells when not handed in)
+    dec_n = max(1, int(cfg.gradient_decimation))
+    bytes_s = (1.0 + 6.0 / dec_n) * (12 + 4 * Kc + 16 * rho * Kc + 36 * k + 64 * k) + 12
+    alg = bytes_s * args.global_bs
+    r = {"kernel": "train_fused_kernel + train_dw_stream_kernel + knn_brick_kernel + lazy Adam (one Mapper.mapping iteration, 2^20 samples)",
+         "bound": "hbm", "achieved": round(alg / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(alg / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round(bytes_s, 1),
+         "traffic": None}
+    path = os.path.join(ROOT, "profiles", "r03_pmc_c4.json")
+    if os.path.exists(path):
+        try:
+            ks = json.load(open(path))["kernels"]
+            per = {"train_fused": ks["train_fused"]["hbm_bytes_per_launch"],
+                   "train_dw_stream": ks["train_dw_stream"]["hbm_bytes_per_launch_if_streaming_x2"],
+                   "knn_brick": int(ks["knn_brick"]["hbm_bytes_per_launch"] / max(1, group)),
+                   "lazy_adam": ks["mark_rows"]["hbm_bytes_per_launch"] + ks["adam_lazy_prepare_rows"]["hbm_bytes_per_launch"]}
+            r["traffic"] = int(sum(per.values()))
+            r["traffic_per_kernel"] = per
+            r["traffic_source"] = "profiles/r03_pmc_c4.json"
+            r["traffic_over_algorithmic"] = round(r["traffic"] / alg, 2)
+            r["kernel_us"] = {kk: ks[kk]["duration_us"] for kk in ("train_fused", "train_dw_stream", "knn_brick", "mark_rows",
+                                                                  "adam_lazy_prepare_rows")}
+            r["note"] = ("the operand stream of the weight gradient (2.2 KB per query, written by the tile kernel and read back by the "
+                         "next launch) is most of the distance between traffic and algorithmic bytes; the search kernel's launch covers "
+                         f"{group} iterations and is divided accordingly")
+        except Exception:
+            pass
+    return r
 
 
 def sync_replicas(npts, dec, world):

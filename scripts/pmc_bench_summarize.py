@@ -14,7 +14,9 @@ O = os.path.join(R, "gpurun_out", "pmc_bench", W)
 CLOCK_GHZ, N_SIMD = 2.4, 1024
 
 CLASSES = (("gn", "gn_accumulate"), ("knn_brick", "knn_brick_kernel"), ("train_fused", "train_fused"), ("train_dw_stream", "train_dw_stream"),
-           ("adam_lazy_prepare", "adam_lazy_prepare"), ("gn_solve", "gn_solve"))
+           ("adam_lazy_prepare_rows", "adam_lazy_prepare_rows"), ("mark_rows", "mark_rows"), ("adam_lazy_prepare", "adam_lazy_prepare"),
+           ("gn_solve", "gn_solve"))
+LARGEST = W == "c4"  # the 2^20-sample mapper: its launches are the largest grids of their kernels, not the most frequent
 
 
 def cls(name):
@@ -43,9 +45,12 @@ for f in glob.glob(os.path.join(O, "stats", "**", "*kernel_trace.csv"), recursiv
         if k:
             g = str(int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)) if "Grid_Size_X" in r else r.get("Grid_Size", "?")
             dur[(k, g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"command": f"scripts/pmc_bench.sh {W}: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {W} --steps 3 --warmup 1 "
-                  "--no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none (separate passes: FETCH_SIZE, WRITE_SIZE, two "
-                  "SQ sets; durations from a --kernel-trace --stats pass of the same command)",
+out = {"command": (f"scripts/pmc_bench.sh {W}: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {W} --steps 3 --warmup 1 "
+                   "--no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none" if not LARGEST else
+                   "scripts/pmc_bench.sh c4: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload c3 --steps 1 --warmup 0 "
+                   "--no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none; per kernel class the LARGEST "
+                   "launch shape = the 2^20-sample Mapper.mapping iterations (the search kernel's launch covers a group of iterations)") +
+                  " (separate passes: FETCH_SIZE, WRITE_SIZE, two SQ sets; durations from a --kernel-trace --stats pass of the same command)",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ_* summed over the chip per launch; duration_us = mean kernel time of "
                 "that launch shape in the stats pass",
        "kernels": {}}
@@ -54,10 +59,23 @@ for (k, g), d in res.items():
     by_class[k].append((len(next(iter(d.values()))), g))
 for k, shapes in by_class.items():
     n, g = max(shapes)  # the shape with the most launches = the hot loop's
+    if LARGEST:
+        n, g = max(shapes, key=lambda t: int(t[1]) if str(t[1]).isdigit() else 0)
     d = res[(k, g)]
-    e = {c: round(sum(v) / len(v), 1) for c, v in d.items()}
+    top = None
+    if LARGEST and k == "train_fused":
+        # persistent blocks: one grid for every batch size.  The 2^20-sample launches are the heaviest ones of the run,
+        # as many as the weight-gradient kernel has launches of its largest grid
+        dw = [(int(gg), len(next(iter(res[("train_dw_stream", gg)].values())))) for (kk, gg) in res if kk == "train_dw_stream" and str(gg).isdigit()]
+        top = max(dw)[1] if dw else None
+    pick = (lambda v: sorted(v, reverse=True)[:top]) if top else (lambda v: v)
+    e = {c: round(sum(pick(v)) / len(pick(v)), 1) for c, v in d.items()}
+    if top:
+        n = top
     e["launch_shape_grid"], e["launches_counted"], e["kernel"] = g, n, names[(k, g)]
     dd = dur.get((k, g)) or [x for (kk, gg), v in dur.items() if kk == k for x in v]
+    if dd and top:
+        dd = sorted(dd, reverse=True)[:top]
     if dd:
         e["duration_us"] = round(sum(dd) / len(dd) / 1e3, 2)
         cyc = e["duration_us"] * 1e-6 * CLOCK_GHZ * 1e9 * N_SIMD
