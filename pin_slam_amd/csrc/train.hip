@@ -636,6 +636,14 @@ static int dw_chunk(int n_tiles, int layers_plus_one, int n_cu) {
     const int chunks = max(1, rounds * n_cu / layers_plus_one);
     return max(1, cdiv(n_tiles, chunks));
 }
+// the weight gradient recomputes the layers' inputs instead of streaming them (train_dw_recompute_kernel) from this many
+// tiles on; PIN_DW_RECOMPUTE=0 / 1 forces the choice (read per call: tests switch it)
+constexpr int DW_RECOMPUTE_MIN_TILES = 8192;
+static bool dw_recompute(int n_tiles) {
+    const char* e = getenv("PIN_DW_RECOMPUTE");
+    if (e != nullptr && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return n_tiles >= DW_RECOMPUTE_MIN_TILES;
+}
 }  // namespace pin
 namespace pin {
 
@@ -956,18 +964,29 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
     const int grid = min(n_cu, ws.n_tiles);
+    const bool image_kept = tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L);
+    if (image_kept) image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
+    // large batches: the layers' inputs stay out of the operand stream, the weight-gradient launch runs the forward pass again
+    const bool recompute = want_dec && dw_recompute(ws.n_tiles);
     if (phase & 1) {
-        if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
-            image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
-        else
+        if (!image_kept)
             hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
         hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TFW_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                            sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
-                           n_dec, loss_partial, fcol);
+                           n_dec, loss_partial, fcol, recompute ? 0 : 1);
         PIN_CHECK_LAUNCH();
     }
     if (!(phase & 2)) return 0;
-    if (want_dec) {
+    if (want_dec && recompute) {
+        constexpr int dlds = train_dw_recompute_lds_bytes<H>(L);
+        static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_dw_recompute_kernel<H>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, train_dw_recompute_lds_bytes<H>(MLP_MAX_LEVELS));
+        if (dattr != hipSuccess) return fail(-2, "weight-gradient kernel: cannot reserve LDS: %s", hipGetErrorString(dattr));
+        const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
+        hipLaunchKernelGGL((train_dw_recompute_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), L + 1), dim3(DWR_WAVES * 64), dlds, s, ws, L, OD,
+                           n_dec, dw_partial, chunk, image);
+        PIN_CHECK_LAUNCH();
+    } else if (want_dec) {
         const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), L + 1), dim3(DW_WAVES * 64), 0, s, ws, L, OD, n_dec,
                            dw_partial, 0, chunk);

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                                                                   DwStream ws, int want_dec, float dscale,
                                                                   const unsigned char* __restrict__ dec_image,
                                                                   float* __restrict__ dw_partial, int n_dec,
-                                                                  double* __restrict__ loss_partial, FusedColor fcol) {
+                                                                  double* __restrict__ loss_partial, FusedColor fcol, int acts_out) {
+    // acts_out = 0: only the deltas and the decoder input z leave for the weight gradient; train_dw_recompute_kernel
+    // runs the forward pass again from z (large batches: half the operand stream)
     using Q = QuadDecoderH<H>;
     using G = DwGeom<H>;
     constexpr int MT = Q::MT, NJ = Q::NJ;
@@ -259,8 +261,9 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         for (int l = 1; l <= L; ++l) {
             v4u_t ph[NJ], pl[NJ];
             pat[l - 1] = pattern16(h);
-            if (l < L || want_dec) Q::split_acts(h, ph, pl);
-            if (want_dec) stream_acts(ph, pl, l);
+            const bool out = want_dec && acts_out;
+            if (l < L || out) Q::split_acts(h, ph, pl);
+            if (out) stream_acts(ph, pl, l);
             if (l < L) {
                 Q::load_bias(lds, L, l, acc);
                 Q::matmul(lds + Q::off_hidf(L, l), ph, pl, acc);
@@ -1256,6 +1259,195 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
             const int o = 16 * ob + 4 * g + r;
             const float v = val[16 + r];
             if (o < rows && v != 0.f) atomicAdd(gb + o, v);
+        }
+    }
+}
+
+// ---- weight gradient with the forward pass run again (large batches) ----------------------------------------------------
+// At 2^20 samples the operand stream is 7.3 of the 11.9 GB an iteration moves (profiles/r03_pmc_c4.json), and half of it is
+// the layers' INPUTS -- which are a function of the decoder input z (one block per tile) and the weights.  Here the tile
+// kernel streams only z and the deltas; a wave takes z back to the query-in-the-lane layout (the identity-MFMA transpose
+// applied twice is the identity), runs layers 0 .. lam - 1 with the tile kernel's own calls -- same instructions, same
+// bits -- and transposes a_lam into the A operand of dW_lam = delta_{lam+1} (x) a_lam.  The matrix cores and the vector
+// ALU of train_dw_stream_kernel are idle four fifths of the time (it waits for HBM); this spends them instead of bytes.
+// grid (chunks, L + 1 layers), 8 waves: a wave = a phase of the chunk's tiles, ALL output blocks of the layer (64 + 16
+// accumulators); the cross products of a tile are folded into the main accumulators tile by tile.
+constexpr int DWR_WAVES = 8;
+constexpr int DWR_VALS = 80;        // per lane: 4 x 4 blocks x 4 + 4 x 4 bias sums
+constexpr int DWR_RED_VALS = 40;    // reduced through LDS in two halves
+template <int H>
+constexpr int train_dw_recompute_lds_bytes(int L) {
+    return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (DWR_WAVES / 2) * DWR_RED_VALS * 64 * 4;
+}
+template <int H>
+__global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(DwStream ws, int L, int OD, int n_dec,
+                                                                              float* __restrict__ partial, int chunk,
+                                                                              const unsigned char* __restrict__ dec_image) {
+    using Q = QuadDecoderH<H>;
+    using G = DwGeom<H>;
+    constexpr int MT = Q::MT, NJ = Q::NJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dwr_smem[];
+    unsigned char* const lds = dwr_smem;
+    const int IMG = (Q::bytes(L) + 15) & ~15;
+    float (*red)[DWR_RED_VALS][64] = reinterpret_cast<float (*)[DWR_RED_VALS][64]>(lds + IMG);
+    const int lam = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int DB = G::d_blocks(L, lam), AB = G::a_blocks(lam);
+    if (lam >= 1) {  // the forward images of layers 0 .. lam - 1 and the biases, at the offsets the decoder calls expect
+        auto copy = [&](int from, int to) {
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image + from);
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds + from);
+            for (int i = threadIdx.x; i < ((to - from) >> 4); i += DWR_WAVES * 64) dst[i] = src[i];
+        };
+        copy(Q::off_hidf(L, 1), Q::off_hidf(L, lam));
+        copy(Q::off_l0f(L), Q::off_l0b(L));
+        copy(Q::off_bias(L), Q::off_out(L));
+        __syncthreads();
+    }
+    v4h_t ident;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ident[r] = (n == 4 * g + r) ? (_Float16)1.0f : (_Float16)0.0f;
+    const v4h_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    auto as4 = [](uint2 v) { const v2u_t u = {v.x, v.y}; return as_h4(u); };
+    const size_t n_tiles = (size_t)ws.n_tiles;
+    const uint2* __restrict__ D = ws.d + G::d_off(n_tiles, lam) + lane;
+    const uint2* __restrict__ A0 = ws.a + G::a_off(n_tiles, 0) + lane;
+    const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, ws.n_tiles);
+    v4f_t mainv[MT][MT], bmain[MT];
+#pragma unroll
+    for (int ob = 0; ob < MT; ++ob) {
+        bmain[ob] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib) mainv[ob][ib] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+    }
+    uint2 z_h = make_uint2(0u, 0u), z_l = make_uint2(0u, 0u);
+    if (t0 + wave < t1) { z_h = A0[(size_t)(t0 + wave) * 128]; z_l = A0[(size_t)(t0 + wave) * 128 + 64]; }
+    for (int t = t0 + wave; t < t1; t += DWR_WAVES) {
+        uint2 dh[MT], dl[MT];
+#pragma unroll
+        for (int ob = 0; ob < MT; ++ob) {
+            const int bb = ob < DB ? ob : 0;
+            dh[ob] = D[((size_t)t * DB + bb) * 128];
+            dl[ob] = D[((size_t)t * DB + bb) * 128 + 64];
+        }
+        const uint2 zc_h = z_h, zc_l = z_l;
+        if (t + DWR_WAVES < t1) { z_h = A0[(size_t)(t + DWR_WAVES) * 128]; z_l = A0[(size_t)(t + DWR_WAVES) * 128 + 64]; }
+        uint2 ah[MT], al[MT];
+        if (lam == 0) {
+            ah[0] = zc_h; al[0] = zc_l;
+#pragma unroll
+            for (int ib = 1; ib < MT; ++ib) { ah[ib] = zc_h; al[ib] = zc_l; }
+        } else {
+            const uint2 qh = transpose_block(zc_h.x, zc_h.y, ident), ql = transpose_block(zc_l.x, zc_l.y, ident);
+            const v2u_t zh = {qh.x, qh.y}, zl = {ql.x, ql.y};
+            v4f_t h[MT], acc[MT];
+            Q::layer0(lds, L, zh, zl, acc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+            v4u_t ph[NJ], pl[NJ];
+            for (int l = 1; l < lam; ++l) {
+                Q::split_acts(h, ph, pl);
+                Q::load_bias(lds, L, l, acc);
+                Q::matmul(lds + Q::off_hidf(L, l), ph, pl, acc);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+            }
+            Q::split_acts(h, ph, pl);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = transpose_block(ph[mt >> 1][2 * (mt & 1)], ph[mt >> 1][2 * (mt & 1) + 1], ident);
+                al[mt] = transpose_block(pl[mt >> 1][2 * (mt & 1)], pl[mt >> 1][2 * (mt & 1) + 1], ident);
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < MT; ++ob) {
+            if (ob >= DB) continue;
+            const v4h_t d_h = as4(dh[ob]), d_l = as4(dl[ob]);
+            {
+                v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, ones, c, 0, 0, 0);
+                bmain[ob] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, ones, bmain[ob], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bmain[ob][r] = fmaf(c[r], H2_DOWN, bmain[ob][r]);
+            }
+#pragma unroll
+            for (int ib = 0; ib < MT; ++ib) {
+                if (ib >= AB) continue;
+                const v4h_t a_h = as4(ah[ib]), a_l = as4(al[ib]);
+                v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_l, c, 0, 0, 0);
+                mainv[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_h, mainv[ob][ib], 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mainv[ob][ib][r] = fmaf(c[r], H2_DOWN, mainv[ob][ib][r]);
+            }
+        }
+    }
+    // add the eight phases up: two halves of the 80 values through the patch behind the image
+    float val[DWR_VALS];
+#pragma unroll
+    for (int ob = 0; ob < MT; ++ob) {
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[16 * ob + 4 * ib + r] = mainv[ob][ib][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[64 + 4 * ob + r] = bmain[ob][r];
+    }
+#pragma unroll
+    for (int ob = MT; ob < 4; ++ob) {  // (H = 32)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) val[16 * ob + c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[64 + 4 * ob + r] = 0.f;
+    }
+    __syncthreads();  // (the image is not read any more; the patch lies behind it anyway)
+#pragma unroll
+    for (int part = 0; part < DWR_VALS / DWR_RED_VALS; ++part) {
+        for (int half = DWR_WAVES / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int c = 0; c < DWR_RED_VALS; ++c) red[wave - half][c][lane] = val[part * DWR_RED_VALS + c];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int c = 0; c < DWR_RED_VALS; ++c) val[part * DWR_RED_VALS + c] += red[wave][c][lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (wave != 0) return;
+    const int rows = lam < L ? H : OD;
+    const int cols_out = lam == 0 ? MLP_IN : H;
+    size_t off = 0;
+    for (int u = 0; u < lam; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
+    float* __restrict__ gW = partial + (size_t)(blockIdx.x % DW_SLOTS) * n_dec + off;
+    float* __restrict__ gb = gW + (size_t)rows * cols_out;
+#pragma unroll
+    for (int ob = 0; ob < MT; ++ob) {
+        if (ob >= DB) continue;
+#pragma unroll
+        for (int ib = 0; ib < MT; ++ib) {
+            if (ib >= AB) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ob + 4 * g + r, i = 16 * ib + n;
+                const float v = val[16 * ob + 4 * ib + r];
+                if (o < rows && i < cols_out && v != 0.f) atomicAdd(gW + (size_t)o * cols_out + i, v);
+            }
+        }
+        if (n == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ob + 4 * g + r;
+                const float v = val[64 + 4 * ob + r];
+                if (o < rows && v != 0.f) atomicAdd(gb + o, v);
+            }
         }
     }
 }

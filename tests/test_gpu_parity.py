@@ -259,6 +259,38 @@ def test_mapping_two_iterations(gold):
     assert np.array_equal(tsu.cpu().numpy(), d["map_ts_after"])
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_weight_gradient_streamed_and_recomputed(gold, mode, monkeypatch):
+    """The decoder's weight gradient by both launches behind pin_train_step -- train_dw_stream_kernel (the layers' inputs
+    come through the operand stream; small batches) and train_dw_recompute_kernel (only the decoder input and the deltas
+    are streamed, the forward pass runs again; chosen from 8 192 tiles on) -- forced on the fixture's first batch
+    (PIN_DW_RECOMPUTE, read per call) and held against the reference's autograd; the two forms against each other."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    import dataclasses
+    d = gold
+    if not bool(d["weighted_first"]):
+        pytest.skip("per-neighbour decoding keeps the streamed form")
+    k, H, L = int(d["query_nn_k"]), int(d["dec_hidden"]), int(d["dec_levels"])
+    feats, dec = U.dev(d["local_geo_features"]), U.dev(d["dec_flat"])
+    fs = dataclasses.replace(d["fs_loc"], feats=feats, dec=dec, certainty=None)
+    bs = d["map_coord0"].shape[0]
+    buf = ops.TrainBuffers(bs, int(d["map_dec"]), k, H, L, weighted_first=True)
+    out = {}
+    for m in (mode, "1" if mode == "0" else "0"):
+        monkeypatch.setenv("PIN_DW_RECOMPUTE", m)
+        gfeat, gdec = torch.zeros_like(feats), torch.zeros_like(dec)
+        ops.train_step(d["st"], fs, buf, U.dev(d["map_coord0"]), U.dev(d["map_label0"]), U.dev(d["map_w0"]),
+                       U.dev(d["map_ts0"], torch.int32), None, None, gfeat, gdec, sigma=d["sdf_scale"],
+                       weight_e=d["map_weight_e"], eik_eps=d["map_eps"], loss_weight_on=bool(d["map_loss_weight_on"]))
+        out[m] = (gfeat.cpu().numpy(), gdec.cpu().numpy())
+    gf, gd = d["map_gfeat0"], d["map_gdec0"]
+    assert np.max(np.abs(out[mode][0] - gf)) < 1e-4 * np.abs(gf).max()
+    assert np.max(np.abs(out[mode][1] - gd)) < 1e-4 * np.abs(gd).max()
+    # same deltas, same (recomputed = bit-identical) inputs: the two launches differ in the order of their fp32 sums only
+    assert np.max(np.abs(out["0"][1] - out["1"][1])) < 2e-6 * np.abs(gd).max()
+
+
 @pytest.mark.parametrize("tag", ["nwf", "pgo", "wf"])
 def test_analytic_eikonal_mapping(tag):
     """numerical_grad_on False (config/lidar_slam/run_livox.yaml:27): the Eikonal term on the autograd gradient of every
