@@ -982,8 +982,8 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
         static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_dw_recompute_kernel<H>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, train_dw_recompute_lds_bytes<H>(MLP_MAX_LEVELS));
         if (dattr != hipSuccess) return fail(-2, "weight-gradient kernel: cannot reserve LDS: %s", hipGetErrorString(dattr));
-        const int chunk = dw_chunk(ws.n_tiles, L + 1, n_cu);
-        hipLaunchKernelGGL((train_dw_recompute_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), L + 1), dim3(DWR_WAVES * 64), dlds, s, ws, L, OD,
+        const int chunk = dw_chunk(ws.n_tiles, dwr_groups(L), n_cu);
+        hipLaunchKernelGGL((train_dw_recompute_kernel<H>), dim3(cdiv(ws.n_tiles, chunk), dwr_groups(L)), dim3(DWR_WAVES * 64), dlds, s, ws, L, OD,
                            n_dec, dw_partial, chunk, image);
         PIN_CHECK_LAUNCH();
     } else if (want_dec) {

@@ -1273,8 +1273,17 @@ __global__ __launch_bounds__(DW_WAVES * 64) void train_dw_stream_kernel(DwStream
 // grid (chunks, L + 1 layers), 8 waves: a wave = a phase of the chunk's tiles, ALL output blocks of the layer (64 + 16
 // accumulators); the cross products of a tile are folded into the main accumulators tile by tile.
 constexpr int DWR_WAVES = 8;
-constexpr int DWR_VALS = 80;        // per lane: 4 x 4 blocks x 4 + 4 x 4 bias sums
-constexpr int DWR_RED_VALS = 40;    // reduced through LDS in two halves
+constexpr int DWR_VALS = 120;       // per lane: 4 x 4 blocks x 4 + 4 x 4 bias sums of the primary layer, 16 + 16 of the secondary, padding
+constexpr int DWR_RED_VALS = 40;    // reduced through LDS in three parts
+// Layers are handled in GROUPS that share one recomputation: {0, 1} (layer 0 reads z itself), the middle layers singly,
+// {L - 1, L} (the out layer needs one more layer on top of L - 1 and has a single row block): 7 instead of 10 layer passes
+// per tile at L = 4.
+__host__ __device__ inline int dwr_groups(int L) { return L == 1 ? 1 : (L == 2 ? 2 : L - 1); }
+__host__ __device__ inline void dwr_group(int L, int grp, int& pri, int& sec) {
+    if (grp == 0) { pri = 1; sec = 0; return; }
+    const int lam = grp + 1;
+    if (lam == L - 1 && lam >= 2) { pri = lam; sec = L; } else { pri = lam; sec = -1; }
+}
 template <int H>
 constexpr int train_dw_recompute_lds_bytes(int L) {
     return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (DWR_WAVES / 2) * DWR_RED_VALS * 64 * 4;
@@ -1290,16 +1299,18 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
     unsigned char* const lds = dwr_smem;
     const int IMG = (Q::bytes(L) + 15) & ~15;
     float (*red)[DWR_RED_VALS][64] = reinterpret_cast<float (*)[DWR_RED_VALS][64]>(lds + IMG);
-    const int lam = blockIdx.y;
+    int pri, sec;
+    dwr_group(L, (int)blockIdx.y, pri, sec);
+    const int depth = sec > pri ? sec : pri;  // layers to run: a_depth
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const int DB = G::d_blocks(L, lam), AB = G::a_blocks(lam);
-    if (lam >= 1) {  // the forward images of layers 0 .. lam - 1 and the biases, at the offsets the decoder calls expect
+    const int DBp = G::d_blocks(L, pri);      // (the primary layer has MT input blocks: pri >= 1)
+    {   // the forward images of layers 0 .. depth - 1 and the biases, at the offsets the decoder calls expect
         auto copy = [&](int from, int to) {
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image + from);
             uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds + from);
             for (int i = threadIdx.x; i < ((to - from) >> 4); i += DWR_WAVES * 64) dst[i] = src[i];
         };
-        copy(Q::off_hidf(L, 1), Q::off_hidf(L, lam));
+        copy(Q::off_hidf(L, 1), Q::off_hidf(L, depth));
         copy(Q::off_l0f(L), Q::off_l0b(L));
         copy(Q::off_bias(L), Q::off_out(L));
         __syncthreads();
@@ -1309,86 +1320,115 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
     for (int r = 0; r < 4; ++r) ident[r] = (n == 4 * g + r) ? (_Float16)1.0f : (_Float16)0.0f;
     const v4h_t ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     auto as4 = [](uint2 v) { const v2u_t u = {v.x, v.y}; return as_h4(u); };
+    // acc += d (x) a for one pair of blocks: hi * hi into the accumulator, the two cross products folded in tile by tile
+    auto outer = [&](v4f_t& acc, uint2 dh, uint2 dl, v4h_t a_h, v4h_t a_l) {
+        const v4h_t d_h = as4(dh), d_l = as4(dl);
+        v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_l, c, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_h, acc, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaf(c[r], H2_DOWN, acc[r]);
+    };
+    auto rowsum = [&](v4f_t& acc, uint2 dh, uint2 dl) {  // bias gradient: the product with a block of ones
+        v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(as4(dl), ones, c, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(as4(dh), ones, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaf(c[r], H2_DOWN, acc[r]);
+    };
     const size_t n_tiles = (size_t)ws.n_tiles;
-    const uint2* __restrict__ D = ws.d + G::d_off(n_tiles, lam) + lane;
+    const uint2* __restrict__ Dp = ws.d + G::d_off(n_tiles, pri) + lane;
+    const uint2* __restrict__ Ds = ws.d + G::d_off(n_tiles, sec < 0 ? 0 : sec) + lane;
     const uint2* __restrict__ A0 = ws.a + G::a_off(n_tiles, 0) + lane;
     const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, ws.n_tiles);
-    v4f_t mainv[MT][MT], bmain[MT];
+    v4f_t mainv[MT][MT], bmain[MT], secv[MT], sbias[MT];
 #pragma unroll
     for (int ob = 0; ob < MT; ++ob) {
-        bmain[ob] = (v4f_t){0.f, 0.f, 0.f, 0.f};
+        bmain[ob] = secv[ob] = sbias[ob] = (v4f_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ib = 0; ib < MT; ++ib) mainv[ob][ib] = (v4f_t){0.f, 0.f, 0.f, 0.f};
     }
     uint2 z_h = make_uint2(0u, 0u), z_l = make_uint2(0u, 0u);
     if (t0 + wave < t1) { z_h = A0[(size_t)(t0 + wave) * 128]; z_l = A0[(size_t)(t0 + wave) * 128 + 64]; }
     for (int t = t0 + wave; t < t1; t += DWR_WAVES) {
-        uint2 dh[MT], dl[MT];
+        uint2 dh[MT], dl[MT], sh[MT], sl[MT];
 #pragma unroll
         for (int ob = 0; ob < MT; ++ob) {
-            const int bb = ob < DB ? ob : 0;
-            dh[ob] = D[((size_t)t * DB + bb) * 128];
-            dl[ob] = D[((size_t)t * DB + bb) * 128 + 64];
+            const int bb = ob < DBp ? ob : 0;
+            dh[ob] = Dp[((size_t)t * DBp + bb) * 128];
+            dl[ob] = Dp[((size_t)t * DBp + bb) * 128 + 64];
+            sh[ob] = sl[ob] = make_uint2(0u, 0u);
+        }
+        if (sec == 0) {  // delta_1: MT blocks
+#pragma unroll
+            for (int ob = 0; ob < MT; ++ob) { sh[ob] = Ds[((size_t)t * MT + ob) * 128]; sl[ob] = Ds[((size_t)t * MT + ob) * 128 + 64]; }
+        } else if (sec > 0) {  // d loss / d heads: one block
+            sh[0] = Ds[(size_t)t * 128]; sl[0] = Ds[(size_t)t * 128 + 64];
         }
         const uint2 zc_h = z_h, zc_l = z_l;
         if (t + DWR_WAVES < t1) { z_h = A0[(size_t)(t + DWR_WAVES) * 128]; z_l = A0[(size_t)(t + DWR_WAVES) * 128 + 64]; }
-        uint2 ah[MT], al[MT];
-        if (lam == 0) {
-            ah[0] = zc_h; al[0] = zc_l;
+        if (sec == 0) {  // layer 0: its input is z as streamed
+            const v4h_t a_h = as4(zc_h), a_l = as4(zc_l);
 #pragma unroll
-            for (int ib = 1; ib < MT; ++ib) { ah[ib] = zc_h; al[ib] = zc_l; }
-        } else {
-            const uint2 qh = transpose_block(zc_h.x, zc_h.y, ident), ql = transpose_block(zc_l.x, zc_l.y, ident);
-            const v2u_t zh = {qh.x, qh.y}, zl = {ql.x, ql.y};
-            v4f_t h[MT], acc[MT];
-            Q::layer0(lds, L, zh, zl, acc);
+            for (int ob = 0; ob < MT; ++ob) { outer(secv[ob], sh[ob], sl[ob], a_h, a_l); rowsum(sbias[ob], sh[ob], sl[ob]); }
+        }
+        // z back in the query-in-the-lane layout, then the tile kernel's forward pass
+        const uint2 qh = transpose_block(zc_h.x, zc_h.y, ident), ql = transpose_block(zc_l.x, zc_l.y, ident);
+        const v2u_t zh = {qh.x, qh.y}, zl = {ql.x, ql.y};
+        v4f_t h[MT], acc[MT];
+        Q::layer0(lds, L, zh, zl, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+        v4u_t ph[NJ], pl[NJ];
+        for (int l = 1; l < pri; ++l) {
+            Q::split_acts(h, ph, pl);
+            Q::load_bias(lds, L, l, acc);
+            Q::matmul(lds + Q::off_hidf(L, l), ph, pl, acc);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
-            v4u_t ph[NJ], pl[NJ];
-            for (int l = 1; l < lam; ++l) {
-                Q::split_acts(h, ph, pl);
-                Q::load_bias(lds, L, l, acc);
-                Q::matmul(lds + Q::off_hidf(L, l), ph, pl, acc);
+        }
+        Q::split_acts(h, ph, pl);  // a_pri
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+        for (int ib = 0; ib < MT; ++ib) {
+            const v4h_t a_h = as4(transpose_block(ph[ib >> 1][2 * (ib & 1)], ph[ib >> 1][2 * (ib & 1) + 1], ident));
+            const v4h_t a_l = as4(transpose_block(pl[ib >> 1][2 * (ib & 1)], pl[ib >> 1][2 * (ib & 1) + 1], ident));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
-            }
-            Q::split_acts(h, ph, pl);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                ah[mt] = transpose_block(ph[mt >> 1][2 * (mt & 1)], ph[mt >> 1][2 * (mt & 1) + 1], ident);
-                al[mt] = transpose_block(pl[mt >> 1][2 * (mt & 1)], pl[mt >> 1][2 * (mt & 1) + 1], ident);
+            for (int ob = 0; ob < MT; ++ob) {
+                if (ob >= DBp) continue;
+                outer(mainv[ob][ib], dh[ob], dl[ob], a_h, a_l);
             }
         }
 #pragma unroll
         for (int ob = 0; ob < MT; ++ob) {
-            if (ob >= DB) continue;
-            const v4h_t d_h = as4(dh[ob]), d_l = as4(dl[ob]);
-            {
-                v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, ones, c, 0, 0, 0);
-                bmain[ob] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, ones, bmain[ob], 0, 0, 0);
+            if (ob >= DBp) continue;
+            rowsum(bmain[ob], dh[ob], dl[ob]);
+        }
+        if (sec > pri) {  // the out layer: one more layer on top, a single block of rows
+            Q::load_bias(lds, L, pri, acc);
+            Q::matmul(lds + Q::off_hidf(L, pri), ph, pl, acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bmain[ob][r] = fmaf(c[r], H2_DOWN, bmain[ob][r]);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+            Q::split_acts(h, ph, pl);
 #pragma unroll
             for (int ib = 0; ib < MT; ++ib) {
-                if (ib >= AB) continue;
-                const v4h_t a_h = as4(ah[ib]), a_l = as4(al[ib]);
-                v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_l, c, 0, 0, 0);
-                mainv[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_h, mainv[ob][ib], 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, c, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mainv[ob][ib][r] = fmaf(c[r], H2_DOWN, mainv[ob][ib][r]);
+                const v4h_t a_h = as4(transpose_block(ph[ib >> 1][2 * (ib & 1)], ph[ib >> 1][2 * (ib & 1) + 1], ident));
+                const v4h_t a_l = as4(transpose_block(pl[ib >> 1][2 * (ib & 1)], pl[ib >> 1][2 * (ib & 1) + 1], ident));
+                outer(secv[ib], sh[0], sl[0], a_h, a_l);
             }
+            rowsum(sbias[0], sh[0], sl[0]);
         }
     }
-    // add the eight phases up: two halves of the 80 values through the patch behind the image
+    // add the eight phases up: three parts of the values through the patch behind the image
     float val[DWR_VALS];
+#pragma unroll
+    for (int c = 0; c < DWR_VALS; ++c) val[c] = 0.f;
 #pragma unroll
     for (int ob = 0; ob < MT; ++ob) {
 #pragma unroll
@@ -1396,18 +1436,12 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
 #pragma unroll
             for (int r = 0; r < 4; ++r) val[16 * ob + 4 * ib + r] = mainv[ob][ib][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) val[64 + 4 * ob + r] = bmain[ob][r];
+        for (int r = 0; r < 4; ++r) { val[64 + 4 * ob + r] = bmain[ob][r]; val[80 + 4 * ob + r] = secv[ob][r]; val[96 + 4 * ob + r] = sbias[ob][r]; }
     }
-#pragma unroll
-    for (int ob = MT; ob < 4; ++ob) {  // (H = 32)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) val[16 * ob + c] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) val[64 + 4 * ob + r] = 0.f;
-    }
-    __syncthreads();  // (the image is not read any more; the patch lies behind it anyway)
+    __syncthreads();
 #pragma unroll
     for (int part = 0; part < DWR_VALS / DWR_RED_VALS; ++part) {
+        if (part == 2 && sec < 0) break;  // (uniform: no secondary layer in this block)
         for (int half = DWR_WAVES / 2; half >= 1; half >>= 1) {
             if (wave >= half && wave < 2 * half) {
 #pragma unroll
@@ -1422,31 +1456,32 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
         }
     }
     if (wave != 0) return;
-    const int rows = lam < L ? H : OD;
-    const int cols_out = lam == 0 ? MLP_IN : H;
-    size_t off = 0;
-    for (int u = 0; u < lam; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
-    float* __restrict__ gW = partial + (size_t)(blockIdx.x % DW_SLOTS) * n_dec + off;
-    float* __restrict__ gb = gW + (size_t)rows * cols_out;
+    float* __restrict__ slot = partial + (size_t)(blockIdx.x % DW_SLOTS) * n_dec;
+    // D layout: element [o = 4 g + r][i = n] of block (ob, ib) of layer lam.  state_dict order: W0 [H][11], b0, (W [H][H], b)*, lout
+    auto emit = [&](int lam, int ob, int ib, int r, float v, bool bias) {
+        const int rows = lam < L ? H : OD, cols = lam == 0 ? MLP_IN : H;
+        size_t off = 0;
+        for (int u = 0; u < lam; ++u) off += (size_t)H * (u == 0 ? MLP_IN : H) + H;
+        const int o = 16 * ob + 4 * g + r, i = 16 * ib + n;
+        if (v == 0.f || o >= rows) return;
+        if (bias) { if (n == 0) atomicAdd(slot + off + (size_t)rows * cols + o, v); }
+        else if (i < cols) atomicAdd(slot + off + (size_t)o * cols + i, v);
+    };
 #pragma unroll
     for (int ob = 0; ob < MT; ++ob) {
-        if (ob >= DB) continue;
 #pragma unroll
-        for (int ib = 0; ib < MT; ++ib) {
-            if (ib >= AB) continue;
+        for (int r = 0; r < 4; ++r) {
+            if (ob < DBp) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ob + 4 * g + r, i = 16 * ib + n;
-                const float v = val[16 * ob + 4 * ib + r];
-                if (o < rows && i < cols_out && v != 0.f) atomicAdd(gW + (size_t)o * cols_out + i, v);
+                for (int ib = 0; ib < MT; ++ib) emit(pri, ob, ib, r, val[16 * ob + 4 * ib + r], false);
+                emit(pri, ob, 0, r, val[64 + 4 * ob + r], true);
             }
-        }
-        if (n == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ob + 4 * g + r;
-                const float v = val[64 + 4 * ob + r];
-                if (o < rows && v != 0.f) atomicAdd(gb + o, v);
+            if (sec == 0) {
+                emit(0, ob, 0, r, val[80 + 4 * ob + r], false);
+                emit(0, ob, 0, r, val[96 + 4 * ob + r], true);
+            } else if (sec > 0) {
+                emit(sec, 0, ob, r, val[80 + 4 * ob + r], false);   // (secv is indexed by the INPUT block there)
+                if (ob == 0) emit(sec, 0, 0, r, val[96 + r], true);
             }
         }
     }
