@@ -686,7 +686,7 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
     dec_n = max(1, int(cfg.gradient_decimation))
     bytes_s = (1.0 + 6.0 / dec_n) * (12 + 4 * Kc + 16 * rho * Kc + 36 * k + 64 * k) + 12
     alg = bytes_s * args.global_bs
-    r = {"kernel": "train_fused_kernel + train_dw_stream_kernel + knn_brick_kernel + lazy Adam (one Mapper.mapping iteration, 2^20 samples)",
+    r = {"kernel": "train_fused_kernel + train_dw_recompute_kernel + knn_brick_kernel + lazy Adam (one Mapper.mapping iteration, 2^20 samples)",
          "bound": "hbm", "achieved": round(alg / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(alg / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round(bytes_s, 1),
          "traffic": None}
@@ -695,17 +695,18 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
         try:
             ks = json.load(open(path))["kernels"]
             per = {"train_fused": ks["train_fused"]["hbm_bytes_per_launch"],
-                   "train_dw_stream": ks["train_dw_stream"]["hbm_bytes_per_launch_if_streaming_x2"],
+                   "train_dw": ks["train_dw_recompute" if "train_dw_recompute" in ks else "train_dw_stream"]["hbm_bytes_per_launch_if_streaming_x2"],
                    "knn_brick": int(ks["knn_brick"]["hbm_bytes_per_launch"] / max(1, group)),
                    "lazy_adam": ks["mark_rows"]["hbm_bytes_per_launch"] + ks["adam_lazy_prepare_rows"]["hbm_bytes_per_launch"]}
             r["traffic"] = int(sum(per.values()))
             r["traffic_per_kernel"] = per
             r["traffic_source"] = "profiles/r03_pmc_c4.json"
             r["traffic_over_algorithmic"] = round(r["traffic"] / alg, 2)
-            r["kernel_us"] = {kk: ks[kk]["duration_us"] for kk in ("train_fused", "train_dw_stream", "knn_brick", "mark_rows",
-                                                                  "adam_lazy_prepare_rows")}
-            r["note"] = ("the operand stream of the weight gradient (2.2 KB per query, written by the tile kernel and read back by the "
-                         "next launch) is most of the distance between traffic and algorithmic bytes; the search kernel's launch covers "
+            r["kernel_us"] = {kk: ks[kk]["duration_us"] for kk in ("train_fused", "train_dw_recompute", "train_dw_stream", "knn_brick",
+                                                                  "mark_rows", "adam_lazy_prepare_rows") if kk in ks}
+            r["note"] = ("the operand stream of the weight gradient (deltas + decoder input, 1.15 KB per query, written by the tile kernel and "
+                         "read back by the next launch; r03a streamed the layers' inputs as well, 2.2 KB) and the read-modify-write of the "
+                         "gradient rows are the distance between traffic and algorithmic bytes; the search kernel's launch covers "
                          f"{group} iterations and is divided accordingly")
         except Exception:
             pass
