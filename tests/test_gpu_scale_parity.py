@@ -259,6 +259,33 @@ def test_scale_training_step_vs_oracle(big):
         assert np.max(np.abs(g["gcdec"] - rc["dec_grad"])) < 1e-4 * np.abs(rc["dec_grad"]).max()
 
 
+def test_scale_analytic_eikonal_step_vs_oracle(big):
+    """numerical_grad_on False at the bench scale: one iteration of 2048 samples with the Eikonal term on the autograd
+    gradient of every sample -- train_fused_an_kernel (weighted-first, the workload's decoder depth) or
+    train_fused_nwf_kernel<AN> (per-neighbour, one layer) -- against the oracle's double backward (float64)."""
+    import dataclasses
+    from pin_slam_amd import ops, synth
+    from tests import gpu_util as U
+    b, w = big, big["w"]
+    if not w["wf"] and b["L"] != 1:
+        pytest.skip("per-neighbour decoding has the analytic term for one-layer decoders")
+    bs = 2048
+    coord, label = synth.make_pool(b["m"], n=bs, seed=9, sigma=w["pool_sigma"])
+    gfeat, gdec = torch.zeros_like(b["fs"].feats), torch.zeros_like(b["fs"].dec)
+    fs = dataclasses.replace(b["fs"], certainty=None)
+    buf = ops.TrainBuffers(bs, 1, b["k"], b["H"], b["L"], eikonal="analytic", weighted_first=w["wf"])
+    loss = ops.train_step(b["st"], fs, buf, U.dev(coord), U.dev(label), torch.ones(bs, device="cuda"),
+                          torch.zeros(bs, dtype=torch.int32, device="cuda"), None, None, gfeat, gdec, sigma=w["sdf_scale"],
+                          weight_e=w["weight_e"], eik_eps=b["eps"], bricks=b["bricks"])
+    r = _oracle_train(b, coord, label, 1, analytic=True)
+    assert r["eik_loss"] > 1e-3
+    assert np.max(np.abs(gfeat.cpu().numpy() - r["feat_grad"])) < 1e-4 * np.abs(r["feat_grad"]).max()
+    assert np.max(np.abs(gdec.cpu().numpy() - r["dec_grad"])) < 1e-4 * np.abs(r["dec_grad"]).max()
+    l_bce, l_eik = (loss.cpu().numpy() / bs).tolist()
+    assert abs(l_bce - r["sdf_loss"]) < 1e-5 * abs(r["sdf_loss"])
+    assert abs(l_eik - r["eik_loss"]) < 1e-4 * abs(r["eik_loss"])
+
+
 def test_c4_batch_is_the_sum_of_its_parts(big):
     """Config C4's shape -- a 2^17-sample shard (one rank's share of the 2^20 batch over 8 GPUs) in ONE launch -- through a
     size-independent property: the gradient of a batch is the sum of the gradients of its parts when every part is
