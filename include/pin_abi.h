@@ -450,6 +450,17 @@ int pin_gather_batches_drawn(const float* pool_coord, const float* pool_label, c
                              int32_t n_eik, int32_t decimation, int32_t first, float eps, int32_t n_batches,
                              int64_t hist_stride, int64_t new_stride, void* stream);
 
+/* Neighbour records of the drawn samples out of records computed ONCE for every pool sample (pin_knn_query over the pool's
+ * coordinates, pool_nbr [pool_n][k][4], pool_nn [pool_n]): the neural points do not move while the map trains
+ * (utils/mapper.py:645-818 only updates features and decoder), so when the iterations of a Mapper.mapping call draw more
+ * samples than the pool holds (batch 2^20: every pool sample ~6 times per call) the search of a sample is done once per
+ * call and copied.  Batch b, sample i -> rows (b * q_per_batch + i) of nbr_out [.][k][4] / nn_out; the six Eikonal probes
+ * of a sample are searched as before (they are not pool samples).  Index arrays as in pin_gather_batches_drawn. */
+int pin_gather_records_drawn(const float* pool_nbr, const int32_t* pool_nn, int32_t k, const int64_t* index_history,
+                             int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
+                             int64_t q_per_batch, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
+                             float* nbr_out, int32_t* nn_out, void* stream);
+
 /* K6a: query points of one training iteration: the batch itself followed by the six
  * central-difference points of every `decimation`-th sample (Mapper.get_numerical_gradient,
  * utils/mapper.py:682-686, 986-1008), grouped per sample: index n_main + 6*s + a with

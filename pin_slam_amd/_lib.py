@@ -184,6 +184,7 @@ SIGNATURES = {
                                      f32, vp]),
     "pin_gather_batches_drawn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                        f32, i32, i64, i64, vp]),
+    "pin_gather_records_drawn": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, i64, i32, i64, i64, vp, vp, vp]),
     "pin_train_make_queries": (i32, [vp, i32, i32, i32, i32, f32, vp, vp]),
     "pin_train_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),

@@ -914,6 +914,41 @@ extern "C" int pin_gather_batches_drawn(const float* pool_coord, const float* po
                           decimation, first, eps, n_batches, hist_stride, new_stride, stream);
 }
 
+// (pin_gather_records_drawn) one thread per (batch, sample, neighbour): 16-byte records, k of them contiguous per sample
+__global__ __launch_bounds__(256) void gather_records_kernel(const float4* __restrict__ pool_nbr, const int* __restrict__ pool_nn,
+                                                             int k, const long long* __restrict__ index_hist, int n_hist,
+                                                             const long long* __restrict__ index_new_batch,
+                                                             const long long* __restrict__ new_idx, int n, long q_per_batch,
+                                                             long hist_stride, long new_stride, float4* __restrict__ nbr_out,
+                                                             int* __restrict__ nn_out) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = (int)(tid % k);
+    const long i = tid / k;
+    if (i >= n) return;
+    const size_t b = blockIdx.y;
+    const size_t s = (size_t)(i < n_hist ? index_hist[b * hist_stride + i] : new_idx[index_new_batch[b * new_stride + (i - n_hist)]]);
+    const size_t o = b * (size_t)q_per_batch + (size_t)i;
+    nbr_out[o * k + t] = pool_nbr[s * k + t];
+    if (t == 0) nn_out[o] = pool_nn[s];
+}
+
+extern "C" int pin_gather_records_drawn(const float* pool_nbr, const int32_t* pool_nn, int32_t k, const int64_t* index_history,
+                                        int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
+                                        int64_t q_per_batch, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
+                                        float* nbr_out, int32_t* nn_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && n_batches >= 1 && k >= 1 && k <= PIN_MAX_K && q_per_batch >= n, "bad sizes");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(pool_nbr && pool_nn && index_history && nbr_out && nn_out, "NULL pointer");
+    PIN_CHECK_ARG(n_history >= 0 && n_history <= n && (n_history == n || (index_new_batch && new_idx)), "index arrays");
+    hipLaunchKernelGGL(gather_records_kernel, dim3(cdiv((long)n * k, 256), n_batches), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(pool_nbr), pool_nn, k, reinterpret_cast<const long long*>(index_history), n_history,
+                       reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), n,
+                       (long)q_per_batch, (long)hist_stride, (long)new_stride, reinterpret_cast<float4*>(nbr_out), nn_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_train_make_queries(const float* coord, int32_t n_main, int32_t n_eik, int32_t decimation,
                                       int32_t first, float eps, float* query_out, void* stream) {
     PIN_ENTER();

@@ -357,6 +357,41 @@ class Mapper(_Base):
             gn, n_hist, 0 if new is None else new.shape[1], ops._stream()), "pin_gather_batches_drawn")
         return coord, label, weight, ts, color
 
+    def _pool_records(self, t, iters):
+        """Neighbour records of every pool sample, once per Mapper.mapping call, when the call draws at least
+        `reuse_pool_records_ratio` x the pool (a 2^20 batch: every pool sample ~6 times per call): the neural points do not
+        move while the map trains, so the records of a drawn sample are copied (pin_gather_records_drawn) and only its Eikonal
+        probes are searched per iteration.  self.reuse_pool_records: None = by the ratio, True / False = forced."""
+        c, n = self.config, self.pool_sample_count
+        want = getattr(self, "reuse_pool_records", None)
+        if want is None:
+            want = iters * c.bs >= getattr(self, "reuse_pool_records_ratio", 2.0) * n
+        if not want or n <= 0 or self.ba_done_flag:
+            return None
+        p, k, dev = self._pool(), t.fs.k, self.device
+        cap = p.cap
+        rec = getattr(self, "_pool_rec", None)
+        if rec is None or rec[0].shape[0] < cap or rec[0].shape[1] != k:
+            rec = self._pool_rec = (torch.empty((cap, k, 4), dtype=torch.float32, device=dev),
+                                    torch.empty((cap,), dtype=torch.int32, device=dev))
+        ops.knn_query(t.st, p.bufs[0]["global_coord"][:n], k, out=(rec[0][:n], rec[1][:n], None), bricks=t.bricks)
+        return rec
+
+    def _records_group(self, t, it0, gn, rec):
+        """knn_group from the pool's records: the samples' records copied, the probes of every iteration searched."""
+        c, drawn, buf = self.config, self._drawn, t.buf
+        hist, new = drawn["hist"], drawn["new"]
+        n_hist, k = hist.shape[1], t.fs.k
+        _lib.check(_lib.lib().pin_gather_records_drawn(
+            rec[0].data_ptr(), rec[1].data_ptr(), k, hist.data_ptr() + 8 * it0 * n_hist, n_hist,
+            None if new is None else new.data_ptr() + 8 * it0 * new.shape[1], None if new is None else self.new_idx.data_ptr(),
+            c.bs, buf.Q, gn, n_hist, 0 if new is None else new.shape[1], buf.nbr_all.data_ptr(), buf.nn_all.data_ptr(),
+            ops._stream()), "pin_gather_records_drawn")
+        if buf.Q > buf.n_main:
+            for j in range(gn):
+                a, b = j * buf.Q + buf.n_main, (j + 1) * buf.Q
+                ops.knn_query(t.st, buf.query_all[a:b], k, out=(buf.nbr_all[a:b], buf.nn_all[a:b], None), bricks=t.bricks)
+
     def _draw_all(self, iters):
         """The batch indices of `iters` get_batch calls in two torch.randint launches instead of 2 x iters (the
         reference draws per iteration, mapper.py:462-480; the draws are iid uniform either way)."""
@@ -441,10 +476,14 @@ class Mapper(_Base):
                 # one GPU: the batches were all drawn above and the neural points do not move while the map trains, so one
                 # gather launch and one kNN launch serve a whole group of iterations (TrainBuffers.group)
                 G = t.buf.group
+                reuse = self._pool_records(t, iter_count)  # large batches: one search per POOL sample and call
                 for it0 in range(0, iter_count, G):
                     gn = min(G, iter_count - it0)
                     outs = self._gather_group(t, it0, gn, global_coord=not self.ba_done_flag)
-                    t.knn_group(gn)
+                    if reuse is None:
+                        t.knn_group(gn)
+                    else:
+                        self._records_group(t, it0, gn, reuse)
                     for j in range(gn):
                         coord, sdf_label, weight, ts, color_label = (None if o is None else o[j] for o in outs)
                         if t.fc is not None and color_label is None:

@@ -294,6 +294,52 @@ def test_mapper_with_analytic_eikonal_term():
     cfg.weighted_first = False
 
 
+def test_pool_records_reused_across_a_mapping_call():
+    """Mapper.mapping with more draws than pool samples (the C4 shape in small): the neighbour records of the drawn samples
+    are copied out of ONE search over the pool (pin_gather_records_drawn) and only the Eikonal probes are searched per
+    iteration -- the group buffers must hold, bit for bit, what the search over the group's queries gives."""
+    from pin_slam_amd import synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    torch.manual_seed(0)
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=8192, local_map_radius=40.0, local_map_travel_dist_ratio=5.0)
+    rng = np.random.default_rng(0)
+    pts, _ = synth.disc_points(rng, 60_000, 20.0, 2)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.zeros(1, device="cuda")
+    npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+    dec = Decoder(cfg, 64, 1, 1)
+    mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
+    base, _ = synth.disc_points(rng, 20_000, 19.0, 2)
+    dd = 0.15 * rng.standard_normal(len(base))
+    mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * np.array([0.0, 0.0, 1.0])).astype(np.float32)).cuda()
+    mp.coord_pool = mp.global_coord_pool
+    mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+    mp.weight_pool = torch.ones(len(base), device="cuda")
+    mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+    mp.pool_sample_count = len(base)
+    checked = []
+    orig = mp._records_group
+
+    def checking(t, it0, gn, rec):
+        orig(t, it0, gn, rec)
+        n = gn * t.buf.Q
+        got_nbr, got_nn = t.buf.nbr_all[:n].clone(), t.buf.nn_all[:n].clone()
+        t.knn_group(gn)  # the plain search over the same queries
+        assert torch.equal(got_nn, t.buf.nn_all[:n])
+        assert torch.equal(got_nbr.view(torch.int32), t.buf.nbr_all[:n].view(torch.int32))
+        checked.append(gn)
+
+    mp._records_group = checking
+    mp.mapping(6)  # 6 x 8192 draws from 20 000 pool samples: above the ratio, the reuse path runs by itself
+    assert sum(checked) == 6
+    mp.reuse_pool_records = False
+    checked.clear()
+    mp.mapping(2)
+    assert not checked
+
+
 def test_mini_slam_loop_with_colour():
     """colour_on through the drop-in classes: Mapper.mapping trains the colour field next to the
     SDF (mapper.py:668-671, 802-812), Tracker.query_source_points returns colour + per-channel
