@@ -666,17 +666,21 @@ def c4_single_gpu(args, cfg, mp, nn_mean=None, Kc=81, k=8):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         group = int(getattr(getattr(mp._trainer, "buf", None), "group", 1) or 1)
+        want = getattr(mp, "reuse_pool_records", None)
+        reused = bool(want) if want is not None else (args.c4_iters * args.global_bs >= getattr(mp, "reuse_pool_records_ratio", 2.0) * mp.pool_sample_count)
     finally:
         cfg.bs = bs0
         mp._trainer = None  # drop the 2^20-sample workspace
     it = reps * args.c4_iters
     out = {"global_batch": args.global_bs, "iterations_timed": it, "ms_per_iteration": round(1e3 * dt / it, 4),
            "mapper_samples_per_sec": round(args.global_bs * it / dt, 1), "optimizer": "lazy exact Adam (single GPU)"}
-    out["roofline_train"] = roofline_train(args, cfg, out["ms_per_iteration"], nn_mean, Kc, k, group)
+    out["pool_records_reused"] = reused
+    out["roofline_train"] = roofline_train(args, cfg, out["ms_per_iteration"], nn_mean, Kc, k, group,
+                                           reuse_pool_n=int(mp.pool_sample_count) if reused else None)
     return out
 
 
-def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
+def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group, reuse_pool_n=None):
     """The mapper iteration at the C4 batch against the HBM roofline: SURVEY 8(d)'s algorithmic bytes per sample (without the
     Adam term: the lazy optimiser's traffic is in the counters, not in the formula) x the batch, over the measured iteration;
     `traffic` = HBM-side bytes of the iteration's kernels from the PMC passes of this command (scripts/pmc_bench.sh c4 ->
@@ -686,6 +690,13 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
     dec_n = max(1, int(cfg.gradient_decimation))
     bytes_s = (1.0 + 6.0 / dec_n) * (12 + 4 * Kc + 16 * rho * Kc + 36 * k + 64 * k) + 12
     alg = bytes_s * args.global_bs
+    n_eik = (args.global_bs + dec_n - 1) // dec_n
+    if reuse_pool_n:  # Mapper._pool_records: the samples' records are copied, the probes and (once per call) the pool searched
+        knn_queries = 6 * n_eik + reuse_pool_n / max(1, args.c4_iters)
+        knn_note = f"6 x {n_eik} probes per iteration + one search over the {reuse_pool_n} pool samples per call of {args.c4_iters} iterations"
+    else:
+        knn_queries = args.global_bs + 6 * n_eik
+        knn_note = "every sample and probe, every iteration"
     r = {"kernel": "train_fused_kernel + train_dw_recompute_kernel + knn_brick_kernel + lazy Adam (one Mapper.mapping iteration, 2^20 samples)",
          "bound": "hbm", "achieved": round(alg / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(alg / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round(bytes_s, 1),
@@ -696,8 +707,11 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
             ks = json.load(open(path))["kernels"]
             per = {"train_fused": ks["train_fused"]["hbm_bytes_per_launch"],
                    "train_dw": ks["train_dw_recompute" if "train_dw_recompute" in ks else "train_dw_stream"]["hbm_bytes_per_launch_if_streaming_x2"],
-                   "knn_brick": int(ks["knn_brick"]["hbm_bytes_per_launch"] / max(1, group)),
+                   # the search kernel's bytes per QUERY (8 lanes per query) x the queries an iteration pays for
+                   "knn_brick": int(ks["knn_brick"]["hbm_bytes_per_launch"] / (int(ks["knn_brick"]["launch_shape_grid"]) / 8.0) * knn_queries),
                    "lazy_adam": ks["mark_rows"]["hbm_bytes_per_launch"] + ks["adam_lazy_prepare_rows"]["hbm_bytes_per_launch"]}
+            if reuse_pool_n:  # the copy of the samples' records (pin_gather_records_drawn) has no counter pass of its own: read + write
+                per["gather_records_computed"] = int(2 * args.global_bs * k * 16)
             r["traffic"] = int(sum(per.values()))
             r["traffic_per_kernel"] = per
             r["traffic_source"] = "profiles/r03_pmc_c4.json"
@@ -706,8 +720,8 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group):
                                                                   "mark_rows", "adam_lazy_prepare_rows") if kk in ks}
             r["note"] = ("the operand stream of the weight gradient (deltas + decoder input, 1.15 KB per query, written by the tile kernel and "
                          "read back by the next launch; r03a streamed the layers' inputs as well, 2.2 KB) and the read-modify-write of the "
-                         "gradient rows are the distance between traffic and algorithmic bytes; the search kernel's launch covers "
-                         f"{group} iterations and is divided accordingly")
+                         "gradient rows are the distance between traffic and algorithmic bytes; the search kernel is counted per query "
+                         f"({knn_note})")
         except Exception:
             pass
     return r
