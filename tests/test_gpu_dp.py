@@ -64,7 +64,8 @@ def test_two_ranks_reproduce_the_reference(tmp_path, case):
 
 
 @pytest.mark.parametrize("case,world,mode", [("c2_wf", 2, "spatial"), ("c3_bigtable", 2, "spatial"), ("c2_wf", 3, "spatial"),
-                                             ("c2_wf", 2, "spatial-skew"), ("c2_wf", 3, "spatial-reduce")])
+                                             ("c2_wf", 2, "spatial-skew"), ("c2_wf", 3, "spatial-reduce"),
+                                             ("c2_wf", 8, "spatial")])  # (8: the world of BASELINE config 4, three k-d levels)
 def test_spatial_shards_reproduce_the_reference(tmp_path, case, world, mode):
     """The spatially sharded mapper (pin_slam_amd.dp): ranks that share cuda:0 cut the fixture's two batches by k-d boxes,
     train their samples (lazy Adam on the rows they own), all-reduce [decoder | halo rows] per iteration (host-staged gloo,
