@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 11
+#define PIN_ABI_VERSION 12
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -290,6 +290,9 @@ typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapp
     float surface_range;     /* surface_sample_range_m: samples with |sdf_label| below it carry colour */
     float weight_i;          /* config.weight_i */
     int32_t dec_image_current;/* as in pin_train_params, for the colour field's dec_image */
+    int32_t n_main_global;   /* with surface_count: size of the GLOBAL batch this call is a shard of (0 = n_main); it bounds the
+                              * loss gradients from below (every global sample on the surface), which picks the power-of-two
+                              * scale of the fp16 backward sweep */
     const int32_t* surface_count; /* DEVICE, may be NULL: the number of surface samples of the GLOBAL batch when this call
                               * evaluates a shard of it (the colour loss is a mean over them, utils/loss.py:31-42);
                               * NULL = count the samples of this call */
@@ -764,6 +767,19 @@ int pin_dp_kd_boxes(const int32_t* cells_host, int32_t n, int32_t world, int32_t
  * (v >> 16 and v & 0xffff, both exact in fp32), rank 0 sends them and the others send zeros through pin_allreduce_f32;
  * this decodes halves [world][6][2] into boxes_out [world][6] on the device. */
 int pin_dp_boxes_decode(const float* halves, int32_t world, int32_t* boxes_out, void* stream);
+
+/* Replica-consistency check of a spatially sharded call (no counterpart in the reference, which trains on one GPU:
+ * pin_slam.py:8).  Only the boxes are agreed through an exchange; halo list, owner lists and the partition are derived by every
+ * rank from ITS copy of the map and the pool, and pin_dp_rows_unpack / the all-gather counts index those local lists with remote
+ * payloads -- replicas that differ in one bit would corrupt the map silently.  sig_out [2 * (world + 4 + n_counts)] fp32:
+ * every 32-bit word as its two 16-bit halves (exact in fp32, and their SUM over <= 64 ranks is exact): word 0 = *n_halo_dev,
+ * words 1 .. world + 1 = offsets[0 .. world] of pin_dp_owner_lists, word world + 2 = checksum of halo_rows[0 .. *n_halo_dev),
+ * word world + 3 = checksum of the low words of first_batch[0 .. n_first) (the drawn indices of the first iteration), then
+ * counts[0 .. n_counts) (this rank's per-iteration sample counts of pin_dp_partition).  The caller all-reduces the buffer:
+ * the first world + 4 words must come back as world x its own on every rank, the counts must add up to the batch. */
+int pin_dp_signature(const int32_t* halo_rows, const int32_t* n_halo_dev, const int32_t* offsets, int32_t world,
+                     const int64_t* first_batch, int32_t n_first, const int32_t* counts, int32_t n_counts, float* sig_out,
+                     void* stream);
 
 /* Voxel coordinates of every `stride`-th sample of one drawn batch (positions s*stride < n of the batch that
  * pin_gather_batch_drawn would gather): cells_out [n_out][3] int32 -- what the host cuts its k-d boxes from. */

@@ -18,7 +18,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 11
+PIN_ABI_VERSION = 12
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -123,7 +123,7 @@ class TrainParams(C.Structure):
 
 class TrainColorParams(C.Structure):
     _fields_ = [("n_main", C.c_int32), ("loss_weight_on", C.c_int32), ("surface_range", C.c_float),
-                ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("surface_count", vp)]
+                ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("n_main_global", C.c_int32), ("surface_count", vp)]
 
 
 class DpRegions(C.Structure):
@@ -220,6 +220,7 @@ SIGNATURES = {
     "pin_allreduce_f32": (i32, [vp, vp, vp, i64, vp]),
     "pin_dp_kd_boxes": (i32, [vp, i32, i32, vp]),
     "pin_dp_boxes_decode": (i32, [vp, i32, vp, vp]),
+    "pin_dp_signature": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]),
     "pin_dp_sample_cells": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
     "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, f32, vp, vp]),
     "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,

@@ -37,21 +37,44 @@ def rccl_library_path() -> str:
 
 
 class RcclComm:
-    def __init__(self, rank: int, world: int, group=None):
-        import torch.distributed as dist
+    def __init__(self, rank: int, world: int, group=None, uid: bytes | None = None):
+        """uid: the 128-byte ncclUniqueId already exchanged by the caller (make_comm does that on its MAIN thread, so that no
+        torch.distributed collective is ever issued from the watchdog thread); None = exchange it here."""
         L = _lib.lib()
-        check(L.pin_comm_load(rccl_library_path().encode()), "pin_comm_load")
-        uid = C.create_string_buffer(_lib.PIN_COMM_ID_BYTES)
-        if rank == 0:
-            check(L.pin_comm_unique_id(uid), "pin_comm_unique_id")
-        if world > 1:
-            box = [bytes(uid.raw) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)
-            uid = C.create_string_buffer(box[0], _lib.PIN_COMM_ID_BYTES)
+        if uid is None:
+            uid = self.exchange_id(rank, world, group)
+        buf = C.create_string_buffer(uid, _lib.PIN_COMM_ID_BYTES)
         handle = C.c_void_p()
-        check(L.pin_comm_init_rank(uid, rank, world, C.byref(handle)), "pin_comm_init_rank")
+        check(L.pin_comm_init_rank(buf, rank, world, C.byref(handle)), "pin_comm_init_rank")
         self._h, self.rank, self.world = handle, rank, world
         self.kind = "rccl"
+
+    @staticmethod
+    def exchange_id(rank: int, world: int, group=None) -> bytes:
+        """Load librccl and carry rank 0's ncclUniqueId to every rank over the job's process group.  Collective: every rank
+        calls it, every rank raises when ANY rank could not load the library or rank 0 could not make the id -- the
+        failure travels in the same two object collectives, so the ranks never disagree about what comes next."""
+        import torch.distributed as dist
+        L = _lib.lib()
+        err, uid = "", None
+        try:
+            check(L.pin_comm_load(rccl_library_path().encode()), "pin_comm_load")
+            if rank == 0:
+                b = C.create_string_buffer(_lib.PIN_COMM_ID_BYTES)
+                check(L.pin_comm_unique_id(b), "pin_comm_unique_id")
+                uid = bytes(b.raw)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+            err = next((f"rank {i}: {e}" for i, e in enumerate(errs) if e), "")
+        if err or uid is None:
+            raise RuntimeError(err or "rank 0 produced no ncclUniqueId")
+        return uid
 
     def allreduce_grads(self, flat: torch.Tensor):
         check(_lib.lib().pin_allreduce_grads(self._h, flat.data_ptr(), flat.numel(), _stream()), "pin_allreduce_grads")
@@ -84,11 +107,12 @@ class HostStagedComm:
         self.kind = "host-staged gloo"
 
     def _stage(self, t: torch.Tensor):
-        key = (t.dtype, t.numel())
-        h = self._host.get(key)
-        if h is None:
-            h = self._host[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
-        return h
+        """One growing pinned buffer per dtype, sliced to the message (the spatial exchange changes size every call)."""
+        n = t.numel()
+        h = self._host.get(t.dtype)
+        if h is None or h.numel() < n:
+            h = self._host[t.dtype] = torch.empty(int(n * 1.25) + 1024, dtype=t.dtype).pin_memory()
+        return h[:n]
 
     def _allreduce(self, t: torch.Tensor, op):
         import torch.distributed as dist
@@ -193,13 +217,22 @@ def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device
     if transport == "torch":
         return TorchComm(rank, world, group)
     comm, why = None, ""
-    # communicator set-up and the self-test run under a watchdog: a bootstrap that never returns (it blocks inside
-    # ncclCommInitRank on every rank alike) must end in the other transport, not in a job that hangs
     box = {}
+    # The id exchange uses the job's process group, so it runs HERE, on the main thread, and reports its failures through the
+    # same collectives on every rank.  Only ncclCommInitRank and the self-test -- which touch no torch.distributed state --
+    # run under the watchdog: a bootstrap that never returns (it blocks inside ncclCommInitRank on every rank alike) must end
+    # in the other transport, not in a job that hangs.
+    uid = None
+    try:
+        uid = RcclComm.exchange_id(rank, world, group)
+    except Exception as e:  # noqa: BLE001 -- raised on every rank together (exchange_id)
+        box["err"] = f"{type(e).__name__}: {e}"
 
     def bring_up():
+        if uid is None:
+            return
         try:
-            c = RcclComm(rank, world, group)
+            c = RcclComm(rank, world, group, uid=uid)
             box["comm"] = c
             box["ok"] = self_test(c, device)
         except Exception as e:  # noqa: BLE001 -- any failure of the optional path selects the other one, on every rank

@@ -257,6 +257,44 @@ __global__ __launch_bounds__(256) void dp_owner_pack_kernel(const unsigned char*
     for (; i < n; i += stride) out[i] = (owner[i >> 3] & 0x7f) == rank ? feats[i] : 0.f;
 }
 
+// Replica-consistency signature of a spatially sharded call (pin_dp_signature): block b < n_arrays folds one int32 array into a
+// position-weighted 32-bit checksum; the words leave as two exactly representable fp32 halves each, so that a SUM all-reduce
+// over <= 64 ranks stays exact and "sum == world x mine on every rank" means "identical on every rank".
+struct SigArray {
+    const int* data;
+    const int* count_dev;  // element count on the device (NULL: `count`)
+    int count, stride;     // stride in int32 words between elements (2 = the low halves of an int64 array)
+};
+
+__device__ __forceinline__ void sig_store(float* out, int word, unsigned v) {
+    out[2 * word] = (float)(v >> 16);
+    out[2 * word + 1] = (float)(v & 0xffffu);
+}
+
+__global__ __launch_bounds__(256) void dp_signature_kernel(SigArray a0, SigArray a1, const int* __restrict__ n_halo_dev,
+                                                           const int* __restrict__ offsets, int world,
+                                                           const int* __restrict__ counts, int n_counts, float* __restrict__ out) {
+    __shared__ unsigned part[256];
+    const int b = blockIdx.x;
+    if (b < 2) {
+        const SigArray a = b == 0 ? a0 : a1;
+        const int n = a.count_dev ? *a.count_dev : a.count;
+        unsigned acc = 0x9e3779b9u * (unsigned)n;
+        for (int i = threadIdx.x; i < n; i += 256) acc += (unsigned)a.data[(size_t)i * a.stride] * (2u * (unsigned)i + 1u);
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sig_store(out, world + 2 + b, part[0]);
+        return;
+    }
+    // block 2: the plain words -- halo count, the owner lists' offsets, then this rank's per-iteration sample counts
+    for (int i = threadIdx.x; i < world + 2; i += 256) sig_store(out, i, (unsigned)(i == 0 ? *n_halo_dev : offsets[i - 1]));
+    for (int i = threadIdx.x; i < n_counts; i += 256) sig_store(out, world + 4 + i, (unsigned)counts[i]);
+}
+
 // int32 box coordinates back from the two exactly representable fp32 halves they travelled in (pin_dp_boxes_decode)
 __global__ void dp_boxes_decode_kernel(const float* __restrict__ halves, int n, int* __restrict__ boxes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,6 +490,21 @@ extern "C" int pin_dp_boxes_decode(const float* halves, int32_t world, int32_t* 
     PIN_ENTER();
     PIN_CHECK_ARG(halves && boxes_out && world >= 1 && world <= DP_MAX_WORLD, "bad arguments");
     hipLaunchKernelGGL(dp_boxes_decode_kernel, dim3(cdiv(6 * world, 64)), dim3(64), 0, as_stream(stream), halves, 6 * world, boxes_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_signature(const int32_t* halo_rows, const int32_t* n_halo_dev, const int32_t* offsets, int32_t world,
+                                const int64_t* first_batch, int32_t n_first, const int32_t* counts, int32_t n_counts,
+                                float* sig_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(world >= 1 && world <= DP_MAX_WORLD && n_first >= 0 && n_counts >= 0, "bad sizes");
+    PIN_CHECK_ARG(halo_rows && n_halo_dev && offsets && sig_out && (n_first == 0 || first_batch) && (n_counts == 0 || counts),
+                  "NULL pointer");
+    const SigArray a0{halo_rows, n_halo_dev, 0, 1};
+    const SigArray a1{reinterpret_cast<const int*>(first_batch), nullptr, n_first, 2};
+    hipLaunchKernelGGL(dp_signature_kernel, dim3(3), dim3(256), 0, as_stream(stream), a0, a1, n_halo_dev, offsets, world, counts,
+                       n_counts, sig_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

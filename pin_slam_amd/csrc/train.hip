@@ -939,8 +939,9 @@ extern "C" int pin_gather_records_drawn(const float* pool_nbr, const int32_t* po
     PIN_ENTER();
     PIN_CHECK_ARG(n >= 0 && n_batches >= 1 && k >= 1 && k <= PIN_MAX_K && q_per_batch >= n, "bad sizes");
     if (n == 0) return 0;
-    PIN_CHECK_ARG(pool_nbr && pool_nn && index_history && nbr_out && nn_out, "NULL pointer");
-    PIN_CHECK_ARG(n_history >= 0 && n_history <= n && (n_history == n || (index_new_batch && new_idx)), "index arrays");
+    PIN_CHECK_ARG(pool_nbr && pool_nn && nbr_out && nn_out, "NULL pointer");
+    PIN_CHECK_ARG(n_history >= 0 && n_history <= n && (n_history == 0 || index_history) &&
+                      (n_history == n || (index_new_batch && new_idx)), "index arrays");  // (an all-new draw has no history rows)
     hipLaunchKernelGGL(gather_records_kernel, dim3(cdiv((long)n * k, 256), n_batches), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(pool_nbr), pool_nn, k, reinterpret_cast<const long long*>(index_history), n_history,
                        reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx), n,
@@ -990,7 +991,10 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
         const float unit_eik = tp->n_eik > 0 ? tp->weight_e * tp->inv_n_eik * f->sdf_scale / tp->eik_eps : 0.f;
         unit = fmaxf(unit_main, unit_eik);
     } else {
-        unit = 8.f * fcol.weight_i / (3.f * (float)tp->n_main);
+        // (a shard of a larger batch -- spatial data-parallel ranks -- is normalised by the surface count of the WHOLE batch: up
+        // to world x n_main; inv_n_main carries the global batch then)
+        const float n_glob = tp->inv_n_main > 0.f ? fmaxf(1.f / tp->inv_n_main, (float)tp->n_main) : (float)tp->n_main;
+        unit = 8.f * fcol.weight_i / (3.f * n_glob);
     }
     const float dscale = exp2f(-ceilf(log2f(fmaxf(unit, 1e-30f))));
     const int want_dec = dec_grad != nullptr;
@@ -1317,6 +1321,7 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
         memset(&sp, 0, sizeof(sp));
         sp.n_main = Q;  // plain tiles of 16 samples, no probes
         sp.dec_image_current = tp->dec_image_current;
+        sp.inv_n_main = (given && tp->n_main_global > Q) ? 1.f / (float)tp->n_main_global : 0.f;  // (only the gradient scale's choice reads it in the colour kernel)
         FusedColor fcol;
         fcol.color = color_label; fcol.count = count; fcol.surface_range = tp->surface_range; fcol.weight_i = tp->weight_i;
         fcol.loss_weight_on = tp->loss_weight_on;

@@ -232,6 +232,7 @@ class SpatialShards:
         self.eik_cap = ecap
         self.n_halo = int(ch[2 * iters])
         self.offsets_host = ch[2 * iters + 1:2 * iters + 1 + W1].numpy().astype(np.int64).copy()
+        self._check_replicas(hist, iters, n, decimation, eikonal, rows, pool_rows)
         self.seg_rows = int(np.diff(self.offsets_host).max(initial=0))
         if self.n_halo > self.halo_rows.shape[0]:
             raise RuntimeError("halo list overflow")  # (cannot happen: the list is sized for every row)
@@ -258,6 +259,50 @@ class SpatialShards:
                           samples_ideal=n / self.world)
         self._hist, self._new, self._new_idx, self._pool_coord = hist, new, new_idx, pool_coord
         return self
+
+    def _check_replicas(self, hist, iters, n, decimation, eikonal, rows, pool_rows):
+        """Only the boxes are agreed through an exchange; the halo list, the owner lists and the partition are derived by every
+        rank from ITS replica of the map and the pool, and publish() indexes those local lists with the other ranks' payloads.
+        Replicas that differ in one bit would write rows to the wrong places or hang the all-gather on mismatched counts, so
+        every call compares a signature (pin_dp_signature: halo count + checksum, owner-list offsets, checksum of the first drawn
+        batch; host: rows, pool size, batch) through one tiny all-reduce and raises when the ranks disagree; the per-rank
+        sample counts ride along and must add up to the batch."""
+        if self.world <= 1 or getattr(self.comm, "kind", "").startswith("none"):
+            return
+        W, L = self.world, _lib.lib()
+        n_first = min(hist.shape[1], 1 << 16)
+        words = W + 4 + 2 * iters
+        host_words = [rows & 0xFFFFFFFF, pool_rows & 0xFFFFFFFF, n & 0xFFFFFFFF, iters, int(decimation), int(bool(eikonal))]
+        nf = 2 * (words + len(host_words))
+        if getattr(self, "_sig", None) is None or self._sig[0].numel() < nf:
+            self._sig = (torch.zeros((nf + 64,), dtype=torch.float32, device=self.device),
+                         torch.zeros((nf + 64,), dtype=torch.float32, device=self.device),
+                         torch.zeros((2 * (nf + 64),), dtype=torch.float32).pin_memory())
+        mine, total, host = self._sig
+        hw = torch.tensor([[float(v >> 16), float(v & 0xFFFF)] for v in host_words], dtype=torch.float32).reshape(-1)
+        mine[2 * words:nf].copy_(hw, non_blocking=True)
+        check(L.pin_dp_signature(self.halo_rows.data_ptr(), self._cnt.data_ptr(), self.offsets.data_ptr(), W, hist.data_ptr(),
+                                 n_first, self.counts.data_ptr(), 2 * iters, mine.data_ptr(), ops._stream()), "pin_dp_signature")
+        self.comm.allreduce(mine[:nf], total[:nf])
+        host[:nf].copy_(mine[:nf], non_blocking=True)
+        host[nf:2 * nf].copy_(total[:nf], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h = host[:2 * nf].numpy().astype(np.int64)
+        own = (h[0:nf:2] << 16) + h[1:nf:2]
+        tot = (h[nf:2 * nf:2] << 16) + h[nf + 1:2 * nf:2]
+        names = ["halo rows"] + [f"owner-list offset {i}" for i in range(W + 1)] + ["halo-list checksum", "first-batch checksum"]
+        names += [f"count[{i // 2}][{i % 2}]" for i in range(2 * iters)]
+        names += ["feature rows", "pool rows", "batch", "iterations", "decimation", "eikonal"]
+        same = list(range(W + 4)) + list(range(words, words + len(host_words)))
+        bad = [names[i] for i in same if tot[i] != W * own[i]]
+        if bad:
+            raise RuntimeError(f"spatially sharded mapper, rank {self.rank}: the ranks' replicas of the map / sample pool have diverged "
+                               f"({', '.join(bad)} differ between ranks); refusing to exchange rows over mismatched lists")
+        cnt = tot[W + 4:words].reshape(iters, 2)
+        n_eik = (n + decimation - 1) // decimation if eikonal else 0
+        if (cnt[:, 0] != n).any() or (eikonal and (cnt[:, 1] != n_eik).any()):
+            raise RuntimeError(f"spatially sharded mapper: the ranks' shares of a batch do not add up to the batch "
+                               f"(main {cnt[:, 0].tolist()} of {n}, Eikonal {cnt[:, 1].tolist()} of {n_eik})")
 
     # ------------------------------------------------------------------ per group of iterations
     def gather(self, pool: dict, global_coord: bool, C_color: int, it0: int, gn: int, out: dict, query_all: torch.Tensor, eps: float):

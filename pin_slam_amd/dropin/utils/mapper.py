@@ -367,11 +367,13 @@ class Mapper(_Base):
         if want is None:
             want = iters * c.bs >= getattr(self, "reuse_pool_records_ratio", 2.0) * n
         if not want or n <= 0 or self.ba_done_flag:
+            self._pool_rec = None  # (reuse is off for this call: give the table back)
             return None
         p, k, dev = self._pool(), t.fs.k, self.device
-        cap = p.cap
+        # sized by the samples in the pool (x1.25 growth), not by the pool's capacity (1e7 samples x k x 16 B would be GBs)
         rec = getattr(self, "_pool_rec", None)
-        if rec is None or rec[0].shape[0] < cap or rec[0].shape[1] != k:
+        if rec is None or rec[0].shape[0] < n or rec[0].shape[1] != k:
+            cap = min(int(n * 1.25) + 1024, max(int(p.cap), n))
             rec = self._pool_rec = (torch.empty((cap, k, 4), dtype=torch.float32, device=dev),
                                     torch.empty((cap,), dtype=torch.int32, device=dev))
         ops.knn_query(t.st, p.bufs[0]["global_coord"][:n], k, out=(rec[0][:n], rec[1][:n], None), bricks=t.bricks)

@@ -390,7 +390,7 @@ class MapTrainer:
                 ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                      self.cgdec if self.c_train_dec else None, surface_range=self.c_range,
                                      weight_i=self.c_weight, loss_weight_on=self.loss_weight_on, image_current=lazy,
-                                     surface_count=surface_count)
+                                     surface_count=surface_count, global_n_main=self.bs)
             if not lazy:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,

@@ -478,7 +478,8 @@ def train_weight_grad(buf: TrainBuffers, dec_grad):
 
 
 def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
-                     surface_range, weight_i=1.0, loss_weight_on=False, image_current=False, surface_count=None):
+                     surface_range, weight_i=1.0, loss_weight_on=False, image_current=False, surface_count=None,
+                     global_n_main=None):
     """Colour term of a training iteration; call after train_step (reuses its queries / kNN)."""
     if buf.color_ws is None:
         nbytes = _lib.lib().pin_train_workspace_bytes(buf.cap_main, fc.hidden, fc.levels, 1 if fc.weighted_first else fc.k) + 256  # (capacity: shards vary)
@@ -490,6 +491,7 @@ def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, 
     tp.dec_image_current = int(bool(image_current) and fc.dec_image is not None)
     if surface_count is not None:  # (a shard of a larger batch: device int32, the batch's number of surface samples)
         tp.surface_count = surface_count.data_ptr()
+        tp.n_main_global = int(global_n_main or 0)
     f = fc.params()
     check(_lib.lib().pin_train_color_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
                                           _ptr(sdf_label, torch.float32), _ptr(color_label, torch.float32),

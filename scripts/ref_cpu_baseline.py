@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """The REAL reference (PRBonn/PIN_SLAM, torch CPU) timed on the bench's C3 inputs: BASELINE.md section 3 protocol.
 
-Build container only (needs /root/reference; the tree cannot travel to the GPU box): loads the unmodified
-NeuralPoints / Decoder / Tracker / Mapper through oracle/ref_loader.py, builds the synthetic C3 map of bench.py
+Runs where the reference tree is: /root/reference in the build container, or -- ON THE GPU BOX'S HOST, which is where
+BASELINE.md section 3 wants the number from -- the git-ignored pack `python scripts/e2e_pin_slam.py pack` leaves under
+oracle/_ref/ (it travels with a gpurun snapshot; unpacked into a temporary directory here, PIN_REFERENCE_ROOT).  Loads the
+unmodified NeuralPoints / Decoder / Tracker / Mapper through oracle/ref_loader.py, builds the synthetic C3 map of bench.py
 (pin_slam_amd.synth: ~2.2 M neural points, 5e7-slot table, Kc = 81, k = 8, decoder 4x64) inside the reference's
 own classes and times
 
@@ -11,8 +13,8 @@ own classes and times
   * Mapper.mapping(12)         (batch 16384 + Eikonal, backward, Adam over every local feature),
 
 with time.perf_counter, 1 warm-up + the median of `--reps` repeats, torch.get_num_threads() threads.  Writes
-profiles/r03_ref_cpu_baseline.json, which bench.py attaches to its JSON line as `cpu_baseline_reference`
-(baseline only: a GPU/CPU ratio says nothing about kernel quality)."""
+profiles/r04_ref_cpu_baseline.json (--out), which bench.py emits as `cpu_baseline` (kind "reference-torch-cpu";
+baseline only: a GPU/CPU ratio says nothing about kernel quality).  No GPU is touched."""
 from __future__ import annotations
 
 import argparse
@@ -28,8 +30,34 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+PACK = os.path.join(ROOT, "oracle", "_ref", "pin_slam_reference.tar.gz")
+if not os.path.isdir(os.environ.get("PIN_REFERENCE_ROOT", "/root/reference")) and os.path.exists(PACK):
+    import tarfile
+    import tempfile
+    _dst = tempfile.mkdtemp(prefix="pin_slam_ref_")
+    with tarfile.open(PACK) as _tf:
+        _tf.extractall(_dst)
+    os.environ["PIN_REFERENCE_ROOT"] = _dst
 from oracle import ref_loader as R  # noqa: E402
 from pin_slam_amd import synth  # noqa: E402
+
+
+def host_string(label):
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    gpu = os.path.exists("/dev/kfd") and torch.cuda.is_available()
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count()
+    what = label or ("gpu box (MI355X host)" if gpu else "build container (no GPU)")
+    return f"{what}: {platform.node()}, {os.cpu_count()} logical CPUs ({aff} usable), {model or platform.machine()}"
 
 
 def timed(fn, reps):
@@ -50,8 +78,12 @@ def main():
     ap.add_argument("--bs", type=int, default=16384)
     ap.add_argument("--map-iters", type=int, default=12)
     ap.add_argument("--reg-iters", type=int, default=50)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_ref_cpu_baseline.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_ref_cpu_baseline.json"))
+    ap.add_argument("--host-label", default="", help="what to call this machine in the record (e.g. 'gpu box (MI355X host)')")
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0 = torch's default for this host)")
     a = ap.parse_args()
+    if a.threads > 0:
+        torch.set_num_threads(a.threads)
     m = R.load()
     H, L, k = 64, 4, 8
     cfg = R.make_config(voxel_size_m=0.4, search_alpha=0.5, num_nei_cells=2, query_nn_k=k, buffer_size=int(5e7),
@@ -100,7 +132,7 @@ def main():
         mp.mapping(a.map_iters)
 
     out = {"what": "unmodified PRBonn/PIN_SLAM classes on torch CPU (oracle/ref_loader.py), bench.py C3 inputs",
-           "host": f"build container, {os.cpu_count()} cores ({platform.processor() or platform.machine()})",
+           "host": host_string(a.host_label),
            "torch_threads": torch.get_num_threads(), "torch": torch.__version__, "neural_points": int(P),
            "scan_points": a.scan, "decoder": f"{L}x{H}", "knn_k": k, "candidate_cells": int(npts.neighbor_K),
            "map_build_s": round(t_update, 2), "reps": a.reps}

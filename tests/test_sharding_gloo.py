@@ -108,14 +108,23 @@ def _fallback_worker(rank, world, port, q, hang=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pin_slam_amd import collective
-    if hang:  # the bootstrap never returns (on any rank): the watchdog ends it
+    if hang == "idfail":
+        # rank 0 cannot even load the library (before the id leaves): the failure travels in exchange_id's own collectives,
+        # on the main thread, and every rank moves to the other transport together (no collective in the watchdog)
+        if rank == 0:
+            collective.rccl_library_path = lambda: (_ for _ in ()).throw(OSError("librccl not readable on this rank"))
+    else:
+        collective.RcclComm.exchange_id = staticmethod(lambda r, w, group=None: b"\0" * 128)
+    if hang is True:  # the bootstrap never returns (on any rank): the watchdog ends it
         import time
         os.environ["PIN_COMM_INIT_TIMEOUT"] = "3"
         collective.RcclComm.__init__ = lambda self, *a, **k: time.sleep(3600)
+    elif hang == "idfail":
+        pass
     elif rank == 1:  # only ONE rank cannot bring RCCL up: every rank must still end on the same transport
         collective.RcclComm.__init__ = lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("no RCCL on this rank"))
     else:
-        def fake(self, r, w, group=None):
+        def fake(self, r, w, group=None, uid=None):
             self.rank, self.world, self.kind, self._h = r, w, "rccl", None
         collective.RcclComm.__init__ = fake
         collective.RcclComm.allreduce = lambda self, s, r: r.copy_(s * 3.0)   # (3 = 1 + 2: passes the self-test alone)
@@ -162,6 +171,24 @@ def test_transport_fallback_is_agreed_by_all_ranks():
     assert all(p.exitcode == 0 for p in procs)
     for _, kind, vals in got:
         assert kind.startswith("torch.distributed gloo") and "rank 1: RuntimeError: no RCCL on this rank" in kind
+        assert vals == [3.0] * 4
+
+
+@pytest.mark.timeout(300)
+def test_id_exchange_failure_on_rank0_falls_back_everywhere():
+    """Rank 0 fails BEFORE the ncclUniqueId is broadcast (it cannot load librccl): RcclComm.exchange_id reports it through its
+    own two object collectives on the main thread, so the other rank is not left waiting in a broadcast on a helper thread
+    while rank 0 moves on -- both ranks end on torch.distributed's communicator with the reason in `kind`."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, "idfail")) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for _, kind, vals in got:
+        assert kind.startswith("torch.distributed gloo") and "rank 0: OSError: librccl not readable" in kind
         assert vals == [3.0] * 4
 
 
