@@ -353,6 +353,17 @@ int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const flo
 int pin_gn_knn_coherent(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
                         const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, float* coh_state,
                         uint32_t* coh_win, int32_t iteration, void* stream);
+/* pin_gn_knn through the brick cache with per-query CANDIDATE LISTS kept across the iterations of one registration (the source
+ * points are searched reg_iter_n times under a pose that moves by centimetres, tracker.py:114-184).  A full search leaves per
+ * query its voxel and the entry offsets of its occupied candidate cells, compacted in candidate order: cell_state [n][4] int32 =
+ * (voxel x, y, z, list length; -1 = this voxel needs the exact probe), cell_list [n][pin_knn_list_stride(n_cand)] uint32.  While
+ * the query stays in that voxel a later call loads the list, gathers and measures those entries and runs the same tournament over
+ * the shorter list; a query that has changed voxel rebuilds its list first.  Records and counts are the bits pin_gn_knn writes.
+ * rebuild != 0 (the first iteration of a registration, or after ANY change of src / map / brick cache): every list is rebuilt. */
+int32_t pin_knn_list_stride(int32_t n_cand);
+int pin_gn_knn_listed(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
+                      const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, int32_t* cell_state,
+                      uint32_t* cell_list, int32_t rebuild, void* stream);
 /* the two halves of pin_gn_accumulate_solve, separately launchable (bench.py brackets the
  * accumulate kernel with HIP events) */
 int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp, const pin_color_term* color,
@@ -811,6 +822,23 @@ int pin_dp_gather(const float* pool_coord, const float* pool_label, const float*
                   const int32_t* sel, int32_t cap, const int32_t* eik_sel, int32_t eik_cap, const int32_t* counts,
                   int32_t n_batches, float* coord_out, float* label_out, float* weight_out, int32_t* ts_out,
                   float* color_out, float* query_out, float eps, void* stream);
+
+/* Neighbour records of THIS rank's pool samples, searched once per Mapper.mapping call (the neural points do not move while
+ * the map trains; a 2^20 batch draws every pool sample ~6 times per call): the one-GPU path's pin_gather_records_drawn for
+ * the spatial shards.
+ * pin_dp_own_pool: after pin_dp_partition (which wrote pool_region): the pool rows of box `rank`, in pool order --
+ *   own_coord_out [own_cap][3] their coordinates (the queries of ONE search over them), pool_to_own_out [pool_rows] = position
+ *   in that list (-1 for the other boxes' rows), *count_out (device) their number; workspace: 4 bytes per 256 pool rows + 256.
+ * pin_dp_gather_records: for batch b < n_batches and this rank's sample j < counts[b][0]: record and neighbour count of the
+ *   sample's pool row -> slot b of the trainer's record buffers (stride cap + 6 * ecap queries per batch, as pin_dp_gather lays
+ *   the queries out); the Eikonal probes behind them are searched per iteration as before. */
+int pin_dp_own_pool(const uint8_t* pool_region, int32_t pool_rows, int32_t rank, const float* pool_coord, float* own_coord_out,
+                    int32_t own_cap, int32_t* pool_to_own_out, int32_t* count_out, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+int pin_dp_gather_records(const float* rec_nbr, const int32_t* rec_nn, int32_t k, const int32_t* pool_to_own,
+                          const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx,
+                          int64_t hist_stride, int64_t new_stride, const int32_t* sel, int32_t cap, int32_t ecap,
+                          const int32_t* counts, int32_t n_batches, float* nbr_out, int32_t* nn_out, void* stream);
 
 /* Halo of the partition over the feature rows at pos [n_rows][3]: halo_rows_out = ascending indices of the rows
  * that are NOT at least `reach` cells inside their own box (the same list on every rank), *count_out of them (at

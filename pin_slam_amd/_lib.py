@@ -160,6 +160,8 @@ SIGNATURES = {
     "pin_decoder_image_bytes": (i64, [i32, i32]),
     "pin_stage_decoder": (i32, [P(Field), vp, i64, vp]),
     "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pin_knn_list_stride": (i32, [i32]),
+    "pin_gn_knn_listed": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pin_gn_knn_coherent": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_gn_solve": (i32, [vp, vp, P(GnLoopParams), vp]),
@@ -225,6 +227,8 @@ SIGNATURES = {
     "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, f32, vp, vp]),
     "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,
                             vp, vp, f32, vp]),
+    "pin_dp_own_pool": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp, i64, vp]),
+    "pin_dp_gather_records": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i64, i64, vp, i32, i32, vp, i32, vp, vp, vp]),
     "pin_dp_mark_halo": (i32, [P(DpRegions), vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]),
     "pin_dp_halo_pack": (i32, [vp, i32, vp, vp, vp]),
     "pin_dp_halo_adam": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, f32, f32, f32, vp]),

@@ -236,6 +236,180 @@ __device__ __forceinline__ unsigned int knn_cell_offset(const unsigned short* __
 // full search -- with ~1 % of the queries on the list the second launch still costs the ~12 us latency chain of one wave,
 // and the pre-pass ~10 us of its own: no gain over the plain search.)
 constexpr unsigned int COH_NONE = 0xffffffffu;
+// The full search of the eight-lanes-per-query scheme for the groups with `active` set (the tables and header rows are this
+// wave's; every lane of the wave takes part in their set-up).  knn_brick_kernel runs it for every query, the listed kernel below
+// only for the groups it cannot serve from a candidate list.
+template <int R, bool COH>
+__device__ __forceinline__ void knn_full_search(const pin_search_params& sp, const pin_brick_cache& bc, const float qx, const float qy,
+                                                const float qz, const bool active, const int qi, const int qq, const int k,
+                                                unsigned short* const lut, unsigned int* const cpack, uint4* const hdr_grp,
+                                                float4* __restrict__ nbr, int* __restrict__ nn_count,
+                                                float4* __restrict__ coh_state, unsigned int* __restrict__ coh_win, const int coh_mode) {
+    constexpr int G = 8;
+    const int nd = bc.n_dilate;
+    const int sub = threadIdx.x & (G - 1);
+    const int wlane = threadIdx.x & 63;
+    const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+    {   // this wave's copies of the two tables
+        reinterpret_cast<uint4*>(lut)[wlane] = reinterpret_cast<const uint4*>(KNN_LUT.v)[wlane];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ci = wlane + 64 * h, c = ci < sp.n_cand ? ci : 0;
+            cpack[ci] = (unsigned int)((bc.cand_dx[3 * c] + nd) | ((bc.cand_dx[3 * c + 1] + nd) << 3) | ((bc.cand_dx[3 * c + 2] + nd) << 6));
+        }
+    }
+    // floor(q / res) as in voxel_coord (IEEE division); the cached path works on 32-bit cell coordinates, anything
+    // farther than 2^29 cells from the origin (never the case for a metric map) takes the exact 64-bit probe
+    float fx, fy, fz;
+    {
+#pragma clang fp contract(off)
+        fx = floorf(__fdiv_rn(qx, sp.resolution)); fy = floorf(__fdiv_rn(qy, sp.resolution)); fz = floorf(__fdiv_rn(qz, sp.resolution));
+    }
+    const float lim = 536870912.f;  // 2^29
+    const bool far = !(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim);
+    const int ix = far ? 0 : (int)fx, iy = far ? 0 : (int)fy, iz = far ? 0 : (int)fz;
+    const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
+    const unsigned int P = (unsigned int)(((ix - nd) & 3) | (((iy - nd) & 3) << 3) | (((iz - nd) & 3) << 6));
+    bool uncached;
+    {   // lane `sub` resolves window brick (sub >> 2, (sub >> 1) & 1, sub & 1) with one 32-byte directory load
+        BrickInfo bi;
+        bi.base = -1; bi.lo = 0; bi.hi = 0;
+        if (!far) bi = dir_lookup(bc, brick_key(b0x + (sub >> 2), b0y + ((sub >> 1) & 1), b0z + (sub & 1)));
+        uncached = bi.base < 0;
+        if (uncached) { bi.lo = 0; bi.hi = 0; }  // its cells miss in the cached pass and are probed exactly below
+        hdr_grp[sub] = make_uint4((unsigned int)bi.base, bi.lo, bi.hi, (unsigned int)bi.base + (unsigned int)__popc(bi.lo));
+    }
+    const bool general = __builtin_amdgcn_ballot_w64(uncached) != 0ull;  // some window brick of the wave is not cached
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tables and header rows were written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const char* const hrow = reinterpret_cast<const char*>(hdr_grp);
+    const unsigned int sentinel = (unsigned int)bc.max_entries;
+
+    // accepted candidates: only the distance bits stay (registers); the k winners' entries are fetched
+    // again at the end (cache hits), one winner per lane.  The candidate pass is straight-line: every lane
+    // issues its R entry loads back to back, so a wave pays one memory round trip for all of them.
+    unsigned int d2b[R];
+    float4 E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c = r * G + sub;
+        unsigned int off = knn_cell_offset(lut, hrow, P + cpack[c & 127], sentinel);
+        if (r == R - 1) off = c < sp.n_cand ? off : sentinel;  // (only the last round can run past the candidate list)
+        E[r] = entries[off];
+    }
+    int cnt = 0;
+    float m_acc = __builtin_inff();  // COH: min over the candidates of |d2 - R^2| (how close anything is to being accepted / rejected)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
+        const float d2 = dist2_exact(dx, dy, dz);
+        const bool acc = !(d2 > sp.max_valid_dist2);  // (the sentinel gives +inf)
+        d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;  // d2 >= 0: the bit pattern orders like the value
+        cnt += acc ? 1 : 0;
+        if (COH) m_acc = fminf(m_acc, fabsf(d2 - sp.max_valid_dist2));
+    }
+    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+    const long long gx = (long long)fx, gy = (long long)fy, gz = (long long)fz;  // (used by the exact probe only)
+    if (general) {  // exact probe for the cells of uncached window bricks (rare: map border, a cache that overflowed)
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            const int c = r * G + sub;
+            if (c >= sp.n_cand) continue;
+            if (!far && (int)hdr_grp[lut[P + cpack[c]] >> 10].x >= 0) continue;  // cached brick: done above
+            const int dxc = bc.cand_dx[3 * c], dyc = bc.cand_dx[3 * c + 1], dzc = bc.cand_dx[3 * c + 2];
+            float4 Pp;
+            int l = -1;
+            if (!lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, Pp, l)) continue;
+            const float dx = Pp.x - qx, dy = Pp.y - qy, dz = Pp.z - qz;
+            const float d2 = dist2_exact(dx, dy, dz);
+            if (d2 > sp.max_valid_dist2) continue;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) d2b[rr] = rr == r ? __float_as_uint(d2) : d2b[rr];
+            ++cnt;
+        }
+    }
+    cnt = (int)group_sum_u32<G>((unsigned int)cnt);
+    if (active && sub == 0) nn_count[qi] = cnt;
+
+    // k rounds of an 8-lane tournament on (d2 bits, candidate order): two 32-bit group reductions
+    // on the DPP path per round (no LDS crossbar, no 64-bit keys); lane t remembers winner t
+    int mine = -1;
+    unsigned int d_last = 0u;  // COH: distance bits of the last winner found
+    int n_win = 0;
+    for (int t = 0; t < k; ++t) {
+        unsigned int bd = d2b[0];
+        int br = 0;
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
+        const unsigned int wd = group_min_u32<G>(bd);
+        if (wd == 0xffffffffu) break;
+        d_last = wd;
+        ++n_win;
+        const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
+        const unsigned int wc = group_min_u32<G>(myc);
+        if (myc == wc) {  // exactly one lane of the group
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r == br) d2b[r] = 0xffffffffu;
+        }
+        if (sub == t) mine = (int)wc;
+    }
+    // lane t < k publishes record t: the winner's entry again (same bits as in the candidate pass)
+    {
+        const int cc = mine >= 0 ? mine : 0;
+        const unsigned int T = P + cpack[cc];
+        float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (mine >= 0) {
+            float4 Ew = make_float4(0.f, 0.f, 0.f, 0.f);
+            int l = -1;
+            if (!far && (int)hdr_grp[lut[T] >> 10].x >= 0) {
+                Ew = entries[knn_cell_offset(lut, hrow, T, sentinel)];
+                l = __float_as_int(Ew.w);
+            } else {
+                lookup_cell(sp, gx + bc.cand_dx[3 * cc], gy + bc.cand_dx[3 * cc + 1], gz + bc.cand_dx[3 * cc + 2], d_cur, Ew, l);
+            }
+            const float dx = Ew.x - qx, dy = Ew.y - qy, dz = Ew.z - qz;
+            rec = make_float4(-dx, -dy, -dz, __int_as_float(l));
+        }
+        if (active && sub < k) nbr[(size_t)qq * k + sub] = rec;
+        if (COH && coh_mode != 0) {
+            // what the coherent path of a later iteration needs: lane t's winner (entry offset | candidate << 24) ...
+            const bool cached = mine >= 0 && !far && (int)hdr_grp[lut[T] >> 10].x >= 0;
+            const unsigned int off = cached ? knn_cell_offset(lut, hrow, T, sentinel) : 0u;
+            const bool bad = (mine >= 0 && !cached) || off >= 0x1000000u;  // a winner from the exact probe: no entry to come back to
+            // ... and the margin.  The winners stay the winners while the query moves less than half the gap between the k-th
+            // and the (k+1)-th accepted distance; a candidate at distance s crosses the acceptance radius Rv after
+            // |s - Rv| = |d - Rv^2| / (s + Rv) >= |d - Rv^2| / (3 Rv) while s <= 2 Rv, and is more than Rv away otherwise.
+            const float Rv = sqrtf(sp.max_valid_dist2);
+            unsigned int d_next = 0xffffffffu;  // the (k+1)-th accepted distance, if the list was full
+            if (n_win == k) {
+                unsigned int bd = d2b[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) bd = min(bd, d2b[r]);
+                d_next = group_min_u32<G>(bd);
+            }
+            float m_sel = __builtin_inff();
+            if (d_next != 0xffffffffu) m_sel = 0.5f * (sqrtf(__uint_as_float(d_next)) - sqrtf(__uint_as_float(d_last)));  // half the gap
+            float m_a = __uint_as_float(group_min_u32<G>(__float_as_uint(m_acc)));  // (non-negative floats order like their bits)
+            m_a = fminf(m_a / (3.f * Rv), Rv);
+            const float r = sp.resolution;
+            const float ux = fmaf(-fx, r, qx), uy = fmaf(-fy, r, qy), uz = fmaf(-fz, r, qz);  // position inside the voxel
+            const float m_cell = fminf(fminf(fminf(ux, r - ux), fminf(uy, r - uy)), fminf(uz, r - uz));
+            // rounding of floor(q / res) and of the position inside the voxel: a few ulp of the coordinate
+            const float safety = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fmaxf(fabsf(qz), 1.f)) * 4.8e-7f + 1e-6f;
+            float m = fminf(fminf(m_sel, m_a), m_cell) - safety;
+            const bool any_bad = group_sum_u32<G>((bad || uncached) ? 1u : 0u) != 0u;
+            if (any_bad || far || !(m > 0.f)) m = 0.f;
+            if (active) {
+                coh_win[(size_t)qq * G + sub] = mine >= 0 && !bad ? (off | ((unsigned int)cc << 24)) : COH_NONE;
+                if (sub == 0) coh_state[qq] = make_float4(qx, qy, qz, m * m);
+            }
+        }
+    }
+}
+
 template <int R, bool COH>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                 const float* __restrict__ query, int n, int k, PoseB pose,
@@ -298,165 +472,213 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
         active = active && !near;
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;  // nobody left for the full search
     }
-    {   // this wave's copies of the two tables
+    knn_full_search<R, COH>(sp, bc, qx, qy, qz, active, qi, qq, k, lut_all[wv], cpack_all[wv], hdr[grp], nbr, nn_count, coh_state,
+                            coh_win, coh_mode);
+}
+
+// The listed search proper: RR registers per lane, straight-line.  Slot r * 8 + sub of the query's list (candidate order) is
+// lane `sub`'s register r; the tournament is the full search's -- ties go to the lowest register, then to the lowest slot, i.e.
+// to the lowest candidate.
+template <int RR, bool FROM_LDS>
+__device__ __forceinline__ void listed_select(const pin_search_params& sp, const float4* __restrict__ entries, const unsigned int sentinel,
+                                              const float qx, const float qy, const float qz, const bool go, const int cnt_list,
+                                              const unsigned int* const ll, const unsigned int* __restrict__ const gl, const int k,
+                                              const int qi, const int qq, float4* __restrict__ nbr, int* __restrict__ nn_count) {
+    constexpr int G = 8;
+    const int sub = threadIdx.x & (G - 1);
+    unsigned int offs[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const int slot = r * G + sub;
+        const bool has = go && slot < cnt_list;
+        const int sl = has ? slot : 0;
+        const unsigned int o = FROM_LDS ? ll[sl] : gl[sl];
+        offs[r] = has ? o : sentinel;
+    }
+    float4 E[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) E[r] = entries[offs[r]];
+    unsigned int d2b[RR];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
+        const float d2 = dist2_exact(dx, dy, dz);
+        const bool acc = !(d2 > sp.max_valid_dist2);  // (the sentinel gives +inf)
+        d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;
+        cnt += acc ? 1 : 0;
+    }
+    cnt = (int)group_sum_u32<G>((unsigned int)cnt);
+    if (go && sub == 0) nn_count[qi] = cnt;
+    int mine = -1;
+    for (int t = 0; t < k; ++t) {
+        unsigned int bd = d2b[0];
+        int br = 0;
+#pragma unroll
+        for (int r = 1; r < RR; ++r)
+            if (d2b[r] < bd) { bd = d2b[r]; br = r; }
+        const unsigned int wd = group_min_u32<G>(bd);
+        if (wd == 0xffffffffu) break;
+        const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
+        const unsigned int wc = group_min_u32<G>(myc);
+        if (myc == wc) {
+#pragma unroll
+            for (int r = 0; r < RR; ++r)
+                if (r == br) d2b[r] = 0xffffffffu;
+        }
+        if (sub == t) mine = (int)wc;
+    }
+    float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (go && mine >= 0) {
+        const float4 Ew = entries[FROM_LDS ? ll[mine] : gl[mine]];
+        rec = make_float4(-(Ew.x - qx), -(Ew.y - qy), -(Ew.z - qz), Ew.w);
+    }
+    if (go && sub < k) nbr[(size_t)qq * k + sub] = rec;
+}
+
+// CANDIDATE LISTS ACROSS THE ITERATIONS OF ONE REGISTRATION (pin_gn_knn_listed; knn_brick_listed_kernel<R>).
+// Tracker.tracking searches the same source points reg_iter_n times under a pose that moves by centimetres
+// (utils/tracker.py:114-184), and two thirds of the full search's instructions do not depend on where inside its voxel a
+// query stands: cell arithmetic, window-brick headers, occupancy bits and prefix counts turn the query's VOXEL into the entry
+// offsets of its occupied candidate cells, and 44 % of the candidate cells of the bench map are empty.  So a full search
+// leaves, per query, its voxel and the COMPACT list of those offsets in candidate order (<= n_cand, ~45 of 81 on the bench
+// map); while the query stays in that voxel -- nearly always: a voxel is 40 cm -- a later iteration only loads the list,
+// gathers the entries, measures them and runs the tournament over ceil(count / 8) registers per lane instead of R.  Same
+// entries, same distance arithmetic, same acceptance test, and the slot order IS the candidate order, so the tie rule picks
+// the same winner: the record is the full search's, bit for bit (tests/test_gpu_bricks.py).  A query that has changed voxel
+// rebuilds its list (the set-up and candidate pass of the full search, then the listed search); queries near uncached bricks
+// (map border, overflowed cache) or absurdly far out keep taking the full search with its exact probe.
+template <int R>
+__global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_search_params sp, pin_brick_cache bc,
+                                                                       const float* __restrict__ query, int n, int k,
+                                                                       float* __restrict__ query_out, float4* __restrict__ nbr,
+                                                                       int* __restrict__ nn_count, const double* __restrict__ state,
+                                                                       int4* __restrict__ cell_state, unsigned int* __restrict__ cell_list,
+                                                                       int rebuild) {
+    constexpr int G = 8, CAP = R * G;
+    __shared__ unsigned short lut_all[BRICK_BLOCK / 64][512];
+    __shared__ unsigned int cpack_all[BRICK_BLOCK / 64][128];
+    __shared__ uint4 hdr[BRICK_BLOCK / G][8];
+    __shared__ unsigned int slist[BRICK_BLOCK / G][CAP];  // the list a group has just built (its lanes read each other's slots)
+    if (state[PIN_GN_STATE_DONE] != 0.0) return;  // (block-uniform)
+    float m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = (float)state[i];
+    const int nd = bc.n_dilate;
+    const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const int wlane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
+    const bool active = qi < n;
+    const int qq = active ? qi : n - 1;
+    float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
+    {
+        const float tx = fmaf(qz, m[2], fmaf(qy, m[1], qx * m[0])) + m[3];
+        const float ty = fmaf(qz, m[6], fmaf(qy, m[5], qx * m[4])) + m[7];
+        const float tz = fmaf(qz, m[10], fmaf(qy, m[9], qx * m[8])) + m[11];
+        qx = tx; qy = ty; qz = tz;
+        if (active && sub == 0) { query_out[3 * qi + 0] = qx; query_out[3 * qi + 1] = qy; query_out[3 * qi + 2] = qz; }
+    }
+    float fx, fy, fz;
+    {
+#pragma clang fp contract(off)
+        fx = floorf(__fdiv_rn(qx, sp.resolution)); fy = floorf(__fdiv_rn(qy, sp.resolution)); fz = floorf(__fdiv_rn(qz, sp.resolution));
+    }
+    const float lim = 536870912.f;  // 2^29, as in the full search
+    const bool far = !(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim);
+    const int ix = far ? 0 : (int)fx, iy = far ? 0 : (int)fy, iz = far ? 0 : (int)fz;
+    const int4 cs = rebuild ? make_int4(0, 0, 0, -2) : cell_state[qq];
+    // cs.w: >= 0 = length of the list of voxel (x, y, z); -1 = this voxel's search needs the exact probe; -2 = nothing yet
+    const bool same = !far && cs.x == ix && cs.y == iy && cs.z == iz;
+    bool listed = same && cs.w >= 0;       // serve from the stored list
+    bool unclean = far || (same && cs.w == -1);  // full search with the exact probe
+    int cnt_list = listed ? cs.w : 0;
+    bool built = false;
+    const float4* __restrict__ entries = reinterpret_cast<const float4*>(bc.entries);
+    const unsigned int sentinel = (unsigned int)bc.max_entries;
+    unsigned int* const gl = cell_list + (size_t)qq * CAP;
+    if (__builtin_amdgcn_ballot_w64(active && !listed) != 0ull) {
+        // some query of this wave is new in its voxel: the full search's tables and header rows, for the whole wave
+        unsigned short* const lut = lut_all[wv];
+        unsigned int* const cpack = cpack_all[wv];
         reinterpret_cast<uint4*>(lut)[wlane] = reinterpret_cast<const uint4*>(KNN_LUT.v)[wlane];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ci = wlane + 64 * h, c = ci < sp.n_cand ? ci : 0;
             cpack[ci] = (unsigned int)((bc.cand_dx[3 * c] + nd) | ((bc.cand_dx[3 * c + 1] + nd) << 3) | ((bc.cand_dx[3 * c + 2] + nd) << 6));
         }
-    }
-    // floor(q / res) as in voxel_coord (IEEE division); the cached path works on 32-bit cell coordinates, anything
-    // farther than 2^29 cells from the origin (never the case for a metric map) takes the exact 64-bit probe
-    float fx, fy, fz;
-    {
-#pragma clang fp contract(off)
-        fx = floorf(__fdiv_rn(qx, sp.resolution)); fy = floorf(__fdiv_rn(qy, sp.resolution)); fz = floorf(__fdiv_rn(qz, sp.resolution));
-    }
-    const float lim = 536870912.f;  // 2^29
-    const bool far = !(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim);
-    const int ix = far ? 0 : (int)fx, iy = far ? 0 : (int)fy, iz = far ? 0 : (int)fz;
-    const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
-    const unsigned int P = (unsigned int)(((ix - nd) & 3) | (((iy - nd) & 3) << 3) | (((iz - nd) & 3) << 6));
-    bool uncached;
-    {   // lane `sub` resolves window brick (sub >> 2, (sub >> 1) & 1, sub & 1) with one 32-byte directory load
+        const int b0x = (ix - nd) >> 2, b0y = (iy - nd) >> 2, b0z = (iz - nd) >> 2;
+        const unsigned int P = (unsigned int)(((ix - nd) & 3) | (((iy - nd) & 3) << 3) | (((iz - nd) & 3) << 6));
         BrickInfo bi;
         bi.base = -1; bi.lo = 0; bi.hi = 0;
-        if (!far) bi = dir_lookup(bc, brick_key(b0x + (sub >> 2), b0y + ((sub >> 1) & 1), b0z + (sub & 1)));
-        uncached = bi.base < 0;
-        if (uncached) { bi.lo = 0; bi.hi = 0; }  // its cells miss in the cached pass and are probed exactly below
+        if (!far && !listed) bi = dir_lookup(bc, brick_key(b0x + (sub >> 2), b0y + ((sub >> 1) & 1), b0z + (sub & 1)));
+        const bool uncached = bi.base < 0;
         hdr[grp][sub] = make_uint4((unsigned int)bi.base, bi.lo, bi.hi, (unsigned int)bi.base + (unsigned int)__popc(bi.lo));
-    }
-    const bool general = __builtin_amdgcn_ballot_w64(uncached) != 0ull;  // some window brick of the wave is not cached
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tables and header rows were written by other lanes of this wave
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const char* const hrow = reinterpret_cast<const char*>(&hdr[grp][0]);
-    const unsigned int sentinel = (unsigned int)bc.max_entries;
-
-    // accepted candidates: only the distance bits stay (registers); the k winners' entries are fetched
-    // again at the end (cache hits), one winner per lane.  The candidate pass is straight-line: every lane
-    // issues its R entry loads back to back, so a wave pays one memory round trip for all of them.
-    unsigned int d2b[R];
-    float4 E[R];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!listed && !unclean) {  // (the eight lanes of a query agree on both)
+            unclean = group_sum_u32<G>(uncached ? 1u : 0u) != 0u;
+            if (!unclean) {
+                const char* const hrow = reinterpret_cast<const char*>(&hdr[grp][0]);
+                const unsigned int shift = (unsigned int)(wlane & 56);
+                int base = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int c = r * G + sub;
-        unsigned int off = knn_cell_offset(lut, hrow, P + cpack[c & 127], sentinel);
-        if (r == R - 1) off = c < sp.n_cand ? off : sentinel;  // (only the last round can run past the candidate list)
-        E[r] = entries[off];
-    }
-    int cnt = 0;
-    float m_acc = __builtin_inff();  // COH: min over the candidates of |d2 - R^2| (how close anything is to being accepted / rejected)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float dx = E[r].x - qx, dy = E[r].y - qy, dz = E[r].z - qz;
-        const float d2 = dist2_exact(dx, dy, dz);
-        const bool acc = !(d2 > sp.max_valid_dist2);  // (the sentinel gives +inf)
-        d2b[r] = acc ? __float_as_uint(d2) : 0xffffffffu;  // d2 >= 0: the bit pattern orders like the value
-        cnt += acc ? 1 : 0;
-        if (COH) m_acc = fminf(m_acc, fabsf(d2 - sp.max_valid_dist2));
-    }
-    const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
-    const long long gx = (long long)fx, gy = (long long)fy, gz = (long long)fz;  // (used by the exact probe only)
-    if (general) {  // exact probe for the cells of uncached window bricks (rare: map border, a cache that overflowed)
-#pragma unroll 1
-        for (int r = 0; r < R; ++r) {
-            const int c = r * G + sub;
-            if (c >= sp.n_cand) continue;
-            if (!far && (int)hdr[grp][lut[P + cpack[c]] >> 10].x >= 0) continue;  // cached brick: done above
-            const int dxc = bc.cand_dx[3 * c], dyc = bc.cand_dx[3 * c + 1], dzc = bc.cand_dx[3 * c + 2];
-            float4 Pp;
-            int l = -1;
-            if (!lookup_cell(sp, gx + dxc, gy + dyc, gz + dzc, d_cur, Pp, l)) continue;
-            const float dx = Pp.x - qx, dy = Pp.y - qy, dz = Pp.z - qz;
-            const float d2 = dist2_exact(dx, dy, dz);
-            if (d2 > sp.max_valid_dist2) continue;
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) d2b[rr] = rr == r ? __float_as_uint(d2) : d2b[rr];
-            ++cnt;
+                for (int r = 0; r < R; ++r) {  // the occupied candidate cells' entry offsets, compacted in candidate order
+                    const int c = r * G + sub;
+                    unsigned int off = knn_cell_offset(lut, hrow, P + cpack[c & 127], sentinel);
+                    if (r == R - 1) off = c < sp.n_cand ? off : sentinel;
+                    const bool occ = off != sentinel;
+                    const unsigned int gb = (unsigned int)(__builtin_amdgcn_ballot_w64(occ) >> shift) & 0xffu;
+                    const int pos = base + __popc(gb & ((1u << sub) - 1u));
+                    if (occ) { slist[grp][pos] = off; if (active) gl[pos] = off; }
+                    base += __popc(gb);
+                }
+                cnt_list = base;
+                built = true;
+            }
+            if (active && sub == 0) cell_state[qi] = make_int4(ix, iy, iz, unclean ? -1 : cnt_list);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // slist: written and read by different lanes of the group
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__builtin_amdgcn_ballot_w64(active && unclean) != 0ull)
+            knn_full_search<R, false>(sp, bc, qx, qy, qz, active && unclean, qi, qq, k, lut, cpack, hdr[grp], nbr, nn_count, nullptr, nullptr, 0);
     }
-    cnt = (int)group_sum_u32<G>((unsigned int)cnt);
-    if (active && sub == 0) nn_count[qi] = cnt;
-
-    // k rounds of an 8-lane tournament on (d2 bits, candidate order): two 32-bit group reductions
-    // on the DPP path per round (no LDS crossbar, no 64-bit keys); lane t remembers winner t
-    int mine = -1;
-    unsigned int d_last = 0u;  // COH: distance bits of the last winner found
-    int n_win = 0;
-    for (int t = 0; t < k; ++t) {
-        unsigned int bd = d2b[0];
-        int br = 0;
-#pragma unroll
-        for (int r = 1; r < R; ++r)
-            if (d2b[r] < bd) { bd = d2b[r]; br = r; }  // strict: the lowest r (= lowest candidate) wins ties
-        const unsigned int wd = group_min_u32<G>(bd);
-        if (wd == 0xffffffffu) break;
-        d_last = wd;
-        ++n_win;
-        const unsigned int myc = bd == wd ? (unsigned int)(br * G + sub) : 0xffffffffu;
-        const unsigned int wc = group_min_u32<G>(myc);
-        if (myc == wc) {  // exactly one lane of the group
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (r == br) d2b[r] = 0xffffffffu;
-        }
-        if (sub == t) mine = (int)wc;
+    const bool go = active && !unclean;
+    // a wave in which some query has just built its list reads every list from LDS (the others copy theirs in): one code
+    // path per wave; in the steady state nobody builds and the lists come straight from memory
+    const bool from_lds = __builtin_amdgcn_ballot_w64(built) != 0ull;
+    if (from_lds) {
+        if (go && !built)
+            for (int slot = sub; slot < cnt_list; slot += G) slist[grp][slot] = gl[slot];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // lane t < k publishes record t: the winner's entry again (same bits as in the candidate pass)
+    // registers per lane this wave needs: the longest list of its eight queries
+    int rounds;
     {
-        const int cc = mine >= 0 ? mine : 0;
-        const unsigned int T = P + cpack[cc];
-        float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (mine >= 0) {
-            float4 Ew = make_float4(0.f, 0.f, 0.f, 0.f);
-            int l = -1;
-            if (!far && (int)hdr[grp][lut[T] >> 10].x >= 0) {
-                Ew = entries[knn_cell_offset(lut, hrow, T, sentinel)];
-                l = __float_as_int(Ew.w);
-            } else {
-                lookup_cell(sp, gx + bc.cand_dx[3 * cc], gy + bc.cand_dx[3 * cc + 1], gz + bc.cand_dx[3 * cc + 2], d_cur, Ew, l);
-            }
-            const float dx = Ew.x - qx, dy = Ew.y - qy, dz = Ew.z - qz;
-            rec = make_float4(-dx, -dy, -dz, __int_as_float(l));
-        }
-        if (active && sub < k) nbr[(size_t)qq * k + sub] = rec;
-        if (COH && coh_mode != 0) {
-            // what the coherent path of a later iteration needs: lane t's winner (entry offset | candidate << 24) ...
-            const bool cached = mine >= 0 && !far && (int)hdr[grp][lut[T] >> 10].x >= 0;
-            const unsigned int off = cached ? knn_cell_offset(lut, hrow, T, sentinel) : 0u;
-            const bool bad = (mine >= 0 && !cached) || off >= 0x1000000u;  // a winner from the exact probe: no entry to come back to
-            // ... and the margin.  The winners stay the winners while the query moves less than half the gap between the k-th
-            // and the (k+1)-th accepted distance; a candidate at distance s crosses the acceptance radius Rv after
-            // |s - Rv| = |d - Rv^2| / (s + Rv) >= |d - Rv^2| / (3 Rv) while s <= 2 Rv, and is more than Rv away otherwise.
-            const float Rv = sqrtf(sp.max_valid_dist2);
-            unsigned int d_next = 0xffffffffu;  // the (k+1)-th accepted distance, if the list was full
-            if (n_win == k) {
-                unsigned int bd = d2b[0];
-#pragma unroll
-                for (int r = 1; r < R; ++r) bd = min(bd, d2b[r]);
-                d_next = group_min_u32<G>(bd);
-            }
-            float m_sel = __builtin_inff();
-            if (d_next != 0xffffffffu) m_sel = 0.5f * (sqrtf(__uint_as_float(d_next)) - sqrtf(__uint_as_float(d_last)));  // half the gap
-            float m_a = __uint_as_float(group_min_u32<G>(__float_as_uint(m_acc)));  // (non-negative floats order like their bits)
-            m_a = fminf(m_a / (3.f * Rv), Rv);
-            const float r = sp.resolution;
-            const float ux = fmaf(-fx, r, qx), uy = fmaf(-fy, r, qy), uz = fmaf(-fz, r, qz);  // position inside the voxel
-            const float m_cell = fminf(fminf(fminf(ux, r - ux), fminf(uy, r - uy)), fminf(uz, r - uz));
-            // rounding of floor(q / res) and of the position inside the voxel: a few ulp of the coordinate
-            const float safety = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fmaxf(fabsf(qz), 1.f)) * 4.8e-7f + 1e-6f;
-            float m = fminf(fminf(m_sel, m_a), m_cell) - safety;
-            const bool any_bad = group_sum_u32<G>((bad || uncached) ? 1u : 0u) != 0u;
-            if (any_bad || far || !(m > 0.f)) m = 0.f;
-            if (active) {
-                coh_win[(size_t)qq * G + sub] = mine >= 0 && !bad ? (off | ((unsigned int)cc << 24)) : COH_NONE;
-                if (sub == 0) coh_state[qq] = make_float4(qx, qy, qz, m * m);
-            }
-        }
+        const unsigned int rl = go ? (unsigned int)((cnt_list + G - 1) / G) : 0u;
+        const unsigned int inv = row_min_u32(~rl);
+        const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)inv, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)inv, 16),
+                           c = (unsigned int)__builtin_amdgcn_readlane((int)inv, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)inv, 48);
+        rounds = (int)~min(min(a, b), min(c, d));
     }
+    const unsigned int* const ll = slist[grp];
+#define PIN_LISTED(RR)                                                                                                             \
+    do {                                                                                                                           \
+        if (from_lds) listed_select<RR, true>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, k, qi, qq, nbr, nn_count);  \
+        else listed_select<RR, false>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, k, qi, qq, nbr, nn_count);          \
+    } while (0)
+    if (R > 4 && rounds > 8) PIN_LISTED(R);
+    else if (R > 7 && rounds > 7) PIN_LISTED((R > 8 ? 8 : R));
+    else if (R > 6 && rounds > 6) PIN_LISTED((R > 7 ? 7 : R));
+    else if (R > 5 && rounds > 5) PIN_LISTED((R > 6 ? 6 : R));
+    else if (R > 4 && rounds > 4) PIN_LISTED((R > 5 ? 5 : R));
+    else PIN_LISTED((R > 4 ? 4 : R));
+#undef PIN_LISTED
 }
+
 }  // namespace pin
 
 using namespace pin;
@@ -516,6 +738,37 @@ extern "C" int pin_gn_knn_coherent(const pin_search_params* sp, const pin_brick_
     PIN_CHECK_ARG(coh_state && coh_win, "coherent state NULL");
     return knn_bricks(sp, bc, src, n, k, nullptr, state, cur_out, nbr_out, nn_count_out, stream, coh_state, coh_win,
                       iteration == 0 ? 1 : 2);
+}
+
+extern "C" int32_t pin_knn_list_stride(int32_t n_cand) {
+    const int rounds = cdiv(n_cand, 8);
+    return 8 * (rounds <= 4 ? 4 : rounds <= 5 ? 5 : rounds <= 8 ? 8 : rounds <= 11 ? 11 : 16);
+}
+
+extern "C" int pin_gn_knn_listed(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n, int32_t k,
+                                 const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out, int32_t* cell_state,
+                                 uint32_t* cell_list, int32_t rebuild, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(sp && bc && state && cur_out && cell_state && cell_list, "NULL pointer");
+    PIN_CHECK_ARG(n >= 0 && k >= 1 && k <= PIN_MAX_K, "bad sizes");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(src && nbr_out && nn_count_out && bc->cand_dx && bc->dir_pack, "NULL pointer");
+    PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && sp->n_cand <= 125 && bc->n_dilate >= 0 && bc->n_dilate <= 2, "bad search state");
+    float4* nbr = reinterpret_cast<float4*>(nbr_out);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(cdiv((long)n * 8, BRICK_BLOCK)), block(BRICK_BLOCK);
+    const int rounds = cdiv(sp->n_cand, 8);
+#define PIN_LAUNCH_KL(R)                                                                                                       \
+    hipLaunchKernelGGL((knn_brick_listed_kernel<R>), grid, block, 0, s, *sp, *bc, src, n, k, cur_out, nbr, nn_count_out, state, \
+                       reinterpret_cast<int4*>(cell_state), cell_list, rebuild)
+    if (rounds <= 4) PIN_LAUNCH_KL(4);
+    else if (rounds <= 5) PIN_LAUNCH_KL(5);
+    else if (rounds <= 8) PIN_LAUNCH_KL(8);
+    else if (rounds <= 11) PIN_LAUNCH_KL(11);
+    else PIN_LAUNCH_KL(16);
+#undef PIN_LAUNCH_KL
+    PIN_CHECK_LAUNCH();
+    return 0;
 }
 
 static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,

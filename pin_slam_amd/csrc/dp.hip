@@ -189,6 +189,56 @@ __global__ __launch_bounds__(256) void dp_gather_kernel(const float* __restrict_
     }
 }
 
+// ---- neighbour records of a rank's pool samples, once per call (pin_dp_own_pool + pin_dp_gather_records) ----
+// own[i] = pool row i lies in this rank's box; the rows leave in pool order with their coordinates, pool_to_own inverts the list
+__global__ __launch_bounds__(MB) void dp_own_count_kernel(const unsigned char* __restrict__ region, int n, int rank,
+                                                          int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    int total;
+    block_flag_scan(i < n && region[i] == rank, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(MB) void dp_own_scatter_kernel(const unsigned char* __restrict__ region, int n, int rank,
+                                                            const int* __restrict__ block_off, const float* __restrict__ pc,
+                                                            float* __restrict__ own_coord, int* __restrict__ pool_to_own, int cap) {
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && region[i] == rank;
+    int total;
+    const int off = block_flag_scan(f, total);
+    if (i >= n) return;
+    int pos = -1;
+    if (f) {
+        pos = block_off[blockIdx.x] + off;
+        if (pos < cap) {
+            own_coord[3 * (size_t)pos] = pc[3 * (size_t)i]; own_coord[3 * (size_t)pos + 1] = pc[3 * (size_t)i + 1];
+            own_coord[3 * (size_t)pos + 2] = pc[3 * (size_t)i + 2];
+        } else pos = -1;
+    }
+    pool_to_own[i] = pos;
+}
+// one thread per (batch, sample of this rank, neighbour): the record of the sample's pool row (16-byte records, k contiguous)
+__global__ __launch_bounds__(256) void dp_gather_records_kernel(const float4* __restrict__ rec_nbr, const int* __restrict__ rec_nn, int k,
+                                                                const int* __restrict__ pool_to_own,
+                                                                const long long* __restrict__ index_hist, int n_hist,
+                                                                const long long* __restrict__ index_new_batch,
+                                                                const long long* __restrict__ new_idx, long hist_stride,
+                                                                long new_stride, const int* __restrict__ sel, int cap, int ecap,
+                                                                const int* __restrict__ counts, float4* __restrict__ nbr_out,
+                                                                int* __restrict__ nn_out) {
+    const int b = blockIdx.y;
+    const int n_main = min(counts[2 * b], cap);
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)n_main * k) return;
+    const int j = (int)(t / k), nb = (int)(t - (long)j * k);
+    index_hist += (size_t)b * hist_stride;
+    if (index_new_batch != nullptr) index_new_batch += (size_t)b * new_stride;
+    const size_t row = drawn_row(index_hist, n_hist, index_new_batch, new_idx, sel[(size_t)b * cap + j]);
+    const int o = pool_to_own[row];  // (>= 0: the partition put this sample in this rank's box)
+    const size_t q = (size_t)b * ((size_t)cap + 6 * (size_t)ecap) + j;
+    nbr_out[q * k + nb] = rec_nbr[(size_t)o * k + nb];
+    if (nb == 0) nn_out[q] = rec_nn[o];
+}
+
 // flags[row] = row is a halo row; owner[row] = its box; the lazy optimiser's pending word of a halo row is parked
 __global__ __launch_bounds__(MB) void dp_halo_flags_kernel(pin_dp_regions rg, const float* __restrict__ pos, int n,
                                                            unsigned char* __restrict__ flags,
@@ -576,6 +626,45 @@ extern "C" int pin_dp_gather(const float* pool_coord, const float* pool_label, c
                        n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
                        (long)hist_stride, (long)new_stride, sel, cap, eik_sel, eik_cap, counts, coord_out, label_out, weight_out,
                        ts_out, color_out, query_out, eps);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_own_pool(const uint8_t* pool_region, int32_t pool_rows, int32_t rank, const float* pool_coord,
+                               float* own_coord_out, int32_t own_cap, int32_t* pool_to_own_out, int32_t* count_out,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(pool_rows >= 0 && own_cap >= 0 && rank >= 0, "bad sizes");
+    PIN_CHECK_ARG(count_out, "count_out NULL");
+    hipStream_t s = as_stream(stream);
+    if (pool_rows == 0) { PIN_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int), s)); return 0; }
+    PIN_CHECK_ARG(pool_region && pool_coord && own_coord_out && pool_to_own_out && workspace, "NULL pointer");
+    const int nb = cdiv(pool_rows, MB);
+    Carver cv{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
+    int* block_cnt = cv.take<int>(nb);
+    PIN_CHECK_ARG(block_cnt != nullptr, "workspace too small (4 bytes per 256 pool rows + 256)");
+    hipLaunchKernelGGL(dp_own_count_kernel, dim3(nb), dim3(MB), 0, s, pool_region, pool_rows, rank, block_cnt);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, count_out);
+    hipLaunchKernelGGL(dp_own_scatter_kernel, dim3(nb), dim3(MB), 0, s, pool_region, pool_rows, rank, block_cnt, pool_coord,
+                       own_coord_out, pool_to_own_out, own_cap);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_dp_gather_records(const float* rec_nbr, const int32_t* rec_nn, int32_t k, const int32_t* pool_to_own,
+                                     const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                                     const int64_t* new_idx, int64_t hist_stride, int64_t new_stride, const int32_t* sel, int32_t cap,
+                                     int32_t ecap, const int32_t* counts, int32_t n_batches, float* nbr_out, int32_t* nn_out,
+                                     void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(k >= 1 && k <= PIN_MAX_K && cap >= 0 && ecap >= 0 && n_batches >= 1 && n_history >= 0, "bad sizes");
+    if (cap == 0) return 0;
+    PIN_CHECK_ARG(rec_nbr && rec_nn && pool_to_own && sel && counts && nbr_out && nn_out && (n_history == 0 || index_history),
+                  "NULL pointer");
+    hipLaunchKernelGGL(dp_gather_records_kernel, dim3(cdiv((long)cap * k, 256), n_batches), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(rec_nbr), rec_nn, k, pool_to_own, reinterpret_cast<const long long*>(index_history),
+                       n_history, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
+                       (long)hist_stride, (long)new_stride, sel, cap, ecap, counts, reinterpret_cast<float4*>(nbr_out), nn_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

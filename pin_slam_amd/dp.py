@@ -107,6 +107,8 @@ class SpatialShards:
         self.counts_host = None
         self._ws = self._pool_region = self._halves = self._halves_host = None
         self.lists = self.offsets = self._send = self._recv = self._side = self.surf_counts = None
+        self.own_coord = self.pool_to_own = self.rec = None  # record reuse (plan(reuse_records=True))
+        self.own_cap, self.n_own = 0, None
         # end-of-call merge: "gather" = every rank publishes the rows it owns (all-gather, certainty / ts ride along, the halo's
         # side effects in compact form); "reduce" = all-reduce of the whole table + the side-effect all-reduces over every row
         self.merge = "gather"
@@ -129,7 +131,7 @@ class SpatialShards:
     def plan(self, pool_coord: torch.Tensor, hist: torch.Tensor, new: Optional[torch.Tensor], new_idx, *, decimation: int,
              eikonal: bool, resolution: float, reach: int, pos: torch.Tensor, lazy_pending: Optional[torch.Tensor],
              nd: int, pool_rows: Optional[int] = None, color_pending: Optional[torch.Tensor] = None,
-             pool_label: Optional[torch.Tensor] = None, surface_range: float = 0.0):
+             pool_label: Optional[torch.Tensor] = None, surface_range: float = 0.0, reuse_records: bool = False):
         """Everything a Mapper.mapping call needs before its first iteration: boxes from a sub-sample of the first drawn
         batch (host, one small read-back), the halo of the feature rows at `pos`, the partition of ALL drawn batches
         (hist [iters][n_hist] / new [iters][n_new] int64, as Mapper._draw_all makes them) and its counts (second
@@ -198,7 +200,8 @@ class SpatialShards:
         W1 = self.world + 1
         if self.counts is None or self.counts.shape[0] < iters:
             self.counts = torch.zeros((max(iters, 16), 2), dtype=torch.int32, device=self.device)
-            self.counts_host = torch.zeros((max(iters, 16) * 2 + 1 + W1,), dtype=torch.int32).pin_memory()
+            self.counts_host = torch.zeros((max(iters, 16) * 2 + 2 + W1,), dtype=torch.int32).pin_memory()
+            self._own_cnt = torch.zeros((1,), dtype=torch.int32, device=self.device)
         want_cap = int(n / self.world * 1.15) + 1024
         want_ecap = (int((n + decimation - 1) // decimation / self.world * 1.25) + 256) if eikonal else 0
         while True:
@@ -217,17 +220,39 @@ class SpatialShards:
                                      self.sel.data_ptr(), self.cap, self.esel.data_ptr(), ecap, self.counts.data_ptr(), pool_rows,
                                      self._pool_region.data_ptr(), pool_label.data_ptr() if want_surf else None, float(surface_range),
                                      self.surf_counts.data_ptr() if want_surf else None, s), "pin_dp_partition")
+            if reuse_records:
+                # this rank's pool samples, compacted in pool order: ONE neighbour search over them serves every iteration of the
+                # call (engine.MapTrainer.run_shards); their number comes back with the partition's counts
+                want_own = int(pool_rows / self.world * 1.3) + 4096
+                if self.own_coord is None or self.own_coord.shape[0] < want_own or self.pool_to_own.shape[0] < pool_rows:
+                    self.own_cap = max(self.own_cap, want_own)
+                    self.own_coord = torch.empty((self.own_cap, 3), dtype=torch.float32, device=self.device)
+                    self.pool_to_own = torch.empty((int(pool_rows * 1.25) + 1024,), dtype=torch.int32, device=self.device)
+                need = 4 * (pool_rows // 256 + 2) + 512
+                if self._ws.numel() < need:
+                    self._ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
+                check(L.pin_dp_own_pool(self._pool_region.data_ptr(), pool_rows, self.rank, pool_coord.data_ptr(), self.own_coord.data_ptr(),
+                                        self.own_coord.shape[0], self.pool_to_own.data_ptr(), self._own_cnt.data_ptr(), self._ws.data_ptr(),
+                                        self._ws.numel(), s), "pin_dp_own_pool")
             ch = self.counts_host
             ch[:2 * iters].copy_(self.counts[:iters].reshape(-1), non_blocking=True)
             ch[2 * iters:2 * iters + 1].copy_(self._cnt, non_blocking=True)
             ch[2 * iters + 1:2 * iters + 1 + W1].copy_(self.offsets, non_blocking=True)
+            if reuse_records:
+                ch[2 * iters + 1 + W1:2 * iters + 2 + W1].copy_(self._own_cnt, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             cnt = ch[:2 * iters].numpy().reshape(iters, 2).copy()
+            n_own = int(ch[2 * iters + 1 + W1]) if reuse_records else None
+            if n_own is not None and n_own > self.own_coord.shape[0]:
+                self.own_cap = int(n_own * 1.1) + 4096  # a clustered pool: more of it in this box than its share
+                self.own_coord = None
+                continue
             if cnt[:, 0].max(initial=0) <= self.cap and (not eikonal or cnt[:, 1].max(initial=0) <= self.ecap):
                 break
             # an unbalanced cut (a clustered pool): grow the lists and partition again
             want_cap = max(want_cap, int(cnt[:, 0].max() * 1.1) + 1024)
             want_ecap = max(want_ecap, int(cnt[:, 1].max() * 1.1) + 256) if eikonal else 0
+        self.n_own = n_own
         self.n_main, self.n_eik = cnt[:, 0].astype(int), (cnt[:, 1].astype(int) if eikonal else np.zeros(iters, int))
         self.eik_cap = ecap
         self.n_halo = int(ch[2 * iters])
@@ -321,25 +346,59 @@ class SpatialShards:
             out["ts"].data_ptr(), None if out.get("color") is None else out["color"].data_ptr(), query_all.data_ptr(),
             float(np.float32(eps)), ops._stream()), "pin_dp_gather")
 
+    def records(self, k: int):
+        """(rec_nbr [n_own][k][4], rec_nn [n_own]) buffers for the one search over this rank's pool samples."""
+        if self.rec is None or self.rec[0].shape[0] < self.n_own or self.rec[0].shape[1] != k:
+            cap = max(self.own_coord.shape[0], self.n_own)
+            self.rec = (torch.empty((cap, k, 4), dtype=torch.float32, device=self.device), torch.empty((cap,), dtype=torch.int32, device=self.device))
+        return self.rec[0][:self.n_own], self.rec[1][:self.n_own]
+
+    def gather_records(self, it0: int, gn: int, k: int, nbr_all: torch.Tensor, nn_all: torch.Tensor):
+        """The records of this rank's samples of iterations it0 .. it0 + gn - 1 into the trainer's record buffers
+        (pin_dp_gather_records); the Eikonal probes behind them are searched per iteration."""
+        hist, new = self._hist, self._new
+        n_hist = hist.shape[1]
+        n_new = 0 if new is None else new.shape[1]
+        check(_lib.lib().pin_dp_gather_records(
+            self.rec[0].data_ptr(), self.rec[1].data_ptr(), k, self.pool_to_own.data_ptr(), hist.data_ptr() + 8 * it0 * n_hist, n_hist,
+            None if new is None else new.data_ptr() + 8 * it0 * n_new, None if new is None else self._new_idx.data_ptr(), n_hist, n_new,
+            self.sel.data_ptr() + 4 * it0 * self.cap, self.cap, self.eik_cap, self.counts.data_ptr() + 8 * it0, gn, nbr_all.data_ptr(),
+            nn_all.data_ptr(), ops._stream()), "pin_dp_gather_records")
+
     # ------------------------------------------------------------------ per iteration
     def exchange(self, feats: torch.Tensor, gfeat: torch.Tensor, step: int, coef: torch.Tensor, t_max: int, b1, b2, eps,
                  on_allreduce=None, color=None):
         """After the backward pass of iteration `step`: halo gradients into the exchange buffer (its head already holds
-        the decoder gradients), ONE all-reduce, the dense Adam step on the halo rows.  color = (colour features, their
-        gradient table) of a colour map: the same rows of the second table ride in the same message."""
-        L, s = _lib.lib(), ops._stream()
-        nh = self.n_halo
-        nx = self.nd + 8 * nh * self.tables
+        the decoder gradients), ONE all-reduce, the dense Adam step on the halo rows -- all on the caller's stream.
+        color = (colour features, their gradient table) of a colour map: the same rows of the second table ride in the same
+        message.  engine.MapTrainer runs the three parts apart (pack_halo / allreduce_range / halo_step) to overlap the
+        all-reduce with work that does not depend on it."""
+        self.pack_halo(gfeat, color)
+        self.allreduce_range(0, self.nd + 8 * self.n_halo * self.tables, on_allreduce)
+        self.halo_step(feats, step, coef, t_max, b1, b2, eps, color)
+
+    def pack_halo(self, gfeat: torch.Tensor, color=None):
+        """Halo-row gradients of the feature table(s) -> the compact buffer behind the decoder gradients (rows cleared)."""
+        L, s, nh = _lib.lib(), ops._stream(), self.n_halo
         check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), nh, gfeat.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd, s),
               "pin_dp_halo_pack")
         if color is not None:
             check(L.pin_dp_halo_pack(self.halo_rows.data_ptr(), nh, color[1].data_ptr(), self.xbuf.data_ptr() + 4 * (self.nd + 8 * nh), s),
                   "pin_dp_halo_pack")
+
+    def allreduce_range(self, lo: int, hi: int, on_allreduce=None):
+        """In-place SUM all-reduce of xbuf[lo:hi] on the current stream ([0, nd) = decoder gradients, [nd, nx) = halo rows)."""
+        if hi <= lo:
+            return
         if on_allreduce is not None:
             on_allreduce(True)
-        self.comm.allreduce(self.xbuf[:nx], self.xbuf[:nx])
+        self.comm.allreduce(self.xbuf[lo:hi], self.xbuf[lo:hi])
         if on_allreduce is not None:
             on_allreduce(False)
+
+    def halo_step(self, feats: torch.Tensor, step: int, coef: torch.Tensor, t_max: int, b1, b2, eps, color=None):
+        """The same dense Adam step on the halo rows of every rank, from the summed gradients."""
+        L, s, nh = _lib.lib(), ops._stream(), self.n_halo
         check(L.pin_dp_halo_adam(self.halo_rows.data_ptr(), nh, feats.data_ptr(), self.xbuf.data_ptr() + 4 * self.nd,
                                  self.hm.data_ptr(), self.hv.data_ptr(), int(step), coef.data_ptr(), int(t_max), float(b1), float(b2),
                                  float(eps), s), "pin_dp_halo_adam")

@@ -523,8 +523,13 @@ class Mapper(_Base):
         if drawn is not None:
             b = p.bufs[0]
             gc = not self.ba_done_flag
+            # large batches: every rank searches the pool samples of its own box once per call (as _pool_records on one GPU)
+            want = getattr(self, "reuse_pool_records", None)
+            if want is None:
+                want = iter_count * c.bs >= getattr(self, "reuse_pool_records_ratio", 2.0) * p.n
             self.dp_stats = t.plan_shards(b["global_coord"] if gc else b["coord"], drawn["hist"], drawn["new"], self.new_idx,
-                                          num_nei_cells=c.num_nei_cells, pool_rows=p.n, pool_label=b["sdf_label"])
+                                          num_nei_cells=c.num_nei_cells, pool_rows=p.n, pool_label=b["sdf_label"],
+                                          reuse_records=bool(want) and not self.ba_done_flag)
             t.run_shards(b, gc, iter_count)
             self.total_iter += iter_count
         t.finish_optimizer()

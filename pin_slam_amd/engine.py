@@ -44,6 +44,11 @@ class GNTracker:
         # (1 cm) for most of the 50 iterations, and a wave only skips the full search when all its 8 queries stand still
         self.coherent = os.environ.get("PIN_KNN_COHERENT", "0") == "1"
         self._coh = None
+        # device loop, brick cache: per-query candidate lists kept across the iterations (pin_gn_knn_listed) -- while a query
+        # stays in its voxel (40 cm against centimetres of motion) an iteration gathers the ~45 occupied candidate cells it
+        # listed instead of deriving all 81 cells' entry offsets again; bit-identical records.  PIN_KNN_LISTED=0: plain search
+        self.listed = os.environ.get("PIN_KNN_LISTED", "1") != "0"
+        self._cells = None
 
     def step(self, src: torch.Tensor, T: Optional[np.ndarray], time_filtering=True, local=True, labels=None,
              color=None):
@@ -122,10 +127,20 @@ class GNTracker:
                 self._coh = (torch.empty((rows, 4), dtype=torch.float32, device=src.device),
                              torch.empty((rows, 8), dtype=torch.int32, device=src.device))
             cs_p, cw_p = (t.data_ptr() for t in self._coh)
+        listed = self.listed and bc is not None and not coh
+        if listed:
+            stride = int(L.pin_knn_list_stride(int(sp.n_cand)))
+            if self._cells is None or self._cells[0].shape[0] < n or self._cells[1].shape[1] != stride:
+                rows = self.nbr.shape[0]
+                self._cells = (torch.empty((rows, 4), dtype=torch.int32, device=src.device),
+                               torch.empty((rows, stride), dtype=torch.int32, device=src.device))
+            cell_p, list_p = (t.data_ptr() for t in self._cells)
         for it in range(iters):
             if self.on_knn:
                 self.on_knn(True)
-            if coh:  # iteration 0: the full search that leaves the coherent state; later ones use it
+            if listed:  # iteration 0 builds every query's candidate list; later ones run off it while the query keeps its voxel
+                rc = L.pin_gn_knn_listed(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, cell_p, list_p, int(it == 0), stream)
+            elif coh:  # iteration 0: the full search that leaves the coherent state; later ones use it
                 rc = L.pin_gn_knn_coherent(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, cs_p, cw_p, it, stream)
             else:
                 rc = L.pin_gn_knn(sp_r, bc_r, src_p, n, k, st_p, cur_p, nbr_p, nn_p, stream)
@@ -186,6 +201,10 @@ class MapTrainer:
         self.dp = None
         self.overlap_weight_grad = None  # None = automatic, True / False force (see step_batch)
         self._wg_stream, self._wg_ev, self._wg_pending = None, None, False
+        # spatial shards: the all-reduce of iteration i on a side stream, beside the weight gradient of iteration i and the
+        # lazy-Adam launch of iteration i + 1 (step_batch); PIN_DP_OVERLAP=0 keeps everything on one stream
+        self.overlap_exchange = os.environ.get("PIN_DP_OVERLAP", "1") != "0"
+        self._dp_stream, self._dp_ev, self._dp_pending = None, None, None
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
         self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
         self._cert0 = self._cert_scratch = None
@@ -262,7 +281,7 @@ class MapTrainer:
         self.cgdec = self.cgrad[:nd]  # (spatial shards: re-pointed at the exchange buffer by plan_shards)
 
     # ------------------------------------------------------------------ spatially sharded data-parallel mapping (dp.py)
-    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None, pool_label=None):
+    def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None, pool_label=None, reuse_records=False):
         """Start of a spatially sharded Mapper.mapping call, after reset_optimizer(): boxes, halo, this rank's samples of
         every drawn batch (SpatialShards.plan) and buffers of the size that came out."""
         dp, fs = self.dp, self.fs
@@ -274,7 +293,7 @@ class MapTrainer:
         dp.plan(pool_coord, hist, new, new_idx, decimation=self.dec, eikonal=eik, resolution=res, reach=reach, pos=fs.pos,
                 lazy_pending=self.lazy.state if self.lazy_on else None, nd=nd + cnd, pool_rows=pool_rows,
                 color_pending=self.lazy_c.state if (self.fc is not None and self.lazy_on) else None,
-                pool_label=pool_label, surface_range=getattr(self, "c_range", 0.0))
+                pool_label=pool_label, surface_range=getattr(self, "c_range", 0.0), reuse_records=bool(reuse_records))
         self.gdec = dp.xbuf[:nd]  # the decoder gradients live at the head of the exchange buffer
         if self.fc is not None:
             self.cgdec = dp.xbuf[nd:nd + cnd]
@@ -300,17 +319,26 @@ class MapTrainer:
         """The iterations of a spatially sharded call: per group one gather launch, per iteration kNN + step_batch."""
         dp, buf = self.dp, self.buf
         out = self._shard_out
+        reuse = dp.n_own is not None and dp.n_own > 0
+        if reuse:  # one search over this rank's pool samples for the whole call (the neural points do not move while the map trains)
+            rec_nbr, rec_nn = dp.records(self.fs.k)
+            ops.knn_query(self.st, dp.own_coord[:dp.n_own], self.fs.k, out=(rec_nbr, rec_nn, None), bricks=self.bricks)
         for it0 in range(0, iters, buf.group):
             gn = min(buf.group, iters - it0)
             C_color = 3 if self.fc is not None else 0
             if C_color and (pool.get("color") is None or pool["color"].shape[1] != 3):
                 raise RuntimeError("colour training needs a 3-channel colour pool")
             dp.gather(pool, global_coord, C_color, it0, gn, out if C_color else dict(out, color=None), buf.query_all, self.eik_eps)
+            if reuse:
+                dp.gather_records(it0, gn, self.fs.k, buf.nbr_all, buf.nn_all)
             for j in range(gn):
                 it = it0 + j
                 buf.set_counts(j, int(dp.n_main[it]), int(dp.n_eik[it]))
                 nm = buf.n_main
-                if nm:
+                if nm and reuse:  # the samples' records were copied: only the probes are searched
+                    if buf.n_eik:
+                        ops.knn_query(self.st, buf.query[nm:], self.fs.k, out=(buf.nbr[nm:], buf.nn[nm:], None), bricks=self.bricks)
+                elif nm:
                     ops.knn_query(self.st, buf.query, self.fs.k, out=(buf.nbr, buf.nn, None), bricks=self.bricks)
                 self.step_batch(out["coord"][j, :nm], out["label"][j, :nm], out["weight"][j, :nm], out["ts"][j, :nm], it + 1,
                                 color_label=out["color"][j, :nm] if C_color else None, queries_ready=True, knn_ready=True,
@@ -360,6 +388,25 @@ class MapTrainer:
                     self._wg_pending = False
         else:
             pre = (lambda: self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=dense)) if lazy else None
+        # Spatial shards.  Nothing of iteration i + 1 up to its forward pass depends on the exchange of iteration i except
+        # through the halo rows and the decoder: the all-reduce goes to a side stream -- first the halo rows (ready behind the tile
+        # kernel), then the decoder gradients (ready behind the weight-gradient launch, which therefore runs BESIDE the halo
+        # message) -- and the caller's stream goes on with the next iteration's search and its lazy-Adam launch (owned rows
+        # only: the decoder's step no longer rides in it); the halo rows' step and the decoder's step follow the all-reduce
+        # right in front of the next tile kernel (_dp_finish_exchange).  Same kernels, same operands, same order per datum.
+        dp_overlap = bool(self.dp is not None and lazy and self.overlap_exchange and self.on_grads is None)
+        dp_defer = False
+        if dp_overlap:
+            main = torch.cuda.current_stream()
+            if self._dp_stream is None:
+                self._dp_stream = torch.cuda.Stream(device=self.fs.feats.device)
+                self._dp_ev = (torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+            dp_defer = bool(self.train_decoder and (self.fs.weighted_first or self.fs.levels == 1) and coord.shape[0] > 0
+                            and os.environ.get("PIN_MLP", "") != "f32")
+
+            def pre():
+                self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=None)
+                self._dp_finish_exchange()
         if self.dp is not None and coord.shape[0] == 0:
             # none of this batch's samples fell into this rank's box: its rows settle nothing, the decoder still takes its
             # step (the dense rider of the lazy launch) and the exchange below still runs -- the other ranks wait in it
@@ -371,7 +418,7 @@ class MapTrainer:
                            sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                            loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
                            bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
-                           knn_ready=knn_ready, defer_weight_grad=overlap)
+                           knn_ready=knn_ready, defer_weight_grad=overlap or dp_defer)
         if overlap:
             self._wg_ev[0].record(main)
             side = self._wg_stream
@@ -397,6 +444,24 @@ class MapTrainer:
                                    eps=self.adam_eps)
                 if self.c_train_dec:
                     ops.adam_step(self.fc.dec, self.cgdec, self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
+        if dp_overlap:
+            dpx, side, (ev_a, ev_a2, ev_b) = self.dp, self._dp_stream, self._dp_ev
+            color = None if self.fc is None else (self.fc.feats, self.cgrad[self.fc.dec.numel():])
+            dpx.pack_halo(self.gfeat, color)
+            ev_a.record(main)
+            side.wait_event(ev_a)
+            with torch.cuda.stream(side):
+                dpx.allreduce_range(dpx.nd, dpx.nd + 8 * dpx.n_halo * dpx.tables, self.on_allreduce)
+            if dp_defer:
+                ops.train_weight_grad(self.buf, self.gdec)  # beside the halo message
+            ev_a2.record(main)
+            side.wait_event(ev_a2)
+            with torch.cuda.stream(side):
+                dpx.allreduce_range(0, dpx.nd)
+                ev_b.record(side)
+            self._dp_pending = (step, dense if self.train_decoder else None)
+            self.total_iter += 1
+            return
         if self.dp is not None:  # spatial shards: [decoder | halo rows] all-reduced, the halo rows' Adam step right behind
             self.dp.exchange(self.fs.feats, self.gfeat, step, self.lazy.coef, self.lazy.t_max, self.lazy.b1, self.lazy.b2,
                              self.lazy.eps, on_allreduce=self.on_allreduce,
@@ -423,6 +488,18 @@ class MapTrainer:
         if self.train_decoder and not lazy:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
+
+    def _dp_finish_exchange(self):
+        """Behind the all-reduce of the last iteration (side stream): the halo rows' Adam step and the decoder's."""
+        if self._dp_pending is None:
+            return
+        step_prev, dense_prev = self._dp_pending
+        torch.cuda.current_stream().wait_event(self._dp_ev[2])
+        color = None if self.fc is None else (self.fc.feats, self.cgrad[self.fc.dec.numel():])
+        self.dp.halo_step(self.fs.feats, step_prev, self.lazy.coef, self.lazy.t_max, self.lazy.b1, self.lazy.b2, self.lazy.eps, color)
+        if dense_prev is not None:
+            self.lazy.step_dense(dense_prev, step_prev)
+        self._dp_pending = None
 
     @staticmethod
     def _dense(fs: ops.FieldState, grad, m, v, lazy: bool):
@@ -485,6 +562,9 @@ class MapTrainer:
         if self._wg_pending:  # the side stream took the decoder through every step already (step_batch)
             torch.cuda.current_stream().wait_event(self._wg_ev[1])
             self._wg_pending = False
+            dense = None
+        if self._dp_pending is not None:  # (spatial shards, overlapped exchange: the last iteration's halo / decoder steps)
+            self._dp_finish_exchange()
             dense = None
         stepped = self.lazy.t > 0
         self.lazy.flush(self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], dense=dense)

@@ -565,6 +565,7 @@ class LazyAdam:
             self.state.zero_()
         self.coef, self.t_max = adam_coef(self.lr, t_max, self.b1, self.b2, device)
         self.t = 0
+        self.rows_launches = 0  # prepare() calls of this lifetime that took the row-parallel form (tests read it)
 
     @staticmethod
     def _dense(dense):
@@ -595,6 +596,7 @@ class LazyAdam:
                                                         self.b1, self.b2, self.eps, C.byref(d) if d is not None else None, _stream()),
                   "pin_adam_lazy_prepare_rows")
             self.t = int(step)
+            self.rows_launches += 1
             return
         check(_lib.lib().pin_adam_lazy_prepare(_ptr(nbr, torch.float32), nbr.numel() // 4, _ptr(param, torch.float32),
                                                _ptr(grad, torch.float32), _ptr(m, torch.float32), _ptr(v, torch.float32),

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--reg-iters", type=int, default=50)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_ref_cpu_baseline.json"))
     ap.add_argument("--host-label", default="", help="what to call this machine in the record (e.g. 'gpu box (MI355X host)')")
+    ap.add_argument("--skip-tracking", action="store_true", help="do not time Tracker.tracking (a thread-count sweep needs the two "
+                                                                 "quantities of the frame only)")
     ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0 = torch's default for this host)")
     a = ap.parse_args()
     if a.threads > 0:
@@ -145,10 +147,11 @@ def main():
     out["mapping_iterations"] = a.map_iters
     out["mapper_samples_per_sec"] = round(a.bs * a.map_iters / t, 1)
     print("mapping", out["mapping_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
-    t, all_ = timed(tracking, a.reps)
-    out["tracking_ms"] = round(t * 1e3, 1)
-    out["tracking_note"] = "Tracker.tracking with its own convergence test (it may stop before reg_iter_n iterations)"
-    print("tracking", out["tracking_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
+    if not a.skip_tracking:
+        t, all_ = timed(tracking, a.reps)
+        out["tracking_ms"] = round(t * 1e3, 1)
+        out["tracking_note"] = "Tracker.tracking with its own convergence test (it may stop before reg_iter_n iterations)"
+        print("tracking", out["tracking_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
     # the bench's frame: reg_iters GN steps without early exit over the whole scan + map_iters mapping iterations
     frame_s = a.reg_iters * out["registration_step_ms"] / 1e3 + out["mapping_ms"] / 1e3
     out["frames_per_sec_bench_definition"] = round(1.0 / frame_s, 5)

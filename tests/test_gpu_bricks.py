@@ -139,3 +139,63 @@ def test_coherent_search_equals_full_search(case, scale):
         assert coherent_share[-1] > 0.8, coherent_share
     else:
         assert 0.0 < max(coherent_share) and min(coherent_share[1:]) < 0.9, coherent_share
+
+
+@pytest.mark.parametrize("case,scale", [("c2_wf", 1.0), ("kitti_nwf", 1.0), ("c3_bigtable", 1.0), ("c2_wf", 30.0)])
+def test_listed_search_equals_full_search(case, scale):
+    """pin_gn_knn_listed (candidate lists kept across the iterations of a registration; what Tracker.tracking launches): over a
+    Gauss-Newton-like sequence of poses -- `scale` 30: steps of up to 1.5 m, so queries change voxel all the time and lists are
+    rebuilt mid-sequence -- every iteration's records, counts and transformed points are the bits of a full search under the
+    same pose; the lists are used (the voxel stored with a list follows the query only when it changes voxel)."""
+    import ctypes as C
+    from pin_slam_amd import _lib, ops
+    from tests import gpu_util as U
+    d = G.load(case)
+    st = U.search_state(d)
+    k = int(d["query_nn_k"])
+    bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(st, wait=True)
+    rng = np.random.default_rng(4)
+    far_out = np.array([[1e4, 0, 0], [0, -1e4, 3.0]], np.float32)  # nothing near: empty lists
+    src_np = np.concatenate([d["reg_src"], d["query"], far_out,
+                             (d["local_neural_points"][::2] + rng.normal(0, 0.2, d["local_neural_points"][::2].shape))]).astype(np.float32)
+    src = U.dev(src_np)
+    n = src.shape[0]
+    L = _lib.lib()
+    sp, bc = st.params(time_filtering=True, local=True), bricks.params()
+    stride = int(L.pin_knn_list_stride(int(sp.n_cand)))
+    assert stride >= int(sp.n_cand)
+    nbr = torch.empty((n, k, 4), dtype=torch.float32, device="cuda")
+    nn = torch.empty((n,), dtype=torch.int32, device="cuda")
+    cur = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    cells = torch.full((n, 4), 123456, dtype=torch.int32, device="cuda")
+    lists = torch.zeros((n, stride), dtype=torch.int32, device="cuda")
+    state = torch.zeros(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device="cuda")
+    T = np.eye(4)
+    moved = []
+    for it in range(14):
+        step = scale * 0.05 * 0.35 ** it
+        ang = step * 0.02
+        dT = np.eye(4)
+        dT[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+        dT[:3, 3] = step * np.array([0.6, -0.5, 0.3])
+        T = dT @ T
+        state[:16] = torch.from_numpy(T.reshape(-1)).cuda()
+        before = cells.clone()
+        _lib.check(L.pin_gn_knn_listed(C.byref(sp), C.byref(bc), src.data_ptr(), n, k, state.data_ptr(), cur.data_ptr(),
+                                       nbr.data_ptr(), nn.data_ptr(), cells.data_ptr(), lists.data_ptr(), int(it == 0),
+                                       ops._stream()), "pin_gn_knn_listed")
+        ref_nbr, ref_nn, ref_cur = ops.knn_query(st, src, k, pose=T, bricks=bricks)
+        assert torch.equal(cur, ref_cur)
+        assert torch.equal(nn, ref_nn), f"nn_count differs at iteration {it}"
+        assert torch.equal(nbr.view(torch.int32), ref_nbr.view(torch.int32)), f"kNN record differs at iteration {it}"
+        # the stored voxel is the query's voxel; the stored length counts the occupied candidate cells (>= the accepted ones)
+        vox = torch.floor(cur / np.float32(d["resolution"])).to(torch.int32)
+        assert torch.equal(cells[:, :3], vox)
+        has = cells[:, 3] >= 0
+        assert bool((cells[has, 3] >= nn[has]).all()) and bool((cells[:, 3] >= -1).all())
+        moved.append(float((before[:, :3] != cells[:, :3]).any(1).float().mean().item()))
+    assert moved[0] == 1.0
+    if scale == 1.0:
+        assert max(moved[4:]) < 0.01, moved  # millimetre steps: (almost) nobody changes voxel, every search runs off its list
+    else:
+        assert moved[1] > 0.5 and moved[-1] < 0.01, moved
