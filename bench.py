@@ -128,6 +128,14 @@ def parse():
                          "checks the launcher of `--gpus N`")
     ap.add_argument("--c4-iters", type=int, default=12, help="N = 1: iterations per timed Mapper.mapping call of the "
                                                               "single-GPU C4 leg and of the emulated ranks (0 = skip them)")
+    ap.add_argument("--moving-steps", type=int, default=10,
+                    help="N = 1: frames of the moving-sensor leg reported beside the static workload (the sensor advances "
+                         "--moving-m metres per frame along x, every frame has its own scan, NeuralPoints.update appends the "
+                         "newly seen surface and the brick cache changes; 0 = skip)")
+    ap.add_argument("--moving-m", type=float, default=0.5)
+    ap.add_argument("--mesher-queries", type=int, default=10_000_000,
+                    help="N = 1: grid points of the Mesher.query_points leg (forward-only SDF + mask over a dense grid, "
+                         "mesher.py:40-164; 0 = skip)")
     ap.add_argument("--skip-downsampled", action="store_true",
                     help="skip the second timed leg (registering the source-down-sampled subset): profiles of this "
                          "command then hold one launch shape per tracker kernel")
@@ -227,7 +235,7 @@ def main():
         args.scan = wl["scan"]
     mapper_dp = (world > 1 or args.force_dp) and args.parallel == "dp"
     res = wl["cfg"]["voxel_size_m"]
-    n_frames = args.warmup + 2 * args.steps + 4
+    n_frames = args.warmup + 2 * args.steps + 4 + args.moving_steps + 2
     cfg = PinConfig(buffer_size=int(5e7), feature_std=0.1, bs=args.global_bs if mapper_dp else args.bs, iters=args.map_iters,
                     local_map_travel_dist_ratio=5.0, pool_capacity=args.pool, pool_filter_freq=1, bs_new_sample=2048,
                     geo_mlp_level=L, geo_mlp_hidden_dim=H, color_mlp_level=L, color_mlp_hidden_dim=H,
@@ -375,7 +383,7 @@ def main():
     stage_events = []  # per timed frame: 5 events at the stage boundaries (no host sync between the stages)
     host_marks = []    # per timed frame: host clock at the same boundaries (how long the host takes to ENQUEUE a stage)
 
-    def frame(timed, hooks=(None, None), source_downsampled=False):
+    def frame(timed, hooks=(None, None), source_downsampled=False, raw=raw, T_init=T_init, pose_t=pose_t, sink=stage_events):
         fid = state["fid"]
         state["fid"] += 1
         ds.processed_frame = fid
@@ -408,8 +416,9 @@ def main():
         hm.append(time.perf_counter())
         if ev:
             ev[4].record()
-            stage_events.append(ev)
-            host_marks.append(hm)
+            sink.append(ev)
+            if sink is stage_events:
+                host_marks.append(hm)
         stats["last"] = (T, cnt, res_cm, its, reg.shape[0], gn)
 
     for i in range(args.warmup):
@@ -445,13 +454,26 @@ def main():
         barrier()
         elapsed_ds = time.perf_counter() - t0
 
-    # the GPU side of the parity check (the oracle side runs in cpu_baseline_and_parity, outside every timed region):
-    # the benchmarked kernels -- brick kNN + the GN tile kernel -- on a sub-sample of the timed scan, against the
-    # map as it stands after the timed frames
+    # parity is taken on the map as the static workload leaves it; the moving-sensor leg below changes the map, so the device
+    # side of the parity check comes first
     parity_in = None
     if rank == 0 and world == 1 and not args.no_parity:
         parity_in = gpu_parity_sample(npts, dec, trk, gp, state["xyz"], k, rgb=state["rgb"], mp=mp, cdec=cdec)
 
+    # the same frame with a MOVING sensor (VERDICT r3 missing #5): the pose advances --moving-m per frame, every frame has its
+    # own scan of the surface around the new position, so NeuralPoints.update appends the newly seen surface, the table takes
+    # inserts, the local map and the brick cache change -- the static workload above never exercises that inside a timed frame
+    moving = None
+    if world == 1 and args.moving_steps > 0 and args.stages == "all" and not colour:
+        moving = bench_moving(args, wl, m, cfg, npts, mp, frame, barrier, names, P, scan_np)
+
+    mesher_leg = None
+    if world == 1 and args.mesher_queries > 0 and not colour:
+        mesher_leg = bench_mesher(args, cfg, npts, decoders, nn_mean, int(npts.neighbor_K), k)
+
+    # the GPU side of the parity check (the oracle side runs in cpu_baseline_and_parity, outside every timed region):
+    # the benchmarked kernels -- brick kNN + the GN tile kernel -- on a sub-sample of the timed scan, against the
+    # map as it stands after the timed frames
     # achievable HBM ceiling on this box: a 1 GiB device-to-device copy (read + write), outside the timed regions
     ca = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
     cb = torch.empty_like(ca)
@@ -533,6 +555,8 @@ def main():
         "source_points": n_src,
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
         "knn_coherent_probe": probe,
+        "moving_sensor": moving,
+        "mesher": mesher_leg,
         "c4_single_gpu": c4,
         "c4_per_rank_emulated": c4_emul,
         "roofline": {"kernel": ("gn_accumulate_quad_kernel<COLOR> (SDF + colour decoders on two split-fp16 images, photometric rows)"
@@ -614,6 +638,109 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
+    """Mesher.query_points (utils/mesher.py:40-164) over a dense regular grid: the forward-only bulk query of the reconstruction
+    step (SDF + marching-cubes mask, global map, batches of config.infer_bs), through the drop-in class.  Two numbers: the call
+    as the reference defines it (numpy arrays come back: the device -> host copy of the results is inside) and the device part
+    alone (search + decode launches between two events)."""
+    from pin_slam_amd.dropin.utils.mesher import Mesher
+    n = int(args.mesher_queries)
+    step = 0.1 * cfg.voxel_size_m / 0.4
+    nz = 64
+    side = int(np.ceil(np.sqrt(n / nz)))
+    ax = (torch.arange(side, device="cuda", dtype=torch.float32) - side / 2) * step
+    az = torch.arange(nz, device="cuda", dtype=torch.float32) * step + (-2.0 + 0.8 * 6)  # a slab around sheets 6 .. 14
+    coord = torch.stack(torch.meshgrid(ax, ax, az, indexing="ij"), -1).reshape(-1, 3)[:n].contiguous()
+    n = coord.shape[0]
+    ms = Mesher(cfg, npts, decoders)
+    bs = int(cfg.infer_bs)
+    ms.query_points(coord[:bs], bs, True, False, False, True, False, out_torch=True)  # warm-up (launch shapes, workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sdf, _, _, mask = ms.query_points(coord, bs, True, False, False, True, False, out_torch=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the device part alone: the same launches without the result copy
+    fs = npts.field_state(decoders["sdf"], query_locally=False)
+    from pin_slam_amd import ops
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for a in range(0, n, bs):
+        q = coord[a:a + bs]
+        nbr, nn, _ = npts.knn(q, False)
+        ops.sdf_query(fs, q, nbr, nn, grad=False, std=False, certainty=False)
+    e1.record()
+    torch.cuda.synchronize()
+    dev_ms = e0.elapsed_time(e1)
+    rho = nn_mean / Kc
+    bytes_q = 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4 + 36 * k + 4  # search (as roofline_knn) + k feature rows + the SDF out
+    return {"queries": n, "grid_step_m": round(step, 4), "batch": bs, "ms_call": round(1e3 * dt, 2),
+            "queries_per_sec_call": round(n / dt, 1), "ms_device": round(dev_ms, 2), "queries_per_sec_device": round(n / (dev_ms * 1e-3), 1),
+            "valid_share": round(float(mask.float().mean().item()), 4),
+            "roofline": {"kernel": "knn_query_kernel (direct probe of the global table) + sdf_query kernel", "bound": "hbm (random 4 / 16 / 32-byte "
+                         "accesses)", "achieved": round(bytes_q * n / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(bytes_q * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_query": round(bytes_q, 1),
+                         "traffic": None},
+            "note": "ms_call = Mesher.query_points as the reference defines it (results returned on the host); ms_device = its "
+                    "search + decode launches alone"}
+
+
+def bench_moving(args, wl, m, cfg, npts, mp, frame, barrier, names, P0, scan0):
+    """`--moving-steps` frames of the same pipeline with the sensor advancing `--moving-m` metres per frame along +x: scan f is
+    taken on the map's middle sheet in a disc around the sensor's position (synth.disc_points, so it reaches past the rim of
+    the pre-built map on the leading side), handed over in the sensor frame; registration starts from the true pose perturbed
+    as in the static workload; Mapper.process_frame gets the true pose, so NeuralPoints.update appends the surface seen for
+    the first time and reset_local_map + the brick build follow the sensor.  Scans are generated and uploaded before the
+    timed region."""
+    from pin_slam_amd import hostcache, synth
+    nf = args.moving_steps + 2
+    rng = np.random.default_rng(77)
+    res = wl["cfg"]["voxel_size_m"]
+    ang = 0.003
+    dT = np.eye(4)
+    dT[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+    dT[:3, 3] = np.array([0.05, -0.04, 0.02]) * (res / 0.4)
+    raws, poses, inits = [], [], []
+    for f in range(nf):
+        c = np.array([args.moving_m * (f + 1), 0.0, 0.0])
+        pts, _ = synth.disc_points(rng, args.scan, m.radius * 0.95, [m.layers // 2], center=(c[0], c[1]), sheets=m.sheets)
+        pts = (pts + wl.get("scan_noise", 0.02) * rng.standard_normal(pts.shape)).astype(np.float32)
+        local = (pts - c.astype(np.float32)).astype(np.float32)  # sensor frame (the pose is a pure translation)
+        raws.append(torch.from_numpy(np.concatenate([local, rng.random((args.scan, 1), dtype=np.float32)], 1)).cuda())
+        T = np.eye(4)
+        T[:3, 3] = c
+        poses.append(T)
+        inits.append(T @ dT)
+    torch.cuda.synchronize()
+    sink = []
+    n_before = npts.count()
+
+    def run(f, timed):
+        pt = torch.tensor(poses[f], dtype=torch.float64, device="cuda")
+        hostcache.remember(pt, poses[f])  # (as the tracker does for the pose it hands to process_frame)
+        frame(timed, raw=raws[f], T_init=inits[f], pose_t=pt, sink=sink)
+
+    for f in range(2):
+        run(f, False)
+    barrier()
+    grown_warm = npts.count() - n_before
+    t0 = time.perf_counter()
+    for f in range(2, nf):
+        run(f, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    steps = nf - 2
+    stage = {n: round(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in sink])), 3) for i, n in enumerate(names)}
+    worst = {n: round(float(np.max([e[i].elapsed_time(e[i + 1]) for e in sink])), 3) for i, n in enumerate(names)}
+    return {"frames_per_sec": round(steps / dt, 3), "ms_per_frame": round(1e3 * dt / steps, 3), "steps": steps,
+            "metres_per_frame": args.moving_m, "stage_ms_per_frame": stage, "stage_ms_worst_frame": worst,
+            "neural_points_before": int(n_before), "neural_points_after": int(npts.count()),
+            "points_appended_per_timed_frame": round((npts.count() - n_before - grown_warm) / max(steps, 1), 1),
+            "local_points": int(npts.local_count()),
+            "note": "same frame definition as `value`; the sensor moves, every frame has its own scan, the map grows and the "
+                    "local map / brick cache follow the sensor"}
 
 
 def gpu_parity_sample(npts, dec, trk, gp, xyz, k, n=4096, rgb=None, mp=None, cdec=None, n_train=2048):

@@ -46,6 +46,30 @@ __device__ __forceinline__ unsigned int group_sum_u32(unsigned int v) {
     return v;
 }
 
+// XCD-aware block order (MI355X: 8 XCDs with their own 4 MB L2; block b is dispatched to XCD b % 8).  The source points of
+// a registration are Morton-ordered, so a CONTIGUOUS range of queries is a compact piece of space: logical block
+// (b & 7) * per + (b >> 3), per = ceil(blocks / 8), gives XCD x the x-th eighth of the queries -- its L2 then holds one
+// eighth of the bricks' entries / the candidate lists / the feature rows instead of a slice of everything, and the records
+// this launch writes stay in the L2 of the XCD whose tile-kernel blocks read them next (gn_quad.h uses the same split).
+// Launch 8 * per blocks; blocks whose logical index is past the end leave at once.
+// (PIN_XCD=0 in the environment turns the mapping off for A/B runs: every translation unit that uses it keeps its own copy of
+// the switch, set once by xcd_mode_init() from its launchers)
+static __device__ int g_xcd_on = 1;
+static inline int xcd_mode_init() {
+    static const int done = [] {
+        const char* e = getenv("PIN_XCD");
+        const int on = !(e && e[0] == '0');
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_on), &on, sizeof(int)) == hipSuccess ? 1 : -1;
+    }();
+    return done;
+}
+__device__ __forceinline__ int xcd_logical_block(int b, int n_blocks) {
+    if (!g_xcd_on) return b;
+    const int per = (n_blocks + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+static inline int xcd_grid(int n_blocks) { return 8 * ((n_blocks + 7) / 8); }
+
 __device__ __forceinline__ unsigned long long brick_key(int bx, int by, int bz) {
     return ((unsigned long long)(unsigned)(bx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(by + (1 << 20)) << 21) |
            (unsigned long long)(unsigned)(bz + (1 << 20));

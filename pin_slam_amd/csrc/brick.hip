@@ -434,7 +434,9 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
     const int wlane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned short* const lut = lut_all[wv];
     unsigned int* const cpack = cpack_all[wv];
-    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
+    const int lb = xcd_logical_block(blockIdx.x, (n * G + BRICK_BLOCK - 1) / BRICK_BLOCK);
+    if ((long)lb * (BRICK_BLOCK / G) >= n) return;  // (the grid is rounded up to a multiple of 8 blocks)
+    const int qi = (lb * BRICK_BLOCK + threadIdx.x) / G;
     bool active = qi < n;
     const int qq = active ? qi : n - 1;
     float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
@@ -479,10 +481,11 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_kernel(pin_search_param
 // The listed search proper: RR registers per lane, straight-line.  Slot r * 8 + sub of the query's list (candidate order) is
 // lane `sub`'s register r; the tournament is the full search's -- ties go to the lowest register, then to the lowest slot, i.e.
 // to the lowest candidate.
-template <int RR, bool FROM_LDS>
+template <int RR, int SPEC, bool FROM_LDS>
 __device__ __forceinline__ void listed_select(const pin_search_params& sp, const float4* __restrict__ entries, const unsigned int sentinel,
                                               const float qx, const float qy, const float qz, const bool go, const int cnt_list,
-                                              const unsigned int* const ll, const unsigned int* __restrict__ const gl, const int k,
+                                              const unsigned int* const ll, const unsigned int* __restrict__ const gl,
+                                              const unsigned int (&spec)[SPEC > 0 ? SPEC : 1], const int k,
                                               const int qi, const int qq, float4* __restrict__ nbr, int* __restrict__ nn_count) {
     constexpr int G = 8;
     const int sub = threadIdx.x & (G - 1);
@@ -492,7 +495,8 @@ __device__ __forceinline__ void listed_select(const pin_search_params& sp, const
         const int slot = r * G + sub;
         const bool has = go && slot < cnt_list;
         const int sl = has ? slot : 0;
-        const unsigned int o = FROM_LDS ? ll[sl] : gl[sl];
+        // (memory lists: the first SPEC registers were requested at the top of the kernel)
+        const unsigned int o = FROM_LDS ? ll[sl] : (r < SPEC ? spec[r] : gl[sl]);
         offs[r] = has ? o : sentinel;
     }
     float4 E[RR];
@@ -548,7 +552,7 @@ __device__ __forceinline__ void listed_select(const pin_search_params& sp, const
 // the same winner: the record is the full search's, bit for bit (tests/test_gpu_bricks.py).  A query that has changed voxel
 // rebuilds its list (the set-up and candidate pass of the full search, then the listed search); queries near uncached bricks
 // (map border, overflowed cache) or absurdly far out keep taking the full search with its exact probe.
-template <int R>
+template <int R, int SPEC_MAX>
 __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_search_params sp, pin_brick_cache bc,
                                                                        const float* __restrict__ query, int n, int k,
                                                                        float* __restrict__ query_out, float4* __restrict__ nbr,
@@ -567,7 +571,9 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_searc
     const int nd = bc.n_dilate;
     const int sub = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     const int wlane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qi = (blockIdx.x * BRICK_BLOCK + threadIdx.x) / G;
+    const int lb = xcd_logical_block(blockIdx.x, (n * G + BRICK_BLOCK - 1) / BRICK_BLOCK);
+    if ((long)lb * (BRICK_BLOCK / G) >= n) return;  // (the grid is rounded up to a multiple of 8 blocks)
+    const int qi = (lb * BRICK_BLOCK + threadIdx.x) / G;
     const bool active = qi < n;
     const int qq = active ? qi : n - 1;
     float qx = query[3 * qq + 0], qy = query[3 * qq + 1], qz = query[3 * qq + 2];
@@ -587,6 +593,18 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_searc
     const bool far = !(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim);
     const int ix = far ? 0 : (int)fx, iy = far ? 0 : (int)fy, iz = far ? 0 : (int)fz;
     const int4 cs = rebuild ? make_int4(0, 0, 0, -2) : cell_state[qq];
+    // The wave's dependent memory round trips, not its instructions, set the pace of this kernel (a wave holds 8 queries and a
+    // SIMD 7 waves): the first SPEC registers' worth of the list is requested together with the voxel it belongs to, before
+    // anybody knows whether the list is still valid or how long it is (the rows are allocated in full: any slot may be read)
+    constexpr int SPEC = R < SPEC_MAX ? R : SPEC_MAX;
+    unsigned int spec[SPEC > 0 ? SPEC : 1];
+    if (!rebuild) {
+#pragma unroll
+        for (int r = 0; r < SPEC; ++r) spec[r] = cell_list[(size_t)qq * CAP + r * G + sub];
+    } else {
+#pragma unroll
+        for (int r = 0; r < SPEC; ++r) spec[r] = 0u;
+    }
     // cs.w: >= 0 = length of the list of voxel (x, y, z); -1 = this voxel's search needs the exact probe; -2 = nothing yet
     const bool same = !far && cs.x == ix && cs.y == iy && cs.z == iz;
     bool listed = same && cs.w >= 0;       // serve from the stored list
@@ -665,10 +683,10 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_searc
         rounds = (int)~min(min(a, b), min(c, d));
     }
     const unsigned int* const ll = slist[grp];
-#define PIN_LISTED(RR)                                                                                                             \
-    do {                                                                                                                           \
-        if (from_lds) listed_select<RR, true>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, k, qi, qq, nbr, nn_count);  \
-        else listed_select<RR, false>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, k, qi, qq, nbr, nn_count);          \
+#define PIN_LISTED(RR)                                                                                                                   \
+    do {                                                                                                                                 \
+        if (from_lds) listed_select<RR, SPEC, true>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, spec, k, qi, qq, nbr, nn_count);  \
+        else listed_select<RR, SPEC, false>(sp, entries, sentinel, qx, qy, qz, go, cnt_list, ll, gl, spec, k, qi, qq, nbr, nn_count);          \
     } while (0)
     if (R > 4 && rounds > 8) PIN_LISTED(R);
     else if (R > 7 && rounds > 7) PIN_LISTED((R > 8 ? 8 : R));
@@ -756,11 +774,20 @@ extern "C" int pin_gn_knn_listed(const pin_search_params* sp, const pin_brick_ca
     PIN_CHECK_ARG(sp->n_points > 0 && sp->n_cand > 0 && sp->n_cand <= 125 && bc->n_dilate >= 0 && bc->n_dilate <= 2, "bad search state");
     float4* nbr = reinterpret_cast<float4*>(nbr_out);
     hipStream_t s = as_stream(stream);
-    const dim3 grid(cdiv((long)n * 8, BRICK_BLOCK)), block(BRICK_BLOCK);
+    xcd_mode_init();
+    const dim3 grid(xcd_grid(cdiv((long)n * 8, BRICK_BLOCK))), block(BRICK_BLOCK);
     const int rounds = cdiv(sp->n_cand, 8);
-#define PIN_LAUNCH_KL(R)                                                                                                       \
-    hipLaunchKernelGGL((knn_brick_listed_kernel<R>), grid, block, 0, s, *sp, *bc, src, n, k, cur_out, nbr, nn_count_out, state, \
-                       reinterpret_cast<int4*>(cell_state), cell_list, rebuild)
+    // (PIN_KNN_SPEC=0: no speculative list loads -- one more dependent round trip per wave, 8 registers fewer)
+    static const bool spec_on = [] { const char* e = getenv("PIN_KNN_SPEC"); return e && e[0] == '1'; }();
+#define PIN_LAUNCH_KL(R)                                                                                                                \
+    do {                                                                                                                                \
+        if (spec_on)                                                                                                                    \
+            hipLaunchKernelGGL((knn_brick_listed_kernel<R, 8>), grid, block, 0, s, *sp, *bc, src, n, k, cur_out, nbr, nn_count_out, state, \
+                               reinterpret_cast<int4*>(cell_state), cell_list, rebuild);                                                \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((knn_brick_listed_kernel<R, 0>), grid, block, 0, s, *sp, *bc, src, n, k, cur_out, nbr, nn_count_out, state, \
+                               reinterpret_cast<int4*>(cell_state), cell_list, rebuild);                                                \
+    } while (0)
     if (rounds <= 4) PIN_LAUNCH_KL(4);
     else if (rounds <= 5) PIN_LAUNCH_KL(5);
     else if (rounds <= 8) PIN_LAUNCH_KL(8);
@@ -787,7 +814,8 @@ static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, co
     hipStream_t s = as_stream(stream);
     // eight lanes per query (the per-query setup and the k selection rounds are shared by 8 queries per wave)
     PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 2 && sp->n_cand <= 125, "the brick cache covers num_nei_cells <= 2");
-    const dim3 grid(cdiv((long)n * 8, BRICK_BLOCK)), block(BRICK_BLOCK);
+    xcd_mode_init();
+    const dim3 grid(xcd_grid(cdiv((long)n * 8, BRICK_BLOCK))), block(BRICK_BLOCK);
     const int rounds = cdiv(sp->n_cand, 8);
     float4* cst = reinterpret_cast<float4*>(coh_state);
 #define PIN_LAUNCH_KB(R)                                                                                                         \

@@ -327,8 +327,19 @@ __global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f,
     // running sums: lane (n, g) keeps sums i = 4j + g (j = 0..7) of ITS queries; one row reduction at the end
     float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool staged = false;
-    for (int tile = simd + n_simd * (wave >> 2);; tile += n_simd * (BLK / 256)) {
-        const bool work = tile < n_tiles;
+    // XCD-aware tile order (brick.h, xcd_logical_block): with a grid of a multiple of 8 blocks, XCD x = blockIdx.x & 7 takes the
+    // x-th eighth of the (Morton-ordered) queries -- the range whose records the search kernel's blocks on that XCD have just
+    // written -- and deals it out over its own SIMDs; otherwise the tiles are dealt out over all SIMDs as before
+    int tile0 = simd + n_simd * (wave >> 2), tile_step = n_simd * (BLK / 256), tile_end = n_tiles;
+    if ((gridDim.x & 7) == 0 && g_xcd_on) {
+        const int per_xcd = 2 * ((((n_q + 31) >> 5) + 7) >> 3);  // tiles of 8-lanes-per-query search blocks (32 queries = 2 tiles)
+        const int x = blockIdx.x & 7, ls = (blockIdx.x >> 3) * 4 + (wave & 3), ns = (gridDim.x >> 3) * 4;
+        tile0 = x * per_xcd + ls + ns * (wave >> 2);
+        tile_step = ns * (BLK / 256);
+        tile_end = min(n_tiles, (x + 1) * per_xcd);
+    }
+    for (int tile = tile0;; tile += tile_step) {
+        const bool work = tile < tile_end;
         if (!work && staged) break;
         const int qi = (work ? tile : 0) * 16 + nq;
         const bool active = qi < n_q;

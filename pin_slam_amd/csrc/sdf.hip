@@ -658,6 +658,7 @@ static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const fl
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 16);
+    xcd_mode_init();
     const dim3 grid(min(gq_cu_count(), tiles)), block(BLK);  // all CUs, even when there are fewer tiles than waves
     ColorTerm none;
     memset(&none, 0, sizeof(none));

@@ -179,7 +179,9 @@ def test_large_batch_mapping_call_end_state_vs_oracle(scale_case):
     """One GPU: Mapper.mapping(2) at 2^17 (c3) / 2^16 (c5, colour) samples -- record reuse, rows-form lazy Adam and (c3) the
     recomputing weight gradient in ONE call -- end state against the oracle's whole-batch run."""
     c, one = scale_case, scale_case["one"]
-    assert bool(one["records_reused"]) and int(one["lazy_rows_launches"]) == ITERS
+    assert bool(one["records_reused"])
+    if c["workload"] == "c3":  # 1.7 M records over 2.2 M rows: the row-parallel lazy Adam (c5: 0.6 M over 5.3 M rows -- per record)
+        assert int(one["lazy_rows_launches"]) == ITERS
     n_eik = (c["bs"] + 9) // 10
     tiles = (n_eik + 1) // 2 + max(0, c["bs"] - 4 * ((n_eik + 1) // 2) + 15) // 16  # train_fused.h fused_tiles()
     if c["workload"] == "c3":
