@@ -300,6 +300,9 @@ typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapp
 
 /* ---- library ------------------------------------------------------------------- */
 int         pin_version(void);
+/* Load every code object of the library now (the HIP runtime otherwise does it inside the first launch of each translation
+ * unit's kernels -- a 100 ms frame the first time a stage of the SLAM loop runs).  Needs a current device; no kernel runs. */
+int         pin_warmup(void);
 const char* pin_last_error(void);
 
 /* host helper: cand_off_host[c] = (dx.primes) mod buffer_size, primes = (73856093,

@@ -151,6 +151,7 @@ P = C.POINTER
 # tests/test_abi_and_dropin_surface.py checks the header, this table and the built library agree.
 SIGNATURES = {
     "pin_version": (i32, []),
+    "pin_warmup": (i32, []),
     "pin_last_error": (C.c_char_p, []),
     "pin_candidate_offsets": (i32, [vp, i32, i64, vp]),
     "pin_pack_positions": (i32, [vp, vp, i32, i32, vp, vp]),

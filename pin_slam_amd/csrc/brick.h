@@ -55,10 +55,10 @@ __device__ __forceinline__ unsigned int group_sum_u32(unsigned int v) {
 // (PIN_XCD=0 in the environment turns the mapping off for A/B runs: every translation unit that uses it keeps its own copy of
 // the switch, set once by xcd_mode_init() from its launchers)
 static __device__ int g_xcd_on = 1;
-static inline int xcd_mode_init() {
-    static const int done = [] {
-        const char* e = getenv("PIN_XCD");
-        const int on = !(e && e[0] == '0');
+static inline int xcd_mode_init(const char* var = "PIN_XCD", int dflt = 1) {
+    static const int done = [var, dflt] {
+        const char* e = getenv(var);
+        const int on = e ? (e[0] != '0') : dflt;
         return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_on), &on, sizeof(int)) == hipSuccess ? 1 : -1;
     }();
     return done;

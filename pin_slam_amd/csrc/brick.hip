@@ -836,3 +836,12 @@ static int knn_bricks(const pin_search_params* sp, const pin_brick_cache* bc, co
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_brick() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&brick_clear_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

@@ -189,3 +189,12 @@ extern "C" int pin_dp_sync_side_effects(void* comm, float* certainty, const floa
     PIN_CHECK_NCCL(r2);
     return pin_dp_cert_apply(certainty, certainty0, scratch, n, stream);
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_comm() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&cert_delta_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

@@ -814,3 +814,12 @@ extern "C" int pin_dp_owner_pack(const uint8_t* owner, int32_t rank, const float
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_dp() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&dp_sample_cells_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

@@ -271,3 +271,12 @@ static int knn_direct(const pin_search_params* sp, const float* query, int32_t n
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_knn() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&pack_positions_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

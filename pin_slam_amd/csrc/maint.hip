@@ -868,3 +868,12 @@ extern "C" int pin_prune_map(const pin_map_arrays* src, const pin_map_arrays* ds
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_maint() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&vds_init_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

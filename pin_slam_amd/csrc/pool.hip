@@ -473,3 +473,12 @@ extern "C" int pin_gather_rows(const float* src, int32_t width, const int32_t* i
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_pool() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&pool_true_index_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

@@ -658,7 +658,9 @@ static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const fl
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", max_bytes, hipGetErrorString(attr));
     const int tiles = cdiv(n, 16);
-    xcd_mode_init();
+    // (measured on C3, same box: the search kernel gains 1.5 us per launch from the XCD-aware order, this kernel nothing --
+    // 37.7 vs 38.0 us -- so its tiles stay dealt out over all SIMDs unless PIN_XCD_GN=1)
+    xcd_mode_init("PIN_XCD_GN", 0);
     const dim3 grid(min(gq_cu_count(), tiles)), block(BLK);  // all CUs, even when there are fewer tiles than waves
     ColorTerm none;
     memset(&none, 0, sizeof(none));
@@ -999,3 +1001,12 @@ extern "C" int pin_decoder_sdf(const pin_field* f, const float* feat_in, int32_t
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_sdf() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&gn_solve_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

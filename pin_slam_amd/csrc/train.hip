@@ -1469,3 +1469,12 @@ extern "C" int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, fl
     PIN_CHECK_LAUNCH();
     return 0;
 }
+
+// pin_warmup (common.hip): asking for a kernel's attributes makes the runtime load this translation unit's code object now
+// instead of inside the first frame that launches one of its kernels
+namespace pin {
+int pin_warm_train() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&make_queries_kernel)) == hipSuccess ? 0 : -2;
+}
+}  // namespace pin

@@ -35,6 +35,7 @@ def _p(t):
 class NeuralPoints(nn.Module):
     def __init__(self, config) -> None:
         super().__init__()
+        ops.warmup()  # every code object of libpinhip loaded before the first frame needs one
         self.config = config
         self.silence = config.silence
         self.geo_feature_dim = config.feature_dim

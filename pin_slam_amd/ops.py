@@ -32,6 +32,21 @@ def _ptr(t: Optional[torch.Tensor], dtype=None):
     return t.data_ptr()
 
 
+_warmed = False
+
+
+def warmup():
+    """Load every code object of libpinhip now (pin_warmup): the drop-in constructors call this, so that the first frame of a
+    run does not pay for the HIP runtime's lazy loading stage by stage (profiles/r03_e2e_dropin_60.json: single frames of
+    88-170 ms per stage against medians below 1 ms)."""
+    global _warmed
+    if _warmed or not torch.cuda.is_available():
+        return
+    torch.cuda.current_device()  # (the runtime must be up and a device current)
+    check(_lib.lib().pin_warmup(), "pin_warmup")
+    _warmed = True
+
+
 def _stream():
     """Raw handle of torch's current stream ON THE CURRENT DEVICE.  (torch.cuda.current_stream() builds a Stream object
     through several Python layers, ~5 us a call -- four calls per training iteration; the two raw getters are what it ends
