@@ -750,6 +750,29 @@ int pin_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
  * spatially sharded mapper for the compact [decoder | halo rows] gradient buffer and for the owner merge. */
 int pin_allreduce_f32(void* comm, const float* send, float* recv, int64_t count, void* stream);
 
+/* The data half of SLAMDataset.preprocess_frame (dataset/slam_dataset.py:359-505) in ONE call with the stage counts on the
+ * device: voxel_down_sample_torch at train resolution (utils/tools.py:583-626) -> crop_frame (slam_dataset.py:1229-1247) ->
+ * [intrinsic_correct, :1251-1269] -> voxel_down_sample_torch at source resolution -> deskewing of the source (utils/tools.py:
+ * 747-779).  Every stage reads its input count from device memory (launches are sized by the raw scan), so nothing comes back
+ * to the host in between.  scan [n][width] rows (xyz first), ts [n] or NULL.  Outputs, sized for n rows by the caller:
+ * pc_out [.][width] the cropped cloud (rows 0 .. c2), ts_out its timestamps, source_xyz_out [.][3] the registration source
+ * (rows 0 .. c3; deskewed with `pose` when deskew != 0 and ts is given), source_rest_out [.][width - 3] its other columns
+ * (may be NULL), counts_out (DEVICE int32[3]) = c1 points kept by the first down-sampling, c2 by the crop, c3 by the second
+ * down-sampling.  c1 or c3 = -1: that point set's voxel ids do not fit the one-word sort key (pin_voxel_downsample_fast) --
+ * the caller runs the stages one by one instead.  Results are those of the separate entry points, bit for bit. */
+typedef struct pin_preprocess_params {
+    float train_vox, source_vox;             /* vox_down_m, source_vox_down_m (scaled by the adaptive range when that is on) */
+    float min_z, max_z, min_range, max_range;/* crop_frame */
+    double correct_deg;                      /* kitti_correction_on ? correction_deg : 0 */
+    int32_t want_source, deskew;
+    double pose[16];                         /* last_odom_tran, row-major (deskewing) */
+    double ts_mid_pose;
+} pin_preprocess_params;
+int64_t pin_preprocess_workspace_bytes(int32_t n, int32_t width);
+int pin_preprocess_frame(const pin_preprocess_params* pp, const float* scan, int32_t width, int32_t n, const float* ts,
+                         float* pc_out, float* ts_out, float* source_xyz_out, float* source_rest_out, int32_t* counts_out,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- spatially sharded data-parallel mapper -------------------------
  * xGMI is point-to-point, so the exchange is made small instead of fast: the voxel grid is cut into `world`
  * axis-aligned boxes (a k-d split of the drawn batch, computed by the host and identical on every rank) and rank r

@@ -126,6 +126,12 @@ class TrainColorParams(C.Structure):
                 ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("n_main_global", C.c_int32), ("surface_count", vp)]
 
 
+class PreprocessParams(C.Structure):
+    _fields_ = [("train_vox", C.c_float), ("source_vox", C.c_float), ("min_z", C.c_float), ("max_z", C.c_float),
+                ("min_range", C.c_float), ("max_range", C.c_float), ("correct_deg", C.c_double), ("want_source", C.c_int32),
+                ("deskew", C.c_int32), ("pose", C.c_double * 16), ("ts_mid_pose", C.c_double)]
+
+
 class DpRegions(C.Structure):
     _fields_ = [("boxes", vp), ("world", C.c_int32), ("rank", C.c_int32), ("reach", C.c_int32), ("resolution", C.c_float)]
 
@@ -223,6 +229,8 @@ SIGNATURES = {
     "pin_allreduce_f32": (i32, [vp, vp, vp, i64, vp]),
     "pin_dp_kd_boxes": (i32, [vp, i32, i32, vp]),
     "pin_dp_boxes_decode": (i32, [vp, i32, vp, vp]),
+    "pin_preprocess_workspace_bytes": (i64, [i32, i32]),
+    "pin_preprocess_frame": (i32, [P(PreprocessParams), vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_dp_signature": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]),
     "pin_dp_sample_cells": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, vp, vp]),
     "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, f32, vp, vp]),

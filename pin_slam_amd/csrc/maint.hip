@@ -136,10 +136,14 @@ __global__ __launch_bounds__(MB) void vds_heads_kernel(const unsigned long long*
 // pin_voxel_downsample.
 struct VdsPartial { unsigned int mn[3], mx[3], dmax, pad; };
 
+// (n_dev, here and in the three kernels below: the number of points on the DEVICE -- a chain of stages whose counts never visit
+// the host, pin_preprocess_frame -- bounded by the host's n, which sizes the launches and the sort)
 __global__ __launch_bounds__(MB) void vds_fast_stats_kernel(const float* __restrict__ p, int n, float vs,
-                                                            VdsPartial* __restrict__ part, VdsStats* __restrict__ st) {
+                                                            VdsPartial* __restrict__ part, VdsStats* __restrict__ st,
+                                                            const int* __restrict__ n_dev) {
 #pragma clang fp contract(off)
     __shared__ unsigned int red[MB / 64];
+    if (n_dev != nullptr) n = min(n, *n_dev);
     if (blockIdx.x == 0 && threadIdx.x == 0) st->nseg = 0;  // (the key kernel stores -1 here if an id does not fit)
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u}, dm = 0u;
     for (int i = blockIdx.x * MB + threadIdx.x; i < n; i += gridDim.x * MB) {
@@ -168,10 +172,12 @@ __global__ __launch_bounds__(MB) void vds_fast_stats_kernel(const float* __restr
 __global__ __launch_bounds__(MB) void vds_fast_keys_kernel(const float* __restrict__ p, int n, float vs,
                                                            const VdsPartial* __restrict__ part, int n_part, long long off10,
                                                            int val_bits, unsigned long long* __restrict__ comp,
-                                                           VdsStats* __restrict__ st) {
+                                                           VdsStats* __restrict__ st, const int* __restrict__ n_dev) {
 #pragma clang fp contract(off)
     __shared__ unsigned int red[MB / 64];
     __shared__ VdsStats sst;
+    const int n_max = n;
+    if (n_dev != nullptr) n = min(n, *n_dev);
     {   // every block reduces the (<= REDUCE_BLOCKS) partials itself: no launch in between, no atomics
         unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u}, dm = 0u;
         for (int b = threadIdx.x; b < n_part; b += MB) {
@@ -195,7 +201,10 @@ __global__ __launch_bounds__(MB) void vds_fast_keys_kernel(const float* __restri
         __syncthreads();
     }
     const int i = blockIdx.x * MB + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) {
+        if (i < n_max) comp[i] = ~0ull;  // (padding behind the device-side count: sorts to the end, never a run head)
+        return;
+    }
     long long g[3]; float dist;
     vds_point(p, i, vs, &sst, g, dist);
     const long long v = sst.gmax;
@@ -209,10 +218,13 @@ __global__ __launch_bounds__(MB) void vds_fast_keys_kernel(const float* __restri
 
 // run heads of the sorted words (same voxel id = same upper part) and their per-block counts, in one launch
 __global__ __launch_bounds__(MB) void vds_fast_heads_kernel(const unsigned long long* __restrict__ comp, int n, int val_bits,
-                                                            unsigned char* __restrict__ flags, int* __restrict__ block_cnt) {
+                                                            unsigned char* __restrict__ flags, int* __restrict__ block_cnt,
+                                                            const int* __restrict__ n_dev) {
+    const int n_max = n;
+    if (n_dev != nullptr) n = min(n, *n_dev);
     const int i = blockIdx.x * MB + threadIdx.x;
     const bool f = i < n && (i == 0 || (comp[i] >> val_bits) != (comp[i - 1] >> val_bits));
-    if (i < n) flags[i] = f ? 1 : 0;
+    if (i < n_max) flags[i] = f ? 1 : 0;
     int total;
     block_flag_scan(f, total);
     if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
@@ -692,9 +704,15 @@ extern "C" int pin_voxel_downsample(const float* points, int32_t n, float voxel_
 extern "C" int pin_voxel_downsample_fast(const float* points, int32_t n, float voxel_size, int32_t* sel_out,
                                          int32_t* count_out, void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();
+    return pin::vds_fast_dev(points, n, nullptr, voxel_size, sel_out, count_out, workspace, workspace_bytes, as_stream(stream));
+}
+
+// n = the host's bound on the number of points (sizes the launches, the sort and the value packing: any off10 > the largest
+// index selects the same winners); n_dev (may be NULL) = the count on the device
+int pin::vds_fast_dev(const float* points, int32_t n, const int32_t* n_dev, float voxel_size, int32_t* sel_out, int32_t* count_out,
+                      void* workspace, int64_t workspace_bytes, hipStream_t s) {
     PIN_CHECK_ARG(n > 0 && points && sel_out && count_out && workspace, "bad arguments");
     PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
-    hipStream_t s = as_stream(stream);
     Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
     VdsStats* st = c.take<VdsStats>(1);
     unsigned long long* comp = c.take<unsigned long long>(n);
@@ -710,11 +728,11 @@ extern "C" int pin_voxel_downsample_fast(const float* points, int32_t n, float v
     for (long long v = n - 1; ; v /= 10) { off10 *= 10; if (v < 10) break; }
     int val_bits = 1;  // values are below 1000 * off10
     while ((1000ll * off10 - 1) >> val_bits) ++val_bits;
-    hipLaunchKernelGGL(vds_fast_stats_kernel, dim3(rb), dim3(MB), 0, s, points, n, voxel_size, part, st);
-    hipLaunchKernelGGL(vds_fast_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, part, rb, off10, val_bits, comp, st);
+    hipLaunchKernelGGL(vds_fast_stats_kernel, dim3(rb), dim3(MB), 0, s, points, n, voxel_size, part, st, n_dev);
+    hipLaunchKernelGGL(vds_fast_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, part, rb, off10, val_bits, comp, st, n_dev);
     PIN_CHECK_LAUNCH();
     PIN_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, comp, comp2, (size_t)n, 0, 64, s));
-    hipLaunchKernelGGL(vds_fast_heads_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off);
+    hipLaunchKernelGGL(vds_fast_heads_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off, n_dev);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, count_out);
     hipLaunchKernelGGL(vds_fast_emit_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off, off10, st, sel_out, count_out);
     PIN_CHECK_LAUNCH();

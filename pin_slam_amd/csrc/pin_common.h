@@ -44,6 +44,11 @@ int knn_direct_dev(const pin_search_params* sp, const float* query, int32_t n, i
 int knn_bricks_dev(const pin_search_params* sp, const pin_brick_cache* bc, const float* query, int32_t n, int32_t k,
                    const double* state, float* query_out, float* nbr_out, int32_t* nn_count_out, void* stream);
 
+// internal: pin_voxel_downsample_fast with the number of points on the device (pin_preprocess_frame chains its stages without
+// a host read-back in between); n bounds *n_dev
+int vds_fast_dev(const float* points, int32_t n, const int32_t* n_dev, float voxel_size, int32_t* sel_out, int32_t* count_out,
+                 void* workspace, int64_t workspace_bytes, hipStream_t s);
+
 // ---- device helpers ----------------------------------------------------------------
 constexpr long long PRIME0 = 73856093LL, PRIME1 = 19349669LL, PRIME2 = 83492791LL;
 constexpr float IDW_EPS = 1e-15f;

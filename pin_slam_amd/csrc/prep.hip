@@ -105,6 +105,114 @@ __global__ __launch_bounds__(MB) void deskew_kernel(float* __restrict__ pts, int
     P[2] = (z * c + kz * s + az * dot) + t * dk.tr[2];
 }
 
+// ---- the whole data half of preprocess_frame in one call, counts on the device (pin_preprocess_frame) -------------------
+// The stages of dataset/slam_dataset.py:359-505 each produce a count the next one is sized by (points kept by the train-
+// resolution down-sampling, by the crop, by the source down-sampling).  Read back one by one they cost three host round trips
+// per frame with Python between the launches; here every stage reads its input count from device memory, launches are sized by
+// the raw scan, and the three counts come back together at the end.
+__global__ __launch_bounds__(MB) void extract_xyz_kernel(const float* __restrict__ rows, int width, int n, const int* __restrict__ n_dev,
+                                                         float* __restrict__ xyz) {
+    if (n_dev != nullptr) n = min(n, *n_dev);
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    xyz[3 * (size_t)i] = rows[(size_t)i * width]; xyz[3 * (size_t)i + 1] = rows[(size_t)i * width + 1];
+    xyz[3 * (size_t)i + 2] = rows[(size_t)i * width + 2];
+}
+
+// crop_frame on the rows the down-sampling selected: flags + per-block counts, then the ordered scatter
+__global__ __launch_bounds__(MB) void sel_crop_flags_kernel(const float* __restrict__ scan, int width, const int* __restrict__ sel,
+                                                            int n, const int* __restrict__ n_dev, float min_z, float max_z, float min_r,
+                                                            float max_r, unsigned char* __restrict__ flags, int* __restrict__ block_cnt) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    bool f = false;
+    if (i < n) {
+        const float* P = scan + (size_t)sel[i] * width;
+        const float d = norm3_rn(P[0], P[1], P[2]);
+        f = d > min_r && d < max_r && P[2] > min_z && P[2] < max_z;
+        flags[i] = f ? 1 : 0;
+    }
+    int total;
+    block_flag_scan(f, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(MB) void sel_crop_scatter_kernel(const float* __restrict__ scan, int width, const float* __restrict__ ts,
+                                                              const int* __restrict__ sel, int n, const int* __restrict__ n_dev,
+                                                              const unsigned char* __restrict__ flags, const int* __restrict__ block_off,
+                                                              float* __restrict__ out, float* __restrict__ ts_out) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    int total;
+    const int ex = block_flag_scan(f, total);
+    if (!f) return;
+    const size_t d = (size_t)(block_off[blockIdx.x] + ex), src = (size_t)sel[i];
+    for (int c = 0; c < width; ++c) out[d * width + c] = scan[src * width + c];
+    if (ts != nullptr) ts_out[d] = ts[src];
+}
+__global__ __launch_bounds__(MB) void intrinsic_correct_dev_kernel(float* __restrict__ pts, int width, int n, const int* __restrict__ n_dev,
+                                                                   float ang) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    float* P = pts + (size_t)i * width;
+    const float dist = norm3_rn(P[0], P[1], P[2]);
+    const float v = asinf(__fdiv_rn(P[2], dist));
+    const float vc = v + ang;
+    const float hs = __fdiv_rn(cosf(vc), cosf(v));
+    P[0] = P[0] * hs;
+    P[1] = P[1] * hs;
+    P[2] = dist * sinf(vc);
+}
+// the registration source: rows sel[i] of the cropped cloud -> xyz [n][3] (+ the other columns, + timestamps)
+__global__ __launch_bounds__(MB) void source_gather_kernel(const float* __restrict__ pc, int width, const float* __restrict__ ts,
+                                                           const int* __restrict__ sel, int n, const int* __restrict__ n_dev,
+                                                           float* __restrict__ xyz, float* __restrict__ rest, float* __restrict__ ts_out) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    const size_t src = (size_t)sel[i];
+    xyz[3 * (size_t)i] = pc[src * width]; xyz[3 * (size_t)i + 1] = pc[src * width + 1]; xyz[3 * (size_t)i + 2] = pc[src * width + 2];
+    if (rest != nullptr)
+        for (int c = 3; c < width; ++c) rest[(size_t)i * (width - 3) + (c - 3)] = pc[src * width + c];
+    if (ts != nullptr) ts_out[i] = ts[src];
+}
+__global__ __launch_bounds__(MB) void ts_range_dev_kernel(const float* __restrict__ ts, int n, const int* __restrict__ n_dev,
+                                                          TsRange* __restrict__ r) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    unsigned int lo = 0xffffffffu, hi = 0u;
+    if (i < n) lo = hi = enc_order(ts[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (unsigned int)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned int)__shfl_xor((int)hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(&r->lo, lo); atomicMax(&r->hi, hi); }
+}
+__global__ __launch_bounds__(MB) void deskew_dev_kernel(float* __restrict__ pts, int width, int n, const int* __restrict__ n_dev,
+                                                        const float* __restrict__ ts, const TsRange* __restrict__ r, Deskew dk) {
+    n = min(n, max(*n_dev, 0));
+    const int i = blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    const float lo = dec_order(r->lo), hi = dec_order(r->hi);
+    float t = __fdiv_rn(ts[i] - lo, hi - lo);
+    t = t - dk.mid;
+    float* P = pts + (size_t)i * width;
+    const float x = P[0], y = P[1], z = P[2];
+    float s, c;
+    sincosf(t * dk.theta, &s, &c);
+    const float ax = dk.ax[0], ay = dk.ax[1], az = dk.ax[2];
+    const float kx = ay * z - az * y, ky = az * x - ax * z, kz = ax * y - ay * x;
+    const float dot = (ax * x + ay * y + az * z) * (1.0f - c);
+    P[0] = (x * c + kx * s + ax * dot) + t * dk.tr[0];
+    P[1] = (y * c + ky * s + ay * dot) + t * dk.tr[1];
+    P[2] = (z * c + kz * s + az * dot) + t * dk.tr[2];
+}
+__global__ void counts_store_kernel(const int* __restrict__ c1, const int* __restrict__ c2, const int* __restrict__ c3, int* __restrict__ out) {
+    out[0] = *c1; out[1] = *c2; out[2] = c3 ? *c3 : 0;
+}
+
 }  // namespace pin
 
 using namespace pin;
@@ -142,13 +250,26 @@ extern "C" int pin_intrinsic_correct(float* points, int32_t width, int32_t n, do
     return 0;
 }
 
+namespace pin { Deskew deskew_params(const double* pose, double ts_mid_pose); }
+
 extern "C" int pin_deskew(float* points, int32_t width, int32_t n, const float* ts, const double* pose, double ts_mid_pose,
                           void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(n >= 0 && width >= 3, "n < 0 or width < 3");
     if (n == 0) return 0;
     PIN_CHECK_ARG(points && ts && pose && workspace && workspace_bytes >= 64, "NULL pointer or workspace < 64 bytes");
-    // log map of float32(R) on the host in float64
+    Deskew dk = deskew_params(pose, ts_mid_pose);
+    hipStream_t s = as_stream(stream);
+    TsRange* r = reinterpret_cast<TsRange*>(workspace);
+    hipLaunchKernelGGL(ts_range_init_kernel, dim3(1), dim3(1), 0, s, r);
+    hipLaunchKernelGGL(ts_range_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, s, ts, n, r);
+    hipLaunchKernelGGL(deskew_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, s, points, width, n, ts, r, dk);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+// log map of float32(R) on the host in float64 (tools.py:763-770)
+Deskew pin::deskew_params(const double* pose, double ts_mid_pose) {
     double R[9];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) R[3 * r + c] = (double)(float)pose[4 * r + c];
@@ -165,11 +286,63 @@ extern "C" int pin_deskew(float* points, int32_t width, int32_t n, const float* 
     }
     for (int i = 0; i < 3; ++i) dk.tr[i] = (float)pose[4 * i + 3];
     dk.mid = (float)ts_mid_pose;
+    return dk;
+}
+
+extern "C" int64_t pin_preprocess_workspace_bytes(int32_t n, int32_t width) {
+    const size_t nb = (size_t)cdiv(n + 1, MB) + 8;
+    return (int64_t)(pin_maint_workspace_bytes(n) + (size_t)n * (2 * 4 + 2 * 12 + 1) + nb * 4 + 4096);
+}
+
+extern "C" int pin_preprocess_frame(const pin_preprocess_params* pp, const float* scan, int32_t width, int32_t n, const float* ts,
+                                    float* pc_out, float* ts_out, float* source_xyz_out, float* source_rest_out, int32_t* counts_out,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(pp && n > 0 && width >= 3 && scan && pc_out && counts_out && workspace, "bad arguments");
+    PIN_CHECK_ARG(ts == nullptr || ts_out, "ts without ts_out");
+    PIN_CHECK_ARG(!pp->want_source || source_xyz_out, "want_source without source_xyz_out");
+    PIN_CHECK_ARG(workspace_bytes >= pin_preprocess_workspace_bytes(n, width), "workspace too small (pin_preprocess_workspace_bytes)");
+    PIN_CHECK_ARG(pp->train_vox > 0.f && (!pp->want_source || pp->source_vox > 0.f), "voxel sizes");
     hipStream_t s = as_stream(stream);
-    TsRange* r = reinterpret_cast<TsRange*>(workspace);
-    hipLaunchKernelGGL(ts_range_init_kernel, dim3(1), dim3(1), 0, s, r);
-    hipLaunchKernelGGL(ts_range_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, s, ts, n, r);
-    hipLaunchKernelGGL(deskew_kernel, dim3(cdiv(n, MB)), dim3(MB), 0, s, points, width, n, ts, r, dk);
+    Carver cv{static_cast<char*>(workspace), static_cast<char*>(workspace) + workspace_bytes};
+    int* cnt = cv.take<int>(8);            // c1, c2, c3 on the device
+    int* sel1 = cv.take<int>(n);
+    int* sel2 = cv.take<int>(n);
+    float* xyz = cv.take<float>((size_t)3 * n);
+    float* src_ts = cv.take<float>(n);
+    unsigned char* flags = cv.take<unsigned char>(n);
+    const int nb = cdiv(n, MB);
+    int* block_cnt = cv.take<int>(nb + 1);
+    TsRange* tr = reinterpret_cast<TsRange*>(cv.take<int>(16));
+    const int64_t vb = pin_maint_workspace_bytes(n);
+    void* vws = cv.take<char>((size_t)vb);
+    PIN_CHECK_ARG(vws != nullptr, "workspace carve failed");
+    // 1. train-resolution down-sampling of the raw scan (host n) -> sel1, c1
+    hipLaunchKernelGGL(extract_xyz_kernel, dim3(nb), dim3(MB), 0, s, scan, width, n, (const int*)nullptr, xyz);
+    if (int e = vds_fast_dev(xyz, n, nullptr, pp->train_vox, sel1, cnt + 0, vws, vb, s)) return e;
+    // 2. crop_frame on the selected rows -> pc_out, ts_out, c2  (a down-sampling that reported "ids too wide", c1 = -1, crops nothing)
+    hipLaunchKernelGGL(sel_crop_flags_kernel, dim3(nb), dim3(MB), 0, s, scan, width, sel1, n, cnt + 0, pp->min_z, pp->max_z,
+                       pp->min_range, pp->max_range, flags, block_cnt);
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_cnt, nb, cnt + 1);
+    hipLaunchKernelGGL(sel_crop_scatter_kernel, dim3(nb), dim3(MB), 0, s, scan, width, ts, sel1, n, cnt + 0, flags, block_cnt, pc_out, ts_out);
+    if (pp->correct_deg != 0.0)
+        hipLaunchKernelGGL(intrinsic_correct_dev_kernel, dim3(nb), dim3(MB), 0, s, pc_out, width, n, cnt + 1,
+                           (float)(pp->correct_deg / 180.0 * 3.141592653589793));
+    // 3. source-resolution down-sampling of the cropped cloud (count on the device) -> sel2, c3; gather; deskew
+    if (pp->want_source) {
+        hipLaunchKernelGGL(extract_xyz_kernel, dim3(nb), dim3(MB), 0, s, pc_out, width, n, cnt + 1, xyz);
+        if (int e = vds_fast_dev(xyz, n, cnt + 1, pp->source_vox, sel2, cnt + 2, vws, vb, s)) return e;
+        const bool dsk = pp->deskew && ts != nullptr;
+        hipLaunchKernelGGL(source_gather_kernel, dim3(nb), dim3(MB), 0, s, pc_out, width, dsk ? ts_out : nullptr, sel2, n, cnt + 2,
+                           source_xyz_out, width > 3 ? source_rest_out : nullptr, src_ts);
+        if (dsk) {
+            const Deskew dk = deskew_params(pp->pose, pp->ts_mid_pose);
+            hipLaunchKernelGGL(ts_range_init_kernel, dim3(1), dim3(1), 0, s, tr);
+            hipLaunchKernelGGL(ts_range_dev_kernel, dim3(nb), dim3(MB), 0, s, src_ts, n, cnt + 2, tr);
+            hipLaunchKernelGGL(deskew_dev_kernel, dim3(nb), dim3(MB), 0, s, source_xyz_out, 3, n, cnt + 2, src_ts, tr, dk);
+        }
+    }
+    hipLaunchKernelGGL(counts_store_kernel, dim3(1), dim3(1), 0, s, cnt + 0, cnt + 1, pp->want_source ? cnt + 2 : (const int*)nullptr, counts_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

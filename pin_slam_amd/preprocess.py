@@ -113,6 +113,57 @@ class ScanPreprocessor:
 
     def __init__(self, config):
         self.config = config
+        # the whole chain behind ONE C-ABI call with the stage counts on the device and one read-back at the end
+        # (pin_preprocess_frame); PIN_PREPROCESS_FUSED=0: stage by stage (three read-backs), the same bits
+        import os
+        self.fused = os.environ.get("PIN_PREPROCESS_FUSED", "1") != "0"
+        self._bufs = None
+
+    def _fused(self, scan, point_ts, train_vox, source_vox, crop_max, last_odom_tran, frame_id, lose_track):
+        c, L = self.config, _lib.lib()
+        n, w = scan.shape
+        if n == 0:
+            return None
+        dev = scan.device
+        ts32 = None if point_ts is None else _dev_f32(point_ts).reshape(-1).contiguous()
+        b = self._bufs
+        if b is None or b["cap"] < n or b["width"] != w:
+            cap = int(n * 1.1) + 1024
+            b = self._bufs = dict(cap=cap, width=w,
+                                  cnt=torch.zeros((4,), dtype=torch.int32, device=dev), cnt_host=torch.zeros((4,), dtype=torch.int32).pin_memory(),
+                                  ws=torch.empty((int(L.pin_preprocess_workspace_bytes(cap, w)) + 256,), dtype=torch.uint8, device=dev))
+        pp = _lib.PreprocessParams()
+        pp.train_vox, pp.source_vox = float(np.float32(train_vox)), float(np.float32(source_vox))
+        pp.min_z, pp.max_z, pp.min_range, pp.max_range = float(c.min_z), float(c.max_z), float(c.min_range), float(crop_max)
+        pp.correct_deg = float(c.correction_deg) if getattr(c, "kitti_correction_on", False) else 0.0
+        pp.want_source = int(frame_id > 0)
+        dsk = bool(getattr(c, "deskew", False) and not lose_track and ts32 is not None and last_odom_tran is not None and frame_id > 0)
+        pp.deskew = int(dsk)
+        if dsk:
+            T = np.ascontiguousarray(last_odom_tran.detach().to("cpu", torch.float64).numpy() if isinstance(last_odom_tran, torch.Tensor)
+                                     else np.asarray(last_odom_tran, np.float64)).reshape(-1)
+            for i in range(16):
+                pp.pose[i] = float(T[i])
+        pp.ts_mid_pose = 0.5
+        # every frame gets fresh output tensors (the caller keeps pc / source across frames); the scratch is reused
+        pc = torch.empty((n, w), dtype=torch.float32, device=dev)
+        ts_out = torch.empty((n,), dtype=torch.float32, device=dev) if ts32 is not None else None
+        src = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        rest = torch.empty((n, w - 3), dtype=torch.float32, device=dev) if (w > 3 and c.color_on) else None
+        check(L.pin_preprocess_frame(C.byref(pp), scan.data_ptr(), w, n, None if ts32 is None else ts32.data_ptr(), pc.data_ptr(),
+                                     None if ts_out is None else ts_out.data_ptr(), src.data_ptr(), None if rest is None else rest.data_ptr(),
+                                     b["cnt"].data_ptr(), b["ws"].data_ptr(), b["ws"].numel(), ops._stream()), "pin_preprocess_frame")
+        b["cnt_host"].copy_(b["cnt"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        c1, c2, c3 = (int(v) for v in b["cnt_host"][:3])
+        if c1 < 0 or c3 < 0:  # voxel ids too wide for the one-word sort key: the stages one by one (general down-sampling)
+            return None
+        ts_ret = None
+        if point_ts is not None:
+            ts_ret = ts_out[:c2].to(point_ts.dtype).reshape((c2,) + tuple(point_ts.shape[1:]))
+        if frame_id <= 0:
+            return pc[:c2], ts_ret, None, None
+        return pc[:c2], ts_ret, src[:c3], (rest[:c3] if rest is not None else None)
 
     def __call__(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None,
                  frame_id: int = 1, lose_track: bool = False):
@@ -126,6 +177,10 @@ class ScanPreprocessor:
         train_vox = (crop_max / c.max_range) * c.vox_down_m
         source_vox = (crop_max / c.max_range) * c.source_vox_down_m
         scan = _dev_f32(scan).contiguous()
+        if self.fused and not getattr(c, "rand_downsample", False):
+            out = self._fused(scan, point_ts, train_vox, source_vox, crop_max, last_odom_tran, frame_id, lose_track)
+            if out is not None:
+                return out
         if getattr(c, "rand_downsample", False):
             idx = torch.randint(0, scan.shape[0], (int(scan.shape[0] * c.rand_down_r),), device=scan.device)
         else:

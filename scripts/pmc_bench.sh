@@ -2,16 +2,16 @@
 # PMC passes of THE BENCH COMMAND, per workload (run on the GPU box through gpurun): separate rocprofv3 runs for
 # FETCH_SIZE, WRITE_SIZE and two SQ sets, kernel-trace only (never combined with other trace domains), plus one
 # kernel-trace --stats run for the durations of the same command.  scripts/pmc_bench_summarize.py turns the output
-# into profiles/r03_pmc_<workload>.json (read by bench.py for roofline.traffic / mfma_util / valu_active) and
-# profiles/r03_bench_<workload>_kernel_stats.csv.
+# into profiles/r04_pmc_<workload>.json (read by bench.py for roofline.traffic / mfma_util / valu_active) and
+# profiles/r04_bench_<workload>_kernel_stats.csv.
 #   usage: scripts/pmc_bench.sh c3 [c2 kitti c5 c4]   (c4 = the 2^20-sample Mapper.mapping of the C3 map: the summary then takes the
 #   LARGEST launch shape of every kernel class instead of the most frequent one)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for W in "$@"; do
   O=$R/gpurun_out/pmc_bench/$W; rm -rf $O; mkdir -p $O
-  CMD="python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none"
-  if [ "$W" = "c4" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none"; fi
+  CMD="python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 0"
+  if [ "$W" = "c4" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none --moving-steps 0 --mesher-queries 0"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $CMD > $O/stats.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -o p -- $CMD > $O/$C.log 2>&1

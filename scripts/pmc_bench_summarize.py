@@ -1,5 +1,5 @@
-"""gpurun_out/pmc_bench/<workload>/ (scripts/pmc_bench.sh) -> gpurun_out/pmc_bench/r03_pmc_<workload>.json and
-r03_bench_<workload>_kernel_stats.csv (copy both into profiles/).
+"""gpurun_out/pmc_bench/<workload>/ (scripts/pmc_bench.sh) -> gpurun_out/pmc_bench/r04_pmc_<workload>.json and
+r04_bench_<workload>_kernel_stats.csv (copy both into profiles/).
 
 Per kernel CLASS and launch SHAPE (grid size): mean counter values per launch.  The tracker's launches of a kernel are the
 shape with the most launches (50 per frame); the training launches of the search kernel have other grids.
@@ -13,7 +13,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 O = os.path.join(R, "gpurun_out", "pmc_bench", W)
 CLOCK_GHZ, N_SIMD = 2.4, 1024
 
-CLASSES = (("gn", "gn_accumulate"), ("knn_brick", "knn_brick_kernel"), ("train_fused", "train_fused"), ("train_dw_recompute", "train_dw_recompute"), ("train_dw_stream", "train_dw_stream"),
+CLASSES = (("gn", "gn_accumulate"), ("knn_brick_listed", "knn_brick_listed_kernel"), ("knn_brick", "knn_brick_kernel"), ("train_fused", "train_fused"), ("train_dw_recompute", "train_dw_recompute"), ("train_dw_stream", "train_dw_stream"),
            ("adam_lazy_prepare_rows", "adam_lazy_prepare_rows"), ("mark_rows", "mark_rows"), ("adam_lazy_prepare", "adam_lazy_prepare"),
            ("gn_solve", "gn_solve"))
 LARGEST = W == "c4"  # the 2^20-sample mapper: its launches are the largest grids of their kernels, not the most frequent
@@ -91,11 +91,11 @@ for k, shapes in by_class.items():
         e["hbm_bytes_per_launch_if_streaming_x2"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
     out["kernels"][k] = e
 dst = os.path.join(R, "gpurun_out", "pmc_bench")
-json.dump(out, open(os.path.join(dst, f"r03_pmc_{W}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"r04_pmc_{W}.json"), "w"), indent=1)
 f = glob.glob(os.path.join(O, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    with open(os.path.join(dst, f"r03_bench_{W}_kernel_stats.csv"), "w") as w:
+    with open(os.path.join(dst, f"r04_bench_{W}_kernel_stats.csv"), "w") as w:
         wr = csv.writer(w)
         wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:40]:

@@ -58,3 +58,37 @@ def test_scan_preprocessor_matches_oracle_chain():
     ref_src = O.deskewing(ref_pc[i2][:, :3], ref_ts[i2], T)
     np.testing.assert_allclose(src.cpu().numpy(), ref_src, rtol=0, atol=3e-5)
     assert 1000 < len(i2) < len(i1)
+
+
+@pytest.mark.parametrize("deskew,correct", [(True, 0.0), (False, 0.205), (True, 0.205)])
+def test_fused_chain_equals_the_stages(monkeypatch, deskew, correct):
+    """pin_preprocess_frame (one call, stage counts on the device, one read-back) against the stage-by-stage path of the same
+    class: identical clouds, timestamps and registration source, bit for bit (incl. the KITTI correction in between, which moves
+    points across voxel borders of the second down-sampling)."""
+    from pin_slam_amd import preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    cfg = PinConfig(vox_down_m=0.08, source_vox_down_m=0.8, min_range=2.5, max_range=60.0, min_z=-5.0, max_z=60.0, deskew=deskew,
+                    kitti_correction_on=correct != 0.0, correction_deg=correct)
+    g = torch.Generator().manual_seed(5)
+    n = 120_000
+    r = 70.0 * torch.sqrt(torch.rand(n, generator=g)); th = 6.2831853 * torch.rand(n, generator=g)
+    scan = torch.stack([r * torch.cos(th), r * torch.sin(th), -2 + 0.3 * torch.sin(0.5 * r) + 0.5 * torch.randn(n, generator=g),
+                        torch.rand(n, generator=g)], 1).float().cuda()
+    ts = torch.rand(n, generator=g).float().cuda()
+    T = np.eye(4); T[:3, 3] = [0.9, 0.02, 0.0]
+    c, s = np.cos(0.03), np.sin(0.03); T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    fused = PP.ScanPreprocessor(cfg)
+    assert fused.fused
+    staged = PP.ScanPreprocessor(cfg)
+    staged.fused = False
+    for frame_id in (0, 3):
+        a = fused(scan, ts, last_odom_tran=T, frame_id=frame_id)
+        b = staged(scan, ts, last_odom_tran=T, frame_id=frame_id)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[0].shape[0] > 50_000
+        if frame_id == 0:
+            assert a[2] is None and b[2] is None
+        else:
+            assert torch.equal(a[2], b[2]) and 1000 < a[2].shape[0] < a[0].shape[0]
+    # no timestamps: no deskewing, no ts output
+    a, b = fused(scan, None, frame_id=2), staged(scan, None, frame_id=2)
+    assert a[1] is None and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
