@@ -403,6 +403,8 @@ class Mapper(_Base):
         bs_new = min(new_idx.shape[0], c.bs_new_sample) if use_new else 0
         if n <= 0 or iters <= 0:
             return None
+        if os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1":
+            return None  # the reference's per-iteration torch.randint calls in get_batch (a replayed random stream expects their shapes)
         hist = torch.randint(0, n, (iters, c.bs - bs_new), device=self.device)
         new = torch.randint(0, new_idx.shape[0], (iters, bs_new), device=self.device) if use_new else None
         return dict(key=(n, c.bs - bs_new, bs_new, 0 if not use_new else new_idx.shape[0]), hist=hist, new=new, next=0)

@@ -140,7 +140,7 @@ pgo:
   context_cosdist: 0.3
 optimizer:
   iters: {iters}
-  batch_size: 10000
+  batch_size: {bs}
   adaptive_iters: True
 eval:
   wandb_vis_on: False
@@ -219,11 +219,100 @@ def install_optional_stand_ins():
         m = types.ModuleType("roma"); m.rotmat_slerp = rotmat_slerp; sys.modules["roma"] = m
 
 
+# ------------------------------------------------------------------------------------------------ paired random streams
+def install_draw_hooks(args, log):
+    """The paired accuracy run: every result of torch.randn / torch.rand / torch.randint -- the
+    sampler's draws (utils/data_sampler.py:51-97), the new points' feature rows (model/neural_points.py:395-405), the pool's
+    discard draw (utils/mapper.py:331) and the batch indices (utils/mapper.py:465-478) -- is recorded in one run and fed,
+    call by call, to another, so that two implementations see the same random numbers.  Module initialisation uses tensor
+    methods (uniform_), not these functions, and is seeded alike in both runs."""
+    import torch
+    if not (args.record_draws or args.replay_draws):
+        return None
+    st = {"orig": {n: getattr(torch, n) for n in ("randn", "rand", "randint")}, "rec": [], "pos": 0}
+    if args.replay_draws:
+        os.environ["PIN_DRAW_PER_ITERATION"] = "1"
+        z = np.load(args.replay_draws)
+        st["kinds"], st["n"] = [str(k) for k in z["kinds"]], int(z["n"])
+        st["arrays"] = z
+
+    def make(kind):
+        orig = st["orig"][kind]
+
+        def f(*a, **k):
+            if args.replay_draws:
+                i = st["pos"]
+                if i >= st["n"]:
+                    raise RuntimeError(f"replayed stream exhausted at call {i} ({kind})")
+                if st["kinds"][i] != kind:
+                    raise RuntimeError(f"replayed stream out of step at call {i}: recorded {st['kinds'][i]}, asked {kind}")
+                arr = st["arrays"][f"a{i}"]
+                exp = _expected_shape(kind, a, k)
+                if exp is not None and tuple(arr.shape) != exp:
+                    # a count that depends on the pose (new map points, samples inside the window) may differ by a few between
+                    # the two implementations: keep the pairing for the common prefix, top up with fresh draws
+                    if len(exp) != arr.ndim or tuple(arr.shape[1:]) != tuple(exp[1:]):
+                        raise RuntimeError(f"replayed stream out of step at call {i} ({kind}): recorded shape {tuple(arr.shape)}, asked {exp}")
+                    st["resized"] = st.get("resized", 0) + 1
+                    if exp[0] <= arr.shape[0]:
+                        arr = arr[:exp[0]]
+                    else:
+                        extra = orig(*((a[0], a[1], (exp[0] - arr.shape[0],) + tuple(exp[1:])) if kind == "randint" and len(a) >= 3 else
+                                       ((exp[0] - arr.shape[0],) + tuple(exp[1:]),)), **{kk: vv for kk, vv in k.items() if kk not in ("device", "size")})
+                        arr = np.concatenate([arr, extra.cpu().numpy().astype(arr.dtype)], 0)
+                t = torch.from_numpy(np.ascontiguousarray(arr))
+                if kind == "randint":  # (the upper bound may differ by a few samples as well)
+                    high = a[1] if len(a) >= 3 else a[0]
+                    t = t % int(high)
+                dev = k.get("device", None)
+                out = t.to(dev) if dev is not None else t
+                st["pos"] = i + 1
+                return out
+            out = orig(*a, **k)
+            st["rec"].append((kind, out.detach().cpu().numpy()))
+            return out
+        return f
+
+    for n in ("randn", "rand", "randint"):
+        setattr(torch, n, make(n))
+    return st
+
+
+def _expected_shape(kind, a, k):
+    try:
+        if kind == "randint":  # randint(low, high, size) or randint(high, size)
+            size = a[2] if len(a) >= 3 else (a[1] if len(a) == 2 and not isinstance(a[1], int) else k.get("size"))
+        else:
+            size = a[0] if (len(a) == 1 and not isinstance(a[0], int)) else (a if a else k.get("size"))
+        return tuple(int(v) for v in size)
+    except Exception:
+        return None
+
+
+def finish_draw_hooks(args, st, log):
+    import torch
+    if st is None:
+        return
+    for n, f in st["orig"].items():
+        setattr(torch, n, f)
+    if args.record_draws:
+        rec = st["rec"]
+        os.makedirs(os.path.dirname(os.path.abspath(args.record_draws)), exist_ok=True)
+        np.savez(args.record_draws, n=np.array(len(rec)), kinds=np.array([k for k, _ in rec]), **{f"a{i}": a for i, (_, a) in enumerate(rec)})
+        log["draws_recorded"] = {"calls": len(rec), "mbytes": round(sum(a.nbytes for _, a in rec) / 1e6, 1)}
+        print("recorded", log["draws_recorded"], "->", args.record_draws)
+    else:
+        log["draws_replayed"] = {"calls_used": st["pos"], "calls_recorded": st["n"], "calls_with_a_different_count": st.get("resized", 0)}
+        print("replayed", log["draws_replayed"])
+
+
 # ------------------------------------------------------------------------------------------------ run
 def run(args):
     import torch
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
+    args.record_draws = os.path.abspath(args.record_draws) if args.record_draws else ""
+    args.replay_draws = os.path.abspath(args.replay_draws) if args.replay_draws else ""
     log = {"impl": args.impl, "frames": args.frames, "scan_points": args.scan_points, "seed": args.seed}
     ref = reference_tree(args.reference)
     work = tempfile.mkdtemp(prefix="pin_e2e_")
@@ -237,7 +326,7 @@ def run(args):
             extra = "  weighted_first: False\n  query_nn_k: 8\n"
             loss = "loss:\n  loss_weight_on: True\n  dist_weight_scale: 0.5\n  ekional_loss_on: True\n  weight_e: 0.5\n  numerical_grad_on: False\n"
         f.write(CONFIG_YAML.format(out=os.path.join(work, "experiments"), pc=pc_dir, iters=args.iters, deskew=bool(args.deskew),
-                                   neural_extra=extra, loss_extra=loss))
+                                   neural_extra=extra, loss_extra=loss, bs=args.batch_size))
     # setup_experiment records `git rev-parse HEAD` (utils/tools.py:105-107): give it a repository to stand in
     subprocess.run("git init -q . && git -c user.email=e2e@x -c user.name=e2e commit -q --allow-empty -m e2e", shell=True,
                    cwd=work, check=True)
@@ -252,6 +341,9 @@ def run(args):
     else:
         sys.path.insert(0, ref)
     sys.argv = ["pin_slam.py", cfg_path]
+    if args.threads > 0:
+        torch.set_num_threads(args.threads)
+    draws = install_draw_hooks(args, log)
     import pin_slam
     classes = {n: f"{getattr(pin_slam, n).__module__}.{n}" for n in ("NeuralPoints", "Decoder", "Mapper", "Tracker", "Mesher")}
     files = {n: sys.modules[getattr(pin_slam, n).__module__].__file__ for n in ("NeuralPoints", "Mapper", "Tracker")}
@@ -272,6 +364,7 @@ def run(args):
     pin_slam.run_pin_slam(cfg_path, None, None, None, None, None, args.seed, False, False, args.impl == "reference", False, False,
                           True, False, False, False)
     log["wall_s"] = round(time.perf_counter() - t0, 2)
+    finish_draw_hooks(args, draws, log)
     ds = keep["dataset"]
     est = np.asarray(ds.odom_poses[:args.frames])
     err = np.linalg.norm(est[:, :3, 3] - gt[:, :3, 3], axis=1)
@@ -279,15 +372,22 @@ def run(args):
     log["translation_error_cm"] = [round(float(e) * 100, 2) for e in err]
     log["max_translation_error_cm"] = round(float(err.max()) * 100, 2)
     log["estimated_x"] = [round(float(v), 4) for v in est[:, 0, 3]]
+    log["estimated_xyz"] = [[round(float(v), 5) for v in row] for row in est[:, :3, 3]]
     names = ["preprocess", "odometry", "map_prep", "mapping", "loop_pgo"]
     log["time_table_ms_per_frame_excluding_first"] = {n: round(float(tt[1:, i].mean() * 1e3), 2) for i, n in enumerate(names)}
     log["time_table_ms_first_frame"] = {n: round(float(tt[0, i] * 1e3), 1) for i, n in enumerate(names)}
+    # a SLAM front end is judged on its slowest frame: median, worst frame and the frames above 3x the median per stage
+    log["time_table_ms_median_excluding_first"] = {n: round(float(np.median(tt[1:, i]) * 1e3), 2) for i, n in enumerate(names)}
+    log["time_table_ms_max_excluding_first"] = {n: round(float(tt[1:, i].max() * 1e3), 2) for i, n in enumerate(names)}
+    log["frames_above_3x_median"] = {n: int((tt[1:, i] > 3.0 * max(np.median(tt[1:, i]), 1e-4)).sum()) for i, n in enumerate(names)}
     log["frames_per_sec_excluding_first"] = round(float(1.0 / tt[1:].sum(1).mean()), 2)
     log["frames_per_sec_hot_path_stages"] = round(float(1.0 / tt[1:, :4].sum(1).mean()), 2)  # without the loop / PGO column
     log["time_table_ms"] = [[round(float(v) * 1e3, 2) for v in row] for row in tt]
     print("estimated x:", log["estimated_x"])
     print("translation error (cm):", log["translation_error_cm"])
     print("time table (ms/frame, frames 1..):", log["time_table_ms_per_frame_excluding_first"])
+    print("  median:", log["time_table_ms_median_excluding_first"], " worst frame:", log["time_table_ms_max_excluding_first"],
+          " frames above 3x median:", log["frames_above_3x_median"])
     # the saved map, loaded the way vis_pin_map.py:86-91 loads it
     run_dirs = sorted(os.listdir(os.path.join(work, "experiments")))
     model = os.path.join(work, "experiments", run_dirs[-1], "model", "pin_map.pth")
@@ -330,6 +430,12 @@ def main():
     r.add_argument("--livox-style", action="store_true", help="run_livox.yaml style: weighted_first False, query_nn_k 8, "
                                                               "numerical_grad_on False (analytic Eikonal term)")
     r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
+    r.add_argument("--batch-size", type=int, default=10000)
+    r.add_argument("--threads", type=int, default=0, help="torch.set_num_threads for the run (0 = default)")
+    r.add_argument("--record-draws", default="", help="write every torch.randn / rand / randint result of the run to this .npz "
+                                                       "(the paired accuracy run: the reference's random stream, recorded on CPU)")
+    r.add_argument("--replay-draws", default="", help="feed the run the recorded stream instead of its own generator (same calls, "
+                                                       "same shapes, in order -- checked); implies per-iteration batch draws")
     r.add_argument("--reference", default=None)
     r.add_argument("--tol-cm", type=float, default=8.0,
                    help="largest position error allowed; the unmodified reference on CPU reaches 3-6 cm on this scene "
