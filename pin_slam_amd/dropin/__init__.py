@@ -14,6 +14,46 @@ import types
 _OURS = ("model.decoder", "model.neural_points", "utils.tracker", "utils.mapper", "utils.mesher")
 
 
+def cpu_quota() -> float:
+    """CPUs this process may use: the cgroup's quota (cpu.max, v2; cfs_quota_us / cfs_period_us, v1) capped by the
+    scheduler affinity.  A GPU box reports every core of the host (256 on the MI355X hosts of this project) while its
+    container may be limited to a few of them."""
+    n = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, float(q) / float(p))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, q / p)
+        except (OSError, ValueError):
+            pass
+    return max(1.0, n)
+
+
+def limit_host_threads(verbose: bool = True) -> int:
+    """torch sizes its intra-op thread pool by the host's core count; the reference's CPU-side code around the hot path (scan-
+    context loop detection, logging) then bursts 128 threads into a container quota of 16 CPUs, the cgroup is throttled for
+    the rest of the 100 ms period and the NEXT stage of the SLAM loop -- whichever it is -- stalls for ~85 ms although the
+    GPU work of a frame is a few ms (measured: profiles/r04_e2e_host_threads.json: 14-25 frames of 60 with a stage above
+    3x its median at 128 threads, none at 4).  In drop-in mode the heavy arithmetic is on the GPU: cap the pool at the
+    quota.  PIN_KEEP_THREADS=1 leaves it alone."""
+    import torch
+    have = torch.get_num_threads()
+    if os.environ.get("PIN_KEEP_THREADS", "0") == "1":
+        return have
+    want = max(1, min(have, int(cpu_quota() // 2) or 1))
+    if want < have:
+        torch.set_num_threads(want)
+        if verbose:
+            print(f"[pin_slam_amd] torch intra-op threads {have} -> {want} (CPU quota of this container: {cpu_quota():.0f}; "
+                  f"PIN_KEEP_THREADS=1 to keep {have})", flush=True)
+    return want
+
+
 def install(reference_root: str):
     """Wire the module namespace for drop-in use.  Call before importing pin_slam."""
     reference_root = os.path.abspath(reference_root)
@@ -31,6 +71,7 @@ def install(reference_root: str):
         m.__path__ = [os.path.join(here, pkg), os.path.join(reference_root, pkg)]
         m.__package__ = pkg
         sys.modules[pkg] = m
+    limit_host_threads()
     out = {}
     for name in _OURS:  # order matters: utils.mapper looks for the reference Mapper to inherit
         real = importlib.import_module("pin_slam_amd.dropin." + name)

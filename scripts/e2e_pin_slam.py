@@ -360,6 +360,16 @@ def run(args):
         orig_init(self, *a, **k)
         keep["dataset"] = self
     sd.SLAMDataset.__init__ = spy_init
+    if args.reserve_mb > 0 and args.impl == "dropin":
+        blk = torch.empty(args.reserve_mb << 20, dtype=torch.uint8, device="cuda")
+        del blk
+    log["reserve_mb"] = args.reserve_mb
+    import gc
+    if args.gc == "off":
+        gc.disable()
+    elif args.gc == "freeze":
+        gc.collect(); gc.freeze()
+    log["gc"] = args.gc
     t0 = time.perf_counter()
     pin_slam.run_pin_slam(cfg_path, None, None, None, None, None, args.seed, False, False, args.impl == "reference", False, False,
                           True, False, False, False)
@@ -431,6 +441,11 @@ def main():
                                                               "numerical_grad_on False (analytic Eikonal term)")
     r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
     r.add_argument("--batch-size", type=int, default=10000)
+    r.add_argument("--reserve-mb", type=int, default=0, help="diagnosis: hand the caching allocator one block of this size before the "
+                                                              "run (later allocations are cut from it instead of going to hipMalloc)")
+    r.add_argument("--gc", choices=["default", "off", "freeze"], default="default",
+                   help="diagnosis of host-side stalls: run the loop with Python's cyclic garbage collector disabled / with everything "
+                        "allocated during set-up frozen out of its generations")
     r.add_argument("--threads", type=int, default=0, help="torch.set_num_threads for the run (0 = default)")
     r.add_argument("--record-draws", default="", help="write every torch.randn / rand / randint result of the run to this .npz "
                                                        "(the paired accuracy run: the reference's random stream, recorded on CPU)")
