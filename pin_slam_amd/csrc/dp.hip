@@ -369,15 +369,30 @@ __global__ __launch_bounds__(MB) void dp_owner_count_kernel(const unsigned char*
     if (threadIdx.x < world) block_cnt[(size_t)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// ... one exclusive scan over the [world][nb] counts in owner-major order (so list w starts at offsets[w]) ...
-__global__ __launch_bounds__(1024) void dp_owner_scan_kernel(int* __restrict__ block_cnt, int total, int nb, int world,
-                                                             int* __restrict__ offsets /*[world + 1]*/) {
+// ... one exclusive scan over the [world][nb] counts in owner-major order (so list w starts at offsets[w]): 1024-element tiles
+// are summed by one block each (coalesced), one block scans the tile sums, then every tile is scanned in place.  (r03: ONE block
+// walked 69 consecutive counts per thread -- uncoalesced -- 111 us per call at 8 ranks x 2.2 M rows.)
+__global__ __launch_bounds__(1024) void dp_owner_tile_sums_kernel(const int* __restrict__ block_cnt, int total, int* __restrict__ tile_sum) {
+    __shared__ int red[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < total ? block_cnt[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        tile_sum[blockIdx.x] = s;
+    }
+}
+__global__ __launch_bounds__(1024) void dp_owner_tile_scan_kernel(int* __restrict__ tile_sum, int n_tiles, int* __restrict__ grand_total) {
     __shared__ int part[1024];
     const int t = threadIdx.x;
-    const int per = (total + 1023) / 1024;
-    const int b0 = t * per, b1 = min(b0 + per, total);
+    const int per = (n_tiles + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, n_tiles);
     int s = 0;
-    for (int b = b0; b < b1; ++b) s += block_cnt[b];
+    for (int b = b0; b < b1; ++b) s += tile_sum[b];
     part[t] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -387,13 +402,29 @@ __global__ __launch_bounds__(1024) void dp_owner_scan_kernel(int* __restrict__ b
         __syncthreads();
     }
     int run = part[t] - s;
-    for (int b = b0; b < b1; ++b) {
-        const int c = block_cnt[b];
-        if (b % nb == 0) offsets[b / nb] = run;
-        block_cnt[b] = run;
-        run += c;
+    for (int b = b0; b < b1; ++b) { const int c = tile_sum[b]; tile_sum[b] = run; run += c; }
+    if (t == 1023) *grand_total = part[1023];
+}
+__global__ __launch_bounds__(1024) void dp_owner_scan_kernel(int* __restrict__ block_cnt, int total, int nb, int world,
+                                                             const int* __restrict__ tile_off, int* __restrict__ offsets /*[world]*/) {
+    __shared__ int wsum[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = i < total ? block_cnt[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
-    if (t == 1023) offsets[world] = part[1023];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = tile_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int run = base + incl - c;
+    if (i < total) {
+        if (i % nb == 0) offsets[i / nb] = run;
+        block_cnt[i] = run;
+    }
 }
 
 // ... and the scatter: row i goes to block_cnt[owner][block] + its rank among the block's rows of that owner.
@@ -732,14 +763,22 @@ extern "C" int pin_dp_owner_lists(const uint8_t* owner, int32_t n_rows, int32_t 
     int* block_cnt = cv.take<int>((size_t)world * nb);
     PIN_CHECK_ARG(block_cnt, "workspace too small (pin_dp_owner_lists_workspace_bytes)");
     hipLaunchKernelGGL(dp_owner_count_kernel, dim3(nb), dim3(MB), 0, s, owner, n_rows, world, block_cnt, nb);
-    hipLaunchKernelGGL(dp_owner_scan_kernel, dim3(1), dim3(1024), 0, s, block_cnt, world * nb, nb, world, offsets_out);
+    {
+        const int total = world * nb, n_tiles = cdiv(total, 1024);
+        int* tile_sum = cv.take<int>(n_tiles + 1);
+        PIN_CHECK_ARG(tile_sum, "workspace too small (pin_dp_owner_lists_workspace_bytes)");
+        hipLaunchKernelGGL(dp_owner_tile_sums_kernel, dim3(n_tiles), dim3(1024), 0, s, block_cnt, total, tile_sum);
+        hipLaunchKernelGGL(dp_owner_tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_sum, n_tiles, offsets_out + world);
+        hipLaunchKernelGGL(dp_owner_scan_kernel, dim3(n_tiles), dim3(1024), 0, s, block_cnt, total, nb, world, tile_sum, offsets_out);
+    }
     hipLaunchKernelGGL(dp_owner_scatter_kernel, dim3(nb), dim3(MB), 0, s, owner, n_rows, world, block_cnt, nb, lists_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int64_t pin_dp_owner_lists_workspace_bytes(int32_t n_rows, int32_t world) {
-    return 512 + (int64_t)sizeof(int) * (world < 1 ? 1 : world) * (int64_t)cdiv(n_rows < 0 ? 0 : n_rows, MB);
+    const int64_t counts = (int64_t)(world < 1 ? 1 : world) * (int64_t)cdiv(n_rows < 0 ? 0 : n_rows, MB);
+    return 1024 + (int64_t)sizeof(int) * (counts + counts / 1024 + 2);
 }
 
 extern "C" int pin_dp_exclude_rows(const int32_t* rows, int32_t n, int32_t* lazy_pending, void* stream) {
