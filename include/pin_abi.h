@@ -108,6 +108,10 @@ typedef struct pin_brick_cache {
     int32_t n_dilate;        /* = num_nei_cells (<= 2): bricks cover every cell within n of a local point */
     uint64_t* dir_pack;      /* [dir_mask+1][4] what a query reads: key, mask, base (low 32 bits; -1 = not cached), pad --
                                 one 32-byte slot per probe instead of the key -> id -> mask/base chain */
+    void* build_ws;          /* scratch of pin_brick_build (pin_brick_build_workspace_bytes(n_points, max_bricks)); with it the
+                                cache is built from the POINTS (one table probe per point instead of one per cell of every brick;
+                                same directory contents, masks and entries) -- NULL: the cell-driven build */
+    int64_t build_ws_bytes;
 } pin_brick_cache;
 
 /* ---- the implicit field: feature tables + decoder (NeuralPoints.query_feature
@@ -382,6 +386,7 @@ int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* gp, const p
 /* Per-frame build of the brick cache (after reset_local_map / update).  counters_out:
  * int32[4] on the device = (bricks, entries, overflow flags, 0); flags != 0 or counts beyond
  * the capacities mean the caller must enlarge the buffers and rebuild. */
+int64_t pin_brick_build_workspace_bytes(int32_t n_points, int32_t max_bricks);
 int pin_brick_build(const pin_search_params* sp, const pin_brick_cache* bc, int32_t* counters_out,
                     void* stream);
 

@@ -38,7 +38,7 @@ class BrickCacheC(C.Structure):
     _fields_ = [
         ("dir_keys", vp), ("dir_vals", vp), ("brick_keys", vp), ("brick_mask", vp), ("brick_base", vp),
         ("entries", vp), ("cand_dx", vp), ("dir_mask", C.c_uint32), ("max_bricks", C.c_int32),
-        ("max_entries", C.c_int32), ("n_dilate", C.c_int32), ("dir_pack", vp),
+        ("max_entries", C.c_int32), ("n_dilate", C.c_int32), ("dir_pack", vp), ("build_ws", vp), ("build_ws_bytes", C.c_int64),
     ]
 
 
@@ -173,6 +173,7 @@ SIGNATURES = {
     "pin_gn_accumulate_dev": (i32, [P(Field), P(GnParams), P(ColorTerm), vp, vp, vp, vp, i32, vp, vp, vp]),
     "pin_gn_solve": (i32, [vp, vp, P(GnLoopParams), vp]),
     "pin_gn_accumulate_solve": (i32, [P(Field), P(GnParams), P(ColorTerm), P(GnLoopParams), vp, vp, vp, vp, i32, vp, vp, vp]),
+    "pin_brick_build_workspace_bytes": (i64, [i32, i32]),
     "pin_brick_build": (i32, [P(SearchParams), P(BrickCacheC), vp, vp]),
     "pin_knn_query_bricks": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_query_feature": (i32, [P(Field), vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),

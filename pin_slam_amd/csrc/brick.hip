@@ -18,6 +18,7 @@
 // are not in the directory fall back to the exact slow path, so results are identical to
 // pin_knn_query in all cases (tests/test_gpu_bricks.py checks bit equality).
 #include "brick.h"
+#include "compact.h"
 
 namespace pin {
 
@@ -142,6 +143,192 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin
         }
         base += __popcll(mask[u]);
     }
+}
+
+// ---- point-driven build (r04; pin_brick_cache.build_ws != NULL) ---------------------------------------------------------------
+// The cell-driven build above asks "what does the table hold for this cell?" for all 64 cells of every brick -- 4.7 M random table
+// probes for 74 k bricks at 2.2 M points, 60 % of them for empty cells (0.22 ms), after a marking pass in which every local point
+// probes the directory for up to 8 bricks (0.15 ms).  The same cache can be built from the POINTS:
+//   * an entry of cell c is non-empty only if table[hash(c)] is a point near c; with no second cell within the pruning reach that
+//     shares c's hash (checked on the host for the table size at hand: brick_alias_free) that point lies IN c.  So point j
+//     contributes exactly to its own cell, and only if it owns its slot (table[hash(cell(j))] == j: the last writer of a
+//     collision) and passes the time filter -- the same chain lookup_cell evaluates, entered from the other end: 2.2 M probes.
+//   * the set of bricks -- those that intersect [g - n, g + n]^3 for the cell g of some local point -- is the set of the local
+//     points' own bricks, dilated: neighbour d in {-1, 0, 1}^3 of an own brick is needed iff one of its occupied cells lies within
+//     n of that face / edge / corner, which the brick's 64-bit mask of local-point cells answers with one AND per direction.
+// Same directory contents (in another order of ids), same masks, same entries per cell: tests/test_gpu_bricks.py builds both ways.
+struct BrickDirMasks { unsigned long long m[27]; };
+
+// every lane of the wave calls this (has = this lane brings a key): directory probe + wave-aggregated id allocation
+__device__ __forceinline__ void brick_insert(const pin_brick_cache& bc, unsigned long long key, bool has, int* __restrict__ counters) {
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(bc.dir_keys);
+    const int lane = threadIdx.x & 63;
+    bool won = false;
+    unsigned int h = 0;
+    if (has) {
+        h = mix64(key) & bc.dir_mask;
+        for (int probe = 0; probe < 64; ++probe) {
+            unsigned long long prev = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == BRICK_EMPTY) prev = atomicCAS(keys + h, BRICK_EMPTY, key);
+            if (prev == BRICK_EMPTY) { won = true; break; }
+            if (prev == key) break;
+            h = (h + 1) & bc.dir_mask;
+            if (probe == 63) atomicOr(counters + 2, 2);
+        }
+    }
+    const unsigned long long bal = __ballot(won);
+    if (bal != 0ull) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(counters + 0, __popcll(bal));
+        base = __shfl(base, leader, 64);
+        if (won) {
+            const int id = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (id < bc.max_bricks) { bc.brick_keys[id] = key; bc.dir_vals[h] = id; }
+            else { bc.dir_vals[h] = -1; atomicOr(counters + 2, 1); }
+        }
+    }
+}
+
+__device__ __forceinline__ bool brick_point_cell(const pin_search_params& sp, int j, float4& P, int (&g)[3]) {
+    P = reinterpret_cast<const float4*>(sp.pos4)[j];
+    g[0] = (int)voxel_coord(P.x, sp.resolution); g[1] = (int)voxel_coord(P.y, sp.resolution); g[2] = (int)voxel_coord(P.z, sp.resolution);
+    return true;
+}
+
+// M1: every local point's OWN brick
+__global__ __launch_bounds__(256) void brick_own_kernel(pin_brick_cache bc, pin_search_params sp, int* __restrict__ counters) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    bool work = j < sp.n_points && !(sp.global2local != nullptr && sp.global2local[j] < 0);
+    unsigned long long key = 0;
+    if (work) {
+        float4 P; int g[3];
+        brick_point_cell(sp, j, P, g);
+        key = brick_key(g[0] >> 2, g[1] >> 2, g[2] >> 2);
+        if (j > 0 && (sp.global2local == nullptr || sp.global2local[j - 1] >= 0)) {  // (neighbours in memory are often neighbours in space)
+            float4 Q; int q[3];
+            brick_point_cell(sp, j - 1, Q, q);
+            if (brick_key(q[0] >> 2, q[1] >> 2, q[2] >> 2) == key) work = false;
+        }
+    }
+    brick_insert(bc, key, work, counters);
+}
+
+// M1b: the cells of the local points, per own brick (what the dilation needs); thread 0 freezes the number of own bricks
+__global__ __launch_bounds__(256) void brick_pmask_kernel(pin_brick_cache bc, pin_search_params sp, unsigned long long* __restrict__ pmask,
+                                                          int* __restrict__ counters) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) counters[3] = min(counters[0], bc.max_bricks);
+    if (j >= sp.n_points || (sp.global2local != nullptr && sp.global2local[j] < 0)) return;
+    float4 P; int g[3];
+    brick_point_cell(sp, j, P, g);
+    const int id = dir_find(bc, brick_key(g[0] >> 2, g[1] >> 2, g[2] >> 2));
+    if (id < 0 || id >= bc.max_bricks) return;
+    const unsigned long long bit = 1ull << (((g[0] & 3) << 4) | ((g[1] & 3) << 2) | (g[2] & 3));
+    if ((__hip_atomic_load(pmask + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0ull) atomicOr(pmask + id, bit);
+}
+
+// M2: one thread per (own brick, direction): the neighbour brick is needed iff a local point's cell lies within n of that side
+__global__ __launch_bounds__(256) void brick_dilate_kernel(pin_brick_cache bc, const unsigned long long* __restrict__ pmask,
+                                                           BrickDirMasks dm, int* __restrict__ counters) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = (int)(t / 27), d = (int)(t - (long)b * 27);
+    bool has = b < counters[3] && d != 13;
+    unsigned long long key = 0;
+    if (has) {
+        has = (pmask[b] & dm.m[d]) != 0ull;
+        if (has) {
+            const unsigned long long k0 = bc.brick_keys[b];
+            const int bx = (int)((k0 >> 42) & 0x1fffff) - (1 << 20), by = (int)((k0 >> 21) & 0x1fffff) - (1 << 20),
+                      bz = (int)(k0 & 0x1fffff) - (1 << 20);
+            key = brick_key(bx + d / 9 - 1, by + (d / 3) % 3 - 1, bz + d % 3 - 1);
+        }
+    }
+    brick_insert(bc, key, has, counters);
+}
+
+// A: every point that owns its table slot, passes the time filter and lies in a marked brick sets its cell's bit
+__global__ __launch_bounds__(256) void brick_point_mask_kernel(pin_brick_cache bc, pin_search_params sp, float prune_dist2,
+                                                               int2* __restrict__ tmp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= sp.n_points) return;
+    int2 out = make_int2(-1, -1);
+    float4 P; int g[3];
+    brick_point_cell(sp, j, P, g);
+    const long long h = (long long)g[0] * PRIME0 + (long long)g[1] * PRIME1 + (long long)g[2] * PRIME2;
+    bool ok = sp.table[mod_nonneg(h, sp.buffer_size)] == j;
+    if (ok && sp.travel_dist != nullptr) {
+        const float d_cur = sp.travel_dist[sp.cur_ts];
+        const float dts = sp.travel_dist[__float_as_int(P.w)];
+        ok = fabsf(d_cur - dts) < sp.diff_travel_dist_local;
+    }
+    int l = j;
+    if (ok && sp.global2local != nullptr) {
+        l = sp.global2local[j];
+        if (l == PIN_NONLOCAL) l = 1 | PIN_NBR_QUIRK_BIT;
+        ok = l >= 0;
+    }
+    if (ok) {  // (the pruning test of the cell-driven fill; a point is always within reach of its own cell)
+        const float r = sp.resolution;
+        const float ex = P.x - (g[0] + 0.5f) * r, ey = P.y - (g[1] + 0.5f) * r, ez = P.z - (g[2] + 0.5f) * r;
+        ok = (ex * ex + ey * ey + ez * ez) <= prune_dist2;
+    }
+    if (ok) {
+        const int id = dir_find(bc, brick_key(g[0] >> 2, g[1] >> 2, g[2] >> 2));
+        if (id >= 0 && id < bc.max_bricks) {
+            const int bit = ((g[0] & 3) << 4) | ((g[1] & 3) << 2) | (g[2] & 3);
+            atomicOr(reinterpret_cast<unsigned long long*>(bc.brick_mask) + id, 1ull << bit);
+            out = make_int2(id | (bit << 24), l);
+        }
+    }
+    tmp[j] = out;
+}
+
+// B: entry ranges, one atomic per block of bricks
+__global__ __launch_bounds__(256) void brick_bases_kernel(pin_brick_cache bc, int* __restrict__ counters) {
+    __shared__ int wave_tot[4];
+    __shared__ int block_base;
+    const int nb = min(counters[0], bc.max_bricks);
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = b < nb ? __popcll(bc.brick_mask[b]) : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) block_base = atomicAdd(counters + 1, wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]);
+    __syncthreads();
+    int base = block_base + incl - cnt;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    if (b < nb) {
+        const bool fits = base + cnt <= bc.max_entries;
+        bc.brick_base[b] = fits ? base : -1;  // (a brick whose entries do not fit is "not cached": its cells take the exact probe)
+        if (!fits && cnt > 0) atomicOr(counters + 2, 4);
+    }
+}
+
+// C: the entries, in cell-bit order inside their brick
+__global__ __launch_bounds__(256) void brick_point_entries_kernel(pin_brick_cache bc, pin_search_params sp, const int2* __restrict__ tmp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= sp.n_points) return;
+    const int2 t = tmp[j];
+    if (t.x < 0) return;
+    const int id = t.x & 0xffffff, bit = t.x >> 24;
+    const int base = bc.brick_base[id];
+    if (base < 0) return;
+    const unsigned long long m = bc.brick_mask[id];
+    const int e = base + __popcll(m & ((1ull << bit) - 1ull));
+    const float4 P = reinterpret_cast<const float4*>(sp.pos4)[j];
+    reinterpret_cast<float4*>(bc.entries)[e] = make_float4(P.x, P.y, P.z, __int_as_float(t.y));
+}
+
+__global__ void brick_zero_masks_kernel(unsigned long long* a, unsigned long long* b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0ull; b[i] = 0ull; }
 }
 
 __global__ void brick_clear_kernel(unsigned long long* keys, int n, int* counters, float4* entries, int max_entries) {
@@ -701,6 +888,31 @@ __global__ __launch_bounds__(BRICK_BLOCK) void knn_brick_listed_kernel(pin_searc
 
 using namespace pin;
 
+extern "C" int64_t pin_brick_build_workspace_bytes(int32_t n_points, int32_t max_bricks) {
+    return 1024 + 8 * (int64_t)(max_bricks < 0 ? 0 : max_bricks) + 8 * (int64_t)(n_points < 0 ? 0 : n_points);
+}
+
+// No second cell within `reach` cells of a cell shares its hash slot: d . (PRIME0, PRIME1, PRIME2) = 0 (mod buffer_size) has no
+// solution 0 < |d|_inf <= reach.  (None for the table sizes in use -- 5e7, 1e7, 2e7, 1e5 up to reach 13 -- but the point-driven
+// build is only exact when that holds, so it is checked, once per (size, reach).)
+static bool brick_alias_free(long long B, int reach) {
+    static long long seen_B = 0;
+    static int seen_reach = 0;
+    static bool seen_ok = false;
+    if (B == seen_B && reach <= seen_reach && seen_ok) return true;
+    if (B == seen_B && reach == seen_reach) return seen_ok;
+    bool ok = B > 0;
+    for (int x = -reach; x <= reach && ok; ++x)
+        for (int y = -reach; y <= reach && ok; ++y)
+            for (int z = -reach; z <= reach && ok; ++z) {
+                if (x == 0 && y == 0 && z == 0) continue;
+                const long long h = x * PRIME0 + y * PRIME1 + z * PRIME2;
+                if (h % B == 0) ok = false;
+            }
+    seen_B = B; seen_reach = reach; seen_ok = ok;
+    return ok;
+}
+
 extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cache* bc, int32_t* counters_out,
                                void* stream) {
     PIN_ENTER();
@@ -715,14 +927,46 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     hipLaunchKernelGGL(brick_clear_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out,
                        reinterpret_cast<float4*>(bc->entries), bc->max_entries);
-    hipLaunchKernelGGL(brick_mark_kernel, dim3(cdiv(sp->n_points, 256)), dim3(256), 0, s, *bc, *sp, bc->n_dilate,
-                       counters_out);
     // a probing query sits within (n+1) cells (per axis) of the cell centre and accepts points
     // within sqrt(max_valid_dist2): anything farther from the cell centre can never be accepted
     const float reach = (bc->n_dilate + 1.0f) * sp->resolution * 1.7320508f + sqrtf(sp->max_valid_dist2);
     const float prune = reach * reach * 1.02f;
-    hipLaunchKernelGGL(brick_fill_kernel, dim3(cdiv(bc->max_bricks, 4 * FILL_PER_WAVE)), dim3(256), 0, s, *bc, *sp, prune,
-                       counters_out);
+    static const bool cells_forced = [] { const char* e = getenv("PIN_BRICK_BUILD"); return e && e[0] == 'c'; }();
+    const bool by_points = bc->build_ws != nullptr && !cells_forced && bc->max_bricks < (1 << 24) &&
+                           bc->build_ws_bytes >= pin_brick_build_workspace_bytes(sp->n_points, bc->max_bricks) &&
+                           brick_alias_free(sp->buffer_size, (int)ceilf(reach * 1.01f / sp->resolution) + 2);
+    if (by_points) {
+        Carver cv{static_cast<char*>(bc->build_ws), static_cast<char*>(bc->build_ws) + bc->build_ws_bytes};
+        unsigned long long* pmask = cv.take<unsigned long long>(bc->max_bricks);
+        int2* tmp = cv.take<int2>(sp->n_points);
+        const int n = bc->n_dilate;
+        BrickDirMasks dm;
+        for (int d = 0; d < 27; ++d) {  // cells of a brick within n of the side (d / 9 - 1, (d / 3) % 3 - 1, d % 3 - 1)
+            const int dir[3] = {d / 9 - 1, (d / 3) % 3 - 1, d % 3 - 1};
+            unsigned long long m = 0;
+            for (int bit = 0; bit < 64; ++bit) {
+                const int c[3] = {bit >> 4, (bit >> 2) & 3, bit & 3};
+                bool in = true;
+                for (int a = 0; a < 3; ++a) in = in && (dir[a] == 0 || (dir[a] < 0 ? c[a] < n : c[a] > 3 - n));
+                if (in) m |= 1ull << bit;
+            }
+            dm.m[d] = m;
+        }
+        const int pb = cdiv(sp->n_points, 256);
+        hipLaunchKernelGGL(brick_zero_masks_kernel, dim3(cdiv(bc->max_bricks, 256)), dim3(256), 0, s, pmask,
+                           reinterpret_cast<unsigned long long*>(bc->brick_mask), bc->max_bricks);
+        hipLaunchKernelGGL(brick_own_kernel, dim3(pb), dim3(256), 0, s, *bc, *sp, counters_out);
+        hipLaunchKernelGGL(brick_pmask_kernel, dim3(pb), dim3(256), 0, s, *bc, *sp, pmask, counters_out);
+        hipLaunchKernelGGL(brick_dilate_kernel, dim3(cdiv((long)bc->max_bricks * 27, 256)), dim3(256), 0, s, *bc, pmask, dm, counters_out);
+        hipLaunchKernelGGL(brick_point_mask_kernel, dim3(pb), dim3(256), 0, s, *bc, *sp, prune, tmp);
+        hipLaunchKernelGGL(brick_bases_kernel, dim3(cdiv(bc->max_bricks, 256)), dim3(256), 0, s, *bc, counters_out);
+        hipLaunchKernelGGL(brick_point_entries_kernel, dim3(pb), dim3(256), 0, s, *bc, *sp, tmp);
+    } else {
+        hipLaunchKernelGGL(brick_mark_kernel, dim3(cdiv(sp->n_points, 256)), dim3(256), 0, s, *bc, *sp, bc->n_dilate,
+                           counters_out);
+        hipLaunchKernelGGL(brick_fill_kernel, dim3(cdiv(bc->max_bricks, 4 * FILL_PER_WAVE)), dim3(256), 0, s, *bc, *sp, prune,
+                           counters_out);
+    }
     hipLaunchKernelGGL(brick_publish_kernel, dim3(cdiv((long)bc->dir_mask + 1, 256)), dim3(256), 0, s, *bc);
     PIN_CHECK_LAUNCH();
     return 0;

@@ -149,6 +149,7 @@ class BrickCache:
         self.counters = torch.zeros(4, dtype=torch.int32, device=device)
         self.mode = None
         self.n_bricks = self.n_entries = 0
+        self.by_points = os.environ.get("PIN_BRICK_BUILD", "points")[:1] != "c"
         self._host = self._event = None
         self._pending = False
         self._alloc(1 << 16, 1 << 18)
@@ -166,6 +167,7 @@ class BrickCache:
         self.brick_base = torch.empty(max_bricks, dtype=torch.int32, device=d)
         self.entries = torch.empty((max_entries + 1, 4), dtype=torch.float32, device=d)  # + the sentinel row (pin_brick_build)
         self.max_bricks, self.max_entries, self.dsize = max_bricks, max_entries, dsize
+        self.build_ws = None  # (sized per build: it depends on the number of points)
 
     def params(self) -> "_lib.BrickCacheC":
         bc = _lib.BrickCacheC()
@@ -174,6 +176,8 @@ class BrickCache:
         bc.cand_dx = self.cand_dx.data_ptr()
         bc.dir_pack = self.dir_pack.data_ptr()
         bc.dir_mask, bc.max_bricks, bc.max_entries, bc.n_dilate = self.dsize - 1, self.max_bricks, self.max_entries, self.n_dilate
+        if self.build_ws is not None:
+            bc.build_ws, bc.build_ws_bytes = self.build_ws.data_ptr(), self.build_ws.numel()
         return bc
 
     def build(self, st: "SearchState", time_filtering=True, local=True, wait: bool = False):
@@ -188,6 +192,12 @@ class BrickCache:
         if want_b > self.max_bricks or want_e > self.max_entries:
             self._alloc(max(self.max_bricks, want_b), max(self.max_entries, want_e))
         sp = st.params(time_filtering=time_filtering, local=local)
+        if self.by_points:  # scratch of the point-driven build (PIN_BRICK_BUILD=cells / by_points = False: the cell-driven one)
+            need = int(_lib.lib().pin_brick_build_workspace_bytes(st.n_points, self.max_bricks))
+            if self.build_ws is None or self.build_ws.numel() < need:
+                self.build_ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.uint8, device=self.device)
+        else:
+            self.build_ws = None
         bc = self.params()
         check(_lib.lib().pin_brick_build(C.byref(sp), C.byref(bc), self.counters.data_ptr(), _stream()), "pin_brick_build")
         if self._host is None:

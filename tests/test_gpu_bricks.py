@@ -199,3 +199,54 @@ def test_listed_search_equals_full_search(case, scale):
         assert max(moved[4:]) < 0.01, moved  # millimetre steps: (almost) nobody changes voxel, every search runs off its list
     else:
         assert moved[1] > 0.5 and moved[-1] < 0.01, moved
+
+
+def _cache_contents(b):
+    """{brick key: (mask, {cell bit: entry bits})} of a built cache (ids and entry ranges differ between the two builds)."""
+    nb = b.n_bricks
+    keys = b.brick_keys[:nb].cpu().numpy()
+    masks = b.brick_mask[:nb].cpu().numpy().astype(np.uint64)
+    bases = b.brick_base[:nb].cpu().numpy()
+    ent = b.entries.cpu().numpy().view(np.uint32)
+    out = {}
+    for key, m, base in zip(keys.tolist(), masks.tolist(), bases.tolist()):
+        cells = {}
+        e = base
+        for bit in range(64):
+            if (m >> bit) & 1:
+                cells[bit] = tuple(ent[e].tolist()) if base >= 0 else None
+                e += 1
+        out[key] = (m, cells)
+    return out
+
+
+@pytest.mark.parametrize("case", ["c2_wf", "kitti_nwf", "c3_bigtable", "nonlocal"])
+def test_point_driven_build_equals_cell_driven_build(case):
+    """pin_brick_build from the POINTS (r04: own bricks + mask-based dilation, one table probe per point) against the build
+    from the CELLS of every brick: the same set of bricks, the same occupancy masks, the same entry per cell, bit for bit --
+    on fixtures with a collision-heavy table, per-neighbour settings and the non-local quirk (points outside the local map
+    still get their entries)."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    d = G.load("c2_wf" if case == "nonlocal" else case)
+    st = U.search_state(d)
+    if case == "nonlocal":
+        mask, g2l = O.local_map_mask(d["neural_points"], d["point_ts_create"], [16.0, 0, 0], 6.0, travel_dist=d["travel_dist"],
+                                     cur_ts=int(d["cur_ts"]), diff_travel_dist_local=d["diff_travel_dist_local"], reboot_ts=0)
+        st = dataclasses.replace(st, global2local=U.dev(U.g2l_to_device_format(g2l, np.append(mask, True))))
+    n = int(d["num_nei_cells"])
+    a = ops.BrickCache(d["neighbor_dx"], n)
+    assert a.by_points
+    a.build(st, wait=True)
+    b = ops.BrickCache(d["neighbor_dx"], n)
+    b.by_points = False
+    b.build(st, wait=True)
+    assert a.build_ws is not None and b.build_ws is None
+    assert a.n_bricks == b.n_bricks and a.n_entries == b.n_entries and a.n_bricks > 100
+    ca, cb = _cache_contents(a), _cache_contents(b)
+    assert ca.keys() == cb.keys()
+    for key in ca:
+        assert ca[key] == cb[key], f"brick {key:#x} differs"
+    q = U.dev(d["query"])
+    ra, rb = ops.knn_query(st, q, int(d["query_nn_k"]), bricks=a), ops.knn_query(st, q, int(d["query_nn_k"]), bricks=b)
+    assert torch.equal(ra[0].view(torch.int32), rb[0].view(torch.int32)) and torch.equal(ra[1], rb[1])
