@@ -558,6 +558,7 @@ def main():
         "frames_per_sec_source_downsampled": None if elapsed_ds is None else round(world * args.steps / elapsed_ds, 3),
         "source_points": n_src,
         "gn_iterations": int(its), "gn_valid_points": int(cnt), "gn_residual_cm": round(float(res_cm), 4),
+        "host_trace_ms": (lambda hc: hc.trace_summary() if hc.TRACE else None)(__import__("pin_slam_amd.hostcache", fromlist=["x"])),
         "knn_coherent_probe": probe,
         "moving_sensor": moving,
         "mesher": mesher_leg,

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import _lib, ops
+from ... import hostcache, _lib, ops
 from ..._lib import PIN_NONLOCAL, LocalArrays, LocalParams, MapArrays, PruneParams, RehashParams, UpdateParams, check
 
 
@@ -261,7 +261,9 @@ class NeuralPoints(nn.Module):
                   "pin_voxel_downsample")
             check(L.pin_map_update(C.byref(ma), C.byref(up), _p(points), _p(sel), _p(self._cnt[0:1]), _p(self._cnt[1:2]),
                                    _p(ws), ws.numel(), stream), "pin_map_update")
+            hostcache.stamp("up:vds_update_enqueued")
             n_sel, n_new = (int(v) for v in self._cnt[:2].tolist())  # the one host sync of update()
+            hostcache.stamp("up:sync2_done")
             if n_sel >= 0:
                 break
         old = self._n
@@ -271,7 +273,9 @@ class NeuralPoints(nn.Module):
         g["geo"][old:self._n + 1] = self.geo_feature_std * torch.randn(n_new + 1, 8, device=self.device)
         if self.color_on:
             g["color"][old:self._n + 1] = self.color_feature_std * torch.randn(n_new + 1, 8, device=self.device)
+        hostcache.stamp("up:features_enqueued")
         self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
+        hostcache.stamp("up:local_map_bricks_enqueued")
         return n_new / max(n_sel, 1)
 
     # ------------------------------------------------------------------ K9: reset_local_map

@@ -169,6 +169,7 @@ class Mapper(_Base):
         if c.color_on and c.color_channel not in (1, 3):
             raise NotImplementedError("colour pool with color_channel not in (1, 3)")
         # the pose on the host: the tracker wrote this tensor from host numbers a moment ago (hostcache), so no copy back
+        hostcache.stamp("pf:start")
         pose_np = np.ascontiguousarray(hostcache.to_host(cur_pose_torch), dtype=np.float64)
         origin, orientation = cur_pose_torch[:3, 3], cur_pose_torch[:3, :3]
         npts._sensor_hint = (origin, pose_np[:3, 3].copy())  # reset_local_map(origin, ...) needs it on the host as well
@@ -185,12 +186,14 @@ class Mapper(_Base):
             scan = scan[self.static_mask].contiguous()
         self.dataset.static_mask = self.static_mask
 
+        hostcache.stamp("pf:before_sampler")
         # K12: DataSampler.sample + pool append + sensor->world transform
         p = self._pool()
         n_hist = p.n
         n_new = p.append_samples(scan, pool_mod.sample_params(c, pose_np, frame_id))
         self.cur_sample_count = n_new
         self.pool_sample_count = n_hist
+        hostcache.stamp("pf:sampler_enqueued")
 
         # map growth (mapper.py:236-262).  The window mask of the pool filter does not depend on the map, so it
         # is queued first and its kept-count comes back in the same read-back as the surface-point count.
@@ -203,6 +206,7 @@ class Mapper(_Base):
                                                  np.float32(c.surface_sample_range_m * c.map_surface_ratio))
         if filtering:
             p.filter_begin(pose_np[:3, 3], c.window_radius, int(c.pool_capacity))
+        hostcache.stamp("pf:select_window_enqueued")
         kept = None
         if sel is not None:
             both = torch.stack((cnt[0], p.counts[0])).tolist() if filtering else [int(cnt.item()), None]
@@ -212,6 +216,7 @@ class Mapper(_Base):
         else:
             update_points = torch.empty((scan.shape[0], 3), dtype=torch.float32, device=self.device)
             ops.transform_points(scan, pose_np, update_points)
+        hostcache.stamp("pf:sync1_done")
         if c.prune_map_on and ((frame_id + 1) % c.prune_freq_frame == 0):
             if npts.prune_map(c.max_prune_certainty):
                 npts.recreate_hash(None, None, True, True, frame_id)
@@ -222,6 +227,7 @@ class Mapper(_Base):
             self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
         finally:
             npts._defer_local_count = False
+        hostcache.stamp("pf:update_done")
         try:
             self._process_frame_tail(c, npts, p, frame_id, filtering, kept, n_new, defer)
         finally:
@@ -240,6 +246,7 @@ class Mapper(_Base):
         else:
             self.cur_sample_count, self.pool_sample_count = n_new, p.n
         self._publish_pool()
+        hostcache.stamp("pf:filter_done_sync3")
 
         # K14: newly observed close-to-surface samples (mapper.py:368-439)
         if c.bs_new_sample > 0:
@@ -248,12 +255,14 @@ class Mapper(_Base):
             cert = npts._query_certainty(p.bufs[0]["global_coord"][first:first + cur], own_cell=True)
             idx, cnt = ops.new_sample_index(cert, p.bufs[0]["sdf_label"][first:first + cur], c.new_certainty_thre,
                                             np.float32(c.surface_sample_range_m * 3.0), offset=first)
+            hostcache.stamp("pf:certainty_enqueued")
             if getattr(npts, "_local_count_pending", False):
                 new_count, counted = (int(v) for v in torch.stack((cnt[0], npts._cnt[2])).tolist())
                 npts._finish_local_map(counted)
                 npts.record_memory(verbose=False)
             else:
                 new_count = int(cnt.item())
+            hostcache.stamp("pf:sync4_done")
             self.new_idx = idx[:new_count]
             self.adaptive_iter_offset = 0
             if c.adaptive_iters and cur > 0:

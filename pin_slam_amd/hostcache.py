@@ -53,3 +53,30 @@ def to_host(t: torch.Tensor) -> np.ndarray:
         a = t.detach().to("cpu").numpy().copy()
         remember(t, a)
     return a
+
+
+# ---- optional host-side stamps (PIN_HOST_TRACE=1): where the Python time of a frame goes ---------------------------------------
+import os as _os
+import time as _time
+
+TRACE = _os.environ.get("PIN_HOST_TRACE", "0") == "1"
+_stamps: list = []
+
+
+def stamp(label: str) -> None:
+    if TRACE:
+        _stamps.append((label, _time.perf_counter()))
+
+
+def trace_summary():
+    """Mean host time (ms) between consecutive stamps, keyed "from -> to", over everything recorded so far."""
+    acc: dict = {}
+    for (a, ta), (b, tb) in zip(_stamps, _stamps[1:]):
+        k = f"{a} -> {b}"
+        s, n = acc.get(k, (0.0, 0))
+        acc[k] = (s + (tb - ta), n + 1)
+    return {k: (round(1e3 * s / n, 4), n) for k, (s, n) in acc.items()}
+
+
+def trace_reset():
+    del _stamps[:]
