@@ -149,7 +149,9 @@ class BrickCache:
         self.counters = torch.zeros(4, dtype=torch.int32, device=device)
         self.mode = None
         self.n_bricks = self.n_entries = 0
-        self.by_points = os.environ.get("PIN_BRICK_BUILD", "points")[:1] != "c"
+        # the point-driven build (one table probe per point, mask-based dilation) is bit-identical to the cell-driven one but NOT
+        # faster: 443 vs 405 us of kernel time per build at 2.2 M points (profiles/r04_bench_c3_kernel_stats.csv) -- off by default
+        self.by_points = os.environ.get("PIN_BRICK_BUILD", "cells")[:1] == "p"
         self._host = self._event = None
         self._pending = False
         self._alloc(1 << 16, 1 << 18)
