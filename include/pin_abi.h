@@ -854,6 +854,20 @@ int pin_dp_gather(const float* pool_coord, const float* pool_label, const float*
                   int32_t n_batches, float* coord_out, float* label_out, float* weight_out, int32_t* ts_out,
                   float* color_out, float* query_out, float eps, void* stream);
 
+/* Training-mode side effects of a whole Mapper.mapping call at once (query_feature(training_mode=True), neural_points.py:
+ * 685-710: certainty[idx_k] += w_k and ts_update[idx_k] = max(., sample ts) for every main query).  With per-pool-sample
+ * neighbour records (pin_gather_records_drawn / pin_dp_gather_records) a sample drawn m times adds m x the same weights:
+ * pin_count_draws counts how often every pool row appears in the call's index batches (index_history [n_history_total] and
+ * new_idx[index_new_batch[.]] [n_new_total], all iterations; count [pool rows] zeroed by the caller), and
+ * pin_certainty_from_records applies certainty[idx_k] += m w_k / the ts maximum from the records in one pass over the pool rows
+ * (pool_to_rec: row -> record index, or NULL for the identity; rows with pool_to_rec < 0 are another rank's).  The training
+ * launches of such a call run with certainty_rw = ts_update_rw = NULL. */
+int pin_count_draws(const int64_t* index_history, int64_t n_history_total, const int64_t* index_new_batch, const int64_t* new_idx,
+                    int64_t n_new_total, int32_t* count, void* stream);
+int pin_certainty_from_records(const float* rec_nbr, const int32_t* rec_nn, int32_t k, const int32_t* pool_to_rec,
+                               const int32_t* count, const int32_t* pool_ts, int64_t n_pool, float* certainty_rw,
+                               int32_t* ts_update_rw, void* stream);
+
 /* Neighbour records of THIS rank's pool samples, searched once per Mapper.mapping call (the neural points do not move while
  * the map trains; a 2^20 batch draws every pool sample ~6 times per call): the one-GPU path's pin_gather_records_drawn for
  * the spatial shards.

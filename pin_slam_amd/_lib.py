@@ -237,6 +237,8 @@ SIGNATURES = {
     "pin_dp_partition": (i32, [P(DpRegions), vp, vp, i32, vp, vp, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, f32, vp, vp]),
     "pin_dp_gather": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp,
                             vp, vp, f32, vp]),
+    "pin_count_draws": (i32, [vp, i64, vp, vp, i64, vp, vp]),
+    "pin_certainty_from_records": (i32, [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp]),
     "pin_dp_own_pool": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp, i64, vp]),
     "pin_dp_gather_records": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i64, i64, vp, i32, i32, vp, i32, vp, vp, vp]),
     "pin_dp_mark_halo": (i32, [P(DpRegions), vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]),

@@ -932,6 +932,70 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const float4* __res
     if (t == 0) nn_out[o] = pool_nn[s];
 }
 
+// ---- training-mode side effects of a whole call at once (pin_count_draws + pin_certainty_from_records) ----------------------
+// query_feature(training_mode=True) adds every main query's IDW weights to the certainty of its neighbours and raises their
+// ts_update (neural_points.py:685-710).  Neither feeds back into the loss, and when a call's neighbour records are per POOL SAMPLE
+// (pin_gather_records_drawn: the neural points do not move while the map trains) a sample drawn m times adds m x the same weights:
+// count the draws of every pool row, then ONE pass over the pool rows does the atomics -- 2 M x k instead of iterations x batch x k
+// (12.6 M x 8 at a 2^20 batch: 0.45 of the tile kernel's 1.34 ms per iteration).  m x w instead of w added m times: the
+// certainty is compared at 1e-4.
+__global__ __launch_bounds__(256) void count_draws_kernel(const long long* __restrict__ hist, long n_hist, const long long* __restrict__ newb,
+                                                          const long long* __restrict__ new_idx, long n_new, int* __restrict__ count) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_hist) atomicAdd(count + hist[i], 1);
+    else if (i < n_hist + n_new) atomicAdd(count + new_idx[newb[i - n_hist]], 1);
+}
+__global__ __launch_bounds__(256) void certainty_from_records_kernel(const float4* __restrict__ rec_nbr, const int* __restrict__ rec_nn, int k,
+                                                                     const int* __restrict__ pool_to_rec, const int* __restrict__ count,
+                                                                     const int* __restrict__ pool_ts, long n_pool, float* __restrict__ cert,
+                                                                     int* __restrict__ ts_rw) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pool) return;
+    const int c = count[i];
+    if (c == 0) return;
+    const int r = pool_to_rec != nullptr ? pool_to_rec[i] : (int)i;
+    if (r < 0) return;  // (another rank's sample)
+    NbrW nb;
+    float vx[PIN_MAX_K], vy[PIN_MAX_K], vz[PIN_MAX_K];
+    bool quirk[PIN_MAX_K];
+    neighbor_weights(rec_nbr, rec_nn[r], r, k, nb, vx, vy, vz, quirk);
+    const int my_ts = pool_ts != nullptr ? pool_ts[i] : 0;
+    const float m = (float)c;
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t)
+        if (nb.idx[t] >= 0) {
+            atomicAdd(cert + nb.idx[t], m * nb.w[t]);
+            if (ts_rw != nullptr && pool_ts != nullptr && ts_rw[nb.idx[t]] < my_ts) atomicMax(ts_rw + nb.idx[t], my_ts);
+        }
+}
+
+extern "C" int pin_count_draws(const int64_t* index_history, int64_t n_history_total, const int64_t* index_new_batch,
+                               const int64_t* new_idx, int64_t n_new_total, int32_t* count, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_history_total >= 0 && n_new_total >= 0 && count, "bad arguments");
+    const long n = (long)(n_history_total + n_new_total);
+    if (n == 0) return 0;
+    PIN_CHECK_ARG((n_history_total == 0 || index_history) && (n_new_total == 0 || (index_new_batch && new_idx)), "NULL index array");
+    hipLaunchKernelGGL(count_draws_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const long long*>(index_history),
+                       (long)n_history_total, reinterpret_cast<const long long*>(index_new_batch), reinterpret_cast<const long long*>(new_idx),
+                       (long)n_new_total, count);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_certainty_from_records(const float* rec_nbr, const int32_t* rec_nn, int32_t k, const int32_t* pool_to_rec,
+                                          const int32_t* count, const int32_t* pool_ts, int64_t n_pool, float* certainty_rw,
+                                          int32_t* ts_update_rw, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n_pool >= 0 && k >= 1 && k <= PIN_MAX_K, "bad sizes");
+    if (n_pool == 0) return 0;
+    PIN_CHECK_ARG(rec_nbr && rec_nn && count && certainty_rw, "NULL pointer");
+    hipLaunchKernelGGL(certainty_from_records_kernel, dim3(cdiv((long)n_pool, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(rec_nbr), rec_nn, k, pool_to_rec, count, pool_ts, (long)n_pool, certainty_rw, ts_update_rw);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pin_gather_records_drawn(const float* pool_nbr, const int32_t* pool_nn, int32_t k, const int64_t* index_history,
                                         int32_t n_history, const int64_t* index_new_batch, const int64_t* new_idx, int32_t n,
                                         int64_t q_per_batch, int32_t n_batches, int64_t hist_stride, int64_t new_stride,

@@ -253,6 +253,7 @@ class SpatialShards:
             want_cap = max(want_cap, int(cnt[:, 0].max() * 1.1) + 1024)
             want_ecap = max(want_ecap, int(cnt[:, 1].max() * 1.1) + 256) if eikonal else 0
         self.n_own = n_own
+        self.pool_rows = pool_rows
         self.n_main, self.n_eik = cnt[:, 0].astype(int), (cnt[:, 1].astype(int) if eikonal else np.zeros(iters, int))
         self.eik_cap = ecap
         self.n_halo = int(ch[2 * iters])

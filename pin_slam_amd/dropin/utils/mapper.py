@@ -473,6 +473,7 @@ class Mapper(_Base):
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         t = self._get_trainer()
         t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
+        t.defer_side_effects = False
         if t.dp is not None:  # spatially sharded over the ranks (pin_slam_amd.dp)
             self._mapping_spatial(t, iter_count)
             return
@@ -490,6 +491,9 @@ class Mapper(_Base):
                 # gather launch and one kNN launch serve a whole group of iterations (TrainBuffers.group)
                 G = t.buf.group
                 reuse = self._pool_records(t, iter_count)  # large batches: one search per POOL sample and call
+                t.defer_side_effects = False
+                if reuse is not None:  # ... and their training-mode side effects applied once, from the draw counts
+                    t.begin_deferred_side_effects(self._drawn["hist"], self._drawn["new"], self.new_idx, self.pool_sample_count)
                 for it0 in range(0, iter_count, G):
                     gn = min(G, iter_count - it0)
                     outs = self._gather_group(t, it0, gn, global_coord=not self.ba_done_flag)
@@ -508,6 +512,8 @@ class Mapper(_Base):
                                      queries_ready=True, knn_ready=True)
                         self.total_iter += 1
                 t.buf.select(0)
+                if reuse is not None:
+                    t.apply_deferred_side_effects(reuse[0], reuse[1], self._pool().bufs[0]["ts"], self.pool_sample_count)
             for it in range(0 if not grouped else iter_count, iter_count):
                 self._queries_for = fused_q
                 coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)

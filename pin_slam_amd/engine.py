@@ -204,6 +204,10 @@ class MapTrainer:
         # spatial shards: the all-reduce of iteration i on a side stream, beside the weight gradient of iteration i and the
         # lazy-Adam launch of iteration i + 1 (step_batch); PIN_DP_OVERLAP=0 keeps everything on one stream
         self.overlap_exchange = os.environ.get("PIN_DP_OVERLAP", "1") != "0"
+        # a call whose neighbour records are per pool sample applies the training-mode side effects (certainty += w, ts_update max)
+        # ONCE at its end from the draw counts (pin_count_draws + pin_certainty_from_records) instead of with k atomics per query
+        # and iteration in the tile kernel: set per call by the Mapper (deferred_side_effects), PIN_DEFER_CERTAINTY=0 turns it off
+        self.defer_side_effects = False
         self._dp_stream, self._dp_ev, self._dp_pending = None, None, None
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
         self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
@@ -320,9 +324,11 @@ class MapTrainer:
         dp, buf = self.dp, self.buf
         out = self._shard_out
         reuse = dp.n_own is not None and dp.n_own > 0
+        self.defer_side_effects = False
         if reuse:  # one search over this rank's pool samples for the whole call (the neural points do not move while the map trains)
             rec_nbr, rec_nn = dp.records(self.fs.k)
             ops.knn_query(self.st, dp.own_coord[:dp.n_own], self.fs.k, out=(rec_nbr, rec_nn, None), bricks=self.bricks)
+            self.begin_deferred_side_effects(dp._hist, dp._new, dp._new_idx, dp.pool_rows)
         for it0 in range(0, iters, buf.group):
             gn = min(buf.group, iters - it0)
             C_color = 3 if self.fc is not None else 0
@@ -345,6 +351,8 @@ class MapTrainer:
                                 surface_count=dp.surf_counts[it:it + 1] if C_color else None)
                 if on_iteration is not None:
                     on_iteration(it)
+        if reuse:  # the side effects of this rank's samples, once (the other ranks' arrive through publish())
+            self.apply_deferred_side_effects(rec_nbr, rec_nn, pool["ts"], dp.pool_rows, pool_to_rec=dp.pool_to_own)
 
     def iteration(self, index_local: torch.Tensor, step: int):
         ops.gather_batch(*self.pool, index_local, (self.coord, self.label, self.weight, self.ts))
@@ -413,8 +421,10 @@ class MapTrainer:
             if pre is not None:
                 pre()
         else:
+            side = not self.defer_side_effects
             ops.train_step(self.st, self.fs, self.buf, coord, label, weight, ts,
-                           self.fs.certainty, self.ts_update, self.gfeat, self.gdec if self.train_decoder else None,
+                           self.fs.certainty if side else None, self.ts_update if side else None, self.gfeat,
+                           self.gdec if self.train_decoder else None,
                            sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                            loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
                            bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
@@ -488,6 +498,34 @@ class MapTrainer:
         if self.train_decoder and not lazy:
             ops.adam_step(self.fs.dec, self.gdec, self.m[:nd], self.v[:nd], step, self.lr, eps=self.adam_eps)
         self.total_iter += 1
+
+    def begin_deferred_side_effects(self, hist, new, new_idx, pool_rows: int) -> bool:
+        """Start of a call with per-pool-sample records: count how often every pool row is drawn (all iterations, one launch);
+        the training launches then skip their certainty / ts atomics and apply_deferred_side_effects() does them once."""
+        if os.environ.get("PIN_DEFER_CERTAINTY", "1") == "0" or self.fs.certainty is None:
+            self.defer_side_effects = False
+            return False
+        dev = self.fs.feats.device
+        c = getattr(self, "_draw_count", None)
+        if c is None or c.numel() < pool_rows:
+            c = self._draw_count = torch.zeros((int(pool_rows * 1.25) + 1024,), dtype=torch.int32, device=dev)
+        else:
+            c[:pool_rows].zero_()
+        check(_lib.lib().pin_count_draws(hist.data_ptr(), hist.numel(), None if new is None else new.data_ptr(),
+                                         None if new is None else new_idx.data_ptr(), 0 if new is None else new.numel(), c.data_ptr(),
+                                         ops._stream()), "pin_count_draws")
+        self.defer_side_effects = True
+        return True
+
+    def apply_deferred_side_effects(self, rec_nbr, rec_nn, pool_ts, pool_rows: int, pool_to_rec=None):
+        """certainty[idx_k] += draws x w_k, ts_update[idx_k] = max(., sample ts) for every drawn pool sample, from its record."""
+        if not self.defer_side_effects:
+            return
+        check(_lib.lib().pin_certainty_from_records(rec_nbr.data_ptr(), rec_nn.data_ptr(), self.fs.k,
+                                                    None if pool_to_rec is None else pool_to_rec.data_ptr(), self._draw_count.data_ptr(),
+                                                    None if pool_ts is None else pool_ts.data_ptr(), int(pool_rows), self.fs.certainty.data_ptr(),
+                                                    self.ts_update.data_ptr(), ops._stream()), "pin_certainty_from_records")
+        self.defer_side_effects = False
 
     def _dp_finish_exchange(self):
         """Behind the all-reduce of the last iteration (side stream): the halo rows' Adam step and the decoder's."""
