@@ -997,6 +997,9 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
     H, L = wl["hidden"], wl["levels"]
     gbs, iters = args.global_bs, args.map_iters
     sync_replicas(npts, mp.sdf_mlp, world)
+    # every rank draws the batches of a call from its own generator: put them in the same state whatever each rank's history was
+    # (the spatial mapper compares a checksum of the first drawn batch across the ranks and refuses to run on diverged replicas)
+    torch.manual_seed(4242)
     ar_pairs, cur = [], {}
     n_ev = 2 * iters
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
