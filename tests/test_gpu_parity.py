@@ -512,7 +512,7 @@ def test_sparse_adam_is_bit_identical_to_dense():
     assert not torch.equal(pd, p0)
 
 
-@pytest.mark.parametrize("steps,rows_form", [(1, False), (12, False), (70, False), (12, True), (5, "mixed")])
+@pytest.mark.parametrize("steps,rows_form", [(1, False), (12, False), (70, False), (12, True), (5, "mixed"), (6, "all")])
 def test_lazy_adam_is_bit_identical_to_dense(steps, rows_form):
     """ops.LazyAdam (ONE launch per iteration, before the forward pass: the rows about to be read settle the step they
     still owe and the gradient-free steps since; flush at the end) against the dense pin_adam_step every iteration:
@@ -524,7 +524,7 @@ def test_lazy_adam_is_bit_identical_to_dense(steps, rows_form):
     settles them) for every iteration, or alternating with the record-parallel form ("mixed") -- the same bits."""
     from pin_slam_amd import ops
     torch.manual_seed(steps)
-    rows, k, Q = 30_000, 8, 1500
+    rows, k, Q = 30_000, 8, (12_000 if rows_form == "all" else 1500)  # "all": > 3 records per row -- no marking pass, every row settles
     p0 = torch.randn(rows + 1, 8, device="cuda")
     pd, pl = p0.clone(), p0.clone()
     md, vd, gd = (torch.zeros_like(p0) for _ in range(3))
@@ -532,7 +532,7 @@ def test_lazy_adam_is_bit_identical_to_dense(steps, rows_form):
     gl = torch.zeros_like(p0)
     lazy = ops.LazyAdam(0.01, eps=1e-15)
     lazy.reset(rows + 1, steps, "cuda")
-    lazy.rows_form_ratio = 0.0 if rows_form is True else 1e9
+    lazy.rows_form_ratio = 0.0 if rows_form in (True, "all") else 1e9
     touched = torch.zeros(rows + 1, dtype=torch.bool, device="cuda")
     d0 = torch.randn(1337, device="cuda")
     dec_a = [d0.clone(), torch.zeros_like(d0), torch.zeros_like(d0)]
