@@ -670,6 +670,7 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     dt = time.perf_counter() - t0
     # the device part alone: the same launches without the result copy
     fs = npts.field_state(decoders["sdf"], query_locally=False)
+    fs.stage_decoder()
     from pin_slam_amd import ops
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -680,12 +681,27 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     e1.record()
     torch.cuda.synchronize()
     dev_ms = e0.elapsed_time(e1)
+    # ... and its two halves (a second pass with an event between the search and the decode launch of every batch)
+    evs = []
+    for a in range(0, n, bs):
+        q = coord[a:a + bs]
+        ea, eb, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ea.record()
+        nbr, nn, _ = npts.knn(q, False)
+        eb.record()
+        ops.sdf_query(fs, q, nbr, nn, grad=False, std=False, certainty=False)
+        ec.record()
+        evs.append((ea, eb, ec))
+    torch.cuda.synchronize()
+    search_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in evs)
+    decode_ms = sum(b_.elapsed_time(c_) for _, b_, c_ in evs)
     rho = nn_mean / Kc
     bytes_q = 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4 + 36 * k + 4  # search (as roofline_knn) + k feature rows + the SDF out
     return {"queries": n, "grid_step_m": round(step, 4), "batch": bs, "ms_call": round(1e3 * dt, 2),
             "queries_per_sec_call": round(n / dt, 1), "ms_device": round(dev_ms, 2), "queries_per_sec_device": round(n / (dev_ms * 1e-3), 1),
+            "ms_search": round(search_ms, 2), "ms_decode": round(decode_ms, 2),
             "valid_share": round(float(mask.float().mean().item()), 4),
-            "roofline": {"kernel": "knn_query_kernel (direct probe of the global table) + sdf_query kernel", "bound": "hbm (random 4 / 16 / 32-byte "
+            "roofline": {"kernel": "knn_query_kernel (direct probe of the global table) + sdf_query_quad_kernel (forward only, 4 lanes per query)", "bound": "hbm (random 4 / 16 / 32-byte "
                          "accesses)", "achieved": round(bytes_q * n / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bytes_q * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_query": round(bytes_q, 1),
                          "traffic": None},

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpinhip.so")
+# (PIN_LIBPINHIP: another build of the same library, for A/B runs of compile-time variants -- scripts/build_variant.sh)
+LIB_PATH = os.environ.get("PIN_LIBPINHIP") or os.path.join(HERE, "libpinhip.so")
 
 PIN_MAX_K = 8
 PIN_MLP_IN = 11

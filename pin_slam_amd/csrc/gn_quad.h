@@ -97,6 +97,73 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
     }
 }
 
+// The colour term's gather: BOTH tables in one sweep over the neighbours -- weights, gradient factors, relative position
+// (and, after PGO, the rotation) computed once per neighbour, a neighbour's record and its two half rows dead as soon as
+// it is done.  (Two calls of quad_gather_pass kept 96 registers of records and rows alive across the first one and, on
+// the GENERAL path, went through neighbor_vector twice per neighbour: 256 registers + 76-232 B of scratch.)  The same
+// arithmetic per accumulator in the same order: in / inc as two passes leave them.
+template <bool ORIENT, bool GENERAL>
+__device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const float4 (&e)[PIN_MAX_K], const float4 (&ft)[PIN_MAX_K],
+                                                  const float4 (&fc)[PIN_MAX_K], const float (&u)[PIN_MAX_K],
+                                                  const int (&raw)[PIN_MAX_K], float S, float px, float py, float pz, int g,
+                                                  QuadIn<ORIENT>& in, QuadIn<ORIENT>& inc) {
+    const float invS = 1.0f / S;
+    const bool is_feat = g < 2;
+    const float mv = g == 2 ? 1.f : 0.f;
+    float z[4] = {0.f, 0.f, 0.f, 0.f}, zc[4] = {0.f, 0.f, 0.f, 0.f};
+    float Y[3][4], Yc[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Y[c][r] = 0.f; Yc[c][r] = 0.f; }
+    float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
+    float M[ORIENT ? 9 : 1] = {0.f};
+#pragma unroll
+    for (int t = 0; t < PIN_MAX_K; ++t) {
+        const float wt = u[t] * invS;
+        const float cg = -2.f * u[t] * u[t];
+        const float g0 = cg * e[t].x, g1 = cg * e[t].y, g2 = cg * e[t].z;
+        Gx += g0; Gy += g1; Gz += g2; wsum += wt;
+        float v[3] = {e[t].x, e[t].y, e[t].z};
+        if constexpr (GENERAL) {
+            float Rm[9];
+            if (raw[t] >= 0) {
+                neighbor_vector(f, raw[t] & ~PIN_NBR_QUIRK_BIT, (raw[t] & PIN_NBR_QUIRK_BIT) != 0, e[t].x, e[t].y, e[t].z, px, py,
+                                pz, v, Rm);
+                if constexpr (ORIENT) {
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) M[rr * 3 + cc] = fmaf(wt, Rm[cc * 3 + rr], M[rr * 3 + cc]);
+                }
+            }
+        }
+        float y[4], yc[4];
+        y[0] = is_feat ? ft[t].x : mv * v[0];  yc[0] = is_feat ? fc[t].x : mv * v[0];
+        y[1] = is_feat ? ft[t].y : mv * v[1];  yc[1] = is_feat ? fc[t].y : mv * v[1];
+        y[2] = is_feat ? ft[t].z : mv * v[2];  yc[2] = is_feat ? fc[t].z : mv * v[2];
+        y[3] = is_feat ? ft[t].w : 0.f;        yc[3] = is_feat ? fc[t].w : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z[r] = fmaf(wt, y[r], z[r]);
+            Y[0][r] = fmaf(g0, y[r], Y[0][r]); Y[1][r] = fmaf(g1, y[r], Y[1][r]); Y[2][r] = fmaf(g2, y[r], Y[2][r]);
+            zc[r] = fmaf(wt, yc[r], zc[r]);
+            Yc[0][r] = fmaf(g0, yc[r], Yc[0][r]); Yc[1][r] = fmaf(g1, yc[r], Yc[1][r]); Yc[2][r] = fmaf(g2, yc[r], Yc[2][r]);
+        }
+    }
+    in.Gx = Gx; in.Gy = Gy; in.Gz = Gz; in.wsum = wsum; in.S = S;
+    inc.Gx = Gx; inc.Gy = Gy; inc.Gz = Gz; inc.wsum = wsum; inc.S = S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        in.z[r] = z[r]; in.Y[0][r] = Y[0][r]; in.Y[1][r] = Y[1][r]; in.Y[2][r] = Y[2][r];
+        inc.z[r] = zc[r]; inc.Y[0][r] = Yc[0][r]; inc.Y[1][r] = Yc[1][r]; inc.Y[2][r] = Yc[2][r];
+    }
+    if constexpr (ORIENT) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { in.M[c] = M[c]; inc.M[c] = M[c]; }
+    }
+}
+
 // COLOR: the same neighbours and weights over a second feature table (the colour features, `feats_c`) -> inc
 template <bool ORIENT, bool COLOR = false>
 __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __restrict__ rp, int kk, int nn, float px, float py,
@@ -125,23 +192,27 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
         any_flag = any_flag || (val && (raw[t] & PIN_NBR_QUIRK_BIT) != 0);
         raw[t] = val ? raw[t] : -1;
     }
-    if constexpr (ORIENT) {
-        quad_gather_pass<true, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
-        if constexpr (COLOR) quad_gather_pass<true, true>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
-    } else {
-        if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) {  // rare
-            quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
-            if constexpr (COLOR) quad_gather_pass<false, true>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
+    if constexpr (COLOR) {
+        if constexpr (ORIENT) {
+            quad_gather_pass2<true, true>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
         } else {
-            quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
-            if constexpr (COLOR) quad_gather_pass<false, false>(f, e, fc, u, raw, S, px, py, pz, g, *inc);
+            if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) quad_gather_pass2<false, true>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);  // rare
+            else quad_gather_pass2<false, false>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
         }
+    } else if constexpr (ORIENT) {
+        quad_gather_pass<true, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
+    } else {
+        if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);  // rare
+        else quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
     }
 }
 
 // chain rule from the decoder's input Jacobian a (d value / d z, this lane's four components) back to the query position
 // (see eval_query): value gradient = scale * (direct term through the relative positions + (sum_t Y_t a - (a . z) G) / S)
-template <bool ORIENT>
+// SWAP: the seven sums over the query's four lanes through the row swaps (rows_sum) instead of the LDS crossbar -- the
+// colour variants, which run at the register limit, take it (no lane-index registers); the plain kernels are bound by their
+// vector-ALU issue and keep the permutes (pin_common.h)
+template <bool ORIENT, bool SWAP = false>
 __device__ __forceinline__ void quad_chain(const QuadIn<ORIENT>& in, const float (&a)[4], int g, float scale, float& gx, float& gy,
                                            float& gz) {
     const float (&z)[4] = in.z;
@@ -161,9 +232,15 @@ __device__ __forceinline__ void quad_chain(const QuadIn<ORIENT>& in, const float
             dzs = M[6] * a[0] + M[7] * a[1] + M[8] * a[2];
         } else { dxs = a[0] * in.wsum; dys = a[1] * in.wsum; dzs = a[2] * in.wsum; }
     }
-    cbar = quad_lanes_sum(cbar);
-    ax = quad_lanes_sum(ax); ay = quad_lanes_sum(ay); az = quad_lanes_sum(az);
-    dxs = quad_lanes_sum(dxs); dys = quad_lanes_sum(dys); dzs = quad_lanes_sum(dzs);
+    if constexpr (SWAP) {
+        cbar = rows_sum(cbar);
+        ax = rows_sum(ax); ay = rows_sum(ay); az = rows_sum(az);
+        dxs = rows_sum(dxs); dys = rows_sum(dys); dzs = rows_sum(dzs);
+    } else {
+        cbar = quad_lanes_sum(cbar);
+        ax = quad_lanes_sum(ax); ay = quad_lanes_sum(ay); az = quad_lanes_sum(az);
+        dxs = quad_lanes_sum(dxs); dys = quad_lanes_sum(dys); dzs = quad_lanes_sum(dzs);
+    }
     const float invS = 1.0f / in.S;
     gx = scale * (dxs + (ax - cbar * in.Gx) * invS);
     gy = scale * (dys + (ay - cbar * in.Gy) * invS);
@@ -188,13 +265,13 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
     const float x = Q::template run<LC>(lds, f.levels, in.z, a);
     const float sdf = s * x;
     float gx, gy, gz;
-    quad_chain<ORIENT>(in, a, g, s, gx, gy, gz);
+    quad_chain<ORIENT, COLOR>(in, a, g, s, gx, gy, gz);
     float ipred = 0.f, igx = 0.f, igy = 0.f, igz = 0.f;
     if constexpr (COLOR) {
         const float kappa[3] = {0.299f, 0.587f, 0.114f};
         float ac[4];
         ipred = QuadDecoderH<H>::template run_color<LC>(lds_c, inc->z, kappa, ct->mode == 2, ac);
-        if (ct->mode == 2) quad_chain<ORIENT>(*inc, ac, g, 1.0f, igx, igy, igz);
+        if (ct->mode == 2) quad_chain<ORIENT, true>(*inc, ac, g, 1.0f, igx, igy, igz);
     }
     // ---- Gauss-Newton terms (tracker.py:409-524, 652-671).  All four lanes of a query hold the
     // result; each accumulates its quarter of the 31 sums (index i = 4j + g), no cross-lane work here.
@@ -247,7 +324,9 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
             }
             // lane g keeps sums 4j + g.  Written as masked FMAs: a select chain over v[] is turned into a
             // dynamically indexed private array (scratch memory) by the compiler
-            const float m0 = g == 0 ? 1.f : 0.f, m1 = g == 1 ? 1.f : 0.f, m2 = g == 2 ? 1.f : 0.f, m3 = g == 3 ? 1.f : 0.f;
+            int gm = g;
+            if constexpr (COLOR) asm volatile("" : "+v"(gm));  // (the colour variants run at the register limit: the four masks are rebuilt per tile there instead of living across the loop)
+            const float m0 = gm == 0 ? 1.f : 0.f, m1 = gm == 1 ? 1.f : 0.f, m2 = gm == 2 ? 1.f : 0.f, m3 = gm == 3 ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 tot[j] += fmaf(m0, v[4 * j], fmaf(m1, v[4 * j + 1], fmaf(m2, v[4 * j + 2], m3 * v[4 * j + 3])));
@@ -392,7 +471,11 @@ __global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f,
 
 constexpr int NWF_BLOCK = 512;  // 2 waves per SIMD (up to 256 VGPRs: the two-deep prefetch state needs ~190)
 
-template <int H, bool ORIENT, bool SPLIT, int LC>
+// MODE 0: the Gauss-Newton sums (pin_gn_accumulate).  MODE 1 / 2: pin_sdf_query on the same tiles (Tracker.query_source_points,
+// Mesher.query_points with weighted_first = False) -- per query the weighted mean of the k predictions, their spread
+// (`std_out`, tracker.py:317-322), the interpolated certainty (`cert_out`, neural_points.py:726-729; lanes g == 3) and, MODE 1,
+// the gradient; MODE 2 runs the forward sweep only.  No sums, no loop state.
+template <int H, bool ORIENT, bool SPLIT, int LC, int MODE = 0>
 __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pin_field f, pin_gn_params gp,
                                                                              const float* __restrict__ query,
                                                                              const float4* __restrict__ nbr,
@@ -400,7 +483,10 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
                                                                              const float* __restrict__ labels, int n_q,
                                                                              double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                              float* __restrict__ grad_out,
-                                                                             const double* __restrict__ state) {
+                                                                             const double* __restrict__ state,
+                                                                             float* __restrict__ std_out = nullptr,
+                                                                             float* __restrict__ cert_out = nullptr) {
+    static_assert(MODE == 0 || SPLIT, "the query modes run on the split-fp16 image");
     using Q = QuadDec<H, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];
     unsigned char* const lds = gq_smem;
@@ -500,7 +586,15 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
         z[1] = is_feat ? ft.y : mv * v[1];
         z[2] = is_feat ? ft.z : mv * v[2];
         z[3] = is_feat ? ft.w : 0.f;
-        const float x = Q::template run<LC>(lds, f.levels, z, a);  // this neighbour's prediction, d x / d its input
+        float x;  // this neighbour's prediction (a: d x / d its input)
+        if constexpr (MODE == 2) {
+            float xo[1];
+            QuadDecoderH<H>::template forward<LC, 1>(lds, z, xo);
+            x = xo[0];
+            a[0] = a[1] = a[2] = a[3] = 0.f;
+        } else {
+            x = Q::template run<LC>(lds, f.levels, z, a);
+        }
         // ---- across the neighbours of the query (eval_query, weighted_first = False)
         const float st = s * x;
         const float mean = octet_sum(wt * st);
@@ -524,6 +618,22 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
         const float gx = s * d0 + (ax - mean * Gx) * invS;
         const float gy = s * d1 + (ay - mean * Gy) * invS;
         const float gz = s * d2 + (az - mean * Gz) * invS;
+        if constexpr (MODE != 0) {
+            float cert = 0.f;
+            if (cert_out != nullptr && f.certainty != nullptr)  // (uniform)
+                cert = octet_sum(wt * ((g == 3 && val) ? f.certainty[id] : 0.f));
+            if (active && t == 0) {
+                if (g == 0) {
+                    if (sdf_out) sdf_out[qi] = mean;
+                    if (MODE == 1 && grad_out) { grad_out[3 * qi] = gx; grad_out[3 * qi + 1] = gy; grad_out[3 * qi + 2] = gz; }
+                } else if (g == 1) {
+                    if (std_out) std_out[qi] = sd;
+                } else if (g == 3) {
+                    if (cert_out) cert_out[qi] = cert;
+                }
+            }
+            continue;
+        }
         if (active) {
             if (t == 0 && g == 0) {
                 if (sdf_out) sdf_out[qi] = mean;
@@ -546,6 +656,7 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
             }
         }
     }
+    if constexpr (MODE != 0) return;
     // the two queries of a tile sit in lanes n and n ^ 8: add them, lane (q2 = 0, t, g) then holds sum 4 t + g of the wave
     tot += dpp_mov<0x128>(tot);  // row_ror:8
     if (q2 == 0) red[wave][si] = tot;

@@ -385,8 +385,7 @@ struct QuadDecoderH {
                 h[kt][r] = h[kt][r] > 0.f ? wo[r] : 0.f;
             }
         }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = rows_sum_lds(x);
         x += O[MF_OD_MAX * H];
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
@@ -401,13 +400,53 @@ struct QuadDecoderH {
         return x;
     }
 
+    // forward pass only (inference: Mesher.query_points, Tracker.query_source_points without the gradient): the value of
+    // run<L>, bit for bit -- the same products in the same order -- without the ReLU patterns and the transposed sweep.
+    // OD heads (1: sdf; 3: the colour heads before their sigmoid), complete in the four lanes of the query.
+    template <int L, int OD = 1>
+    __device__ __forceinline__ static void forward(const unsigned char* __restrict__ w, const float (&z)[4], float (&x)[OD]) {
+        static_assert(L >= 1 && L <= MLP_MAX_LEVELS, "1..4 layers");
+        const int g = (threadIdx.x & 63) >> 4;
+        v4f_t h[MT], acc[MT];
+        layer0(w, L, z, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            v4u_t bh[NJ], bl[NJ];
+            split_acts(h, bh, bl);
+            load_bias(w, L, l, acc);
+            matmul(w + off_hidf(L, l), bh, bl, acc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
+        }
+        const float* __restrict__ O = reinterpret_cast<const float*>(w + off_out(L));
+#pragma unroll
+        for (int c = 0; c < OD; ++c) {
+            float o = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+                const v4f_t wo = *reinterpret_cast<const v4f_t*>(O + c * H + 16 * kt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = fmaf(wo[r], h[kt][r], o);
+            }
+            o = rows_sum(o);
+            x[c] = o + O[MF_OD_MAX * H + c];
+        }
+    }
+
     // The colour decoder (3 sigmoid heads, Decoder.regress_color, model/decoder.py:112) on the same tile layout:
     // returns value = sum_c kappa[c] sigmoid(head_c) (complete in the four lanes of the query) and, when `grad`,
     // a[r] = d value / d z[4g + r]: ONE transposed sweep seeded with sum_c kappa[c] s_c (1 - s_c) wo_c under the last
     // ReLU pattern.  The image is staged with OD = 3 (stage(dec, L, w, tid, nthreads, 3)).
     template <int L>
     __device__ __forceinline__ static float run_color(const unsigned char* __restrict__ w, const float (&z)[4],
-                                                      const float (&kappa)[3], bool grad, float (&a)[4]) {
+                                                      const float (&kappa)[3], bool grad, float (&a)[4],
+                                                      float (*heads)[3] = nullptr) {  // heads: the three sigmoid outputs, if wanted
         static_assert(L >= 1 && L <= MLP_MAX_LEVELS, "1..4 layers");
         const int g = (threadIdx.x & 63) >> 4;
         v4f_t h[MT], acc[MT];
@@ -439,8 +478,7 @@ struct QuadDecoderH {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[c] = fmaf(wo[r], h[kt][r], o[c]);
             }
-            o[c] += __shfl_xor(o[c], 16, 64);
-            o[c] += __shfl_xor(o[c], 32, 64);
+            o[c] = rows_sum(o[c]);
             o[c] += O[MF_OD_MAX * H + c];
         }
         float value = 0.f, coef[3];
@@ -449,6 +487,7 @@ struct QuadDecoderH {
             const float sgm = 1.f / (1.f + expf(-o[c]));
             value = fmaf(kappa[c], sgm, value);
             coef[c] = kappa[c] * sgm * (1.f - sgm);
+            if (heads != nullptr) (*heads)[c] = sgm;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = 0.f;

@@ -189,8 +189,7 @@ struct MfmaDecoder {
         for (int c = 0; c < OD; ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                xo[c][nt] += __shfl_xor(xo[c][nt], 16, 64);
-                xo[c][nt] += __shfl_xor(xo[c][nt], 32, 64);
+                xo[c][nt] = rows_sum(xo[c][nt]);
                 xo[c][nt] += O[MF_OD_MAX * H + c];
             }
     }

@@ -155,8 +155,7 @@ struct QuadDecoder {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
         }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = rows_sum_lds(x);
         x += O[MF_OD_MAX * H];
         // ---- transposed sweep: seed with the output weights under the last ReLU mask
         unsigned int mlast = masks[0];
@@ -194,8 +193,7 @@ __device__ __forceinline__ float octet_sum(float v) {  // over aligned groups of
     return v;
 }
 __device__ __forceinline__ float quad_lanes_sum(float v) {  // over the four lanes (n, g = 0..3) of a query
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = rows_sum_lds(v);
     return v;
 }
 

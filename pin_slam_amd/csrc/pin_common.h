@@ -105,6 +105,36 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// v + (lane ^ 16's v) + ... over the four 16-lane rows of the wave, in every lane: the sum over the four lanes
+// (n, g = 0..3) of a query of the quad layout.  gfx950's row swaps instead of two ds_bpermute round trips through the LDS
+// pipeline: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second -- with both
+// operands = v they come back as [r0 r0 r2 r2] and [r1 r1 r3 r3], whose sum is v + xor16(v) in every lane;
+// v_permlane32_swap does the same for the wave's halves.  Same additions as `v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)`
+// (fp32 addition commutes: identical bits), no lane-index arithmetic, no LDS traffic.
+typedef unsigned int swap2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_pair_sum16(float v) {
+    const swap2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows_pair_sum32(float v) {
+    const swap2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same sum through the LDS crossbar (two ds_bpermute): no vector-ALU slots for the exchange itself.  The registration
+// tile kernels are bound by their vector-ALU issue and keep this form (measured, same box, 4 runs each: 37.7 vs 38.3 us per
+// launch at C3, 50.4 vs 51.2 at the per-neighbour workload); everything else uses the swaps (fewer registers: the lane-index
+// arithmetic of the permute is loop-invariant and used to be spilled).
+__device__ __forceinline__ float rows_sum_lds(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+#ifdef PIN_AB_ROWS_SHFL  // (A/B builds only, scripts/build_variant.sh)
+__device__ __forceinline__ float rows_sum(float v) { return rows_sum_lds(v); }
+#else
+__device__ __forceinline__ float rows_sum(float v) { return rows_pair_sum32(rows_pair_sum16(v)); }
+#endif
+
 // float wave sum on the DPP path (no LDS crossbar): quad xor 1, 2, row_half_mirror, row_mirror
 // give every lane its 16-lane row sum; the 4 row sums are then added through readlane.
 template <int CTRL>

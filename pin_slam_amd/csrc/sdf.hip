@@ -276,7 +276,7 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
 // per-neighbour decoding (weighted_first = False), the colour term and plain forward queries -----------
 
 template <int H, bool WF, int OD = 1>
-__global__ __launch_bounds__(MF_BLOCK, 2) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
+__global__ __launch_bounds__(MF_BLOCK, 1) void sdf_query_mfma_kernel(pin_field f, const float* __restrict__ query,
                                                                   const float4* __restrict__ nbr,
                                                                   const int* __restrict__ nn_count, int n,
                                                                   float* __restrict__ sdf_out, float* __restrict__ grad_out,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void sdf_query_mfma_kernel(pin_field f
 }
 
 template <int H, bool WF>
-__global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_field f, pin_gn_params gp,
+__global__ __launch_bounds__(MF_BLOCK, 1) void gn_accumulate_mfma_kernel(pin_field f, pin_gn_params gp,
                                                                       const float* __restrict__ query,
                                                                       const float4* __restrict__ nbr,
                                                                       const int* __restrict__ nn_count,
@@ -404,6 +404,7 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void gn_accumulate_mfma_kernel(pin_fie
 
 }  // namespace pin
 #include "gn_quad.h"
+#include "sdf_quad.h"
 namespace pin {
 
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
@@ -670,20 +671,11 @@ static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const fl
     return 0;
 }
 
-// waves per SIMD of the tile kernel: 2 (up to 256 registers) or 3 (168 registers; PIN_GQ_WAVES=3)
-static int gq_waves() {
-    static const int w = [] { const char* e = getenv("PIN_GQ_WAVES"); return (e && e[0] == '3') ? 3 : 2; }();
-    return w;
-}
-
 template <int H, bool ORIENT, bool SPLIT, int LC>
 static int launch_quad_inst(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                             const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
                             float* grad_out, const double* state, hipStream_t s) {
-    if constexpr (SPLIT && !ORIENT) {
-        if (gq_waves() == 3)
-            return launch_quad_blk<H, ORIENT, SPLIT, LC, 768>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
-    }
+    // (three waves per SIMD -- 768 threads, 168 registers -- was measured in r03 and is not built: slower, and it spills)
     return launch_quad_blk<H, ORIENT, SPLIT, LC, GQ_BLOCK>(f, gp, pts, nb4, nn_count, labels, n, sums, sdf_out, grad_out, state, s);
 }
 
@@ -693,12 +685,16 @@ template <int H, bool ORIENT, int LC>
 static int launch_quad_color_inst(const pin_field* f, const pin_gn_params* gp, const ColorTerm& ct, const float* pts,
                                   const float4* nb4, const int32_t* nn_count, const float* labels, int32_t n, double* sums,
                                   float* sdf_out, float* grad_out, const double* state, hipStream_t s) {
-    constexpr int lds_bytes = 2 * gq_red_offset(QuadDecoderH<H>::bytes(LC)) + (GQ_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, true, LC, true>),
+    // (after PGO with two 64-wide layers per decoder the tile's state -- both inputs, the rotation sums, two decoders' masks --
+    // exceeds 256 registers: that one variant runs one wave per SIMD with the other half of the register file instead of
+    // spilling 75 registers to scratch memory)
+    constexpr int BLK = (H == 64 && ORIENT && LC == 2) ? 256 : GQ_BLOCK;
+    constexpr int lds_bytes = 2 * gq_red_offset(QuadDecoderH<H>::bytes(LC)) + (BLK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_kernel<H, ORIENT, true, LC, true, BLK>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
-    const dim3 grid(min(gq_cu_count(), cdiv(n, 16))), block(GQ_BLOCK);
-    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, true, LC, true>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
+    const dim3 grid(min(gq_cu_count(), cdiv(n, 16))), block(BLK);
+    hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, true, LC, true, BLK>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
                        labels, n, sums, sdf_out, grad_out, state, ct);
     return 0;
 }
@@ -811,6 +807,89 @@ static int launch_gn(const pin_field* f, const pin_gn_params* gp, const pin_colo
     return 0;
 }
 
+// pin_sdf_query on the tile decoder (sdf_quad.h): interpolate-first, one head, split-fp16 image
+template <int H, bool ORIENT, int LC, bool GRAD, int OD>
+static int launch_query_quad_inst(const pin_field* f, const float* query, const float4* nb4, const int32_t* nn_count, int32_t n,
+                                  float* sdf_out, float* grad_out, float* std_out, float* cert_out, const Kappa& kap,
+                                  float* color_out, hipStream_t s) {
+    constexpr int lds_bytes = gq_red_offset(QuadDecoderH<H>::bytes(LC));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_query_quad_kernel<H, ORIENT, LC, GRAD, OD>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "query tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    constexpr int SQ_BLOCK = sq_block<GRAD>();
+    const dim3 grid(min(gq_cu_count(), cdiv(cdiv(n, 16), SQ_BLOCK / 64))), block(SQ_BLOCK);
+    hipLaunchKernelGGL((sdf_query_quad_kernel<H, ORIENT, LC, GRAD, OD>), grid, block, lds_bytes, s, *f, query, nb4, nn_count, n,
+                       sdf_out, grad_out, std_out, cert_out, kap, color_out);
+    return 0;
+}
+
+template <int H, bool ORIENT, bool GRAD, int OD>
+static int launch_query_quad_l(const pin_field* f, const float* query, const float4* nb4, const int32_t* nn_count, int32_t n,
+                               float* sdf_out, float* grad_out, float* std_out, float* cert_out, const Kappa& kap,
+                               float* color_out, hipStream_t s) {
+#define PIN_LQQ(LL) \
+    return launch_query_quad_inst<H, ORIENT, LL, GRAD, OD>(f, query, nb4, nn_count, n, sdf_out, grad_out, std_out, cert_out, kap, color_out, s)
+    switch (f->levels) {
+        case 1: PIN_LQQ(1);
+        case 2: PIN_LQQ(2);
+        case 3: PIN_LQQ(3);
+        default: PIN_LQQ(4);
+    }
+#undef PIN_LQQ
+}
+
+// OD = 1: pin_sdf_query; OD = 3: pin_color_query (value -> sdf_out)
+template <int OD>
+static int launch_query_quad(const pin_field* f, const float* query, const float4* nb4, const int32_t* nn_count, int32_t n,
+                             float* sdf_out, float* grad_out, float* std_out, float* cert_out, const Kappa& kap, float* color_out,
+                             hipStream_t s) {
+#define PIN_LQQ(HH, OO)                                                                                                          \
+    do {                                                                                                                         \
+        if (grad_out != nullptr)                                                                                                 \
+            return launch_query_quad_l<HH, OO, true, OD>(f, query, nb4, nn_count, n, sdf_out, grad_out, std_out, cert_out, kap, color_out, s); \
+        return launch_query_quad_l<HH, OO, false, OD>(f, query, nb4, nn_count, n, sdf_out, grad_out, std_out, cert_out, kap, color_out, s);    \
+    } while (0)
+    if (f->hidden == 64) { if (f->orient) PIN_LQQ(64, true); else PIN_LQQ(64, false); }
+    if (f->orient) PIN_LQQ(32, true); else PIN_LQQ(32, false);
+#undef PIN_LQQ
+}
+
+// weighted_first = False with the one-layer decoder every shipped configuration of that mode uses: the query modes of the
+// per-neighbour tile kernel (gn_quad.h)
+template <int H, bool ORIENT, int MODE>
+static int launch_query_nwf_inst(const pin_field* f, const float* query, const float4* nb4, const int32_t* nn_count, int32_t n,
+                                 float* sdf_out, float* grad_out, float* std_out, float* cert_out, hipStream_t s) {
+    constexpr int lds_bytes = gq_red_offset(QuadDec<H, true>::bytes(1)) + (NWF_BLOCK / 64) * PIN_GN_NSUMS * (int)sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_accumulate_quad_nwf_kernel<H, ORIENT, true, 1, MODE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) return fail(-2, "query tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
+    const int tiles = cdiv(n, 2);
+    const dim3 grid(min(gq_cu_count(), cdiv(tiles, NWF_BLOCK / 64))), block(NWF_BLOCK);
+    pin_gn_params none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((gn_accumulate_quad_nwf_kernel<H, ORIENT, true, 1, MODE>), grid, block, lds_bytes, s, *f, none, query, nb4, nn_count,
+                       (const float*)nullptr, n, (double*)nullptr, sdf_out, grad_out, (const double*)nullptr, std_out, cert_out);
+    return 0;
+}
+
+static int launch_query_nwf(const pin_field* f, const float* query, const float4* nb4, const int32_t* nn_count, int32_t n,
+                            float* sdf_out, float* grad_out, float* std_out, float* cert_out, hipStream_t s) {
+#define PIN_LQN(HH, OO)                                                                                                                \
+    do {                                                                                                                               \
+        if (grad_out != nullptr) return launch_query_nwf_inst<HH, OO, 1>(f, query, nb4, nn_count, n, sdf_out, grad_out, std_out, cert_out, s); \
+        return launch_query_nwf_inst<HH, OO, 2>(f, query, nb4, nn_count, n, sdf_out, grad_out, std_out, cert_out, s);                 \
+    } while (0)
+    if (f->hidden == 64) { if (f->orient) PIN_LQN(64, true); else PIN_LQN(64, false); }
+    if (f->orient) PIN_LQN(32, true); else PIN_LQN(32, false);
+#undef PIN_LQN
+}
+
+// PIN_QUERY_QUAD=0: the thread-per-query kernel everywhere (A/B runs)
+static bool query_quad_on() {
+    static const bool on = [] { const char* e = getenv("PIN_QUERY_QUAD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count,
                              int32_t n, float* sdf_out, float* grad_out, float* std_out, float* certainty_out,
                              void* stream) {
@@ -819,6 +898,20 @@ extern "C" int pin_sdf_query(const pin_field* f, const float* query, const float
     PIN_CHECK_ARG(n >= 0, "n < 0");
     if (n == 0) return 0;
     PIN_CHECK_ARG(query && nbr && nn_count && f->feats, "NULL pointer");
+    if (f->weighted_first && f->out_dim <= 1 && use_split_decoder() && query_quad_on()) {  // four lanes per query (sdf_quad.h)
+        if (int e = launch_query_quad<1>(f, query, reinterpret_cast<const float4*>(nbr), nn_count, n, sdf_out, grad_out, std_out,
+                                         certainty_out, Kappa(), nullptr, as_stream(stream)))
+            return e;
+        PIN_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!f->weighted_first && f->levels == 1 && f->out_dim <= 1 && use_split_decoder() && query_quad_on()) {  // a column per (query, neighbour)
+        if (int e = launch_query_nwf(f, query, reinterpret_cast<const float4*>(nbr), nn_count, n, sdf_out, grad_out, std_out,
+                                     certainty_out, as_stream(stream)))
+            return e;
+        PIN_CHECK_LAUNCH();
+        return 0;
+    }
     PIN_DISPATCH_FIELD(f, sdf_query, n, as_stream(stream), *f, query, reinterpret_cast<const float4*>(nbr), nn_count, n,
                        sdf_out, grad_out, std_out, certainty_out);
     PIN_CHECK_LAUNCH();
@@ -871,6 +964,11 @@ extern "C" int pin_color_query(const pin_field* fc, const float* query, const fl
     const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
     const float4* nb4 = reinterpret_cast<const float4*>(nbr);
     hipStream_t s = as_stream(stream);
+    if (fc->weighted_first && use_split_decoder() && query_quad_on()) {  // four lanes per query (sdf_quad.h)
+        if (int e = launch_query_quad<3>(fc, query, nb4, nn_count, n, value_out, grad_out, nullptr, nullptr, kap, color_out, s)) return e;
+        PIN_CHECK_LAUNCH();
+        return 0;
+    }
 #define PIN_COLOR_Q(HH, WFV) \
     hipLaunchKernelGGL((sdf_query_mfma_kernel<HH, WFV, 3>), grid, block, 0, s, *fc, query, nb4, nn_count, n, value_out, \
                        grad_out, (float*)nullptr, (float*)nullptr, kap, color_out)

@@ -575,8 +575,7 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
     // row sums over the 4 k-groups -> bias gradient (kept in lanes g == 0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        bsum[t] += __shfl_xor(bsum[t], 16, 64);
-        bsum[t] += __shfl_xor(bsum[t], 32, 64);
+        bsum[t] = rows_sum(bsum[t]);
     }
     // block reduction: waves 1..3 park their tiles in LDS, wave 0 adds and publishes
     if (wave > 0) {
@@ -1047,6 +1046,9 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     if (attr != hipSuccess) return fail(-2, "training tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
     DwStream ws;
     ws.n_tiles = fused_tiles(tp->n_main, tp->n_eik);
+    // (stream_at: a lane's byte offset inside one region of the operand stream is a 32-bit number)
+    if ((long)ws.n_tiles * 128 * G::MT * 8 >= (1L << 32))
+        return fail(-1, "training batch too large for one launch: %d tiles (limit %ld)", ws.n_tiles, (1L << 32) / (128 * G::MT * 8) - 1);
     ws.d = reinterpret_cast<uint2*>(workspace);
     ws.a = ws.d + G::total((size_t)ws.n_tiles, L);
     // power of two that maps a unit loss gradient to ~1 (see train_fused.h "Scaling"); the colour loss is normalised by
@@ -1132,6 +1134,8 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
     if (attr != hipSuccess) return fail(-2, "training tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
     DwStream ws, ws2;
     ws.n_tiles = ws2.n_tiles = cdiv(tp->n_main, 16);
+    if ((long)ws.n_tiles * 128 * G::MT * 8 >= (1L << 32))  // (stream_at's 32-bit lane offsets)
+        return fail(-1, "training batch too large for one launch: %d tiles (limit %ld)", ws.n_tiles, (1L << 32) / (128 * G::MT * 8) - 1);
     const size_t per_stream = 2 * G::total((size_t)ws.n_tiles, L);
     const size_t need = 2 * per_stream * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
     PIN_CHECK_ARG((size_t)workspace_bytes >= need, "workspace too small");
@@ -1152,7 +1156,7 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
         image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
     else
         hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
-    hipLaunchKernelGGL((train_fused_an_kernel<H, L>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+    hipLaunchKernelGGL((train_fused_an_kernel<H, L>), dim3(grid), dim3(tf_an_block<H, L>()), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                        sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
                        dw_partial, n_dec, loss_partial);
     PIN_CHECK_LAUNCH();
@@ -1198,6 +1202,8 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     DwStream ws, ws2;
     const int n_groups = (tp->n_main + 5) / 6 + tp->n_eik;
     ws.n_tiles = ws2.n_tiles = 3 * n_groups;
+    if ((long)ws.n_tiles * 128 * G::MT * 8 >= (1L << 32))  // (stream_at's 32-bit lane offsets)
+        return fail(-1, "training batch too large for one launch: %d tiles (limit %ld)", ws.n_tiles, (1L << 32) / (128 * G::MT * 8) - 1);
     const size_t per_stream = 2 * G::total((size_t)ws.n_tiles, L);
     const size_t need = (AN ? 2 : 1) * per_stream * sizeof(uint2) + ((size_t)DW_SLOTS * FUSED_NDEC_MAX + 2048 + 32768) * 4;
     PIN_CHECK_ARG((size_t)workspace_bytes >= need, "workspace too small");
@@ -1214,13 +1220,13 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
     float* dw_partial = reinterpret_cast<float*>(ws.d + (AN ? 2 : 1) * per_stream);
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
-    const int grid = min(n_cu, cdiv(n_groups, TF_BLOCK / 64));
+    const int grid = min(n_cu, cdiv(n_groups, tf_nwf_block<H, AN>() / 64));
     if (phase & 1) {
         if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
             image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
         else
             hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
-        hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(TF_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
+        hipLaunchKernelGGL((train_fused_nwf_kernel<H, AN>), dim3(grid), dim3(tf_nwf_block<H, AN>()), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                            sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, ws2, want_dec, dscale, image,
                            dw_partial, n_dec, loss_partial);
         PIN_CHECK_LAUNCH();

@@ -48,6 +48,11 @@ struct FusedColor {          // OD = 3 only
 };
 
 constexpr int TF_BLOCK = 512;  // 8 waves per CU, 2 per SIMD (<= 256 VGPRs): the per-neighbour and analytic-Eikonal kernels
+// the two shapes of those kernels whose tile state exceeds 256 registers (64-wide per-neighbour decoding with the analytic
+// Eikonal term: three tiles' pieces + the derivative network; the analytic term at three or four 64-wide layers) run ONE wave per SIMD
+// with the other half of the register file instead of spilling to scratch memory
+template <int H, bool AN> constexpr int tf_nwf_block() { return (H == 64 && AN) ? 256 : TF_BLOCK; }
+template <int H, int L> constexpr int tf_an_block() { return (H == 64 && L >= 3) ? 256 : TF_BLOCK; }
 constexpr int TFW_BLOCK = 768; // train_fused_kernel: 12 waves per CU, 3 per SIMD (<= 168 VGPRs) -- a tile is a latency chain
                                // (~80 k cycles for ~11 k cycles of vector issue): throughput at large batches is waves in flight
 // (DW_SLOTS partial weight gradients, train.hip: chunk c of the streamed product adds into slot c % DW_SLOTS)
@@ -70,6 +75,18 @@ struct DwGeom {
     __host__ __device__ static size_t a_off(size_t n_tiles, int lam) { return lam == 0 ? 0 : n_tiles * 128 * (size_t)(1 + (lam - 1) * MT); }
     __host__ __device__ static size_t total(size_t n_tiles, int L) { return n_tiles * 128 * (size_t)(L * MT + 1); }  // of each stream
 };
+
+// Element `elem` of a stream region: a UNIFORM 64-bit base (scalar registers) plus a 32-bit byte offset (one vector register
+// per lane) -- the store then takes its base from the scalar file instead of keeping one 64-bit lane address per region in
+// vector registers across the tile loop (10 regions at four layers).  8 * elem < 2^32: n_tiles < 2^20 at H = 64
+// (launch_fused_l checks it).
+__device__ __forceinline__ uint2* stream_at(uint2* region, unsigned int elem) {
+#ifdef PIN_AB_STREAM_64  // (A/B builds only: one 64-bit lane address per region)
+    return region + (size_t)elem;
+#else
+    return reinterpret_cast<uint2*>(reinterpret_cast<char*>(region) + (size_t)(elem * 8u));
+#endif
+}
 
 __host__ __device__ inline int fused_mixed_tiles(int n_eik) { return (n_eik + 1) >> 1; }
 __host__ __device__ inline int fused_tiles(int n_main, int n_eik) {
@@ -117,7 +134,8 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
     const int n_mixed = fused_mixed_tiles(n_eik);
     const int n_tiles = ws.n_tiles;
     const int n_waves = gridDim.x * (TFW_BLOCK / 64);
-    const float inv_dscale = 1.0f / dscale;
+    // dscale is a power of two (launch_fused_l): its reciprocal by exponent arithmetic, exact, on the scalar unit
+    const float inv_dscale = __uint_as_float(0x7f000000u - __float_as_uint(dscale));
     // identity operand of the transposing MFMA: B[k = 4 (lane >> 4) + r][n = lane & 15]
     v4h_t ident;
 #pragma unroll
@@ -156,20 +174,27 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         bool is_probe = false;
         int qi, probe_a = 0;
         bool valid;
-        if (tl < n_mixed) {
-            if (nq < 12) {
-                const int s = 2 * tl + (nq >= 6 ? 1 : 0);
-                probe_a = nq >= 6 ? nq - 6 : nq;
-                is_probe = true;
-                valid = s < n_eik;
-                qi = n_main + 6 * s + probe_a;
+        {
+            // (opaque copy of the lane index, as at the scatter below: the column arithmetic is redone per tile, its
+            // loop-invariant pieces would otherwise be spilled)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int nq_t = lane_t & 15;
+            if (tl < n_mixed) {
+                if (nq_t < 12) {
+                    const int s = 2 * tl + (nq_t >= 6 ? 1 : 0);
+                    probe_a = nq_t >= 6 ? nq_t - 6 : nq_t;
+                    is_probe = true;
+                    valid = s < n_eik;
+                    qi = n_main + 6 * s + probe_a;
+                } else {
+                    qi = 4 * tl + (nq_t - 12);
+                    valid = qi < n_main;
+                }
             } else {
-                qi = 4 * tl + (nq - 12);
+                qi = 4 * n_mixed + 16 * (tl - n_mixed) + nq_t;
                 valid = qi < n_main;
             }
-        } else {
-            qi = 4 * n_mixed + 16 * (tl - n_mixed) + nq;
-            valid = qi < n_main;
         }
         const bool active = work && valid;
         const int qq = valid ? qi : 0;
@@ -225,10 +250,10 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         // ---- forward.  The pieces of a layer's input are the B operand of its product AND the A operand of its weight
         // gradient: they go out to the operand stream right here and only the layer's ReLU pattern (16 bits per lane)
         // stays for the backward sweep -- r03a kept all pieces in registers (64 at 4 x 64) and ran 2 waves per SIMD
-        const size_t tbase = (size_t)tile * 128 + lane;
-        const size_t tbig = (size_t)tile * 128 * (MT - 1) + tbase;
+        const unsigned int tbase = (unsigned int)tile * 128u + (unsigned int)lane;
+        const unsigned int tbig = (unsigned int)tile * (128u * MT) + (unsigned int)lane;
         auto stream_acts = [&](const v4u_t (&ph)[NJ], const v4u_t (&pl)[NJ], int l) {  // a_l, l = 1 .. L
-            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + tbig;
+            uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, l), tbig);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 A[mt * 128] = transpose_block(ph[mt >> 1][2 * (mt & 1)], ph[mt >> 1][2 * (mt & 1) + 1], ident);
@@ -246,7 +271,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         v2u_t zh, zl;
         Q::split_input(z, zh, zl);
         if (want_dec && work) {
-            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
+            uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, 0), tbase);
             A[0] = transpose_block(zh[0], zh[1], ident);
             A[64] = transpose_block(zl[0], zl[1], ident);
         }
@@ -283,8 +308,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
             }
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
+            x = rows_sum(x);
             x += O[MF_OD_MAX * H];
             const float pred = f.sdf_scale * x;
             if (active && !is_probe && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
@@ -328,8 +352,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o = fmaf(wo[r], h[kt][r], o);
                 }
-                o += __shfl_xor(o, 16, 64);
-                o += __shfl_xor(o, 32, 64);
+                o = rows_sum(o);
                 o += O[MF_OD_MAX * H + c];
                 const float pc = sigmoidf_(o);
                 const float diff = pc - fcol.color[3 * (size_t)qq + c];
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
             unsigned int dh0, dl0, dh1 = 0u, dl1 = 0u;
             h2_split2((g == 0) ? dxc[0] : 0.f, (g == 0 && OD > 1) ? dxc[OD > 1 ? 1 : 0] : 0.f, dh0, dl0);
             if constexpr (OD > 2) h2_split2((g == 0) ? dxc[2] : 0.f, 0.f, dh1, dl1);
-            uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
+            uint2* __restrict__ D = stream_at(ws.d + G::d_off(n_tiles, L), tbase);
             D[0] = transpose_block(dh0, dh1, ident);
             D[64] = transpose_block(dl0, dl1, ident);
         }
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
             v4u_t bh[NJ], bl[NJ];
             Q::split_acts(h, bh, bl);
             if (want_dec) {
-                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + tbig;
+                uint2* __restrict__ D = stream_at(ws.d + G::d_off(n_tiles, l), tbig);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
@@ -391,8 +414,10 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                 // dims, whole 32-byte rows per instruction): exchange through the wave's LDS patch
                 const bool live = active && any_dx;
                 if (g < 2) {
+                    float ids = inv_dscale;  // (a local copy, not a vector pair held across the loop body)
+                    asm volatile("" : "+v"(ids));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r] * inv_dscale;
+                    for (int r = 0; r < 4; ++r) sdz[nq * 8 + 4 * g + r] = dz[r] * ids;
                 } else if (g == 3) {
                     if (!live) {
 #pragma unroll
@@ -403,7 +428,11 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         }
         wave_lds_sync();
         {
-            const int t = lane >> 3, j = lane & 7;
+            // (the lane index goes through an opaque move: what derives from it here is computed here, per tile, instead of
+            // sitting in registers across the whole loop body -- the tile kernel runs at its 168-register limit)
+            int lane_s = lane;
+            asm volatile("" : "+v"(lane_s));
+            const int t = lane_s >> 3, j = lane_s & 7;
             for (int i = 0; i < 16; ++i) {
                 const int idx = sidx[i * 8 + t];
                 if (idx >= 0) atomicAdd(feat_grad + (size_t)idx * PIN_FEATURE_DIM + j, sw[i * 8 + t] * sdz[i * 8 + j]);
@@ -464,7 +493,7 @@ __device__ __forceinline__ void neighbor_vector_rot(const pin_field& f, int idx,
 }
 
 template <int H, bool AN>
-__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field f, pin_train_params tp,
+__global__ __launch_bounds__((tf_nwf_block<H, AN>()), 1) void train_fused_nwf_kernel(pin_field f, pin_train_params tp,
                                                                       const float* __restrict__ query,
                                                                       const float4* __restrict__ nbr,
                                                                       const int* __restrict__ nn_count,
@@ -477,6 +506,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                                                                       const unsigned char* __restrict__ dec_image,
                                                                       float* __restrict__ dw_partial, int n_dec,
                                                                       double* __restrict__ loss_partial) {
+    constexpr int BLK = tf_nwf_block<H, AN>();  // (the LDS patches stay laid out for TF_BLOCK / 64 waves)
     using Q = QuadDecoderH<H>;
     using G = DwGeom<H>;
     constexpr int MT = Q::MT, NJ = Q::NJ, L = 1;
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
     const int n_main = tp.n_main, n_eik = tp.n_eik, kk = f.k;
     const int n_main_groups = (n_main + 5) / 6, n_groups = n_main_groups + n_eik;
     const int n_tiles = ws.n_tiles;  // 3 * n_groups
-    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const int n_waves = gridDim.x * (BLK / 64);
     const float inv_dscale = 1.0f / dscale, s = f.sdf_scale;
     v4h_t ident;
 #pragma unroll
@@ -499,13 +529,13 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
     double acc_bce = 0.0, acc_eik = 0.0;
     if (want_dec) {
         const int n = DW_SLOTS * n_dec;
-        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) dw_partial[i] = 0.f;
     }
     {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         constexpr int n16 = Q::bytes(L) >> 4;
-        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n16; i += BLK) dst[i] = src[i];
     }
     __syncthreads();
     const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
@@ -567,8 +597,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { h[mt][r] = relu1(acc[mt][r]); x = fmaf(wo[mt][r], h[mt][r], x); }
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
+            x = rows_sum(x);
             x += bo;
             Q::split_acts(h, ph[j], pl[j]);
             wt[j] = w; id[j] = idn; valn[j] = val;
@@ -652,8 +681,8 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
         // ---- backward of the three tiles
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const size_t tile = (size_t)3 * grp + j;
-            const size_t tbase = tile * 128 + lane;
+            const unsigned int tile = 3u * (unsigned int)grp + (unsigned int)j;
+            const unsigned int tbase = tile * 128u + (unsigned int)lane, tbig = tile * (128u * MT) + (unsigned int)lane;
             float up = dp[j] * wt[j];  // pred = sum_t w_t * sdf_scale * head_t
             if constexpr (AN)  // c . d w_t / d q,  d w_t / d q = (d u_t / d q - w_t sum_t' d u_t' / d q) / S
                 up += (cgn[j] * (cx[j] * ex[j] + cy[j] * ey[j] + cz[j] * ez[j]) - wt[j] * (cx[j] * Gx[j] + cy[j] * Gy[j] + cz[j] * Gz[j])) * invS[j];
@@ -672,11 +701,11 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
             if (want_dec) {
                 unsigned int dh0, dl0;
                 h2_split2((g == 0) ? dx : 0.f, 0.f, dh0, dl0);
-                uint2* __restrict__ D1 = ws.d + G::d_off(n_tiles, 1) + tbase;
+                uint2* __restrict__ D1 = stream_at(ws.d + G::d_off(n_tiles, 1), tbase);
                 D1[0] = transpose_block(dh0, 0u, ident);
                 D1[64] = transpose_block(dl0, 0u, ident);
-                uint2* __restrict__ A1 = ws.a + G::a_off(n_tiles, 1) + tile * 128 * (MT - 1) + tbase;
-                uint2* __restrict__ D0 = ws.d + G::d_off(n_tiles, 0) + tile * 128 * (MT - 1) + tbase;
+                uint2* __restrict__ A1 = stream_at(ws.a + G::a_off(n_tiles, 1), tbig);
+                uint2* __restrict__ D0 = stream_at(ws.d + G::d_off(n_tiles, 0), tbig);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     A1[mt * 128] = transpose_block(ph[j][mt >> 1][2 * (mt & 1)], ph[j][mt >> 1][2 * (mt & 1) + 1], ident);
@@ -684,7 +713,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                     D0[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
                     D0[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
                 }
-                uint2* __restrict__ A0 = ws.a + G::a_off(n_tiles, 0) + tbase;
+                uint2* __restrict__ A0 = stream_at(ws.a + G::a_off(n_tiles, 0), tbase);
                 A0[0] = transpose_block(zh[j][0], zh[j][1], ident);
                 A0[64] = transpose_block(zl[j][0], zl[j][1], ident);
                 if constexpr (AN) {  // the derivative network along chat_t (x dscale), upstream tau_t = s w_t
@@ -724,11 +753,11 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                     Q::split_acts(tb, th2, tl2);
                     unsigned int eh0, el0;
                     h2_split2((g == 0) ? tau : 0.f, 0.f, eh0, el0);
-                    uint2* __restrict__ E1 = ws2.d + G::d_off(n_tiles, 1) + tbase;
+                    uint2* __restrict__ E1 = stream_at(ws2.d + G::d_off(n_tiles, 1), tbase);
                     E1[0] = transpose_block(eh0, 0u, ident);
                     E1[64] = transpose_block(el0, 0u, ident);
-                    uint2* __restrict__ B1 = ws2.a + G::a_off(n_tiles, 1) + tile * 128 * (MT - 1) + tbase;
-                    uint2* __restrict__ E0 = ws2.d + G::d_off(n_tiles, 0) + tile * 128 * (MT - 1) + tbase;
+                    uint2* __restrict__ B1 = stream_at(ws2.a + G::a_off(n_tiles, 1), tbig);
+                    uint2* __restrict__ E0 = stream_at(ws2.d + G::d_off(n_tiles, 0), tbig);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         B1[mt * 128] = transpose_block(mh[mt >> 1][2 * (mt & 1)], mh[mt >> 1][2 * (mt & 1) + 1], ident);
@@ -736,7 +765,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
                         E0[mt * 128] = transpose_block(th2[mt >> 1][2 * (mt & 1)], th2[mt >> 1][2 * (mt & 1) + 1], ident);
                         E0[mt * 128 + 64] = transpose_block(tl2[mt >> 1][2 * (mt & 1)], tl2[mt >> 1][2 * (mt & 1) + 1], ident);
                     }
-                    uint2* __restrict__ B0 = ws2.a + G::a_off(n_tiles, 0) + tbase;
+                    uint2* __restrict__ B0 = stream_at(ws2.a + G::a_off(n_tiles, 0), tbase);
                     B0[0] = transpose_block(th[0], th[1], ident);
                     B0[64] = transpose_block(tl[0], tl[1], ident);
                 }
@@ -770,7 +799,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_nwf_kernel(pin_field 
     if (threadIdx.x < 2) {
         double tt = 0.0;
 #pragma unroll
-        for (int w = 0; w < TF_BLOCK / 64; ++w) tt += lred[w][threadIdx.x];
+        for (int w = 0; w < BLK / 64; ++w) tt += lred[w][threadIdx.x];
         loss_partial[2 * blockIdx.x + threadIdx.x] = tt;
     }
 }
@@ -792,7 +821,7 @@ constexpr int train_fused_nwf_lds_bytes() {
 //     d (c . g) / d f_t = s a_feat (c . d w_t / d q),
 // a second operand stream (ws2: D = deltau pieces, A = t_l pieces, no bias gradient) next to the BCE term's.
 template <int H, int L>
-__global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f, pin_train_params tp,
+__global__ __launch_bounds__((tf_an_block<H, L>()), 1) void train_fused_an_kernel(pin_field f, pin_train_params tp,
                                                                      const float* __restrict__ query,
                                                                      const float4* __restrict__ nbr,
                                                                      const int* __restrict__ nn_count,
@@ -805,6 +834,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
                                                                      const unsigned char* __restrict__ dec_image,
                                                                      float* __restrict__ dw_partial, int n_dec,
                                                                      double* __restrict__ loss_partial) {
+    constexpr int BLK = tf_an_block<H, L>();  // (the LDS patches stay laid out for TF_BLOCK / 64 waves)
     using Q = QuadDecoderH<H>;
     using G = DwGeom<H>;
     constexpr int MT = Q::MT, NJ = Q::NJ;
@@ -820,7 +850,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
     const int lane = threadIdx.x & 63, nq = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int n_main = tp.n_main;
     const int n_tiles = ws.n_tiles;
-    const int n_waves = gridDim.x * (TF_BLOCK / 64);
+    const int n_waves = gridDim.x * (BLK / 64);
     const float inv_dscale = 1.0f / dscale, s = f.sdf_scale;
     const bool orient = f.orient != nullptr;
     v4h_t ident;
@@ -829,13 +859,13 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
     double acc_bce = 0.0, acc_eik = 0.0;
     if (want_dec) {
         const int n = DW_SLOTS * n_dec;
-        for (int i = blockIdx.x * TF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TF_BLOCK) dw_partial[i] = 0.f;
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) dw_partial[i] = 0.f;
     }
     {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(dec_image);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
         constexpr int n16 = Q::bytes(L) >> 4;
-        for (int i = threadIdx.x; i < n16; i += TF_BLOCK) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n16; i += BLK) dst[i] = src[i];
     }
     __syncthreads();
     const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
@@ -940,8 +970,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
 #pragma unroll
             for (int r = 0; r < 4; ++r) x = fmaf(wo[r], h[kt][r], x);
         }
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
+        x = rows_sum(x);
         x += O[MF_OD_MAX * H];
         const float pred = s * x;
         if (active && g == 0 && pred_out != nullptr) pred_out[qi] = pred;
@@ -956,19 +985,19 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
             dxm = active ? gg * tp.inv_n_main / tp.sigma * s * dscale : 0.f;
         }
         // ---- the unit backward sweep: deltau_l; the BCE term's deltas are dxm * deltau_l
-        const size_t tbase = (size_t)tile * 128 + lane;
-        const size_t tbig = (size_t)tile * 128 * (MT - 1) + tbase;
+        const unsigned int tbase = (unsigned int)tile * 128u + (unsigned int)lane;
+        const unsigned int tbig = (unsigned int)tile * (128u * MT) + (unsigned int)lane;
         if (want_dec) {
             unsigned int dh0, dl0, eh0, el0;
             h2_split2((g == 0) ? dxm : 0.f, 0.f, dh0, dl0);
             h2_split2((g == 0 && active) ? 1.f : 0.f, 0.f, eh0, el0);
-            uint2* __restrict__ D = ws.d + G::d_off(n_tiles, L) + tbase;
+            uint2* __restrict__ D = stream_at(ws.d + G::d_off(n_tiles, L), tbase);
             D[0] = transpose_block(dh0, 0u, ident);
             D[64] = transpose_block(dl0, 0u, ident);
-            uint2* __restrict__ E = ws2.d + G::d_off(n_tiles, L) + tbase;
+            uint2* __restrict__ E = stream_at(ws2.d + G::d_off(n_tiles, L), tbase);
             E[0] = transpose_block(eh0, 0u, ident);
             E[64] = transpose_block(el0, 0u, ident);
-            uint2* __restrict__ A = ws.a + G::a_off(n_tiles, L) + tbig;
+            uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, L), tbig);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 A[mt * 128] = transpose_block(ph[L - 1][mt >> 1][2 * (mt & 1)], ph[L - 1][mt >> 1][2 * (mt & 1) + 1], ident);
@@ -994,8 +1023,8 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
                     for (int r = 0; r < 4; ++r) hm[mt][r] = dxm * h[mt][r];
                 v4u_t bh[NJ], bl[NJ];
                 Q::split_acts(hm, bh, bl);
-                uint2* __restrict__ D = ws.d + G::d_off(n_tiles, l) + tbig;
-                uint2* __restrict__ E = ws2.d + G::d_off(n_tiles, l) + tbig;
+                uint2* __restrict__ D = stream_at(ws.d + G::d_off(n_tiles, l), tbig);
+                uint2* __restrict__ E = stream_at(ws2.d + G::d_off(n_tiles, l), tbig);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
@@ -1004,14 +1033,14 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
                     E[mt * 128 + 64] = transpose_block(ul[mt >> 1][2 * (mt & 1)], ul[mt >> 1][2 * (mt & 1) + 1], ident);
                 }
                 if (l > 0) {
-                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, l) + tbig;
+                    uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, l), tbig);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         A[mt * 128] = transpose_block(ph[l - 1][mt >> 1][2 * (mt & 1)], ph[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
                         A[mt * 128 + 64] = transpose_block(pl[l - 1][mt >> 1][2 * (mt & 1)], pl[l - 1][mt >> 1][2 * (mt & 1) + 1], ident);
                     }
                 } else {
-                    uint2* __restrict__ A = ws.a + G::a_off(n_tiles, 0) + tbase;
+                    uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, 0), tbase);
                     A[0] = transpose_block(zh[0], zh[1], ident);
                     A[64] = transpose_block(zl[0], zl[1], ident);
                 }
@@ -1065,7 +1094,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
             }
             v2u_t th, tl;
             Q::split_input(zd, th, tl);
-            uint2* __restrict__ B0 = ws2.a + G::a_off(n_tiles, 0) + tbase;
+            uint2* __restrict__ B0 = stream_at(ws2.a + G::a_off(n_tiles, 0), tbase);
             B0[0] = transpose_block(th[0], th[1], ident);
             B0[64] = transpose_block(tl[0], tl[1], ident);
 #pragma unroll
@@ -1079,7 +1108,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
                     for (int r = 0; r < 4; ++r) h[mj][r] = piece_on(ph[l - 1], pl[l - 1], mj, r) ? acc[mj][r] : 0.f;
                 v4u_t mh[NJ], ml[NJ];
                 Q::split_acts(h, mh, ml);
-                uint2* __restrict__ B = ws2.a + G::a_off(n_tiles, l) + tbig;
+                uint2* __restrict__ B = stream_at(ws2.a + G::a_off(n_tiles, l), tbig);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     B[mt * 128] = transpose_block(mh[mt >> 1][2 * (mt & 1)], mh[mt >> 1][2 * (mt & 1) + 1], ident);
@@ -1121,7 +1150,7 @@ __global__ __launch_bounds__(TF_BLOCK, 1) void train_fused_an_kernel(pin_field f
     if (threadIdx.x < 2) {
         double tt = 0.0;
 #pragma unroll
-        for (int w = 0; w < TF_BLOCK / 64; ++w) tt += lred[w][threadIdx.x];
+        for (int w = 0; w < BLK / 64; ++w) tt += lred[w][threadIdx.x];
         loss_partial[2 * blockIdx.x + threadIdx.x] = tt;
     }
 }

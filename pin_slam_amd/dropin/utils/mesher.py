@@ -60,6 +60,9 @@ class Mesher(_Base):
         mask_d = torch.zeros(n, dtype=torch.bool, device=dev) if query_mask else None
         fs = npts.field_state(self.sdf_mlp, query_locally=query_locally) if query_sdf else None
         fc = npts.field_state(self.color_mlp, query_locally=query_locally, color=True) if query_color else None
+        for fld in (fs, fc):  # the decoders do not change during the call: one staged image for all its launches
+            if fld is not None:
+                fld.stage_decoder()
         for i in range(math.ceil(n / bs)):
             head, tail = i * bs, min((i + 1) * bs, n)
             q = coord[head:tail].detach().to(device=dev, dtype=torch.float32).contiguous()

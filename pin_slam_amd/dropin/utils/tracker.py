@@ -131,6 +131,7 @@ class Tracker:
         sdf = grad = std = cert = None
         if query_sdf or query_sdf_grad or query_certainty:
             fs = npts.field_state(self.sdf_mlp, query_locally=query_locally)
+            fs.stage_decoder()
             sdf, grad, std, cert = ops.sdf_query(fs, q, nbr, nn, grad=query_sdf_grad)
         color = color_grad = None
         if query_color:
