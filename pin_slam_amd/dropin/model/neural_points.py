@@ -340,8 +340,24 @@ class NeuralPoints(nn.Module):
     def _rebuild_bricks(self):
         """Per-frame cell-coherent cache of the hash lookups for local, time-filtered queries."""
         self._bricks = None
+        self._bricks_pending = False
         if self.config.num_nei_cells > 2 or self._n == 0:
             return
+        if getattr(self, "_defer_bricks", False):
+            # Mapper.process_frame queues the build later (build_pending_bricks): its two ~150-200 us launches hold every
+            # compute unit, and a small launch of the caller's stream that arrives meanwhile waits behind them (kernel
+            # trace, r04: the pool filter's 25 us discard kernel took 192 us beside brick_fill) -- so the build goes in
+            # behind the pool filter and the certainty query, where the caller's stream only waits for count read-backs
+            self._bricks_pending = True
+            return
+        self._build_bricks()
+
+    def build_pending_bricks(self):
+        if getattr(self, "_bricks_pending", False):
+            self._bricks_pending = False
+            self._build_bricks()
+
+    def _build_bricks(self):
         if self._brick_cache is None or self._brick_cache.cand_dx.shape[0] != self.neighbor_K:
             self._brick_cache = ops.BrickCache(self.neighbor_dx.cpu().numpy(), int(self.config.num_nei_cells), self.device)
         tf = self.temporal_local_map_on and self.travel_dist is not None
@@ -349,6 +365,10 @@ class NeuralPoints(nn.Module):
         # certainty query, new-sample index) is a chain of small kernels and count read-backs that leaves the GPU
         # mostly idle and does not touch the cache.  Consumers go through _use_bricks(), which orders their stream
         # behind the build.
+        # (Measured and not kept, r04: a stream of the lowest queue priority -- the small launches of the caller's stream
+        # still wait for compute units behind the build's 8 700-block launches, map prep 1.11 -> 1.20 ms; a stream with a
+        # compute-unit mask that leaves an eighth of the device free -- hipExtStreamCreateWithCUMask makes a BLOCKING
+        # stream, which serialises with torch's null stream: 1.02 -> 1.25 ms.)
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         side, main = self._side_stream, torch.cuda.current_stream()
@@ -360,12 +380,14 @@ class NeuralPoints(nn.Module):
     def _wait_bricks(self):
         """Order the caller's stream behind a brick build that may still be reading the map arrays on the side stream
         (before anything rewrites the table / positions / global2local)."""
+        self.build_pending_bricks()
         ev = getattr(self, "_bricks_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
     def _use_bricks(self):
         """The current brick cache (or None), with the caller's stream ordered behind its build."""
+        self.build_pending_bricks()
         ev = getattr(self, "_bricks_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)

@@ -223,14 +223,17 @@ class Mapper(_Base):
         # (the size of the new local map is read back together with the last count of this function)
         defer = c.bs_new_sample > 0 and self.silence
         npts._defer_local_count = defer
+        npts._defer_bricks = os.environ.get("PIN_DEFER_BRICKS", "1") != "0"  # (queued by _process_frame_tail, see NeuralPoints._rebuild_bricks)
         try:
             self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
         finally:
             npts._defer_local_count = False
+            npts._defer_bricks = False
         hostcache.stamp("pf:update_done")
         try:
             self._process_frame_tail(c, npts, p, frame_id, filtering, kept, n_new, defer)
         finally:
+            npts.build_pending_bricks()
             # an exception between update() and the read-back below must not leave the local tables at last frame's size
             if getattr(npts, "_local_count_pending", False):
                 npts._finish_local_map(int(npts._cnt[2].item()))
@@ -241,10 +244,18 @@ class Mapper(_Base):
         self.determine_used_pose()
 
         # K13: pool window + capacity (mapper.py:303-360); the discard draw comes after update's, as in the reference
+        # (the brick build deferred by update() goes to its side stream once the filter's launches are queued: they run
+        # unhindered, the build takes the device while this stream waits for the filter's counts.  Same box, 2 runs each,
+        # map prep + mapping per frame: build queued by update() 2.37-2.39 ms; here 2.28-2.32; behind the certainty query
+        # (PIN_DEFER_BRICKS=2) 2.38 -- then Mapper.mapping waits for it)
+        late = os.environ.get("PIN_DEFER_BRICKS", "1") == "2"
         if filtering:
-            self.pool_sample_count, self.cur_sample_count = p.filter_finish(int(c.pool_capacity), kept=kept)
+            self.pool_sample_count, self.cur_sample_count = p.filter_finish(int(c.pool_capacity), kept=kept,
+                                                                            before_sync=None if late else npts.build_pending_bricks)
         else:
             self.cur_sample_count, self.pool_sample_count = n_new, p.n
+        if not late:
+            npts.build_pending_bricks()
         self._publish_pool()
         hostcache.stamp("pf:filter_done_sync3")
 
@@ -256,6 +267,7 @@ class Mapper(_Base):
             idx, cnt = ops.new_sample_index(cert, p.bufs[0]["sdf_label"][first:first + cur], c.new_certainty_thre,
                                             np.float32(c.surface_sample_range_m * 3.0), offset=first)
             hostcache.stamp("pf:certainty_enqueued")
+            npts.build_pending_bricks()  # beside the count read-back below and the host work up to Mapper.mapping
             if getattr(npts, "_local_count_pending", False):
                 new_count, counted = (int(v) for v in torch.stack((cnt[0], npts._cnt[2])).tolist())
                 npts._finish_local_map(counted)

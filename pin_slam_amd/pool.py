@@ -154,9 +154,11 @@ class SamplePool:
                                      self.counts.data_ptr(), self.ws.data_ptr(), self.ws.numel(), ops._stream()),
               "pin_pool_window_mask")
 
-    def filter_finish(self, capacity: int, discard_index: Optional[torch.Tensor] = None, kept: Optional[int] = None):
+    def filter_finish(self, capacity: int, discard_index: Optional[torch.Tensor] = None, kept: Optional[int] = None,
+                      before_sync=None):
         """Random discard (the reference's torch.randint draw) + compaction + the two counts (one read-back;
-        one more for `kept` if the caller has not fetched it)."""
+        one more for `kept` if the caller has not fetched it).  before_sync(): called once the launches are queued, in
+        front of the read-back (the caller queues work for other streams there, to run while this one waits)."""
         L = _lib.lib()
         n, dev = self.n, self.device
         if n == 0:
@@ -178,6 +180,8 @@ class SamplePool:
         check(L.pin_pool_compact(C.byref(a), C.byref(b), self.mask.data_ptr(), n, self.n_cur, self.counts.data_ptr(),
                                  self.ws.data_ptr(), self.ws.numel(), stream), "pin_pool_compact")
         self.counts_host.copy_(self.counts, non_blocking=True)
+        if before_sync is not None:
+            before_sync()
         torch.cuda.current_stream().synchronize()
         self.bufs = [self.bufs[1], self.bufs[0]]
         self.n, self.n_cur = int(self.counts_host[0]), int(self.counts_host[1])
