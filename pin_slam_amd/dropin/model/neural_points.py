@@ -385,6 +385,12 @@ class NeuralPoints(nn.Module):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def _peek_bricks(self):
+        """The current brick cache (or None) WITHOUT ordering the caller's stream behind its build: for a caller that queues
+        other work first and calls _use_bricks() right in front of its first search."""
+        self.build_pending_bricks()
+        return self._bricks
+
     def _use_bricks(self):
         """The current brick cache (or None), with the caller's stream ordered behind its build."""
         self.build_pending_bricks()

@@ -447,7 +447,7 @@ class Mapper(_Base):
         if bad:
             raise NotImplementedError("Mapper.mapping on libpinhip does not cover: " + ", ".join(bad))
 
-    def _get_trainer(self) -> engine.MapTrainer:
+    def _get_trainer(self, peek_bricks: bool = False) -> engine.MapTrainer:
         c, npts = self.config, self.neural_points
         st = npts.search_state()
         fs = npts.field_state(self.sdf_mlp, query_locally=True)
@@ -474,7 +474,9 @@ class Mapper(_Base):
                         train_decoder=bool(self.color_mlp.lout.weight.requires_grad))
         else:
             t.set_color(None)
-        b = npts._use_bricks()
+        # (the build may still be running on its side stream: mapping() orders this stream behind it right in front of its
+        # first search, after the optimiser reset, the batch draws and the first gather launch have been queued)
+        b = npts._peek_bricks() if peek_bricks else npts._use_bricks()
         tf = bool(npts.temporal_local_map_on and npts.travel_dist is not None)
         t.bricks = b if (b is not None and b.mode[:2] == (tf, True) and npts.neighbor_K == b.cand_dx.shape[0]) else None
         return t
@@ -483,10 +485,11 @@ class Mapper(_Base):
         """PIN map online training given fixed poses (mapper.py:600-844)."""
         self._check_supported()
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
-        t = self._get_trainer()
+        t = self._get_trainer(peek_bricks=True)
         t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
         t.defer_side_effects = False
         if t.dp is not None:  # spatially sharded over the ranks (pin_slam_amd.dp)
+            self.neural_points._use_bricks()
             self._mapping_spatial(t, iter_count)
             return
         from ...sharding import shard_range
@@ -502,13 +505,21 @@ class Mapper(_Base):
                 # one GPU: the batches were all drawn above and the neural points do not move while the map trains, so one
                 # gather launch and one kNN launch serve a whole group of iterations (TrainBuffers.group)
                 G = t.buf.group
+                outs0 = None
+                want_reuse = getattr(self, "reuse_pool_records", None)
+                if want_reuse is None:
+                    want_reuse = iter_count * self.config.bs >= getattr(self, "reuse_pool_records_ratio", 2.0) * self.pool_sample_count
+                if not want_reuse:
+                    # (no per-pool search in this call: the first group's gather launch goes in front of the wait as well)
+                    outs0 = self._gather_group(t, 0, min(G, iter_count), global_coord=not self.ba_done_flag)
+                self.neural_points._use_bricks()  # the searches below read the cache
                 reuse = self._pool_records(t, iter_count)  # large batches: one search per POOL sample and call
                 t.defer_side_effects = False
                 if reuse is not None:  # ... and their training-mode side effects applied once, from the draw counts
                     t.begin_deferred_side_effects(self._drawn["hist"], self._drawn["new"], self.new_idx, self.pool_sample_count)
                 for it0 in range(0, iter_count, G):
                     gn = min(G, iter_count - it0)
-                    outs = self._gather_group(t, it0, gn, global_coord=not self.ba_done_flag)
+                    outs = outs0 if (it0 == 0 and outs0 is not None) else self._gather_group(t, it0, gn, global_coord=not self.ba_done_flag)
                     if reuse is None:
                         t.knn_group(gn)
                     else:
@@ -526,6 +537,8 @@ class Mapper(_Base):
                 t.buf.select(0)
                 if reuse is not None:
                     t.apply_deferred_side_effects(reuse[0], reuse[1], self._pool().bufs[0]["ts"], self.pool_sample_count)
+            if not grouped:
+                self.neural_points._use_bricks()
             for it in range(0 if not grouped else iter_count, iter_count):
                 self._queries_for = fused_q
                 coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)

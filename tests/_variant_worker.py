@@ -40,6 +40,59 @@ def main(out, hidden, levels, orient):
              sums=sums.cpu().numpy().sum(0), sdf=sdf.cpu().numpy(), grad=grad.cpu().numpy())
 
 
+def query(out):
+    """pin_sdf_query / pin_color_query over several field shapes on a small synthetic map, under the environment the process
+    was started with (PIN_QUERY_QUAD picks the tile kernels or the thread-per-query kernels, read once per process)."""
+    m = synth.build_map(layers=2, radius=20.0, raw_per_layer=120_000)
+    P = len(m.positions)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pos = dev(m.positions)
+    pos4 = torch.empty((P, 4), dtype=torch.float32, device="cuda")
+    ops.pack_positions(pos, torch.zeros(P, dtype=torch.int32, device="cuda"), pos4)
+    dx, mv = ops.search_neighborhood(2, 0.5, 0.4)
+    g2l = torch.arange(P + 1, dtype=torch.int32, device="cuda"); g2l[-1] = -1
+    st = ops.SearchState(table=dev(m.table), pos4=pos4, cand_off=dev(ops.candidate_offsets(dx, m.buffer_size)), n_points=P,
+                         resolution=0.4, max_valid_dist2=mv, travel_dist=torch.zeros(1, device="cuda"), cur_ts=0,
+                         diff_travel_dist_local=410.0, global2local=g2l)
+    rng = np.random.default_rng(11)
+    q4 = rng.standard_normal((P + 1, 4)).astype(np.float32)
+    quat = dev(q4 / np.linalg.norm(q4, axis=1, keepdims=True))
+    cert = dev(rng.uniform(0.0, 5.0, P).astype(np.float32))
+    # queries: a scan on the surface, points off the surface (fewer neighbours) and a few with none at all
+    scan = synth.make_scan(m, n=6_001, radius=18.0)
+    off = scan[:1500] + rng.normal(0, 0.35, (1500, 3)).astype(np.float32)
+    off[:, 2] += (rng.uniform(0.9, 2.3, 1500) * rng.choice([-1.0, 1.0], 1500)).astype(np.float32)  # out to the edge of the search radius
+    far = scan[:37] + np.float32(500.0)
+    q = dev(np.concatenate([scan, off, far]).astype(np.float32))
+    nbr, nn, _ = ops.knn_query(st, q, 8)
+    res = {"nn": nn.cpu().numpy()}
+    def big(h, l, od=1):  # a decoder with outputs and gradients well above rounding noise
+        w = synth.init_decoder(h, l, out_dim=od)
+        return dev((w + 0.2 * rng.standard_normal(w.shape)).astype(np.float32))
+    cases = [("wf_64x4", 64, 4, True, None), ("wf_32x2_pgo", 32, 2, True, quat), ("wf_64x1", 64, 1, True, None),
+             ("nwf_64x1", 64, 1, False, None), ("nwf_32x1_pgo", 32, 1, False, quat)]
+    for tag, h, l, wf, ori in cases:
+        fs = ops.FieldState(feats=dev(m.features), dec=big(h, l), k=8, hidden=h, levels=l, weighted_first=wf, sdf_scale=0.055,
+                            certainty=cert, pos=pos, orient=ori)
+        for staged in (False, True):
+            if staged:
+                fs.stage_decoder()
+            sdf, grad, std, ce = ops.sdf_query(fs, q, nbr, nn)
+            sdf0, _, _, _ = ops.sdf_query(fs, q, nbr, nn, grad=False, std=False, certainty=False)
+            k = tag + ("_staged" if staged else "")
+            res.update({k + "_sdf": sdf.cpu().numpy(), k + "_grad": grad.cpu().numpy(), k + "_std": std.cpu().numpy(),
+                        k + "_cert": ce.cpu().numpy(), k + "_sdf_fwd": sdf0.cpu().numpy()})
+    for tag, h, l, ori in (("col_64x2", 64, 2, None), ("col_32x1_pgo", 32, 1, quat)):
+        fc = ops.FieldState(feats=dev(m.features), dec=big(h, l, 3), k=8, hidden=h,
+                            levels=l, weighted_first=True, sdf_scale=1.0, certainty=None, pos=pos, orient=ori, out_dim=3)
+        col, val, g = ops.color_query(fc, q, nbr, nn)
+        col0, val0, _ = ops.color_query(fc, q, nbr, nn, want_grad=False)
+        res.update({tag + "_col": col.cpu().numpy(), tag + "_val": val.cpu().numpy(), tag + "_grad": g.cpu().numpy(),
+                    tag + "_col_fwd": col0.cpu().numpy(), tag + "_val_fwd": val0.cpu().numpy()})
+    torch.cuda.synchronize()
+    np.savez(out, **res)
+
+
 def fixture(out, case):
     """Per-point outputs and sums of the GN tile kernel on a golden fixture's query set (local index space)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -88,6 +141,8 @@ def color(out):
 if __name__ == "__main__":
     if sys.argv[2] == "color":
         color(sys.argv[1])
+    elif sys.argv[2] == "query":
+        query(sys.argv[1])
     elif sys.argv[2] == "fixture":
         fixture(sys.argv[1], sys.argv[3])
     else:
