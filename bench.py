@@ -885,7 +885,8 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group, reuse_pool_n=None)
                    "train_dw": ks["train_dw_recompute" if "train_dw_recompute" in ks else "train_dw_stream"]["hbm_bytes_per_launch_if_streaming_x2"],
                    # the search kernel's bytes per QUERY (8 lanes per query) x the queries an iteration pays for
                    "knn_brick": int(ks["knn_brick"]["hbm_bytes_per_launch"] / (int(ks["knn_brick"]["launch_shape_grid"]) / 8.0) * knn_queries),
-                   "lazy_adam": ks["mark_rows"]["hbm_bytes_per_launch"] + ks["adam_lazy_prepare_rows"]["hbm_bytes_per_launch"]}
+                   # (from three records per table row on the row-marking launch is skipped: no "mark_rows" class then)
+                   "lazy_adam": ks.get("mark_rows", {}).get("hbm_bytes_per_launch", 0) + ks["adam_lazy_prepare_rows"]["hbm_bytes_per_launch"]}
             if reuse_pool_n:  # the copy of the samples' records (pin_gather_records_drawn) has no counter pass of its own: read + write
                 per["gather_records_computed"] = int(2 * args.global_bs * k * 16)
             r["traffic"] = int(sum(per.values()))

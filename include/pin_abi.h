@@ -425,7 +425,9 @@ int pin_color_query(const pin_field* fc, const float* query, const float* nbr, c
 
 /* K2+K3+K4 fused: interpolate, decode, analytic d sdf/d q through MLP, neighbour vectors
  * and IDW weights (Tracker.query_source_points, utils/tracker.py:297-354, get_gradient
- * utils/tools.py:247-260).  Any output pointer may be NULL. */
+ * utils/tools.py:247-260; Mesher.query_points, utils/mesher.py:60-140, with grad_out = NULL: forward sweep only).  Any
+ * output pointer may be NULL.  With f->dec_image (pin_stage_decoder) the launch copies the staged decoder instead of
+ * splitting it per block -- worth one staging launch when several queries follow on one decoder (the mesher's batches). */
 int pin_sdf_query(const pin_field* f, const float* query, const float* nbr,
                   const int32_t* nn_count, int32_t n, float* sdf_out, float* grad_out,
                   float* std_out, float* certainty_out, void* stream);
