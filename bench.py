@@ -662,7 +662,9 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     n = coord.shape[0]
     ms = Mesher(cfg, npts, decoders)
     bs = int(cfg.infer_bs)
-    ms.query_points(coord[:bs], bs, True, False, False, True, False, out_torch=True)  # warm-up (launch shapes, workspaces)
+    keep, ms.global_bricks_min_queries = ms.global_bricks_min_queries, (0 if n >= ms.global_bricks_min_queries else ms.global_bricks_min_queries)
+    ms.query_points(coord[:bs], bs, True, False, False, True, False, out_torch=True)  # warm-up (launch shapes, workspaces, the brick cache's buffers)
+    ms.global_bricks_min_queries = keep
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sdf, _, _, mask = ms.query_points(coord, bs, True, False, False, True, False, out_torch=True)
@@ -672,11 +674,21 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     fs = npts.field_state(decoders["sdf"], query_locally=False)
     fs.stage_decoder()
     from pin_slam_amd import ops
+    gb = getattr(ms, "_global_bricks", None) if n >= ms.global_bricks_min_queries else None  # (the call's brick cache over the global map)
+    st_g = npts.search_state()
+
+    def search(q):
+        if gb is not None:
+            return ops.knn_query(st_g, q, int(cfg.query_nn_k), time_filtering=False, local=False, bricks=gb)
+        return npts.knn(q, False)
+
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    if gb is not None:
+        gb.build(st_g, time_filtering=False, local=False)  # (inside the device time, as inside the call)
     for a in range(0, n, bs):
         q = coord[a:a + bs]
-        nbr, nn, _ = npts.knn(q, False)
+        nbr, nn, _ = search(q)
         ops.sdf_query(fs, q, nbr, nn, grad=False, std=False, certainty=False)
     e1.record()
     torch.cuda.synchronize()
@@ -687,7 +699,7 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
         q = coord[a:a + bs]
         ea, eb, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         ea.record()
-        nbr, nn, _ = npts.knn(q, False)
+        nbr, nn, _ = search(q)
         eb.record()
         ops.sdf_query(fs, q, nbr, nn, grad=False, std=False, certainty=False)
         ec.record()
@@ -701,7 +713,8 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
             "queries_per_sec_call": round(n / dt, 1), "ms_device": round(dev_ms, 2), "queries_per_sec_device": round(n / (dev_ms * 1e-3), 1),
             "ms_search": round(search_ms, 2), "ms_decode": round(decode_ms, 2),
             "valid_share": round(float(mask.float().mean().item()), 4),
-            "roofline": {"kernel": "knn_query_kernel (direct probe of the global table) + sdf_query_quad_kernel (forward only, 4 lanes per query)", "bound": "hbm (random 4 / 16 / 32-byte "
+            "search": "brick cache over the global map, built per call" if gb is not None else "direct probe of the global table",
+            "roofline": {"kernel": ("knn_brick_kernel (global brick cache, built inside the timed region)" if gb is not None else "knn_query_kernel (direct probe of the global table)") + " + sdf_query_quad_kernel (forward only, 4 lanes per query)", "bound": "hbm (random 4 / 16 / 32-byte "
                          "accesses)", "achieved": round(bytes_q * n / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bytes_q * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_query": round(bytes_q, 1),
                          "traffic": None},

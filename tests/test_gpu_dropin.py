@@ -405,10 +405,12 @@ def test_mini_slam_loop_with_colour():
 
 
 @pytest.mark.parametrize("case", ["c2_wf", "kitti_nwf"])
-@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("local", [False, True, "global_bricks"])
 def test_mesher_query_points_matches_reference(case, local):
     """Drop-in Mesher.query_points (fused search + decode, chunked) against the reference's output on a grid
-    that reaches into unobserved space: mask identical, SDF within 1e-4, zeros where nothing is near."""
+    that reaches into unobserved space: mask identical, SDF within 1e-4, zeros where nothing is near.
+    "global_bricks": the call builds a brick cache over the global map for its searches (what it does from 3e6 queries on)."""
+    use_bricks, local = local == "global_bricks", local is True
     import ctypes as C
     from pin_slam_amd import _lib, ops
     from pin_slam_amd.dropin.utils.mesher import Mesher
@@ -419,22 +421,44 @@ def test_mesher_query_points_matches_reference(case, local):
     d2["geo_features"], d2["local_geo_features"], d2["dec_flat"] = (mz[case + "_geo_features"], mz[case + "_local_geo_features"],
                                                                    mz[case + "_dec_flat"])
 
-    class _Pts:  # the two calls Mesher.query_points makes on the map object
+    class _MapCfg:
+        num_nei_cells = int(d["num_nei_cells"])
+
+    class _Pts:  # what Mesher.query_points touches on the map object
+        config = _MapCfg()
+        neighbor_dx = torch.from_numpy(np.ascontiguousarray(d["neighbor_dx"]))
+        neighbor_K = int(d["neighbor_dx"].shape[0])
+
         def knn(self, q, query_locally):
+            assert not use_bricks, "the call should search through its own brick cache"
             return ops.knn_query(st, q, int(d["query_nn_k"]), time_filtering=query_locally, local=query_locally)
 
         def field_state(self, decoder, query_locally=True, color=False):
             return U.field_state(d2, local=query_locally)
 
+        def count(self):
+            return int(st.n_points)
+
+        def search_state(self):
+            return st
+
+        def _wait_bricks(self):
+            pass
+
     class _Cfg:
-        silence, device, dtype, color_channel = True, "cuda", torch.float32, 0
+        silence, device, dtype, color_channel, query_nn_k = True, "cuda", torch.float32, 0, int(d["query_nn_k"])
 
     mesher = Mesher(_Cfg(), _Pts(), {"sdf": None, "semantic": None, "color": None})
+    if use_bricks:
+        mesher.global_bricks_min_queries = 0
     grid = torch.from_numpy(mz[case + "_grid"]).cuda()
     sdf, _, _, mask = mesher.query_points(grid, 3000, True, False, False, True, query_locally=local, out_torch=True)
     key = "local" if local else "global"
     assert np.array_equal(mask.numpy() != 0, mz[f"{case}_mask_{key}"] != 0)
     np.testing.assert_allclose(sdf.numpy(), mz[f"{case}_sdf_{key}"], rtol=1e-4, atol=3e-6)
+    assert (getattr(mesher, "_global_bricks", None) is not None) == use_bricks
+    mesher.global_bricks_min_queries = 10 ** 9
+    _Pts.knn = lambda self, q, query_locally: ops.knn_query(st, q, int(d["query_nn_k"]), time_filtering=query_locally, local=query_locally)
     sdf_np, _, _, mask_np = mesher.query_points(grid[:500], 200, out_torch=False)
     assert sdf_np.dtype == np.float64 and sdf_np.shape == (500,) and mask_np.shape == (500,)
 
