@@ -22,22 +22,48 @@ def _listing(src, out_dir):
     return open(out).read()
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_no_kernel_uses_scratch_memory(tmp_path):
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    """{mangled kernel name: (file, vgprs, spilled vgprs, scratch bytes, LDS bytes)} of every kernel of the library."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     assert len(srcs) >= 9
+    out_dir = str(tmp_path_factory.mktemp("asm"))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        texts = list(ex.map(lambda s: _listing(s, str(tmp_path)), srcs))
-    n_kernels, bad = 0, []
+        texts = list(ex.map(lambda s: _listing(s, out_dir), srcs))
+    table = {}
     for src, txt in zip(srcs, texts):
         for blk in txt.split("  - .agpr_count:")[1:]:
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-            if name.startswith("_ZN7rocprim"):
-                continue
-            n_kernels += 1
-            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
-            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
-            if scratch != 0 or spills != 0:
-                bad.append((os.path.basename(src), name, scratch, spills))
-    assert n_kernels > 250, n_kernels
+            table[name] = (os.path.basename(src), g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"),
+                           g("group_segment_fixed_size"))
+    return table
+
+
+def test_no_kernel_uses_scratch_memory(kernels):
+    ours = {k: v for k, v in kernels.items() if not k.startswith("_ZN7rocprim")}
+    assert len(ours) > 250, len(ours)
+    bad = [(v[0], k, v[3], v[2]) for k, v in ours.items() if v[3] != 0 or v[2] != 0]
     assert not bad, f"kernels with scratch memory / spilled vector registers: {bad}"
+
+
+def test_register_budgets_of_the_hot_kernels(kernels):
+    """The occupancy each hot kernel was tuned for, as a register count (512 vector registers per SIMD lane: <= 256 -> 2 waves
+    per SIMD, <= 168 -> 3, <= 72 -> 7).  Guards against silent inflation -- e.g. a second `extern __shared__` symbol in
+    sdf.hip took the registration tile kernel from 187 to 211 registers and added 30 address instructions."""
+    def one(prefix):
+        hit = [(k, v) for k, v in kernels.items() if k.startswith(prefix)]
+        assert len(hit) == 1, (prefix, [k for k, _ in hit])
+        return hit[0][1]
+    # Tracker.tracking at 4 x 64 (the kernel `roofline` is stated on): two waves per SIMD, and not a register more than it had
+    assert one("_ZN3pin25gn_accumulate_quad_kernelILi64ELb0ELb1ELi4ELb0ELi512EEE")[1] <= 192
+    # its search: seven waves per SIMD
+    assert one("_ZN3pin23knn_brick_listed_kernelILi11ELi0EEE")[1] <= 72
+    # Mapper.mapping's tile kernel: three waves per SIMD
+    assert one("_ZN3pin18train_fused_kernelILi64ELi4ELi1EEE")[1] <= 168
+    # forward-only queries (Mesher.query_points): three waves per SIMD
+    assert one("_ZN3pin21sdf_query_quad_kernelILi64ELb0ELi4ELb0ELi1EEE")[1] <= 168
+    # the C5 colour registration at 1 x 64: two waves per SIMD
+    assert one("_ZN3pin25gn_accumulate_quad_kernelILi64ELb0ELb1ELi1ELb1ELi512EEE")[1] <= 256
