@@ -32,7 +32,7 @@ def kernels(tmp_path_factory):
     out_dir = str(tmp_path_factory.mktemp("asm"))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         texts = list(ex.map(lambda s: _listing(s, out_dir), srcs))
-    table = {}
+    table = {"__texts__": dict(zip((os.path.basename(x) for x in srcs), texts))}
     for src, txt in zip(srcs, texts):
         for blk in txt.split("  - .agpr_count:")[1:]:
             g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
@@ -43,7 +43,7 @@ def kernels(tmp_path_factory):
 
 
 def test_no_kernel_uses_scratch_memory(kernels):
-    ours = {k: v for k, v in kernels.items() if not k.startswith("_ZN7rocprim")}
+    ours = {k: v for k, v in kernels.items() if not k.startswith("_ZN7rocprim") and k != "__texts__"}
     assert len(ours) > 250, len(ours)
     bad = [(v[0], k, v[3], v[2]) for k, v in ours.items() if v[3] != 0 or v[2] != 0]
     assert not bad, f"kernels with scratch memory / spilled vector registers: {bad}"
@@ -54,7 +54,7 @@ def test_register_budgets_of_the_hot_kernels(kernels):
     per SIMD, <= 168 -> 3, <= 72 -> 7).  Guards against silent inflation -- e.g. a second `extern __shared__` symbol in
     sdf.hip took the registration tile kernel from 187 to 211 registers and added 30 address instructions."""
     def one(prefix):
-        hit = [(k, v) for k, v in kernels.items() if k.startswith(prefix)]
+        hit = [(k, v) for k, v in kernels.items() if k.startswith(prefix) and k != "__texts__"]
         assert len(hit) == 1, (prefix, [k for k, _ in hit])
         return hit[0][1]
     # Tracker.tracking at 4 x 64 (the kernel `roofline` is stated on): two waves per SIMD, and not a register more than it had
@@ -67,3 +67,16 @@ def test_register_budgets_of_the_hot_kernels(kernels):
     assert one("_ZN3pin21sdf_query_quad_kernelILi64ELb0ELi4ELb0ELi1EEE")[1] <= 168
     # the C5 colour registration at 1 x 64: two waves per SIMD
     assert one("_ZN3pin25gn_accumulate_quad_kernelILi64ELb0ELb1ELi1ELb1ELi512EEE")[1] <= 256
+
+
+def test_the_benchmarked_kernel_runs_on_the_matrix_cores(kernels):
+    """gn_accumulate_quad_kernel<64, false, true, 4>: the split-fp16 decoder sweeps are MFMA instructions written out by hand
+    (mlp_h2.h), not a library call -- 150 v_mfma_f32_16x16x32_f16 (hidden layers, forward and transposed: 3 products per
+    split value) and 12 v_mfma_f32_16x16x16_f16 (the 11-wide input layer and its transpose)."""
+    txt = kernels["__texts__"]["sdf.hip"]
+    name = "_ZN3pin25gn_accumulate_quad_kernelILi64ELb0ELb1ELi4ELb0ELi512EEE"
+    start = txt.index("\n" + name)
+    body = txt[start:txt.index("s_endpgm", start)]
+    assert body.count("v_mfma_f32_16x16x32_f16") >= 150
+    assert body.count("v_mfma_f32_16x16x16_f16") >= 12
+    assert "scratch_" not in body
