@@ -709,15 +709,29 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     decode_ms = sum(b_.elapsed_time(c_) for _, b_, c_ in evs)
     rho = nn_mean / Kc
     bytes_q = 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4 + 36 * k + 4  # search (as roofline_knn) + k feature rows + the SDF out
+    # HBM-side bytes per query from the counter passes of this leg (scripts/pmc_bench.sh mesher), when they are committed
+    traffic = traffic_src = None
+    pm = os.path.join(ROOT, "profiles", "r04_pmc_mesher.json")
+    if os.path.exists(pm):
+        try:
+            ks = json.load(open(pm))["kernels"]
+            per_batch = ks["knn_brick"]["hbm_bytes_per_launch"] + ks["sdf_query_quad"]["hbm_bytes_per_launch"]
+            traffic, traffic_src = round(per_batch / float(bs), 1), "profiles/r04_pmc_mesher.json"
+        except Exception:
+            pass
     return {"queries": n, "grid_step_m": round(step, 4), "batch": bs, "ms_call": round(1e3 * dt, 2),
             "queries_per_sec_call": round(n / dt, 1), "ms_device": round(dev_ms, 2), "queries_per_sec_device": round(n / (dev_ms * 1e-3), 1),
             "ms_search": round(search_ms, 2), "ms_decode": round(decode_ms, 2),
             "valid_share": round(float(mask.float().mean().item()), 4),
             "search": "brick cache over the global map, built per call" if gb is not None else "direct probe of the global table",
-            "roofline": {"kernel": ("knn_brick_kernel (global brick cache, built inside the timed region)" if gb is not None else "knn_query_kernel (direct probe of the global table)") + " + sdf_query_quad_kernel (forward only, 4 lanes per query)", "bound": "hbm (random 4 / 16 / 32-byte "
-                         "accesses)", "achieved": round(bytes_q * n / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": ("knn_brick_kernel (global brick cache, built inside the timed region)" if gb is not None else "knn_query_kernel (direct probe of the global table)") + " + sdf_query_quad_kernel (forward only, 4 lanes per query)", "bound": "valu" if pmc_note else "hbm (random 4 / 16 / 32-byte accesses)",
+                         "bound_note": ("vector-ALU instruction issue, not HBM: a regular grid's queries share their bricks and rows, the counted "
+                                        "HBM-side traffic is a fraction of the algorithmic bytes (PMC of this leg: search valu_active, decode "
+                                        "valu_active / mfma_util below); the GB/s figure is the algorithmic rate, stated against HBM for scale only")
+                         if pmc_note else None, "pmc": pmc_note,
+                         "achieved": round(bytes_q * n / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bytes_q * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_query": round(bytes_q, 1),
-                         "traffic": None},
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per query (search + decode launches of one batch)", "traffic_source": traffic_src},
             "note": "ms_call = Mesher.query_points as the reference defines it (results returned on the host); ms_device = its "
                     "search + decode launches alone"}
 

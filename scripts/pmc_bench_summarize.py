@@ -13,7 +13,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 O = os.path.join(R, "gpurun_out", "pmc_bench", W)
 CLOCK_GHZ, N_SIMD = 2.4, 1024
 
-CLASSES = (("gn", "gn_accumulate"), ("knn_brick_listed", "knn_brick_listed_kernel"), ("knn_brick", "knn_brick_kernel"), ("train_fused", "train_fused"), ("train_dw_recompute", "train_dw_recompute"), ("train_dw_stream", "train_dw_stream"),
+CLASSES = (("sdf_query_quad", "sdf_query_quad_kernel"), ("gn", "gn_accumulate"), ("knn_brick_listed", "knn_brick_listed_kernel"), ("knn_brick", "knn_brick_kernel"), ("train_fused", "train_fused"), ("train_dw_recompute", "train_dw_recompute"), ("train_dw_stream", "train_dw_stream"),
            ("adam_lazy_prepare_rows", "adam_lazy_prepare_rows"), ("mark_rows", "mark_rows"), ("adam_lazy_prepare", "adam_lazy_prepare"),
            ("gn_solve", "gn_solve"))
 LARGEST = W == "c4"  # the 2^20-sample mapper: its launches are the largest grids of their kernels, not the most frequent
@@ -45,7 +45,10 @@ for f in glob.glob(os.path.join(O, "stats", "**", "*kernel_trace.csv"), recursiv
         if k:
             g = str(int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)) if "Grid_Size_X" in r else r.get("Grid_Size", "?")
             dur[(k, g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"command": (f"scripts/pmc_bench.sh {W}: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {W} --steps 3 --warmup 1 "
+out = {"command": ("scripts/pmc_bench.sh mesher: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload c3 --steps 1 --warmup 0 "
+                   "--no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 10000000; the "
+                   "most frequent launch shape of knn_brick / sdf_query_quad = one 524 288-query batch of Mesher.query_points" if W == "mesher" else
+                   f"scripts/pmc_bench.sh {W}: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {W} --steps 3 --warmup 1 "
                    "--no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none" if not LARGEST else
                    "scripts/pmc_bench.sh c4: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload c3 --steps 1 --warmup 0 "
                    "--no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none; per kernel class the LARGEST "
