@@ -710,13 +710,15 @@ def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):
     rho = nn_mean / Kc
     bytes_q = 12 + 4 * Kc + 16 * rho * Kc + 16 * k + 4 + 36 * k + 4  # search (as roofline_knn) + k feature rows + the SDF out
     # HBM-side bytes per query from the counter passes of this leg (scripts/pmc_bench.sh mesher), when they are committed
-    traffic = traffic_src = None
+    traffic = traffic_src = pmc_note = None
     pm = os.path.join(ROOT, "profiles", "r04_pmc_mesher.json")
     if os.path.exists(pm):
         try:
             ks = json.load(open(pm))["kernels"]
             per_batch = ks["knn_brick"]["hbm_bytes_per_launch"] + ks["sdf_query_quad"]["hbm_bytes_per_launch"]
             traffic, traffic_src = round(per_batch / float(bs), 1), "profiles/r04_pmc_mesher.json"
+            pmc_note = {"search_valu_active": ks["knn_brick"].get("valu_active"), "decode_valu_active": ks["sdf_query_quad"].get("valu_active"),
+                        "decode_mfma_util": ks["sdf_query_quad"].get("mfma_util")}
         except Exception:
             pass
     return {"queries": n, "grid_step_m": round(step, 4), "batch": bs, "ms_call": round(1e3 * dt, 2),
