@@ -626,9 +626,21 @@ def main():
                     "registration_queries_per_sec": r["registration_queries_per_sec"],
                     "mapper_samples_per_sec": r["mapper_samples_per_sec"], "tracking_ms": r.get("tracking_ms"),
                     "torch": r.get("torch")}
+                # the record is a stored measurement: say which host THIS command runs on and whether it is the kind of
+                # host the record was taken on (CPU model + logical CPU count), so a stale record shows in the line
+                now = _host_now()
+                out["cpu_baseline"]["host_now"] = now["text"]
+                out["cpu_baseline"]["host_matches_record"] = bool(now["model"] and now["model"] in r["host"]
+                                                                  and f"{now['cpus']} logical CPUs" in r["host"])
+                out["cpu_baseline"]["live"] = False
                 break
             except Exception:
                 pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c3":
+        live = _ref_cpu_live(args)
+        if live is not None:
+            out["cpu_baseline_record"] = out.get("cpu_baseline")
+            out["cpu_baseline"] = live
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         port = cpu_baseline(
             m, cfg, scan_np, raw.cpu().numpy(), raw_ts.cpu().numpy(), pool_c, pool_l, m.features,
@@ -1125,6 +1137,55 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
                              "spatial shards the message is a few MB and latency-bound by design -- the lever is its SIZE "
                              "(bytes_per_iteration against the 71 MB of the dense exchange), see share_of_iteration"},
     }
+
+
+def _ref_cpu_live(args):
+    """cpu_baseline timed by THIS command: when the reference pack travels with the snapshot (oracle/_ref/, written by
+    `scripts/e2e_pin_slam.py pack`; git-ignored, never part of the repository), scripts/ref_cpu_baseline.py runs the
+    unmodified reference classes on torch CPU on this host -- after the timed region, the GPU idle -- with as many threads as
+    the container's CPU quota allows (more are throttled: profiles/r04_ref_cpu_baseline.json holds the sweep).  None when the
+    pack is absent or the run fails: the committed record stays the baseline."""
+    import subprocess
+    pack = os.path.join(ROOT, "oracle", "_ref", "pin_slam_reference.tar.gz")
+    if not os.path.exists(pack) or os.environ.get("PIN_BENCH_REF_LIVE", "1") == "0":
+        return None
+    from pin_slam_amd.dropin import cpu_quota
+    threads = max(1, int(cpu_quota()))
+    dst = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(dst, exist_ok=True)
+    rec = os.path.join(dst, "ref_cpu_baseline_live.json")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "ref_cpu_baseline.py"), "--reps", "3", "--skip-tracking", "--threads",
+           str(threads), "--reg-iters", str(args.reg_iters), "--map-iters", str(args.map_iters), "--out", rec,
+           "--host-label", "host of this bench run"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        subprocess.run(cmd, check=True, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+        r = json.load(open(rec))
+    except Exception:
+        return None
+    return {"value": r["frames_per_sec_bench_definition"], "unit": "frames/s", "cores": r["torch_threads"],
+            "kind": "reference-torch-cpu", "live": True, "host": r["host"],
+            "sample": (f"unmodified reference classes on torch CPU timed by this command after the GPU legs: median of {r['reps']} x "
+                       f"Tracker.registration_step over the {r['scan_points']}-point scan ({r['registration_step_ms']} ms) and of "
+                       f"{r['reps']} x Mapper.mapping({r['mapping_iterations']}) ({r['mapping_ms']} ms), 1 warm-up each; frame = "
+                       f"{args.reg_iters} registration steps + one mapping call (preprocess / map prep not included, which favours "
+                       f"the CPU); {r['torch_threads']} torch threads = this container's CPU quota"),
+            "registration_queries_per_sec": r["registration_queries_per_sec"],
+            "mapper_samples_per_sec": r["mapper_samples_per_sec"], "torch": r.get("torch")}
+
+
+def _host_now():
+    """CPU model / logical CPU count of the host this command runs on (the cpu_baseline record names its own)."""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cpus = os.cpu_count() or 0
+    return {"model": model, "cpus": cpus, "text": f"{cpus} logical CPUs, {model or 'unknown CPU'}"}
 
 
 def cpu_baseline(m, cfg, scan, raw, raw_ts, pool_c, pool_l, feats, dec, H, L, k, sdf_scale, args):

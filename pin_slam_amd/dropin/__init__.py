@@ -39,13 +39,19 @@ def limit_host_threads(verbose: bool = True) -> int:
     context loop detection, logging) then bursts 128 threads into a container quota of 16 CPUs, the cgroup is throttled for
     the rest of the 100 ms period and the NEXT stage of the SLAM loop -- whichever it is -- stalls for ~85 ms although the
     GPU work of a frame is a few ms (measured: profiles/r04_e2e_host_threads.json: 14-25 frames of 60 with a stage above
-    3x its median at 128 threads, none at 4).  In drop-in mode the heavy arithmetic is on the GPU: cap the pool at the
-    quota.  PIN_KEEP_THREADS=1 leaves it alone."""
+    3x its median at 128 threads, none at 4).  In drop-in mode the heavy arithmetic is on the GPU: when -- and only when -- the
+    container's quota is below the CPUs the scheduler shows, cap the pool at half the quota (the other half is for the
+    reference's own helper threads; 16 threads in a quota of 16 still throttled in the measurement).  An unconstrained host keeps
+    torch's sizing.  PIN_KEEP_THREADS=1 leaves it alone in every case."""
     import torch
     have = torch.get_num_threads()
     if os.environ.get("PIN_KEEP_THREADS", "0") == "1":
         return have
-    want = max(1, min(have, int(cpu_quota() // 2) or 1))
+    affinity = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    quota = cpu_quota()
+    if quota >= affinity:  # no cgroup limit below what the scheduler offers: torch's own sizing is right, leave it alone
+        return have
+    want = max(1, min(have, int(quota // 2) or 1))
     if want < have:
         torch.set_num_threads(want)
         if verbose:

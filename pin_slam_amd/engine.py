@@ -561,6 +561,15 @@ class MapTrainer:
         """setup_optimizer is called anew by every Mapper.mapping (mapper.py:615).  With the iteration count
         known (and one GPU) the feature tables use the lazy exact Adam: call finish_optimizer() after the last
         iteration; without it, the row-flagged / dense step."""
+        # a call that ended between step_batch and finish_optimizer (an exception in the caller's loop) leaves the side
+        # streams' hand-over state behind: order this stream behind whatever they still run and forget the owed steps --
+        # they belong to the optimiser state that is thrown away below
+        if self._wg_pending:
+            torch.cuda.current_stream().wait_event(self._wg_ev[1])
+            self._wg_pending = False
+        if self._dp_pending is not None:
+            torch.cuda.current_stream().wait_event(self._dp_ev[2])
+            self._dp_pending = None
         self.lazy_on = bool(iters) and (self.comm is None or self.dp is not None)
         if self.dp is not None and not self.lazy_on:
             raise ValueError("the spatially sharded mapper needs the iteration count (lazy Adam on the owned rows)")

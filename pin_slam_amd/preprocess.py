@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -161,9 +163,18 @@ class ScanPreprocessor:
         ts_ret = None
         if point_ts is not None:
             ts_ret = ts_out[:c2].to(point_ts.dtype).reshape((c2,) + tuple(point_ts.shape[1:]))
+        # The prefixes are returned as views: pc / src are sized by the raw scan, so a frame's results hold the raw scan's
+        # bytes (n x (w + 3 [+ w - 3]) floats: 2.8 MB per 100 000 points) until the caller drops them at the next frame --
+        # one frame's worth, never more, against a copy launch per output in a 0.27 ms stage.  PIN_PREPROCESS_COMPACT=1
+        # returns compact copies instead (a caller that keeps every frame's cloud).
+        compact = os.environ.get("PIN_PREPROCESS_COMPACT", "0") == "1"
+        out = (lambda t: t.clone()) if compact else (lambda t: t)
         if frame_id <= 0:
-            return pc[:c2], ts_ret, None, None
-        return pc[:c2], ts_ret, src[:c3], (rest[:c3] if rest is not None else None)
+            return out(pc[:c2]), ts_ret, None, None
+        # colours: the staged path hands back src[:, 3:] whenever color_on is set -- an empty [c3, 0] tensor for a scan
+        # without colour columns, not None
+        colors = out(rest[:c3]) if rest is not None else (src.new_empty((c3, 0)) if c.color_on else None)
+        return out(pc[:c2]), ts_ret, out(src[:c3]), colors
 
     def __call__(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None,
                  frame_id: int = 1, lose_track: bool = False):
