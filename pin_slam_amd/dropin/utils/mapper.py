@@ -415,7 +415,7 @@ class Mapper(_Base):
                 a, b = j * buf.Q + buf.n_main, (j + 1) * buf.Q
                 ops.knn_query(t.st, buf.query_all[a:b], k, out=(buf.nbr_all[a:b], buf.nn_all[a:b], None), bricks=t.bricks)
 
-    def _draw_all(self, iters, per_iteration_ok=True):
+    def _draw_all(self, iters):
         """The batch indices of `iters` get_batch calls in two torch.randint launches instead of 2 x iters (the
         reference draws per iteration, mapper.py:462-480; the draws are iid uniform either way)."""
         c, ds, new_idx, n = self.config, self.dataset, self.new_idx, self.pool_sample_count
@@ -425,10 +425,6 @@ class Mapper(_Base):
         if n <= 0 or iters <= 0:
             return None
         if os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1":
-            if not per_iteration_ok:  # the spatial shards partition the batches of a whole call up front
-                raise NotImplementedError("PIN_DRAW_PER_ITERATION=1 (per-iteration batch draws, as a replayed random stream "
-                                          "expects them) is a one-GPU switch: the spatially sharded mapper plans its shards "
-                                          "from the draws of the whole call")
             return None  # the reference's per-iteration torch.randint calls in get_batch (a replayed random stream expects their shapes)
         hist = torch.randint(0, n, (iters, c.bs - bs_new), device=self.device)
         new = torch.randint(0, new_idx.shape[0], (iters, bs_new), device=self.device) if use_new else None
@@ -565,7 +561,11 @@ class Mapper(_Base):
         rank: same generator state), each rank trains on the samples of every batch that lie in its box."""
         c, p = self.config, self._pool()
         t.begin_side_effects()
-        drawn = self._draw_all(iter_count, per_iteration_ok=False)
+        if os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1":  # (it would come back as "nothing drawn": a silent no-op)
+            raise NotImplementedError("PIN_DRAW_PER_ITERATION=1 (per-iteration batch draws, as a replayed random stream expects "
+                                      "them) is a one-GPU switch: the spatially sharded mapper plans its shards from the draws "
+                                      "of the whole call")
+        drawn = self._draw_all(iter_count)
         if drawn is not None:  # (None: an empty pool -- nothing to train on, as on one GPU)
             b = p.bufs[0]
             gc = not self.ba_done_flag
