@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 12
+#define PIN_ABI_VERSION 13
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -112,6 +112,11 @@ typedef struct pin_brick_cache {
                                 cache is built from the POINTS (one table probe per point instead of one per cell of every brick;
                                 same directory contents, masks and entries) -- NULL: the cell-driven build */
     int64_t build_ws_bytes;
+    int32_t build_grid;      /* > 0: at most this many 256-thread blocks per launch of pin_brick_build, each walking its share of
+                                the work (the build is bound by random table probes: a few waves per compute unit keep the memory
+                                system busy and leave the dispatcher's slots to the launches of a stream that runs beside it);
+                                0: one block per unit of work */
+    int32_t pad_;
 } pin_brick_cache;
 
 /* ---- the implicit field: feature tables + decoder (NeuralPoints.query_feature

@@ -19,7 +19,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 12
+PIN_ABI_VERSION = 13
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -40,6 +40,7 @@ class BrickCacheC(C.Structure):
         ("dir_keys", vp), ("dir_vals", vp), ("brick_keys", vp), ("brick_mask", vp), ("brick_base", vp),
         ("entries", vp), ("cand_dx", vp), ("dir_mask", C.c_uint32), ("max_bricks", C.c_int32),
         ("max_entries", C.c_int32), ("n_dilate", C.c_int32), ("dir_pack", vp), ("build_ws", vp), ("build_ws_bytes", C.c_int64),
+        ("build_grid", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

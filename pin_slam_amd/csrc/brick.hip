@@ -25,9 +25,12 @@ namespace pin {
 // ---- build ----------------------------------------------------------------------------------
 // A: every local point registers the (up to 8) bricks that cover its +-n cell neighbourhood.
 // Brick ids are allocated wave-aggregated (one atomic per wave and slot, not per brick).
+// (n_vb, here and in the fill / clear / publish kernels: the number of 256-thread units of work; the grid may be narrower --
+// PIN_BRICK_GRID, pin_brick_build -- and then walks them, so that the build leaves room for the launches of another stream)
 __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin_search_params sp, int n_dilate,
-                                                         int* __restrict__ counters) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+                                                         int* __restrict__ counters, int n_vb) {
+  for (int vb = blockIdx.x; vb < n_vb; vb += gridDim.x) {
+    const int j = vb * 256 + threadIdx.x;
     bool work = j < sp.n_points && !(sp.global2local != nullptr && sp.global2local[j] < 0);
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (work) {
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin
             }
         }
     }
+  }
 }
 
 // B: one lane per cell, one wave per brick at a time; a block (4 waves) takes 32 bricks and
@@ -88,13 +92,14 @@ __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin
 // that alone was 0.7 ms at 74k bricks).
 constexpr int FILL_PER_WAVE = 8;
 __global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin_search_params sp, float prune_dist2,
-                                                        int* __restrict__ counters) {
+                                                        int* __restrict__ counters, int n_vb) {
     __shared__ int wave_tot[4];
     __shared__ int block_base;
     const int nb = min(counters[0], bc.max_bricks);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b0 = (blockIdx.x * 4 + wave) * FILL_PER_WAVE;
     const float d_cur = sp.travel_dist ? sp.travel_dist[sp.cur_ts] : 0.f;
+  for (int vb = blockIdx.x; vb < n_vb && vb * 4 * FILL_PER_WAVE < nb; vb += gridDim.x) {
+    const int b0 = (vb * 4 + wave) * FILL_PER_WAVE;
     float4 P[FILL_PER_WAVE];
     int l[FILL_PER_WAVE];
     unsigned long long mask[FILL_PER_WAVE];
@@ -143,6 +148,8 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(pin_brick_cache bc, pin
         }
         base += __popcll(mask[u]);
     }
+    __syncthreads();  // (wave_tot / block_base are rewritten by the next unit)
+  }
 }
 
 // ---- point-driven build (r04; pin_brick_cache.build_ws != NULL) ---------------------------------------------------------------
@@ -332,8 +339,8 @@ __global__ void brick_zero_masks_kernel(unsigned long long* a, unsigned long lon
 }
 
 __global__ void brick_clear_kernel(unsigned long long* keys, int n, int* counters, float4* entries, int max_entries) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) keys[k] = BRICK_EMPTY;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = BRICK_EMPTY;
     if (i < 4) counters[i] = 0;
     // the sentinel entry behind the last real one: what an empty cell reads in the query kernel (rejected by distance)
     if (i == 0) entries[max_entries] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(-1));
@@ -347,8 +354,7 @@ struct PoseB {
 
 // C: one 32-byte slot per directory entry with everything a query reads (see dir_lookup)
 __global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) {
-    const unsigned int h = blockIdx.x * 256 + threadIdx.x;
-    if (h > bc.dir_mask) return;
+  for (unsigned int h = blockIdx.x * 256 + threadIdx.x; h <= bc.dir_mask; h += gridDim.x * 256) {
     const unsigned long long key = bc.dir_keys[h];
     unsigned long long mask = 0, base = 0xffffffffull;
     if (key != BRICK_EMPTY) {
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void brick_publish_kernel(pin_brick_cache bc) 
     ulonglong2* pack = reinterpret_cast<ulonglong2*>(bc.dir_pack);
     pack[2 * (size_t)h] = make_ulonglong2(key, mask);
     pack[2 * (size_t)h + 1] = make_ulonglong2(base, 0ull);
+  }
 }
 
 // T = tx | ty << 3 | tz << 6 (t = position of a candidate cell inside the query's 2x2x2-brick window, 0..7 per axis)
@@ -924,7 +931,15 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     PIN_CHECK_ARG(bc->n_dilate >= 0 && bc->n_dilate <= 2, "n_dilate must be in [0, 2]");
     hipStream_t s = as_stream(stream);
     const int D = (int)bc->dir_mask + 1;
-    hipLaunchKernelGGL(brick_clear_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s,
+    // bc->build_grid = g > 0: at most g blocks per launch of the build, each walking its share of the work.  The build is
+    // bound by random table / directory probes, not by arithmetic: a few waves per compute unit with eight probes in flight
+    // per lane keep the memory system nearly as busy as 8 700 blocks do, and the dispatcher's slots stay free for the small
+    // launches of the stream that runs beside it (pool filter, certainty query, the mapper's set-up).  0: one block per unit.
+    // (PIN_BRICK_GRID in the environment overrides the field: A/B runs.)
+    static const int grid_env = [] { const char* e = getenv("PIN_BRICK_GRID"); return e ? atoi(e) : -1; }();
+    const int grid_cap = grid_env >= 0 ? grid_env : bc->build_grid;
+    auto grid_of = [grid_cap](int units) { return dim3((unsigned)(grid_cap > 0 ? (units < grid_cap ? units : grid_cap) : units)); };
+    hipLaunchKernelGGL(brick_clear_kernel, grid_of(cdiv(D, 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out,
                        reinterpret_cast<float4*>(bc->entries), bc->max_entries);
     // a probing query sits within (n+1) cells (per axis) of the cell centre and accepts points
@@ -962,12 +977,11 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
         hipLaunchKernelGGL(brick_bases_kernel, dim3(cdiv(bc->max_bricks, 256)), dim3(256), 0, s, *bc, counters_out);
         hipLaunchKernelGGL(brick_point_entries_kernel, dim3(pb), dim3(256), 0, s, *bc, *sp, tmp);
     } else {
-        hipLaunchKernelGGL(brick_mark_kernel, dim3(cdiv(sp->n_points, 256)), dim3(256), 0, s, *bc, *sp, bc->n_dilate,
-                           counters_out);
-        hipLaunchKernelGGL(brick_fill_kernel, dim3(cdiv(bc->max_bricks, 4 * FILL_PER_WAVE)), dim3(256), 0, s, *bc, *sp, prune,
-                           counters_out);
+        const int mark_units = cdiv(sp->n_points, 256), fill_units = cdiv(bc->max_bricks, 4 * FILL_PER_WAVE);
+        hipLaunchKernelGGL(brick_mark_kernel, grid_of(mark_units), dim3(256), 0, s, *bc, *sp, bc->n_dilate, counters_out, mark_units);
+        hipLaunchKernelGGL(brick_fill_kernel, grid_of(fill_units), dim3(256), 0, s, *bc, *sp, prune, counters_out, fill_units);
     }
-    hipLaunchKernelGGL(brick_publish_kernel, dim3(cdiv((long)bc->dir_mask + 1, 256)), dim3(256), 0, s, *bc);
+    hipLaunchKernelGGL(brick_publish_kernel, grid_of(cdiv((long)bc->dir_mask + 1, 256)), dim3(256), 0, s, *bc);
     PIN_CHECK_LAUNCH();
     return 0;
 }

@@ -605,30 +605,59 @@ __device__ __forceinline__ unsigned int spread3(unsigned int v) {  // 10 bits ->
     v = (v | (v << 4)) & 0x030C30C3u;
     return (v | (v << 2)) & 0x09249249u;
 }
+// one word per point: Morton code above, index below -- sorting the words is the stable sort of (code, index) pairs
 __global__ __launch_bounds__(256) void morton_keys_kernel(const float* __restrict__ p, int n, float inv_cell,
-                                                          unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
+                                                          unsigned long long* __restrict__ words) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned int x = ((int)floorf(p[3 * i] * inv_cell) + 512) & 1023;
     const unsigned int y = ((int)floorf(p[3 * i + 1] * inv_cell) + 512) & 1023;
     const unsigned int z = ((int)floorf(p[3 * i + 2] * inv_cell) + 512) & 1023;
-    keys[i] = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
-    vals[i] = (unsigned int)i;
+    const unsigned int key = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+    words[i] = ((unsigned long long)key << 32) | (unsigned long long)(unsigned int)i;
 }
-__global__ __launch_bounds__(256) void permute_points_kernel(const float* __restrict__ p, const unsigned int* __restrict__ perm,
+__global__ __launch_bounds__(256) void permute_points_kernel(const float* __restrict__ p, const unsigned long long* __restrict__ words,
                                                              int n, float* __restrict__ out, int* __restrict__ perm_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const unsigned int j = perm[i];
+    const unsigned int j = (unsigned int)words[i];
     out[3 * i] = p[3 * (size_t)j]; out[3 * i + 1] = p[3 * (size_t)j + 1]; out[3 * i + 2] = p[3 * (size_t)j + 2];
     if (perm_out != nullptr) perm_out[i] = (int)j;
 }
 
+// ---- sort of 64-bit words in few launches (the per-frame sorts: three voxel down-samplings, one Morton order) ----------
+// rocprim::radix_sort_* hands inputs of this size (3e4 .. 3e5 words) to its merge sort with tiles of 512 words: one
+// block-sort launch + log2(n / 512) merge launches, 10-11 dependent launches of ~5 us each whatever they move
+// (profiles/r04_frame_timeline.txt).  The same merge sort with larger tiles (PIN_SORT_BLOCK threads x PIN_SORT_IPT words, sorted
+// in LDS) needs fewer merge launches, but its block sort grows faster than the launches shrink: measured per down-sampling of
+// 1e5 points (scripts/sort_microbench.py, HIP events, same box) 75.4 us with the library's default, 70.1 / 65.3 / 69.8 /
+// 107.9 us with tiles of 1024 / 2048 / 4096 / 8192 words -- 2048 (512 x 4) it is; the Morton order of the registration
+// points (key and index in one word instead of a pairs sort) 56.9 -> 52.4 us.  Outside the profiler a dependent launch
+// costs ~2.5 us, not the ~5 us the kernel trace shows, so the launch chain is a smaller share than the timeline suggests.
+// Words are unique in every use (an index sits in the low bits), so any correct sort gives the same order.
+#ifndef PIN_SORT_BLOCK
+#define PIN_SORT_BLOCK 512
+#endif
+#ifndef PIN_SORT_IPT
+#define PIN_SORT_IPT 4
+#endif
+#ifndef PIN_SORT_ODDEVEN_BLOCK
+#define PIN_SORT_ODDEVEN_BLOCK 512
+#endif
+using SortU64Config = rocprim::merge_sort_config<PIN_SORT_ODDEVEN_BLOCK, PIN_SORT_BLOCK, PIN_SORT_IPT>;
+constexpr int SORT_U64_MAX = 1 << 20;  // above it the radix sort's passes move fewer bytes than the merge passes would
+
+static hipError_t sort_u64(void* temp, size_t& temp_bytes, unsigned long long* in, unsigned long long* out, int n, hipStream_t s) {
+    if (n > SORT_U64_MAX) return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, 64, s);
+    return rocprim::merge_sort<SortU64Config>(temp, temp_bytes, in, out, (size_t)n, rocprim::less<unsigned long long>(), s);
+}
+
 static size_t sort_temp_bytes(int n) {
-    size_t bytes = 0;
+    size_t bytes = 0, b2 = 0;
     unsigned long long* k = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0, 64, hipStream_t(0));
-    return bytes;
+    (void)sort_u64(nullptr, b2, k, k, n, hipStream_t(0));
+    return bytes > b2 ? bytes : b2;
 }
 
 }  // namespace pin
@@ -648,18 +677,15 @@ extern "C" int pin_spatial_sort(const float* points, int32_t n, float cell, floa
     PIN_CHECK_ARG(workspace_bytes >= pin_maint_workspace_bytes(n), "workspace too small");
     hipStream_t s = as_stream(stream);
     Carver c{reinterpret_cast<char*>(workspace), reinterpret_cast<char*>(workspace) + workspace_bytes};
-    unsigned int* keys = c.take<unsigned int>(n);
-    unsigned int* vals = c.take<unsigned int>(n);
-    unsigned int* keys2 = c.take<unsigned int>(n);
-    unsigned int* vals2 = c.take<unsigned int>(n);
-    size_t tb = 0;
-    PIN_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t)n, 0, 30, s));
+    unsigned long long* words = c.take<unsigned long long>(n);
+    unsigned long long* words2 = c.take<unsigned long long>(n);
+    size_t tb = sort_temp_bytes(n);
     void* temp = c.take<char>(tb);
     PIN_CHECK_ARG(temp != nullptr, "workspace carve failed");
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, n, 1.0f / cell, keys, vals);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, n, 1.0f / cell, words);
     PIN_CHECK_LAUNCH();
-    PIN_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (size_t)n, 0, 30, s));
-    hipLaunchKernelGGL(permute_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, vals2, n, out, perm_out);
+    PIN_CHECK_HIP(sort_u64(temp, tb, words, words2, n, s));
+    hipLaunchKernelGGL(permute_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, points, words2, n, out, perm_out);
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -731,7 +757,7 @@ int pin::vds_fast_dev(const float* points, int32_t n, const int32_t* n_dev, floa
     hipLaunchKernelGGL(vds_fast_stats_kernel, dim3(rb), dim3(MB), 0, s, points, n, voxel_size, part, st, n_dev);
     hipLaunchKernelGGL(vds_fast_keys_kernel, dim3(nb), dim3(MB), 0, s, points, n, voxel_size, part, rb, off10, val_bits, comp, st, n_dev);
     PIN_CHECK_LAUNCH();
-    PIN_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, comp, comp2, (size_t)n, 0, 64, s));
+    PIN_CHECK_HIP(sort_u64(temp, tb, comp, comp2, n, s));
     hipLaunchKernelGGL(vds_fast_heads_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off, n_dev);
     hipLaunchKernelGGL(scan_block_counts_kernel, dim3(1), dim3(1024), 0, s, block_off, nb, count_out);
     hipLaunchKernelGGL(vds_fast_emit_kernel, dim3(nb), dim3(MB), 0, s, comp2, n, val_bits, flags, block_off, off10, st, sel_out, count_out);

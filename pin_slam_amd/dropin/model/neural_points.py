@@ -344,10 +344,11 @@ class NeuralPoints(nn.Module):
         if self.config.num_nei_cells > 2 or self._n == 0:
             return
         if getattr(self, "_defer_bricks", False):
-            # Mapper.process_frame queues the build later (build_pending_bricks): its two ~150-200 us launches hold every
-            # compute unit, and a small launch of the caller's stream that arrives meanwhile waits behind them (kernel
-            # trace, r04: the pool filter's 25 us discard kernel took 192 us beside brick_fill) -- so the build goes in
-            # behind the pool filter and the certainty query, where the caller's stream only waits for count read-backs
+            # (PIN_DEFER_BRICKS=1 / 2, the r04 schedule: Mapper.process_frame queues the build behind the pool filter /
+            # behind the certainty query (build_pending_bricks).  At FULL width its two ~150-200 us launches hold every compute
+            # unit, and a small launch of the caller's stream that arrives meanwhile waits behind them -- kernel trace, r04: the
+            # pool filter's 25 us discard kernel took 192 us beside brick_fill.  With the narrow build below that no longer
+            # happens and the build starts as soon as the local map is there.)
             self._bricks_pending = True
             return
         self._build_bricks()
@@ -373,6 +374,13 @@ class NeuralPoints(nn.Module):
             self._side_stream = torch.cuda.Stream(device=self.device)
         side, main = self._side_stream, torch.cuda.current_stream()
         side.wait_stream(main)  # the local map it reads was written on the caller's stream
+        # r05: launches at most 512 blocks wide (pin_brick_cache.build_grid).  The build is bound by its random table probes:
+        # two blocks per compute unit with eight probes in flight per lane are nearly as fast as 8 700 blocks, and the small
+        # launches of the caller's stream find free slots at once -- so the build is queued right here, as soon as the local
+        # map exists, instead of behind the pool filter.  Same box, two runs each (frames/s, map prep ms): full width behind
+        # the filter 174.4 / 0.99; 512 wide, queued here 179.3 / 0.86; 256 wide 173.9 (the mapper waits for the build);
+        # 1024 wide and more, queued here: 167-171 (the small launches wait again).
+        self._brick_cache.build_grid = int(os.environ.get("PIN_BRICK_BUILD_GRID", "512"))
         with torch.cuda.stream(side):
             self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
             self._bricks_event = side.record_event()

@@ -223,7 +223,9 @@ class Mapper(_Base):
         # (the size of the new local map is read back together with the last count of this function)
         defer = c.bs_new_sample > 0 and self.silence
         npts._defer_local_count = defer
-        npts._defer_bricks = os.environ.get("PIN_DEFER_BRICKS", "1") != "0"  # (queued by _process_frame_tail, see NeuralPoints._rebuild_bricks)
+        # (r05: the narrow brick build is queued by update() itself; PIN_DEFER_BRICKS=1 / 2 = r04's schedules, queued by
+        # _process_frame_tail behind the pool filter / the certainty query -- see NeuralPoints._rebuild_bricks)
+        npts._defer_bricks = os.environ.get("PIN_DEFER_BRICKS", "0") != "0"
         try:
             self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
         finally:
@@ -248,7 +250,7 @@ class Mapper(_Base):
         # unhindered, the build takes the device while this stream waits for the filter's counts.  Same box, 2 runs each,
         # map prep + mapping per frame: build queued by update() 2.37-2.39 ms; here 2.28-2.32; behind the certainty query
         # (PIN_DEFER_BRICKS=2) 2.38 -- then Mapper.mapping waits for it)
-        late = os.environ.get("PIN_DEFER_BRICKS", "1") == "2"
+        late = os.environ.get("PIN_DEFER_BRICKS", "0") == "2"
         if filtering:
             self.pool_sample_count, self.cur_sample_count = p.filter_finish(int(c.pool_capacity), kept=kept,
                                                                             before_sync=None if late else npts.build_pending_bricks)

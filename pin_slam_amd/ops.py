@@ -154,6 +154,9 @@ class BrickCache:
         self.by_points = os.environ.get("PIN_BRICK_BUILD", "cells")[:1] == "p"
         self._host = self._event = None
         self._pending = False
+        # > 0: the build's launches are at most this many blocks wide (pin_brick_cache.build_grid): for a build that runs on
+        # a side stream beside other launches (NeuralPoints._build_bricks); 0 = full width, for a build the caller waits for
+        self.build_grid = 0
         self._alloc(1 << 16, 1 << 18)
 
     def _alloc(self, max_bricks, max_entries):
@@ -180,6 +183,7 @@ class BrickCache:
         bc.dir_mask, bc.max_bricks, bc.max_entries, bc.n_dilate = self.dsize - 1, self.max_bricks, self.max_entries, self.n_dilate
         if self.build_ws is not None:
             bc.build_ws, bc.build_ws_bytes = self.build_ws.data_ptr(), self.build_ws.numel()
+        bc.build_grid = int(self.build_grid)
         return bc
 
     def build(self, st: "SearchState", time_filtering=True, local=True, wait: bool = False):
