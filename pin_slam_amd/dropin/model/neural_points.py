@@ -380,7 +380,8 @@ class NeuralPoints(nn.Module):
         # map exists, instead of behind the pool filter.  Same box, two runs each (frames/s, map prep ms): full width behind
         # the filter 174.4 / 0.99; 512 wide, queued here 179.3 / 0.86; 256 wide 173.9 (the mapper waits for the build);
         # 1024 wide and more, queued here: 167-171 (the small launches wait again).
-        self._brick_cache.build_grid = int(os.environ.get("PIN_BRICK_BUILD_GRID", "512"))
+        # (5.3 M points, C5: 1024 wide -- at 512 the mapper waits for the build: mapping 2.0 -> 2.13 ms)
+        self._brick_cache.build_grid = int(os.environ.get("PIN_BRICK_BUILD_GRID", "512" if self._n < 3_000_000 else "1024"))
         with torch.cuda.stream(side):
             self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
             self._bricks_event = side.record_event()

@@ -646,3 +646,86 @@ def test_map_pickles_like_the_reference_saves_it():
     feat1, _, _, nn1, _ = npts2.query_feature(q, training_mode=False, query_locally=False)
     assert torch.equal(nn0, nn1)
     np.testing.assert_allclose(dec2.sdf(feat1).cpu().numpy(), sdf0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def _small_mapper(bs=2048, **kw):
+    """A drop-in Mapper over a small synthetic map with a pool (the set-up of test_grouped_iterations_train_like_single_ones)."""
+    from pin_slam_amd import synth
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.model.neural_points import NeuralPoints
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    rng = np.random.default_rng(3)
+    pts, _ = synth.disc_points(rng, 30_000, 20.0, 2)
+    base, _ = synth.disc_points(rng, 60_000, 19.0, 2)
+    nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
+    dd = 0.15 * rng.standard_normal(len(base))
+    torch.manual_seed(11)
+    cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=bs, local_map_radius=40.0, local_map_travel_dist_ratio=5.0, **kw)
+    npts = NeuralPoints(cfg)
+    npts.travel_dist = torch.zeros(1, device="cuda")
+    npts.update(torch.from_numpy(pts).cuda(), torch.zeros(3), torch.eye(3), 0)
+    dec = Decoder(cfg, 32, 2, 1)
+    mp = Mapper(cfg, _FakeDataset(), npts, {"sdf": dec, "semantic": None, "color": None})
+    mp.global_coord_pool = torch.from_numpy((base + dd[:, None] * nrm).astype(np.float32)).cuda()
+    mp.coord_pool = mp.global_coord_pool
+    mp.sdf_label_pool = torch.from_numpy(dd.astype(np.float32)).cuda()
+    mp.weight_pool = torch.ones(len(base), device="cuda")
+    mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
+    mp.pool_sample_count = len(base)
+    return mp, npts, dec
+
+
+def test_spatial_mapper_refuses_per_iteration_draws(monkeypatch):
+    """PIN_DRAW_PER_ITERATION=1 (a replayed random stream: scripts/e2e_pin_slam.py --replay-draws) makes Mapper._draw_all hand
+    back nothing; the one-GPU path then draws per iteration, the spatially sharded path plans its shards from the draws of
+    the whole call and must say so instead of silently training on nothing."""
+    from pin_slam_amd import collective
+    mp, npts, dec = _small_mapper()
+    mp.dp_comm, mp.dp_rank, mp.dp_world = collective.NullComm(0, 1), 0, 1  # one rank of the spatial mapper, identity exchange
+    before = npts.local_geo_features.data.clone()
+    monkeypatch.setenv("PIN_DRAW_PER_ITERATION", "1")
+    with pytest.raises(NotImplementedError, match="PIN_DRAW_PER_ITERATION"):
+        mp.mapping(3)
+    monkeypatch.delenv("PIN_DRAW_PER_ITERATION")
+    torch.manual_seed(5)
+    mp.mapping(3)  # ... and the same object trains normally afterwards
+    assert not torch.equal(before, npts.local_geo_features.data)
+
+
+def test_an_aborted_call_leaves_no_owed_steps_behind():
+    """A Mapper.mapping that ends between step_batch and finish_optimizer (an exception in the caller's loop) leaves the side
+    stream's hand-over state set; the next call's reset_optimizer must order itself behind that stream and drop the owed
+    steps -- they belong to the optimiser state that is thrown away -- and then train like a call on a fresh trainer."""
+    results = []
+    for abort in (False, True):
+        mp, npts, dec = _small_mapper()
+        t = mp._get_trainer()
+        t.overlap_weight_grad = True  # the weight gradient + decoder step of an iteration on the side stream
+        if abort:
+            calls = {"n": 0}
+            step = t.step_batch
+
+            def failing(*a, **k):
+                step(*a, **k)
+                calls["n"] += 1
+                if calls["n"] == 2:
+                    raise RuntimeError("interrupted")
+            t.step_batch = failing
+            feats0, dec0 = npts.local_geo_features.data.clone(), dec.flat_params().clone()
+            cert0 = npts.local_point_certainties.clone()
+            torch.manual_seed(7)
+            with pytest.raises(RuntimeError, match="interrupted"):
+                mp.mapping(6)
+            assert t._wg_pending  # the hand-over state of the interrupted iteration is still there
+            t.step_batch = step
+            # back to the state the other run starts from (the aborted call has moved features, decoder and certainties)
+            torch.cuda.synchronize()
+            npts.local_geo_features.data.copy_(feats0)
+            dec.flat_params().copy_(dec0)
+            npts.local_point_certainties.copy_(cert0)
+        torch.manual_seed(5)
+        mp.mapping(4)
+        assert not t._wg_pending and t._dp_pending is None
+        results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone()))
+    (fa, da), (fb, db) = results
+    assert (fa - fb).abs().mean().item() < 1e-5 and (da - db).abs().max().item() < 1e-3
