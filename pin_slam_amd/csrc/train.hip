@@ -1555,3 +1555,9 @@ int pin_warm_train() {
     return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&make_queries_kernel)) == hipSuccess ? 0 : -2;
 }
 }  // namespace pin
+
+#ifdef PIN_TF_STAMPS
+extern "C" int pin_debug_tf_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pin::g_tf_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -105,6 +105,13 @@ __device__ __forceinline__ uint2 transpose_block(unsigned int w0, unsigned int w
     return make_uint2(__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi));
 }
 
+#ifdef PIN_TF_STAMPS
+// debug builds (scripts/exp/tf_stamps.py): wall-clock stamps (100 MHz) of the phases of a wave's first tile, one row per block
+__device__ unsigned long long g_tf_stamps[1024 * 16];
+#define TF_STAMP(i) do { if (lane == 0 && wave == (PIN_TF_STAMPS) && !stamped) g_tf_stamps[(blockIdx.x & 1023) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define TF_STAMP(i) do { } while (0)
+#endif
 template <int H, int L, int OD = 1>
 __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, pin_train_params tp,
                                                                   const float* __restrict__ query,
@@ -144,6 +151,10 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
     float* sw = sdz + 16 * 8;
     int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
     double acc_bce = 0.0, acc_eik = 0.0;
+#ifdef PIN_TF_STAMPS
+    bool stamped = false;
+#endif
+    TF_STAMP(0);
     if (want_dec) {  // the slot partials of the weight-gradient launch start from zero (it runs after this kernel)
         const int n = DW_SLOTS * n_dec;
         for (int i = blockIdx.x * TFW_BLOCK + threadIdx.x; i < n; i += gridDim.x * TFW_BLOCK) dw_partial[i] = 0.f;
@@ -209,12 +220,20 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
             const size_t id = nb.idx[t] >= 0 ? (size_t)nb.idx[t] : 0;
             row[t] = reinterpret_cast<const float4*>(f.feats)[id * (PIN_FEATURE_DIM / 4) + (g & 1)];
         }
+        TF_STAMP(1);  // records + rows requested
         if (!staged) {
             __syncthreads();
             staged = true;
             if (!work) break;
         }
-        // training-mode side effects (neural_points.py:685-710)
+        TF_STAMP(2);  // image in LDS
+        // training-mode side effects (neural_points.py:685-710).  (r05, measured and not kept -- phase stamps of a tile at the
+        // reference's batch, scripts/exp/tf_stamps.py: 27 us = 5.2 until the rows are requested + 1.6 image barrier + 8.2 until
+        // the decoder input is there + 2.9 forward + 1.8 head and loss + 3.5 backward + 3.5 scatter.  The 8.2 contain this
+        // block: a wave that wants its rows waits for everything it has issued, these atomics and the look at the time
+        // stamps included.  Moved to the end of the tile the same microseconds are spent waiting there (backward 6.9, scatter
+        // 6.8: 26.5 us a tile); without the look (an atomic maximum per neighbour) the interpolation waits for 16 atomics
+        // instead of ~8: 30.6 us.  The tile is a chain of memory operations at one wave per SIMD wherever they sit.)
         if (g == 3 && active && !is_probe && cert_rw != nullptr) {
             const int my_ts = sample_ts != nullptr ? sample_ts[qi] : 0;
 #pragma unroll
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         };
         v2u_t zh, zl;
         Q::split_input(z, zh, zl);
+        TF_STAMP(3);  // gather arithmetic done (the rows have arrived)
         if (want_dec && work) {
             uint2* __restrict__ A = stream_at(ws.a + G::a_off(n_tiles, 0), tbase);
             A[0] = transpose_block(zh[0], zh[1], ident);
@@ -298,6 +318,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                     for (int r = 0; r < 4; ++r) h[mt][r] = relu1(acc[mt][r]);
             }
         }
+        TF_STAMP(4);  // forward layers
         const float* __restrict__ O = reinterpret_cast<const float*>(lds + Q::off_out(L));
         float dxc[OD];  // d loss / d head c of this column, times dscale
         if constexpr (OD == 1) {
@@ -361,6 +382,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                 dxc[c] = active ? dpred * pc * (1.f - pc) * dscale : 0.f;
             }
         }
+        TF_STAMP(5);  // head + loss
         // ---- backward
         if (want_dec) {  // out layer: delta = d loss / d heads in units 0 .. OD - 1 of a 16-unit block (its input a_L is out already)
             unsigned int dh0, dl0, dh1 = 0u, dl1 = 0u;
@@ -426,6 +448,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                 }
             }
         }
+        TF_STAMP(6);  // backward sweep
         wave_lds_sync();
         {
             // (the lane index goes through an opaque move: what derives from it here is computed here, per tile, instead of
@@ -439,6 +462,10 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
             }
         }
         wave_lds_sync();
+        TF_STAMP(7);  // scatter issued
+#ifdef PIN_TF_STAMPS
+        stamped = true;
+#endif
     }
     // loss values: one pair per block, summed by train_finalize_kernel (no atomics, no clearing launch)
     acc_bce = wave_sum(acc_bce);

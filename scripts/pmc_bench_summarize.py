@@ -1,5 +1,5 @@
-"""gpurun_out/pmc_bench/<workload>/ (scripts/pmc_bench.sh) -> gpurun_out/pmc_bench/r04_pmc_<workload>.json and
-r04_bench_<workload>_kernel_stats.csv (copy both into profiles/).
+"""gpurun_out/pmc_bench/<workload>/ (scripts/pmc_bench.sh) -> gpurun_out/pmc_bench/<round>_pmc_<workload>.json and
+<round>_bench_<workload>_kernel_stats.csv (PIN_ROUND, default r05) (copy both into profiles/).
 
 Per kernel CLASS and launch SHAPE (grid size): mean counter values per launch.  The tracker's launches of a kernel are the
 shape with the most launches (50 per frame); the training launches of the search kernel have other grids.
@@ -7,6 +7,7 @@ HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB -> bytes; the narrow random
 face value (calibration in profiles/r01_pmc.json: FETCH_SIZE ~= TCC_MISS x 64 B for them; only wide streaming reads show
 up halved on gfx950, /opt/skills/guides/MI355X_MICROARCH.md, HBM section -- `fetch_streaming_x2` gives that bound too)."""
 import collections, csv, glob, json, os, shutil, sys
+RND = os.environ.get("PIN_ROUND", "r05")
 
 W = sys.argv[1]
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -94,11 +95,11 @@ for k, shapes in by_class.items():
         e["hbm_bytes_per_launch_if_streaming_x2"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
     out["kernels"][k] = e
 dst = os.path.join(R, "gpurun_out", "pmc_bench")
-json.dump(out, open(os.path.join(dst, f"r04_pmc_{W}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{RND}_pmc_{W}.json"), "w"), indent=1)
 f = glob.glob(os.path.join(O, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    with open(os.path.join(dst, f"r04_bench_{W}_kernel_stats.csv"), "w") as w:
+    with open(os.path.join(dst, f"{RND}_bench_{W}_kernel_stats.csv"), "w") as w:
         wr = csv.writer(w)
         wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:40]:
