@@ -69,13 +69,12 @@ def stamp(label: str) -> None:
 
 
 def trace_summary():
-    """Mean host time (ms) between consecutive stamps, keyed "from -> to", over everything recorded so far."""
+    """Host time (ms) between consecutive stamps, keyed "from -> to", over everything recorded so far: (mean, count, median)."""
     acc: dict = {}
     for (a, ta), (b, tb) in zip(_stamps, _stamps[1:]):
-        k = f"{a} -> {b}"
-        s, n = acc.get(k, (0.0, 0))
-        acc[k] = (s + (tb - ta), n + 1)
-    return {k: (round(1e3 * s / n, 4), n) for k, (s, n) in acc.items()}
+        acc.setdefault(f"{a} -> {b}", []).append(tb - ta)
+    # (mean, count, median: the mean carries the first frames' allocations and the legs with other workloads)
+    return {k: (round(1e3 * sum(v) / len(v), 4), len(v), round(1e3 * sorted(v)[len(v) // 2], 4)) for k, v in acc.items()}
 
 
 def trace_reset():
