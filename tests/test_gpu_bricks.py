@@ -250,3 +250,53 @@ def test_point_driven_build_equals_cell_driven_build(case):
     q = U.dev(d["query"])
     ra, rb = ops.knn_query(st, q, int(d["query_nn_k"]), bricks=a), ops.knn_query(st, q, int(d["query_nn_k"]), bricks=b)
     assert torch.equal(ra[0].view(torch.int32), rb[0].view(torch.int32)) and torch.equal(ra[1], rb[1])
+
+
+@pytest.mark.parametrize("case", ["c2_wf", "c3_bigtable", "bench_map"])
+def test_narrow_build_equals_full_width_build(case):
+    """pin_brick_cache.build_grid (r05): launches of the build at most that many blocks wide, each block walking its share of
+    the points / bricks / directory slots -- the per-frame build beside the caller's small launches.  Whatever the width, the
+    cache holds the same bricks, the same occupancy masks and the same entry per cell, and a search through it returns the
+    same records; `bench_map` = the 2.2 M-point map of the benchmark (8 700 units of work walked by 3 / 64 / 512 blocks)."""
+    from pin_slam_amd import ops
+    from tests import gpu_util as U
+    if case == "bench_map":
+        from pin_slam_amd import synth
+        m = synth.build_map(layers=16)
+        P = len(m.positions)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        pos4 = torch.empty((P, 4), dtype=torch.float32, device="cuda")
+        ops.pack_positions(dev(m.positions), torch.zeros(P, dtype=torch.int32, device="cuda"), pos4)
+        dx, mv = ops.search_neighborhood(2, 0.5, 0.4)
+        g2l = torch.arange(P + 1, dtype=torch.int32, device="cuda")
+        g2l[-1] = -1
+        st = ops.SearchState(table=dev(m.table), pos4=pos4, cand_off=dev(ops.candidate_offsets(dx, m.buffer_size)), n_points=P,
+                             resolution=0.4, max_valid_dist2=mv, travel_dist=torch.zeros(1, device="cuda"), cur_ts=0,
+                             diff_travel_dist_local=410.0, global2local=g2l)
+        n, k = 2, 8
+        q = dev(synth.make_scan(m, n=20_000, seed=5))
+        widths = (3, 512)
+    else:
+        d = G.load(case)
+        st = U.search_state(d)
+        dx, n, k = d["neighbor_dx"], int(d["num_nei_cells"]), int(d["query_nn_k"])
+        q = U.dev(d["query"])
+        widths = (1, 7, 64)
+    full = ops.BrickCache(dx, n)
+    full.build(st, wait=True)
+    assert full.build_grid == 0 and full.n_bricks > 100
+    ref_contents = _cache_contents(full) if case != "bench_map" else None
+    ref = ops.knn_query(st, q, k, bricks=full)
+    for w in widths:
+        nb = ops.BrickCache(dx, n)
+        nb.build_grid = w
+        nb.build(st, wait=True)
+        assert nb.params().build_grid == w
+        assert (nb.n_bricks, nb.n_entries) == (full.n_bricks, full.n_entries), w
+        if ref_contents is not None:
+            got = _cache_contents(nb)
+            assert got.keys() == ref_contents.keys()
+            for key in got:
+                assert got[key] == ref_contents[key], f"width {w}: brick {key:#x} differs"
+        r = ops.knn_query(st, q, k, bricks=nb)
+        assert torch.equal(r[0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(r[1], ref[1]), w
