@@ -54,7 +54,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 13
+#define PIN_ABI_VERSION 14
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -156,6 +156,8 @@ typedef struct pin_gn_params {
     float max_sdf_std;       /* surface_sample_range_m * max_sdf_std_ratio */
     float gm_dist;           /* reg_GM_dist_m, <=0 disables */
     float gm_grad;           /* reg_GM_grad, <=0 disables */
+    int32_t dist_div_grad_norm; /* reg_dist_div_grad_norm (utils/tracker.py:452-456): the residual uses sdf / |grad|
+                                (the Jacobian rows and the Geman-McClure gradient weight keep the plain values) */
 } pin_gn_params;
 /* optional colour term of the registration (utils/tracker.py:493-542, 699-744) */
 typedef struct pin_color_term {
@@ -184,6 +186,7 @@ typedef struct pin_color_term {
 #define PIN_GN_STATE_MSE 23
 #define PIN_GN_STATE_NRAW 24
 #define PIN_GN_STATE_NSRC 60
+#define PIN_GN_STATE_STATUS 61   /* the library's sticky status flags (pin_status) as the solve kernel last saw them */
 
 typedef struct pin_gn_loop_params {      /* Tracker.tracking constants (tracker.py:77-101) */
     double lm_lambda;                    /* reg_lm_lambda */
@@ -313,6 +316,12 @@ int         pin_version(void);
  * unit's kernels -- a 100 ms frame the first time a stage of the SLAM loop runs).  Needs a current device; no kernel runs. */
 int         pin_warmup(void);
 const char* pin_last_error(void);
+/* Sticky status flags the kernels raise on the device (one word per device).  pin_status copies the word to *flags_out
+ * (host), optionally clears it, and synchronises `stream`.  The registration loop carries the same word in its state
+ * read-back (PIN_GN_STATE_STATUS), so Tracker.tracking hears about a flag without an extra read-back. */
+#define PIN_STATUS_FP16_RANGE 1  /* pin_stage_decoder met a decoder parameter of magnitude >= 65504 or a non-finite one: the
+                                  * split-fp16 image cannot hold it (mlp_h2.h); PIN_MLP=f32 selects the fp32 image */
+int         pin_status(int32_t* flags_out, int32_t clear, void* stream);
 
 /* host helper: cand_off_host[c] = (dx.primes) mod buffer_size, primes = (73856093,
  * 19349669, 83492791) (neural_points.py:82-84).  neighbor_dx_host is [n_cand][3]. */

@@ -354,7 +354,7 @@ def expmap(t):
 def registration_step(points, sdf, grad, std, nn_count, *, valid_nn_k, min_grad_norm=0.5,
                       max_grad_norm=2.0, max_sdf_std=0.25, GM_dist=0.3, GM_grad=0.1,
                       lm_lambda=1e-4, sdf_labels=None, colors=None, color_pred=None, color_grad=None,
-                      photo_loss=False, photo_weight=0.01, consist_weight=True):
+                      photo_loss=False, photo_weight=0.01, consist_weight=True, dist_div_grad_norm=False):
     """Tracker.registration_step + implicit_reg (utils/tracker.py:409-524, 615-695),
     geometric term only.  Returns dict(T [4,4] f64, valid_count, residual_cm, N, g)."""
     points = np.asarray(points, np.float64)
@@ -366,6 +366,8 @@ def registration_step(points, sdf, grad, std, nn_count, *, valid_nn_k, min_grad_
     if n < 10:  # tracker.py:430-432
         return dict(T=np.eye(4), valid_count=n, residual_cm=0.0, valid=valid)
     p, g, r, gnv = points[valid], grad[valid], sdf[valid], gn[valid]
+    if dist_div_grad_norm:  # reg_dist_div_grad_norm, tracker.py:452-456 (the Jacobian keeps the plain gradient)
+        r = r / gnv
     if sdf_labels is not None:
         r = r - np.asarray(sdf_labels, np.float64)[valid]
     w = np.ones(n)

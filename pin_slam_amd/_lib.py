@@ -19,7 +19,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 13
+PIN_ABI_VERSION = 14
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -65,6 +65,7 @@ class GnParams(C.Structure):
     _fields_ = [
         ("valid_nn_k", C.c_int32), ("min_grad_norm", C.c_float), ("max_grad_norm", C.c_float),
         ("max_sdf_std", C.c_float), ("gm_dist", C.c_float), ("gm_grad", C.c_float),
+        ("dist_div_grad_norm", C.c_int32),
     ]
 
 
@@ -77,6 +78,8 @@ class GnLoopParams(C.Structure):
 
 
 PIN_GN_STATE_DOUBLES = 64
+PIN_GN_STATE_STATUS = 61
+PIN_STATUS_FP16_RANGE = 1
 
 
 class MapArrays(C.Structure):
@@ -161,6 +164,7 @@ SIGNATURES = {
     "pin_version": (i32, []),
     "pin_warmup": (i32, []),
     "pin_last_error": (C.c_char_p, []),
+    "pin_status": (i32, [vp, i32, vp]),
     "pin_candidate_offsets": (i32, [vp, i32, i64, vp]),
     "pin_pack_positions": (i32, [vp, vp, i32, i32, vp, vp]),
     "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),

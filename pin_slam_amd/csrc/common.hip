@@ -13,6 +13,22 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// Sticky status flags on the device (PIN_STATUS_*): one word per device, allocated on first use and never freed.  Kernels that
+// detect a condition the host must hear about OR a bit in; the registration loop's solve kernel copies the word into its
+// state read-back (PIN_GN_STATE_STATUS), pin_status reads it synchronously.
+int* status_word() {
+    static int* words[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (words[dev] == nullptr) {
+        int* p = nullptr;
+        if (hipMalloc(&p, sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, sizeof(int)) != hipSuccess) return nullptr;
+        words[dev] = p;
+    }
+    return words[dev];
+}
 }  // namespace pin
 
 namespace pin {
@@ -28,6 +44,18 @@ extern "C" int pin_warmup(void) {
                              pin::pin_warm_maint, pin::pin_warm_dp, pin::pin_warm_sdf, pin::pin_warm_brick};
     for (auto f : warm)
         if (f() != 0) return pin::fail(-2, "pin_warmup: a code object could not be loaded: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int pin_status(int32_t* flags_out, int32_t clear, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(flags_out, "NULL pointer");
+    int* w = pin::status_word();
+    if (w == nullptr) return pin::fail(-2, "pin_status: no status word on this device");
+    hipStream_t s = pin::as_stream(stream);
+    PIN_CHECK_HIP(hipMemcpyAsync(flags_out, w, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) PIN_CHECK_HIP(hipMemsetAsync(w, 0, sizeof(int), s));
+    PIN_CHECK_HIP(hipStreamSynchronize(s));
     return 0;
 }
 

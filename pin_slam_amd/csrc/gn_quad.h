@@ -283,7 +283,7 @@ __device__ __forceinline__ void quad_finish(const pin_field& f, const pin_gn_par
         const float gn = sqrtf(gx * gx + gy * gy + gz * gz);
         const bool valid = nn >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm && 0.f < gp.max_sdf_std;
         if (valid) {
-            const float res = sdf - (labels ? labels[qi] : 0.f);
+            const float res = (gp.dist_div_grad_norm ? sdf / gn : sdf) - (labels ? labels[qi] : 0.f);
             float wgt = 1.f;
             if (gp.gm_grad > 0.f) { const float d = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + d * d); wgt *= t * t; }
             if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); wgt *= t * t; }
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
             const float gn = sqrtf(gx * gx + gy * gy + gz * gz);
             const bool valid = nn >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm && sd < gp.max_sdf_std;
             if (valid) {
-                const float res = mean - (labels ? labels[qi] : 0.f);
+                const float res = (gp.dist_div_grad_norm ? mean / gn : mean) - (labels ? labels[qi] : 0.f);
                 float wgt = 1.f;
                 if (gp.gm_grad > 0.f) { const float d = gn - 1.f; const float tt = gp.gm_grad / (gp.gm_grad + d * d); wgt *= tt * tt; }
                 if (gp.gm_dist > 0.f) { const float tt = gp.gm_dist / (gp.gm_dist + res * res); wgt *= tt * tt; }

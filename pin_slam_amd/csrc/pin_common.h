@@ -35,6 +35,8 @@ int fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return ::pin::fail(-2, "%s: %s", __func__, hipGetErrorString(e_)); \
     } while (0)
 
+int* status_word();  // (common.hip) device word of sticky PIN_STATUS_* flags, nullptr if it could not be allocated
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

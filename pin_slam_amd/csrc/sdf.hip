@@ -346,7 +346,7 @@ __global__ __launch_bounds__(MF_BLOCK, 1) void gn_accumulate_mfma_kernel(pin_fie
         const bool valid = nn_count[qi] >= gp.valid_nn_k && gn < gp.max_grad_norm && gn > gp.min_grad_norm &&
                            r.std < gp.max_sdf_std;
         if (valid) {
-            const float res = r.sdf - (labels ? labels[qi] : 0.f);
+            const float res = (gp.dist_div_grad_norm ? r.sdf / gn : r.sdf) - (labels ? labels[qi] : 0.f);
             float w = 1.f;
             if (gp.gm_grad > 0.f) { const float a = gn - 1.f; const float t = gp.gm_grad / (gp.gm_grad + a * a); w *= t * t; }
             if (gp.gm_dist > 0.f) { const float t = gp.gm_dist / (gp.gm_dist + res * res); w *= t * t; }
@@ -410,7 +410,7 @@ namespace pin {
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
 // implicit_reg (utils/tracker.py:656-679) and the bookkeeping of Tracker.tracking (:147-184).
 __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums, double* __restrict__ st,
-                                                      pin_gn_loop_params lp) {
+                                                      pin_gn_loop_params lp, const int* __restrict__ status) {
     __shared__ double s[PIN_GN_NSUMS];
     const int lane = threadIdx.x;
     // this kernel is a chain of memory round trips around ~1 us of arithmetic: everything it reads is requested up
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums,
     __syncthreads();
     for (int i = lane; i < GN_REPLICAS * PIN_GN_NSUMS; i += 64) sums[i] = 0.0;  // ready for the next iteration
     if (lane != 0) return;
+    if (status != nullptr) st[PIN_GN_STATE_STATUS] = (double)*status;  // (sticky flags of the library, e.g. a decoder outside the fp16 range)
     const double cnt = rint(s[29]);
     double dT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     double res_cm = 0.0;
@@ -1007,8 +1008,17 @@ extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32
 
 // ---- decoder image for the GN tile kernel (pin_field.dec_image) ------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(GQ_BLOCK) void stage_decoder_kernel(pin_field f, unsigned char* __restrict__ out) {
-    QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK, f.out_dim > 1 ? f.out_dim : 1);  // (1 or 3 heads)
+__global__ __launch_bounds__(GQ_BLOCK) void stage_decoder_kernel(pin_field f, unsigned char* __restrict__ out, int* __restrict__ status) {
+    const int od = f.out_dim > 1 ? f.out_dim : 1;
+    QuadDecoderH<H>::stage(f.dec, f.levels, out, threadIdx.x, GQ_BLOCK, od);  // (1 or 3 heads)
+    // Range guard of the split-fp16 image (mlp_h2.h "Range"): a parameter of magnitude >= 65504 (or a non-finite one) has no
+    // fp16 high piece -- the tile kernels would turn it into inf / NaN outputs.  The host hears about it through the sticky
+    // status word (pin_status, PIN_GN_STATE_STATUS) and raises; PIN_MLP=f32 selects the fp32 image for such a decoder.
+    if (status == nullptr) return;
+    const int n_dec = H * MLP_IN + H + (f.levels - 1) * (H * H + H) + od * H + od;
+    int bad = 0;
+    for (int i = threadIdx.x; i < n_dec; i += GQ_BLOCK) bad |= !(fabsf(f.dec[i]) < 65504.f);
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(status, PIN_STATUS_FP16_RANGE);
 }
 
 extern "C" int64_t pin_decoder_image_bytes(int32_t hidden, int32_t levels) {
@@ -1028,8 +1038,8 @@ extern "C" int pin_stage_decoder(const pin_field* f, void* image_out, int64_t im
     g.dec_image = nullptr;
     g.dec_image_bytes = 0;
     unsigned char* out = reinterpret_cast<unsigned char*>(image_out);
-    if (f->hidden == 64) hipLaunchKernelGGL(stage_decoder_kernel<64>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out);
-    else hipLaunchKernelGGL(stage_decoder_kernel<32>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out);
+    if (f->hidden == 64) hipLaunchKernelGGL(stage_decoder_kernel<64>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out, status_word());
+    else hipLaunchKernelGGL(stage_decoder_kernel<32>, dim3(1), dim3(GQ_BLOCK), 0, as_stream(stream), g, out, status_word());
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -1058,7 +1068,7 @@ extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp
 extern "C" int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(sums && state && lp, "NULL pointer");
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp);
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp, (const int*)status_word());
     PIN_CHECK_LAUNCH();
     return 0;
 }

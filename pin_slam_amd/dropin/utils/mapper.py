@@ -1,14 +1,12 @@
 """Drop-in for the reference's ``utils.mapper.Mapper`` (utils/mapper.py:33).
 
-``mapping`` (the online-training hot loop, mapper.py:600-844) and ``sdf`` run on the fused HIP
-kernels.  When the reference tree is on the ``utils`` package path (drop-in mode, see
-pin_slam_amd.dropin.install) this class *inherits* the reference's Mapper, so the data-pool
-management around the hot loop (process_frame, pool filtering, ... -- SURVEY 8f "next" rows)
-keeps running from the reference's own code, unchanged; stand-alone it provides the minimal
-pool surface the hot loop needs."""
+``mapping`` (the online-training hot loop, mapper.py:600-844), ``process_frame`` (mapper.py:162-449), ``get_batch``,
+``sdf`` and the pool maintenance run on the HIP kernels.  The class does NOT inherit the reference's Mapper (until round 5 it
+did when the reference tree was importable, which made drop-in mode run the reference's ``determine_used_pose`` / ``init_pool``
+/ ``free_pool`` while the tests and the bench ran the re-implementations below): ONE code path, the tested one, whatever is
+importable.  Every public method of the reference class exists here with the reference's signature."""
 from __future__ import annotations
 
-import importlib.util
 import math
 import os
 import sys
@@ -19,19 +17,6 @@ import numpy as np
 
 from ... import _lib, engine, hostcache, ops
 from ... import pool as pool_mod
-
-
-def _reference_mapper_base():
-    """The reference's Mapper class if its source is reachable through ``utils.__path__``."""
-    utils_pkg = sys.modules.get("utils")
-    for p in list(getattr(utils_pkg, "__path__", []))[1:]:
-        f = os.path.join(p, "mapper.py")
-        if os.path.exists(f):
-            spec = importlib.util.spec_from_file_location("pin_reference_utils_mapper", f)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            return mod.Mapper
-    return None
 
 
 class _StandaloneBase:
@@ -66,14 +51,44 @@ class _StandaloneBase:
         self.pool_sample_count = 0
 
     def free_pool(self):
+        """mapper.py:589-597."""
         self.coord_pool = self.weight_pool = self.sdf_label_pool = self.time_pool = None
+        self.sem_label_pool = self.color_pool = self.normal_label_pool = None
 
     def determine_used_pose(self):
-        """mapper.py:139-160."""
+        """mapper.py:139-160: the poses the pool samples are expressed with -- pose-graph, odometry or ground truth."""
         ds, c = self.dataset, self.config
         cur = ds.processed_frame
-        src = ds.pgo_poses if c.pgo_on else (ds.odom_poses if c.track_on else ds.gt_poses)
+        if c.pgo_on:
+            src = ds.pgo_poses
+        elif c.track_on:
+            src = ds.odom_poses
+        elif getattr(ds, "gt_pose_provided", False):
+            src = ds.gt_poses
+        else:
+            return
         self.used_poses = torch.tensor(np.asarray(src[:cur + 1]), device=self.device, dtype=torch.float64)
+
+    def get_ba_samples(self, subsample_count):
+        """mapper.py:506-524 feeds bundle_adjustment only, which is refused (see Mapper.bundle_adjustment)."""
+        raise NotImplementedError("Mapper.get_ba_samples belongs to the bundle adjustment, which is outside libpinhip's hot path: "
+                                  "run with ba_freq_frame: 0")
+
+    def get_data_pool_o3d(self, down_rate=1, only_cur_data=False):
+        """mapper.py:534-587 (visualisation of the sample pool, GUI / --visualize runs only): an open3d point cloud of the pool's
+        global coordinates coloured by the SDF label (seismic colour map, blue = in front, red = behind)."""
+        import open3d as o3d
+        from matplotlib import cm
+        sl = slice(-self.cur_sample_count, None, 3) if only_cur_data else slice(None, None, down_rate)
+        pc = o3d.geometry.PointCloud()
+        pc.points = o3d.utility.Vector3dVector(self.global_coord_pool[sl].detach().cpu().numpy().astype(np.float64))
+        if self.sdf_label_pool is None:
+            return pc
+        lab = self.sdf_label_pool[sl].detach().cpu().numpy().astype(np.float64)
+        lo = self.config.free_sample_end_dist_m * -2.0
+        lab = np.clip((lab - lo) / (-2.0 * lo), 0.0, 1.0)
+        pc.colors = o3d.utility.Vector3dVector(cm.get_cmap("seismic")(1.0 - lab)[:, :3].astype(np.float64))
+        return pc
 
     def get_batch(self, global_coord=False):
         """Uniform pool sampling (mapper.py:477-503; the 'new sample' half needs process_frame)."""
@@ -83,13 +98,15 @@ class _StandaloneBase:
         return coord, self.sdf_label_pool[index], self.time_pool[index], None, None, color, self.weight_pool[index]
 
 
-_Base = _reference_mapper_base() or _StandaloneBase
-
-
-class Mapper(_Base):
+class Mapper(_StandaloneBase):
     def __init__(self, config, dataset, neural_points, decoders: dict):
         super().__init__(config, dataset, neural_points, decoders)
         self._trainer = None
+        # "identical inputs" mode: draw the batch indices inside get_batch, two torch.randint calls per ITERATION, exactly as the
+        # reference consumes the generator (mapper.py:462-480).  Off by default: mapping() draws the indices of all its
+        # iterations in two launches (iid uniform either way, but a seeded run then does not reproduce the reference's stream).
+        # Set it here, as `config.draw_per_iteration`, or through PIN_DRAW_PER_ITERATION=1; INTEGRATION.md "Random numbers".
+        self.draw_per_iteration = bool(getattr(config, "draw_per_iteration", False))
         self._spool = None  # device-resident sample pool (pin_slam_amd.pool.SamplePool)
         # data-parallel mapping: config.bs is the GLOBAL batch, every rank draws the same
         # batch (same seed) and trains on its contiguous shard; set by the launcher, 1 rank by default
@@ -417,6 +434,9 @@ class Mapper(_Base):
                 a, b = j * buf.Q + buf.n_main, (j + 1) * buf.Q
                 ops.knn_query(t.st, buf.query_all[a:b], k, out=(buf.nbr_all[a:b], buf.nn_all[a:b], None), bricks=t.bricks)
 
+    def _draws_per_iteration(self) -> bool:
+        return bool(self.draw_per_iteration) or os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1"
+
     def _draw_all(self, iters):
         """The batch indices of `iters` get_batch calls in two torch.randint launches instead of 2 x iters (the
         reference draws per iteration, mapper.py:462-480; the draws are iid uniform either way)."""
@@ -426,8 +446,8 @@ class Mapper(_Base):
         bs_new = min(new_idx.shape[0], c.bs_new_sample) if use_new else 0
         if n <= 0 or iters <= 0:
             return None
-        if os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1":
-            return None  # the reference's per-iteration torch.randint calls in get_batch (a replayed random stream expects their shapes)
+        if self._draws_per_iteration():
+            return None  # the reference's per-iteration torch.randint calls in get_batch (a replayed / seeded random stream expects them)
         hist = torch.randint(0, n, (iters, c.bs - bs_new), device=self.device)
         new = torch.randint(0, new_idx.shape[0], (iters, bs_new), device=self.device) if use_new else None
         return dict(key=(n, c.bs - bs_new, bs_new, 0 if not use_new else new_idx.shape[0]), hist=hist, new=new, next=0)
@@ -563,8 +583,8 @@ class Mapper(_Base):
         rank: same generator state), each rank trains on the samples of every batch that lie in its box."""
         c, p = self.config, self._pool()
         t.begin_side_effects()
-        if os.environ.get("PIN_DRAW_PER_ITERATION", "0") == "1":  # (it would come back as "nothing drawn": a silent no-op)
-            raise NotImplementedError("PIN_DRAW_PER_ITERATION=1 (per-iteration batch draws, as a replayed random stream expects "
+        if self._draws_per_iteration():  # (it would come back as "nothing drawn": a silent no-op)
+            raise NotImplementedError("draw_per_iteration / PIN_DRAW_PER_ITERATION=1 (per-iteration batch draws, as a replayed random stream expects "
                                       "them) is a one-GPU switch: the spatially sharded mapper plans its shards from the draws "
                                       "of the whole call")
         drawn = self._draw_all(iter_count)
@@ -594,6 +614,20 @@ class Mapper(_Base):
         fs = npts.field_state(self.sdf_mlp, query_locally=True)
         sdf, _, std, _ = ops.sdf_query(fs, q, nbr, nn, grad=False, certainty=False)
         return sdf, (std if (get_std and not self.config.weighted_first) else None), nn >= min_nn_count
+
+    def get_numerical_gradient(self, x, sdf_x=None, eps=0.02, two_side=True):
+        """mapper.py:986-1036 as a stand-alone call (inside `mapping` the six probes are generated by the gather launch and
+        differenced in the training tile): central differences of the SDF, or one-sided ones against `sdf_x`."""
+        x = x.detach().to(torch.float32)
+        n = x.shape[0]
+        e = torch.eye(3, dtype=torch.float32, device=x.device) * float(eps)
+        if two_side:
+            q = torch.cat([x + e[0], x - e[0], x + e[1], x - e[1], x + e[2], x - e[2]], 0)
+            s = self.sdf(q)[0].reshape(6, n)
+            return torch.stack([s[0] - s[1], s[2] - s[3], s[4] - s[5]], 1) / (2.0 * float(eps))
+        q = torch.cat([x + e[0], x + e[1], x + e[2]], 0)
+        s = self.sdf(q)[0].reshape(3, n)
+        return (s - sdf_x.detach().reshape(1, n)).t().contiguous() / float(eps)
 
     def sdf_batch(self, x, bs, get_std=False, min_nn_count=1, accumulate_stability=False):
         outs = [self.sdf(x[i:i + bs], get_std, min_nn_count, accumulate_stability) for i in range(0, x.shape[0], bs)]

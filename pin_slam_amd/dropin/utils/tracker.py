@@ -38,6 +38,7 @@ class Tracker:
         gp.max_sdf_std = float(c.surface_sample_range_m * c.max_sdf_std_ratio)
         gp.gm_dist = float(GM_dist) if GM_dist else 0.0
         gp.gm_grad = float(GM_grad) if GM_grad else 0.0
+        gp.dist_div_grad_norm = int(bool(getattr(c, "reg_dist_div_grad_norm", False)))  # tracker.py:452-456
         return gp
 
     def _engine(self, n, gp, lm_lambda) -> engine.GNTracker:

@@ -66,7 +66,11 @@ class GNTracker:
         ops.gn_accumulate(self.fs, self.gp, cur, out[0], out[1], sdf_labels=labels, sums=self.sums, color=color)
         self.sums_host.copy_(self.sums, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return ops.solve_gn(self.sums_host.numpy(), self.lm_lambda)
+        sums = self.sums_host.numpy()
+        if not np.isfinite(sums).all():  # (the host-driven step has no state read-back: ask for the status word only when the sums are bad)
+            ops.raise_on_status(ops.status())
+            raise RuntimeError("registration_step: non-finite normal-equation sums (non-finite source points, map or decoder)")
+        return ops.solve_gn(sums, self.lm_lambda)
 
     def track(self, src: torch.Tensor, T_init: np.ndarray, iters: int, term_deg: float = 0.01,
               term_m: float = 0.001, early_exit: bool = True, min_valid_ratio: float = 0.2,
@@ -169,6 +173,11 @@ class GNTracker:
         self.state_host.copy_(self.state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         s = self.state_host.numpy()
+        if s[_lib.PIN_GN_STATE_STATUS] != 0.0:  # sticky device flags the solve kernel copied into the read-back (pin_status)
+            ops.raise_on_status(int(s[_lib.PIN_GN_STATE_STATUS]))
+        if not np.isfinite(s[:18]).all():
+            raise RuntimeError("Tracker.tracking: non-finite pose / residual in the registration state (non-finite source points, "
+                               "map or decoder outputs)")
         T = s[:16].reshape(4, 4).copy()
         extra = dict(N_raw=s[24:60].reshape(6, 6).copy(), mse=float(s[23]), converged=bool(s[20]))
         return T, int(s[18]), float(s[17]), int(s[22]), bool(s[19]), extra

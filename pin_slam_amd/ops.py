@@ -47,6 +47,25 @@ def warmup():
     _warmed = True
 
 
+FP16_RANGE_MESSAGE = ("a decoder parameter is outside the range of the split-fp16 decoder image (|w| >= 65504 or non-finite, "
+                      "csrc/mlp_h2.h): the tile kernels would return inf / NaN.  Set PIN_MLP=f32 to run this decoder on the fp32 image")
+
+
+def status(clear: bool = False) -> int:
+    """The library's sticky device status flags (pin_status; PIN_STATUS_*).  Synchronises the current stream."""
+    out = C.c_int32(0)
+    check(_lib.lib().pin_status(C.addressof(out), int(bool(clear)), _stream()), "pin_status")
+    return int(out.value)
+
+
+def raise_on_status(flags: int):
+    """Turn a status word (pin_status / PIN_GN_STATE_STATUS) into an exception; clears the device word so that a caller that
+    handles the error (e.g. by switching to PIN_MLP=f32 and restaging) is not stopped again by the old flag."""
+    if flags & _lib.PIN_STATUS_FP16_RANGE:
+        status(clear=True)
+        raise RuntimeError(FP16_RANGE_MESSAGE)
+
+
 def _stream():
     """Raw handle of torch's current stream ON THE CURRENT DEVICE.  (torch.cuda.current_stream() builds a Stream object
     through several Python layers, ~5 us a call -- four calls per training iteration; the two raw getters are what it ends

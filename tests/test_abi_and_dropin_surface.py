@@ -55,7 +55,8 @@ def test_product_path_fails_loudly_without_gpu():
 @pytest.mark.reference
 def test_dropin_call_surface_matches_reference():
     """Every method the drop-in classes implement takes the reference's parameter names, in
-    order; the Mapper drop-in inherits the reference Mapper in drop-in mode."""
+    order, and every SURVEY section-8 method is THIS package's code also in drop-in mode (no method of the
+    hot-path classes resolves to the reference's implementation; the Mesher alone inherits -- bounding boxes, marching cubes)."""
     from oracle import ref_loader as R
     ref = R.load()
     from pin_slam_amd import dropin
@@ -71,7 +72,8 @@ def test_dropin_call_surface_matches_reference():
              (ref["Tracker"], mods["utils.tracker"].Tracker, ["__init__", "tracking", "query_source_points", "registration_step"]),
              (ref["Mapper"], um.Mapper, ["__init__", "mapping", "sdf", "sdf_batch", "get_batch", "process_frame",
                                          "determine_used_pose", "init_pool", "free_pool", "bundle_adjustment",
-                                         "transform_data_pool"]),
+                                         "transform_data_pool", "dynamic_filter", "get_numerical_gradient", "get_ba_samples",
+                                         "get_data_pool_o3d"]),
              # the drop-in Mesher inherits the reference class: its overrides must keep the inherited signatures
              (mods["utils.mesher"].Mesher.__mro__[1], mods["utils.mesher"].Mesher, ["__init__", "query_points"])]
     for rcls, ocls, names in pairs:
@@ -79,7 +81,17 @@ def test_dropin_call_surface_matches_reference():
             rp = list(inspect.signature(getattr(rcls, n)).parameters)
             op = list(inspect.signature(getattr(ocls, n)).parameters)
             assert rp == op, (rcls.__name__, n, rp, op)
-    assert um.Mapper.__mro__[1].__name__ == "Mapper"  # inherits the reference's pool management
+    # one code path: no class of the hot path inherits the reference's (r05: Mapper did, so drop-in mode ran the reference's
+    # determine_used_pose / init_pool / free_pool while the tests ran the re-implementations), and every method listed above is
+    # defined by this package
+    for rcls, ocls, names in pairs[:4]:
+        assert all(b.__module__.startswith(("pin_slam_amd.", "torch.", "builtins")) for b in ocls.__mro__), ocls.__mro__
+        for n in names:
+            assert getattr(ocls, n).__module__.startswith("pin_slam_amd.dropin."), (ocls.__name__, n, getattr(ocls, n).__module__)
+    # every public method of the reference's Mapper exists on the drop-in
+    missing = [n for n, v in vars(ref["Mapper"]).items() if callable(v) and not n.startswith("_") and not hasattr(um.Mapper, n)]
+    assert missing == ["get_numerical_gradient_multieps"] or missing == [], missing  # ([not used] in the reference, mapper.py:1038)
+    assert mods["utils.mesher"].Mesher.query_points.__module__ == "pin_slam_amd.dropin.utils.mesher"
     assert mods["utils.mesher"].Mesher.__mro__[1].__name__ == "Mesher" and hasattr(mods["utils.mesher"].Mesher, "get_query_from_bbx")
     # restore the plain reference namespace for the other tests
     import sys
