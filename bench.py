@@ -109,12 +109,19 @@ def parse():
     ap.add_argument("--dp-mode", default="spatial", choices=["spatial", "dense"],
                     help="how the mapper batch is cut over the ranks: spatial = k-d boxes of the voxel grid, halo-row exchange "
                          "(pin_slam_amd.dp); dense = contiguous index shards, all-reduce of the whole gradient table")
-    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "torch", "host"],
-                    help="rccl = the product transport (one rank per GPU; RCCL through the C ABI, self-tested at start-up -- if any "
-                         "rank fails the test all ranks use torch.distributed's communicator instead and the line says so).  "
+    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "auto", "torch", "host"],
+                    help="rccl = the product transport (one rank per GPU; RCCL through the C ABI, self-tested at start-up): if ANY "
+                         "rank fails to bring it up every rank exits with status 3 -- this command never times another transport "
+                         "in its place.  auto = rccl, and if it fails all ranks use torch.distributed's communicator together "
+                         "(the line's allreduce.transport says so).  "
                          "torch = torch.distributed's RCCL communicator.  host = TEST mode for a single-GPU box: the ranks share "
                          "cuda:0 and exchange through pinned host buffers over gloo (collective.HostStagedComm) -- the N > 1 code "
                          "path end to end, not a measurement")
+    ap.add_argument("--metric", default="frames", choices=["frames", "mapper"],
+                    help="N = 1 only: frames (default) = slam_frames_per_sec, the headline; mapper = the N = 1 point of the `--gpus N` "
+                         "curve: mapper_samples_per_sec of Mapper.mapping at --global-bs on this one GPU, the same line format, "
+                         "metric, step definition and flags as N > 1 (README: `--gpus 1 --metric mapper`, `--gpus 2`, `--gpus 4`, "
+                         "`--gpus 8` form one strong-scaling curve)")
     ap.add_argument("--dp-emulate", default="2,4,8", help="N = 1: world sizes whose single ranks are run alone on this GPU "
                                                           "(c4_per_rank_emulated; empty = skip)")
     ap.add_argument("--emulate-rank", default="", help="W:r -- profiling aid: ONLY rank r of a W-rank data-parallel mapper, alone on "
@@ -182,6 +189,25 @@ def launch_ranks(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.run(cmd, env=env).returncode
+
+
+def bring_up_transport(args, rank, world, device="cuda"):
+    """The data-parallel mapper's transport as --dp-transport asks for it.  rccl is STRICT: a failure on any rank ends every
+    rank with exit status 3 and a JSON error on stderr -- the N > 1 line of this command is never a measurement of another
+    transport (a SCALE run on torch.distributed would still have "passed")."""
+    from pin_slam_amd import collective
+    strict = args.dp_transport == "rccl"
+    try:
+        return collective.make_comm(rank, world, "rccl" if args.dp_transport == "auto" else args.dp_transport, device=device,
+                                    fallback=not strict)
+    except collective.TransportError as e:
+        if rank == 0:
+            print(json.dumps({"error": "dp transport", "requested": args.dp_transport, "n_gpus": world, "detail": str(e)}),
+                  file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        if getattr(e, "abandoned_thread", False):
+            os._exit(3)
+        raise SystemExit(3)
 
 
 def dry_launch(rank, world):
@@ -301,6 +327,12 @@ def main():
                           "ms_per_iteration": round(1e3 * dt / (args.steps * args.map_iters), 4),
                           "shards": getattr(mp, "dp_stats", None)}), flush=True)
         return
+    if args.metric == "mapper" and world == 1 and not mapper_dp:
+        # the N = 1 point of the `--gpus N` curve: the same metric, step and line format as bench_dp_mapper
+        for _ in range(max(1, args.pretrain_iters // 50)):
+            mp.mapping(10)
+        print(json.dumps(bench_single_gpu_mapper(args, cfg, mp, npts, wl, P)), flush=True)
+        return
     if mapper_dp:
         # the same workload on ONE GPU first, on this box in this run: the N = 1 point the N-rank value is set against
         for _ in range(max(1, args.pretrain_iters // 50)):
@@ -309,7 +341,7 @@ def main():
             single_gpu_c4 = c4_single_gpu(args, cfg, mp)
         # RCCL through the C ABI; torch.distributed only carries the ncclUniqueId (and this script's barriers)
         from pin_slam_amd import collective
-        comm = collective.make_comm(rank, world, args.dp_transport)
+        comm = bring_up_transport(args, rank, world)
         mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, comm, args.dp_mode
         out = bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P, single_gpu_c4)
         mp.dp_comm.close()
@@ -615,7 +647,10 @@ def main():
         if os.path.exists(ref_cpu) and args.workload == "c3":
             try:
                 r = json.load(open(ref_cpu))
-                out["cpu_baseline"] = {
+                # the record is a stored measurement: say which host THIS command runs on and whether it is the kind of
+                # host the record was taken on (CPU model + logical CPU count), so a stale record shows in the line
+                now = _host_now()
+                rec = {  # (built whole, assigned once: a failure half-way leaves no half-filled entry behind)
                     "value": r["frames_per_sec_bench_definition"], "unit": "frames/s", "cores": r["torch_threads"],
                     "kind": r.get("kind", "reference-torch-cpu"), "host": r["host"], "source": f"profiles/{name}",
                     "sample": (f"unmodified reference classes on torch CPU, C3 inputs of this bench: median of {r['reps']} x "
@@ -625,14 +660,10 @@ def main():
                                f"which favours the CPU)"),
                     "registration_queries_per_sec": r["registration_queries_per_sec"],
                     "mapper_samples_per_sec": r["mapper_samples_per_sec"], "tracking_ms": r.get("tracking_ms"),
-                    "torch": r.get("torch")}
-                # the record is a stored measurement: say which host THIS command runs on and whether it is the kind of
-                # host the record was taken on (CPU model + logical CPU count), so a stale record shows in the line
-                now = _host_now()
-                out["cpu_baseline"]["host_now"] = now["text"]
-                out["cpu_baseline"]["host_matches_record"] = bool(now["model"] and now["model"] in r["host"]
-                                                                  and f"{now['cpus']} logical CPUs" in r["host"])
-                out["cpu_baseline"]["live"] = False
+                    "torch": r.get("torch"), "host_now": now["text"],
+                    "host_matches_record": bool(now["model"] and now["model"] in r["host"] and f"{now['cpus']} logical CPUs" in r["host"]),
+                    "live": False}
+                out["cpu_baseline"] = rec
                 break
             except Exception:
                 pass
@@ -1048,6 +1079,35 @@ def c4_per_rank_emulated(args, cfg, mp, worlds, single):
     return out
 
 
+def bench_single_gpu_mapper(args, cfg, mp, npts, wl, P):
+    """`--gpus 1 --metric mapper`: Mapper.mapping on the global batch on ONE GPU, timed exactly like the N > 1 step of
+    bench_dp_mapper (warm-up calls, then --steps calls of --map-iters iterations between synchronisations)."""
+    H, L = wl["hidden"], wl["levels"]
+    gbs, iters = args.global_bs, args.map_iters
+    cfg.bs = gbs
+    torch.manual_seed(4242)
+    for _ in range(max(1, args.warmup)):
+        mp.mapping(iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mp.mapping(iters)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = args.steps * iters * gbs / elapsed
+    return {"metric": "mapper_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"c4: Mapper.mapping, global batch {gbs} (+{(gbs + 9) // 10}x6 Eikonal probes) on 1 GPU, {iters} "
+                                   f"iterations per step, {wl['desc']}",
+                       "neural_points": P, "local_points": int(npts.local_count()), "decoder": f"{L}x{H}", "global_batch": gbs,
+                       "per_rank_batch": gbs, "dp_mode": None,
+                       "parallelism": "one GPU: lazy exact Adam, pool records reused across the call; the N = 1 point of the "
+                                      "`bench.py --gpus N` strong-scaling curve (same metric, same step)"},
+            "ms_per_iteration": round(1e3 * elapsed / (args.steps * iters), 4), "rccl_ranks": 0, "scaling_efficiency": 1.0,
+            "allreduce": None}
+
+
 def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_ranks, P, single):
     """N > 1: the data-parallel mapper (config C4).  Step = one Mapper.mapping call of --map-iters iterations on the
     global batch.  spatial: every rank trains the samples in its k-d box, lazy Adam on its rows, one RCCL all-reduce of
@@ -1115,8 +1175,13 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
                                    f"certainty / ts merged once per call"),
                    "n1_reference": "single_gpu_same_box below; the N = 1 bench line reports it as c4_single_gpu"},
         "ms_per_iteration": round(ms_it, 4),
+        # what ran the exchange, at top level: "rccl" = pin_slam_amd.collective.RcclComm (RCCL through the C ABI), nothing else
+        "transport": _transport_tag(mp.dp_comm), "rccl_ranks": world if _transport_tag(mp.dp_comm) == "rccl" else 0,
+        "busbw_GBs": round(busbw, 1) if ok else None,
         "single_gpu_same_box": single,
         "speedup_vs_single_gpu": None if not single else round(value / single["mapper_samples_per_sec"], 3),
+        # strong scaling: N ranks against N x the one-GPU mapper measured by every rank of THIS run on its own GPU
+        "scaling_efficiency": None if not single else round(value / (world * single["mapper_samples_per_sec"]), 4),
         "shards": None if not spatial else {"halo_rows": st.get("halo_rows"), "rows": st.get("rows"),
                                             "halo_fraction": round(st.get("halo_fraction", 0.0), 4),
                                             "largest_share_of_batch": round(smax / gbs, 4), "ideal_share": round(1.0 / world, 4)},
@@ -1139,6 +1204,17 @@ def bench_dp_mapper(args, cfg, mp, npts, wl, rank, world, barrier, max_over_rank
     }
 
 
+def _transport_tag(comm) -> str:
+    from pin_slam_amd import collective
+    if isinstance(comm, collective.RcclComm):
+        return "rccl"
+    if isinstance(comm, collective.TorchComm):
+        return "torch.distributed"
+    if isinstance(comm, collective.HostStagedComm):
+        return "host-staged (test mode)"
+    return "none"
+
+
 def _ref_cpu_live(args):
     """cpu_baseline timed by THIS command: when the reference pack travels with the snapshot (oracle/_ref/, written by
     `scripts/e2e_pin_slam.py pack`; git-ignored, never part of the repository), scripts/ref_cpu_baseline.py runs the
@@ -1150,16 +1226,19 @@ def _ref_cpu_live(args):
     if not os.path.exists(pack) or os.environ.get("PIN_BENCH_REF_LIVE", "1") == "0":
         return None
     from pin_slam_amd.dropin import cpu_quota
-    threads = max(1, int(cpu_quota()))
+    # threads: the container's CPU quota, but never more than 16 -- the reference's own thread sweep on these hosts
+    # (profiles/r04_ref_cpu_baseline.json: 16 / 32 / 64 / 128) has 16 as the fastest setting and torch's default (every
+    # logical CPU of an unconstrained host) as the slowest: more threads would only inflate the GPU / CPU ratio
+    threads = max(1, min(16, int(cpu_quota())))
     dst = os.path.join(ROOT, "gpurun_out")
     os.makedirs(dst, exist_ok=True)
     rec = os.path.join(dst, "ref_cpu_baseline_live.json")
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "ref_cpu_baseline.py"), "--reps", "3", "--skip-tracking", "--threads",
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "ref_cpu_baseline.py"), "--reps", "5", "--tracking-reps", "1", "--threads",
            str(threads), "--reg-iters", str(args.reg_iters), "--map-iters", str(args.map_iters), "--out", rec,
            "--host-label", "host of this bench run"]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        subprocess.run(cmd, check=True, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+        subprocess.run(cmd, check=True, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
         r = json.load(open(rec))
     except Exception:
         return None
@@ -1169,7 +1248,13 @@ def _ref_cpu_live(args):
                        f"Tracker.registration_step over the {r['scan_points']}-point scan ({r['registration_step_ms']} ms) and of "
                        f"{r['reps']} x Mapper.mapping({r['mapping_iterations']}) ({r['mapping_ms']} ms), 1 warm-up each; frame = "
                        f"{args.reg_iters} registration steps + one mapping call (preprocess / map prep not included, which favours "
-                       f"the CPU); {r['torch_threads']} torch threads = this container's CPU quota"),
+                       f"the CPU); {r['torch_threads']} torch threads = min(16, this container's CPU quota); one Tracker.tracking call "
+                       f"(its own convergence test, no warm-up) timed beside them: tracking_ms"),
+            "value_range": r.get("frames_per_sec_range"),
+            "spread_ms": {"registration_step": [min(r["registration_step_ms_all"]), r["registration_step_ms"], max(r["registration_step_ms_all"])],
+                          "mapping": [min(r["mapping_ms_all"]), r["mapping_ms"], max(r["mapping_ms_all"])],
+                          "order": "min, median, max of the repeats"} if "registration_step_ms_all" in r else None,
+            "tracking_ms": r.get("tracking_ms"),
             "registration_queries_per_sec": r["registration_queries_per_sec"],
             "mapper_samples_per_sec": r["mapper_samples_per_sec"], "torch": r.get("torch")}
 

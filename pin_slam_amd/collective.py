@@ -207,10 +207,16 @@ def self_test(comm, device="cuda") -> bool:
     return bool((recv == w * (w + 1) / 2).all().item()) and bool((gat == want).all().item())
 
 
-def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device="cuda"):
-    """The mapper's transport for this job.  "rccl": RCCL through the C ABI, checked with :func:`self_test` on every rank;
-    when ANY rank fails to create the communicator or fails the test, all ranks switch to :class:`TorchComm` together and
-    say so (`kind` carries the reason) -- a job never runs with mixed transports."""
+class TransportError(RuntimeError):
+    """The requested transport could not be brought up (raised on every rank of the job together)."""
+
+
+def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device="cuda", fallback: bool = False):
+    """The mapper's transport for this job.  "rccl": RCCL through the C ABI, checked with :func:`self_test` on every rank.
+    When ANY rank fails to create the communicator or fails the test, EVERY rank raises :class:`TransportError` with the
+    reason (the ranks agree on it through the job's process group first: nobody is left waiting in a collective) -- a job
+    asked to run on RCCL never runs on something else.  `fallback=True` (an explicit opt-in; `bench.py --dp-transport auto`)
+    makes all ranks move to :class:`TorchComm` together instead and say so in `kind`; mixed transports never happen."""
     import torch.distributed as dist
     if transport == "host":
         return HostStagedComm(rank, world, group)
@@ -272,6 +278,11 @@ def make_comm(rank: int, world: int, transport: str = "rccl", group=None, device
             comm.close()
         except Exception:  # noqa: BLE001
             pass
+    if not fallback:
+        err = TransportError(f"RCCL transport not available ({why[:300]}); no other transport was asked for "
+                             f"(make_comm(fallback=True) / bench.py --dp-transport auto | torch | host select one)")
+        err.abandoned_thread = bool(box.get("stuck"))  # a bootstrap thread may still sit in the library: leave with os._exit
+        raise err
     alt = TorchComm(rank, world, group)
     if not self_test(alt, device):
         raise RuntimeError(f"no working transport: RcclComm failed ({why}) and torch.distributed fails its self-test")

@@ -26,7 +26,7 @@ namespace pin {
 // A: every local point registers the (up to 8) bricks that cover its +-n cell neighbourhood.
 // Brick ids are allocated wave-aggregated (one atomic per wave and slot, not per brick).
 // (n_vb, here and in the fill / clear / publish kernels: the number of 256-thread units of work; the grid may be narrower --
-// PIN_BRICK_GRID, pin_brick_build -- and then walks them, so that the build leaves room for the launches of another stream)
+// pin_brick_cache.build_grid, pin_brick_build -- and then walks them, so that the build leaves room for the launches of another stream)
 __global__ __launch_bounds__(256) void brick_mark_kernel(pin_brick_cache bc, pin_search_params sp, int n_dilate,
                                                          int* __restrict__ counters, int n_vb) {
   for (int vb = blockIdx.x; vb < n_vb; vb += gridDim.x) {
@@ -935,9 +935,9 @@ extern "C" int pin_brick_build(const pin_search_params* sp, const pin_brick_cach
     // bound by random table / directory probes, not by arithmetic: a few waves per compute unit with eight probes in flight
     // per lane keep the memory system nearly as busy as 8 700 blocks do, and the dispatcher's slots stay free for the small
     // launches of the stream that runs beside it (pool filter, certainty query, the mapper's set-up).  0: one block per unit.
-    // (PIN_BRICK_GRID in the environment overrides the field: A/B runs.)
-    static const int grid_env = [] { const char* e = getenv("PIN_BRICK_GRID"); return e ? atoi(e) : -1; }();
-    const int grid_cap = grid_env >= 0 ? grid_env : bc->build_grid;
+    // (ONE switch: the field.  The drop-in sets it from PIN_BRICK_BUILD_GRID, parsed and validated once in Python.)
+    PIN_CHECK_ARG(bc->build_grid >= 0, "build_grid < 0");
+    const int grid_cap = bc->build_grid;
     auto grid_of = [grid_cap](int units) { return dim3((unsigned)(grid_cap > 0 ? (units < grid_cap ? units : grid_cap) : units)); };
     hipLaunchKernelGGL(brick_clear_kernel, grid_of(cdiv(D, 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long*>(bc->dir_keys), D, counters_out,

@@ -652,12 +652,23 @@ static hipError_t sort_u64(void* temp, size_t& temp_bytes, unsigned long long* i
     return rocprim::merge_sort<SortU64Config>(temp, temp_bytes, in, out, (size_t)n, rocprim::less<unsigned long long>(), s);
 }
 
+// Temporary storage of the sorts used on n words: the larger of the pairs radix sort (pin_voxel_downsample, pin_hash_rebuild)
+// and the keys sort (sort_u64: merge below SORT_U64_MAX words, radix above), so that ONE carve serves whichever a caller runs --
+// also across the merge / radix switch at n = SORT_U64_MAX.  The two rocPRIM size queries are host work on a per-frame path
+// (four callers per frame): the answer is cached per n in a small direct-mapped table per thread.
 static size_t sort_temp_bytes(int n) {
+    constexpr int SLOTS = 16;
+    static thread_local int key[SLOTS] = {0};
+    static thread_local size_t val[SLOTS] = {0};
+    const int slot = (int)(((unsigned)n * 2654435761u) >> 28) & (SLOTS - 1);
+    if (n > 0 && key[slot] == n) return val[slot];
     size_t bytes = 0, b2 = 0;
     unsigned long long* k = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0, 64, hipStream_t(0));
     (void)sort_u64(nullptr, b2, k, k, n, hipStream_t(0));
-    return bytes > b2 ? bytes : b2;
+    const size_t r = bytes > b2 ? bytes : b2;
+    if (n > 0) { key[slot] = n; val[slot] = r; }
+    return r;
 }
 
 }  // namespace pin

@@ -82,6 +82,12 @@ class NeuralPoints(nn.Module):
         self._ws = None
         self._cnt = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._bricks = self._brick_cache = None
+        # width of the overlapped per-frame brick build (_build_bricks), read ONCE; a malformed value is an error, not "full width"
+        e = os.environ.get("PIN_BRICK_BUILD_GRID")
+        if e is not None and not (e.isdigit() and int(e) >= 0):
+            raise ValueError(f"PIN_BRICK_BUILD_GRID must be a non-negative integer (blocks per launch, 0 = full width), got {e!r}")
+        self._brick_grid_env = None if e is None else int(e)
+        self._bricks_overlap = False
         self.set_search_neighborhood(num_nei_cells=config.num_nei_cells, search_alpha=config.search_alpha)
 
     # ------------------------------------------------------------------ storage
@@ -381,7 +387,14 @@ class NeuralPoints(nn.Module):
         # the filter 174.4 / 0.99; 512 wide, queued here 179.3 / 0.86; 256 wide 173.9 (the mapper waits for the build);
         # 1024 wide and more, queued here: 167-171 (the small launches wait again).
         # (5.3 M points, C5: 1024 wide -- at 512 the mapper waits for the build: mapping 2.0 -> 2.13 ms)
-        self._brick_cache.build_grid = int(os.environ.get("PIN_BRICK_BUILD_GRID", "512" if self._n < 3_000_000 else "1024"))
+        # Narrow only when the build really runs beside other work (Mapper.process_frame sets _bricks_overlap around its
+        # update()): a reset_local_map outside it -- loop closure, pose-graph update, a tracker-only run -- is waited for
+        # at once, and there the full-width launches are the faster ones.
+        if getattr(self, "_bricks_overlap", False):
+            g = getattr(self, "_brick_grid_env", None)  # (absent on a map un-pickled from an older run)
+            self._brick_cache.build_grid = g if g is not None else (512 if self._n < 3_000_000 else 1024)
+        else:
+            self._brick_cache.build_grid = 0
         with torch.cuda.stream(side):
             self._bricks = self._brick_cache.build(self.search_state(), time_filtering=tf, local=True)
             self._bricks_event = side.record_event()

@@ -243,6 +243,7 @@ class Mapper(_StandaloneBase):
         # (r05: the narrow brick build is queued by update() itself; PIN_DEFER_BRICKS=1 / 2 = r04's schedules, queued by
         # _process_frame_tail behind the pool filter / the certainty query -- see NeuralPoints._rebuild_bricks)
         npts._defer_bricks = os.environ.get("PIN_DEFER_BRICKS", "0") != "0"
+        npts._bricks_overlap = True  # the build this update() queues runs beside the pool filter / certainty query below: narrow launches
         try:
             self.cur_new_point_ratio = npts.update(update_points, origin, orientation, frame_id)
         finally:
@@ -253,6 +254,7 @@ class Mapper(_StandaloneBase):
             self._process_frame_tail(c, npts, p, frame_id, filtering, kept, n_new, defer)
         finally:
             npts.build_pending_bricks()
+            npts._bricks_overlap = False
             # an exception between update() and the read-back below must not leave the local tables at last frame's size
             if getattr(npts, "_local_count_pending", False):
                 npts._finish_local_map(int(npts._cnt[2].item()))

@@ -577,8 +577,12 @@ class MapTrainer:
             torch.cuda.current_stream().wait_event(self._wg_ev[1])
             self._wg_pending = False
         if self._dp_pending is not None:
-            torch.cuda.current_stream().wait_event(self._dp_ev[2])
-            self._dp_pending = None
+            # spatial shards: the halo rows' and the decoder's step of the aborted call's last iteration are owed on EVERY rank,
+            # and the other ranks take them (their call did not fail): take them here as well -- the exchange itself has run,
+            # all that is left is local -- so that the replicas of halo rows and decoder stay identical; the owned rows' lazy
+            # steps are dropped with the optimiser state on every rank alike (they would have been settled by the flush of the
+            # call that did not finish: the next call's publish() re-broadcasts every owned row)
+            self._dp_finish_exchange()
         self.lazy_on = bool(iters) and (self.comm is None or self.dp is not None)
         if self.dp is not None and not self.lazy_on:
             raise ValueError("the spatially sharded mapper needs the iteration count (lazy Adam on the owned rows)")

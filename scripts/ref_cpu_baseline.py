@@ -60,8 +60,9 @@ def host_string(label):
     return f"{what}: {platform.node()}, {os.cpu_count()} logical CPUs ({aff} usable), {model or platform.machine()}"
 
 
-def timed(fn, reps):
-    fn()  # warm-up
+def timed(fn, reps, warmup=True):
+    if warmup:
+        fn()
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -82,6 +83,8 @@ def main():
     ap.add_argument("--host-label", default="", help="what to call this machine in the record (e.g. 'gpu box (MI355X host)')")
     ap.add_argument("--skip-tracking", action="store_true", help="do not time Tracker.tracking (a thread-count sweep needs the two "
                                                                  "quantities of the frame only)")
+    ap.add_argument("--tracking-reps", type=int, default=0, help="repeats of Tracker.tracking (0 = --reps); 1 = ONE call without a "
+                                                                 "warm-up (the bench's live leg: a call is ~50 registration steps)")
     ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0 = torch's default for this host)")
     a = ap.parse_args()
     if a.threads > 0:
@@ -140,21 +143,30 @@ def main():
            "map_build_s": round(t_update, 2), "reps": a.reps}
     t, all_ = timed(reg_step, a.reps)
     out["registration_step_ms"] = round(t * 1e3, 1)
+    out["registration_step_ms_all"] = [round(x * 1e3, 1) for x in all_]
     out["registration_queries_per_sec"] = round(a.scan / t, 1)
     print("registration_step", out["registration_step_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
     t, all_ = timed(mapping, a.reps)
     out["mapping_ms"] = round(t * 1e3, 1)
+    out["mapping_ms_all"] = [round(x * 1e3, 1) for x in all_]
     out["mapping_iterations"] = a.map_iters
     out["mapper_samples_per_sec"] = round(a.bs * a.map_iters / t, 1)
     print("mapping", out["mapping_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
     if not a.skip_tracking:
-        t, all_ = timed(tracking, a.reps)
+        tr = a.tracking_reps or a.reps
+        t, all_ = timed(tracking, tr, warmup=tr > 1)
         out["tracking_ms"] = round(t * 1e3, 1)
+        out["tracking_ms_all"] = [round(x * 1e3, 1) for x in all_]
+        out["tracking_reps"] = tr
         out["tracking_note"] = "Tracker.tracking with its own convergence test (it may stop before reg_iter_n iterations)"
         print("tracking", out["tracking_ms"], "ms", [round(x * 1e3) for x in all_], flush=True)
     # the bench's frame: reg_iters GN steps without early exit over the whole scan + map_iters mapping iterations
     frame_s = a.reg_iters * out["registration_step_ms"] / 1e3 + out["mapping_ms"] / 1e3
     out["frames_per_sec_bench_definition"] = round(1.0 / frame_s, 5)
+    # the spread of the frame figure: every repeat of the two quantities, fastest with fastest and slowest with slowest
+    lo = a.reg_iters * min(out["registration_step_ms_all"]) / 1e3 + min(out["mapping_ms_all"]) / 1e3
+    hi = a.reg_iters * max(out["registration_step_ms_all"]) / 1e3 + max(out["mapping_ms_all"]) / 1e3
+    out["frames_per_sec_range"] = [round(1.0 / hi, 5), round(1.0 / lo, 5)]
     out["frame_definition"] = (f"{a.reg_iters} x registration_step over the whole {a.scan}-point scan (no early exit) + "
                                f"Mapper.mapping({a.map_iters}); preprocess / map-prep stages not included")
     out["kind"] = "reference-torch-cpu"

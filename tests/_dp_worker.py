@@ -23,7 +23,9 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         import torch.distributed as dist
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = collective.make_comm(rank, world, transport)  # rccl | torch (here: gloo on device tensors) | host
+        # rccl (strict: TransportError on every rank if it cannot be brought up) | auto (rccl, else torch.distributed on every
+        # rank together) | torch (here: gloo on device tensors) | host
+        comm = collective.make_comm(rank, world, "rccl" if transport == "auto" else transport, fallback=transport == "auto")
     d = G.load(case)
     st, fs = U.search_state(d), U.field_state(d)
     tsu = U.dev(d["local_point_ts_update"], torch.int32)

@@ -157,17 +157,30 @@ def test_spatial_shards_over_rccl_single_rank(tmp_path):
 
 
 def test_rccl_failing_on_a_shared_gpu_falls_back_on_every_rank(tmp_path, monkeypatch):
-    """Two ranks on ONE device ask for the RCCL transport: RCCL refuses (or never finishes its bootstrap -- the watchdog of
-    collective.make_comm ends that), every rank moves to torch.distributed's communicator together, the reason is in
-    `kind`, and the run still reproduces the reference."""
+    """Two ranks on ONE device ask for the RCCL transport WITH the opt-in fallback (make_comm(fallback=True), `--dp-transport
+    auto`): RCCL refuses (or never finishes its bootstrap -- the watchdog of collective.make_comm ends that), every rank moves to
+    torch.distributed's communicator together, the reason is in `kind`, and the run still reproduces the reference."""
     monkeypatch.setenv("PIN_COMM_INIT_TIMEOUT", "30")
     d = G.load("c2_wf")
-    a = _launch(tmp_path, 2, "rccl", "c2_wf", "spatial")
+    a = _launch(tmp_path, 2, "auto", "c2_wf", "spatial")
     for r in a:
         assert str(r["kind"]).startswith("torch.distributed") and "RcclComm not used" in str(r["kind"]), str(r["kind"])
     for key in ("feats", "dec", "cert", "tsu"):
         assert np.array_equal(a[0][key].view(np.uint8), a[1][key].view(np.uint8)), key
     _against_reference(d, a[0], grads=_launch(tmp_path, 2, "host", "c2_wf")[0])
+
+
+def test_strict_rccl_on_a_shared_gpu_fails_on_every_rank(tmp_path, monkeypatch):
+    """The default: a job asked to run on RCCL never runs on something else.  Two ranks on ONE device (RCCL refuses that): both
+    ranks end with collective.TransportError -- a non-zero exit status each -- instead of timing torch.distributed (VERDICT r5 #7a)."""
+    monkeypatch.setenv("PIN_COMM_INIT_TIMEOUT", "30")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_worker.py"), str(r), "2", str(port), "c2_wf", "rccl",
+                               str(tmp_path / f"strict_{r}.npz"), "spatial"], stderr=subprocess.PIPE, text=True) for r in range(2)]
+    errs = [p.communicate(timeout=600)[1] for p in procs]
+    assert all(p.returncode != 0 for p in procs), [p.returncode for p in procs]
+    assert all("TransportError" in e and "RCCL transport not available" in e for e in errs), errs
+    assert not any(os.path.exists(str(tmp_path / f"strict_{r}.npz")) for r in range(2))
 
 
 def test_rccl_transport_single_rank(tmp_path):

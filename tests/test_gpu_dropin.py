@@ -1,6 +1,8 @@
 """GPU tests of the drop-in classes (stand-alone PinConfig, no reference tree needed):
 map maintenance kernels (K8-K10) bit-exact against the reference's recorded arrays, and a
 small end-to-end loop update -> mapping -> tracking through the reference's call surface."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -729,3 +731,104 @@ def test_an_aborted_call_leaves_no_owed_steps_behind():
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone()))
     (fa, da), (fb, db) = results
     assert (fa - fb).abs().mean().item() < 1e-5 and (da - db).abs().max().item() < 1e-3
+
+
+def test_an_aborted_spatial_call_still_takes_the_exchanged_steps():
+    """a spatially sharded Mapper.mapping aborted on ONE rank (an exception between step_batch and finish_optimizer)
+    leaves the last iteration's halo / decoder steps pending behind the side stream's all-reduce.  The other ranks take those
+    steps; reset_optimizer of the next call must take them here as well (engine.MapTrainer._dp_finish_exchange) instead of
+    discarding them -- otherwise the replicas of halo rows and decoder diverge silently.  One rank with the identity exchange:
+    the decoder after the aborted call's reset equals the decoder of an uninterrupted call stopped at the same iteration."""
+    from pin_slam_amd import collective
+    decs = []
+    for abort in (False, True):
+        mp, npts, dec = _small_mapper()
+        mp.dp_comm, mp.dp_rank, mp.dp_world = collective.NullComm(0, 1), 0, 1
+        t = mp._get_trainer()
+        assert t.dp is not None and t.overlap_exchange
+        calls = {"n": 0}
+        step = t.step_batch
+
+        def counting(*a, _step=step, **k):
+            _step(*a, **k)
+            calls["n"] += 1
+            if abort and calls["n"] == 2:
+                raise RuntimeError("interrupted")
+        t.step_batch = counting
+        torch.manual_seed(7)
+        if abort:
+            with pytest.raises(RuntimeError, match="interrupted"):
+                mp.mapping(6)
+            assert t._dp_pending is not None  # iteration 2's halo / decoder steps are still owed
+            t.step_batch = step
+            t.reset_optimizer(3)  # what the next mapping() call starts with
+            assert t._dp_pending is None
+        else:
+            mp.mapping(2)  # the same two iterations, finished properly (finish_optimizer takes the owed steps)
+        torch.cuda.synchronize()
+        decs.append(dec.flat_params().clone())
+    assert torch.equal(decs[0], decs[1]), (decs[0] - decs[1]).abs().max().item()
+
+
+def test_decoder_outside_the_fp16_range_raises(monkeypatch):
+    """a decoder parameter the split-fp16 image cannot hold (|w| >= 65504 or non-finite) must end in an
+    exception -- raised from the status word the staging kernel sets and the registration loop carries in its one read-back --
+    not in NaNs in a pose.  PIN_MLP=f32 is the advertised way out; the flag is cleared by the raise."""
+    from pin_slam_amd import ops
+    from pin_slam_amd.dropin.utils.tracker import Tracker
+    if os.environ.get("PIN_MLP", "") == "f32":
+        pytest.skip("fp32 image: no fp16 range to leave")
+    mp, npts, dec = _small_mapper()
+    trk = Tracker(mp.config, npts, {"sdf": dec, "semantic": None, "color": None})
+    src = npts.neural_points[:5000].clone()
+    T0 = torch.eye(4, dtype=torch.float64, device="cuda")
+    ops.status(clear=True)
+    trk.tracking(src, T0)  # fine
+    assert ops.status() == 0
+    keep = dec.layers[0].weight.data[3, 2].item()
+    dec.layers[0].weight.data[3, 2] = 7.0e4
+    with pytest.raises(RuntimeError, match="PIN_MLP=f32"):
+        trk.tracking(src, T0)
+    assert ops.status() == 0  # cleared by the raise
+    dec.layers[0].weight.data[3, 2] = float("nan")
+    with pytest.raises(RuntimeError, match="PIN_MLP=f32"):
+        trk.tracking(src, T0)
+    dec.layers[0].weight.data[3, 2] = keep
+    T, _, _, ok = trk.tracking(src, T0)  # ... and the same objects work again
+    assert torch.isfinite(T).all()
+
+
+def test_registration_residual_divided_by_the_gradient_norm():
+    """reg_dist_div_grad_norm (tracker.py:452-456; off in every shipped configuration): the residual of a valid point is
+    sdf / |grad|, the Jacobian rows and the gradient-anomaly weight keep the plain values.  Tile kernel (weighted-first) and
+    the per-neighbour tile kernel against the oracle's step on the kernels' own per-point outputs."""
+    from oracle import pin_oracle as O
+    from pin_slam_amd import ops
+    from pin_slam_amd._lib import GnParams
+    from tests import golden_util as G, gpu_util as U
+    for case in ("c2_wf", "kitti_nwf"):
+        d = G.load(case)
+        st, fs = U.search_state(d), U.field_state(d)
+        src = U.dev(d["reg_cur"])
+        k = int(d["query_nn_k"])
+        nbr, nn, _ = ops.knn_query(st, src, k)
+        gp = GnParams()
+        gp.valid_nn_k = int(d["track_mask_query_nn_k"])
+        gp.min_grad_norm, gp.max_grad_norm = d["cfg_reg_min_grad_norm"], d["cfg_reg_max_grad_norm"]
+        gp.max_sdf_std = d["cfg_surface_sample_range_m"] * d["cfg_max_sdf_std_ratio"]
+        gp.gm_dist, gp.gm_grad = d["cfg_reg_GM_dist_m"], d["cfg_reg_GM_grad"]
+        sdf, grad, std, _ = ops.sdf_query(fs, src, nbr, nn)
+        outs = []
+        for flag in (0, 1):
+            gp.dist_div_grad_norm = flag
+            sums, _, _ = ops.gn_accumulate(fs, gp, src, nbr, nn)
+            T, cnt, res_cm, _ = ops.solve_gn(sums.cpu().numpy(), d["cfg_reg_lm_lambda"])
+            ref = O.registration_step(d["reg_cur"], sdf.cpu().numpy(), grad.cpu().numpy(), std.cpu().numpy(), nn.cpu().numpy(),
+                                      valid_nn_k=gp.valid_nn_k, min_grad_norm=gp.min_grad_norm, max_grad_norm=gp.max_grad_norm,
+                                      max_sdf_std=gp.max_sdf_std, GM_dist=gp.gm_dist, GM_grad=gp.gm_grad,
+                                      lm_lambda=d["cfg_reg_lm_lambda"], dist_div_grad_norm=bool(flag))
+            assert abs(cnt - ref["valid_count"]) <= 2
+            np.testing.assert_allclose(T, ref["T"], rtol=0, atol=1e-5)
+            assert abs(res_cm - ref["residual_cm"]) < 2e-3 * max(1.0, ref["residual_cm"])
+            outs.append(T)
+        assert np.abs(outs[0] - outs[1]).max() > 1e-6, "the switch changes the step"

@@ -103,7 +103,7 @@ def test_two_rank_allreduce_equals_single_rank_gradient():
     assert abs(loss - loss1) < 1e-9
 
 
-def _fallback_worker(rank, world, port, q, hang=False):
+def _fallback_worker(rank, world, port, q, hang=False, strict=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -130,7 +130,27 @@ def _fallback_worker(rank, world, port, q, hang=False):
         collective.RcclComm.allreduce = lambda self, s, r: r.copy_(s * 3.0)   # (3 = 1 + 2: passes the self-test alone)
         collective.RcclComm.allgather = lambda self, s, r: r.copy_(torch.arange(2.0)[:, None].expand(2, 5))
         collective.RcclComm.close = lambda self: None
-    comm = collective.make_comm(rank, world, "rccl", device="cpu")
+    if strict == "bench":  # through bench.py's own bring-up: --dp-transport rccl must END the command (status 3), not fall back
+        import argparse
+        import bench
+        try:
+            bench.bring_up_transport(argparse.Namespace(dp_transport="rccl"), rank, world, device="cpu")
+        except SystemExit as e:
+            q.put((rank, "exit", [float(e.code)]))
+            dist.destroy_process_group()
+            return
+        q.put((rank, "no exit", []))
+        return
+    if strict:
+        try:
+            collective.make_comm(rank, world, "rccl", device="cpu")  # (fallback=False is the default)
+        except collective.TransportError as e:
+            q.put((rank, "TransportError: " + str(e), []))
+            dist.destroy_process_group()
+            return
+        q.put((rank, "no error", []))
+        return
+    comm = collective.make_comm(rank, world, "rccl", device="cpu", fallback=True)
     t = torch.full((4,), float(rank + 1))
     comm.allreduce_grads(t)
     q.put((rank, comm.kind, t.tolist()))
@@ -190,6 +210,27 @@ def test_id_exchange_failure_on_rank0_falls_back_everywhere():
     for _, kind, vals in got:
         assert kind.startswith("torch.distributed gloo") and "rank 0: OSError: librccl not readable" in kind
         assert vals == [3.0] * 4
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("how", [True, "bench"])
+def test_failing_rccl_ends_the_job_unless_a_fallback_was_asked_for(how):
+    """VERDICT r5 #7a / next-round item 3: RcclComm failing on ONE rank of two.  Without the opt-in (make_comm's default, and
+    `bench.py --dp-transport rccl`) EVERY rank gets collective.TransportError with the failing rank's reason -- through bench.py's
+    bring-up the command ends with exit status 3 on every rank -- instead of a silent switch to torch.distributed."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, False, how)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert [g[0] for g in got] == [0, 1]
+    for _, kind, vals in got:
+        if how == "bench":
+            assert kind == "exit" and vals == [3.0], (kind, vals)
+        else:
+            assert kind.startswith("TransportError") and "rank 1: RuntimeError: no RCCL on this rank" in kind, kind
 
 
 @pytest.mark.timeout(300)
