@@ -22,11 +22,19 @@
 
 namespace pin {
 
+// share of the IDW weight on the nearest neighbour from which a wave takes the pivoted gather (quad_gather_pass): the
+// plain form's error is ~ 2^-24 rho |cbar| / |spread of c| of the gradient with rho = u_0 / (S - u_0); 0.98 <=> rho = 49
+constexpr float QUAD_PIVOT_SHARE = 0.98f;
+#ifndef PIN_AB_PIVOT2  // (A/B builds: the pivot of the colour variants' geometry rows -- see quad_gather_pass2)
+#define PIN_AB_PIVOT2 false
+#endif
+
 // ---- decoder-phase building blocks (lane = query n + 16 * component group g) ---------------------------
 template <bool ORIENT>
 struct QuadIn {  // what the gather leaves in the registers of lane (n, g)
     float z[4];      // interpolated decoder input, components 4g..4g+3
-    float Y[3][4];   // sum_t g_t (x) y_t, the same components
+    float zt[4];     // the same relative to the pivot row: z - y_pivot (PIVOT) or z itself; what the chain rule contracts with
+    float Y[3][4];   // sum_t g_t (x) (y_t - y_pivot), the same components
     float Gx, Gy, Gz, wsum, S;
     float M[ORIENT ? 9 : 1];  // sum_t w_t R_t^T (after PGO), lane g == 2
 };
@@ -42,7 +50,20 @@ struct QuadIn {  // what the gather leaves in the registers of lane (n, g)
 // (1 ulp) and w_t = u_t * (1 / S) with one division per query (the IDW weights are compared at 1e-4, not bit for
 // bit, in this kernel).  After PGO (ORIENT) and for the rare flagged neighbours (non-local points, see PIN_NONLOCAL)
 // the relative position comes from neighbor_vector as before.
-template <bool ORIENT, bool GENERAL>
+//
+// PIVOT (r06): the weight-derivative term of the chain rule is sum_t g_t (c_t - cbar) with c_t = a . y_t, cbar = a . z.  When
+// one neighbour carries nearly all the weight (a query a millimetre from a neural point: u_0 ~ 1e6 against ~4e2 for the
+// others) cbar is c_0 up to 1e-3..1e-4 of itself and g_0 ~ u_0^2: forming (sum_t g_t c_t) - cbar G, or even g_0 (c_0 - cbar),
+// in fp32 loses those digits -- the reference's autograd and this kernel alike sat at 1e-4 of the gradient there (c5:
+// 1.09e-4, the one comparison above the bar).  The sum does not change when every row is taken RELATIVE TO ONE OF THEM,
+//     sum_t g_t (c_t - cbar) = a . Ytilde - (a . ztilde) G,   Ytilde = sum_t g_t (y_t - y_0),  ztilde = sum_t w_t (y_t - y_0),
+// (sum_t w_t = 1), and with the pivot y_0 = the NEAREST neighbour's row (records are sorted by distance) the dominant term
+// vanishes identically (y_0 - y_0), ztilde is a small number computed to full relative accuracy, and what is left does not
+// cancel: a . Ytilde ~ sum_{t>0} u_t / d_t against (a . ztilde) G ~ u_0 / d_0 -- the second dominates by d_t / d_0.  The
+// decoder input is rebuilt as z = wsum y_0 + ztilde.  Four subtractions per neighbour and lane: taken on the rare path only --
+// a wave in which some query has u_0 > QUAD_PIVOT_SHARE S (quad_gather; ~1 % of the queries, wave-uniform: the same branch as
+// `any_flag`, i.e. the GENERAL pass IS the pivoted one), and always after PGO.
+template <bool ORIENT, bool GENERAL, bool PIVOT = GENERAL>
 __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float4 (&e)[PIN_MAX_K], const float4 (&ft)[PIN_MAX_K],
                                                  const float (&u)[PIN_MAX_K], const int (&raw)[PIN_MAX_K], float S, float px,
                                                  float py, float pz, int g, QuadIn<ORIENT>& in) {
@@ -57,6 +78,7 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
         for (int r = 0; r < 4; ++r) Y[c][r] = 0.f;
     float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
     float M[ORIENT ? 9 : 1] = {0.f};
+    float y0[4] = {0.f, 0.f, 0.f, 0.f};  // (PIVOT) the nearest neighbour's four input components
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t) {
         const float wt = u[t] * invS;
@@ -82,6 +104,15 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
         y[1] = is_feat ? ft[t].y : mv * v[1];
         y[2] = is_feat ? ft[t].z : mv * v[2];
         y[3] = is_feat ? ft[t].w : 0.f;
+        if constexpr (PIVOT) {
+            if (t == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y0[r] = y[r];
+                continue;  // (y_0 - y_0: the pivot's own terms vanish)
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] -= y0[r];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z[r] = fmaf(wt, y[r], z[r]);
@@ -90,7 +121,11 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
     }
     in.Gx = Gx; in.Gy = Gy; in.Gz = Gz; in.wsum = wsum; in.S = S;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { in.z[r] = z[r]; in.Y[0][r] = Y[0][r]; in.Y[1][r] = Y[1][r]; in.Y[2][r] = Y[2][r]; }
+    for (int r = 0; r < 4; ++r) {
+        in.zt[r] = z[r];
+        in.z[r] = PIVOT ? fmaf(wsum, y0[r], z[r]) : z[r];
+        in.Y[0][r] = Y[0][r]; in.Y[1][r] = Y[1][r]; in.Y[2][r] = Y[2][r];
+    }
     if constexpr (ORIENT) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) in.M[c] = M[c];
@@ -102,7 +137,12 @@ __device__ __forceinline__ void quad_gather_pass(const pin_field& f, const float
 // it is done.  (Two calls of quad_gather_pass kept 96 registers of records and rows alive across the first one and, on
 // the GENERAL path, went through neighbor_vector twice per neighbour: 256 registers + 76-232 B of scratch.)  The same
 // arithmetic per accumulator in the same order: in / inc as two passes leave them.
-template <bool ORIENT, bool GENERAL>
+// PIVOT (see quad_gather_pass) is written for the GEOMETRY rows here and is OFF: in these two-table variants the pivoted rare
+// path costs the kernel 70 registers (214 -> 256 + 29 spilled at 1 x 64, measured with -DPIN_AB_PIVOT2=GENERAL), i.e. scratch
+// memory in C5's registration kernel; their gradients are the plain form's (c5: 3.5e-5 on the tested points, the colour
+// gradient is compared at 3e-4).  The single-table kernels -- every query kernel, the registration kernel without the colour
+// term -- are pivoted.
+template <bool ORIENT, bool GENERAL, bool PIVOT = PIN_AB_PIVOT2>
 __device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const float4 (&e)[PIN_MAX_K], const float4 (&ft)[PIN_MAX_K],
                                                   const float4 (&fc)[PIN_MAX_K], const float (&u)[PIN_MAX_K],
                                                   const int (&raw)[PIN_MAX_K], float S, float px, float py, float pz, int g,
@@ -118,6 +158,7 @@ __device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const floa
         for (int r = 0; r < 4; ++r) { Y[c][r] = 0.f; Yc[c][r] = 0.f; }
     float Gx = 0.f, Gy = 0.f, Gz = 0.f, wsum = 0.f;
     float M[ORIENT ? 9 : 1] = {0.f};
+    float y0[4] = {0.f, 0.f, 0.f, 0.f};  // (PIVOT)
 #pragma unroll
     for (int t = 0; t < PIN_MAX_K; ++t) {
         const float wt = u[t] * invS;
@@ -143,6 +184,15 @@ __device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const floa
         y[1] = is_feat ? ft[t].y : mv * v[1];  yc[1] = is_feat ? fc[t].y : mv * v[1];
         y[2] = is_feat ? ft[t].z : mv * v[2];  yc[2] = is_feat ? fc[t].z : mv * v[2];
         y[3] = is_feat ? ft[t].w : 0.f;        yc[3] = is_feat ? fc[t].w : 0.f;
+        if constexpr (PIVOT) {
+            if (t == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { y0[r] = y[r]; y[r] = 0.f; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] -= y0[r];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z[r] = fmaf(wt, y[r], z[r]);
@@ -155,8 +205,9 @@ __device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const floa
     inc.Gx = Gx; inc.Gy = Gy; inc.Gz = Gz; inc.wsum = wsum; inc.S = S;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        in.z[r] = z[r]; in.Y[0][r] = Y[0][r]; in.Y[1][r] = Y[1][r]; in.Y[2][r] = Y[2][r];
-        inc.z[r] = zc[r]; inc.Y[0][r] = Yc[0][r]; inc.Y[1][r] = Yc[1][r]; inc.Y[2][r] = Yc[2][r];
+        in.zt[r] = z[r]; in.z[r] = PIVOT ? fmaf(wsum, y0[r], z[r]) : z[r];
+        in.Y[0][r] = Y[0][r]; in.Y[1][r] = Y[1][r]; in.Y[2][r] = Y[2][r];
+        inc.z[r] = zc[r]; inc.zt[r] = zc[r]; inc.Y[0][r] = Yc[0][r]; inc.Y[1][r] = Yc[1][r]; inc.Y[2][r] = Yc[2][r];
     }
     if constexpr (ORIENT) {
 #pragma unroll
@@ -165,7 +216,9 @@ __device__ __forceinline__ void quad_gather_pass2(const pin_field& f, const floa
 }
 
 // COLOR: the same neighbours and weights over a second feature table (the colour features, `feats_c`) -> inc
-template <bool ORIENT, bool COLOR = false>
+// PIV = false: the one instantiation that cannot afford the pivot row's four registers (after PGO with a 3 x 64 decoder: 255
+// registers without it)
+template <bool ORIENT, bool COLOR = false, bool PIV = true>
 __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __restrict__ rp, int kk, int nn, float px, float py,
                                             float pz, int g, QuadIn<ORIENT>& in, const float* __restrict__ feats_c = nullptr,
                                             QuadIn<ORIENT>* inc = nullptr) {
@@ -192,17 +245,20 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
         any_flag = any_flag || (val && (raw[t] & PIN_NBR_QUIRK_BIT) != 0);
         raw[t] = val ? raw[t] : -1;
     }
+    // (PIVOT, see quad_gather_pass) some query of the wave has nearly all its weight on its nearest neighbour: such a wave
+    // takes the GENERAL pass, which is the pivoted one -- ONE rare variant beside the straight-line one
+    const bool rare = __builtin_amdgcn_ballot_w64(any_flag || u[0] > QUAD_PIVOT_SHARE * S) != 0ull;
     if constexpr (COLOR) {
         if constexpr (ORIENT) {
-            quad_gather_pass2<true, true>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
+            quad_gather_pass2<true, true, false>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
         } else {
-            if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) quad_gather_pass2<false, true>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);  // rare
-            else quad_gather_pass2<false, false>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
+            if (rare) quad_gather_pass2<false, true>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
+            else quad_gather_pass2<false, false, false>(f, e, ft, fc, u, raw, S, px, py, pz, g, in, *inc);
         }
     } else if constexpr (ORIENT) {
-        quad_gather_pass<true, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
+        quad_gather_pass<true, true, PIV>(f, e, ft, u, raw, S, px, py, pz, g, in);
     } else {
-        if (__builtin_amdgcn_ballot_w64(any_flag) != 0ull) quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);  // rare
+        if (rare) quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
         else quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
     }
 }
@@ -215,7 +271,7 @@ __device__ __forceinline__ void quad_gather(const pin_field& f, const float4* __
 template <bool ORIENT, bool SWAP = false>
 __device__ __forceinline__ void quad_chain(const QuadIn<ORIENT>& in, const float (&a)[4], int g, float scale, float& gx, float& gy,
                                            float& gz) {
-    const float (&z)[4] = in.z;
+    const float (&z)[4] = in.zt;  // (relative to the gather's pivot row, as Y is: see quad_gather_pass)
     const float (&Y)[3][4] = in.Y;
     const float (&M)[ORIENT ? 9 : 1] = in.M;
     float cbar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
@@ -428,7 +484,7 @@ __global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f,
         QuadIn<ORIENT> in;
         QuadIn<ORIENT> inc;  // (COLOR)
         if constexpr (COLOR) quad_gather<ORIENT, true>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in, ct.fc.feats, &inc);
-        else quad_gather<ORIENT>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in);
+        else quad_gather<ORIENT, false, !(ORIENT && H == 64 && LC == 3)>(f, nbr + (size_t)qq * f.k, f.k, nn, px, py, pz, g, in);
         if (!staged) {  // the first gather overlaps the weight staging of the block
             __syncthreads();
             staged = true;
@@ -612,12 +668,17 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
         }
         d0 = quad_lanes_sum(octet_sum(d0)); d1 = quad_lanes_sum(octet_sum(d1)); d2 = quad_lanes_sum(octet_sum(d2));
         const float cg = -2.f * u * u;  // d u_t / d q = cg * (q - P_t); through the weights: sum_t (s_t - mean) d w_t
-        const float cs = cg * st;
+        // ... with every prediction taken relative to the NEAREST neighbour's (t = 0): sum_t g_t (s_t - mean) =
+        // sum_t g_t (s_t - s_0) - (sum_t w_t (s_t - s_0)) G, whose dominant term vanishes identically when one neighbour
+        // carries nearly all the weight (quad_gather_pass, PIVOT: the plain form cancels to 1e-4 of the gradient there)
+        const float sp = st - octet_sum(t == 0 ? st : 0.f);
+        const float cs = cg * sp;
+        const float mt = octet_sum(wt * sp);
         const float ax = octet_sum(cs * e.x), ay = octet_sum(cs * e.y), az = octet_sum(cs * e.z);
         const float Gx = octet_sum(cg * e.x), Gy = octet_sum(cg * e.y), Gz = octet_sum(cg * e.z);
-        const float gx = s * d0 + (ax - mean * Gx) * invS;
-        const float gy = s * d1 + (ay - mean * Gy) * invS;
-        const float gz = s * d2 + (az - mean * Gz) * invS;
+        const float gx = s * d0 + (ax - mt * Gx) * invS;
+        const float gy = s * d1 + (ay - mt * Gy) * invS;
+        const float gz = s * d2 + (az - mt * Gz) * invS;
         if constexpr (MODE != 0) {
             float cert = 0.f;
             if (cert_out != nullptr && f.certainty != nullptr)  // (uniform)

@@ -159,6 +159,11 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
 #pragma unroll
             for (int c = 0; c < 9; ++c) M[c] = 0.f;
         }
+        // (GRAD) every row relative to the nearest neighbour's, y_t - y_0: the weight-derivative term sum_t g_t (c_t - cbar)
+        // keeps its digits when one neighbour dominates (gn_quad.h, quad_gather_pass PIVOT); zt = sum_t w_t (y_t - y_0)
+        float y0[MLP_IN], zt[MLP_IN];
+#pragma unroll
+        for (int j = 0; j < MLP_IN; ++j) y0[j] = zt[j] = 0.f;
 #pragma unroll
         for (int t = 0; t < PIN_MAX_K; ++t)
             if (nb.idx[t] >= 0) {
@@ -171,6 +176,12 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
 #pragma unroll
                 for (int j = 0; j < MLP_IN; ++j) z[j] = fmaf(nb.w[t], y[j], z[j]);
                 if (GRAD) {
+                    if (t == 0) {
+#pragma unroll
+                        for (int j = 0; j < MLP_IN; ++j) y0[j] = y[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < MLP_IN; ++j) { y[j] -= y0[j]; zt[j] = fmaf(nb.w[t], y[j], zt[j]); }
                     const float cg = -2.f * nb.u[t] * nb.u[t];
                     const float g0 = cg * nb.vx[t], g1 = cg * nb.vy[t], g2 = cg * nb.vz[t];
 #pragma unroll
@@ -191,7 +202,7 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
         if (GRAD) {
             float cbar = 0.f;
 #pragma unroll
-            for (int j = 0; j < MLP_IN; ++j) cbar = fmaf(a[j], z[j], cbar);  // = sum_t w_t c_t
+            for (int j = 0; j < MLP_IN; ++j) cbar = fmaf(a[j], zt[j], cbar);  // = sum_t w_t (c_t - c_0), as Y holds the g_t (x) (y_t - y_0)
             float ax = 0.f, ay = 0.f, az = 0.f;  // sum_t c_t g_t
 #pragma unroll
             for (int j = 0; j < MLP_IN; ++j) { ax = fmaf(Y[0][j], a[j], ax); ay = fmaf(Y[1][j], a[j], ay); az = fmaf(Y[2][j], a[j], az); }
@@ -210,7 +221,7 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
         // decode every neighbour, then weight (weighted_first = False, run_kitti.yaml:25)
         float sk[PIN_MAX_K];
         float mean = 0.f, dxs = 0.f, dys = 0.f, dzs = 0.f;
-        float ax = 0.f, ay = 0.f, az = 0.f;
+        float ax = 0.f, ay = 0.f, az = 0.f, s0 = 0.f, mt = 0.f;
 #pragma unroll 1
         for (int t = 0; t < f.k; ++t) {
             // static-index copies of neighbour t
@@ -248,7 +259,10 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
                         } else {
                             dxs = fmaf(wt, a[8], dxs); dys = fmaf(wt, a[9], dys); dzs = fmaf(wt, a[10], dzs);
                         }
-                        const float cg = -2.f * ut * ut * st;
+                        if (t == 0) s0 = st;  // (predictions relative to the nearest neighbour's: see the weighted-first branch)
+                        const float sp = st - s0;
+                        mt = fmaf(wt, sp, mt);
+                        const float cg = -2.f * ut * ut * sp;
                         ax = fmaf(cg, vgx, ax); ay = fmaf(cg, vgy, ay); az = fmaf(cg, vgz, az);
                     }
                 }
@@ -264,9 +278,9 @@ __device__ __forceinline__ SdfResult eval_query(const pin_field& f, const float4
         r.std = sqrtf(var);  // tracker.py:317-322
         if (GRAD) {
             const float invS = 1.0f / nb.S;
-            r.gx = s * dxs + (ax - mean * Gx) * invS;
-            r.gy = s * dys + (ay - mean * Gy) * invS;
-            r.gz = s * dzs + (az - mean * Gz) * invS;
+            r.gx = s * dxs + (ax - mt * Gx) * invS;
+            r.gy = s * dys + (ay - mt * Gy) * invS;
+            r.gz = s * dzs + (az - mt * Gz) * invS;
         }
     }
     return r;

@@ -44,7 +44,10 @@ __device__ __forceinline__ void quad_gather_query(const pin_field& f, const floa
         if constexpr (ORIENT) {
             quad_gather_pass<true, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
         } else {
-            if (general) quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);  // rare
+            // rare: a flagged neighbour, or a query with nearly all its weight on its nearest neighbour (the GENERAL pass is the
+            // pivoted one: quad_gather_pass, PIVOT)
+            if (general || __builtin_amdgcn_ballot_w64(u[0] > QUAD_PIVOT_SHARE * S) != 0ull)
+                quad_gather_pass<false, true>(f, e, ft, u, raw, S, px, py, pz, g, in);
             else quad_gather_pass<false, false>(f, e, ft, u, raw, S, px, py, pz, g, in);
         }
     } else {

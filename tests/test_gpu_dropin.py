@@ -738,7 +738,7 @@ def test_an_aborted_spatial_call_still_takes_the_exchanged_steps():
     leaves the last iteration's halo / decoder steps pending behind the side stream's all-reduce.  The other ranks take those
     steps; reset_optimizer of the next call must take them here as well (engine.MapTrainer._dp_finish_exchange) instead of
     discarding them -- otherwise the replicas of halo rows and decoder diverge silently.  One rank with the identity exchange:
-    the decoder after the aborted call's reset equals the decoder of an uninterrupted call stopped at the same iteration."""
+    the decoder after the aborted call's reset is the decoder of an uninterrupted call stopped at the same iteration."""
     from pin_slam_amd import collective
     decs = []
     for abort in (False, True):
@@ -767,7 +767,8 @@ def test_an_aborted_spatial_call_still_takes_the_exchanged_steps():
             mp.mapping(2)  # the same two iterations, finished properly (finish_optimizer takes the owed steps)
         torch.cuda.synchronize()
         decs.append(dec.flat_params().clone())
-    assert torch.equal(decs[0], decs[1]), (decs[0] - decs[1]).abs().max().item()
+    # (float atomics order the gradient sums differently from run to run: 1e-8; a dropped step would be a whole Adam step, ~lr = 1e-2)
+    assert (decs[0] - decs[1]).abs().max().item() < 1e-5, (decs[0] - decs[1]).abs().max().item()
 
 
 def test_decoder_outside_the_fp16_range_raises(monkeypatch):
