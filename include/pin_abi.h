@@ -35,6 +35,7 @@ typedef struct pin_pool_arrays {
     float* color;         /* [n][color_channels] or NULL */
     int32_t color_channels;
     int32_t reserved;
+    int32_t* sem_label;   /* [n] semantic label of the sample (sem_label_pool, utils/mapper.py:92, 280-283) or NULL */
 } pin_pool_arrays;
 
 /* DataSampler.sample configuration (utils/data_sampler.py:26-36, config.py:124-129,169-171).
@@ -48,6 +49,9 @@ typedef struct pin_sample_params {
     double free_begin_ratio, free_end_dist; /* free_sample_begin_ratio, free_sample_end_dist_m */
     double dist_weight_scale, max_range;
     double pose[12];                        /* sensor pose rows [R|t] (cur_pose_torch[:3,:]) */
+    const int32_t* sem_labels;              /* DEVICE [n] or NULL: per-point semantic labels of the scan (frame_label_torch);
+                                             * the measured point and its close-to-surface samples inherit them, free-space
+                                             * samples get label 0 (utils/data_sampler.py:59-62, 83-84, 105-106, 184-194) */
 } pin_sample_params;
 
 #ifdef __cplusplus
@@ -309,6 +313,42 @@ typedef struct pin_train_color_params {   /* colour term of Mapper.mapping (mapp
                               * evaluates a shard of it (the colour loss is a mean over them, utils/loss.py:31-42);
                               * NULL = count the samples of this call */
 } pin_train_color_params;
+
+/* ---- semantic head (config.semantic_on, config/lidar_slam/run_demo_sem.yaml) ------------------------------------------------
+ * A decoder with heads = sem_class_count + 1 outputs over the SAME interpolated geometry feature as the SDF decoder
+ * (pin_field.feats = geometry features, pin_field.dec = the semantic decoder's flat parameters, state_dict order), read through
+ * a log-softmax: Decoder.sem_label_prob (model/decoder.py:100-103). */
+typedef struct pin_sem_params {
+    int32_t n_main;          /* batch size */
+    int32_t heads;           /* sem_class_count + 1, 2..32 */
+    float weight_s;          /* config.weight_s */
+    int32_t reserved;
+    const int32_t* labels;   /* DEVICE [n_main] semantic label of every batch sample (Mapper.get_batch's sem_label) */
+    const uint8_t* selected; /* DEVICE [n_main] 1 = the sample is in the loss (pin_sem_select) */
+    const int32_t* count;    /* DEVICE: number of selected samples, the mean's denominator (pin_sem_select) */
+} pin_sem_params;
+int64_t pin_sem_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels, int32_t expand);
+/* utils/mapper.py:786-799: label_mask = label > 0 (>= 0 with freespace_label_on); of the masked samples, in order, every
+ * decimation-th (sem_pred[label_mask][::sem_label_decimation]).  selected_out [n] in {0, 1}, count_out [1] = number selected. */
+int pin_sem_select(const int32_t* labels, int32_t n, int32_t freespace_label_on, int32_t decimation, uint8_t* selected_out,
+                   int32_t* count_out, void* stream);
+/* Mapper.get_batch's sem_label gather (utils/mapper.py:490-491) with the index arrays of pin_gather_batches_drawn; out [n_batches][n]. */
+int pin_gather_labels_drawn(const int32_t* pool_sem, const int64_t* index_history, int32_t n_history, const int64_t* index_new_batch,
+                            const int64_t* new_idx, int32_t n, int32_t n_batches, int64_t hist_stride, int64_t new_stride,
+                            int32_t* out, void* stream);
+/* The semantic term of one Mapper.mapping iteration (utils/mapper.py:664-667, 782-800) on the queries / kNN records of
+ * pin_train_step's main samples: sem_pred = log_softmax(mlp(feature)) (per neighbour and weighted when !weighted_first), NLL
+ * mean over the selected samples x weight_s; gradients ADD into feat_grad (the geometry feature table's, shared with
+ * pin_train_step) and dec_grad (the semantic decoder's, may be NULL = frozen); loss_out[0] += sum over the selected samples of
+ * -sem_pred[label] (divide by *count for the reference's mean). */
+int pin_train_sem_step(const pin_field* f, const pin_sem_params* sp, const float* query, const float* nbr, const int32_t* nn_count,
+                       float* feat_grad, float* dec_grad, double* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Tracker.query_source_points(query_sem) / Mesher.query_points(query_sem) (utils/tracker.py:336-341, utils/mesher.py:137-145):
+ * label_out [n] = argmax of the (weighted) log-probabilities, logprob_out [n][heads] the log-probabilities; either may be NULL. */
+int pin_sem_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count, int32_t n, int32_t heads,
+                  int32_t* label_out, float* logprob_out, void* stream);
+/* Decoder.sem_label_prob on given decoder inputs feat_in [n][11] -> out [n][heads] (raw != 0: Decoder.mlp's plain outputs). */
+int pin_decoder_sem(const pin_field* f, const float* feat_in, int32_t n, int32_t heads, int32_t raw, float* out, void* stream);
 
 /* ---- library ------------------------------------------------------------------- */
 int         pin_version(void);

@@ -806,6 +806,200 @@ def gen_postloop():
 
 
 
+
+def ref_state_from_fixture(m, name):
+    """The reference's NeuralPoints + SDF Decoder rebuilt FROM a committed fixture (so that a new fixture can share the
+    map of an old one instead of carrying 10 MB of arrays again): global arrays and table as recorded, then
+    reset_local_map at the fixture's sensor position -- checked against the fixture's own local arrays."""
+    d = dict(np.load(os.path.join(OUT, name + ".npz")))
+    over, (levels, hidden) = CASES[name]
+    cfg = R.make_config(local_map_radius=20.0, local_map_travel_dist_ratio=1.0, bs=512, feature_std=0.1,
+                        gradient_decimation=10, track_on=True, **over)
+    cfg.geo_mlp_level, cfg.geo_mlp_hidden_dim = levels, hidden
+    npts = m["NeuralPoints"](cfg)
+    npts.neural_points = torch.from_numpy(d["neural_points"].copy())
+    npts.point_orientations = torch.from_numpy(d["point_orientations"].copy())
+    npts.geo_features = torch.from_numpy(d["geo_features"].copy())
+    npts.point_ts_create = torch.from_numpy(d["point_ts_create"].copy())
+    npts.point_ts_update = torch.from_numpy(d["point_ts_update"].copy())
+    npts.point_certainties = torch.from_numpy(d["point_certainties"].copy())
+    npts.buffer_pt_index[torch.from_numpy(d["table_slots"])] = torch.from_numpy(d["table_vals"])
+    npts.travel_dist = torch.from_numpy(d["travel_dist"].copy())
+    npts.reset_local_map(torch.tensor([16.0, 0.0, 0.0]), torch.eye(3), int(d["cur_ts"]))
+    assert np.array_equal(t2n(npts.local_neural_points), d["local_neural_points"])
+    assert np.array_equal(t2n(npts.global2local), d["global2local"]) and np.array_equal(t2n(npts.local_mask), d["local_mask"])
+    npts.local_geo_features.data.copy_(torch.from_numpy(d["local_geo_features"]))
+    npts.local_point_certainties = torch.from_numpy(d["local_point_certainties"].copy())
+    npts.local_point_ts_update = torch.from_numpy(d["local_point_ts_update"].copy())
+    dec = m["Decoder"](cfg, hidden, levels, 1)
+    sd = dec.state_dict()
+    flat, o = torch.from_numpy(d["dec_flat"].copy()), 0
+    for k_, v in sd.items():
+        sd[k_] = flat[o:o + v.numel()].view_as(v).clone()
+        o += v.numel()
+    dec.load_state_dict(sd)
+    return d, cfg, npts, dec
+
+
+def gen_variants():
+    """Small fixture ON THE MAPS of c2_wf / kitti_nwf (loaded back into the reference's classes): configuration branches the
+    other fixtures leave out.
+      * reg_dist_div_grad_norm (tracker.py:452-456): one registration_step per map with the residual divided by |grad|;
+      * the SEMANTIC head (run_demo_sem.yaml; decoder.py:100-103, mapper.py:664-667 / 782-800, tracker.py:336-341): a
+        semantic decoder of sem_class_count + 1 = 21 heads (seeded), Decoder.sem_label_prob on query features,
+        Tracker.query_source_points(query_sem=True), and two Mapper.mapping iterations on fixed batches WITH labels
+        (-1 / 0 / classes), sem_label_decimation 1 (weighted-first map) and 3 with freespace_label_on (per-neighbour map):
+        per-iteration gradients of the geometry features, the SDF decoder and the semantic decoder, the NLL term, the total
+        loss, the parameters after the two Adam steps."""
+    m = R.load()
+    out = {}
+    for name in ("c2_wf", "kitti_nwf"):
+        d, cfg, npts, dec = ref_state_from_fixture(m, name)
+        tools = m["tools"]
+        trk = m["Tracker"](cfg, npts, {"sdf": dec, "semantic": None, "color": None})
+        # ---- registration_step with reg_dist_div_grad_norm
+        cfg.reg_dist_div_grad_norm = True
+        cur = torch.from_numpy(d["reg_cur"])
+        step = trk.registration_step(cur.clone(), None, torch.zeros(len(cur)), None, cfg.reg_min_grad_norm, cfg.reg_max_grad_norm,
+                                     cfg.reg_GM_dist_m, cfg.reg_GM_grad, cfg.reg_lm_lambda, False)
+        out[f"{name}_ddgn_dT"] = t2n(step[0]); out[f"{name}_ddgn_valid_count"] = np.int64(step[4].shape[0])
+        out[f"{name}_ddgn_residual_cm"] = np.float64(step[5])
+        cfg.reg_dist_div_grad_norm = False
+        # ---- semantic head
+        cfg.semantic_on, cfg.sem_class_count, cfg.weight_s = True, 20, 1.0
+        cfg.sem_label_decimation = 1 if cfg.weighted_first else 3
+        cfg.freespace_label_on = not cfg.weighted_first
+        S = cfg.sem_class_count + 1
+        torch.manual_seed(77)
+        sem = m["Decoder"](cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, S)
+        with torch.no_grad():  # (default init on features of size 0.1 gives logits = the biases: scale the first layer and the head so that the argmax depends on the input)
+            sem.layers[0].weight.mul_(12.0); sem.lout.weight.mul_(6.0)
+        out[f"{name}_sem_dec_flat"] = flat_decoder(sem)
+        out[f"{name}_sem_heads"] = np.int64(S)
+        q = torch.from_numpy(d["query"])
+        gf, _, w, nn, _ = npts.query_feature(q.clone(), training_mode=False, query_locally=True)
+        out[f"{name}_sem_prob"] = t2n(sem.sem_label_prob(gf))   # [N, S] / [N, k, S]
+        trk = m["Tracker"](cfg, npts, {"sdf": dec, "semantic": sem, "color": None})
+        res = trk.query_source_points(q.clone(), cfg.infer_bs, True, False, False, False, query_sem=True, query_locally=True,
+                                      mask_min_nn_count=cfg.track_mask_query_nn_k)
+        out[f"{name}_sem_pred"] = t2n(res[4])
+        # ---- two mapping iterations with the semantic term
+        gen = torch.Generator().manual_seed(5 if cfg.weighted_first else 6)
+        ds = R.FakeDataset(n_frames=3)
+        mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": sem, "color": None})
+        mp.determine_used_pose()
+        bs, batches = cfg.bs, []
+        for it in range(2):
+            coord, label = surface_samples(gen, bs, 12.0, (16.0, 0.0), sigma=0.2)
+            ts = torch.randint(0, 3, (bs,), generator=gen).int()
+            w_ = torch.ones(bs)
+            sl = torch.randint(-1, S, (bs,), generator=gen).int()   # -1 unlabelled, 0 free space, 1..20 classes
+            batches.append((coord, label, ts, w_, sl))
+            out[f"{name}_map_coord{it}"] = t2n(coord); out[f"{name}_map_label{it}"] = t2n(label)
+            out[f"{name}_map_ts{it}"] = t2n(ts); out[f"{name}_map_sem{it}"] = t2n(sl)
+        box = {"i": 0}
+
+        def fake_get_batch(global_coord=False):
+            c, l, t, w_, sl = batches[box["i"]]
+            box["i"] += 1
+            return c.clone(), l.clone(), t.clone(), None, sl.clone(), None, w_.clone()
+
+        mp.get_batch = fake_get_batch
+        grads, nll = [], []
+        real_setup = m["mapper_mod"].setup_optimizer
+
+        def spy_setup(*a, **k):
+            opt = real_setup(*a, **k)
+            real_step = opt.step
+
+            def stepf(*aa, **kk):
+                grads.append(dict(feat=t2n(npts.local_geo_features.grad),
+                                  dec=np.concatenate([t2n(p.grad).ravel() for p in dec.parameters()]),
+                                  sem=np.concatenate([t2n(p.grad).ravel() for p in sem.parameters()])))
+                return real_step(*aa, **kk)
+
+            opt.step = stepf
+            return opt
+
+        real_nll = torch.nn.NLLLoss
+
+        class SpyNLL(real_nll):
+            def forward(self, a, b):
+                v = super().forward(a, b)
+                nll.append(float(v.detach()))
+                return v
+
+        m["mapper_mod"].setup_optimizer = spy_setup
+        torch.nn.NLLLoss = SpyNLL
+        try:
+            with LossSpy(m["mapper_mod"]) as spy:
+                mp.mapping(2)
+        finally:
+            m["mapper_mod"].setup_optimizer = real_setup
+            torch.nn.NLLLoss = real_nll
+        out[f"{name}_map_loss_sdf"] = np.asarray(spy.sdf, np.float64); out[f"{name}_map_loss_total"] = np.asarray(spy.total, np.float64)
+        out[f"{name}_map_loss_sem"] = np.asarray(nll, np.float64)
+        for it, g in enumerate(grads):
+            out[f"{name}_map_gfeat{it}"] = g["feat"]; out[f"{name}_map_gdec{it}"] = g["dec"]; out[f"{name}_map_gsem{it}"] = g["sem"]
+        out[f"{name}_map_feat_after"] = t2n(npts.local_geo_features.data)
+        out[f"{name}_map_dec_after"] = flat_decoder(dec)
+        out[f"{name}_map_sem_after"] = flat_decoder(sem)
+        for kname in ("sem_label_decimation", "freespace_label_on", "weight_s", "weight_e", "lr", "adam_eps", "gradient_decimation"):
+            out[f"{name}_cfg_{kname}"] = np.float64(getattr(cfg, kname))
+        out[f"{name}_map_eps"] = np.float64(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    return out
+
+
+def gen_process_sem():
+    """Mapper.process_frame with per-point semantic labels (mapper.py:221, 280-283, 349-350; data_sampler.py:59-62,
+    184-194): two frames of the `process` fixture's set-up; recorded: the scan, its labels, the random draws, and
+    sem_label_pool after the sampler / the pool filter (the other pools are the `process` fixture's business)."""
+    m = R.load()
+    cfg = R.make_config(voxel_size_m=0.4, buffer_size=40009, local_map_radius=22.0, local_map_travel_dist_ratio=5.0,
+                        bs=1024, bs_new_sample=256, feature_std=0.05, track_on=True, pool_capacity=20000,
+                        pool_filter_freq=1, new_certainty_thre=1.0, surface_sample_range_m=0.25,
+                        free_sample_end_dist_m=1.0, max_range=20.0, adaptive_iters=True, search_alpha=0.5, query_nn_k=6)
+    cfg.window_radius = 13.0
+    cfg.semantic_on, cfg.sem_class_count = True, 20
+    torch.manual_seed(7)
+    dec = m["Decoder"](cfg, 32, 1, 1)
+    sem = m["Decoder"](cfg, 32, 1, 21)
+    npts = m["NeuralPoints"](cfg)
+    nfr = 2
+    ds = R.FakeDataset(n_frames=nfr)
+    mp = m["Mapper"](cfg, ds, npts, {"sdf": dec, "semantic": sem, "color": None})
+    gen = torch.Generator().manual_seed(13)
+    out = dict(n_frames=np.int64(nfr), buffer_size=np.int64(cfg.buffer_size), resolution=np.float64(cfg.voxel_size_m))
+    for k in ("surface_sample_range_m", "surface_sample_n", "free_front_n", "free_behind_n", "free_sample_begin_ratio",
+              "free_sample_end_dist_m", "dist_weight_on", "dist_weight_scale", "max_range", "behind_dropoff_on",
+              "window_radius", "pool_capacity", "new_certainty_thre", "map_surface_ratio", "bs_new_sample"):
+        out[k] = np.asarray(getattr(cfg, k))
+    travel = [0.0]
+    for ts in range(nfr):
+        pose = np.eye(4)
+        pose[:3, 3] = [6.0 * ts, 0.5 * ts, 0.1 * ts]
+        if ts:
+            travel.append(travel[-1] + float(np.linalg.norm(pose[:3, 3] - prev[:3, 3])))
+        prev = pose
+        ds.odom_poses[ts] = pose
+        ds.processed_frame = ts
+        npts.travel_dist = torch.tensor(travel + [0.0] * (nfr - len(travel)), dtype=torch.float32)
+        scan = sheet_points(gen, 2000, 12.0)
+        labels = torch.randint(0, 21, (scan.shape[0],), generator=gen).int()
+        with _RngSpy() as spy:
+            mp.process_frame(scan, labels, torch.tensor(pose, dtype=torch.float64), ts)
+        f = f"f{ts}_"
+        out[f + "scan"] = t2n(scan); out[f + "labels"] = t2n(labels); out[f + "pose"] = pose
+        out[f + "rnd_surface"], out[f + "rnd_front"], out[f + "rnd_behind"] = (t2n(c[1]).reshape(-1) for c in spy.calls[:3])
+        disc = [c[1] for c in spy.calls if c[0] == "randint"]
+        out[f + "discard_index"] = t2n(disc[0]) if disc else np.zeros((0,), np.int64)
+        out[f + "after_sem_label_pool"] = t2n(mp.sem_label_pool)
+        out[f + "after_sdf_label_pool"] = t2n(mp.sdf_label_pool)
+        out[f + "pool_sample_count"] = np.int64(mp.pool_sample_count); out[f + "cur_sample_count"] = np.int64(mp.cur_sample_count)
+    out["travel_dist"] = np.asarray(travel, np.float32)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -853,6 +1047,16 @@ def main():
         np.savez_compressed(path, **d)
         print("preprocess ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", "train", len(d["idx_train"]), "cropped",
               len(d["cropped"]), "source", len(d["idx_source"]))
+    if only in (None, "variants"):
+        d = gen_variants()
+        path = os.path.join(OUT, "variants.npz")
+        np.savez_compressed(path, **d)
+        print("variants ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", {k: v for k, v in d.items() if "loss" in k or "ddgn_valid" in k})
+    if only in (None, "process_sem"):
+        d = gen_process_sem()
+        path = os.path.join(OUT, "process_sem.npz")
+        np.savez_compressed(path, **d)
+        print("process_sem ->", path, f"{os.path.getsize(path)/1e6:.2f} MB", [int(d[f"f{t}_pool_sample_count"]) for t in range(2)])
     if only not in (None, "update"):
         return
     d = gen_update()

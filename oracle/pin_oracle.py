@@ -644,6 +644,89 @@ def train_color_step(coord, sdf_label, color_label, sample_weight, searcher, cfe
     return dict(loss=loss, feat_grad=feat_grad, dec_grad=gflat, color_pred=pred)
 
 
+
+# --------------------------------------------------------------------------- semantic head
+def log_softmax(x):
+    """F.log_softmax(x, dim=-1) (model/decoder.py:100-103)."""
+    m = x.max(-1, keepdims=True)
+    return x - m - np.log(np.exp(x - m).sum(-1, keepdims=True))
+
+
+def sem_label_prob(z, params):
+    """Decoder.sem_label_prob (model/decoder.py:100-103): log_softmax(mlp(features)) over the heads."""
+    return log_softmax(mlp_forward(z, params))
+
+
+def sem_select_mask(sem_label, freespace_label_on=False, decimation=1):
+    """The samples the semantic loss runs over (utils/mapper.py:786-799): label_mask = label > 0 (>= 0 with
+    freespace_label_on), then every `decimation`-th of the masked samples in order (sem_pred[label_mask][::dec])."""
+    lab = np.asarray(sem_label)
+    mask = lab >= 0 if freespace_label_on else lab > 0
+    idx = np.nonzero(mask)[0][::max(1, int(decimation))]
+    sel = np.zeros(lab.shape[0], bool)
+    sel[idx] = True
+    return sel
+
+
+def query_sem(points, search, feats, positions, params, k, weighted_first=True, global2local=None, orientations=None,
+              dtype=np.float64):
+    """Tracker.query_source_points / Mesher.query_points with query_sem (utils/tracker.py:336-341, utils/mesher.py:137-145):
+    sem_pred = sem_label_prob(feature) -- per neighbour and summed with the IDW weights when not weighted_first -- and its
+    argmax.  Returns (sem_pred [N, S], label [N] int64, nn_count)."""
+    T = dtype
+    qf = query_feature(points, search, feats, positions, None, k, global2local, orientations, weighted_first=False)
+    fv = qf["geo_feat"].astype(T)
+    valid = qf["knn_idx"] >= 0
+    _, _, w = idw_weights(qf["knn_d2"], valid, qf["nn_count"], dtype=T)
+    params = tuple([x.astype(T) for x in p] if isinstance(p, list) else p.astype(T) for p in params)
+    if weighted_first:
+        pred = sem_label_prob((fv * w[..., None]).sum(1), params)
+    else:
+        pred = (sem_label_prob(fv, params) * w[..., None]).sum(1)
+    return pred, pred.argmax(-1), qf["nn_count"]
+
+
+def train_sem_step(coord, sem_label, searcher, feats, flat_params, dec_shape, k, *, weighted_first=True, weight_s=1.0,
+                   decimation=1, freespace_label_on=False, dtype=np.float64):
+    """Semantic term of Mapper.mapping (utils/mapper.py:664-667, 782-800): sem_pred = sem_label_prob(geo_feature)
+    (x weight_knn summed over the neighbours when not weighted_first), torch.nn.NLLLoss(mean) over the selected samples
+    (sem_select_mask), times weight_s; backward to the GEOMETRY features and the semantic decoder.  ``searcher(points)``
+    returns query_feature output over the geometry feature table with per-neighbour vectors.
+    Returns dict(loss (weight_s NOT applied, the reference's sem_loss), feat_grad, dec_grad, sem_pred, selected)."""
+    T = dtype
+    in_dim, hidden, levels, out_dim = dec_shape
+    params = unpack_decoder(np.asarray(flat_params, T), in_dim, hidden, levels, out_dim)
+    F = feats.shape[1]
+    feat_grad = np.zeros((feats.shape[0], F), T)
+    qf = searcher(coord)
+    fv = qf["geo_feat"].astype(T)
+    valid = qf["knn_idx"] >= 0
+    _, _, w = idw_weights(qf["knn_d2"], valid, qf["nn_count"], dtype=T)
+    z = (fv * w[..., None]).sum(1) if weighted_first else fv
+    out, acts = mlp_forward(z, params, keep=True)
+    lp = log_softmax(out)                                     # [N, S] or [N, k, S]
+    pred = lp if weighted_first else (lp * w[..., None]).sum(1)
+    sel = sem_select_mask(sem_label, freespace_label_on, decimation)
+    lab = np.asarray(sem_label).astype(np.int64)
+    n_s = int(sel.sum())
+    rows = np.nonzero(sel)[0]
+    loss = float(-pred[rows, lab[rows]].mean()) if n_s else 0.0
+    onehot = np.zeros(pred.shape, T)
+    onehot[rows, lab[rows]] = 1.0
+    coef = np.where(sel, weight_s / max(n_s, 1), 0.0).astype(T)    # d (weight_s * mean NLL) / d (-pred[i, label_i])
+    if weighted_first:
+        dout = coef[:, None] * (np.exp(lp) - onehot)               # d / d logits: softmax - onehot
+        dz, gflat = mlp_backward(acts, params, dout)
+        dfeat = w[..., None] * dz[:, None, :F]
+    else:
+        dout = coef[:, None, None] * w[..., None] * (np.exp(lp) - onehot[:, None, :])
+        dz, gflat = mlp_backward(acts, params, dout)
+        dfeat = dz[..., :F]
+    dfeat = np.where(valid[..., None], dfeat, 0.0)
+    np.add.at(feat_grad, np.where(valid, qf["knn_idx"], 0).reshape(-1), dfeat.reshape(-1, F))
+    return dict(loss=loss, feat_grad=feat_grad, dec_grad=gflat, sem_pred=pred, selected=sel)
+
+
 def adam_step(p, g, m, v, step, lr=0.01, b1=0.9, b2=0.99, eps=1e-15):
     """torch.optim.Adam (no amsgrad, no weight decay) as configured by
     utils/tools.py:198-199 (betas (0.9, 0.99), eps = adam_eps)."""
@@ -819,6 +902,17 @@ def sample_rays(points, colors, rnd_surface, rnd_front, rnd_behind, *, surface_r
         color = call.reshape(A, N, C).transpose(1, 0, 2).reshape(-1, C)
     return np.ascontiguousarray(coord), np.ascontiguousarray(label), color, np.ascontiguousarray(weight)
 
+
+
+def sample_sem_labels(labels, surface_n, front_n, behind_n):
+    """Semantic labels of DataSampler.sample's output rows (utils/data_sampler.py:59-62, 83-84, 105-106, 184-194 and the final
+    point-major reshape :104-107): the measured point and its surface_n close-to-surface samples carry the point's label,
+    the free-space samples label 0; row i * A + j belongs to point i."""
+    lab = np.asarray(labels, np.int32)
+    A = 1 + surface_n + front_n + behind_n
+    out = np.zeros((lab.shape[0], A), np.int32)
+    out[:, :1 + surface_n] = lab[:, None]
+    return out.reshape(-1)
 
 def pool_filter_mask(global_coord, origin, window_radius, pool_capacity=None, discard_index=None):
     """Distance window + random discard of Mapper.process_frame (utils/mapper.py:303-323).  The

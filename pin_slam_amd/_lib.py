@@ -131,6 +131,11 @@ class TrainColorParams(C.Structure):
                 ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("n_main_global", C.c_int32), ("surface_count", vp)]
 
 
+class SemParams(C.Structure):
+    _fields_ = [("n_main", C.c_int32), ("heads", C.c_int32), ("weight_s", C.c_float), ("reserved", C.c_int32), ("labels", vp),
+                ("selected", vp), ("count", vp)]
+
+
 class PreprocessParams(C.Structure):
     _fields_ = [("train_vox", C.c_float), ("source_vox", C.c_float), ("min_z", C.c_float), ("max_z", C.c_float),
                 ("min_range", C.c_float), ("max_range", C.c_float), ("correct_deg", C.c_double), ("want_source", C.c_int32),
@@ -143,7 +148,7 @@ class DpRegions(C.Structure):
 
 class PoolArrays(C.Structure):
     _fields_ = [("coord", vp), ("global_coord", vp), ("sdf_label", vp), ("weight", vp), ("ts", vp), ("color", vp),
-                ("color_channels", C.c_int32), ("reserved", C.c_int32)]
+                ("color_channels", C.c_int32), ("reserved", C.c_int32), ("sem_label", vp)]
 
 
 class SampleParams(C.Structure):
@@ -151,7 +156,7 @@ class SampleParams(C.Structure):
         ("surface_n", C.c_int32), ("front_n", C.c_int32), ("behind_n", C.c_int32), ("dist_weight_on", C.c_int32),
         ("behind_dropoff_on", C.c_int32), ("frame_id", C.c_int32), ("surface_range", C.c_double),
         ("free_begin_ratio", C.c_double), ("free_end_dist", C.c_double), ("dist_weight_scale", C.c_double),
-        ("max_range", C.c_double), ("pose", C.c_double * 12),
+        ("max_range", C.c_double), ("pose", C.c_double * 12), ("sem_labels", vp),
     ]
 
 
@@ -165,6 +170,12 @@ SIGNATURES = {
     "pin_warmup": (i32, []),
     "pin_last_error": (C.c_char_p, []),
     "pin_status": (i32, [vp, i32, vp]),
+    "pin_sem_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "pin_sem_select": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "pin_gather_labels_drawn": (i32, [vp, vp, i32, vp, vp, i32, i32, i64, i64, vp, vp]),
+    "pin_train_sem_step": (i32, [P(Field), P(SemParams), vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "pin_sem_query": (i32, [P(Field), vp, vp, vp, i32, i32, vp, vp, vp]),
+    "pin_decoder_sem": (i32, [P(Field), vp, i32, i32, i32, vp, vp]),
     "pin_candidate_offsets": (i32, [vp, i32, i64, vp]),
     "pin_pack_positions": (i32, [vp, vp, i32, i32, vp, vp]),
     "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),

@@ -38,6 +38,13 @@ class PinConfig:
         self.color_on = False
         self.color_channel = 0
         self.semantic_on = False
+        # semantic head (config.py:70-74, 143-144, 186)
+        self.sem_class_count = 20
+        self.sem_label_decimation = 1
+        self.freespace_label_on = False
+        self.sem_mlp_level = 1
+        self.sem_mlp_hidden_dim = 64
+        self.weight_s = 1.0
         # local map (config.py:113-116)
         self.diff_ts_local = 400.0
         self.local_map_travel_dist_ratio = 5.0

@@ -30,7 +30,8 @@ struct SampleConsts {  // python-double config values cast to float32 where torc
 __global__ __launch_bounds__(MB) void sample_rays_kernel(SampleConsts sc, const float* __restrict__ points,
                                                          const float* __restrict__ colors, int stride, int n,
                                                          const float* __restrict__ rnd_s, const float* __restrict__ rnd_f,
-                                                         const float* __restrict__ rnd_b, pin_pool_arrays out) {
+                                                         const float* __restrict__ rnd_b, pin_pool_arrays out,
+                                                         const int* __restrict__ sem_labels) {
 #pragma clang fp contract(off)
     const long idx = (long)blockIdx.x * MB + threadIdx.x;
     if (idx >= (long)n * sc.A) return;
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(MB) void sample_rays_kernel(SampleConsts sc, const 
     if (sc.C > 0) {
         for (int c = 0; c < sc.C; ++c) out.color[o * sc.C + c] = surface ? colors[(size_t)i * stride + c] : 0.0f;
     }
+    // semantic label: the point's for the measured point and its close-to-surface samples, 0 (free space) for the others
+    if (out.sem_label != nullptr) out.sem_label[o] = (surface && sem_labels != nullptr) ? sem_labels[i] : 0;
 }
 
 // ---- K13 ------------------------------------------------------------------------------------
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(MB) void pool_scatter_kernel(pin_pool_arrays src, p
     dst.ts[d] = src.ts[s];
     if (src.color_channels > 0)
         for (int c = 0; c < src.color_channels; ++c) dst.color[d * src.color_channels + c] = src.color[s * src.color_channels + c];
+    if (src.sem_label != nullptr) dst.sem_label[d] = src.sem_label[s];
 }
 
 // ---- K14 ------------------------------------------------------------------------------------
@@ -301,6 +305,7 @@ extern "C" int pin_sample_rays(const pin_sample_params* p, const float* points, 
     PIN_CHECK_ARG((p->surface_n == 0 || rnd_surface) && (p->front_n == 0 || rnd_front) && (p->behind_n == 0 || rnd_behind),
                   "random draws NULL");
     PIN_CHECK_ARG(out->color_channels == 0 || colors, "colour pool without scan colours");
+    PIN_CHECK_ARG(p->sem_labels == nullptr || out->sem_label != nullptr, "semantic labels without a label pool");
     SampleConsts sc;
     sc.S = p->surface_n; sc.Ff = p->front_n; sc.Fb = p->behind_n; sc.A = sc.S + sc.Ff + sc.Fb + 1;
     PIN_CHECK_ARG((long)n * sc.A < (1L << 31), "too many samples for one call");
@@ -319,7 +324,7 @@ extern "C" int pin_sample_rays(const pin_sample_params* p, const float* points, 
     sc.frame_id = p->frame_id;
     for (int i = 0; i < 12; ++i) sc.pose[i] = (float)p->pose[i];
     hipLaunchKernelGGL(sample_rays_kernel, dim3(cdiv((long)n * sc.A, MB)), dim3(MB), 0, as_stream(stream), sc, points, colors,
-                       row_stride, n, rnd_surface, rnd_front, rnd_behind, *out);
+                       row_stride, n, rnd_surface, rnd_front, rnd_behind, *out, p->sem_labels);
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -367,6 +372,7 @@ extern "C" int pin_pool_compact(const pin_pool_arrays* src, const pin_pool_array
     if (int e = check_pool(src, "pin_pool_compact(src)")) return e;
     if (int e = check_pool(dst, "pin_pool_compact(dst)")) return e;
     PIN_CHECK_ARG(src->color_channels == dst->color_channels, "colour channel mismatch");
+    PIN_CHECK_ARG((src->sem_label == nullptr) == (dst->sem_label == nullptr), "semantic label pool on one side only");
     PIN_CHECK_ARG(src->coord != dst->coord, "compaction is out of place: src and dst must differ");
     PIN_CHECK_ARG(mask && workspace && workspace_bytes >= pin_pool_workspace_bytes(n), "mask NULL or workspace too small");
     Carver cv{static_cast<char*>(workspace), static_cast<char*>(workspace) + workspace_bytes};

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) void train_dw_kernel(TrainWs ws, DwLayers dl, 
 }
 
 }  // namespace pin
+#include "sem.h"
 #include "train_fused.h"
 
 namespace pin {
@@ -1424,6 +1425,127 @@ extern "C" int pin_train_color_step(const pin_field* fc, const pin_train_color_p
         dl.per_wave = per_wave;
         hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(QT, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
     }
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- semantic head (sem.h) ----------------------------------------------------------------------------------------------------
+static size_t sem_ws_floats(int Q, int H, int L, int expand) {
+    const size_t Qs = (size_t)((Q + 63) / 64) * 64, QsT = Qs * (size_t)(expand < 1 ? 1 : expand);
+    return QsT * (12 + (size_t)L * H + (size_t)L * H + SEM_MAX_HEADS);
+}
+
+extern "C" int64_t pin_sem_workspace_bytes(int32_t n_queries, int32_t hidden, int32_t levels, int32_t expand) {
+    return (int64_t)sem_ws_floats(n_queries, hidden, levels, expand) * 4 + 256;
+}
+
+extern "C" int pin_sem_select(const int32_t* labels, int32_t n, int32_t freespace_label_on, int32_t decimation, uint8_t* selected_out,
+                              int32_t* count_out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && decimation >= 1 && count_out, "bad arguments");
+    hipStream_t s = as_stream(stream);
+    PIN_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int), s));
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(labels && selected_out, "NULL pointer");
+    hipLaunchKernelGGL(sem_select_kernel, dim3(1), dim3(1024), 0, s, labels, n, freespace_label_on, decimation, selected_out, count_out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_gather_labels_drawn(const int32_t* pool_sem, const int64_t* index_history, int32_t n_history,
+                                       const int64_t* index_new_batch, const int64_t* new_idx, int32_t n, int32_t n_batches,
+                                       int64_t hist_stride, int64_t new_stride, int32_t* out, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(n >= 0 && n_batches >= 0 && n_batches <= 65535 && n_history >= 0 && n_history <= n, "bad sizes");
+    if (n == 0 || n_batches == 0) return 0;
+    PIN_CHECK_ARG(pool_sem && out && (n_history == 0 || index_history) && (n_history == n || (index_new_batch && new_idx)), "NULL pointer");
+    hipLaunchKernelGGL(gather_labels_drawn_kernel, dim3(cdiv(n, 256), n_batches), dim3(256), 0, as_stream(stream), pool_sem,
+                       reinterpret_cast<const long long*>(index_history), n_history, reinterpret_cast<const long long*>(index_new_batch),
+                       reinterpret_cast<const long long*>(new_idx), n, (long)hist_stride, (long)new_stride, out);
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_sem_field(const pin_field* f, int heads) {
+    PIN_CHECK_ARG(f != nullptr && f->dec != nullptr, "field / decoder NULL");
+    PIN_CHECK_ARG(f->k >= 1 && f->k <= PIN_MAX_K && (f->hidden == 32 || f->hidden == 64) && f->levels >= 1 && f->levels <= MLP_MAX_LEVELS,
+                  "bad semantic field (k, hidden in {32, 64}, 1..4 layers)");
+    PIN_CHECK_ARG(heads >= 2 && heads <= SEM_MAX_HEADS, "semantic heads must be in [2, 32] (sem_class_count + 1)");
+    return 0;
+}
+
+extern "C" int pin_train_sem_step(const pin_field* f, const pin_sem_params* sp, const float* query, const float* nbr,
+                                  const int32_t* nn_count, float* feat_grad, float* dec_grad, double* loss_out, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(sp != nullptr, "params NULL");
+    if (int e = check_sem_field(f, sp->heads)) return e;
+    const int Q = sp->n_main, H = f->hidden, L = f->levels;
+    if (Q == 0) return 0;
+    PIN_CHECK_ARG(Q > 0, "bad batch size");
+    const int expand = f->weighted_first ? 1 : f->k;
+    PIN_CHECK_ARG(workspace && workspace_bytes >= pin_sem_workspace_bytes(Q, H, L, expand), "workspace too small");
+    PIN_CHECK_ARG(query && nbr && nn_count && feat_grad && loss_out && f->feats && sp->labels && sp->selected && sp->count, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    TrainWs ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.Qs = ((Q + 63) / 64) * 64;
+    ws.QsT = ws.Qs * expand;
+    float* w = reinterpret_cast<float*>(workspace);
+    ws.z = w; w += (size_t)12 * ws.QsT;
+    ws.h = w; w += (size_t)L * H * ws.QsT;
+    ws.d = w;
+    SemTrain st;
+    st.labels = sp->labels; st.sel = sp->selected; st.count = sp->count; st.weight_s = sp->weight_s; st.S = sp->heads;
+    const int want_dec = dec_grad != nullptr;
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    const dim3 grid(cdiv(ws.Qs, MF_BLOCK)), block(MF_BLOCK);
+#define PIN_SEM_T(HH, WW) hipLaunchKernelGGL((sem_train_kernel<HH, WW>), grid, block, 0, s, *f, query, nb4, nn_count, Q, ws, st, feat_grad, want_dec, loss_out)
+    if (H == 64) { if (f->weighted_first) PIN_SEM_T(64, true); else PIN_SEM_T(64, false); }
+    else { if (f->weighted_first) PIN_SEM_T(32, true); else PIN_SEM_T(32, false); }
+#undef PIN_SEM_T
+    PIN_CHECK_LAUNCH();
+    if (want_dec) {  // dW_l = sum_q delta_l[q] (x) input_l[q] over the unit-major rows (train_dw_kernel; the head layer has `heads` rows)
+        DwLayers dl;
+        const int QT = expand == 1 ? Q : ws.QsT;
+        dl.H = H; dl.L = L; dl.Q = QT; dl.Qs = ws.QsT; dl.OD = sp->heads;
+        int per_wave = 64;
+        while ((long)cdiv(QT, per_wave * 4) > 256) per_wave *= 2;
+        dl.per_wave = per_wave;
+        hipLaunchKernelGGL(train_dw_kernel, dim3(cdiv(QT, per_wave * 4), L + 1), dim3(256), 0, s, ws, dl, dec_grad);
+        PIN_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int pin_sem_query(const pin_field* f, const float* query, const float* nbr, const int32_t* nn_count, int32_t n, int32_t heads,
+                             int32_t* label_out, float* logprob_out, void* stream) {
+    PIN_ENTER();
+    if (int e = check_sem_field(f, heads)) return e;
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(query && nbr && nn_count && f->feats && (label_out || logprob_out), "NULL pointer");
+    const float4* nb4 = reinterpret_cast<const float4*>(nbr);
+    const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
+    hipStream_t s = as_stream(stream);
+#define PIN_SEM_Q(HH, WW) hipLaunchKernelGGL((sem_query_kernel<HH, WW, 0>), grid, block, 0, s, *f, query, nb4, nn_count, n, heads, 0, label_out, logprob_out)
+    if (f->hidden == 64) { if (f->weighted_first) PIN_SEM_Q(64, true); else PIN_SEM_Q(64, false); }
+    else { if (f->weighted_first) PIN_SEM_Q(32, true); else PIN_SEM_Q(32, false); }
+#undef PIN_SEM_Q
+    PIN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pin_decoder_sem(const pin_field* f, const float* feat_in, int32_t n, int32_t heads, int32_t raw, float* out, void* stream) {
+    PIN_ENTER();
+    if (int e = check_sem_field(f, heads)) return e;
+    PIN_CHECK_ARG(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    PIN_CHECK_ARG(feat_in && out, "NULL pointer");
+    const dim3 grid(cdiv(n, MF_BLOCK)), block(MF_BLOCK);
+    hipStream_t s = as_stream(stream);
+    if (f->hidden == 64) hipLaunchKernelGGL((sem_query_kernel<64, true, 1>), grid, block, 0, s, *f, feat_in, (const float4*)nullptr, (const int*)nullptr, n, heads, raw, (int*)nullptr, out);
+    else hipLaunchKernelGGL((sem_query_kernel<32, true, 1>), grid, block, 0, s, *f, feat_in, (const float4*)nullptr, (const int*)nullptr, n, heads, raw, (int*)nullptr, out);
     PIN_CHECK_LAUNCH();
     return 0;
 }

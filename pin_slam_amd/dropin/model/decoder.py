@@ -71,6 +71,8 @@ class Decoder(nn.Module):
                               out_dim=self.out_dim)
 
     def mlp(self, features):
+        if self.out_dim > 3:  # the semantic decoder's raw outputs (sem_class_count + 1 heads)
+            return self._sem(features, raw=True)
         if self.out_dim != 1:
             raise NotImplementedError("raw multi-head outputs are only reachable through regress_color (3 heads)")
         shape = features.shape[:-1]
@@ -93,5 +95,17 @@ class Decoder(nn.Module):
         f = features.detach().reshape(-1, 11).to(torch.float32).contiguous()
         return ops.decoder_color(self._field(), f).reshape(*shape, 3)
 
+    def _sem(self, features, raw: bool):
+        if not 2 <= self.out_dim <= 32:
+            raise NotImplementedError("libpinhip semantic decoders have 2..32 heads (sem_class_count + 1)")
+        shape = features.shape[:-1]
+        f = features.detach().reshape(-1, 11).to(torch.float32).contiguous()
+        return ops.decoder_sem(self._field(), f, self.out_dim, raw=raw).reshape(*shape, self.out_dim)
+
     def sem_label_prob(self, features):
-        raise NotImplementedError("semantic decoder head is out of the benchmark scope")
+        """F.log_softmax(mlp(features), dim=-1) (decoder.py:100-103); [..., 11] -> [..., heads]."""
+        return self._sem(features, raw=False)
+
+    def sem_label(self, features):
+        """decoder.py:105-107."""
+        return torch.argmax(self.sem_label_prob(features), dim=1)

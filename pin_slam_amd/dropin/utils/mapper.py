@@ -46,6 +46,7 @@ class _StandaloneBase:
         self.global_coord_pool = torch.empty((0, 3), device=d, dtype=f)
         self.sdf_label_pool = torch.empty((0,), device=d, dtype=f)
         self.color_pool = torch.empty((0, self.config.color_channel), device=d, dtype=f) if self.config.color_on else None
+        self.sem_label_pool = torch.empty((0,), device=d, dtype=torch.int) if getattr(self.config, "semantic_on", False) else None
         self.weight_pool = torch.empty((0,), device=d, dtype=f)
         self.time_pool = torch.empty((0,), device=d, dtype=torch.int)
         self.pool_sample_count = 0
@@ -127,13 +128,14 @@ class Mapper(_StandaloneBase):
 
     # ------------------------------------------------------------------ data pool
     _POOL_ATTRS = (("coord_pool", "coord"), ("global_coord_pool", "global_coord"), ("sdf_label_pool", "sdf_label"),
-                   ("weight_pool", "weight"), ("time_pool", "ts"), ("color_pool", "color"))
+                   ("weight_pool", "weight"), ("time_pool", "ts"), ("color_pool", "color"), ("sem_label_pool", "sem_label"))
 
     def _pool(self) -> pool_mod.SamplePool:
         c = self.config
         C = int(c.color_channel) if c.color_on else 0
-        if self._spool is None or self._spool.C != C:
-            self._spool = pool_mod.SamplePool(self.device, color_channels=C)
+        sem = bool(getattr(c, "semantic_on", False))
+        if self._spool is None or self._spool.C != C or self._spool.semantic != sem:
+            self._spool = pool_mod.SamplePool(self.device, color_channels=C, semantic=sem)
             self._spool.clear()
         p = self._spool
         # somebody replaced a pool tensor (init_pool, transform_data_pool, bundle adjustment, a test): adopt it
@@ -157,7 +159,7 @@ class Mapper(_StandaloneBase):
         p = self._spool
         for attr, name in self._POOL_ATTRS:
             setattr(self, attr, p.view(name))
-        self.sem_label_pool = self.normal_label_pool = None
+        self.normal_label_pool = None
         self.pool_sample_count = p.n
 
     def dynamic_filter(self, points_torch, type_2_on: bool = True):
@@ -179,8 +181,9 @@ class Mapper(_StandaloneBase):
         pool tail, the filter compacts between the pool's two generations; host syncs = the
         counts the reference reads back as well."""
         c, npts = self.config, self.neural_points
-        if frame_label_torch is not None or getattr(c, "semantic_on", False):
-            raise NotImplementedError("semantic labels are outside the hot-path scope")
+        sem_on = bool(getattr(c, "semantic_on", False))
+        if frame_label_torch is not None and not sem_on:
+            frame_label_torch = None  # (the reference's sampler would carry them into a pool nothing reads, mapper.py:280-283)
         if self.ba_done_flag:
             raise NotImplementedError("process_frame after bundle adjustment (pool re-projection with per-frame poses)")
         if c.color_on and c.color_channel not in (1, 3):
@@ -201,13 +204,15 @@ class Mapper(_StandaloneBase):
             ops.transform_points(scan, pose_np, glob)
             self.static_mask = self.dynamic_filter(glob)
             scan = scan[self.static_mask].contiguous()
+            if frame_label_torch is not None:
+                frame_label_torch = frame_label_torch[self.static_mask]
         self.dataset.static_mask = self.static_mask
 
         hostcache.stamp("pf:before_sampler")
         # K12: DataSampler.sample + pool append + sensor->world transform
         p = self._pool()
         n_hist = p.n
-        n_new = p.append_samples(scan, pool_mod.sample_params(c, pose_np, frame_id))
+        n_new = p.append_samples(scan, pool_mod.sample_params(c, pose_np, frame_id), sem_labels=frame_label_torch if sem_on else None)
         self.cur_sample_count = n_new
         self.pool_sample_count = n_hist
         hostcache.stamp("pf:sampler_enqueued")
@@ -373,7 +378,15 @@ class Mapper(_StandaloneBase):
             0 if _queries_for is None else _queries_for.eik_first,
             0.0 if _queries_for is None else float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
             ops._stream()), "pin_gather_batch_drawn")
-        return out[0], out[1], out[3], None, None, color, out[2]
+        sem = None
+        if p.semantic:  # sem_label = sem_label_pool[index] (mapper.py:490-491)
+            sem = torch.empty((nb,), dtype=torch.int32, device=dev)
+            _lib.check(L.pin_gather_labels_drawn(
+                b["sem_label"].data_ptr(), index_history.data_ptr() + 8 * h_lo, h_hi - h_lo,
+                None if index_new_batch is None else index_new_batch.data_ptr() + 8 * n_lo,
+                None if index_new_batch is None else new_idx.data_ptr(), nb, 1, 0, 0, sem.data_ptr(), ops._stream()),
+                "pin_gather_labels_drawn")
+        return out[0], out[1], out[3], None, sem, color, out[2]
 
     def _gather_group(self, t, it0, gn, global_coord):
         """get_batch for iterations it0 .. it0 + gn - 1 in ONE launch (pin_gather_batches_drawn): the drawn index rows of
@@ -381,14 +394,15 @@ class Mapper(_StandaloneBase):
         c, p, drawn, buf = self.config, self._pool(), self._drawn, t.buf
         hist, new = drawn["hist"], drawn["new"]
         nb, n_hist = c.bs, hist.shape[1]
-        key = (buf.group, nb, p.C)
+        key = (buf.group, nb, p.C, p.semantic)
         if getattr(self, "_group_key", None) != key:
             dev, G = self.device, buf.group
             self._group_out = (torch.empty((G, nb, 3), dtype=torch.float32, device=dev), torch.empty((G, nb), dtype=torch.float32, device=dev),
                                torch.empty((G, nb), dtype=torch.float32, device=dev), torch.empty((G, nb), dtype=torch.int32, device=dev),
-                               torch.empty((G, nb, p.C), dtype=torch.float32, device=dev) if p.C else None)
+                               torch.empty((G, nb, p.C), dtype=torch.float32, device=dev) if p.C else None,
+                               torch.empty((G, nb), dtype=torch.int32, device=dev) if p.semantic else None)
             self._group_key = key
-        coord, label, weight, ts, color = self._group_out
+        coord, label, weight, ts, color, sem = self._group_out
         b = p.bufs[0]
         _lib.check(_lib.lib().pin_gather_batches_drawn(
             (b["global_coord"] if global_coord else b["coord"]).data_ptr(), b["sdf_label"].data_ptr(), b["weight"].data_ptr(),
@@ -397,7 +411,12 @@ class Mapper(_StandaloneBase):
             nb, coord.data_ptr(), label.data_ptr(), weight.data_ptr(), ts.data_ptr(), None if color is None else color.data_ptr(),
             buf.query_all.data_ptr(), buf.n_eik, buf.dec, buf.eik_first, float(np.float32(c.voxel_size_m * c.num_grad_step_ratio)),
             gn, n_hist, 0 if new is None else new.shape[1], ops._stream()), "pin_gather_batches_drawn")
-        return coord, label, weight, ts, color
+        if sem is not None:
+            _lib.check(_lib.lib().pin_gather_labels_drawn(
+                b["sem_label"].data_ptr(), hist.data_ptr() + 8 * it0 * n_hist, n_hist,
+                None if new is None else new.data_ptr() + 8 * it0 * new.shape[1], None if new is None else self.new_idx.data_ptr(),
+                nb, gn, n_hist, 0 if new is None else new.shape[1], sem.data_ptr(), ops._stream()), "pin_gather_labels_drawn")
+        return coord, label, weight, ts, color, sem
 
     def _pool_records(self, t, iters):
         """Neighbour records of every pool sample, once per Mapper.mapping call, when the call draws at least
@@ -458,7 +477,10 @@ class Mapper(_StandaloneBase):
     def _check_supported(self):
         c = self.config
         bad = []
-        if getattr(c, "semantic_on", False): bad.append("semantic_on")
+        if getattr(c, "semantic_on", False):
+            if self.sem_mlp is None: bad.append("semantic_on without a semantic decoder")
+            elif not 2 <= int(self.sem_mlp.out_dim) <= 32: bad.append("semantic decoder with more than 32 heads")
+            if self.dp_comm is not None: bad.append("semantic_on on the data-parallel mapper")
         if getattr(c, "color_on", False) and c.weight_i > 0 and c.color_channel != 3: bad.append("color_channel != 3")
         if c.main_loss_type != "bce": bad.append("main_loss_type != bce")
         if c.proj_correction_on or c.consistency_loss_on: bad.append("proj_correction / consistency loss")
@@ -498,6 +520,13 @@ class Mapper(_StandaloneBase):
                         train_decoder=bool(self.color_mlp.lout.weight.requires_grad))
         else:
             t.set_color(None)
+        if getattr(c, "semantic_on", False) and c.weight_s > 0:  # semantic branch (mapper.py:664-667, 782-800)
+            fsem = npts.field_state(self.sem_mlp, query_locally=True)
+            t.set_semantic(fsem, heads=int(self.sem_mlp.out_dim), weight_s=c.weight_s, decimation=int(c.sem_label_decimation),
+                           freespace_label_on=bool(getattr(c, "freespace_label_on", False)),
+                           train_decoder=bool(self.sem_mlp.lout.weight.requires_grad))
+        else:
+            t.set_semantic(None)
         # (the build may still be running on its side stream: mapping() orders this stream behind it right in front of its
         # first search, after the optimiser reset, the batch draws and the first gather launch have been queued)
         b = npts._peek_bricks() if peek_bricks else npts._use_bricks()
@@ -549,14 +578,14 @@ class Mapper(_StandaloneBase):
                     else:
                         self._records_group(t, it0, gn, reuse)
                     for j in range(gn):
-                        coord, sdf_label, weight, ts, color_label = (None if o is None else o[j] for o in outs)
+                        coord, sdf_label, weight, ts, color_label, sem_label = (None if o is None else o[j] for o in outs)
                         if t.fc is not None and color_label is None:
                             raise RuntimeError("color_on but the data pool holds no colour labels")
                         t.buf.select(j)
                         t.step_batch(coord, sdf_label, weight, ts, it0 + j + 1,
                                      color_label=None if t.fc is None else
                                      (color_label if color_label.shape[1] == 3 else color_label[:, :3].contiguous()),
-                                     queries_ready=True, knn_ready=True)
+                                     queries_ready=True, knn_ready=True, sem_label=sem_label)
                         self.total_iter += 1
                 t.buf.select(0)
                 if reuse is not None:
@@ -565,14 +594,14 @@ class Mapper(_StandaloneBase):
                 self.neural_points._use_bricks()
             for it in range(0 if not grouped else iter_count, iter_count):
                 self._queries_for = fused_q
-                coord, sdf_label, ts, _, _, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
+                coord, sdf_label, ts, _, sem_label, color_label, weight = self.get_batch(global_coord=not self.ba_done_flag)
                 self._queries_for = None
                 if t.fc is not None and color_label is None:
                     raise RuntimeError("color_on but the data pool holds no colour labels")
                 t.step_batch(coord, sdf_label, weight, ts, it + 1,
                              color_label=None if t.fc is None else
                              (color_label if color_label.shape[1] == 3 else color_label[:, :3].contiguous()),
-                             queries_ready=fused_q is not None)
+                             queries_ready=fused_q is not None, sem_label=sem_label)
                 self.total_iter += 1
         finally:
             self._queries_for = self._drawn = self._shard = None

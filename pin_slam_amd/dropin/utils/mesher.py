@@ -50,8 +50,8 @@ class Mesher(_Base):
 
     def query_points(self, coord, bs, query_sdf=True, query_sem=False, query_color=False, query_mask=True,
                      query_locally=False, mask_min_nn_count: int = 4, out_torch: bool = False):
-        if query_sem:
-            raise NotImplementedError("semantic queries are out of the hot-path scope")
+        if query_sem and self.sem_mlp is None:
+            raise RuntimeError("query_sem without a semantic decoder (config.semantic_on)")
         if query_color and self.config.color_channel != 3:
             raise NotImplementedError("libpinhip colour decoders have 3 heads (color_channel = 3)")
         npts = self.neural_points
@@ -60,6 +60,8 @@ class Mesher(_Base):
         sdf_d = torch.zeros(n, dtype=torch.float32, device=dev) if query_sdf else None
         col_d = torch.zeros((n, 3), dtype=torch.float32, device=dev) if query_color else None
         mask_d = torch.zeros(n, dtype=torch.bool, device=dev) if query_mask else None
+        sem_d = torch.zeros(n, dtype=torch.float32, device=dev) if query_sem else None
+        fsem = npts.field_state(self.sem_mlp, query_locally=query_locally) if query_sem else None
         fs = npts.field_state(self.sdf_mlp, query_locally=query_locally) if query_sdf else None
         fc = npts.field_state(self.color_mlp, query_locally=query_locally, color=True) if query_color else None
         for fld in (fs, fc):  # the decoders do not change during the call: one staged image for all its launches
@@ -90,6 +92,9 @@ class Mesher(_Base):
             if query_color:
                 col, _, _ = ops.color_query(fc, q, nbr, nn, want_grad=False)
                 col_d[head:tail] = col
+            if query_sem:  # argmax of the (weighted) log-probabilities (mesher.py:137-145)
+                lab, _ = ops.sem_query(fsem, q, nbr, nn, int(self.sem_mlp.out_dim))
+                sem_d[head:tail] = lab
             if query_mask:
                 mask_d[head:tail] = nn >= mask_min_nn_count
         def out(t, as_float64=False):
@@ -97,4 +102,4 @@ class Mesher(_Base):
                 return None
             t = t.float().cpu()
             return t if out_torch else (t.numpy().astype(np.float64))
-        return out(sdf_d), None, out(col_d), out(mask_d)
+        return out(sdf_d), out(sem_d), out(col_d), out(mask_d)

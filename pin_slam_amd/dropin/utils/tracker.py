@@ -122,8 +122,8 @@ class Tracker:
     def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, query_color=False,
                             query_color_grad=False, query_sem=False, query_mask=True, query_certainty=True,
                             query_locally=True, mask_min_nn_count: int = 4):
-        if query_sem:
-            raise NotImplementedError("semantic queries are out of the hot-path scope")
+        if query_sem and self.sem_mlp is None:
+            raise RuntimeError("query_sem without a semantic decoder (config.semantic_on)")
         if (query_color or query_color_grad) and self.config.color_channel != 3:
             raise NotImplementedError("libpinhip colour decoders have 3 heads (color_channel = 3)")
         npts = self.neural_points
@@ -144,8 +144,13 @@ class Tracker:
                     color_grad[:, ch, :] = g
             else:
                 color, _, _ = ops.color_query(fc, q, nbr, nn, want_grad=False)
+        sem = None
+        if query_sem:  # argmax of the (weighted) log-probabilities (tracker.py:336-341); a float tensor as the reference's buffer
+            fsem = npts.field_state(self.sem_mlp, query_locally=query_locally)
+            lab, _ = ops.sem_query(fsem, q, nbr, nn, int(self.sem_mlp.out_dim))
+            sem = lab.to(torch.float32)
         mask = (nn >= mask_min_nn_count) if query_mask else None
-        return sdf, grad, color, color_grad, None, mask, (cert if query_certainty else None), std
+        return sdf, grad, color, color_grad, sem, mask, (cert if query_certainty else None), std
 
     def registration_step(self, points, normals, sdf_labels, colors, min_grad_norm, max_grad_norm, GM_dist=None,
                           GM_grad=None, lm_lambda=0.0, vis_weight_pc=False):

@@ -251,6 +251,7 @@ class MapTrainer:
         self.total_iter = 0
         self.bricks = None
         self.fc = None  # colour field (set_color)
+        self.fsem = None  # semantic field (set_semantic)
 
     def resize(self, fs: ops.FieldState):
         """Point the optimiser buffers at `fs` (the local map changes size every frame): views of
@@ -292,6 +293,41 @@ class MapTrainer:
             self.cm, self.cv = torch.zeros_like(self.cgrad), torch.zeros_like(self.cgrad)
         self.fc, self.c_range, self.c_weight, self.c_train_dec = fc, float(surface_range), float(weight_i), train_decoder
         self.cgdec = self.cgrad[:nd]  # (spatial shards: re-pointed at the exchange buffer by plan_shards)
+
+    def set_semantic(self, fsem: Optional[ops.FieldState], heads: int = 0, weight_s: float = 0.0, decimation: int = 1,
+                     freespace_label_on: bool = False, train_decoder: bool = True):
+        """Enable the semantic branch of Mapper.mapping (mapper.py:664-667, 782-800): a decoder with `heads` outputs over the
+        geometry features (fsem.feats is fs.feats), log-softmax, NLL on the labelled samples.  Its feature gradients add into
+        the geometry gradient buffer (one optimiser over both terms, as the reference's single backward), the decoder has its
+        own dense Adam state."""
+        if fsem is None:
+            self.fsem = None
+            return
+        if self.comm is not None:
+            raise NotImplementedError("semantic training on the data-parallel mapper (no shipped configuration; run it on one GPU)")
+        nd = fsem.dec.numel()
+        if self.fsem is None or self.sgdec.numel() != nd:
+            dev = fsem.feats.device
+            self.sgdec = torch.zeros((nd,), dtype=torch.float32, device=dev)
+            self.sm, self.sv = torch.zeros_like(self.sgdec), torch.zeros_like(self.sgdec)
+            self._sem_sel = None
+        self.fsem, self.s_heads, self.s_weight, self.s_dec = fsem, int(heads), float(weight_s), max(1, int(decimation))
+        self.s_freespace, self.s_train_dec = bool(freespace_label_on), bool(train_decoder)
+
+    def _semantic_step(self, sem_label, step: int):
+        """The semantic term of the iteration just run by train_step (same queries / records), then the decoder's Adam step."""
+        n = self.buf.n_main
+        if sem_label is None:
+            raise RuntimeError("semantic_on but the batch carries no semantic labels (Mapper.process_frame needs frame labels)")
+        if self._sem_sel is None or self._sem_sel[0].shape[0] < n:
+            dev = self.fsem.feats.device
+            self._sem_sel = (torch.empty((max(n, self.bs_local),), dtype=torch.uint8, device=dev), torch.empty((1,), dtype=torch.int32, device=dev))
+        sel, cnt = ops.sem_select(sem_label[:n], self.s_freespace, self.s_dec, out=(self._sem_sel[0][:n], self._sem_sel[1]))
+        self.sem_loss = ops.train_sem_step(self.fsem, self.buf, sem_label[:n], sel, cnt, self.gfeat, self.sgdec if self.s_train_dec else None,
+                                           heads=self.s_heads, weight_s=self.s_weight)
+        self.sem_count = cnt
+        if self.s_train_dec:
+            ops.adam_step(self.fsem.dec, self.sgdec, self.sm, self.sv, step, self.lr, eps=self.adam_eps)
 
     # ------------------------------------------------------------------ spatially sharded data-parallel mapping (dp.py)
     def plan_shards(self, pool_coord, hist, new, new_idx, num_nei_cells: int, pool_rows=None, pool_label=None, reuse_records=False):
@@ -374,7 +410,7 @@ class MapTrainer:
                       bricks=self.bricks)
 
     def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False,
-                   knn_ready: bool = False, surface_count=None):
+                   knn_ready: bool = False, surface_count=None, sem_label=None):
         """One iteration on an explicit (already gathered) batch shard.  queries_ready: buf.query already holds this
         batch's queries (written by the gather launch); knn_ready: buf.nbr / buf.nn hold their neighbours (knn_group)."""
         nd = self.gdec.numel()
@@ -447,6 +483,8 @@ class MapTrainer:
                 self.lazy.step_dense(dense, step)
                 self._wg_ev[1].record(side)
             self._wg_pending = True
+        if self.fsem is not None and coord.shape[0] > 0:  # semantic branch: adds into the geometry feature gradients of this iteration
+            self._semantic_step(sem_label, step)
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
@@ -602,6 +640,10 @@ class MapTrainer:
         if not getattr(self, "_grad_clean", False):
             self.grad.zero_()
         self._grad_clean = False
+        if self.fsem is not None:  # a new Adam per call (mapper.py:615) for the semantic decoder as well
+            self.sm.zero_()
+            self.sv.zero_()
+            self.sgdec.zero_()
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             if self.lazy_on:

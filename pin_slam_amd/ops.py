@@ -551,6 +551,59 @@ def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, 
     return buf.color_loss
 
 
+# ------------------------------------------------------------------------------- semantic head (csrc/sem.h)
+def sem_select(labels: torch.Tensor, freespace_label_on: bool, decimation: int, out=None):
+    """The samples the semantic loss runs over (mapper.py:786-799): (selected uint8 [n], count int32 [1])."""
+    n = labels.shape[0]
+    sel, cnt = out if out is not None else (torch.empty((n,), dtype=torch.uint8, device=labels.device),
+                                            torch.empty((1,), dtype=torch.int32, device=labels.device))
+    check(_lib.lib().pin_sem_select(_ptr(labels, torch.int32), n, int(bool(freespace_label_on)), max(1, int(decimation)), _ptr(sel), _ptr(cnt),
+                                    _stream()), "pin_sem_select")
+    return sel, cnt
+
+
+def train_sem_step(fsem: FieldState, buf: "TrainBuffers", labels, selected, count, feat_grad, dec_grad, *, heads: int, weight_s: float):
+    """Semantic term of a training iteration; call after train_step (reuses the queries / kNN records of its main samples).
+    fsem: geometry feature table + the semantic decoder's flat parameters.  Returns the device double the kernel adds
+    sum(-sem_pred[label]) over the selected samples to (the reference's loss = that / count)."""
+    if buf.n_main == 0:
+        return getattr(buf, "sem_loss", None)
+    nbytes = _lib.lib().pin_sem_workspace_bytes(buf.cap_main, fsem.hidden, fsem.levels, 1 if fsem.weighted_first else fsem.k)
+    if getattr(buf, "sem_ws", None) is None or buf.sem_ws.numel() * 4 < nbytes:
+        buf.sem_ws = torch.empty((nbytes // 4 + 1,), dtype=torch.float32, device=buf.query.device)
+    if getattr(buf, "sem_loss", None) is None:
+        buf.sem_loss = torch.zeros((1,), dtype=torch.float64, device=buf.query.device)
+    sp = _lib.SemParams()
+    sp.n_main, sp.heads, sp.weight_s = buf.n_main, int(heads), float(weight_s)
+    sp.labels, sp.selected, sp.count = _ptr(labels, torch.int32), _ptr(selected, torch.uint8), _ptr(count, torch.int32)
+    f = fsem.params()
+    check(_lib.lib().pin_train_sem_step(C.byref(f), C.byref(sp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn), _ptr(feat_grad, torch.float32),
+                                        _ptr(dec_grad), _ptr(buf.sem_loss), _ptr(buf.sem_ws), buf.sem_ws.numel() * 4, _stream()),
+          "pin_train_sem_step")
+    return buf.sem_loss
+
+
+def sem_query(fsem: FieldState, query, nbr, nn, heads: int, want_labels=True, want_logprob=False):
+    """Semantic prediction at query points: (labels int32 [n] = argmax of the (weighted) log-probabilities, logprob [n, heads])."""
+    n = query.shape[0]
+    dev = query.device
+    lab = torch.empty((n,), dtype=torch.int32, device=dev) if want_labels else None
+    lp = torch.empty((n, int(heads)), dtype=torch.float32, device=dev) if want_logprob else None
+    f = fsem.params()
+    check(_lib.lib().pin_sem_query(C.byref(f), _ptr(query, torch.float32), _ptr(nbr), _ptr(nn, torch.int32), n, int(heads), _ptr(lab), _ptr(lp),
+                                   _stream()), "pin_sem_query")
+    return lab, lp
+
+
+def decoder_sem(fsem: FieldState, feat: torch.Tensor, heads: int, raw: bool = False):
+    """Decoder.sem_label_prob (raw: Decoder.mlp) on [n, 11] decoder inputs -> [n, heads]."""
+    n = feat.shape[0]
+    out = torch.empty((n, int(heads)), dtype=torch.float32, device=feat.device)
+    f = fsem.params()
+    check(_lib.lib().pin_decoder_sem(C.byref(f), _ptr(feat, torch.float32), n, int(heads), int(bool(raw)), _ptr(out), _stream()), "pin_decoder_sem")
+    return out
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=0.01, beta1=0.9, beta2=0.99, eps=1e-15, zero_grad=True):
     check(_lib.lib().pin_adam_step(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(exp_avg, torch.float32),
                                    _ptr(exp_avg_sq, torch.float32), param.numel(), int(step), float(lr), float(beta1),

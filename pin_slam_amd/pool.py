@@ -16,7 +16,7 @@ import torch
 from . import _lib, ops
 from ._lib import PoolArrays, SampleParams, check
 
-FIELDS = ("coord", "global_coord", "sdf_label", "weight", "ts", "color")
+FIELDS = ("coord", "global_coord", "sdf_label", "weight", "ts", "color", "sem_label")
 
 
 def sample_params(cfg, pose: np.ndarray, frame_id: int) -> SampleParams:
@@ -35,9 +35,10 @@ def sample_params(cfg, pose: np.ndarray, frame_id: int) -> SampleParams:
 
 
 class SamplePool:
-    def __init__(self, device="cuda", color_channels: int = 0, capacity: int = 1 << 16):
+    def __init__(self, device="cuda", color_channels: int = 0, capacity: int = 1 << 16, semantic: bool = False):
         self.device = torch.device(device)
         self.C = int(color_channels)
+        self.semantic = bool(semantic)  # carry sem_label_pool (int32 per sample)
         self.n = 0          # samples in the pool
         self.n_cur = 0      # of which belong to the newest frame (the tail)
         self.cap = 0
@@ -55,7 +56,8 @@ class SamplePool:
                  sdf_label=torch.empty((cap,), dtype=torch.float32, device=d),
                  weight=torch.empty((cap,), dtype=torch.float32, device=d),
                  ts=torch.empty((cap,), dtype=torch.int32, device=d),
-                 color=torch.empty((cap, self.C), dtype=torch.float32, device=d) if self.C else None)
+                 color=torch.empty((cap, self.C), dtype=torch.float32, device=d) if self.C else None,
+                 sem_label=torch.empty((cap,), dtype=torch.int32, device=d) if self.semantic else None)
         return b
 
     def _ensure(self, need):
@@ -77,6 +79,7 @@ class SamplePool:
         a.sdf_label, a.weight, a.ts = b["sdf_label"][offset:].data_ptr(), b["weight"][offset:].data_ptr(), b["ts"][offset:].data_ptr()
         a.color = b["color"][offset:].data_ptr() if self.C else None
         a.color_channels = self.C
+        a.sem_label = b["sem_label"][offset:].data_ptr() if self.semantic else None
         return a
 
     def view(self, name) -> Optional[torch.Tensor]:
@@ -98,7 +101,7 @@ class SamplePool:
         self.n_cur = min(self.n_cur, n)
 
     # ------------------------------------------------------------------ K12
-    def append_samples(self, scan: torch.Tensor, sp: SampleParams, rnd=None) -> int:
+    def append_samples(self, scan: torch.Tensor, sp: SampleParams, rnd=None, sem_labels: Optional[torch.Tensor] = None) -> int:
         """DataSampler.sample + pool append for one frame.  scan [N, 3(+C)] float32 rows in the
         sensor frame (colour channels after xyz when the pool carries colour).  rnd = optional
         (surface, front, behind) draws; by default they are drawn here with torch.randn / rand in
@@ -114,6 +117,16 @@ class SamplePool:
             rnd = (torch.randn(N * sp.surface_n, 1, device=dev), torch.rand(N * sp.front_n, 1, device=dev),
                    torch.rand(N * sp.behind_n, 1, device=dev))
         self._ensure(self.n + N * A)
+        if self.semantic:  # per-point labels of this scan (frame_label_torch); None: every sample gets label 0
+            if sem_labels is not None:
+                if sem_labels.shape[0] != N:
+                    raise RuntimeError("one semantic label per scan point is needed")
+                sem_labels = sem_labels.detach().to(device=scan.device, dtype=torch.int32).contiguous()
+                sp.sem_labels = sem_labels.data_ptr()
+            else:
+                sp.sem_labels = None
+        elif sem_labels is not None:
+            raise RuntimeError("this pool carries no semantic labels (SamplePool(semantic=True))")
         out = self._arrays(self.bufs[0], self.n)
         colors = scan.data_ptr() + 12 if self.C else None
         check(_lib.lib().pin_sample_rays(C.byref(sp), scan.data_ptr(), colors, stride, N, ops._ptr(rnd[0].reshape(-1)),

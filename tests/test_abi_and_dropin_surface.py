@@ -130,8 +130,9 @@ def test_standalone_config_carries_the_reference_defaults():
 @pytest.mark.reference
 def test_shipped_configurations_pass_the_support_checks():
     """Every YAML the reference ships, loaded by the reference's own Config, against the drop-in Mapper's support check
-    (what raises NotImplementedError instead of falling back): only the semantic demo is refused.  The two configurations
-    with `ba_freq_frame` train and track like the others; their bundle adjustment (pypose) is outside the hot path."""
+    (what raises NotImplementedError instead of falling back): NONE is refused any more (r06: the semantic demo, run_demo_sem.yaml,
+    runs on csrc/sem.h).  The two configurations with `ba_freq_frame` train and track like the others; their bundle adjustment
+    (pypose) is outside the hot path."""
     import glob, importlib, os, sys, types
     from oracle import ref_loader as R
     R.load()
@@ -143,7 +144,8 @@ def test_shipped_configurations_pass_the_support_checks():
     for path in files:
         c = Config()
         c.load(path)
-        fake = types.SimpleNamespace(config=c, sdf_mlp=types.SimpleNamespace(hidden_level=c.geo_mlp_level), ba_done_flag=False)
+        fake = types.SimpleNamespace(config=c, sdf_mlp=types.SimpleNamespace(hidden_level=c.geo_mlp_level), ba_done_flag=False, dp_comm=None,
+                                     sem_mlp=types.SimpleNamespace(out_dim=c.sem_class_count + 1) if c.semantic_on else None)
         try:
             Mapper._check_supported(fake)
         except NotImplementedError:
@@ -152,7 +154,10 @@ def test_shipped_configurations_pass_the_support_checks():
             analytic.append(os.path.basename(path))
         per_neighbour += int(not c.weighted_first)
         assert c.geo_mlp_level == 1 and c.geo_mlp_hidden_dim == 64 and c.query_nn_k in (6, 8)  # the tile-kernel shapes
-    assert refused == ["run_demo_sem.yaml"] and analytic == ["run_livox.yaml"] and per_neighbour == 9
+    assert refused == [] and analytic == ["run_livox.yaml"] and per_neighbour == 9
+    sem = Config()
+    sem.load(os.path.join(R.REF_ROOT, "config", "lidar_slam", "run_demo_sem.yaml"))
+    assert sem.semantic_on and sem.sem_class_count + 1 == 21 and sem.weighted_first
     for k in [k for k in sys.modules if k in ("model", "utils") or k.startswith(("model.", "utils."))]:
         del sys.modules[k]
     R._loaded.clear()
