@@ -551,7 +551,7 @@ def main():
     # counters of THIS command on this workload (scripts/pmc_bench.sh -> profiles/r03_pmc_<workload>.json): HBM-side bytes per
     # launch, matrix-pipe and vector-ALU utilisation of the two tracker kernels
     pmc_data, pmc_src = {}, None
-    for rnd in ("r05", "r04", "r03"):  # (the newest committed counter passes of this workload)
+    for rnd in ("r06", "r05", "r04", "r03"):  # (the newest committed counter passes of this workload)
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.workload}.json")
         if os.path.exists(path):
             try:
@@ -949,7 +949,7 @@ def roofline_train(args, cfg, ms_iter, nn_mean, Kc, k, group, reuse_pool_n=None)
          "bound": "hbm", "achieved": round(alg / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(alg / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sample": round(bytes_s, 1),
          "traffic": None}
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"{rnd}_pmc_c4.json") for rnd in ("r05", "r04", "r03")) if os.path.exists(q)), "")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"{rnd}_pmc_c4.json") for rnd in ("r06", "r05", "r04", "r03")) if os.path.exists(q)), "")
     if path:
         try:
             ks = json.load(open(path))["kernels"]

@@ -139,6 +139,37 @@ class GNTracker:
                 self._cells = (torch.empty((rows, 4), dtype=torch.int32, device=src.device),
                                torch.empty((rows, stride), dtype=torch.int32, device=src.device))
             cell_p, list_p = (t.data_ptr() for t in self._cells)
+        if os.environ.get("PIN_GN_SPLIT", "0") == "1" and listed and n >= 8192 and lab_p is None and ct_r is None and probe is None:
+            # EXPERIMENT (measured and not kept, DESIGN section 8 "Round 6"): the Morton-ordered scan in two
+            # halves on two streams -- the search of half B beside the tile kernel of half A.  Per iteration two cross-stream
+            # dependencies (solve -> search B, tile kernel B -> solve).
+            main = torch.cuda.current_stream()
+            if getattr(self, "_split_stream", None) is None:
+                self._split_stream = torch.cuda.Stream(device=src.device)
+                self._split_ev = [torch.cuda.Event() for _ in range(3)]
+            side, (ev_solved, ev_b, ev_start) = self._split_stream, self._split_ev
+            side_h = side.cuda_stream
+            nA = ((n // 2) + 63) & ~63
+            nB = n - nA
+            off = lambda p, rows, width: p + 4 * rows * width  # noqa: E731 (float32 / int32 rows)
+            srcB, curB, nbrB, nnB = off(src_p, nA, 3), off(cur_p, nA, 3), off(nbr_p, nA, 4 * k), off(nn_p, nA, 1)
+            cellB, listB = off(cell_p, nA, 4), off(list_p, nA, stride)
+            ev_start.record(main)
+            side.wait_event(ev_start)
+            for it in range(iters):
+                first = int(it == 0)
+                rc = L.pin_gn_knn_listed(sp_r, bc_r, src_p, nA, k, st_p, cur_p, nbr_p, nn_p, cell_p, list_p, first, stream)
+                rc |= L.pin_gn_knn_listed(sp_r, bc_r, srcB, nB, k, st_p, curB, nbrB, nnB, cellB, listB, first, side_h)
+                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, ct_r, cur_p, nbr_p, nn_p, None, nA, sums_p, st_p, stream)
+                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, ct_r, curB, nbrB, nnB, None, nB, sums_p, st_p, side_h)
+                ev_b.record(side)
+                main.wait_event(ev_b)
+                rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
+                ev_solved.record(main)
+                side.wait_event(ev_solved)
+                if rc:
+                    check(rc, "split registration iteration")
+            iters = 0  # (the loop below is skipped)
         for it in range(iters):
             if self.on_knn:
                 self.on_knn(True)

@@ -1,5 +1,5 @@
 """gpurun_out/pmc_bench/<workload>/ (scripts/pmc_bench.sh) -> gpurun_out/pmc_bench/<round>_pmc_<workload>.json and
-<round>_bench_<workload>_kernel_stats.csv (PIN_ROUND, default r05) (copy both into profiles/).
+<round>_bench_<workload>_kernel_stats.csv (PIN_ROUND, default r06) (copy both into profiles/).
 
 Per kernel CLASS and launch SHAPE (grid size): mean counter values per launch.  The tracker's launches of a kernel are the
 shape with the most launches (50 per frame); the training launches of the search kernel have other grids.
@@ -7,7 +7,7 @@ HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB -> bytes; the narrow random
 face value (calibration in profiles/r01_pmc.json: FETCH_SIZE ~= TCC_MISS x 64 B for them; only wide streaming reads show
 up halved on gfx950, /opt/skills/guides/MI355X_MICROARCH.md, HBM section -- `fetch_streaming_x2` gives that bound too)."""
 import collections, csv, glob, json, os, shutil, sys
-RND = os.environ.get("PIN_ROUND", "r05")
+RND = os.environ.get("PIN_ROUND", "r06")
 
 W = sys.argv[1]
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
