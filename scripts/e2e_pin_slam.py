@@ -87,14 +87,23 @@ def scene_points(rng, n_ground=1_500_000, n_wall=900_000, n_pillar=250_000):
     for (px, py) in centres:
         th = rng.uniform(0, 2 * np.pi, per)
         pillars.append(np.stack([px + 0.5 * np.cos(th), py + 0.5 * np.sin(th), rng.uniform(-1.7, 3.5, per)], 1))
+    parts = np.concatenate([np.full(len(ground), 40, np.uint32)] + [np.full(len(w), 50, np.uint32) for w in walls] +
+                           [np.full(len(q), 80, np.uint32) for q in pillars])  # SemanticKITTI ids: road, building, pole
+    scene_points.parts = parts
     return np.concatenate([ground] + walls + pillars, 0)
 
 
-def write_sequence(out_dir: str, frames: int, step: float = 0.5, n_scan: int = 60_000, seed: int = 0):
+# SemanticKITTI raw id -> the reduced label the reference trains on (utils/semantic_kitti_utils.py: sem_kitti_learning_map)
+SEM_REDUCED = {40: 9, 50: 13, 80: 18}
+
+
+def write_sequence(out_dir: str, frames: int, step: float = 0.5, n_scan: int = 60_000, seed: int = 0, labels: bool = False):
     rng = np.random.default_rng(seed)
     world = scene_points(rng)
     pc_dir = os.path.join(out_dir, "velodyne")
     os.makedirs(pc_dir, exist_ok=True)
+    if labels:  # --semantic: per-point labels in SemanticKITTI's *.label format (uint32, semantic id in the low 16 bits)
+        os.makedirs(os.path.join(out_dir, "labels"), exist_ok=True)
     poses = []
     for i in range(frames):
         yaw = 0.004 * i
@@ -111,6 +120,8 @@ def write_sequence(out_dir: str, frames: int, step: float = 0.5, n_scan: int = 6
         pts = local[sel] + rng.normal(0.0, 0.01, (len(sel), 3))
         scan = np.concatenate([pts, rng.random((len(sel), 1))], 1).astype(np.float32)
         scan.tofile(os.path.join(pc_dir, f"{i:06d}.bin"))
+        if labels:
+            scene_points.parts[sel].astype(np.uint32).tofile(os.path.join(out_dir, "labels", f"{i:06d}.label"))
     return pc_dir, np.stack(poses)
 
 
@@ -119,7 +130,7 @@ CONFIG_YAML = """setting:
   output_root: "{out}"
   pc_path: "{pc}"
   deskew: {deskew}
-process:
+{setting_extra}process:
   min_range_m: 2.5
   max_range_m: 60.0
 sampler:
@@ -316,7 +327,7 @@ def run(args):
     log = {"impl": args.impl, "frames": args.frames, "scan_points": args.scan_points, "seed": args.seed}
     ref = reference_tree(args.reference)
     work = tempfile.mkdtemp(prefix="pin_e2e_")
-    pc_dir, gt = write_sequence(work, args.frames, n_scan=args.scan_points)
+    pc_dir, gt = write_sequence(work, args.frames, n_scan=args.scan_points, labels=args.semantic)
     cfg_path = os.path.join(work, "e2e.yaml")
     with open(cfg_path, "w") as f:
         # --per-neighbour: decode every neighbour and weight the predictions (run_kitti.yaml: weighted_first False, 6 neighbours)
@@ -325,8 +336,10 @@ def run(args):
         if args.livox_style:  # run_livox.yaml: per-neighbour decoding with 8 neighbours, Eikonal term on the autograd gradient
             extra = "  weighted_first: False\n  query_nn_k: 8\n"
             loss = "loss:\n  loss_weight_on: True\n  dist_weight_scale: 0.5\n  ekional_loss_on: True\n  weight_e: 0.5\n  numerical_grad_on: False\n"
+        # --semantic: config/lidar_slam/run_demo_sem.yaml's switch (semantic_on + label_path; a 21-head semantic decoder, NLL term)
+        setting = f'  semantic_on: True\n  label_path: "{os.path.join(work, "labels")}"\n' if args.semantic else ""
         f.write(CONFIG_YAML.format(out=os.path.join(work, "experiments"), pc=pc_dir, iters=args.iters, deskew=bool(args.deskew),
-                                   neural_extra=extra, loss_extra=loss, bs=args.batch_size))
+                                   neural_extra=extra, loss_extra=loss, bs=args.batch_size, setting_extra=setting))
     # setup_experiment records `git rev-parse HEAD` (utils/tools.py:105-107): give it a repository to stand in
     subprocess.run("git init -q . && git -c user.email=e2e@x -c user.name=e2e commit -q --allow-empty -m e2e", shell=True,
                    cwd=work, check=True)
@@ -360,6 +373,14 @@ def run(args):
         orig_init(self, *a, **k)
         keep["dataset"] = self
     sd.SLAMDataset.__init__ = spy_init
+    if args.semantic:  # keep the tracker the run builds: its query_source_points(query_sem=True) is asked about the scene afterwards
+        trk_cls = pin_slam.Tracker
+        orig_trk = trk_cls.__init__
+
+        def spy_trk(self, *a, **k):
+            orig_trk(self, *a, **k)
+            keep["tracker"] = self
+        trk_cls.__init__ = spy_trk
     if args.reserve_mb > 0 and args.impl == "dropin":
         blk = torch.empty(args.reserve_mb << 20, dtype=torch.uint8, device="cuda")
         del blk
@@ -415,7 +436,29 @@ def run(args):
                         "mean_nn_count_at_own_points": round(float(nn_count.float().mean()), 2),
                         "decoder_keys": sorted(k for k in loaded["sdf"].keys())}
     print("saved map:", log["saved_map"])
-    ok = log["max_translation_error_cm"] < args.tol_cm and log["saved_map"]["mean_nn_count_at_own_points"] > 3
+    sem_ok = True
+    if args.semantic:
+        # the trained semantic field against the scene's labels: the points of a mid-sequence scan, in the world frame, through
+        # Tracker.query_source_points(query_sem=True) on the global map (tracker.py:336-341)
+        trk = keep["tracker"]
+        trk.neural_points = npts  # (the run released its own map's hash table at the end: the RE-LOADED, re-hashed map above)
+        fid = args.frames // 2
+        scan = np.fromfile(os.path.join(pc_dir, f"{fid:06d}.bin"), dtype=np.float32).reshape(-1, 4)[:, :3]
+        raw = np.fromfile(os.path.join(work, "labels", f"{fid:06d}.label"), dtype=np.uint32) & 0xFFFF
+        want = np.vectorize(SEM_REDUCED.get)(raw).astype(np.int64)
+        pts = scan.astype(np.float64) @ gt[fid][:3, :3].T + gt[fid][:3, 3]
+        dev = trk.neural_points.neural_points.device
+        q = torch.tensor(pts, dtype=torch.float32, device=dev)
+        res = trk.query_source_points(q, 1 << 18, False, False, False, False, query_sem=True, query_mask=True, query_certainty=False,
+                                      query_locally=False, mask_min_nn_count=4)
+        pred, mask = res[4].cpu().numpy().astype(np.int64), res[5].cpu().numpy().astype(bool)
+        acc = float((pred[mask] == want[mask]).mean())
+        log["semantic"] = {"frame": fid, "points": int(mask.sum()), "accuracy": round(acc, 4),
+                           "per_class_accuracy": {str(c): round(float((pred[mask & (want == c)] == c).mean()), 4) for c in sorted(set(want))},
+                           "decoder_heads": int(loaded["semantic"]["lout.bias"].shape[0]), "classes": {"9": "road", "13": "building", "18": "pole"}}
+        print("semantic:", log["semantic"])
+        sem_ok = acc > 0.9
+    ok = log["max_translation_error_cm"] < args.tol_cm and log["saved_map"]["mean_nn_count_at_own_points"] > 3 and sem_ok
     log["ok"] = bool(ok)
     with open(os.path.join(out, f"e2e_{args.impl}.json"), "w") as f:
         json.dump(log, f, indent=1)
@@ -439,6 +482,9 @@ def main():
     r.add_argument("--per-neighbour", action="store_true", help="weighted_first: False, query_nn_k: 6 (run_kitti.yaml style)")
     r.add_argument("--livox-style", action="store_true", help="run_livox.yaml style: weighted_first False, query_nn_k 8, "
                                                               "numerical_grad_on False (analytic Eikonal term)")
+    r.add_argument("--semantic", action="store_true", help="run_demo_sem.yaml style: semantic_on with SemanticKITTI-format *.label files of "
+                                                            "the synthetic scene (road / building / pole); the trained semantic field is "
+                                                            "checked against the scene's labels after the run")
     r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "e2e"))
     r.add_argument("--batch-size", type=int, default=10000)
     r.add_argument("--reserve-mb", type=int, default=0, help="diagnosis: hand the caching allocator one block of this size before the "
