@@ -197,7 +197,10 @@ class Mapper(_StandaloneBase):
         if scan.dtype != torch.float32 or not scan.is_cuda or scan.stride(1) != 1:
             scan = scan.to(device=self.device, dtype=torch.float32).contiguous()
         n_scan = scan.shape[0]
-        self.static_mask = torch.ones(n_scan, dtype=torch.bool, device=self.device)
+        ones = getattr(self, "_ones_mask", None)  # (a view of a cached all-true mask: no fill launch per frame; never written)
+        if ones is None or ones.shape[0] < n_scan:
+            ones = self._ones_mask = torch.ones(int(n_scan * 1.25) + 1024, dtype=torch.bool, device=self.device)
+        self.static_mask = ones[:n_scan]
         if filter_dynamic:
             npts.reset_local_map(origin, orientation, frame_id)
             glob = torch.empty((n_scan, 3), dtype=torch.float32, device=self.device)
@@ -225,14 +228,17 @@ class Mapper(_StandaloneBase):
         sel = cnt = None
         if c.from_sample_points and not c.from_all_samples:
             sel, cnt = ops.select_surface_points(p.bufs[0]["global_coord"][tail], lab_new,
-                                                 np.float32(c.surface_sample_range_m * c.map_surface_ratio))
+                                                 np.float32(c.surface_sample_range_m * c.map_surface_ratio), cnt=p.counts[2:3])
         if filtering:
             p.filter_begin(pose_np[:3, 3], c.window_radius, int(c.pool_capacity))
         hostcache.stamp("pf:select_window_enqueued")
         kept = None
         if sel is not None:
-            both = torch.stack((cnt[0], p.counts[0])).tolist() if filtering else [int(cnt.item()), None]
-            update_points, kept = sel[:both[0]], both[1]
+            if filtering:  # the window's kept count and the surface count sit in one block: one read-back
+                kept, _, n_surf = p.read_counts(3)
+            else:
+                n_surf, kept = int(cnt.item()), None
+            update_points = sel[:n_surf]
         elif c.from_sample_points:  # from_all_samples: the reference passes sensor-frame samples here (mapper.py:238)
             update_points = p.bufs[0]["coord"][tail]
         else:
@@ -291,11 +297,11 @@ class Mapper(_StandaloneBase):
             first = self.pool_sample_count - cur
             cert = npts._query_certainty(p.bufs[0]["global_coord"][first:first + cur], own_cell=True)
             idx, cnt = ops.new_sample_index(cert, p.bufs[0]["sdf_label"][first:first + cur], c.new_certainty_thre,
-                                            np.float32(c.surface_sample_range_m * 3.0), offset=first)
+                                            np.float32(c.surface_sample_range_m * 3.0), offset=first, cnt=npts._cnt[3:4])
             hostcache.stamp("pf:certainty_enqueued")
             npts.build_pending_bricks()  # beside the count read-back below and the host work up to Mapper.mapping
             if getattr(npts, "_local_count_pending", False):
-                new_count, counted = (int(v) for v in torch.stack((cnt[0], npts._cnt[2])).tolist())
+                counted, new_count = (int(v) for v in npts._cnt[2:4].tolist())  # (adjacent slots of one block: one read-back)
                 npts._finish_local_map(counted)
                 npts.record_memory(verbose=False)
             else:

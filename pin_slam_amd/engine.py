@@ -64,6 +64,7 @@ class GNTracker:
             self.on_knn(False)
         cur = out[2] if T is not None else src
         ops.gn_accumulate(self.fs, self.gp, cur, out[0], out[1], sdf_labels=labels, sums=self.sums, color=color)
+        self._sums_clean = False
         self.sums_host.copy_(self.sums, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         sums = self.sums_host.numpy()
@@ -101,7 +102,11 @@ class GNTracker:
             self.state_host = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64).pin_memory()
         T0 = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64))
         check(L.pin_gn_state_init(self.state.data_ptr(), T0.ctypes.data, n, stream), "pin_gn_state_init")
-        self.sums.zero_()
+        # the solve kernel of every iteration leaves the sums zeroed for the next one -- also the last one of the previous call:
+        # a fill launch is needed only the first time and after the host-driven step(), which does not run that kernel
+        if not getattr(self, "_sums_clean", False):
+            self.sums.zero_()
+        self._sums_clean = False  # (until this call's last solve has run: set again behind the read-back below)
         sp = self.st.params(time_filtering=time_filtering, local=local)
         # the decoder does not change during a registration: stage it once for all launches (pin_stage_decoder; the
         # colour decoder was staged by ops.color_term)
@@ -139,6 +144,7 @@ class GNTracker:
                 self._cells = (torch.empty((rows, 4), dtype=torch.int32, device=src.device),
                                torch.empty((rows, stride), dtype=torch.int32, device=src.device))
             cell_p, list_p = (t.data_ptr() for t in self._cells)
+        iters_run = iters
         if os.environ.get("PIN_GN_SPLIT", "0") == "1" and listed and n >= 8192 and lab_p is None and ct_r is None and probe is None:
             # EXPERIMENT (measured and not kept, DESIGN section 8 "Round 6"): the Morton-ordered scan in two
             # halves on two streams -- the search of half B beside the tile kernel of half A.  Per iteration two cross-stream
@@ -203,6 +209,7 @@ class GNTracker:
                 probe.append(rec)
         self.state_host.copy_(self.state, non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        self._sums_clean = iters_run > 0
         s = self.state_host.numpy()
         if s[_lib.PIN_GN_STATE_STATUS] != 0.0:  # sticky device flags the solve kernel copied into the read-back (pin_status)
             ops.raise_on_status(int(s[_lib.PIN_GN_STATE_STATUS]))

@@ -778,12 +778,14 @@ def pool_workspace(n: int, device, extra: int = 0) -> torch.Tensor:
     return torch.empty((_lib.lib().pin_pool_workspace_bytes(n) + extra,), dtype=torch.uint8, device=device)
 
 
-def new_sample_index(certainty, sdf_label, certainty_thre, label_thre, offset=0, ws=None):
-    """where(certainty < thre & |label| < label_thre) + offset -> (int64 index buffer [n], count tensor [1])."""
+def new_sample_index(certainty, sdf_label, certainty_thre, label_thre, offset=0, ws=None, cnt=None):
+    """where(certainty < thre & |label| < label_thre) + offset -> (int64 index buffer [n], count tensor [1]).
+    cnt: where the count goes (an int32 [1] view of a caller's block of counts: one read-back for several counts)."""
     n = certainty.shape[0]
     dev = certainty.device
     idx = torch.empty((n,), dtype=torch.int64, device=dev)
-    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    if cnt is None:
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
     if ws is None or ws.numel() < _lib.lib().pin_pool_workspace_bytes(n) + n:
         ws = pool_workspace(n, dev, extra=n)
     check(_lib.lib().pin_new_sample_index(_ptr(certainty, torch.float32), _ptr(sdf_label, torch.float32), n,
@@ -792,12 +794,13 @@ def new_sample_index(certainty, sdf_label, certainty_thre, label_thre, offset=0,
     return idx, cnt
 
 
-def select_surface_points(rows, sdf_label, label_thre, ws=None):
-    """rows[|sdf_label| < label_thre] -> (buffer [n,3], count tensor [1]); order preserved."""
+def select_surface_points(rows, sdf_label, label_thre, ws=None, cnt=None):
+    """rows[|sdf_label| < label_thre] -> (buffer [n,3], count tensor [1]); order preserved.  cnt: as in new_sample_index."""
     n = sdf_label.shape[0]
     dev = rows.device
     out = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    if cnt is None:
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
     if ws is None or ws.numel() < _lib.lib().pin_pool_workspace_bytes(n) + n:
         ws = pool_workspace(n, dev, extra=n)
     check(_lib.lib().pin_select_surface_points(_ptr(rows, torch.float32), _ptr(sdf_label, torch.float32), n, float(label_thre),

@@ -44,8 +44,10 @@ class SamplePool:
         self.cap = 0
         self.bufs = [None, None]  # two generations: compaction goes from bufs[0] to bufs[1], then they swap
         self._ensure(capacity)
-        self.counts = torch.zeros((2,), dtype=torch.int32, device=self.device)
-        self.counts_host = torch.zeros((2,), dtype=torch.int32).pin_memory()
+        # [0] kept by the window / the compaction, [1] kept among the newest frame's samples, [2] a caller's count that is read
+        # back together with [0] (Mapper.process_frame: the surface-point count) -- one block, one read-back, no torch.stack
+        self.counts = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        self.counts_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
         self.mask = self.true_index = self.ws = None
 
     # ------------------------------------------------------------------ storage
@@ -199,3 +201,9 @@ class SamplePool:
         self.bufs = [self.bufs[1], self.bufs[0]]
         self.n, self.n_cur = int(self.counts_host[0]), int(self.counts_host[1])
         return self.n, self.n_cur
+
+    def read_counts(self, n: int = 3):
+        """counts[:n] on the host (one copy into the pinned block + one stream synchronisation)."""
+        self.counts_host[:n].copy_(self.counts[:n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.counts_host[:n].tolist()
