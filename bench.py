@@ -143,6 +143,10 @@ def parse():
     ap.add_argument("--mesher-queries", type=int, default=10_000_000,
                     help="N = 1: grid points of the Mesher.query_points leg (forward-only SDF + mask over a dense grid, "
                          "mesher.py:40-164; 0 = skip)")
+    ap.add_argument("--semantic-leg", type=int, default=1,
+                    help="N = 1: 1 = report the semantic head beside the frame (run_demo_sem.yaml's branch, not part of `value`): "
+                         "Mapper.mapping with the 21-head semantic decoder and the NLL term on the timed map, and query_sem over "
+                         "the timed scan; 0 = skip")
     ap.add_argument("--skip-downsampled", action="store_true",
                     help="skip the second timed leg (registering the source-down-sampled subset): profiles of this "
                          "command then hold one launch shape per tracker kernel")
@@ -503,6 +507,10 @@ def main():
     if world == 1 and args.mesher_queries > 0 and not colour:
         mesher_leg = bench_mesher(args, cfg, npts, decoders, nn_mean, int(npts.neighbor_K), k)
 
+    semantic_leg = None
+    if world == 1 and args.semantic_leg and not colour and args.stages == "all":
+        semantic_leg = bench_semantic(args, cfg, npts, dec, mp, state["xyz"], H, L, k)
+
     # the GPU side of the parity check (the oracle side runs in cpu_baseline_and_parity, outside every timed region):
     # the benchmarked kernels -- brick kNN + the GN tile kernel -- on a sub-sample of the timed scan, against the
     # map as it stands after the timed frames
@@ -594,6 +602,7 @@ def main():
         "knn_coherent_probe": probe,
         "moving_sensor": moving,
         "mesher": mesher_leg,
+        "semantic": semantic_leg,
         "c4_single_gpu": c4,
         "c4_per_rank_emulated": c4_emul,
         "roofline": {"kernel": ("gn_accumulate_quad_kernel<COLOR> (SDF + colour decoders on two split-fp16 images, photometric rows)"
@@ -687,6 +696,73 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def bench_semantic(args, cfg, npts, dec, mp, scan_xyz, H, L, k):
+    """The semantic head on the timed map (config.semantic_on; csrc/sem.h): Mapper.mapping(--map-iters) with a 21-head semantic
+    decoder and the NLL term (labels of the pool samples = the sheet they lie on, 1..20) against the same call without it, and
+    Tracker.query_source_points-style label queries over the timed scan.  Reported beside the frame; never part of `value`."""
+    import copy
+    from pin_slam_amd import ops
+    from pin_slam_amd.dropin.model.decoder import Decoder
+    from pin_slam_amd.dropin.utils.mapper import Mapper
+    cfg2 = copy.copy(cfg)
+    cfg2.semantic_on, cfg2.sem_class_count, cfg2.weight_s = True, 20, 1.0
+    S = cfg2.sem_class_count + 1
+    torch.manual_seed(7)
+    sem = Decoder(cfg2, H, L, S)
+    mp2 = Mapper(cfg2, mp.dataset, npts, {"sdf": dec, "semantic": sem, "color": None})
+    n = int(mp.pool_sample_count)
+    for a in ("coord_pool", "global_coord_pool", "sdf_label_pool", "weight_pool", "time_pool"):
+        setattr(mp2, a, getattr(mp, a)[:n].clone())
+    z = mp2.global_coord_pool[:, 2]
+    mp2.sem_label_pool = (1 + torch.clamp(((z + 2.0) / 0.8).round(), 0, 19)).to(torch.int32)  # the sheet index (synth.build_map)
+    mp2.sem_label_pool[mp2.weight_pool < 0] = 0  # free-space samples carry label 0
+    mp2.pool_sample_count, mp2.new_idx = n, None
+    mp2._pool(); mp2._publish_pool()
+    mp2.determine_used_pose()
+
+    def timed(mapper, reps=5):
+        mapper.mapping(args.map_iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mapper.mapping(args.map_iters)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    with_sem = timed(mp2)
+    t = mp2._get_trainer()
+    loss = float(t.sem_loss.item()) / max(int(t.sem_count.item()), 1) / (6 * args.map_iters)
+    cfg3 = copy.copy(cfg2)
+    cfg3.semantic_on = False
+    mp3 = Mapper(cfg3, mp.dataset, npts, {"sdf": dec, "semantic": None, "color": None})
+    for a in ("coord_pool", "global_coord_pool", "sdf_label_pool", "weight_pool", "time_pool"):
+        setattr(mp3, a, getattr(mp2, a))
+    mp3.pool_sample_count, mp3.new_idx = n, None
+    mp3._pool(); mp3._publish_pool()
+    mp3.determine_used_pose()
+    without = timed(mp3)
+    q = scan_xyz.contiguous()
+    nbr, nn, _ = npts.knn(q, True)
+    fsem = npts.field_state(sem, query_locally=True)
+    ops.sem_query(fsem, q, nbr, nn, S)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lab, _ = ops.sem_query(fsem, q, nbr, nn, S)
+    e1.record()
+    torch.cuda.synchronize()
+    q_ms = e0.elapsed_time(e1) / 10
+    truth = (1 + torch.clamp(((q[:, 2] + 2.0) / 0.8).round(), 0, 19)).to(torch.int32)
+    return {"what": "config.semantic_on on the timed map: 21-head semantic decoder over the geometry features, NLL on the labelled pool "
+                    "samples (label = sheet index), csrc/sem.h; beside the frame, not in `value`",
+            "mapping_ms_per_call_with_semantic": round(with_sem, 3), "mapping_ms_per_call_without": round(without, 3),
+            "semantic_term_us_per_iteration": round(1e3 * (with_sem - without) / args.map_iters, 1),
+            "mean_nll_over_the_timed_calls": round(loss, 4),
+            "sem_query_ms": round(q_ms, 4), "sem_query_points": int(q.shape[0]),
+            "sem_query_points_per_sec": round(q.shape[0] / (q_ms * 1e-3), 1),
+            "label_accuracy_on_the_scan_after_the_timed_calls": round(float((lab == truth).float().mean().item()), 4)}
 
 
 def bench_mesher(args, cfg, npts, decoders, nn_mean, Kc, k):

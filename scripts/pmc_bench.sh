@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for W in "$@"; do
   O=$R/gpurun_out/pmc_bench/$W; rm -rf $O; mkdir -p $O
-  CMD="python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 0"
+  CMD="python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 0 --semantic-leg 0"
   # mesher = Mesher.query_points over 1e7 grid queries on the C3 map (the forward-only tile decoder + the search through the call's brick cache)
-  if [ "$W" = "mesher" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 10000000"; fi
-  if [ "$W" = "c4" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none --moving-steps 0 --mesher-queries 0"; fi
+  if [ "$W" = "mesher" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 0 --skip-downsampled --events none --moving-steps 0 --mesher-queries 10000000 --semantic-leg 0"; fi
+  if [ "$W" = "c4" ]; then CMD="python $R/bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-parity --c4-iters 6 --dp-emulate= --skip-downsampled --events none --moving-steps 0 --mesher-queries 0 --semantic-leg 0"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $CMD > $O/stats.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -o p -- $CMD > $O/$C.log 2>&1
