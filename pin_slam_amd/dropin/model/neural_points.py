@@ -619,3 +619,9 @@ class NeuralPoints(nn.Module):
         pcd = o3d.geometry.PointCloud()
         pcd.points = o3d.utility.Vector3dVector(pts.detach().cpu().numpy().astype(np.float64))
         return pcd
+
+    def get_map_o3d_bbx(self):
+        """neural_points.py:1057-1070: the axis-aligned box around every neural point of the global map."""
+        import open3d as o3d
+        lo, hi = torch.aminmax(self.neural_points.detach(), dim=0)
+        return o3d.geometry.AxisAlignedBoundingBox(lo.cpu().numpy().astype(np.float64), hi.cpu().numpy().astype(np.float64))

@@ -91,6 +91,13 @@ def test_dropin_call_surface_matches_reference():
     # every public method of the reference's Mapper exists on the drop-in
     missing = [n for n, v in vars(ref["Mapper"]).items() if callable(v) and not n.startswith("_") and not hasattr(um.Mapper, n)]
     assert missing == ["get_numerical_gradient_multieps"] or missing == [], missing  # ([not used] in the reference, mapper.py:1038)
+    # ... and of its NeuralPoints / Tracker / Decoder (time_conditionded_sdf: the constructor refuses is_time_conditioned,
+    # which the reference itself never sets -- decoder.py:40)
+    for key, ocls, allowed in (("NeuralPoints", mods["model.neural_points"].NeuralPoints, set()),
+                               ("Tracker", mods["utils.tracker"].Tracker, set()),
+                               ("Decoder", mods["model.decoder"].Decoder, {"time_conditionded_sdf"})):
+        missing = {n for n, v in vars(ref[key]).items() if callable(v) and not n.startswith("_") and not hasattr(ocls, n)}
+        assert missing <= allowed, (key, sorted(missing))
     assert mods["utils.mesher"].Mesher.query_points.__module__ == "pin_slam_amd.dropin.utils.mesher"
     assert mods["utils.mesher"].Mesher.__mro__[1].__name__ == "Mesher" and hasattr(mods["utils.mesher"].Mesher, "get_query_from_bbx")
     # restore the plain reference namespace for the other tests
