@@ -21,7 +21,7 @@ _ws_cache = {}
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    key = str(device)
+    key = (str(device), ops._stream())  # (one scratch per stream: launches of two streams never share it)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty((int(nbytes * 1.25) + 256,), dtype=torch.uint8, device=device)
@@ -177,8 +177,36 @@ class ScanPreprocessor:
         return out(pc[:c2]), ts_ret, out(src[:c3]), colors
 
     def __call__(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None,
-                 frame_id: int = 1, lose_track: bool = False):
+                 frame_id: int = 1, lose_track: bool = False, stream: Optional[torch.cuda.Stream] = None):
+        """``stream``: queue the whole chain (and wait for its counts) on THIS stream instead of the current one -- the
+        loader's upload stream in a pipeline that reads frame f+1 while frame f's map update is still running on the main
+        stream: nothing in the chain reads the map, so it need not queue behind it, and its one read-back then waits for
+        0.25 ms of its own launches instead of for the whole main stream.  The caller vouches that ``scan`` / ``point_ts``
+        are complete on the device (uploaded on ``stream``, or by work the host has already waited for); the results are
+        complete when the call returns and are registered with the caller's current stream (record_stream), so they can
+        be used there without an event and their memory is not recycled under it."""
+        if stream is not None and scan.is_cuda:
+            user = torch.cuda.current_stream(scan.device)
+            if stream != user:
+                if isinstance(last_odom_tran, torch.Tensor) and last_odom_tran.is_cuda:
+                    last_odom_tran = last_odom_tran.detach().to("cpu", torch.float64)  # (written on the caller's stream: read there)
+                with torch.cuda.stream(stream):
+                    out = self._run(scan, point_ts, last_odom_tran, frame_id, lose_track)
+                    stream.synchronize()  # (the staged path ends in launches; the fused one has waited already)
+                for t in out:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(user)
+                return out
+        return self._run(scan, point_ts, last_odom_tran, frame_id, lose_track)
+
+    def _run(self, scan, point_ts, last_odom_tran, frame_id, lose_track):
         c = self.config
+        if scan.is_cuda:  # the scratch is shared by all calls: a call on another stream than the last one waits for that one first
+            cur = torch.cuda.current_stream(scan.device)
+            last = getattr(self, "_last_stream", None)
+            if last is not None and last != cur:
+                last.synchronize()
+            self._last_stream = cur
         crop_max = c.max_range
         scan = _dev_f32(scan)
         if getattr(c, "adaptive_range_on", False):  # slam_dataset.py:399-407: crop range from the scan's own extent

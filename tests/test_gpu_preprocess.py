@@ -92,3 +92,45 @@ def test_fused_chain_equals_the_stages(monkeypatch, deskew, correct):
     # no timestamps: no deskewing, no ts output
     a, b = fused(scan, None, frame_id=2), staged(scan, None, frame_id=2)
     assert a[1] is None and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_chain_on_its_own_stream_does_not_wait_for_the_main_stream(fused):
+    """ScanPreprocessor(..., stream=s): the same bits as on the current stream, results usable on the current stream when the
+    call returns, and the call does not queue behind the main stream: with ~40 ms of work pending there it returns long
+    before that work ends (the pipeline bench.py times: the scan chain of frame f+1 beside Mapper.mapping of frame f)."""
+    import time
+    from pin_slam_amd import preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    cfg = PinConfig(vox_down_m=0.08, source_vox_down_m=0.8, min_range=2.5, max_range=60.0, min_z=-5.0, max_z=60.0, deskew=True)
+    g = torch.Generator().manual_seed(11)
+    n = 100_000
+    r = 70.0 * torch.sqrt(torch.rand(n, generator=g)); th = 6.2831853 * torch.rand(n, generator=g)
+    scan = torch.stack([r * torch.cos(th), r * torch.sin(th), -2 + 0.5 * torch.randn(n, generator=g), torch.rand(n, generator=g)], 1).float().cuda()
+    ts = torch.rand(n, generator=g).float().cuda()
+    T = np.eye(4); T[:3, 3] = [0.9, 0.02, 0.0]
+    plain, other = PP.ScanPreprocessor(cfg), PP.ScanPreprocessor(cfg)
+    plain.fused = other.fused = fused
+    want = plain(scan, ts, last_odom_tran=T, frame_id=3)
+    side = torch.cuda.Stream()
+    other(scan, ts, last_odom_tran=T, frame_id=3, stream=side)  # (first call: allocations)
+    a = torch.randn(6144, 6144, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        a = a @ a * 1e-3
+    torch.cuda.synchronize()
+    busy = time.perf_counter() - t0
+    for _ in range(8):  # pending on the main stream while the chain runs on its own
+        a = a @ a * 1e-3
+    t0 = time.perf_counter()
+    got = other(scan, ts, last_odom_tran=T, frame_id=3, stream=side)
+    t_call = time.perf_counter() - t0
+    main_done_at_return = torch.cuda.current_stream().query()
+    s = got[0].sum() + got[2].sum()  # used on the main stream at once, no event
+    torch.cuda.synchronize()
+    for w, x in zip(want, got):
+        assert (w is None and x is None) or torch.equal(w, x)
+    assert torch.isfinite(s)
+    if busy > 0.01:  # (the matmuls were long enough to tell)
+        assert not main_done_at_return and t_call < 0.6 * busy, (t_call, busy)
