@@ -58,7 +58,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 14
+#define PIN_ABI_VERSION 15
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -179,7 +179,7 @@ typedef struct pin_color_term {
  * [18] valid point count   [19] valid_flag   [20] converged   [21] done (loop has ended)
  * [22] iterations run      [23] weighted mse (cov scale)     [24..59] un-damped J^T W J (6x6)
  * [60] source point count */
-#define PIN_GN_STATE_DOUBLES 64
+#define PIN_GN_STATE_DOUBLES 80
 #define PIN_GN_STATE_LAST_RES 16
 #define PIN_GN_STATE_RES 17
 #define PIN_GN_STATE_CNT 18
@@ -191,6 +191,9 @@ typedef struct pin_color_term {
 #define PIN_GN_STATE_NRAW 24
 #define PIN_GN_STATE_NSRC 60
 #define PIN_GN_STATE_STATUS 61   /* the library's sticky status flags (pin_status) as the solve kernel last saw them */
+#define PIN_GN_STATE_TICKET 62   /* 64-bit block counter of the tile kernels that finish the iteration themselves (pin_gn_accumulate_solve); 0 between launches */
+#define PIN_GN_STATE_LP 64       /* pin_gn_loop_init: the loop parameters as 8 doubles, in the order of pin_gn_loop_params */
+#define PIN_GN_STATE_STATUS_PTR 72  /* pin_gn_loop_init: bit pattern of the device address of the library's status word */
 
 typedef struct pin_gn_loop_params {      /* Tracker.tracking constants (tracker.py:77-101) */
     double lm_lambda;                    /* reg_lm_lambda */
@@ -398,8 +401,14 @@ int pin_knn_query(const pin_search_params* sp, const float* query, int32_t n, in
  *   replicas, applies w /= 2 mean(w) (tracker.py:524), LM damping, the 6x6 float64 solve and
  *   expmap (tracker.py:656-679), T <- dT T and the reference's validity / convergence rules
  *   (tracker.py:147-184), and clears the sums for the next iteration (sums must be zeroed by
- *   the caller before the first one).  The host reads the 64 doubles back once per frame. */
+ *   the caller before the first one).  The host reads the state (PIN_GN_STATE_DOUBLES doubles) back once per frame.
+ * pin_gn_loop_init: pin_gn_state_init with the pose passed by value (one launch, no copy) and the loop parameters stored IN the
+ *   state (PIN_GN_STATE_LP).  On a state initialised this way pin_gn_accumulate_solve with the same parameters is TWO launches per
+ *   iteration: the block of the tile kernel whose sums land last (a ticket in the state) runs the solve itself.  With other
+ *   parameters, on a state from pin_gn_state_init, or for the decoder shapes without a tile kernel it launches the solve kernel
+ *   behind the tile kernel as before; the results are the same bits either way. */
 int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, void* stream);
+int pin_gn_loop_init(double* state, const double* T_init_host, int32_t n_src, const pin_gn_loop_params* lp, void* stream);
 int pin_gn_knn(const pin_search_params* sp, const pin_brick_cache* bc, const float* src, int32_t n,
                int32_t k, const double* state, float* cur_out, float* nbr_out, int32_t* nn_count_out,
                void* stream);

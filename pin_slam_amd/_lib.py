@@ -19,7 +19,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 14
+PIN_ABI_VERSION = 15
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -77,7 +77,7 @@ class GnLoopParams(C.Structure):
     ]
 
 
-PIN_GN_STATE_DOUBLES = 64
+PIN_GN_STATE_DOUBLES = 80
 PIN_GN_STATE_STATUS = 61
 PIN_STATUS_FP16_RANGE = 1
 
@@ -181,6 +181,7 @@ SIGNATURES = {
     "pin_radius_search": (i32, [P(SearchParams), vp, i32, vp, vp, vp]),
     "pin_knn_query": (i32, [P(SearchParams), vp, i32, i32, vp, vp, vp, vp, vp]),
     "pin_gn_state_init": (i32, [vp, vp, i32, vp]),
+    "pin_gn_loop_init": (i32, [vp, vp, i32, vp, vp]),
     "pin_decoder_image_bytes": (i64, [i32, i32]),
     "pin_stage_decoder": (i32, [P(Field), vp, i64, vp]),
     "pin_gn_knn": (i32, [P(SearchParams), P(BrickCacheC), vp, i32, i32, vp, vp, vp, vp, vp]),

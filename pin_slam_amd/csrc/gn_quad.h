@@ -408,7 +408,7 @@ __global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f,
                                                                          const float* __restrict__ labels, int n_q,
                                                                          double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                          float* __restrict__ grad_out,
-                                                                         const double* __restrict__ state, ColorTerm ct) {
+                                                                         const double* state, ColorTerm ct, int tail_on) {
     using Q = QuadDec<H, SPLIT>;
     static_assert(!COLOR || (SPLIT && LC >= 1), "the colour term runs on the split-fp16 images");
     extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];  // decoder image(s), then the block reduction
@@ -511,6 +511,11 @@ __global__ __launch_bounds__(BLK, 1) void gn_accumulate_quad_kernel(pin_field f,
         for (int w = 0; w < BLK / 64; ++w) t += (double)red[w][threadIdx.x];
         if (t != 0.0) atomicAdd(sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS + threadIdx.x, t);
     }
+    // pin_gn_accumulate_solve: the block whose atomics land last solves the normal equations and moves the loop state (gn_solve.h)
+    // (not in the colour variants: they sit at the register limit, and four more live values put one of them into scratch memory)
+    if constexpr (!COLOR) {
+        if (tail_on && wave == 0) gn_tail_last_block(const_cast<double*>(state), sums);
+    }
 }
 
 
@@ -539,9 +544,9 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
                                                                              const float* __restrict__ labels, int n_q,
                                                                              double* __restrict__ sums, float* __restrict__ sdf_out,
                                                                              float* __restrict__ grad_out,
-                                                                             const double* __restrict__ state,
+                                                                             const double* state,
                                                                              float* __restrict__ std_out = nullptr,
-                                                                             float* __restrict__ cert_out = nullptr) {
+                                                                             float* __restrict__ cert_out = nullptr, int tail_on = 0) {
     static_assert(MODE == 0 || SPLIT, "the query modes run on the split-fp16 image");
     using Q = QuadDec<H, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gq_smem[];
@@ -728,6 +733,7 @@ __global__ __launch_bounds__(NWF_BLOCK, 1) void gn_accumulate_quad_nwf_kernel(pi
         for (int w = 0; w < NWF_BLOCK / 64; ++w) tt += (double)red[w][threadIdx.x];
         if (tt != 0.0) atomicAdd(sums + (size_t)(blockIdx.x % GN_REPLICAS) * PIN_GN_NSUMS + threadIdx.x, tt);
     }
+    if (tail_on && threadIdx.x < 64) gn_tail_last_block(const_cast<double*>(state), sums);
 }
 
 }  // namespace pin

@@ -8,6 +8,7 @@
 //
 // One thread per query.  Input is the kNN record written by knn.hip (k x 16 B, coalesced
 // per thread), so the only random traffic here is the k feature rows (32 B each).
+#include <mutex>
 #include "mlp_mfma.h"
 
 namespace pin {
@@ -417,14 +418,21 @@ __global__ __launch_bounds__(MF_BLOCK, 1) void gn_accumulate_mfma_kernel(pin_fie
 
 
 }  // namespace pin
+#include "gn_solve.h"
 #include "gn_quad.h"
 #include "sdf_quad.h"
 namespace pin {
 
 // ---- device-side normal-equation solve + loop control (one wave) ---------------------------
 // implicit_reg (utils/tracker.py:656-679) and the bookkeeping of Tracker.tracking (:147-184).
+// (the system spread over the lanes of the wave: gn_solve.h; PIN_GN_SOLVE=seq launches the r01-r05 form below for A/B runs)
 __global__ __launch_bounds__(64) void gn_solve_kernel(double* __restrict__ sums, double* __restrict__ st,
                                                       pin_gn_loop_params lp, const int* __restrict__ status) {
+    gn_solve_wave<false>(sums, st, lp, status);
+}
+
+__global__ __launch_bounds__(64) void gn_solve_seq_kernel(double* __restrict__ sums, double* __restrict__ st,
+                                                          pin_gn_loop_params lp, const int* __restrict__ status) {
     __shared__ double s[PIN_GN_NSUMS];
     const int lane = threadIdx.x;
     // this kernel is a chain of memory round trips around ~1 us of arithmetic: everything it reads is requested up
@@ -556,6 +564,31 @@ __global__ void gn_state_init_kernel(double* st, int n_src) {
     if (i == 0) { st[PIN_GN_STATE_LAST_RES] = 1e5; st[PIN_GN_STATE_VALID] = 1.0; st[PIN_GN_STATE_NSRC] = (double)n_src; }
 }
 
+// pin_gn_loop_init: the same with the pose by value (no copy in front of the launch) and the loop parameters in the state
+struct Pose16 { double m[16]; };
+__global__ __launch_bounds__(128) void gn_loop_init_kernel(double* st, Pose16 T, int n_src, pin_gn_loop_params lp, const int* status) {
+    const int i = threadIdx.x;
+    if (i >= PIN_GN_STATE_DOUBLES) return;
+    double v = 0.0;
+    if (i < 16) v = T.m[i];
+    switch (i) {
+        case PIN_GN_STATE_LAST_RES: v = 1e5; break;
+        case PIN_GN_STATE_VALID: v = 1.0; break;
+        case PIN_GN_STATE_NSRC: v = (double)n_src; break;
+        case PIN_GN_STATE_LP + 0: v = lp.lm_lambda; break;
+        case PIN_GN_STATE_LP + 1: v = lp.term_thre_deg; break;
+        case PIN_GN_STATE_LP + 2: v = lp.term_thre_m; break;
+        case PIN_GN_STATE_LP + 3: v = lp.min_valid_ratio; break;
+        case PIN_GN_STATE_LP + 4: v = lp.max_increment_ratio; break;
+        case PIN_GN_STATE_LP + 5: v = (double)lp.min_valid_points; break;
+        case PIN_GN_STATE_LP + 6: v = (double)lp.iter_n; break;
+        case PIN_GN_STATE_LP + 7: v = (double)lp.early_exit; break;
+        case PIN_GN_STATE_STATUS_PTR: v = __longlong_as_double((long long)(unsigned long long)status); break;
+        default: break;
+    }
+    st[i] = v;
+}
+
 // ---- tensor-API kernels (Mesher / drop-in query_feature, Decoder.sdf) --------------------
 __global__ __launch_bounds__(256) void query_feature_kernel(pin_field f, const float* __restrict__ query,
                                                             const float4* __restrict__ nbr,
@@ -665,6 +698,15 @@ static int gq_cu_count() {
     return n_cu;
 }
 
+// pin_gn_accumulate_solve tells the tile kernels that can finish the iteration themselves (gn_solve.h) to do so through this flag
+// instead of through five layers of launchers; a launcher that takes it says so in `tl_tail_taken`
+static thread_local bool tl_tail = false;
+static thread_local bool tl_tail_taken = false;
+static int take_tail() {
+    if (tl_tail) tl_tail_taken = true;
+    return tl_tail ? 1 : 0;
+}
+
 template <int H, bool ORIENT, bool SPLIT, int LC, int BLK>
 static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const float* pts, const float4* nb4,
                            const int32_t* nn_count, const float* labels, int32_t n, double* sums, float* sdf_out,
@@ -682,7 +724,7 @@ static int launch_quad_blk(const pin_field* f, const pin_gn_params* gp, const fl
     memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, SPLIT, LC, false, BLK>), grid, block,
                        gq_lds_bytes(QuadDec<H, SPLIT>::bytes(f->levels), BLK), s, *f, *gp, pts, nb4, nn_count, labels, n, sums, sdf_out,
-                       grad_out, state, none);
+                       grad_out, state, none, take_tail());
     return 0;
 }
 
@@ -710,7 +752,7 @@ static int launch_quad_color_inst(const pin_field* f, const pin_gn_params* gp, c
     if (attr != hipSuccess) return fail(-2, "gn tile kernel: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr));
     const dim3 grid(min(gq_cu_count(), cdiv(n, 16))), block(BLK);
     hipLaunchKernelGGL((gn_accumulate_quad_kernel<H, ORIENT, true, LC, true, BLK>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
-                       labels, n, sums, sdf_out, grad_out, state, ct);
+                       labels, n, sums, sdf_out, grad_out, state, ct, 0);  // (no tail in the colour variants: gn_quad.h)
     return 0;
 }
 
@@ -763,7 +805,7 @@ static int launch_quad_nwf_inst(const pin_field* f, const pin_gn_params* gp, con
     const int tiles = cdiv(n, 2);
     const dim3 grid(min(gq_cu_count(), cdiv(tiles, NWF_BLOCK / 64))), block(NWF_BLOCK);
     hipLaunchKernelGGL((gn_accumulate_quad_nwf_kernel<H, ORIENT, SPLIT, LC>), grid, block, lds_bytes, s, *f, *gp, pts, nb4, nn_count,
-                       labels, n, sums, sdf_out, grad_out, state);
+                       labels, n, sums, sdf_out, grad_out, state, (float*)nullptr, (float*)nullptr, take_tail());
     return 0;
 }
 
@@ -1010,9 +1052,52 @@ extern "C" int pin_gn_accumulate(const pin_field* f, const pin_gn_params* gp, co
     return 0;
 }
 
+// States that hold their loop parameters (pin_gn_loop_init), by address: pin_gn_accumulate_solve lets the tile kernel finish the
+// iteration only on one of these and only with the parameters it holds.  A handful of trackers per process: a short table.
+namespace {
+struct LoopState { const double* state; pin_gn_loop_params lp; };
+std::mutex g_loop_mutex;
+LoopState g_loop_states[8];
+int g_loop_next = 0;
+void loop_state_forget(const double* state) {
+    std::lock_guard<std::mutex> lock(g_loop_mutex);
+    for (auto& e : g_loop_states) if (e.state == state) e.state = nullptr;
+}
+void loop_state_remember(const double* state, const pin_gn_loop_params& lp) {
+    std::lock_guard<std::mutex> lock(g_loop_mutex);
+    LoopState* slot = nullptr;
+    for (auto& e : g_loop_states) if (e.state == state) slot = &e;
+    if (slot == nullptr) { slot = &g_loop_states[g_loop_next]; g_loop_next = (g_loop_next + 1) % 8; }
+    slot->state = state;
+    slot->lp = lp;
+}
+bool same_lp(const pin_gn_loop_params& a, const pin_gn_loop_params& b) {
+    return a.lm_lambda == b.lm_lambda && a.term_thre_deg == b.term_thre_deg && a.term_thre_m == b.term_thre_m &&
+           a.min_valid_ratio == b.min_valid_ratio && a.max_increment_ratio == b.max_increment_ratio &&
+           a.min_valid_points == b.min_valid_points && a.iter_n == b.iter_n && a.early_exit == b.early_exit;
+}
+}  // namespace
+static bool loop_state_holds(const double* state, const pin_gn_loop_params* lp) {
+    std::lock_guard<std::mutex> lock(g_loop_mutex);
+    for (const auto& e : g_loop_states) if (e.state == state && e.state != nullptr) return same_lp(e.lp, *lp);
+    return false;
+}
+
+extern "C" int pin_gn_loop_init(double* state, const double* T_init_host, int32_t n_src, const pin_gn_loop_params* lp, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(state && T_init_host && lp && n_src > 0, "bad arguments");
+    Pose16 T;
+    memcpy(T.m, T_init_host, sizeof(T.m));
+    hipLaunchKernelGGL(gn_loop_init_kernel, dim3(1), dim3(128), 0, as_stream(stream), state, T, n_src, *lp, (const int*)status_word());
+    PIN_CHECK_LAUNCH();
+    loop_state_remember(state, *lp);
+    return 0;
+}
+
 extern "C" int pin_gn_state_init(double* state, const double* T_init_host, int32_t n_src, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(state && T_init_host && n_src > 0, "bad arguments");
+    loop_state_forget(state);
     hipStream_t s = as_stream(stream);
     PIN_CHECK_HIP(hipMemcpyAsync(state, T_init_host, 16 * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(gn_state_init_kernel, dim3(1), dim3(64), 0, s, state, n_src);
@@ -1082,7 +1167,9 @@ extern "C" int pin_gn_accumulate_dev(const pin_field* f, const pin_gn_params* gp
 extern "C" int pin_gn_solve(double* sums, double* state, const pin_gn_loop_params* lp, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(sums && state && lp, "NULL pointer");
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp, (const int*)status_word());
+    static const bool seq = [] { const char* e = getenv("PIN_GN_SOLVE"); return e && e[0] == 's'; }();
+    if (seq) hipLaunchKernelGGL(gn_solve_seq_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp, (const int*)status_word());
+    else hipLaunchKernelGGL(gn_solve_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, state, *lp, (const int*)status_word());
     PIN_CHECK_LAUNCH();
     return 0;
 }
@@ -1091,7 +1178,18 @@ extern "C" int pin_gn_accumulate_solve(const pin_field* f, const pin_gn_params* 
                                        const pin_gn_loop_params* lp, const float* cur, const float* nbr,
                                        const int32_t* nn_count, const float* sdf_labels, int32_t n, double* sums,
                                        double* state, void* stream) {
-    if (int e = pin_gn_accumulate_dev(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, state, stream)) return e;
+    // On a state from pin_gn_loop_init with these parameters the tile kernels finish the iteration in their last block
+    // (gn_solve.h: solve, pose, loop state, sums cleared): two launches per iteration instead of three.  The 64-queries-per-wave
+    // kernel (deep decoders with a colour term or per-neighbour decoding), other parameters than the state holds, a state from
+    // pin_gn_state_init and PIN_GN_FUSE=0 (A/B runs) keep the solve kernel behind the tile kernel.
+    static const bool fuse = [] { const char* e = getenv("PIN_GN_FUSE"); return !(e && e[0] == '0'); }();
+    PIN_CHECK_ARG(lp != nullptr && state != nullptr, "NULL pointer");
+    tl_tail = fuse && loop_state_holds(state, lp);
+    tl_tail_taken = false;
+    const int e = pin_gn_accumulate_dev(f, gp, color, cur, nbr, nn_count, sdf_labels, n, sums, state, stream);
+    tl_tail = false;
+    if (e) return e;
+    if (tl_tail_taken) return 0;
     return pin_gn_solve(sums, state, lp, stream);
 }
 

@@ -68,7 +68,21 @@ class _StandaloneBase:
             src = ds.gt_poses
         else:
             return
-        self.used_poses = torch.tensor(np.asarray(src[:cur + 1]), device=self.device, dtype=torch.float64)
+        # The reference uploads the whole pose history here, every frame (a synchronous copy from pageable memory: the host waits
+        # for everything queued so far).  Nothing of the hot path reads it on the device, so the host keeps the snapshot and
+        # `used_poses` turns it into the same tensor when somebody asks (property below).
+        self._used_poses_host = np.array(src[:cur + 1], dtype=np.float64)
+        self._used_poses_dev = None
+
+    @property
+    def used_poses(self):
+        if self._used_poses_dev is None and self._used_poses_host is not None:
+            self._used_poses_dev = torch.tensor(self._used_poses_host, device=self.device, dtype=torch.float64)
+        return self._used_poses_dev
+
+    @used_poses.setter
+    def used_poses(self, value):
+        self._used_poses_host, self._used_poses_dev = None, value
 
     def get_ba_samples(self, subsample_count):
         """mapper.py:506-524 feeds bundle_adjustment only, which is refused (see Mapper.bundle_adjustment)."""

@@ -11,6 +11,7 @@ The drop-in classes in ``pin_slam_amd.dropin`` wrap these with the reference's s
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Optional
 
@@ -101,7 +102,13 @@ class GNTracker:
             self.state = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device=src.device)
             self.state_host = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64).pin_memory()
         T0 = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64))
-        check(L.pin_gn_state_init(self.state.data_ptr(), T0.ctypes.data, n, stream), "pin_gn_state_init")
+        lp = _lib.GnLoopParams()
+        lp.lm_lambda, lp.term_thre_deg, lp.term_thre_m = float(self.lm_lambda), float(term_deg), float(term_m)
+        lp.min_valid_ratio, lp.max_increment_ratio, lp.min_valid_points = float(min_valid_ratio), 1.1, 30
+        lp.iter_n, lp.early_exit = int(iters), int(bool(early_exit))
+        # (the loop parameters go INTO the state: pin_gn_accumulate_solve is then two launches per iteration -- the tile kernel's
+        # last block runs the solve)
+        check(L.pin_gn_loop_init(self.state.data_ptr(), T0.ctypes.data, n, C.byref(lp), stream), "pin_gn_loop_init")
         # the solve kernel of every iteration leaves the sums zeroed for the next one -- also the last one of the previous call:
         # a fill launch is needed only the first time and after the host-driven step(), which does not run that kernel
         if not getattr(self, "_sums_clean", False):
@@ -117,11 +124,6 @@ class GNTracker:
             if self.bricks.mode[:2] != (bool(time_filtering), bool(local)):
                 raise RuntimeError("brick cache was built for another query mode")
             bc = self.bricks.params()
-        lp = _lib.GnLoopParams()
-        lp.lm_lambda, lp.term_thre_deg, lp.term_thre_m = float(self.lm_lambda), float(term_deg), float(term_m)
-        lp.min_valid_ratio, lp.max_increment_ratio, lp.min_valid_points = float(min_valid_ratio), 1.1, 30
-        lp.iter_n, lp.early_exit = int(iters), int(bool(early_exit))
-        import ctypes as C
         sp_r, f_r, gp_r, lp_r = C.byref(sp), C.byref(f), C.byref(self.gp), C.byref(lp)
         ct_r = C.byref(color) if color is not None else None
         bc_r = C.byref(bc) if bc is not None else None

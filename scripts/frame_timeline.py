@@ -1,7 +1,8 @@
 """Timeline of ONE frame of bench.py out of a rocprofv3 kernel trace (csv): every launch of the last complete frame with its
 start offset, duration and the idle gap in front of it; the registration loop and the training iterations are collapsed to
 one line per kernel class.  Frames are cut at extract_xyz_kernel (the first launch of pin_preprocess_frame).
-  usage: python scripts/frame_timeline.py <..._kernel_trace.csv> [--full]"""
+  usage: python scripts/frame_timeline.py <..._kernel_trace.csv> [--full] [--back=K]   (K = 0: the last complete frame, 1: the one before, ...)
+With --preprocess-stream side the scan chain of frame f+1 starts beside the mapping of frame f: the cut is still its first launch."""
 import collections
 import csv
 import sys
@@ -13,12 +14,13 @@ if len(marks) < 2:
     sys.exit("fewer than two frames in the trace")
 per = 2 if "--marks-per-frame=1" not in sys.argv else 1  # (pin_preprocess_frame runs twice per frame: source and map clouds)
 marks = marks[::per]
-a, b = marks[-2], marks[-1]
+back = next((int(x.split("=")[1]) for x in sys.argv if x.startswith("--back=")), 0)
+a, b = marks[-2 - back], marks[-1 - back]
 seg = ev[a:b]
 t0 = seg[0][0]
 wall = seg[-1][1] - t0
 busy = sum(e[1] - e[0] for e in seg)
-print(f"last complete frame: {len(seg)} launches, wall {wall / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(wall - busy) / 1e6:.3f} ms")
+print(f"frame {-1 - back} of the trace: {len(seg)} launches, wall {wall / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(wall - busy) / 1e6:.3f} ms")
 
 
 def short(n):
