@@ -34,6 +34,7 @@ class GNTracker:
         self.sums_host = torch.empty((PIN_GN_REPLICAS, PIN_GN_NSUMS), dtype=torch.float64).pin_memory()
         self.on_knn = None  # optional hooks(start: bool) used by bench.py to bracket the kNN / GN launches
         self.on_gn = None
+        self.fuse_solve = True  # pin_gn_accumulate_solve per iteration (False: pin_gn_accumulate_dev + pin_gn_solve)
         self.bricks = None  # ops.BrickCache built for (time_filtering, local) of the calls below
         self.state = self.state_host = None
         # device loop: Morton-order the source points once per registration (pin_spatial_sort); cell ~ voxel / 4
@@ -191,11 +192,13 @@ class GNTracker:
                 self.on_knn(False)
             if self.on_gn:
                 self.on_gn(True)
-                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, ct_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
-                self.on_gn(False)
-                rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
-            else:
+            if self.fuse_solve:  # the tile kernel's last block runs the solve (a state from pin_gn_loop_init): one launch
                 rc |= L.pin_gn_accumulate_solve(f_r, gp_r, ct_r, lp_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+            else:  # tile kernel and solve kernel, one by one (tests: both forms agree)
+                rc |= L.pin_gn_accumulate_dev(f_r, gp_r, ct_r, cur_p, nbr_p, nn_p, lab_p, n, sums_p, st_p, stream)
+                rc |= L.pin_gn_solve(sums_p, st_p, lp_r, stream)
+            if self.on_gn:
+                self.on_gn(False)
             if rc:
                 check(rc, "pin_gn_knn / pin_gn_accumulate_solve")
             if probe is not None:  # diagnostics (bench.py --coherent-probe): synchronises every iteration

@@ -134,8 +134,7 @@ def test_both_forms_of_the_iteration_agree(gold, early_exit):
     for form in ("own_launch", "last_block"):
         gn = engine.GNTracker(d["st"], d["fs_loc"], _gn_params(d), d["cfg_reg_lm_lambda"], src.shape[0])
         gn.bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(d["st"])
-        if form == "own_launch":  # (hooks around the launches: search, tile kernel and solve are queued one by one)
-            gn.on_knn = gn.on_gn = lambda start: None
+        gn.fuse_solve = form == "last_block"
         for _ in range(2):  # (twice: the second call starts from what the first one left in the sums and the ticket)
             out[form] = gn.track(src, d["reg_Tinit"], iters, term_deg=d["cfg_reg_term_thre_deg"], term_m=d["cfg_reg_term_thre_m"],
                                  early_exit=early_exit)
