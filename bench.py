@@ -436,13 +436,26 @@ def main():
             se = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if (ev and side is not None) else None
             if se: se[0].record(side)
             _ = prep(raw, raw_ts, last_odom_tran=last_odom, frame_id=fid, stream=side)
+            pc, src = _[0], _[2]
+            state["cloud"], state["src"] = pc, src
+            if side is not None:
+                # ... and what the registration needs of the cloud: its coordinates as a table of their own, Morton-ordered into the
+                # tracker's buffer (GNTracker.presort) -- still on the scan's stream, beside the previous frame's mapping
+                main_stream = torch.cuda.current_stream()
+                with torch.cuda.stream(side):
+                    state["xyz"] = pc[:, :3].contiguous()
+                    state["xyz"].record_stream(main_stream)
+                    if trk._gn is not None and not source_downsampled:
+                        trk._gn.presort(state["xyz"], stream=side)
+                    side_done = torch.cuda.Event()
+                    side_done.record(side)
+                main_stream.wait_event(side_done)  # (queued behind the previous frame's mapping: the copy is long done by then)
+            else:
+                state["xyz"] = pc[:, :3].contiguous()
             if se:
                 se[1].record(side)
                 if sink is stage_events:
                     side_events.append(se)
-            pc, src = _[0], _[2]
-            state["cloud"], state["src"] = pc, src
-            state["xyz"] = pc[:, :3].contiguous()
             state["rgb"], state["src_rgb"] = (pc[:, 3:6].contiguous(), _[3]) if colour else (None, None)
         pc = state["cloud"]
         reg = state["src"] if source_downsampled else state["xyz"]

@@ -75,6 +75,32 @@ class GNTracker:
             raise RuntimeError("registration_step: non-finite normal-equation sums (non-finite source points, map or decoder)")
         return ops.solve_gn(sums, self.lm_lambda)
 
+    def _sort_into_buffer(self, src: torch.Tensor, stream):
+        L = _lib.lib()
+        n = src.shape[0]
+        if self._sorted is None or self._sorted.shape[0] < n:
+            self._sorted = torch.empty((n, 3), dtype=torch.float32, device=src.device)
+            nb = int(L.pin_maint_workspace_bytes(n))
+            self._sort_ws = torch.empty((nb,), dtype=torch.uint8, device=src.device)
+        check(L.pin_spatial_sort(src.data_ptr(), n, float(self.sort_cell), self._sorted.data_ptr(), None, self._sort_ws.data_ptr(),
+                                 self._sort_ws.numel(), stream), "pin_spatial_sort")
+
+    def presort(self, src: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
+        """The Morton ordering of track()'s source points ahead of time, on `stream` (default: the current one) -- a loader
+        that prepares frame f+1's scan on its own stream while the main stream trains on frame f queues this behind the scan
+        chain: 60 us of launches less between Mapper.mapping and the first registration iteration.  The next track() call on
+        the SAME tensor (address, length) waits for the order through an event instead of sorting; any other call sorts as
+        usual.  The caller vouches that no registration of this tracker is still running (track() returns after its read-back)."""
+        if not (self.sort_points and src.is_cuda and src.shape[0] >= self.sort_min_points):
+            return
+        s = stream if stream is not None else torch.cuda.current_stream(src.device)
+        with torch.cuda.stream(s):
+            self._sort_into_buffer(src, ops._stream())
+            if getattr(self, "_presort_ev", None) is None:
+                self._presort_ev = torch.cuda.Event()
+            self._presort_ev.record(s)
+        self._presorted = ((src.data_ptr(), src.shape[0], float(self.sort_cell)), self._presort_ev)
+
     def track(self, src: torch.Tensor, T_init: np.ndarray, iters: int, term_deg: float = 0.01,
               term_m: float = 0.001, early_exit: bool = True, min_valid_ratio: float = 0.2,
               time_filtering=True, local=True, labels=None, color=None, probe: Optional[list] = None):
@@ -90,15 +116,13 @@ class GNTracker:
         # x-fastest voxel id, and both per-iteration kernels are ~20 % faster on a Morton-ordered scan (30 -> 25 us
         # kNN, 37 -> 34.5 us GN per 98.7k points, scripts/knn_order_probe.py): one sort per registration pays after
         # the second iteration.  Per-point inputs (labels, colours) would have to follow: those calls keep the order.
+        pre, self._presorted = getattr(self, "_presorted", None), None
         if self.sort_points and labels is None and color is None and n >= self.sort_min_points and iters > 2:
-            if self._sorted is None or self._sorted.shape[0] < n:
-                self._sorted = torch.empty((n, 3), dtype=torch.float32, device=src.device)
-                nb = int(L.pin_maint_workspace_bytes(n))
-                self._sort_ws = torch.empty((nb,), dtype=torch.uint8, device=src.device)
-            out = self._sorted[:n]
-            check(L.pin_spatial_sort(src.data_ptr(), n, float(self.sort_cell), out.data_ptr(), None, self._sort_ws.data_ptr(),
-                                     self._sort_ws.numel(), stream), "pin_spatial_sort")
-            src = out
+            if pre is not None and pre[0] == (src.data_ptr(), n, float(self.sort_cell)):
+                torch.cuda.current_stream().wait_event(pre[1])  # presort(): the order is there already, queued on another stream
+            else:
+                self._sort_into_buffer(src, stream)
+            src = self._sorted[:n]
         if self.state is None:
             self.state = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64, device=src.device)
             self.state_host = torch.empty(_lib.PIN_GN_STATE_DOUBLES, dtype=torch.float64).pin_memory()

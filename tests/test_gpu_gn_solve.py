@@ -150,3 +150,33 @@ def test_both_forms_of_the_iteration_agree(gold, early_exit):
         np.testing.assert_allclose(Ta[:3, 3], d["trk_T"][:3, 3], rtol=0, atol=1e-4)
     else:
         assert ia == iters
+
+
+def test_presorted_registration_is_the_sorted_one(gold):
+    """GNTracker.presort on another stream, then track() on the same tensor: the order is taken from the buffer (no sort launch in
+    track), the result is the one of a call that sorts itself; a call on another tensor in between sorts as usual."""
+    from pin_slam_amd import engine, ops
+    from tests import gpu_util as U
+    from tests.test_gpu_parity import _gn_params
+    d = gold
+    src = U.dev(d["reg_src"])
+    kw = dict(term_deg=d["cfg_reg_term_thre_deg"], term_m=d["cfg_reg_term_thre_m"])
+    gn = engine.GNTracker(d["st"], d["fs_loc"], _gn_params(d), d["cfg_reg_lm_lambda"], src.shape[0])
+    gn.sort_min_points = 1
+    gn.bricks = ops.BrickCache(d["neighbor_dx"], int(d["num_nei_cells"])).build(d["st"])
+    want = gn.track(src, d["reg_Tinit"], int(d["cfg_reg_iter_n"]), **kw)
+    side = torch.cuda.Stream()
+    calls = []
+    sort = gn._sort_into_buffer
+    gn._sort_into_buffer = lambda s, stream: (calls.append(s.data_ptr()), sort(s, stream))[1]
+    gn.presort(src, stream=side)
+    assert calls == [src.data_ptr()] and gn._presorted is not None
+    got = gn.track(src, d["reg_Tinit"], int(d["cfg_reg_iter_n"]), **kw)
+    assert calls == [src.data_ptr()] and gn._presorted is None  # (track() did not sort again)
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=2e-7)
+    assert got[1:5] == want[1:5] or (got[1], got[3], got[4]) == (want[1], want[3], want[4])
+    other = src.clone()
+    gn.presort(src, stream=side)
+    got2 = gn.track(other, d["reg_Tinit"], int(d["cfg_reg_iter_n"]), **kw)  # another tensor: the stale order is not used
+    assert calls[-1] == other.data_ptr() and len(calls) == 3
+    np.testing.assert_allclose(got2[0], want[0], rtol=0, atol=2e-7)
