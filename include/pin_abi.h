@@ -58,7 +58,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 15
+#define PIN_ABI_VERSION 16
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -228,6 +228,10 @@ typedef struct pin_train_params {
                               * and kept current by pin_adam_dense.image): skip the staging launch */
     int32_t defer_weight_grad;/* pin_train_step stops after the tile kernel (feature gradients done, operand stream in the
                               * workspace); pin_train_weight_grad finishes the step.  Fused tile paths only. */
+    int32_t defer_dec_reduce; /* leave the decoder's weight gradient of this step as the weight-gradient launch wrote it -- slot copies in
+                              * the workspace -- instead of adding it into dec_grad with a launch of its own: the optimiser's decoder
+                              * step takes it from there (pin_adam_dense.grad_partial; pin_train_deferred_partial says where it is).
+                              * The loss sums of the step are not formed (loss_out keeps its value).  Fused tile paths only. */
 } pin_train_params;
 
 /* ---- map maintenance (NeuralPoints.update / reset_local_map / assign_local_to_global,
@@ -584,6 +588,12 @@ int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* 
                    int32_t* ts_update_rw, float* feat_grad, float* dec_grad, double* loss_out,
                    float* pred_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Where the last pin_train_step / pin_train_weight_grad of THIS thread that ran with tp->defer_dec_reduce left the decoder's gradient:
+ * slots copies of n floats each (inside that call's workspace, valid until the next training launch on it) and the factor that
+ * turns their sum into the gradient.  Returns -1 if that call did not defer (no decoder gradient asked for, or a path without
+ * the slot copies). */
+int pin_train_deferred_partial(const float** partial_out, int32_t* slots_out, int64_t* n_out, float* scale_out);
+
 /* The second half of a pin_train_step called with tp->defer_weight_grad: streamed weight gradient into dec_grad (+=) and
  * the loss sums into loss_out, from the operand stream the first half left in `workspace` (same f / tp / workspace).  It
  * touches neither the feature table nor the feature gradients, so a caller may run it on ANOTHER stream beside the
@@ -687,6 +697,9 @@ typedef struct pin_adam_dense {
     int64_t n;
     void* image;                       /* or NULL */
     int32_t hidden, levels, out_dim;   /* decoder shape of `image` */
+    const float* grad_partial;         /* or NULL: the step's gradient is grad[e] + partial_scale * sum_c grad_partial[c * n + e], */
+    int32_t partial_slots;             /*   c < partial_slots (what pin_train_step leaves with defer_dec_reduce: the same sum, in the */
+    float partial_scale;               /*   same order, its own reduction launch would have added into grad) */
 } pin_adam_dense;
 int pin_adam_lazy_prepare(const float* nbr, int64_t n_records, float* param, float* grad, float* exp_avg,
                           float* exp_avg_sq, int32_t* pending, int32_t step, const float* coef, int32_t t_max,

@@ -19,7 +19,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 15
+PIN_ABI_VERSION = 16
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -54,7 +54,8 @@ class Field(C.Structure):
 
 class AdamDense(C.Structure):
     _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", C.c_int64), ("image", vp),
-                ("hidden", C.c_int32), ("levels", C.c_int32), ("out_dim", C.c_int32)]
+                ("hidden", C.c_int32), ("levels", C.c_int32), ("out_dim", C.c_int32),
+                ("grad_partial", vp), ("partial_slots", C.c_int32), ("partial_scale", C.c_float)]
 
 
 class ColorTerm(C.Structure):
@@ -122,7 +123,7 @@ class TrainParams(C.Structure):
         ("n_main", C.c_int32), ("n_eik", C.c_int32), ("loss_weight_on", C.c_int32),
         ("sigma", C.c_float), ("weight_e", C.c_float), ("eik_eps", C.c_float),
         ("inv_n_main", C.c_float), ("inv_n_eik", C.c_float), ("eik_analytic", C.c_int32),
-        ("dec_image_current", C.c_int32), ("defer_weight_grad", C.c_int32),
+        ("dec_image_current", C.c_int32), ("defer_weight_grad", C.c_int32), ("defer_dec_reduce", C.c_int32),
     ]
 
 
@@ -217,6 +218,7 @@ SIGNATURES = {
     "pin_train_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_train_weight_grad": (i32, [P(Field), P(TrainParams), vp, vp, vp, i64, vp]),
+    "pin_train_deferred_partial": (i32, [vp, vp, vp, vp]),
     "pin_train_color_step": (i32, [P(Field), P(TrainColorParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),

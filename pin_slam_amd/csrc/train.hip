@@ -20,6 +20,9 @@ namespace pin {
 
 
 constexpr int DW_SLOTS = 32;            // (train_fused.h)
+// pin_train_params.defer_dec_reduce: where the last training call of this thread left the decoder's gradient (pin_train_deferred_partial)
+struct DeferredPartial { const float* partial; int64_t n; float scale; };
+static thread_local DeferredPartial tl_deferred = {nullptr, 0, 0.f};
 constexpr int FUSED_NDEC_MAX = 16384;   // >= parameters of the largest decoder (4 x 64: 13 313)
 
 struct TrainWs {
@@ -715,6 +718,28 @@ __device__ __forceinline__ void dense_image_entry(const pin_adam_dense& d, int e
     else QuadDecoderH<32>::stage_param(e, x, d.levels, d.out_dim, w);
 }
 
+// The dense tensor that rides along with the lazy launches (the decoder), step `dense_step`, element e.  grad_partial: the weight
+// gradient of the step as the weight-gradient launch left it (pin_train_params.defer_dec_reduce) -- summed here exactly as
+// train_finalize_kernel sums it (same order, same scale), so that the decoder's step is the bits of the two-launch form
+__device__ __forceinline__ void dense_rider_step(const pin_adam_dense& dense, long e, const float* __restrict__ coef, int t_max, int dense_step,
+                                                 float b1, float b2, float eps) {
+    float gi = dense.grad[e];
+    if (dense.grad_partial != nullptr) {
+        float v[DW_SLOTS];
+#pragma unroll
+        for (int c = 0; c < DW_SLOTS; ++c) v[c] = dense.grad_partial[(size_t)c * dense.n + e];
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < DW_SLOTS; ++c) t += v[c];
+        gi += t * dense.partial_scale;
+    }
+    float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
+    adam_elem(pi, mi, vi, gi, coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
+    dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
+    dense.grad[e] = 0.f;
+    dense_image_entry(dense, (int)e, pi);
+}
+
 __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __restrict__ nbr, long n_records,
                                                                 float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
@@ -724,13 +749,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
                                                                 pin_adam_dense dense, int dense_step) {
     if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
         const long e = (long)((int)blockIdx.x - rec_blocks) * 256 + threadIdx.x;
-        if (e < dense.n) {
-            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
-            adam_elem(pi, mi, vi, dense.grad[e], coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
-            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
-            dense.grad[e] = 0.f;
-            dense_image_entry(dense, (int)e, pi);
-        }
+        if (e < dense.n) dense_rider_step(dense, e, coef, t_max, dense_step, b1, b2, eps);
         return;
     }
     // the step coefficients go through LDS: lazy_settle indexes them per lane inside its replay loop, and a global
@@ -781,13 +800,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_rows_kernel(float* __re
                                                                      pin_adam_dense dense, int dense_step, int all_rows) {
     if ((int)blockIdx.x >= row_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
         const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
-        if (e < dense.n) {
-            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
-            adam_elem(pi, mi, vi, dense.grad[e], coef[dense_step], coef[t_max + 1 + dense_step], b1, b2, eps);
-            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
-            dense.grad[e] = 0.f;
-            dense_image_entry(dense, (int)e, pi);
-        }
+        if (e < dense.n) dense_rider_step(dense, e, coef, t_max, dense_step, b1, b2, eps);
         return;
     }
     extern __shared__ float lazy_coef[];  // (see adam_lazy_prepare_kernel)
@@ -820,13 +833,7 @@ __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict_
                                                               float eps, int row_blocks, pin_adam_dense dense) {
     if ((int)blockIdx.x >= row_blocks) {  // the dense tensor's last step
         const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
-        if (e < dense.n) {
-            float pi = dense.param[e], mi = dense.exp_avg[e], vi = dense.exp_avg_sq[e];
-            adam_elem(pi, mi, vi, dense.grad[e], coef[t_final], coef[t_max + 1 + t_final], b1, b2, eps);
-            dense.param[e] = pi; dense.exp_avg[e] = mi; dense.exp_avg_sq[e] = vi;
-            dense.grad[e] = 0.f;
-            dense_image_entry(dense, (int)e, pi);
-        }
+        if (e < dense.n) dense_rider_step(dense, e, coef, t_max, t_final, b1, b2, eps);
         return;
     }
     extern __shared__ float lazy_coef[];  // (see adam_lazy_prepare_kernel)
@@ -1100,6 +1107,10 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
                            dw_partial, 0, chunk);
         PIN_CHECK_LAUNCH();
     }
+    if (tp->defer_dec_reduce && want_dec) {  // the optimiser's decoder step sums the slot copies itself (pin_adam_dense.grad_partial)
+        tl_deferred = {dw_partial, (int64_t)n_dec, 1.0f / dscale};
+        return 0;
+    }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
                        dec_grad, loss_partial, grid, loss_out, OD == 1 ? 2 : 1);
     PIN_CHECK_LAUNCH();
@@ -1167,6 +1178,10 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
         PIN_CHECK_LAUNCH();
+    }
+    if (tp->defer_dec_reduce && want_dec) {  // the optimiser's decoder step sums the slot copies itself (pin_adam_dense.grad_partial)
+        tl_deferred = {dw_partial, (int64_t)n_dec, 1.0f / dscale};
+        return 0;
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
                        dec_grad, loss_partial, grid, loss_out, 2);
@@ -1239,6 +1254,10 @@ static int launch_fused_nwf(const pin_field* f, const pin_train_params* tp, cons
         hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws, L, 1, n_dec, dw_partial, 0, chunk);
         if (AN) hipLaunchKernelGGL((train_dw_stream_kernel<H>), dgrid, dim3(DW_WAVES * 64), 0, s, ws2, L, 1, n_dec, dw_partial, 1, chunk);
         PIN_CHECK_LAUNCH();
+    }
+    if (tp->defer_dec_reduce && want_dec) {  // the optimiser's decoder step sums the slot copies itself (pin_adam_dense.grad_partial)
+        tl_deferred = {dw_partial, (int64_t)n_dec, 1.0f / dscale};
+        return 0;
     }
     hipLaunchKernelGGL(train_finalize_kernel, dim3(want_dec ? cdiv(n_dec, 256) : 1), dim3(256), 0, s, dw_partial, n_dec, 1.0f / dscale,
                        dec_grad, loss_partial, grid, loss_out, 2);
@@ -1349,13 +1368,23 @@ extern "C" int pin_train_step(const pin_field* f, const pin_train_params* tp, co
                               float* feat_grad, float* dec_grad, double* loss_out, float* pred_out,
                               void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();
+    tl_deferred = {nullptr, 0, 0.f};
     return train_step_impl(f, tp, query, nbr, nn_count, sdf_label, sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad,
                            dec_grad, loss_out, pred_out, workspace, workspace_bytes, stream, (tp && tp->defer_weight_grad) ? 1 : 3);
+}
+
+extern "C" int pin_train_deferred_partial(const float** partial_out, int32_t* slots_out, int64_t* n_out, float* scale_out) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(partial_out && slots_out && n_out && scale_out, "NULL pointer");
+    if (tl_deferred.partial == nullptr) return -1;  // (not an error to report: the caller asks whether the call deferred)
+    *partial_out = tl_deferred.partial; *slots_out = DW_SLOTS; *n_out = tl_deferred.n; *scale_out = tl_deferred.scale;
+    return 0;
 }
 
 extern "C" int pin_train_weight_grad(const pin_field* f, const pin_train_params* tp, float* dec_grad, double* loss_out,
                                      void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();
+    tl_deferred = {nullptr, 0, 0.f};
     return train_step_impl(f, tp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dec_grad,
                            loss_out, nullptr, workspace, workspace_bytes, stream, 2);
 }
@@ -1603,6 +1632,8 @@ static int lazy_dense(const pin_adam_dense* dense, const float* coef, pin_adam_d
                               dense->n == (int64_t)H * MLP_IN + H + (int64_t)(L - 1) * (H * H + H) + OD * H + OD,
                           "dense tensor: the image's decoder shape does not match the parameter count");
         }
+        PIN_CHECK_ARG(dense->grad_partial == nullptr || dense->partial_slots == DW_SLOTS,
+                      "dense tensor: grad_partial must hold the slot copies pin_train_deferred_partial reports");
         d = *dense;
     }
     return 0;

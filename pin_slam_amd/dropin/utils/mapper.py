@@ -561,6 +561,9 @@ class Mapper(_StandaloneBase):
         t = self._get_trainer(peek_bricks=True)
         t.reset_optimizer(iter_count)  # a new Adam per call (mapper.py:615)
         t.defer_side_effects = False
+        # (three launches per iteration instead of four: the next iteration's lazy-Adam launch sums the decoder's weight gradient
+        # where its tail blocks need it -- engine.MapTrainer.step_batch; PIN_DEFER_DEC_REDUCE=0: the reduction launch, A/B runs)
+        t.defer_dec_reduce = os.environ.get("PIN_DEFER_DEC_REDUCE", "1") != "0"
         if t.dp is not None:  # spatially sharded over the ranks (pin_slam_amd.dp)
             self.neural_points._use_bricks()
             self._mapping_spatial(t, iter_count)

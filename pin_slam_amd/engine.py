@@ -276,6 +276,8 @@ class MapTrainer:
         self.dp_mode = dp_mode if comm is not None else None
         self.dp = None
         self.overlap_weight_grad = None  # None = automatic, True / False force (see step_batch)
+        self.defer_dec_reduce = False   # see step_batch; Mapper.mapping switches it on for its loop
+        self._pending_partial, self._iters_planned = None, 0
         self._wg_stream, self._wg_ev, self._wg_pending = None, None, False
         # spatial shards: the all-reduce of iteration i on a side stream, beside the weight gradient of iteration i and the
         # lazy-Adam launch of iteration i + 1 (step_batch); PIN_DP_OVERLAP=0 keeps everything on one stream
@@ -485,7 +487,8 @@ class MapTrainer:
         # lazy exact Adam: ONE launch per iteration, before the forward pass -- the rows this iteration reads settle the
         # step they still owe from the iteration that last read them (+ the gradient-free steps since), and the decoder's
         # step of the previous iteration rides along in the same launch
-        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], lazy) if self.train_decoder else None
+        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], lazy, self._pending_partial) if self.train_decoder else None
+        self._pending_partial = None  # (this iteration's lazy launch takes it)
         # Two streams (one GPU, decoder training, fused tile paths): the weight gradient of this iteration, its finalize and the
         # decoder's step (with the image write-through) go to a side stream -- they touch the decoder, its gradient and
         # the workspace only -- while the caller's stream goes on with the colour branch and the lazy-Adam launch of
@@ -527,6 +530,14 @@ class MapTrainer:
             def pre():
                 self.lazy.prepare(self.buf.nbr, self.fs.feats, self.gfeat, self.m[nd:], self.v[nd:], step, dense=None)
                 self._dp_finish_exchange()
+        # One launch less per iteration (Mapper.mapping sets defer_dec_reduce): the weight-gradient launch leaves the decoder's gradient
+        # as slot copies, and instead of a reduction launch the NEXT iteration's lazy launch -- whose tail blocks take the decoder's
+        # step anyway -- sums them where it needs them (same sum, same order: the same bits).  Not on the call's last iteration
+        # (its loss sums are the ones a caller can see, and the flush wants a plain gradient), nor with anything else that reads or
+        # writes the decoder gradient between the launches (hooks, a second stream, ranks, colour / semantic branches).
+        defer_reduce = bool(self.defer_dec_reduce and lazy and self.train_decoder and not overlap and self.dp is None and self.comm is None
+                            and self.on_grads is None and self.fc is None and self.fsem is None and step < self._iters_planned
+                            and coord.shape[0] > 0)
         if self.dp is not None and coord.shape[0] == 0:
             # none of this batch's samples fell into this rank's box: its rows settle nothing, the decoder still takes its
             # step (the dense rider of the lazy launch) and the exchange below still runs -- the other ranks wait in it
@@ -540,7 +551,9 @@ class MapTrainer:
                            sigma=self.sigma, weight_e=self.weight_e, eik_eps=self.eik_eps,
                            loss_weight_on=self.loss_weight_on, global_n_main=self.bs, global_n_eik=self.n_eik_global,
                            bricks=self.bricks, before_forward=pre, queries_ready=queries_ready, image_current=lazy,
-                           knn_ready=knn_ready, defer_weight_grad=overlap or dp_defer)
+                           knn_ready=knn_ready, defer_weight_grad=overlap or dp_defer, defer_dec_reduce=defer_reduce)
+            if defer_reduce:
+                self._pending_partial = ops.train_deferred_partial()  # (None: a path that reduced as usual)
         if overlap:
             self._wg_ev[0].record(main)
             side = self._wg_stream
@@ -654,11 +667,16 @@ class MapTrainer:
         self._dp_pending = None
 
     @staticmethod
-    def _dense(fs: ops.FieldState, grad, m, v, lazy: bool):
-        """The decoder as the dense rider of the lazy optimiser, with its staged image when there is one."""
+    def _dense(fs: ops.FieldState, grad, m, v, lazy: bool, partial=None):
+        """The decoder as the dense rider of the lazy optimiser, with its staged image when there is one; `partial`: the weight
+        gradient the last training step left as slot copies (ops.train_deferred_partial), which the rider's step then sums itself."""
         if lazy and fs.dec_image is not None:
-            return (fs.dec, grad, m, v, fs.dec_image, fs.hidden, fs.levels, fs.out_dim)
-        return (fs.dec, grad, m, v)
+            d = (fs.dec, grad, m, v, fs.dec_image, fs.hidden, fs.levels, fs.out_dim)
+        else:
+            d = (fs.dec, grad, m, v)
+        if partial is not None:
+            d = d + (None,) * (8 - len(d)) + (partial,)
+        return d
 
     def _stage_images(self):
         """One staging launch per Mapper.mapping call and decoder: from then on the lazy optimiser writes every parameter it
@@ -689,6 +707,7 @@ class MapTrainer:
             # call that did not finish: the next call's publish() re-broadcasts every owned row)
             self._dp_finish_exchange()
         self.lazy_on = bool(iters) and (self.comm is None or self.dp is not None)
+        self._pending_partial, self._iters_planned = None, int(iters or 0)  # (an aborted call's owed gradient goes with its optimiser state)
         if self.dp is not None and not self.lazy_on:
             raise ValueError("the spatially sharded mapper needs the iteration count (lazy Adam on the owned rows)")
         nd = self.gdec.numel()
@@ -727,7 +746,8 @@ class MapTrainer:
         if not self.lazy_on:
             return
         nd = self.gdec.numel()
-        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], True) if self.train_decoder else None
+        dense = self._dense(self.fs, self.gdec, self.m[:nd], self.v[:nd], True, self._pending_partial) if self.train_decoder else None
+        self._pending_partial = None
         if self._wg_pending:  # the side stream took the decoder through every step already (step_batch)
             torch.cuda.current_stream().wait_event(self._wg_ev[1])
             self._wg_pending = False

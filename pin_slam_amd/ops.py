@@ -483,14 +483,16 @@ class TrainBuffers:
 def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_label, sample_weight, sample_ts,
                certainty_rw, ts_update_rw, feat_grad, dec_grad, *, sigma, weight_e, eik_eps, loss_weight_on=False,
                global_n_main=None, global_n_eik=None, pred_out=None, bricks=None, before_forward=None,
-               queries_ready=False, image_current=False, knn_ready=False, defer_weight_grad=False):
+               queries_ready=False, image_current=False, knn_ready=False, defer_weight_grad=False, defer_dec_reduce=False):
     """One Mapper.mapping iteration up to (not including) the optimiser step: queries -> kNN
     -> fused forward/loss/backward.  Gradients accumulate into feat_grad / dec_grad.
     `before_forward()` runs between the kNN and the forward pass (the lazy optimiser's catch-up).
     image_current: fs.dec_image holds the decoder's current parameters (LazyAdam keeps it so when it is handed the
     image) -- the launch sequence then has no staging kernel.
     defer_weight_grad: stop after the tile kernel; train_weight_grad(buf, dec_grad) finishes the step (the decoder's
-    weight gradient and the loss sums), possibly on another stream."""
+    weight gradient and the loss sums), possibly on another stream.
+    defer_dec_reduce: the decoder's weight gradient stays where the weight-gradient launch wrote it (no reduction launch, no
+    loss sums); train_deferred_partial() says where -- hand that to the optimiser's decoder step (LazyAdam, dense[8])."""
     L = _lib.lib()
     s = _stream()
     if not queries_ready:  # (pin_gather_batch_drawn can write them in its own launch)
@@ -511,6 +513,7 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
     if buf.analytic:  # mean over every sample of the (global) batch, mapper.py:778-781
         tp.inv_n_eik = tp.inv_n_main
     tp.defer_weight_grad = int(bool(defer_weight_grad))
+    tp.defer_dec_reduce = int(bool(defer_dec_reduce) and dec_grad is not None)
     f = fs.params()
     buf.last_call = (f, tp)
     check(L.pin_train_step(C.byref(f), C.byref(tp), _ptr(buf.query), _ptr(buf.nbr), _ptr(buf.nn),
@@ -518,6 +521,16 @@ def train_step(st: SearchState, fs: FieldState, buf: TrainBuffers, coord, sdf_la
                            _ptr(ts_update_rw), _ptr(feat_grad, torch.float32), _ptr(dec_grad), _ptr(buf.loss),
                            _ptr(pred_out), _ptr(buf.ws), buf.ws.numel() * 4, s), "pin_train_step")
     return buf.loss
+
+
+def train_deferred_partial():
+    """(address, slots, n, scale) of the decoder gradient the last train_step(..., defer_dec_reduce=True) of this thread left
+    as slot copies in its workspace, or None if that call reduced it as usual (a path without the slot copies)."""
+    ptr, slots, n, scale = C.c_void_p(), C.c_int32(), C.c_int64(), C.c_float()
+    rc = _lib.lib().pin_train_deferred_partial(C.addressof(ptr), C.addressof(slots), C.addressof(n), C.addressof(scale))
+    if rc != 0 or not ptr.value:
+        return None
+    return (ptr.value, slots.value, n.value, scale.value)
 
 
 def train_weight_grad(buf: TrainBuffers, dec_grad):
@@ -679,6 +692,11 @@ class LazyAdam:
         d.n = dense[0].numel()
         if len(dense) > 4 and dense[4] is not None:  # (image, hidden, levels, out_dim): the staged decoder follows the step
             d.image, d.hidden, d.levels, d.out_dim = dense[4].data_ptr(), int(dense[5]), int(dense[6]), int(dense[7])
+        if len(dense) > 8 and dense[8] is not None:  # (address, slots, n, scale) of train_deferred_partial(): the step's weight gradient
+            ptr, slots, n, scale = dense[8]
+            if n != d.n:
+                raise ValueError("the deferred weight gradient belongs to a decoder of another size")
+            d.grad_partial, d.partial_slots, d.partial_scale = ptr, int(slots), float(scale)
         return d
 
     def prepare(self, nbr, param, grad, m, v, step, dense=None):

@@ -194,9 +194,11 @@ def test_mini_slam_loop_update_map_track():
 
 
 @pytest.mark.parametrize("wf", [True, False])
-def test_grouped_iterations_train_like_single_ones(wf):
+def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
     """Mapper.mapping gathers and searches a group of iterations in one launch each (their inputs do not depend on the
     training) and stages the decoder once per call; `group_iterations = False` keeps one gather / kNN per iteration.
+    With the weight gradient in line, the decoder's gradient of an iteration is left as slot copies and summed by the next
+    iteration's lazy-Adam launch (three launches per iteration); PIN_DEFER_DEC_REDUCE=0 keeps the reduction launch.
     The weight gradient and the decoder's step of an iteration run on a side stream beside the next iteration's
     optimiser launch; `overlap_weight_grad = False` keeps them in line.  Same seed, same state: the same batches, and
     the trained features / decoder agree to rounding (atomics order) whatever the launch structure."""
@@ -210,7 +212,9 @@ def test_grouped_iterations_train_like_single_ones(wf):
     nrm = synth.sheet_normal(base[:, 0].astype(np.float64), base[:, 1].astype(np.float64))
     dd = 0.15 * rng.standard_normal(len(base))
     results = []
-    for grouped, overlap in ((True, True), (False, True), (True, False)):
+    deferred = []
+    for grouped, overlap, defer in ((True, True, "1"), (False, True, "1"), (True, False, "1"), (True, False, "0"), (False, False, "1")):
+        monkeypatch.setenv("PIN_DEFER_DEC_REDUCE", defer)
         torch.manual_seed(11)
         cfg = _cfg(search_alpha=0.5, query_nn_k=8, bs=2048, local_map_radius=40.0, local_map_travel_dist_ratio=5.0,
                    weighted_first=wf)
@@ -228,9 +232,16 @@ def test_grouped_iterations_train_like_single_ones(wf):
         mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
         mp.pool_sample_count = len(base)
         torch.manual_seed(5)
+        from pin_slam_amd import ops as _ops
+        seen, real = [], _ops.train_deferred_partial
+        monkeypatch.setattr(_ops, "train_deferred_partial", lambda: (seen.append(real()), seen[-1])[1])
         mp.mapping(20)  # more than one group of 16
-        assert mp._trainer.buf.group == 16
+        monkeypatch.setattr(_ops, "train_deferred_partial", real)
+        deferred.append(sum(x is not None for x in seen))
+        assert mp._trainer.buf.group == 16 and mp._trainer._pending_partial is None
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
+    # the deferred reduction ran where it can: in line (no second stream), in 19 of the 20 iterations (the last one reduces itself)
+    assert deferred == [0, 0, 19, 0, 19], deferred
     fa, da, ca = results[0]
     assert not torch.equal(fa, torch.zeros_like(fa))
     for fb, db, cb in results[1:]:

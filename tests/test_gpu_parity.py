@@ -616,6 +616,47 @@ def test_decoder_image_follows_the_optimiser(H, L, OD):
     assert not torch.equal(before, dec) and torch.equal(img, fresh())
 
 
+@pytest.mark.parametrize("form", ["prepare", "prepare_rows", "flush"])
+def test_dense_rider_sums_the_slot_copies(form):
+    """pin_adam_dense.grad_partial (what pin_train_step leaves with defer_dec_reduce): the decoder's step in the lazy launches takes
+    grad + scale * (the 32 slot copies summed in slot order) -- the bits of train_finalize_kernel's sum followed by the plain step."""
+    from pin_slam_amd import ops
+    torch.manual_seed(7)
+    n, slots, scale = 1337, 32, 2.0 ** -9
+    partial = torch.randn(slots, n, device="cuda") * 100
+    g0 = torch.randn(n, device="cuda") * 0.1
+    p, m, v = torch.randn(n, device="cuda"), torch.rand(n, device="cuda") * 0.01, torch.rand(n, device="cuda") * 1e-4
+    # the reference: finalize's sum (float32, slot order), then the dense step
+    t = torch.zeros(n, device="cuda")
+    for c in range(slots):
+        t = t + partial[c]
+    ga = g0 + t * scale
+    pa, ma, va = p.clone(), m.clone(), v.clone()
+    ops.adam_step(pa, ga, ma, va, 3, 0.01, eps=1e-15)
+    pb, gb, mb, vb = p.clone(), g0.clone(), m.clone(), v.clone()
+    feats = torch.randn(64, 8, device="cuda")
+    gf, mf, vf = torch.zeros_like(feats), torch.zeros_like(feats), torch.zeros_like(feats)
+    lazy = ops.LazyAdam(0.01, eps=1e-15)
+    lazy.reset(feats.shape[0], 6, "cuda")
+    lazy.rows_form_ratio = 0.0 if form == "prepare_rows" else 1e9
+    nbr = torch.zeros((16, 8, 4), dtype=torch.float32, device="cuda")
+    nbr.view(torch.int32)[..., 3] = torch.randint(0, 60, (16, 8), device="cuda", dtype=torch.int32)
+    dense = (pb, gb, mb, vb, None, None, None, None, (partial.data_ptr(), slots, n, scale))
+    if form == "flush":
+        for step in (1, 2, 3):
+            lazy.prepare(nbr, feats, gf, mf, vf, step, dense=None)
+        lazy.flush(feats, gf, mf, vf, dense=dense)  # the decoder's step 3
+    else:
+        for step in (1, 2, 3):
+            lazy.prepare(nbr, feats, gf, mf, vf, step, dense=None)
+        lazy.prepare(nbr, feats, gf, mf, vf, 4, dense=dense)  # ... which takes the decoder's step 3
+    for x, y in ((pa, pb), (ma, mb), (va, vb)):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert not gb.any()
+    with pytest.raises(ValueError):
+        ops.LazyAdam._dense((pb, gb, mb, vb, None, None, None, None, (partial.data_ptr(), slots, n + 1, scale)))
+
+
 def test_staged_decoder_image_changes_no_bit():
     """pin_stage_decoder + pin_field.dec_image (the GN tile kernel copies the staged image instead of splitting the
     decoder in every block): SDF and gradient of every point are bit-identical with and without it, and a restaged
