@@ -641,6 +641,14 @@ static int dw_chunk(int n_tiles, int layers_plus_one, int n_cu) {
 }
 // the weight gradient recomputes the layers' inputs instead of streaming them (train_dw_recompute_kernel) from this many
 // tiles on; PIN_DW_RECOMPUTE=0 / 1 forces the choice (read per call: tests switch it)
+// With the forward pass recomputed, the deltas are what is left of the operand stream (1.0 of 1.15 KB per query at 4 x 64), half of
+// it their LOW fp16 pieces: bits 12-23 of numbers that are summed over >= 131 072 queries per weight.  PIN_DW_DELTA=hi streams
+// the high pieces only (an experiment: see DESIGN section 8 "Round 6" for what it does to the gradient and to the iteration);
+// read per call (tests switch it)
+static bool dw_delta_hi_only() {
+    const char* e = getenv("PIN_DW_DELTA");
+    return e != nullptr && e[0] == 'h';
+}
 constexpr int DW_RECOMPUTE_MIN_TILES = 8192;
 static bool dw_recompute(int n_tiles) {
     const char* e = getenv("PIN_DW_RECOMPUTE");
@@ -1083,16 +1091,26 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     if (image_kept) image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
     // large batches: the layers' inputs stay out of the operand stream, the weight-gradient launch runs the forward pass again
     const bool recompute = want_dec && dw_recompute(ws.n_tiles);
+    const bool hi_only = recompute && dw_delta_hi_only();
     if (phase & 1) {
         if (!image_kept)
             hipLaunchKernelGGL((train_stage_kernel<H>), dim3(STAGE_BLOCKS), dim3(512), 0, s, *f, const_cast<unsigned char*>(image));
         hipLaunchKernelGGL((train_fused_kernel<H, L, OD>), dim3(grid), dim3(TFW_BLOCK), lds_bytes, s, *f, *tp, query, nb4, nn_count, sdf_label,
                            sample_weight, sample_ts, certainty_rw, ts_update_rw, feat_grad, pred_out, ws, want_dec, dscale, image, dw_partial,
-                           n_dec, loss_partial, fcol, recompute ? 0 : 1);
+                           n_dec, loss_partial, fcol, recompute ? (hi_only ? 2 : 0) : 1);
         PIN_CHECK_LAUNCH();
     }
     if (!(phase & 2)) return 0;
-    if (want_dec && recompute) {
+    if (want_dec && recompute && hi_only) {
+        constexpr int dlds = train_dw_recompute_lds_bytes<H>(L);
+        static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_dw_recompute_kernel<H, true>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, train_dw_recompute_lds_bytes<H>(MLP_MAX_LEVELS));
+        if (dattr != hipSuccess) return fail(-2, "weight-gradient kernel: cannot reserve LDS: %s", hipGetErrorString(dattr));
+        const int chunk = dw_chunk(ws.n_tiles, dwr_groups(L), n_cu);
+        hipLaunchKernelGGL((train_dw_recompute_kernel<H, true>), dim3(cdiv(ws.n_tiles, chunk), dwr_groups(L)), dim3(DWR_WAVES * 64), dlds, s, ws, L, OD,
+                           n_dec, dw_partial, chunk, image);
+        PIN_CHECK_LAUNCH();
+    } else if (want_dec && recompute) {
         constexpr int dlds = train_dw_recompute_lds_bytes<H>(L);
         static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&train_dw_recompute_kernel<H>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, train_dw_recompute_lds_bytes<H>(MLP_MAX_LEVELS));

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
                                                                   float* __restrict__ dw_partial, int n_dec,
                                                                   double* __restrict__ loss_partial, FusedColor fcol, int acts_out) {
     // acts_out = 0: only the deltas and the decoder input z leave for the weight gradient; train_dw_recompute_kernel
-    // runs the forward pass again from z (large batches: half the operand stream)
+    // runs the forward pass again from z (large batches: half the operand stream).  acts_out = 2: the same with the HIGH fp16
+    // pieces of the deltas only (train.hip, dw_delta_hi_only)
+    const bool delta_lo = acts_out != 2;
     using Q = QuadDecoderH<H>;
     using G = DwGeom<H>;
     constexpr int MT = Q::MT, NJ = Q::NJ;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
             if constexpr (OD > 2) h2_split2((g == 0) ? dxc[2] : 0.f, 0.f, dh1, dl1);
             uint2* __restrict__ D = stream_at(ws.d + G::d_off(n_tiles, L), tbase);
             D[0] = transpose_block(dh0, dh1, ident);
-            D[64] = transpose_block(dl0, dl1, ident);
+            if (delta_lo) D[64] = transpose_block(dl0, dl1, ident);
         }
         bool any_dx = false;
 #pragma unroll
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     D[mt * 128] = transpose_block(bh[mt >> 1][2 * (mt & 1)], bh[mt >> 1][2 * (mt & 1) + 1], ident);
-                    D[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
+                    if (delta_lo) D[mt * 128 + 64] = transpose_block(bl[mt >> 1][2 * (mt & 1)], bl[mt >> 1][2 * (mt & 1) + 1], ident);
                 }
             }
             if (l > 0) {
@@ -1344,7 +1346,9 @@ template <int H>
 constexpr int train_dw_recompute_lds_bytes(int L) {
     return ((QuadDecoderH<H>::bytes(L) + 15) & ~15) + (DWR_WAVES / 2) * DWR_RED_VALS * 64 * 4;
 }
-template <int H>
+// HI_ONLY: the deltas were streamed as their high fp16 pieces only (train_fused_kernel, acts_out = 2): no low piece is read
+// and the product d_lo (x) a_hi is not formed -- two matrix instructions per pair of blocks instead of three
+template <int H, bool HI_ONLY = false>
 __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(DwStream ws, int L, int OD, int n_dec,
                                                                               float* __restrict__ partial, int chunk,
                                                                               const unsigned char* __restrict__ dec_image) {
@@ -1382,16 +1386,18 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
         v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
         c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_l, c, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x16f16(d_h, a_h, acc, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, c, 0, 0, 0);
+        if constexpr (!HI_ONLY) c = __builtin_amdgcn_mfma_f32_16x16x16f16(d_l, a_h, c, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaf(c[r], H2_DOWN, acc[r]);
     };
     auto rowsum = [&](v4f_t& acc, uint2 dh, uint2 dl) {  // bias gradient: the product with a block of ones
-        v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_16x16x16f16(as4(dl), ones, c, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x16f16(as4(dh), ones, acc, 0, 0, 0);
+        if constexpr (!HI_ONLY) {
+            v4f_t c = (v4f_t){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x16f16(as4(dl), ones, c, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaf(c[r], H2_DOWN, acc[r]);
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(c[r], H2_DOWN, acc[r]);
+        }
     };
     const size_t n_tiles = (size_t)ws.n_tiles;
     const uint2* __restrict__ Dp = ws.d + G::d_off(n_tiles, pri) + lane;
@@ -1413,14 +1419,18 @@ __global__ __launch_bounds__(DWR_WAVES * 64, 1) void train_dw_recompute_kernel(D
         for (int ob = 0; ob < MT; ++ob) {
             const int bb = ob < DBp ? ob : 0;
             dh[ob] = Dp[((size_t)t * DBp + bb) * 128];
-            dl[ob] = Dp[((size_t)t * DBp + bb) * 128 + 64];
+            dl[ob] = HI_ONLY ? make_uint2(0u, 0u) : Dp[((size_t)t * DBp + bb) * 128 + 64];
             sh[ob] = sl[ob] = make_uint2(0u, 0u);
         }
         if (sec == 0) {  // delta_1: MT blocks
 #pragma unroll
-            for (int ob = 0; ob < MT; ++ob) { sh[ob] = Ds[((size_t)t * MT + ob) * 128]; sl[ob] = Ds[((size_t)t * MT + ob) * 128 + 64]; }
+            for (int ob = 0; ob < MT; ++ob) {
+                sh[ob] = Ds[((size_t)t * MT + ob) * 128];
+                if constexpr (!HI_ONLY) sl[ob] = Ds[((size_t)t * MT + ob) * 128 + 64];
+            }
         } else if (sec > 0) {  // d loss / d heads: one block
-            sh[0] = Ds[(size_t)t * 128]; sl[0] = Ds[(size_t)t * 128 + 64];
+            sh[0] = Ds[(size_t)t * 128];
+            if constexpr (!HI_ONLY) sl[0] = Ds[(size_t)t * 128 + 64];
         }
         const uint2 zc_h = z_h, zc_l = z_l;
         if (t + DWR_WAVES < t1) { z_h = A0[(size_t)(t + DWR_WAVES) * 128]; z_l = A0[(size_t)(t + DWR_WAVES) * 128 + 64]; }
