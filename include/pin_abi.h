@@ -663,9 +663,12 @@ int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arrays* la, co
                         uint8_t* local_mask_out, int32_t* n_local_out, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
-/* NeuralPoints.assign_local_to_global (neural_points.py:515-526). */
+/* NeuralPoints.assign_local_to_global (neural_points.py:515-526).  row_marker (or NULL): int32 [n_local], non-zero for the local
+ * rows that changed since pin_reset_local_map cut the local map out of the global one -- only those are copied back (the others
+ * still hold the global rows' bits).  Mapper.mapping passes the lazy optimiser's pending words: every row a training query of
+ * the call read (features through the optimiser, certainty / ts_update through the queries' side effects). */
 int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
-                               int32_t n_local, void* stream);
+                               int32_t n_local, const int32_t* row_marker, void* stream);
 
 /* Exact sparse Adam for the feature tables.  The optimiser state is created anew by every
  * Mapper.mapping call (utils/mapper.py:615), so a row that no query of this call has touched yet

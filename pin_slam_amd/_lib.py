@@ -207,7 +207,7 @@ SIGNATURES = {
     "pin_voxel_downsample_fast": (i32, [vp, i32, f32, vp, vp, vp, i64, vp]),
     "pin_map_update": (i32, [P(MapArrays), P(UpdateParams), vp, vp, vp, vp, vp, i64, vp]),
     "pin_reset_local_map": (i32, [P(MapArrays), P(LocalArrays), P(LocalParams), vp, vp, vp, i64, vp]),
-    "pin_assign_local_to_global": (i32, [P(MapArrays), P(LocalArrays), i32, i32, vp]),
+    "pin_assign_local_to_global": (i32, [P(MapArrays), P(LocalArrays), i32, i32, vp, vp]),
     "pin_gather_batch": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "pin_gather_batch_drawn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                      f32, vp]),

@@ -431,11 +431,16 @@ __global__ __launch_bounds__(MB) void local_scatter_kernel(pin_map_arrays ma, pi
 }
 
 // ---- K10: assign_local_to_global ---------------------------------------------------------------
-__global__ __launch_bounds__(MB) void assign_local_kernel(pin_map_arrays ma, pin_local_arrays la, int n_points, int n_local) {
+// row_marker (or NULL): [n_local] words that are non-zero exactly for the local rows that changed since the local map was cut
+// out of the global one (the lazy optimiser's pending words after a Mapper.mapping call: every row a training query read) --
+// the other rows still hold the global map's bits, and copying them back is 140 MB of traffic for nothing on the bench map
+__global__ __launch_bounds__(MB) void assign_local_kernel(pin_map_arrays ma, pin_local_arrays la, int n_points, int n_local,
+                                                          const int* __restrict__ row_marker) {
     const int i = blockIdx.x * MB + threadIdx.x;
     if (i > n_points) return;
     int l = i == n_points ? n_local : la.global2local[i];
     if (l < 0) return;
+    if (row_marker != nullptr && i < n_points && row_marker[l] == 0) return;
     const float4* s = reinterpret_cast<const float4*>(la.geo + (size_t)l * PIN_FEATURE_DIM);
     float4* d = reinterpret_cast<float4*>(ma.geo + (size_t)i * PIN_FEATURE_DIM);
     d[0] = s[0]; d[1] = s[1];
@@ -829,11 +834,11 @@ extern "C" int pin_reset_local_map(const pin_map_arrays* ma, const pin_local_arr
 }
 
 extern "C" int pin_assign_local_to_global(const pin_map_arrays* ma, const pin_local_arrays* la, int32_t n_points,
-                                          int32_t n_local, void* stream) {
+                                          int32_t n_local, const int32_t* row_marker, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(ma && la && n_points >= 0 && n_local >= 0, "bad arguments");
     hipLaunchKernelGGL(assign_local_kernel, dim3(cdiv(n_points + 1, MB)), dim3(MB), 0, as_stream(stream), *ma, *la,
-                       n_points, n_local);
+                       n_points, n_local, row_marker);
     PIN_CHECK_LAUNCH();
     return 0;
 }

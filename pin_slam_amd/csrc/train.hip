@@ -748,6 +748,14 @@ __device__ __forceinline__ void dense_rider_step(const pin_adam_dense& dense, lo
     dense_image_entry(dense, (int)e, pi);
 }
 
+// The decoder's blocks ride in the lazy launches behind the `work` blocks of the rows in the launch's numbering; in the order the
+// device starts them they come FIRST (with the slot copies to sum they are the longest blocks of the launch: started last, they
+// were its tail -- 4 us per training iteration under the trace)
+__device__ __forceinline__ int lazy_block(int work_blocks) {
+    const int dense_blocks = (int)gridDim.x - work_blocks, b = (int)blockIdx.x;
+    return b < dense_blocks ? work_blocks + b : b - dense_blocks;
+}
+
 __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __restrict__ nbr, long n_records,
                                                                 float* __restrict__ p, float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
@@ -755,8 +763,9 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
                                                                 const float* __restrict__ coef, int t_max,
                                                                 float b1, float b2, float eps, int rec_blocks,
                                                                 pin_adam_dense dense, int dense_step) {
-    if ((int)blockIdx.x >= rec_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
-        const long e = (long)((int)blockIdx.x - rec_blocks) * 256 + threadIdx.x;
+    const int bid = lazy_block(rec_blocks);
+    if (bid >= rec_blocks) {  // the dense tensor that rides along (the decoder), step `dense_step`
+        const long e = (long)(bid - rec_blocks) * 256 + threadIdx.x;
         if (e < dense.n) dense_rider_step(dense, e, coef, t_max, dense_step, b1, b2, eps);
         return;
     }
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     extern __shared__ float lazy_coef[];
     for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
     __syncthreads();
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tid = (long)bid * 256 + threadIdx.x;
     const long rec = tid >> 3;
     const int j = (int)(tid & 7), lane = threadIdx.x & 63;
     int row = -1, own = 0, n = 0;
@@ -777,6 +786,12 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     // the other records of the row find +-step there (or lose the compare-and-swap) and leave.  No separate claim array:
     // the election rides on the word the owner has to update anyway (r02a: an atomicMax stamp on a second int per row --
     // 210k more random line updates per iteration, which the tile kernel that follows could feel).
+    // The row's values are requested together with its pending word, before anybody knows whether this record will own the row
+    // (nobody but the owner writes a row in this launch, so what an owner-to-be reads here is what it would read later): one
+    // dependent memory round trip less in a kernel that is a chain of four.  Records that lose the election drop the values.
+    const size_t i = (size_t)(row >= 0 ? row : 0) * PIN_FEATURE_DIM + j;
+    float pi = 0.f, gi = 0.f, mi = 0.f, vi = 0.f;
+    if (row >= 0) { pi = p[i]; gi = g[i]; mi = m[i]; vi = v[i]; }
     if (row >= 0 && j == 0) {
         const int cur = pend[row];  // (a stale value only makes the compare-and-swap fail)
         // (PIN_ADAM_ROW_EXCLUDED: a row some other step owns -- the halo rows of the spatially sharded mapper, dp.hip)
@@ -788,10 +803,8 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const float4* __
     own = __shfl(own, lane & ~7, 64);  // the 8 lanes of a record follow their leader
     n = __shfl(n, lane & ~7, 64);
     if (!own || n == 0) return;  // (a first touch has nothing to settle: its moments start from zero at its first step)
-    const size_t i = (size_t)row * PIN_FEATURE_DIM + j;
-    float pi = p[i], mi = 0.f, vi = 0.f;
-    if (n > 0) { mi = m[i]; vi = v[i]; }
-    lazy_settle(pi, mi, vi, g[i], n, step - 1, lazy_coef, t_max, b1, b2, eps);
+    if (n < 0) { mi = 0.f; vi = 0.f; }  // (first step of the row: the moment arrays are not valid yet)
+    lazy_settle(pi, mi, vi, gi, n, step - 1, lazy_coef, t_max, b1, b2, eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
     g[i] = 0.f;
 }
@@ -806,8 +819,9 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_rows_kernel(float* __re
                                                                      long n_rows, int step, const float* __restrict__ coef, int t_max,
                                                                      float b1, float b2, float eps, int row_blocks,
                                                                      pin_adam_dense dense, int dense_step, int all_rows) {
-    if ((int)blockIdx.x >= row_blocks) {  // tail blocks: the dense tensor that rides along (the decoder), step `dense_step`
-        const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    const int bid = lazy_block(row_blocks);
+    if (bid >= row_blocks) {  // the dense tensor that rides along (the decoder), step `dense_step`
+        const long e = (long)(bid - row_blocks) * 256 + threadIdx.x;
         if (e < dense.n) dense_rider_step(dense, e, coef, t_max, dense_step, b1, b2, eps);
         return;
     }
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_rows_kernel(float* __re
     for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
     __syncthreads();
     const long stride = (long)row_blocks * 32;
-    for (long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3); row < n_rows; row += stride) {
+    for (long row = (long)bid * 32 + (threadIdx.x >> 3); row < n_rows; row += stride) {
         // (all_rows: a batch with several records per row touches practically every row -- no marking pass, every row counts as
         // read: a row no query reads settles a zero gradient on zero moments, which changes no bit of it)
         if (!all_rows && !flags[row]) continue;
@@ -835,28 +849,45 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_rows_kernel(float* __re
 }
 
 __global__ __launch_bounds__(256) void adam_lazy_flush_kernel(float* __restrict__ p, float* __restrict__ g,
-                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              float* __restrict__ m_, float* __restrict__ v,
                                                               const int* __restrict__ pend, long n, int t_final,
                                                               const float* __restrict__ coef, int t_max, float b1, float b2,
                                                               float eps, int row_blocks, pin_adam_dense dense) {
-    if ((int)blockIdx.x >= row_blocks) {  // the dense tensor's last step
-        const long e = (long)((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    const int bid = lazy_block(row_blocks);
+    if (bid >= row_blocks) {  // the dense tensor's last step
+        const long e = (long)(bid - row_blocks) * 256 + threadIdx.x;
         if (e < dense.n) dense_rider_step(dense, e, coef, t_max, t_final, b1, b2, eps);
         return;
     }
     extern __shared__ float lazy_coef[];  // (see adam_lazy_prepare_kernel)
     for (int i = threadIdx.x; i < 2 * (t_max + 1); i += 256) lazy_coef[i] = coef[i];
     __syncthreads();
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)row_blocks * 256;
-    for (; i < n; i += stride) {
-        const int nn = pend[i / PIN_FEATURE_DIM];
-        if (nn == 0 || nn == PIN_ADAM_ROW_EXCLUDED) continue;
-        float pi = p[i], mi = 0.f, vi = 0.f;
-        if (nn > 0) { mi = m[i]; vi = v[i]; }
-        lazy_settle(pi, mi, vi, g[i], nn, t_final, lazy_coef, t_max, b1, b2, eps);
-        p[i] = pi; m[i] = mi; v[i] = vi;
-        g[i] = 0.f;
+    // A lane per ROW looks at its pending word (most rows of a map are untouched in a call: 2.2 M rows, a few hundred thousand
+    // read); the touched rows of the wave's 64 are then settled eight at a time, eight lanes per row.  (r01-r05: a lane per
+    // ELEMENT, eight looks at every word: 60-110 us per Mapper.mapping call on the bench map.)
+    const long n_rows = n / PIN_FEATURE_DIM;
+    const int lane = threadIdx.x & 63, j = lane & 7, sub = lane >> 3;
+    const long wave0 = ((long)bid * 256 + threadIdx.x) >> 6, n_waves = (long)row_blocks * 4;
+    for (long base = wave0 * 64; base < n_rows; base += n_waves * 64) {
+        const long row = base + lane;
+        const int nn = row < n_rows ? pend[row] : 0;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(nn != 0 && nn != PIN_ADAM_ROW_EXCLUDED);
+        while (todo != 0ull) {
+            // this group's row: the (sub + 1)-th set bit of `todo`, if there is one
+            unsigned long long m = todo;
+            for (int s = 0; s < sub && m != 0ull; ++s) m &= m - 1ull;
+            const int src = m != 0ull ? __builtin_ctzll(m) : -1;
+            const int pn = __shfl(nn, src < 0 ? 0 : src, 64);
+            if (src >= 0) {
+                const size_t i = (size_t)(base + src) * PIN_FEATURE_DIM + j;
+                float pi = p[i], mi = 0.f, vi = 0.f;
+                if (pn > 0) { mi = m_[i]; vi = v[i]; }
+                lazy_settle(pi, mi, vi, g[i], pn, t_final, lazy_coef, t_max, b1, b2, eps);
+                p[i] = pi; m_[i] = mi; v[i] = vi;
+                g[i] = 0.f;
+            }
+            for (int s = 0; s < 8 && todo != 0ull; ++s) todo &= todo - 1ull;  // (wave-uniform: the eight rows just settled)
+        }
     }
 }
 
@@ -1711,7 +1742,8 @@ extern "C" int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, fl
     if (n_rows == 0 && d.n == 0) return 0;
     PIN_CHECK_ARG(n_rows == 0 || (param && grad && exp_avg && exp_avg_sq && pending && coef), "NULL pointer");
     const long n = (long)n_rows * PIN_FEATURE_DIM;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), dense_blocks = (int)cdiv(d.n, 256);
+    const long row_waves = (n_rows + 63) / 64;  // a wave per 64 rows, at most 4096 blocks of four waves
+    const int blocks = n_rows == 0 ? 0 : (int)((row_waves + 3) / 4 < 4096 ? (row_waves + 3) / 4 : 4096), dense_blocks = (int)cdiv(d.n, 256);
     hipLaunchKernelGGL(adam_lazy_flush_kernel, dim3(blocks + dense_blocks), dim3(256), 2 * (t_max + 1) * sizeof(float), as_stream(stream), param, grad, exp_avg,
                        exp_avg_sq, pending, n, t_final, coef, t_max, beta1, beta2, eps, blocks, d);
     PIN_CHECK_LAUNCH();

@@ -424,12 +424,17 @@ class NeuralPoints(nn.Module):
 
     # ------------------------------------------------------------------ K10
     def assign_local_to_global(self):
+        """neural_points.py:515-526.  `self._changed_rows` (set by Mapper.mapping for ITS call, consumed here): int32 [>= local
+        rows], non-zero for the local rows that changed since the local map was cut out -- only those go back; None: all."""
+        changed_rows, self._changed_rows = getattr(self, "_changed_rows", None), None
         ma, la = self._map_arrays(), self._local_arrays()
         la.geo = _p(self.local_geo_features.data)
         if self.color_on:
             la.color = _p(self.local_color_features.data)
+        if changed_rows is not None and (changed_rows.dtype != torch.int32 or changed_rows.shape[0] < self._m + 1):
+            raise ValueError("changed_rows: int32, one word per local row")
         check(_lib.lib().pin_assign_local_to_global(C.byref(ma), C.byref(la), self._n, self._m,
-                                                    ops._stream()),
+                                                    None if changed_rows is None else changed_rows.data_ptr(), ops._stream()),
               "pin_assign_local_to_global")
 
     # ------------------------------------------------------------------ K1 / K2 tensor API

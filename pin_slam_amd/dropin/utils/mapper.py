@@ -630,6 +630,10 @@ class Mapper(_StandaloneBase):
             self._queries_for = self._drawn = self._shard = None
         t.finish_optimizer()
         t.merge_side_effects()  # dp: certainty / ts side effects of the other ranks' shards, one exchange per call
+        # only the rows the call's queries read have changed (features through the lazy optimiser, certainty / ts_update through
+        # the queries' side effects), and the optimiser's pending words say which: the others are not copied back
+        if t.lazy_finished and t.dp is None and t.comm is None and os.environ.get("PIN_ASSIGN_ALL_ROWS", "0") != "1":
+            self.neural_points._changed_rows = t.lazy.state
         self.neural_points.assign_local_to_global()
 
     def _mapping_spatial(self, t, iter_count):

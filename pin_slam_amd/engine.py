@@ -277,6 +277,7 @@ class MapTrainer:
         self.dp = None
         self.overlap_weight_grad = None  # None = automatic, True / False force (see step_batch)
         self.defer_dec_reduce = False   # see step_batch; Mapper.mapping switches it on for its loop
+        self.lazy_finished = False
         self._pending_partial, self._iters_planned = None, 0
         self._wg_stream, self._wg_ev, self._wg_pending = None, None, False
         # spatial shards: the all-reduce of iteration i on a side stream, beside the weight gradient of iteration i and the
@@ -708,6 +709,7 @@ class MapTrainer:
             self._dp_finish_exchange()
         self.lazy_on = bool(iters) and (self.comm is None or self.dp is not None)
         self._pending_partial, self._iters_planned = None, int(iters or 0)  # (an aborted call's owed gradient goes with its optimiser state)
+        self.lazy_finished = False
         if self.dp is not None and not self.lazy_on:
             raise ValueError("the spatially sharded mapper needs the iteration count (lazy Adam on the owned rows)")
         nd = self.gdec.numel()
@@ -766,6 +768,7 @@ class MapTrainer:
                             color=None if self.fc is None else (self.fc.feats, self.cm[self.fc.dec.numel():]))
         self._grad_clean = self.train_decoder  # (a frozen decoder's gradient slot is never written either, but keep it simple)
         self.lazy_on = False
+        self.lazy_finished = stepped  # (lazy.state now marks the rows this call's queries read: Mapper.mapping copies only those back)
 
     def mapping(self, index_batches):
         """One Mapper.mapping call: a fresh Adam state (mapper.py:615) and len(index_batches)

@@ -239,6 +239,14 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
         monkeypatch.setattr(_ops, "train_deferred_partial", real)
         deferred.append(sum(x is not None for x in seen))
         assert mp._trainer.buf.group == 16 and mp._trainer._pending_partial is None
+        # assign_local_to_global copied back the rows the call changed -- which is all that differs: global == local afterwards
+        assert npts.local_count() == npts.count() and npts._changed_rows is None
+        n_pts = npts.count()
+        touched = int((mp._trainer.lazy.state[:n_pts] != 0).sum())
+        assert 0 < touched < n_pts  # (the marker is selective here: some rows were never read)
+        assert torch.equal(npts.geo_features[:n_pts], npts.local_geo_features.data[:n_pts])
+        assert torch.equal(npts.point_certainties[:n_pts], npts.local_point_certainties[:n_pts])
+        assert torch.equal(npts.point_ts_update[:n_pts], npts.local_point_ts_update[:n_pts])
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
     # the deferred reduction ran where it can: in line (no second stream), in 19 of the 20 iterations (the last one reduces itself)
     assert deferred == [0, 0, 19, 0, 19], deferred
