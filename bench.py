@@ -445,7 +445,7 @@ def main():
                 with torch.cuda.stream(side):
                     state["xyz"] = pc[:, :3].contiguous()
                     state["xyz"].record_stream(main_stream)
-                    if trk._gn is not None and not source_downsampled:
+                    if trk._gn is not None and not source_downsampled and os.environ.get("PIN_BENCH_PRESORT", "1") != "0":  # (A/B switch)
                         trk._gn.presort(state["xyz"], stream=side)
                     side_done = torch.cuda.Event()
                     side_done.record(side)
