@@ -649,6 +649,17 @@ static bool dw_delta_hi_only() {
     const char* e = getenv("PIN_DW_DELTA");
     return e != nullptr && e[0] == 'h';
 }
+// Compute units the persistent training tile kernels take.  They hold a unit's whole register file (12 waves x 168 registers), so while
+// one runs nothing else does -- a stream beside the mapper (the next frame's scan chain, the brick build) advances only between
+// tile kernels.  At the reference's batch there are fewer tiles than waves (1 639 for 3 072), so an eighth of the units is left to
+// the other streams at no cost in rounds (same box, two runs each: mapping 1.28 / 1.27 -> 1.28 / 1.26 ms, the scan chain beside it
+// 0.71 -> 0.60 ms, the main stream's wait for it 0.06 -> 0.045 ms; it matters on boxes whose host queues the training loop
+// slowly: there the wait was 0.14 ms).  Large batches take every unit.  PIN_TRAIN_CU_RESERVE=<units> overrides (read once).
+static int train_grid_cus(int n_cu, int n_tiles) {
+    static const int reserve = [] { const char* e = getenv("PIN_TRAIN_CU_RESERVE"); const int v = e ? atoi(e) : 32; return v < 0 ? 0 : v; }();
+    const int cus = n_cu - reserve;
+    return (cus >= 64 && n_tiles <= cus * 8) ? cus : n_cu;
+}
 constexpr int DW_RECOMPUTE_MIN_TILES = 8192;
 static bool dw_recompute(int n_tiles) {
     const char* e = getenv("PIN_DW_RECOMPUTE");
@@ -1117,7 +1128,7 @@ static int launch_fused_l(const pin_field* f, const pin_train_params* tp, const 
     float* dw_partial = reinterpret_cast<float*>(ws.a + G::total((size_t)ws.n_tiles, L));
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
-    const int grid = min(n_cu, ws.n_tiles);
+    const int grid = min(train_grid_cus(n_cu, ws.n_tiles), ws.n_tiles);
     const bool image_kept = tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L);
     if (image_kept) image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
     // large batches: the layers' inputs stay out of the operand stream, the weight-gradient launch runs the forward pass again
@@ -1212,7 +1223,7 @@ static int launch_fused_an_l(const pin_field* f, const pin_train_params* tp, con
     float* dw_partial = reinterpret_cast<float*>(ws.d + 2 * per_stream);
     double* loss_partial = reinterpret_cast<double*>(dw_partial + (size_t)DW_SLOTS * FUSED_NDEC_MAX);
     const unsigned char* image = reinterpret_cast<unsigned char*>(loss_partial + 1024);
-    const int grid = min(n_cu, ws.n_tiles);
+    const int grid = min(train_grid_cus(n_cu, ws.n_tiles), ws.n_tiles);
     if (tp->dec_image_current && f->dec_image != nullptr && f->dec_image_bytes == QuadDecoderH<H>::bytes(L))
         image = reinterpret_cast<const unsigned char*>(f->dec_image);  // kept current by the optimiser (pin_adam_dense.image)
     else
