@@ -421,7 +421,10 @@ def main():
     state = {"fid": 1, "cloud": None, "src": None}
 
     stage_events = []  # per timed frame: 5 events at the stage boundaries (no host sync between the stages)
-    side = torch.cuda.Stream(priority=-1) if args.preprocess_stream == "side" else None
+    # (default priority: a high-priority stream changed nothing for the frame -- 196.8 / 200.9 against 198.4 / 198.2 frames/s, same box --
+    # but its existence slowed ONE of the streams the data-parallel mapper's legs create later in this process (one emulated rank
+    # per world 30-45 % slower: the runtime maps streams to a handful of hardware queues by priority class))
+    side = torch.cuda.Stream(priority=int(os.environ.get("PIN_BENCH_SIDE_PRIORITY", "0"))) if args.preprocess_stream == "side" else None
     side_events = []   # per timed frame: the scan chain's own two events on its stream
     host_marks = []    # per timed frame: host clock at the same boundaries (how long the host takes to ENQUEUE a stage)
 
