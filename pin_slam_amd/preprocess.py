@@ -121,7 +121,7 @@ class ScanPreprocessor:
         self.fused = os.environ.get("PIN_PREPROCESS_FUSED", "1") != "0"
         self._bufs = None
 
-    def _fused(self, scan, point_ts, train_vox, source_vox, crop_max, last_odom_tran, frame_id, lose_track):
+    def _fused(self, scan, point_ts, train_vox, source_vox, crop_max, last_odom_tran, frame_id, lose_track, enqueue_only=False):
         c, L = self.config, _lib.lib()
         n, w = scan.shape
         if n == 0:
@@ -156,7 +156,16 @@ class ScanPreprocessor:
                                      None if ts_out is None else ts_out.data_ptr(), src.data_ptr(), None if rest is None else rest.data_ptr(),
                                      b["cnt"].data_ptr(), b["ws"].data_ptr(), b["ws"].numel(), ops._stream()), "pin_preprocess_frame")
         b["cnt_host"].copy_(b["cnt"], non_blocking=True)
+        st = dict(pc=pc, ts_out=ts_out, src=src, rest=rest, point_ts=point_ts, frame_id=frame_id)
+        if enqueue_only:  # begin(): the caller waits for the counts later (finish())
+            return st
         torch.cuda.current_stream().synchronize()
+        return self._fused_finish(st)
+
+    def _fused_finish(self, st):
+        """The second half of _fused, once the counts are on the host: the outputs as prefix views."""
+        c, b = self.config, self._bufs
+        pc, ts_out, src, rest, point_ts, frame_id = (st[k] for k in ("pc", "ts_out", "src", "rest", "point_ts", "frame_id"))
         c1, c2, c3 = (int(v) for v in b["cnt_host"][:3])
         if c1 < 0 or c3 < 0:  # voxel ids too wide for the one-word sort key: the stages one by one (general down-sampling)
             return None
@@ -185,6 +194,8 @@ class ScanPreprocessor:
         are complete on the device (uploaded on ``stream``, or by work the host has already waited for); the results are
         complete when the call returns and are registered with the caller's current stream (record_stream), so they can
         be used there without an event and their memory is not recycled under it."""
+        if getattr(self, "_ticket_open", False):
+            raise RuntimeError("ScanPreprocessor: a ticket of begin() is open (its counts sit in this object's buffers): finish() it first")
         if stream is not None and scan.is_cuda:
             user = torch.cuda.current_stream(scan.device)
             if stream != user:
@@ -199,14 +210,57 @@ class ScanPreprocessor:
                 return out
         return self._run(scan, point_ts, last_odom_tran, frame_id, lose_track)
 
-    def _run(self, scan, point_ts, last_odom_tran, frame_id, lose_track):
+    def begin(self, scan: torch.Tensor, point_ts: Optional[torch.Tensor] = None, last_odom_tran=None, frame_id: int = 1,
+              lose_track: bool = False, stream: Optional[torch.cuda.Stream] = None):
+        """The call in two halves, for a loader that has the next scan early: begin() queues the chain on `stream` and returns at
+        once with a ticket (it may run on a loader THREAD: the stream context is per thread); finish(ticket) waits for the chain's
+        counts and returns what the call returns.  One ticket at a time per object.  Configurations whose set-up needs a read-back
+        of its own (adaptive_range_on, random down-sampling) and calls without a stream run whole in finish()."""
+        if getattr(self, "_ticket_open", False):
+            raise RuntimeError("ScanPreprocessor.begin: the previous ticket has not been finished")
         c = self.config
+        args = (scan, point_ts, last_odom_tran, frame_id, lose_track, stream)
+        self._ticket_open = True
+        if (stream is None or not scan.is_cuda or not self.fused or getattr(c, "adaptive_range_on", False)
+                or getattr(c, "rand_downsample", False) or scan.shape[0] == 0):
+            return dict(whole=args)
+        if isinstance(last_odom_tran, torch.Tensor) and last_odom_tran.is_cuda:
+            last_odom_tran = last_odom_tran.detach().to("cpu", torch.float64)
+        with torch.cuda.stream(stream):
+            self._switch_stream(scan)
+            st = self._fused(_dev_f32(scan).contiguous(), point_ts, c.vox_down_m, c.source_vox_down_m, c.max_range, last_odom_tran, frame_id,
+                             lose_track, enqueue_only=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return dict(st=st, event=ev, stream=stream, whole=args)
+
+    def finish(self, ticket):
+        self._ticket_open = False
+        if "st" not in ticket:
+            return self(*ticket["whole"][:5], stream=ticket["whole"][5])
+        ticket["event"].synchronize()
+        stream = ticket["stream"]
+        user = torch.cuda.current_stream(stream.device)
+        with torch.cuda.stream(stream):
+            out = self._fused_finish(ticket["st"])
+        if out is None:  # (voxel ids too wide for the one-word key: the general path, whole)
+            return self(*ticket["whole"][:5], stream=stream)
+        for t in out:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(user)
+        return out
+
+    def _switch_stream(self, scan):
         if scan.is_cuda:  # the scratch is shared by all calls: a call on another stream than the last one waits for that one first
             cur = torch.cuda.current_stream(scan.device)
             last = getattr(self, "_last_stream", None)
             if last is not None and last != cur:
                 last.synchronize()
             self._last_stream = cur
+
+    def _run(self, scan, point_ts, last_odom_tran, frame_id, lose_track):
+        c = self.config
+        self._switch_stream(scan)
         crop_max = c.max_range
         scan = _dev_f32(scan)
         if getattr(c, "adaptive_range_on", False):  # slam_dataset.py:399-407: crop range from the scan's own extent

@@ -134,3 +134,44 @@ def test_chain_on_its_own_stream_does_not_wait_for_the_main_stream(fused):
     assert torch.isfinite(s)
     if busy > 0.01:  # (the matmuls were long enough to tell)
         assert not main_done_at_return and t_call < 0.6 * busy, (t_call, busy)
+
+
+def test_begin_finish_is_the_call_in_two_halves():
+    """ScanPreprocessor.begin / finish: the chain queued on a stream at once (here from a loader THREAD, as bench.py does), its
+    results collected later on the main thread -- the bits of the plain call; one ticket at a time; a configuration whose set-up
+    needs a read-back runs whole in finish()."""
+    import threading
+    from pin_slam_amd import preprocess as PP
+    from pin_slam_amd.config import PinConfig
+    g = torch.Generator().manual_seed(13)
+    n = 80_000
+    r = 70.0 * torch.sqrt(torch.rand(n, generator=g)); th = 6.2831853 * torch.rand(n, generator=g)
+    scan = torch.stack([r * torch.cos(th), r * torch.sin(th), -2 + 0.5 * torch.randn(n, generator=g), torch.rand(n, generator=g)], 1).float().cuda()
+    ts = torch.rand(n, generator=g).float().cuda()
+    T = np.eye(4); T[:3, 3] = [0.9, 0.02, 0.0]
+    side = torch.cuda.Stream()
+    for adaptive in (False, True):
+        cfg = PinConfig(vox_down_m=0.08, source_vox_down_m=0.8, min_range=2.5, max_range=60.0, min_z=-5.0, max_z=60.0, deskew=True,
+                        adaptive_range_on=adaptive)
+        plain, two = PP.ScanPreprocessor(cfg), PP.ScanPreprocessor(cfg)
+        want = plain(scan, ts, last_odom_tran=T, frame_id=3)
+        box = {}
+        th_ = threading.Thread(target=lambda: box.update(tk=two.begin(scan, ts, last_odom_tran=T, frame_id=3, stream=side)))
+        th_.start()
+        a = torch.randn(2048, 2048, device="cuda")
+        a = a @ a  # (the main thread is free meanwhile)
+        th_.join()
+        tk = box["tk"]
+        assert ("st" in tk) == (not adaptive)
+        with pytest.raises(RuntimeError):
+            two.begin(scan, ts, last_odom_tran=T, frame_id=4, stream=side)
+        with pytest.raises(RuntimeError):
+            two(scan, ts, last_odom_tran=T, frame_id=4)
+        got = two.finish(tk)
+        s = got[0].sum() + got[2].sum()
+        torch.cuda.synchronize()
+        for w, x in zip(want, got):
+            assert (w is None and x is None) or torch.equal(w, x)
+        assert torch.isfinite(s)
+        got2 = two.finish(two.begin(scan, ts, last_odom_tran=T, frame_id=3, stream=side))  # (and again: the ticket was closed)
+        assert torch.equal(want[0], got2[0])
