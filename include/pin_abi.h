@@ -594,6 +594,7 @@ int pin_train_step(const pin_field* f, const pin_train_params* tp, const float* 
  * the slot copies). */
 int pin_train_deferred_partial(const float** partial_out, int32_t* slots_out, int64_t* n_out, float* scale_out);
 
+
 /* The second half of a pin_train_step called with tp->defer_weight_grad: streamed weight gradient into dec_grad (+=) and
  * the loss sums into loss_out, from the operand stream the first half left in `workspace` (same f / tp / workspace).  It
  * touches neither the feature table nor the feature gradients, so a caller may run it on ANOTHER stream beside the
@@ -717,6 +718,36 @@ int pin_adam_lazy_prepare_rows(const float* nbr, int64_t n_records, float* param
 int pin_adam_lazy_flush(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* pending,
                         int64_t n_rows, int32_t t_final, const float* coef, int32_t t_max, float beta1, float beta2,
                         float eps, const pin_adam_dense* dense, void* stream);
+
+/* A GROUP of consecutive training iterations in one call (Mapper.mapping gathers and searches a group's batches in one launch each:
+ * their inputs sit in strided buffers): per iteration i = 0 .. n_iters - 1 exactly the launches of
+ *     pin_adam_lazy_prepare[_rows](records of iteration i, step first_step + i, dense rider = the decoder with the previous
+ *                                  iteration's weight gradient as slot copies)
+ *     pin_train_step(tp with defer_dec_reduce = 1, except on the call's last iteration)
+ * -- the host-side loop of engine.MapTrainer.step_batch moved behind the ABI: one foreign call per group instead of two or three
+ * per iteration (0.57 -> 0.35 ms of host time per Mapper.mapping call at 12 iterations).  Strides are in ELEMENTS of the
+ * pointer's type, from one iteration to the next.  partial_*: in = the slot copies the iteration BEFORE the group left (NULL: none),
+ * out = what the group's last iteration left (NULL after the call's last iteration). */
+typedef struct pin_train_group {
+    int32_t n_iters, first_step;
+    int32_t last_of_call;                 /* the group's last iteration is the Mapper.mapping call's last */
+    int32_t rows_form;                    /* pin_adam_lazy_prepare_rows instead of pin_adam_lazy_prepare */
+    const float* query;   int64_t query_stride;     /* [n_iters][Q][3] */
+    const float* nbr;     int64_t nbr_stride;       /* [n_iters][Q][k][4] */
+    const int32_t* nn;    int64_t nn_stride;        /* [n_iters][Q] */
+    const float* sdf_label; int64_t label_stride;   /* [n_iters][n_main] */
+    const float* sample_weight; int64_t weight_stride;  /* or NULL */
+    const int32_t* sample_ts;   int64_t ts_stride;      /* or NULL */
+    float* certainty_rw; int32_t* ts_update_rw;     /* or NULL (side effects deferred) */
+    float* feat_grad; float* dec_grad; double* loss_out;
+    void* workspace; int64_t workspace_bytes;
+    int64_t n_records;                    /* Q * k: records per iteration */
+    float* exp_avg; float* exp_avg_sq; int32_t* pending; uint8_t* row_flags; int64_t n_rows;   /* lazy Adam of f->feats */
+    const float* coef; int32_t t_max; float beta1, beta2, eps;
+    pin_adam_dense dense;                 /* the decoder as the rider (grad_partial is set per iteration from partial_*) */
+    const float* partial; int32_t partial_slots; float partial_scale;   /* in / out, see above */
+} pin_train_group;
+int pin_train_group_steps(const pin_field* f, const pin_train_params* tp, pin_train_group* g, void* stream);
 
 /* ---- Mapper.process_frame data path (utils/mapper.py:162-449) ------------------------------ */
 

@@ -127,6 +127,17 @@ class TrainParams(C.Structure):
     ]
 
 
+class TrainGroup(C.Structure):
+    _fields_ = [("n_iters", C.c_int32), ("first_step", C.c_int32), ("last_of_call", C.c_int32), ("rows_form", C.c_int32),
+                ("query", vp), ("query_stride", C.c_int64), ("nbr", vp), ("nbr_stride", C.c_int64), ("nn", vp), ("nn_stride", C.c_int64),
+                ("sdf_label", vp), ("label_stride", C.c_int64), ("sample_weight", vp), ("weight_stride", C.c_int64),
+                ("sample_ts", vp), ("ts_stride", C.c_int64), ("certainty_rw", vp), ("ts_update_rw", vp),
+                ("feat_grad", vp), ("dec_grad", vp), ("loss_out", vp), ("workspace", vp), ("workspace_bytes", C.c_int64),
+                ("n_records", C.c_int64), ("exp_avg", vp), ("exp_avg_sq", vp), ("pending", vp), ("row_flags", vp), ("n_rows", C.c_int64),
+                ("coef", vp), ("t_max", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("dense", AdamDense), ("partial", vp), ("partial_slots", C.c_int32), ("partial_scale", C.c_float)]
+
+
 class TrainColorParams(C.Structure):
     _fields_ = [("n_main", C.c_int32), ("loss_weight_on", C.c_int32), ("surface_range", C.c_float),
                 ("weight_i", C.c_float), ("dec_image_current", C.c_int32), ("n_main_global", C.c_int32), ("surface_count", vp)]
@@ -219,6 +230,7 @@ SIGNATURES = {
     "pin_train_step": (i32, [P(Field), P(TrainParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_train_weight_grad": (i32, [P(Field), P(TrainParams), vp, vp, vp, i64, vp]),
     "pin_train_deferred_partial": (i32, [vp, vp, vp, vp]),
+    "pin_train_group_steps": (i32, [P(Field), P(TrainParams), P(TrainGroup), vp]),
     "pin_train_color_step": (i32, [P(Field), P(TrainColorParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "pin_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp]),
     "pin_mark_rows": (i32, [vp, i64, vp, vp]),

@@ -1441,6 +1441,41 @@ extern "C" int pin_train_deferred_partial(const float** partial_out, int32_t* sl
     return 0;
 }
 
+extern "C" int pin_train_group_steps(const pin_field* f, const pin_train_params* tp, pin_train_group* g, void* stream) {
+    PIN_ENTER();
+    PIN_CHECK_ARG(f && tp && g && g->n_iters >= 0 && g->first_step >= 1, "bad arguments");
+    PIN_CHECK_ARG(g->query && g->nbr && g->nn && g->sdf_label && g->feat_grad && g->dec_grad && g->workspace && g->pending && g->coef,
+                  "NULL pointer");
+    PIN_CHECK_ARG(g->dense.param && g->dense.grad == g->dec_grad, "the rider must be the decoder whose gradient the steps write");
+    pin_train_params t = *tp;
+    pin_adam_dense d = g->dense;
+    float* const feats = const_cast<float*>(f->feats);  // (the field's table is what the optimiser steps)
+    for (int i = 0; i < g->n_iters; ++i) {
+        const int step = g->first_step + i;
+        const float* nbr = g->nbr + (int64_t)i * g->nbr_stride;
+        d.grad_partial = g->partial; d.partial_slots = g->partial_slots; d.partial_scale = g->partial_scale;
+        int rc = g->rows_form
+                     ? pin_adam_lazy_prepare_rows(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, g->row_flags,
+                                                  g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, &d, stream)
+                     : pin_adam_lazy_prepare(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, step, g->coef,
+                                             g->t_max, g->beta1, g->beta2, g->eps, &d, stream);
+        if (rc) return rc;
+        g->partial = nullptr;  // (taken by the launch above)
+        t.defer_dec_reduce = (g->last_of_call && i == g->n_iters - 1) ? 0 : 1;
+        rc = pin_train_step(f, &t, g->query + (int64_t)i * g->query_stride, nbr, g->nn + (int64_t)i * g->nn_stride,
+                            g->sdf_label + (int64_t)i * g->label_stride,
+                            g->sample_weight ? g->sample_weight + (int64_t)i * g->weight_stride : nullptr,
+                            g->sample_ts ? g->sample_ts + (int64_t)i * g->ts_stride : nullptr, g->certainty_rw, g->ts_update_rw, g->feat_grad,
+                            g->dec_grad, g->loss_out, nullptr, g->workspace, g->workspace_bytes, stream);
+        if (rc) return rc;
+        if (t.defer_dec_reduce && tl_deferred.partial != nullptr) {
+            PIN_CHECK_ARG(tl_deferred.n == d.n, "the deferred weight gradient belongs to a decoder of another size");
+            g->partial = tl_deferred.partial; g->partial_slots = DW_SLOTS; g->partial_scale = tl_deferred.scale;
+        }
+    }
+    return 0;
+}
+
 extern "C" int pin_train_weight_grad(const pin_field* f, const pin_train_params* tp, float* dec_grad, double* loss_out,
                                      void* workspace, int64_t workspace_bytes, void* stream) {
     PIN_ENTER();

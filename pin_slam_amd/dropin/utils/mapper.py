@@ -600,6 +600,11 @@ class Mapper(_StandaloneBase):
                         t.knn_group(gn)
                     else:
                         self._records_group(t, it0, gn, reuse)
+                    if t.defer_dec_reduce and t.can_step_group():
+                        # the plain path: the group's iterations queued by ONE foreign call (engine.MapTrainer.step_group)
+                        t.step_group(outs[1], outs[2], outs[3], it0 + 1, gn)
+                        self.total_iter += gn
+                        continue
                     for j in range(gn):
                         coord, sdf_label, weight, ts, color_label, sem_label = (None if o is None else o[j] for o in outs)
                         if t.fc is not None and color_label is None:

@@ -479,6 +479,62 @@ class MapTrainer:
         ops.knn_query(self.st, self.buf.query_all[:n], self.fs.k, out=(self.buf.nbr_all[:n], self.buf.nn_all[:n], None),
                       bricks=self.bricks)
 
+    def can_step_group(self) -> bool:
+        """The plain one-GPU training loop (lazy exact Adam with the decoder riding along, no colour / semantic branch, no second
+        stream, no ranks, no hooks): what pin_train_group_steps runs behind the ABI."""
+        want = self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None)
+        return bool(self.lazy_on and self.train_decoder and not want and self.dp is None and self.comm is None and self.on_grads is None
+                    and self.on_allreduce is None and self.fc is None and self.fsem is None and not self.buf.analytic
+                    and self.fs.dec_image is not None and os.environ.get("PIN_TRAIN_GROUP", "1") != "0")
+
+    def step_group(self, label, weight, ts, first_step: int, n_iters: int):
+        """Iterations first_step .. first_step + n_iters - 1 on the group buffers (queries, records and counts of iteration i in slot i
+        of buf.query_all / nbr_all / nn_all, labels / weights / timestamps in row i of the [group, bs] tensors) in ONE foreign call:
+        per iteration the launches of step_batch(queries_ready=True, knn_ready=True) on the plain path, queued by a C loop."""
+        buf, fs, nd = self.buf, self.fs, self.gdec.numel()
+        side = not self.defer_side_effects
+        tp = _lib.TrainParams()
+        tp.n_main, tp.n_eik, tp.loss_weight_on = buf.n_main, buf.n_eik, int(bool(self.loss_weight_on))
+        tp.sigma, tp.weight_e, tp.eik_eps = float(self.sigma), float(self.weight_e), float(np.float32(self.eik_eps))
+        tp.inv_n_main = 1.0 / float(self.bs or buf.n_main)
+        tp.inv_n_eik = 1.0 / float(self.n_eik_global or max(buf.n_eik, 1))
+        tp.eik_analytic, tp.dec_image_current, tp.defer_weight_grad = 0, 1, 0
+        f = fs.params()
+        g = _lib.TrainGroup()
+        g.n_iters, g.first_step = int(n_iters), int(first_step)
+        g.last_of_call = int(first_step + n_iters - 1 >= self._iters_planned)
+        n_rec = buf.Q * fs.k
+        g.rows_form = int(n_rec >= self.lazy.rows_form_ratio * fs.feats.shape[0])
+        g.query, g.query_stride = buf.query_all.data_ptr(), 3 * buf.Q
+        g.nbr, g.nbr_stride = buf.nbr_all.data_ptr(), 4 * fs.k * buf.Q
+        g.nn, g.nn_stride = buf.nn_all.data_ptr(), buf.Q
+        g.sdf_label, g.label_stride = label.data_ptr(), label.stride(0)
+        if weight is not None:
+            g.sample_weight, g.weight_stride = weight.data_ptr(), weight.stride(0)
+        if ts is not None:
+            g.sample_ts, g.ts_stride = ts.data_ptr(), ts.stride(0)
+        if side:
+            g.certainty_rw, g.ts_update_rw = fs.certainty.data_ptr(), self.ts_update.data_ptr()
+        g.feat_grad, g.dec_grad, g.loss_out = self.gfeat.data_ptr(), self.gdec.data_ptr(), buf.loss.data_ptr()
+        g.workspace, g.workspace_bytes = buf.ws.data_ptr(), buf.ws.numel() * 4
+        g.n_records = n_rec
+        lz = self.lazy
+        g.exp_avg, g.exp_avg_sq, g.pending = self.m[nd:].data_ptr(), self.v[nd:].data_ptr(), lz.state.data_ptr()
+        g.row_flags, g.n_rows = lz.flags.data_ptr(), fs.feats.shape[0]
+        g.coef, g.t_max, g.beta1, g.beta2, g.eps = lz.coef.data_ptr(), lz.t_max, lz.b1, lz.b2, lz.eps
+        d = ops.LazyAdam._dense(self._dense(fs, self.gdec, self.m[:nd], self.v[:nd], True))
+        g.dense = d
+        if self._pending_partial is not None:
+            g.partial, g.partial_slots, _n, g.partial_scale = self._pending_partial
+        if first_step + n_iters - 1 > lz.t_max or first_step <= lz.t:
+            raise ValueError("steps must grow within one optimiser lifetime and stay within the count reset() was sized for")
+        check(_lib.lib().pin_train_group_steps(C.byref(f), C.byref(tp), C.byref(g), ops._stream()), "pin_train_group_steps")
+        lz.t = first_step + n_iters - 1
+        if g.rows_form:
+            lz.rows_launches += n_iters
+        self._pending_partial = (g.partial, g.partial_slots, d.n, g.partial_scale) if g.partial else None
+        self.total_iter += n_iters
+
     def step_batch(self, coord, label, weight, ts, step: int, color_label=None, queries_ready: bool = False,
                    knn_ready: bool = False, surface_count=None, sem_label=None):
         """One iteration on an explicit (already gathered) batch shard.  queries_ready: buf.query already holds this

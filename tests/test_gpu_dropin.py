@@ -198,7 +198,8 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
     """Mapper.mapping gathers and searches a group of iterations in one launch each (their inputs do not depend on the
     training) and stages the decoder once per call; `group_iterations = False` keeps one gather / kNN per iteration.
     With the weight gradient in line, the decoder's gradient of an iteration is left as slot copies and summed by the next
-    iteration's lazy-Adam launch (three launches per iteration); PIN_DEFER_DEC_REDUCE=0 keeps the reduction launch.
+    iteration's lazy-Adam launch (three launches per iteration); PIN_DEFER_DEC_REDUCE=0 keeps the reduction launch.  Grouped and in
+    line, the iterations of a group are queued by one foreign call (engine.MapTrainer.step_group).
     The weight gradient and the decoder's step of an iteration run on a side stream beside the next iteration's
     optimiser launch; `overlap_weight_grad = False` keeps them in line.  Same seed, same state: the same batches, and
     the trained features / decoder agree to rounding (atomics order) whatever the launch structure."""
@@ -232,12 +233,15 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
         mp.time_pool = torch.zeros(len(base), dtype=torch.int, device="cuda")
         mp.pool_sample_count = len(base)
         torch.manual_seed(5)
-        from pin_slam_amd import ops as _ops
+        from pin_slam_amd import engine as _engine, ops as _ops
         seen, real = [], _ops.train_deferred_partial
         monkeypatch.setattr(_ops, "train_deferred_partial", lambda: (seen.append(real()), seen[-1])[1])
+        groups, real_group = [], _engine.MapTrainer.step_group
+        monkeypatch.setattr(_engine.MapTrainer, "step_group", lambda self, *a: (groups.append(a[-1]), real_group(self, *a))[1])
         mp.mapping(20)  # more than one group of 16
         monkeypatch.setattr(_ops, "train_deferred_partial", real)
-        deferred.append(sum(x is not None for x in seen))
+        monkeypatch.setattr(_engine.MapTrainer, "step_group", real_group)
+        deferred.append((sum(x is not None for x in seen), tuple(groups)))
         assert mp._trainer.buf.group == 16 and mp._trainer._pending_partial is None
         # assign_local_to_global copied back the rows the call changed -- which is all that differs: global == local afterwards
         assert npts.local_count() == npts.count() and npts._changed_rows is None
@@ -248,8 +252,9 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
         assert torch.equal(npts.point_certainties[:n_pts], npts.local_point_certainties[:n_pts])
         assert torch.equal(npts.point_ts_update[:n_pts], npts.local_point_ts_update[:n_pts])
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
-    # the deferred reduction ran where it can: in line (no second stream), in 19 of the 20 iterations (the last one reduces itself)
-    assert deferred == [0, 0, 19, 0, 19], deferred
+    # the deferred reduction ran where it can: in line (no second stream), in 19 of the 20 iterations (the last one reduces itself) --
+    # grouped, the whole loop behind the ABI (pin_train_group_steps: one call per group of 16 + 4); iteration by iteration from Python
+    assert deferred == [(0, ()), (0, ()), (0, (16, 4)), (0, ()), (19, ())], deferred
     fa, da, ca = results[0]
     assert not torch.equal(fa, torch.zeros_like(fa))
     for fb, db, cb in results[1:]:
