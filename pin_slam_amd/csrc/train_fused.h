@@ -108,7 +108,10 @@ __device__ __forceinline__ uint2 transpose_block(unsigned int w0, unsigned int w
 #ifdef PIN_TF_STAMPS
 // debug builds (scripts/exp/tf_stamps.py): wall-clock stamps (100 MHz) of the phases of a wave's first tile, one row per block
 __device__ unsigned long long g_tf_stamps[1024 * 16];
-#define TF_STAMP(i) do { if (lane == 0 && wave == (PIN_TF_STAMPS) && !stamped) g_tf_stamps[(blockIdx.x & 1023) * 16 + (i)] = wall_clock64(); } while (0)
+#ifndef PIN_TF_STAMP_TILE
+#define PIN_TF_STAMP_TILE 0  // which of the wave's tiles is stamped (0 = its first)
+#endif
+#define TF_STAMP(i) do { if (lane == 0 && wave == (PIN_TF_STAMPS) && stamped == (PIN_TF_STAMP_TILE)) g_tf_stamps[(blockIdx.x & 1023) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define TF_STAMP(i) do { } while (0)
 #endif
@@ -154,9 +157,11 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
     int* sidx = reinterpret_cast<int*>(sdz + 2 * 16 * 8);
     double acc_bce = 0.0, acc_eik = 0.0;
 #ifdef PIN_TF_STAMPS
-    bool stamped = false;
+    int stamped = 0;  // tiles this wave has finished
 #endif
+#if !defined(PIN_TF_STAMPS) || PIN_TF_STAMP_TILE == 0
     TF_STAMP(0);
+#endif
     if (want_dec) {  // the slot partials of the weight-gradient launch start from zero (it runs after this kernel)
         const int n = DW_SLOTS * n_dec;
         for (int i = blockIdx.x * TFW_BLOCK + threadIdx.x; i < n; i += gridDim.x * TFW_BLOCK) dw_partial[i] = 0.f;
@@ -182,6 +187,9 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
     for (int tile = blockIdx.x + gridDim.x * wave;; tile += n_waves) {
         const bool work = tile < n_tiles;
         if (!work && staged) break;
+#if defined(PIN_TF_STAMPS) && PIN_TF_STAMP_TILE > 0
+        TF_STAMP(0);
+#endif
         // ---- which query this column is
         const int tl = work ? tile : 0;
         bool is_probe = false;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(TFW_BLOCK, 1) void train_fused_kernel(pin_field f, 
         wave_lds_sync();
         TF_STAMP(7);  // scatter issued
 #ifdef PIN_TF_STAMPS
-        stamped = true;
+        ++stamped;
 #endif
     }
     // loss values: one pair per block, summed by train_finalize_kernel (no atomics, no clearing launch)

@@ -57,7 +57,7 @@ for bs in sizes:
 
     def step(dec_grad):
         ops.check(_L.lib().pin_train_step(C.byref(f), C.byref(tp), P_(buf.query), P_(buf.nbr), P_(buf.nn), P_(label), P_(w), P_(ts),
-                                          P_(fs.certainty), P_(tsu), P_(gfeat), P_(dec_grad), P_(buf.loss), None, P_(buf.ws),
+                                          *((None, None) if os.environ.get("NO_SIDE") else (P_(fs.certainty), P_(tsu))), P_(gfeat), P_(dec_grad), P_(buf.loss), None, P_(buf.ws),
                                           buf.ws.numel() * 4, ops._stream()), "pin_train_step")
 
     def timeit(fn, n=reps):
@@ -76,3 +76,17 @@ for bs in sizes:
     t_full, t_frozen = timeit(lambda: step(gdec)), timeit(lambda: step(None))
     print(f"bs={bs:8d} queries={buf.Q:8d}  train_step {t_full:8.1f} us ({bs / t_full:7.1f} samples/us)   frozen decoder {t_frozen:8.1f} us   kNN {t_knn:6.1f} us"
           f"   loss {buf.loss.cpu().numpy()}")
+
+    if os.environ.get("TF_STAMPS"):  # debug build (scripts/build_variant.sh NAME -DPIN_TF_STAMPS=<wave> [-DPIN_TF_STAMP_TILE=<n>]): phases of that tile
+        buf_s = (C.c_ulonglong * (1024 * 16))()
+        assert C.CDLL(_L.LIB_PATH).pin_debug_tf_stamps(buf_s, 1024 * 16) == 0
+        a = np.frombuffer(buf_s, dtype=np.uint64).reshape(1024, 16).astype(np.int64)[:256, :8]
+        a = a[(a[:, 7] > a[:, 0]) & (a[:, 0] > 0)]
+        names = ["top -> loads requested", "-> image in LDS (barrier)", "-> gather arithmetic done", "-> forward layers", "-> head + loss",
+                 "-> backward sweep", "-> scatter issued"]
+        d = np.diff(a, axis=1) * 10.0 / 1e3
+        if len(a) == 0:
+            print("  no stamped tiles at this size"); continue
+        print(f"  stamped tiles: {len(a)}; whole tile {np.mean((a[:, 7] - a[:, 0]) * 0.01):.2f} us (median {np.median((a[:, 7] - a[:, 0]) * 0.01):.2f})")
+        for i, n in enumerate(names):
+            print(f"    {n:32s} mean {d[:, i].mean():6.2f} us   median {np.median(d[:, i]):6.2f}   p90 {np.percentile(d[:, i], 90):6.2f}")
