@@ -303,6 +303,9 @@ def main():
     mp._publish_pool()
 
     def barrier():
+        # (this rank's own queue first: the job's process group and the mapper's communicator are two RCCL communicators, and a
+        # barrier kernel queued beside a still-running all-reduce of the other one would have the two spin on each other's ranks)
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
