@@ -290,6 +290,7 @@ class MapTrainer:
         self._dp_stream, self._dp_ev, self._dp_pending = None, None, None
         self.on_grads = None  # optional hook(flat gradient buffer) between the all-reduce and the optimiser step
         self.on_allreduce = None  # optional hook(start: bool) around the gradient exchange (bench.py brackets it with events)
+        self.on_color_grads = None  # optional hook(flat colour gradient payload) behind the dense shards' colour exchange (tests)
         self._cert0 = self._cert_scratch = None
         dev = fs.feats.device
         self._store = None
@@ -354,9 +355,8 @@ class MapTrainer:
         if fc is None:
             self.fc = None
             return
-        if self.comm is not None and self.dp is None:
-            raise NotImplementedError("colour training with dp_mode = 'dense' (the flat all-reduce buffer holds the geometry only): use the "
-                                      "spatial shards")
+        # (dp_mode = 'dense': the colour table's gradient is a second whole-table payload [colour decoder | colour features] and
+        # the batch's surface-sample count a third, tiny one -- step_batch)
         nf, nd = fc.feats.numel(), fc.dec.numel()
         if self.fc is None or self.cgrad.numel() != nf + nd:
             self.cgrad = torch.zeros((nd + nf,), dtype=torch.float32, device=fc.feats.device)
@@ -625,14 +625,36 @@ class MapTrainer:
         if self.fc is not None:
             cnd = self.fc.dec.numel()
             cdense = self._dense(self.fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], lazy) if self.c_train_dec else None
+            dense_dp = self.comm is not None and self.dp is None  # contiguous index shards: whole-table exchange, replicated dense Adam
             if lazy:
                 self.lazy_c.prepare(self.buf.nbr, self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, dense=cdense)
+            if dense_dp and surface_count is None:
+                # color_diff_loss divides by the number of surface samples of the WHOLE batch (utils/loss.py:31-42): every rank
+                # counts its shard, one one-word SUM exchange (exact in fp32: a count below 2^24), back to the int32 the kernel reads
+                if getattr(self, "_surf_f", None) is None:
+                    dev = self.fc.feats.device
+                    self._surf_f = torch.zeros((1,), dtype=torch.float32, device=dev)
+                    self._surf_i = torch.zeros((1,), dtype=torch.int32, device=dev)
+                torch.sum(label.abs() < self.c_range, dim=(0,), keepdim=True, dtype=torch.float32, out=self._surf_f)
+                self.comm.allreduce(self._surf_f, self._surf_f)
+                self._surf_i.copy_(self._surf_f)
+                surface_count = self._surf_i
             if coord.shape[0] > 0:  # (a rank whose box holds none of this batch's samples only takes the decoder's step above)
                 ops.train_color_step(self.fc, self.buf, label, color_label, weight, self.cgrad[cnd:],
                                      self.cgdec if self.c_train_dec else None, surface_range=self.c_range,
                                      weight_i=self.c_weight, loss_weight_on=self.loss_weight_on, image_current=lazy,
                                      surface_count=surface_count, global_n_main=self.bs)
-            if not lazy:
+            if dense_dp:
+                # SUM of the ranks' [colour decoder | colour features] gradients, then the same dense Adam step on every replica
+                # (rows touched only by other ranks' shards arrive through the exchange) -- as the geometry table below
+                payload = self.cgrad if self.c_train_dec else self.cgrad[cnd:]
+                self.comm.allreduce(payload, payload)
+                if self.on_color_grads is not None:
+                    self.on_color_grads(payload)
+                ops.adam_step(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], step, self.lr, eps=self.adam_eps)
+                if self.c_train_dec:
+                    ops.adam_step(self.fc.dec, self.cgdec, self.cm[:cnd], self.cv[:cnd], step, self.lr, eps=self.adam_eps)
+            elif not lazy:
                 ops.mark_rows(self.buf.nbr, self.dirty)  # the colour pass reuses the records of the geometry pass
                 ops.adam_step_rows(self.fc.feats, self.cgrad[cnd:], self.cm[cnd:], self.cv[cnd:], self.dirty, step, self.lr,
                                    eps=self.adam_eps)

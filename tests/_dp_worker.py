@@ -54,6 +54,8 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         if fc is not None:  # this rank's colour-feature gradient after the exchange: private rows (the halo rows were moved out)
             cgrads.append(t.cgrad[fc.dec.numel():].cpu().numpy().copy())
     t.on_grads = on_grads
+    cpay = []  # dense shards: the colour payload [colour decoder | colour features] behind its all-reduce
+    t.on_color_grads = lambda g: cpay.append(g.cpu().numpy().copy())
     nd = fs.dec.numel()
     extra = {}
     if comm is not None and mode == "spatial":
@@ -84,11 +86,15 @@ def main(rank, world, port, case, transport, out, mode="dense"):
         a, b = sharding.shard_range(bs, rank, world)
         for it in range(2):
             t.step_batch(U.dev(d[f"map_coord{it}"][a:b]), U.dev(d[f"map_label{it}"][a:b]), U.dev(d[f"map_w{it}"][a:b]),
-                         U.dev(d[f"map_ts{it}"][a:b], torch.int32), it + 1)
+                         U.dev(d[f"map_ts{it}"][a:b], torch.int32), it + 1,
+                         color_label=None if fc is None else U.dev(d[f"map_color{it}"][a:b]))
         t.finish_optimizer()
         t.merge_side_effects()
         torch.cuda.synchronize()
         gsave = dict(gdec0=grads[0][:nd], gfeat0=grads[0][nd:], gdec1=grads[1][:nd], gfeat1=grads[1][nd:])
+        if cpay:
+            cnd = fc.dec.numel()
+            gsave.update(cgdec0=cpay[0][:cnd], cgfeat0=cpay[0][cnd:])
     if fc is not None:
         extra = dict(extra, cfeats=fc.feats.cpu().numpy(), cdec=fc.dec.cpu().numpy())
     np.savez(out, feats=fs.feats.cpu().numpy(), dec=fs.dec.cpu().numpy(), cert=fs.certainty.cpu().numpy(),

@@ -66,7 +66,7 @@ def digest(t):
     return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
 
 
-def main(rank, world, port, out, workload, bs, iters, diverge=False):
+def main(rank, world, port, out, workload, bs, iters, diverge=False, mode="spatial"):
     torch.cuda.set_device(0)
     comm = None
     if world > 1:
@@ -76,7 +76,7 @@ def main(rank, world, port, out, workload, bs, iters, diverge=False):
         comm = collective.make_comm(rank, world, "host")
     cfg, npts, dec, cdec, mp = build(workload, bs, iters)
     if world > 1:
-        mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, comm, "spatial"
+        mp.dp_rank, mp.dp_world, mp.dp_comm, mp.dp_mode = rank, world, comm, mode
     # the 2^20 path's record reuse -- one search over the (rank's) pool samples per call -- forced on at this batch (it is chosen
     # by batch x iterations / pool)
     mp.reuse_pool_records = True
@@ -134,4 +134,5 @@ def main(rank, world, port, out, workload, bs, iters, diverge=False):
 
 if __name__ == "__main__":
     a = sys.argv
-    main(int(a[1]), int(a[2]), int(a[3]), a[4], a[5], int(a[6]), int(a[7]), diverge=len(a) > 8 and a[8] == "diverge")
+    main(int(a[1]), int(a[2]), int(a[3]), a[4], a[5], int(a[6]), int(a[7]), diverge=len(a) > 8 and a[8] == "diverge",
+         mode="dense" if len(a) > 8 and a[8] == "dense" else "spatial")

@@ -142,6 +142,29 @@ def test_spatial_shards_with_the_colour_branch(tmp_path, mode):
         assert np.mean(diff < 1e-4) > 0.95, key
 
 
+def test_dense_shards_with_the_colour_branch(tmp_path):
+    """Colour maps through the DENSE shards (contiguous index shards of every batch, north_star's split): the colour table's
+    gradient is a second whole-table exchange [colour decoder | colour features], the number of surface samples the colour loss
+    divides by (utils/loss.py:31-42) is the whole batch's (a one-word SUM exchange), the Adam step on the colour table is the
+    replicated dense one.  Both ranks end bit-identical; the exchanged gradient of the first iteration is the reference's
+    whole-batch gradient and the trained tables are the reference's (the bars of the spatial test above)."""
+    d = G.load("replica_color")
+    r0, r1 = _launch(tmp_path, 2, "host", "replica_color", "dense")
+    for key in ("feats", "dec", "cfeats", "cdec", "cert", "tsu", "cgdec0", "cgfeat0"):
+        assert np.array_equal(r0[key].view(np.uint8), r1[key].view(np.uint8)), key
+    ref = d["map_cfeat0"]
+    assert np.max(np.abs(r0["cgfeat0"].reshape(ref.shape) - ref)) < 4e-4 * np.abs(ref).max()
+    assert np.max(np.abs(r0["cgdec0"] - d["map_cdec0"])) < 4e-4 * np.abs(d["map_cdec0"]).max()
+    for got, key, gk in ((r0["feats"], "map_geo_after", "map_gfeat"), (r0["cfeats"], "map_color_after", "map_cfeat"),
+                         (r0["dec"], "map_gdec_after", "map_gdec"), (r0["cdec"], "map_cdec_after", "map_cdec")):
+        g0, g1 = d[gk + "0"].reshape(got.shape), d[gk + "1"].reshape(got.shape)
+        clean = (np.abs(g0) > 4e-2 * np.abs(g0).max()) & (np.abs(g1) > 4e-2 * np.abs(g1).max())
+        diff = np.abs(got - d[key].reshape(got.shape))
+        assert clean.any() and diff[clean].max() < 1e-4, key
+        assert diff.max() <= 2.0 * d["map_lr"] * 2 * 1.05, key
+        assert np.mean(diff < 1e-4) > 0.95, key
+
+
 def test_spatial_shards_over_rccl_single_rank(tmp_path):
     """The spatial path through RCCL itself (pin_allreduce_f32 for the halo exchange and the owner merge): with one rank
     every row is owned and private, the reductions are identities and the run must equal the reference."""

@@ -220,6 +220,22 @@ def test_spatial_shards_at_scale(scale_case):
         np.testing.assert_allclose(r0["cert"], one["cert"], rtol=1e-4, atol=1e-5)
 
 
+def test_dense_shards_at_scale(scale_case):
+    """2 ranks sharing the GPU, DENSE shards (north_star's literal split: contiguous halves of every drawn batch, one whole-table
+    all-reduce of [decoder | features] per iteration, replicated dense Adam) through the drop-in Mapper on the same recorded
+    batches -- on the colour map (c5) with the colour table's own exchange and the whole batch's surface-sample count: ranks
+    bit-identical, rank 0 against the oracle like the spatial shards."""
+    c, one, ora = scale_case, scale_case["one"], scale_case["ora"]
+    rs = _launch(c["tmp"], c["workload"], 2, c["bs"], extra=("dense",))
+    r0 = rs[0]
+    assert np.array_equal(r0["hist"], one["hist"])
+    keys = [k for k in r0.files if k.startswith("sha_")]
+    assert len(keys) >= 6
+    for key in keys:
+        assert str(rs[1][key]) == str(r0[key]), f"{key} differs between the ranks"
+    _check_against_oracle(r0, ora, one, c["colour"], f"{c['workload']} 2 ranks, dense shards")
+
+
 def test_diverged_replicas_refuse_to_exchange(tmp_path):
     """only the boxes are agreed by an exchange; every other list of the spatial mapper is derived per rank from its
     replica.  One changed index on rank 1 -> the signature exchange (pin_dp_signature) stops BOTH ranks with a diagnostic."""
