@@ -58,7 +58,7 @@ typedef struct pin_sample_params {
 extern "C" {
 #endif
 
-#define PIN_ABI_VERSION 17
+#define PIN_ABI_VERSION 18
 #define PIN_FEATURE_DIM 8          /* config.feature_dim (utils/config.py:103) */
 #define PIN_MLP_IN (PIN_FEATURE_DIM + 3)
 #define PIN_MAX_K 8                /* query_nn_k: 6 default, 8 in the benchmark configs */
@@ -746,6 +746,21 @@ typedef struct pin_train_group {
     const float* coef; int32_t t_max; float beta1, beta2, eps;
     pin_adam_dense dense;                 /* the decoder as the rider (grad_partial is set per iteration from partial_*) */
     const float* partial; int32_t partial_slots; float partial_scale;   /* in / out, see above */
+    /* ABI v18 -- the TWO-STREAM form (engine.MapTrainer.step_batch's `overlap` path, the default with a colour decoder) and the
+     * colour branch of the iteration (mapper.py:668-671, 802-812).  side_stream != NULL: per iteration the lazy launch carries no
+     * rider, pin_train_step stops behind the tile kernel (defer_weight_grad), pin_train_weight_grad and the decoder's step (`dense`
+     * alone: pin_adam_lazy_flush with no table) run on side_stream behind it, and the NEXT tile kernel waits for them; partial_*
+     * unused.  The caller orders the two streams in front of the group (side work of an earlier call) and behind it (the last
+     * iteration's side work is still running when the call returns).  fc != NULL: on `stream`, behind the above, the colour
+     * table's lazy launch (c_dense riding along unless its param is NULL: a frozen colour decoder) and pin_train_color_step on the
+     * same queries / records. */
+    void* side_stream;
+    const pin_field* fc; const pin_train_color_params* cp;
+    const float* color_label; int64_t color_stride;   /* [n_iters][n_main][3] */
+    float* c_feat_grad; float* c_dec_grad; double* c_loss_out;
+    void* c_workspace; int64_t c_workspace_bytes;
+    float* c_exp_avg; float* c_exp_avg_sq; int32_t* c_pending; uint8_t* c_row_flags;   /* lazy Adam of fc->feats (n_rows rows) */
+    pin_adam_dense c_dense;
 } pin_train_group;
 int pin_train_group_steps(const pin_field* f, const pin_train_params* tp, pin_train_group* g, void* stream);
 

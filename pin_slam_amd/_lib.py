@@ -19,7 +19,7 @@ PIN_NONLOCAL = -2
 PIN_NBR_QUIRK_BIT = 0x40000000
 PIN_GN_NSUMS = 32
 PIN_GN_REPLICAS = 16
-PIN_ABI_VERSION = 17
+PIN_ABI_VERSION = 18
 PIN_ADAM_ROW_EXCLUDED = -(1 << 31)
 PIN_COMM_ID_BYTES = 128
 
@@ -135,7 +135,10 @@ class TrainGroup(C.Structure):
                 ("feat_grad", vp), ("dec_grad", vp), ("loss_out", vp), ("workspace", vp), ("workspace_bytes", C.c_int64),
                 ("n_records", C.c_int64), ("exp_avg", vp), ("exp_avg_sq", vp), ("pending", vp), ("row_flags", vp), ("n_rows", C.c_int64),
                 ("coef", vp), ("t_max", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("dense", AdamDense), ("partial", vp), ("partial_slots", C.c_int32), ("partial_scale", C.c_float)]
+                ("dense", AdamDense), ("partial", vp), ("partial_slots", C.c_int32), ("partial_scale", C.c_float),
+                ("side_stream", vp), ("fc", vp), ("cp", vp), ("color_label", vp), ("color_stride", C.c_int64),
+                ("c_feat_grad", vp), ("c_dec_grad", vp), ("c_loss_out", vp), ("c_workspace", vp), ("c_workspace_bytes", C.c_int64),
+                ("c_exp_avg", vp), ("c_exp_avg_sq", vp), ("c_pending", vp), ("c_row_flags", vp), ("c_dense", AdamDense)]
 
 
 class TrainColorParams(C.Structure):

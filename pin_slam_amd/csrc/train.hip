@@ -1441,6 +1441,72 @@ extern "C" int pin_train_deferred_partial(const float** partial_out, int32_t* sl
     return 0;
 }
 
+// The two-stream form of a group (engine.MapTrainer.step_batch's `overlap` path, the default with a colour decoder): per iteration
+//   main:  lazy-Adam launch of the geometry table (no rider) -> [wait: the decoder's step of the iteration before] -> tile kernel
+//   side:  [wait: the tile kernel] -> weight gradient + its reduction -> the decoder's step (dense rider alone, image written through)
+//   main:  lazy-Adam launch of the colour table with the colour decoder riding along -> colour tile kernel + its weight gradient
+// so that the weight gradient and the decoder's step of the SDF term run beside the colour term and the next iteration's lazy
+// launch.  The two events are the library's own (per thread); the caller orders the streams in front of and behind the group.
+static int train_group_two_streams(const pin_field* f, pin_train_params t, pin_train_group* g, void* stream) {
+    static thread_local hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    if (ev_main == nullptr) {
+        if (hipEventCreateWithFlags(&ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_side, hipEventDisableTiming) != hipSuccess) {
+            ev_main = ev_side = nullptr;
+            return fail(-2, "pin_train_group_steps: cannot create the events of the two-stream form");
+        }
+    }
+    PIN_CHECK_ARG(g->partial == nullptr, "the two-stream form reduces every iteration's weight gradient itself");
+    if (g->fc != nullptr)
+        PIN_CHECK_ARG(g->cp && g->color_label && g->c_feat_grad && g->c_workspace && g->c_pending && g->c_loss_out, "colour branch: NULL pointer");
+    const hipStream_t main = reinterpret_cast<hipStream_t>(stream), side = reinterpret_cast<hipStream_t>(g->side_stream);
+    pin_adam_dense d = g->dense;
+    d.grad_partial = nullptr; d.partial_slots = 0; d.partial_scale = 0.f;
+    float* const feats = const_cast<float*>(f->feats);
+    t.defer_weight_grad = 1;
+    t.defer_dec_reduce = 0;
+    for (int i = 0; i < g->n_iters; ++i) {
+        const int step = g->first_step + i;
+        const float* nbr = g->nbr + (int64_t)i * g->nbr_stride;
+        const float* query = g->query + (int64_t)i * g->query_stride;
+        const int32_t* nn = g->nn + (int64_t)i * g->nn_stride;
+        const float* label = g->sdf_label + (int64_t)i * g->label_stride;
+        const float* weight = g->sample_weight ? g->sample_weight + (int64_t)i * g->weight_stride : nullptr;
+        int rc = g->rows_form
+                     ? pin_adam_lazy_prepare_rows(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, g->row_flags,
+                                                  g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, nullptr, stream)
+                     : pin_adam_lazy_prepare(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, step, g->coef,
+                                             g->t_max, g->beta1, g->beta2, g->eps, nullptr, stream);
+        if (rc) return rc;
+        if (i > 0 && hipStreamWaitEvent(main, ev_side, 0) != hipSuccess) return fail(-2, "pin_train_group_steps: hipStreamWaitEvent");
+        rc = pin_train_step(f, &t, query, nbr, nn, label, weight, g->sample_ts ? g->sample_ts + (int64_t)i * g->ts_stride : nullptr,
+                            g->certainty_rw, g->ts_update_rw, g->feat_grad, g->dec_grad, g->loss_out, nullptr, g->workspace,
+                            g->workspace_bytes, stream);
+        if (rc) return rc;
+        if (hipEventRecord(ev_main, main) != hipSuccess || hipStreamWaitEvent(side, ev_main, 0) != hipSuccess)
+            return fail(-2, "pin_train_group_steps: cannot order the side stream behind the tile kernel");
+        rc = pin_train_weight_grad(f, &t, g->dec_grad, g->loss_out, g->workspace, g->workspace_bytes, g->side_stream);
+        if (rc) return rc;
+        rc = pin_adam_lazy_flush(nullptr, nullptr, nullptr, nullptr, nullptr, 0, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, &d,
+                                 g->side_stream);
+        if (rc) return rc;
+        if (hipEventRecord(ev_side, side) != hipSuccess) return fail(-2, "pin_train_group_steps: hipEventRecord");
+        if (g->fc != nullptr) {
+            float* const cfeats = const_cast<float*>(g->fc->feats);
+            const pin_adam_dense* cd = g->c_dense.param != nullptr ? &g->c_dense : nullptr;
+            rc = g->rows_form
+                     ? pin_adam_lazy_prepare_rows(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending,
+                                                  g->c_row_flags, g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream)
+                     : pin_adam_lazy_prepare(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending, step,
+                                             g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream);
+            if (rc) return rc;
+            rc = pin_train_color_step(g->fc, g->cp, query, nbr, nn, label, g->color_label + (int64_t)i * g->color_stride, weight,
+                                      g->c_feat_grad, cd ? g->c_dec_grad : nullptr, g->c_loss_out, g->c_workspace, g->c_workspace_bytes, stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
 extern "C" int pin_train_group_steps(const pin_field* f, const pin_train_params* tp, pin_train_group* g, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(f && tp && g && g->n_iters >= 0 && g->first_step >= 1, "bad arguments");
@@ -1450,6 +1516,8 @@ extern "C" int pin_train_group_steps(const pin_field* f, const pin_train_params*
     pin_train_params t = *tp;
     pin_adam_dense d = g->dense;
     float* const feats = const_cast<float*>(f->feats);  // (the field's table is what the optimiser steps)
+    if (g->side_stream != nullptr) return train_group_two_streams(f, t, g, stream);
+    PIN_CHECK_ARG(g->fc == nullptr, "the colour branch runs in the two-stream form (side_stream)");
     for (int i = 0; i < g->n_iters; ++i) {
         const int step = g->first_step + i;
         const float* nbr = g->nbr + (int64_t)i * g->nbr_stride;

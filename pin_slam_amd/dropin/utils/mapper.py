@@ -600,9 +600,12 @@ class Mapper(_StandaloneBase):
                         t.knn_group(gn)
                     else:
                         self._records_group(t, it0, gn, reuse)
-                    if t.defer_dec_reduce and t.can_step_group():
-                        # the plain path: the group's iterations queued by ONE foreign call (engine.MapTrainer.step_group)
-                        t.step_group(outs[1], outs[2], outs[3], it0 + 1, gn)
+                    if t.fc is not None and outs[4] is None:
+                        raise RuntimeError("color_on but the data pool holds no colour labels")
+                    if t.defer_dec_reduce and t.can_step_group(outs[4]):
+                        # the group's iterations queued by ONE foreign call (engine.MapTrainer.step_group): the plain path, and the
+                        # two-stream path of the colour maps
+                        t.step_group(outs[1], outs[2], outs[3], it0 + 1, gn, color_label=outs[4] if t.fc is not None else None)
                         self.total_iter += gn
                         continue
                     for j in range(gn):

@@ -540,14 +540,19 @@ def train_weight_grad(buf: TrainBuffers, dec_grad):
                                            _stream()), "pin_train_weight_grad")
 
 
-def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
-                     surface_range, weight_i=1.0, loss_weight_on=False, image_current=False, surface_count=None,
-                     global_n_main=None):
-    """Colour term of a training iteration; call after train_step (reuses its queries / kNN)."""
+def color_workspace(buf: TrainBuffers, fc: FieldState):
+    """The colour term's scratch on `buf` (allocated with its first use)."""
     if buf.color_ws is None:
         nbytes = _lib.lib().pin_train_workspace_bytes(buf.cap_main, fc.hidden, fc.levels, 1 if fc.weighted_first else fc.k) + 256  # (capacity: shards vary)
         buf.color_ws = torch.empty((nbytes // 4 + 1,), dtype=torch.float32, device=buf.query.device)
         buf.color_loss = torch.zeros((1,), dtype=torch.float64, device=buf.query.device)
+
+
+def train_color_step(fc: FieldState, buf: TrainBuffers, sdf_label, color_label, sample_weight, feat_grad, dec_grad, *,
+                     surface_range, weight_i=1.0, loss_weight_on=False, image_current=False, surface_count=None,
+                     global_n_main=None):
+    """Colour term of a training iteration; call after train_step (reuses its queries / kNN)."""
+    color_workspace(buf, fc)
     tp = _lib.TrainColorParams()
     tp.n_main, tp.loss_weight_on = buf.n_main, int(bool(loss_weight_on))
     tp.surface_range, tp.weight_i = float(surface_range), float(weight_i)

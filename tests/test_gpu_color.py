@@ -121,3 +121,66 @@ def test_color_mapping_two_iterations(cg):
     for name, key in (("geo", "map_geo_after"), ("col", "map_color_after"), ("gdec", "map_gdec_after"), ("cdec", "map_cdec_after")):
         diff = np.abs(params[name].cpu().numpy() - d[key])
         assert np.mean(diff < 1e-4) > 0.99, name
+
+
+@pytest.mark.parametrize("overlap", [None, False])
+def test_grouped_colour_iterations_behind_the_abi(cg, overlap, monkeypatch):
+    """engine.MapTrainer.step_group with a colour decoder: the iterations of a group queued by ONE foreign call
+    (pin_train_group_steps, two-stream form: the SDF term's weight gradient and decoder step on a side stream beside the colour
+    term) train like the same iterations stepped one by one from Python -- same launches, same operands; what differs is the
+    order of the float atomics.  overlap False: no second stream -- a colour map is then stepped from Python (can_step_group says so)."""
+    import ctypes as C
+    from pin_slam_amd import _lib, engine, ops
+    from tests import gpu_util as U
+    d = cg
+    bs, iters = d["map_coord0"].shape[0], 4
+    batches = [0, 1, 0, 1]
+    results = []
+    for arm in ("python", "group"):
+        geo, col = U.dev(d["local_geo_features"]), U.dev(d["local_color_features"])
+        cert, tsu = U.dev(d["local_point_certainties"]), U.dev(d["local_point_ts_update"], torch.int32)
+        fs = dataclasses.replace(d["fs"], feats=geo, dec=U.dev(d["dec_flat"]), certainty=cert, dec_image=None)
+        fc = dataclasses.replace(d["fc"], feats=col, dec=U.dev(d["cdec_flat"]), certainty=cert, dec_image=None)
+        t = engine.MapTrainer(d["st"], fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
+                              weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
+                              loss_weight_on=bool(d.get("map_loss_weight_on", False)))
+        t.overlap_weight_grad = overlap
+        t.set_color(fc, surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"])
+        assert t.buf.group >= iters
+        t.reset_optimizer(iters)
+        t.begin_side_effects()
+        coords = [U.dev(d[f"map_coord{b}"]) for b in batches]
+        for j, c in enumerate(coords):  # the group's queries, slot by slot (Mapper.mapping's gather launch writes them)
+            t.buf.select(j)
+            ops.check(_lib.lib().pin_train_make_queries(ops._ptr(c), t.buf.n_main, t.buf.n_eik, t.buf.dec, t.buf.eik_first,
+                                                        float(np.float32(d["map_eps"])), ops._ptr(t.buf.query), ops._stream()), "make_queries")
+        t.knn_group(iters)
+        lab = torch.stack([U.dev(d[f"map_label{b}"]) for b in batches]).contiguous()
+        w = torch.stack([U.dev(d[f"map_w{b}"]) for b in batches]).contiguous()
+        ts = torch.stack([U.dev(d[f"map_ts{b}"], torch.int32) for b in batches]).contiguous()
+        colr = torch.stack([U.dev(d[f"map_color{b}"]) for b in batches]).contiguous()
+        if arm == "group":
+            if overlap is False:
+                assert not t.can_step_group(colr)  # (the in-line form has no colour branch behind the ABI)
+                continue
+            assert t.can_step_group(colr)
+            t.step_group(lab, w, ts, 1, iters, color_label=colr)
+            assert t._wg_pending and t.lazy.t == iters and t.lazy_c.t == iters
+        else:
+            for j in range(iters):
+                t.buf.select(j)
+                t.step_batch(coords[j], lab[j], w[j], ts[j], j + 1, color_label=colr[j], queries_ready=True, knn_ready=True)
+        t.buf.select(0)
+        t.finish_optimizer()
+        torch.cuda.synchronize()
+        results.append([x.clone() for x in (geo, col, fs.dec, fc.dec, cert)])
+    if len(results) < 2:
+        return
+    for name, a, b in zip(("features", "colour features", "decoder", "colour decoder", "certainty"), *results):
+        assert not torch.equal(a, torch.zeros_like(a))
+        if "decoder" in name:
+            assert (a - b).abs().max().item() < 1e-3, name
+        elif name == "certainty":
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+        else:  # (Adam with eps = 1e-15 turns the rounding noise of a near-zero gradient into a step of ~lr: bound their share)
+            assert (a - b).abs().mean().item() < 1e-5 and ((a - b).abs() > 5e-3).float().mean().item() < 1e-3, name

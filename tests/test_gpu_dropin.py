@@ -237,7 +237,7 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
         seen, real = [], _ops.train_deferred_partial
         monkeypatch.setattr(_ops, "train_deferred_partial", lambda: (seen.append(real()), seen[-1])[1])
         groups, real_group = [], _engine.MapTrainer.step_group
-        monkeypatch.setattr(_engine.MapTrainer, "step_group", lambda self, *a: (groups.append(a[-1]), real_group(self, *a))[1])
+        monkeypatch.setattr(_engine.MapTrainer, "step_group", lambda self, *a, **k: (groups.append(a[-1]), real_group(self, *a, **k))[1])
         mp.mapping(20)  # more than one group of 16
         monkeypatch.setattr(_ops, "train_deferred_partial", real)
         monkeypatch.setattr(_engine.MapTrainer, "step_group", real_group)
@@ -253,8 +253,9 @@ def test_grouped_iterations_train_like_single_ones(wf, monkeypatch):
         assert torch.equal(npts.point_ts_update[:n_pts], npts.local_point_ts_update[:n_pts])
         results.append((npts.local_geo_features.data.clone(), dec.flat_params().clone(), npts.local_point_certainties.clone()))
     # the deferred reduction ran where it can: in line (no second stream), in 19 of the 20 iterations (the last one reduces itself) --
-    # grouped, the whole loop behind the ABI (pin_train_group_steps: one call per group of 16 + 4); iteration by iteration from Python
-    assert deferred == [(0, ()), (0, ()), (0, (16, 4)), (0, ()), (19, ())], deferred
+    # grouped, the whole loop behind the ABI (pin_train_group_steps: one call per group of 16 + 4), in its two-stream form (first
+    # arm) and in line (third); iteration by iteration from Python otherwise
+    assert deferred == [(0, (16, 4)), (0, ()), (0, (16, 4)), (0, ()), (19, ())], deferred
     fa, da, ca = results[0]
     assert not torch.equal(fa, torch.zeros_like(fa))
     for fb, db, cb in results[1:]:
@@ -737,13 +738,19 @@ def test_an_aborted_call_leaves_no_owed_steps_behind():
                 if calls["n"] == 2:
                     raise RuntimeError("interrupted")
             t.step_batch = failing
+            group = t.step_group
+
+            def failing_group(*a, **k):  # (the same interruption when the iterations are queued by one foreign call)
+                group(*a, **k)
+                raise RuntimeError("interrupted")
+            t.step_group = failing_group
             feats0, dec0 = npts.local_geo_features.data.clone(), dec.flat_params().clone()
             cert0 = npts.local_point_certainties.clone()
             torch.manual_seed(7)
             with pytest.raises(RuntimeError, match="interrupted"):
                 mp.mapping(6)
             assert t._wg_pending  # the hand-over state of the interrupted iteration is still there
-            t.step_batch = step
+            t.step_batch, t.step_group = step, group
             # back to the state the other run starts from (the aborted call has moved features, decoder and certainties)
             torch.cuda.synchronize()
             npts.local_geo_features.data.copy_(feats0)
