@@ -751,9 +751,11 @@ typedef struct pin_train_group {
      * rider, pin_train_step stops behind the tile kernel (defer_weight_grad), pin_train_weight_grad and the decoder's step (`dense`
      * alone: pin_adam_lazy_flush with no table) run on side_stream behind it, and the NEXT tile kernel waits for them; partial_*
      * unused.  The caller orders the two streams in front of the group (side work of an earlier call) and behind it (the last
-     * iteration's side work is still running when the call returns).  fc != NULL: on `stream`, behind the above, the colour
-     * table's lazy launch (c_dense riding along unless its param is NULL: a frozen colour decoder) and pin_train_color_step on the
-     * same queries / records. */
+     * iteration's side work is still running when the call returns).  fc != NULL (either form): on `stream`, behind the above, the
+     * colour table's lazy launch (c_dense riding along unless its param is NULL: a frozen colour decoder) and pin_train_color_step
+     * on the same queries / records; with a colour branch the in-line form reduces every iteration's weight gradient itself.
+     * dense.param == NULL (in-line form only): a FROZEN decoder (freeze_decoders, utils/tools.py:263-292 -- every frame of a run
+     * after freeze_after_frame): no rider, no weight gradient, dec_grad unused. */
     void* side_stream;
     const pin_field* fc; const pin_train_color_params* cp;
     const float* color_label; int64_t color_stride;   /* [n_iters][n_main][3] */

@@ -1447,6 +1447,22 @@ extern "C" int pin_train_deferred_partial(const float** partial_out, int32_t* sl
 //   main:  lazy-Adam launch of the colour table with the colour decoder riding along -> colour tile kernel + its weight gradient
 // so that the weight gradient and the decoder's step of the SDF term run beside the colour term and the next iteration's lazy
 // launch.  The two events are the library's own (per thread); the caller orders the streams in front of and behind the group.
+// the colour term of iteration i of a group (mapper.py:668-671, 802-812): the colour table's lazy launch with the colour decoder
+// riding along (unless frozen), then the colour tile kernel and its weight gradient on the iteration's queries / records
+static int train_group_color(const pin_train_group* g, int i, int step, const float* query, const float* nbr, const int32_t* nn,
+                             const float* label, const float* weight, void* stream) {
+    float* const cfeats = const_cast<float*>(g->fc->feats);
+    const pin_adam_dense* cd = g->c_dense.param != nullptr ? &g->c_dense : nullptr;
+    int rc = g->rows_form
+                 ? pin_adam_lazy_prepare_rows(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending,
+                                              g->c_row_flags, g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream)
+                 : pin_adam_lazy_prepare(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending, step,
+                                         g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream);
+    if (rc) return rc;
+    return pin_train_color_step(g->fc, g->cp, query, nbr, nn, label, g->color_label + (int64_t)i * g->color_stride, weight,
+                                g->c_feat_grad, cd ? g->c_dec_grad : nullptr, g->c_loss_out, g->c_workspace, g->c_workspace_bytes, stream);
+}
+
 static int train_group_two_streams(const pin_field* f, pin_train_params t, pin_train_group* g, void* stream) {
     static thread_local hipEvent_t ev_main = nullptr, ev_side = nullptr;
     if (ev_main == nullptr) {
@@ -1491,16 +1507,7 @@ static int train_group_two_streams(const pin_field* f, pin_train_params t, pin_t
         if (rc) return rc;
         if (hipEventRecord(ev_side, side) != hipSuccess) return fail(-2, "pin_train_group_steps: hipEventRecord");
         if (g->fc != nullptr) {
-            float* const cfeats = const_cast<float*>(g->fc->feats);
-            const pin_adam_dense* cd = g->c_dense.param != nullptr ? &g->c_dense : nullptr;
-            rc = g->rows_form
-                     ? pin_adam_lazy_prepare_rows(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending,
-                                                  g->c_row_flags, g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream)
-                     : pin_adam_lazy_prepare(nbr, g->n_records, cfeats, g->c_feat_grad, g->c_exp_avg, g->c_exp_avg_sq, g->c_pending, step,
-                                             g->coef, g->t_max, g->beta1, g->beta2, g->eps, cd, stream);
-            if (rc) return rc;
-            rc = pin_train_color_step(g->fc, g->cp, query, nbr, nn, label, g->color_label + (int64_t)i * g->color_stride, weight,
-                                      g->c_feat_grad, cd ? g->c_dec_grad : nullptr, g->c_loss_out, g->c_workspace, g->c_workspace_bytes, stream);
+            rc = train_group_color(g, i, step, query, nbr, nn, label, weight, stream);
             if (rc) return rc;
         }
     }
@@ -1510,35 +1517,48 @@ static int train_group_two_streams(const pin_field* f, pin_train_params t, pin_t
 extern "C" int pin_train_group_steps(const pin_field* f, const pin_train_params* tp, pin_train_group* g, void* stream) {
     PIN_ENTER();
     PIN_CHECK_ARG(f && tp && g && g->n_iters >= 0 && g->first_step >= 1, "bad arguments");
-    PIN_CHECK_ARG(g->query && g->nbr && g->nn && g->sdf_label && g->feat_grad && g->dec_grad && g->workspace && g->pending && g->coef,
-                  "NULL pointer");
-    PIN_CHECK_ARG(g->dense.param && g->dense.grad == g->dec_grad, "the rider must be the decoder whose gradient the steps write");
+    PIN_CHECK_ARG(g->query && g->nbr && g->nn && g->sdf_label && g->feat_grad && g->workspace && g->pending && g->coef, "NULL pointer");
+    const bool rider = g->dense.param != nullptr;  // (NULL: a frozen decoder -- no rider, no weight gradient, utils/tools.py:263-292)
+    PIN_CHECK_ARG(!rider || (g->dec_grad != nullptr && g->dense.grad == g->dec_grad), "the rider must be the decoder whose gradient the steps write");
+    if (g->fc != nullptr)
+        PIN_CHECK_ARG(g->cp && g->color_label && g->c_feat_grad && g->c_workspace && g->c_pending && g->c_loss_out, "colour branch: NULL pointer");
     pin_train_params t = *tp;
+    if (g->side_stream != nullptr) {
+        PIN_CHECK_ARG(rider, "the two-stream form is the form of a TRAINED decoder (its weight gradient and step go to the side stream)");
+        return train_group_two_streams(f, t, g, stream);
+    }
     pin_adam_dense d = g->dense;
     float* const feats = const_cast<float*>(f->feats);  // (the field's table is what the optimiser steps)
-    if (g->side_stream != nullptr) return train_group_two_streams(f, t, g, stream);
-    PIN_CHECK_ARG(g->fc == nullptr, "the colour branch runs in the two-stream form (side_stream)");
+    t.defer_weight_grad = 0;
     for (int i = 0; i < g->n_iters; ++i) {
         const int step = g->first_step + i;
         const float* nbr = g->nbr + (int64_t)i * g->nbr_stride;
+        const float* query = g->query + (int64_t)i * g->query_stride;
+        const int32_t* nn = g->nn + (int64_t)i * g->nn_stride;
+        const float* label = g->sdf_label + (int64_t)i * g->label_stride;
+        const float* weight = g->sample_weight ? g->sample_weight + (int64_t)i * g->weight_stride : nullptr;
         d.grad_partial = g->partial; d.partial_slots = g->partial_slots; d.partial_scale = g->partial_scale;
         int rc = g->rows_form
                      ? pin_adam_lazy_prepare_rows(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, g->row_flags,
-                                                  g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, &d, stream)
+                                                  g->n_rows, step, g->coef, g->t_max, g->beta1, g->beta2, g->eps, rider ? &d : nullptr, stream)
                      : pin_adam_lazy_prepare(nbr, g->n_records, feats, g->feat_grad, g->exp_avg, g->exp_avg_sq, g->pending, step, g->coef,
-                                             g->t_max, g->beta1, g->beta2, g->eps, &d, stream);
+                                             g->t_max, g->beta1, g->beta2, g->eps, rider ? &d : nullptr, stream);
         if (rc) return rc;
         g->partial = nullptr;  // (taken by the launch above)
-        t.defer_dec_reduce = (g->last_of_call && i == g->n_iters - 1) ? 0 : 1;
-        rc = pin_train_step(f, &t, g->query + (int64_t)i * g->query_stride, nbr, g->nn + (int64_t)i * g->nn_stride,
-                            g->sdf_label + (int64_t)i * g->label_stride,
-                            g->sample_weight ? g->sample_weight + (int64_t)i * g->weight_stride : nullptr,
-                            g->sample_ts ? g->sample_ts + (int64_t)i * g->ts_stride : nullptr, g->certainty_rw, g->ts_update_rw, g->feat_grad,
-                            g->dec_grad, g->loss_out, nullptr, g->workspace, g->workspace_bytes, stream);
+        // (the deferred reduction: a trained decoder, nothing else between the launches that reads its gradient -- no colour branch --
+        // and not the call's last iteration: engine.MapTrainer.step_batch's `defer_reduce`)
+        t.defer_dec_reduce = (rider && g->fc == nullptr && !(g->last_of_call && i == g->n_iters - 1)) ? 1 : 0;
+        rc = pin_train_step(f, &t, query, nbr, nn, label, weight, g->sample_ts ? g->sample_ts + (int64_t)i * g->ts_stride : nullptr,
+                            g->certainty_rw, g->ts_update_rw, g->feat_grad, rider ? g->dec_grad : nullptr, g->loss_out, nullptr, g->workspace,
+                            g->workspace_bytes, stream);
         if (rc) return rc;
         if (t.defer_dec_reduce && tl_deferred.partial != nullptr) {
             PIN_CHECK_ARG(tl_deferred.n == d.n, "the deferred weight gradient belongs to a decoder of another size");
             g->partial = tl_deferred.partial; g->partial_slots = DW_SLOTS; g->partial_scale = tl_deferred.scale;
+        }
+        if (g->fc != nullptr) {  // the colour term in line (a frozen SDF decoder, or a caller that wants one stream)
+            rc = train_group_color(g, i, step, query, nbr, nn, label, weight, stream);
+            if (rc) return rc;
         }
     }
     return 0;

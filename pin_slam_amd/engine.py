@@ -479,20 +479,21 @@ class MapTrainer:
         ops.knn_query(self.st, self.buf.query_all[:n], self.fs.k, out=(self.buf.nbr_all[:n], self.buf.nn_all[:n], None),
                       bricks=self.bricks)
 
+    def _two_streams(self) -> bool:
+        """step_batch's `overlap`: the weight gradient and the decoder's step of an iteration on a side stream."""
+        want = self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None)
+        return bool(self.lazy_on and self.train_decoder and want and self.on_grads is None and self.dp is None
+                    and (self.fs.weighted_first or self.fs.levels == 1) and os.environ.get("PIN_MLP", "") != "f32")
+
     def can_step_group(self, color_label=None) -> bool:
-        """What pin_train_group_steps runs behind the ABI: the plain one-GPU training loop (lazy exact Adam with the decoder riding
-        along, no second stream) and the two-stream form with or without the colour branch (the weight gradient and the decoder's
-        step on a side stream: step_batch's `overlap` path, the default with a colour decoder) -- no semantic branch, no ranks, no
-        hooks, no analytic Eikonal term."""
-        if not (self.lazy_on and self.train_decoder and self.dp is None and self.comm is None and self.on_grads is None
+        """What pin_train_group_steps runs behind the ABI: the one-GPU training loop on the lazy exact Adam -- in line (the decoder
+        riding along in the lazy launch, or frozen) or in step_batch's two-stream form (a trained decoder's weight gradient and step on
+        a side stream: the default with a colour decoder), with or without the colour branch -- no semantic branch, no ranks, no hooks,
+        no analytic Eikonal term."""
+        if not (self.lazy_on and self.dp is None and self.comm is None and self.on_grads is None
                 and self.on_allreduce is None and self.fsem is None and not self.buf.analytic and self.fs.dec_image is not None
                 and os.environ.get("PIN_TRAIN_GROUP", "1") != "0"):
             return False
-        want = self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None)
-        if not want:
-            return self.fc is None
-        if not ((self.fs.weighted_first or self.fs.levels == 1) and os.environ.get("PIN_MLP", "") != "f32"):
-            return False  # (step_batch runs these in line, without the deferred reduction when a colour branch is on)
         return self.fc is None or (color_label is not None and color_label.shape[-1] == 3 and color_label.stride(-1) == 1
                                    and color_label.stride(-2) == 3 and self.fc.dec_image is not None)
 
@@ -502,7 +503,7 @@ class MapTrainer:
         call: per iteration the launches of step_batch(queries_ready=True, knn_ready=True), queued by a C loop."""
         buf, fs, nd = self.buf, self.fs, self.gdec.numel()
         side = not self.defer_side_effects
-        two = bool(self.overlap_weight_grad if self.overlap_weight_grad is not None else (self.fc is not None))
+        two = self._two_streams()
         tp = _lib.TrainParams()
         tp.n_main, tp.n_eik, tp.loss_weight_on = buf.n_main, buf.n_eik, int(bool(self.loss_weight_on))
         tp.sigma, tp.weight_e, tp.eik_eps = float(self.sigma), float(self.weight_e), float(np.float32(self.eik_eps))
@@ -525,66 +526,66 @@ class MapTrainer:
             g.sample_ts, g.ts_stride = ts.data_ptr(), ts.stride(0)
         if side:
             g.certainty_rw, g.ts_update_rw = fs.certainty.data_ptr(), self.ts_update.data_ptr()
-        g.feat_grad, g.dec_grad, g.loss_out = self.gfeat.data_ptr(), self.gdec.data_ptr(), buf.loss.data_ptr()
+        g.feat_grad, g.loss_out = self.gfeat.data_ptr(), buf.loss.data_ptr()
         g.workspace, g.workspace_bytes = buf.ws.data_ptr(), buf.ws.numel() * 4
         g.n_records = n_rec
         lz = self.lazy
         g.exp_avg, g.exp_avg_sq, g.pending = self.m[nd:].data_ptr(), self.v[nd:].data_ptr(), lz.state.data_ptr()
         g.row_flags, g.n_rows = lz.flags.data_ptr(), fs.feats.shape[0]
         g.coef, g.t_max, g.beta1, g.beta2, g.eps = lz.coef.data_ptr(), lz.t_max, lz.b1, lz.b2, lz.eps
-        d = ops.LazyAdam._dense(self._dense(fs, self.gdec, self.m[:nd], self.v[:nd], True))
-        g.dense = d
+        d = None
+        if self.train_decoder:  # (frozen: no rider, no weight gradient -- every frame of a run after freeze_after_frame)
+            d = ops.LazyAdam._dense(self._dense(fs, self.gdec, self.m[:nd], self.v[:nd], True))
+            g.dense, g.dec_grad = d, self.gdec.data_ptr()
         last = first_step + n_iters - 1
         if last > lz.t_max or first_step <= lz.t:
             raise ValueError("steps must grow within one optimiser lifetime and stay within the count reset() was sized for")
         keep = [f, tp, d]  # (ctypes structures the group points at: alive until the call has returned)
-        main = None
+        if self._wg_pending:  # (the side work of an iteration stepped from Python, or of the group before)
+            torch.cuda.current_stream().wait_event(self._wg_ev[1])
+            self._wg_pending = False
         if two:
-            main = torch.cuda.current_stream()
             if self._wg_stream is None:
                 self._wg_stream = torch.cuda.Stream(device=fs.feats.device)
                 self._wg_ev = (torch.cuda.Event(), torch.cuda.Event())
-            if self._wg_pending:  # (the side work of an iteration stepped from Python, or of the group before)
-                main.wait_event(self._wg_ev[1])
-                self._wg_pending = False
             g.side_stream = self._wg_stream.cuda_stream
-            if self.fc is not None:
-                fc, lc, cnd = self.fc, self.lazy_c, self.fc.dec.numel()
-                if last > lc.t_max or first_step <= lc.t:
-                    raise ValueError("colour table: steps must grow within one optimiser lifetime")
-                ops.color_workspace(buf, fc)
-                cf = fc.params()
-                cp = _lib.TrainColorParams()
-                cp.n_main, cp.loss_weight_on = buf.n_main, int(bool(self.loss_weight_on))
-                cp.surface_range, cp.weight_i, cp.dec_image_current = float(self.c_range), float(self.c_weight), 1
-                g.fc, g.cp = C.cast(C.pointer(cf), C.c_void_p), C.cast(C.pointer(cp), C.c_void_p)
-                g.color_label, g.color_stride = color_label.data_ptr(), color_label.stride(0)
-                g.c_feat_grad, g.c_loss_out = self.cgrad[cnd:].data_ptr(), buf.color_loss.data_ptr()
-                g.c_workspace, g.c_workspace_bytes = buf.color_ws.data_ptr(), buf.color_ws.numel() * 4
-                g.c_exp_avg, g.c_exp_avg_sq = self.cm[cnd:].data_ptr(), self.cv[cnd:].data_ptr()
-                g.c_pending, g.c_row_flags = lc.state.data_ptr(), lc.flags.data_ptr()
-                if self.c_train_dec:
-                    g.c_dec_grad = self.cgdec.data_ptr()
-                    cd = ops.LazyAdam._dense(self._dense(fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], True))
-                    g.c_dense = cd
-                    keep.append(cd)
-                keep += [cf, cp]
-        elif self._pending_partial is not None:
+        elif self.fc is None and self._pending_partial is not None:
             g.partial, g.partial_slots, _n, g.partial_scale = self._pending_partial
+        if self.fc is not None:
+            fc, lc, cnd = self.fc, self.lazy_c, self.fc.dec.numel()
+            if last > lc.t_max or first_step <= lc.t:
+                raise ValueError("colour table: steps must grow within one optimiser lifetime")
+            ops.color_workspace(buf, fc)
+            cf = fc.params()
+            cp = _lib.TrainColorParams()
+            cp.n_main, cp.loss_weight_on = buf.n_main, int(bool(self.loss_weight_on))
+            cp.surface_range, cp.weight_i, cp.dec_image_current = float(self.c_range), float(self.c_weight), 1
+            g.fc, g.cp = C.cast(C.pointer(cf), C.c_void_p), C.cast(C.pointer(cp), C.c_void_p)
+            g.color_label, g.color_stride = color_label.data_ptr(), color_label.stride(0)
+            g.c_feat_grad, g.c_loss_out = self.cgrad[cnd:].data_ptr(), buf.color_loss.data_ptr()
+            g.c_workspace, g.c_workspace_bytes = buf.color_ws.data_ptr(), buf.color_ws.numel() * 4
+            g.c_exp_avg, g.c_exp_avg_sq = self.cm[cnd:].data_ptr(), self.cv[cnd:].data_ptr()
+            g.c_pending, g.c_row_flags = lc.state.data_ptr(), lc.flags.data_ptr()
+            if self.c_train_dec:
+                g.c_dec_grad = self.cgdec.data_ptr()
+                cd = ops.LazyAdam._dense(self._dense(fc, self.cgdec, self.cm[:cnd], self.cv[:cnd], True))
+                g.c_dense = cd
+                keep.append(cd)
+            keep += [cf, cp]
         check(_lib.lib().pin_train_group_steps(C.byref(f), C.byref(tp), C.byref(g), ops._stream()), "pin_train_group_steps")
         lz.t = last
         if g.rows_form:
             lz.rows_launches += n_iters
+        if self.fc is not None:
+            self.lazy_c.t = last
+            if g.rows_form:
+                self.lazy_c.rows_launches += n_iters
         if two:
             self._wg_ev[1].record(self._wg_stream)  # (the last iteration's weight gradient and decoder step: whoever needs them waits)
             self._wg_pending = True
             self._pending_partial = None
-            if self.fc is not None:
-                self.lazy_c.t = last
-                if g.rows_form:
-                    self.lazy_c.rows_launches += n_iters
         else:
-            self._pending_partial = (g.partial, g.partial_slots, d.n, g.partial_scale) if g.partial else None
+            self._pending_partial = (g.partial, g.partial_slots, d.n, g.partial_scale) if (g.partial and d is not None) else None
         self.total_iter += n_iters
         del keep
 

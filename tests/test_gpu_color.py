@@ -123,13 +123,13 @@ def test_color_mapping_two_iterations(cg):
         assert np.mean(diff < 1e-4) > 0.99, name
 
 
-@pytest.mark.parametrize("overlap", [None, False])
-def test_grouped_colour_iterations_behind_the_abi(cg, overlap, monkeypatch):
+@pytest.mark.parametrize("form,overlap,frozen", [("two streams", None, False), ("in line", False, False), ("frozen decoders", None, True)])
+def test_grouped_colour_iterations_behind_the_abi(cg, form, overlap, frozen):
     """engine.MapTrainer.step_group with a colour decoder: the iterations of a group queued by ONE foreign call
-    (pin_train_group_steps, two-stream form: the SDF term's weight gradient and decoder step on a side stream beside the colour
-    term) train like the same iterations stepped one by one from Python -- same launches, same operands; what differs is the
-    order of the float atomics.  overlap False: no second stream -- a colour map is then stepped from Python (can_step_group says so)."""
-    import ctypes as C
+    (pin_train_group_steps) train like the same iterations stepped one by one from Python -- same launches, same operands; what
+    differs is the order of the float atomics.  Two streams: the SDF term's weight gradient and decoder step on a side stream beside
+    the colour term (the default of a colour map); in line: everything on the caller's stream; frozen decoders (every frame of a run
+    after freeze_after_frame, utils/tools.py:263-292): no rider, no weight gradient -- the decoders must not move."""
     from pin_slam_amd import _lib, engine, ops
     from tests import gpu_util as U
     d = cg
@@ -143,12 +143,13 @@ def test_grouped_colour_iterations_behind_the_abi(cg, overlap, monkeypatch):
         fc = dataclasses.replace(d["fc"], feats=col, dec=U.dev(d["cdec_flat"]), certainty=cert, dec_image=None)
         t = engine.MapTrainer(d["st"], fs, None, None, None, None, tsu, bs=bs, decimation=int(d["map_dec"]), sigma=d["sdf_scale"],
                               weight_e=d["map_weight_e"], eik_eps=d["map_eps"], lr=d["map_lr"], adam_eps=d["map_adam_eps"],
-                              loss_weight_on=bool(d.get("map_loss_weight_on", False)))
+                              loss_weight_on=bool(d.get("map_loss_weight_on", False)), train_decoder=not frozen)
         t.overlap_weight_grad = overlap
-        t.set_color(fc, surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"])
+        t.set_color(fc, surface_range=d["surface_sample_range_m"], weight_i=d["weight_i"], train_decoder=not frozen)
         assert t.buf.group >= iters
         t.reset_optimizer(iters)
         t.begin_side_effects()
+        assert t._two_streams() == (form == "two streams")
         coords = [U.dev(d[f"map_coord{b}"]) for b in batches]
         for j, c in enumerate(coords):  # the group's queries, slot by slot (Mapper.mapping's gather launch writes them)
             t.buf.select(j)
@@ -160,12 +161,9 @@ def test_grouped_colour_iterations_behind_the_abi(cg, overlap, monkeypatch):
         ts = torch.stack([U.dev(d[f"map_ts{b}"], torch.int32) for b in batches]).contiguous()
         colr = torch.stack([U.dev(d[f"map_color{b}"]) for b in batches]).contiguous()
         if arm == "group":
-            if overlap is False:
-                assert not t.can_step_group(colr)  # (the in-line form has no colour branch behind the ABI)
-                continue
             assert t.can_step_group(colr)
             t.step_group(lab, w, ts, 1, iters, color_label=colr)
-            assert t._wg_pending and t.lazy.t == iters and t.lazy_c.t == iters
+            assert t._wg_pending == (form == "two streams") and t.lazy.t == iters and t.lazy_c.t == iters
         else:
             for j in range(iters):
                 t.buf.select(j)
@@ -174,13 +172,14 @@ def test_grouped_colour_iterations_behind_the_abi(cg, overlap, monkeypatch):
         t.finish_optimizer()
         torch.cuda.synchronize()
         results.append([x.clone() for x in (geo, col, fs.dec, fc.dec, cert)])
-    if len(results) < 2:
-        return
     for name, a, b in zip(("features", "colour features", "decoder", "colour decoder", "certainty"), *results):
         assert not torch.equal(a, torch.zeros_like(a))
         if "decoder" in name:
             assert (a - b).abs().max().item() < 1e-3, name
+            if frozen:
+                assert torch.equal(a, U.dev(d["dec_flat" if name == "decoder" else "cdec_flat"])) and torch.equal(a, b), name
         elif name == "certainty":
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
         else:  # (Adam with eps = 1e-15 turns the rounding noise of a near-zero gradient into a step of ~lr: bound their share)
             assert (a - b).abs().mean().item() < 1e-5 and ((a - b).abs() > 5e-3).float().mean().item() < 1e-3, name
+            assert not torch.equal(a, U.dev(d["local_geo_features" if name == "features" else "local_color_features"])), name

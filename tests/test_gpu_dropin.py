@@ -702,6 +702,31 @@ def _small_mapper(bs=2048, **kw):
     return mp, npts, dec
 
 
+def test_frozen_decoder_mapping_behind_the_abi(monkeypatch):
+    """freeze_decoders (utils/tools.py:263-292: every frame of a run after freeze_after_frame) -- Mapper.mapping then trains the
+    features only: no rider in the lazy launch, no weight gradient.  The group call (pin_train_group_steps with dense.param NULL)
+    trains like the Python loop, and the decoder does not move."""
+    from pin_slam_amd import engine as _engine
+    results = []
+    for group in ("1", "0"):
+        monkeypatch.setenv("PIN_TRAIN_GROUP", group)
+        mp, npts, dec = _small_mapper()
+        for p_ in dec.parameters():
+            p_.requires_grad_(False)
+        dec0, feats0 = dec.flat_params().clone(), npts.local_geo_features.data.clone()
+        calls, real = [], _engine.MapTrainer.step_group
+        monkeypatch.setattr(_engine.MapTrainer, "step_group", lambda self, *a, **k: (calls.append(a[-1]), real(self, *a, **k))[1])
+        torch.manual_seed(5)
+        mp.mapping(6)
+        monkeypatch.setattr(_engine.MapTrainer, "step_group", real)
+        assert calls == ([6] if group == "1" else []), calls
+        assert not mp._trainer.train_decoder
+        assert torch.equal(dec.flat_params(), dec0) and not torch.equal(npts.local_geo_features.data, feats0)
+        results.append(npts.local_geo_features.data.clone())
+    fa, fb = results
+    assert (fa - fb).abs().mean().item() < 1e-5 and ((fa - fb).abs() > 5e-3).float().mean().item() < 1e-3
+
+
 def test_spatial_mapper_refuses_per_iteration_draws(monkeypatch):
     """PIN_DRAW_PER_ITERATION=1 (a replayed random stream: scripts/e2e_pin_slam.py --replay-draws) makes Mapper._draw_all hand
     back nothing; the one-GPU path then draws per iteration, the spatially sharded path plans its shards from the draws of
